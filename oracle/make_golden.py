@@ -1,0 +1,206 @@
+"""TEST INFRASTRUCTURE ONLY -- generate tests/golden/* from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference).  Imports the
+reference's unmodified ``TargetDiff`` / ``UniTransformer`` through
+``oracle/ref_shim.py``, loads the deterministic synthetic weights of
+``oracle/weights.py`` with ``load_state_dict(strict=True)``, runs the reference
+on seeded inputs and stores inputs + outputs as small ``.npz`` fixtures.  The
+oracle (``tests/test_oracle_golden.py``) and the HIP path (``tests/test_gpu_*``)
+are both checked against these files.
+
+    python -m oracle.make_golden            # rewrites tests/golden/
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim, weights as W  # noqa: E402
+from cbgbench_amd import synthetic as S  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _np(t):
+    t = t.detach().cpu()
+    if t.dtype == torch.int64:
+        return t.numpy().astype(np.int64)
+    return t.numpy()
+
+
+def compose_inputs(model, batch, x_lig, c_lig):
+    """Exactly targetdiff.py:155-160 on the reference modules; returns the denoiser kwargs."""
+    from repo.modules.common import compose_context
+    x_rec = batch["protein_pos"]
+    aa = F.one_hot(batch["protein_aa_type"], 20).float()
+    lig_flag, rec_flag = batch["ligand_lig_flag"], batch["protein_lig_flag"]
+    gen_l = batch.get("ligand_gen_flag", lig_flag)
+    gen_r = torch.zeros_like(rec_flag)
+    bl, br = batch["ligand_element_batch"], batch["protein_element_batch"]
+    xl, xr, hl, hr = model.context_embedder(x_lig, x_rec, c_lig, batch["protein_atom_feature"], aa,
+                                            bl, br, lig_flag, rec_flag, None)
+    ctx, batch_idx, _ = compose_context({"x": xl, "h": hl, "gen_flag": gen_l, "lig_flag": lig_flag},
+                                        {"x": xr, "h": hr, "gen_flag": gen_r, "lig_flag": rec_flag}, bl, br)
+    return ctx, batch_idx
+
+
+def small_batch(sizes, seed, num_classes=13, ctx=None):
+    rng = np.random.default_rng(seed)
+    pockets = [S.make_pocket(rng, nr, radius=7.0) for nr, _ in sizes]
+    return S.make_batch(pockets, [nl for _, nl in sizes], rng, num_classes, n_ctx_list=ctx)
+
+
+def denoiser_case(model, name, batch):
+    c_lig = F.one_hot(batch["ligand_atom_type"], model.num_classes).float()
+    ctx, batch_idx = compose_inputs(model, batch, batch["ligand_pos"], c_lig)
+    with torch.no_grad():
+        x, h = ctx["x"], ctx["h"]
+        den = model.denoiser
+        edge_index = den._connect_edge(x, ctx["lig_flag"], batch_idx)
+        edge_type = den._build_edge_type(edge_index, ctx["lig_flag"])
+        src, dst = edge_index
+        e_w = torch.sigmoid(den.dist_emb(torch.norm(x[dst] - x[src], p=2, dim=-1, keepdim=True)))
+        h_l0 = den.blocks[0].x2h_layers[0](x, h, edge_type, edge_index, e_w)
+        x_l0, _ = den.blocks[0](x, h, edge_type, edge_index, e_w=e_w, gen_flag=ctx["gen_flag"])
+        xo, ho, logits = den(batch_idx=batch_idx, **ctx)
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        x=_np(x), h=_np(h), batch_idx=_np(batch_idx), lig_flag=_np(ctx["lig_flag"]), gen_flag=_np(ctx["gen_flag"]),
+        edge_index=_np(edge_index).astype(np.int32), edge_type=_np(edge_type.argmax(-1)).astype(np.int8), e_w=_np(e_w),
+        h_layer0=_np(h_l0), x_layer0=_np(x_l0), x_out=_np(xo), h_out=_np(ho), logits=_np(logits),
+    )
+    print(name, "N =", x.shape[0], "E =", edge_index.shape[1])
+
+
+def step_case(model, name, batch, t_idx, seed):
+    """One pass of the loop body targetdiff.py:150-180 with torch RNG seeded so that the
+    scheduler's randn_like / rand_like draws can be replayed as explicit eps / u."""
+    C = model.num_classes
+    x_lig = batch["ligand_pos"]
+    c_lig = F.one_hot(batch["ligand_atom_type"], C).float()
+    bl = batch["ligand_element_batch"]
+    gen_l = batch.get("ligand_gen_flag", batch["ligand_lig_flag"])
+    B = int(bl.max()) + 1
+    t = torch.full((B,), t_idx, dtype=torch.long)
+    with torch.no_grad():
+        ctx, batch_idx = compose_inputs(model, batch, x_lig, c_lig)
+        x, h, v = model.denoiser(batch_idx=batch_idx, **ctx)
+        x_pred, c_pred = x[ctx["lig_flag"]], v[ctx["lig_flag"]]
+        torch.manual_seed(seed)
+        x_next = model.pos_scheduler.backward_remove_noise(x_pred, x_lig, t, bl, gen_l, type="denoise")
+        c_next, v_next = model.type_scheduler.backward_remove_noise(c_pred, c_lig, t, bl, gen_l, pred_logit=True)
+    torch.manual_seed(seed)
+    eps = torch.randn_like(x_lig)
+    u = torch.rand(x_lig.shape[0], C)
+    d = {k: _np(v) for k, v in batch.items()}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), t_idx=t_idx, eps=_np(eps), u=_np(u),
+                        x_pred=_np(x_pred), c_pred=_np(c_pred), x_next=_np(x_next), c_next=_np(c_next),
+                        v_next=_np(v_next), **{"batch_" + k: v for k, v in d.items()})
+    print(name, "t =", t_idx)
+
+
+def sample_case(name, batch, T, seed):
+    """Full ``TargetDiff.sample`` (targetdiff.py:127-184) of a T-step model, torch RNG seeded."""
+    M = ref_shim.load_reference()
+    cfg = ref_shim.targetdiff_config(13, 9)
+    cfg.generator.num_diffusion_timesteps = T
+    model = M.get_model(cfg).eval()
+    model.load_state_dict(W.synthetic_state_dict(13, 9, seed=0, num_timesteps=T), strict=True)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        traj = model.sample(batch)
+    out = {"T": T, "seed": seed}
+    for k, (xx, cc, bb) in traj.items():
+        out[f"traj_x_{k}"] = _np(xx)
+        out[f"traj_c_{k}"] = _np(cc)
+    out.update({"batch_" + k: _np(v) for k, v in batch.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "keys", sorted(traj.keys()))
+
+
+def eg5_pocket(radius=10.0):
+    """scripts/example/Eg5 (PDB 3ZCW) heavy atoms of residues with any atom within ``radius`` A of
+    a ligand heavy atom -- the pocket criterion of datasets/parsers/protein_parser.py:167-177 --
+    parsed from plain text (no RDKit/BioPython here)."""
+    base = os.path.join(ref_shim.REFERENCE_ROOT, "scripts", "example", "Eg5")
+    lig = []
+    with open(os.path.join(base, "3zcw_ligand.sdf")) as f:
+        lines = f.read().splitlines()
+    na = int(lines[3][:3])
+    for ln in lines[4:4 + na]:
+        if ln[31:34].strip() != "H":
+            lig.append([float(ln[0:10]), float(ln[10:20]), float(ln[20:30])])
+    lig = np.array(lig, np.float32)
+    atoms = []
+    aa3 = ["ALA", "CYS", "ASP", "GLU", "PHE", "GLY", "HIS", "ILE", "LYS", "LEU", "MET", "ASN", "PRO", "GLN",
+           "ARG", "SER", "THR", "VAL", "TRP", "TYR"]
+    elem_idx = {"H": 0, "C": 1, "N": 2, "O": 3, "S": 4, "SE": 5}
+    with open(os.path.join(base, "3zcw_protein.pdb")) as f:
+        for ln in f:
+            if not ln.startswith("ATOM"):
+                continue
+            el = ln[76:78].strip().upper()
+            res = ln[17:20]
+            if el == "H" or el not in elem_idx or res not in aa3:
+                continue
+            atoms.append((ln[21], int(ln[22:26]), ln[26], res, ln[12:16].strip(), el,
+                          float(ln[30:38]), float(ln[38:46]), float(ln[46:54])))
+    pos = np.array([a[6:9] for a in atoms], np.float32)
+    d = np.sqrt(((pos[:, None] - lig[None]) ** 2).sum(-1)).min(1)
+    keep_res = {(a[0], a[1], a[2]) for a, dd in zip(atoms, d) if dd <= radius}
+    sel = [i for i, a in enumerate(atoms) if (a[0], a[1], a[2]) in keep_res]
+    pos = pos[sel]
+    feat = np.zeros((len(sel), 7), np.float32)
+    aa = np.zeros(len(sel), np.int64)
+    for r, i in enumerate(sel):
+        a = atoms[i]
+        feat[r, elem_idx[a[5]]] = 1.0
+        feat[r, 6] = a[4] in ("N", "CA", "C", "O")
+        aa[r] = aa3.index(a[3])
+    centre = pos.mean(0, keepdims=True)
+    return (pos - centre).astype(np.float32), feat, aa, (lig - centre).astype(np.float32)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    M = ref_shim.load_reference()
+    for C, tag in ((13, "add_aromatic"), (8, "basic")):
+        torch.manual_seed(0)
+        m = M.get_model(ref_shim.targetdiff_config(C, 9))
+        with open(os.path.join(OUT, f"state_dict_keys_{tag}.json"), "w") as f:
+            json.dump({k: list(v.shape) for k, v in m.state_dict().items()}, f, indent=0)
+    model = M.get_model(ref_shim.targetdiff_config(13, 9)).eval()
+    sd = W.synthetic_state_dict(13, 9, seed=0)
+    model.load_state_dict(sd, strict=True)
+
+    # schedule tables straight from a freshly constructed reference model
+    torch.manual_seed(0)
+    fresh = M.get_model(ref_shim.targetdiff_config(13, 9)).state_dict()
+    np.savez_compressed(os.path.join(OUT, "schedule_tables.npz"),
+                        **{k: _np(v) for k, v in fresh.items() if "scheduler" in k})
+
+    denoiser_case(model, "denoiser_2graphs", small_batch([(70, 9), (55, 13)], seed=11))
+    # graphs with n <= k nodes (degree n-1 < 32), a 2-node graph and a protein-only single node
+    denoiser_case(model, "denoiser_small_graphs", small_batch([(20, 5), (28, 5), (1, 1), (30, 4), (1, 0)], seed=12))
+    denoiser_case(model, "denoiser_linker", small_batch([(60, 14), (48, 11)], seed=13, ctx=[9, 7]))
+
+    pos, feat, aa, lig = eg5_pocket()
+    rng = np.random.default_rng(14)
+    b = S.make_batch([(pos, feat, aa)], [lig.shape[0]], rng, 13)
+    b["ligand_pos"] = torch.from_numpy(lig + rng.standard_normal(lig.shape).astype(np.float32) * 0.5)
+    denoiser_case(model, "denoiser_eg5_pocket10", b)
+
+    step_case(model, "step_t500", small_batch([(64, 10), (50, 12)], seed=21), 500, seed=5)
+    step_case(model, "step_t0", small_batch([(64, 10), (50, 12)], seed=22), 0, seed=6)
+    step_case(model, "step_t999_linker", small_batch([(58, 15), (44, 12)], seed=23, ctx=[10, 8]), 999, seed=7)
+    sample_case("sample_T5", small_batch([(40, 8), (36, 6)], seed=31), T=5, seed=9)
+
+
+if __name__ == "__main__":
+    main()
