@@ -1,0 +1,74 @@
+"""ctypes binding of libcbgx.so (include/cbgx.h).  There is no fallback: if the library is missing
+or a call fails, this raises."""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime libcbgx links against, by SONAME)
+
+from .build import LIBPATH
+
+_LIB = None
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+EXPORTS = {
+    "cbgx_abi_version": (_i, []),
+    "cbgx_last_error": (ctypes.c_char_p, []),
+    "cbgx_packed_weights_floats": (_sz, [_i, _i]),
+    "cbgx_pack_weights": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _vp, _vp]),
+    "cbgx_workspace_bytes": (_sz, [_i, _i]),
+    "cbgx_unitransformer_forward": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cbgx_knn_graph": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "cbgx_edge_gate": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "cbgx_x2h_attention": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "cbgx_h2x_attention": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "cbgx_classifier": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "cbgx_profile_begin": (_i, [_i]),
+    "cbgx_profile_end": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i), _i]),
+}
+
+PROFILE_CLASSES = ("knn", "gate", "node_gemm", "node_query", "edge_x2h", "edge_h2x")
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libcbgx.so (once). Raises NativeError if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIBPATH):
+            raise NativeError(
+                f"{LIBPATH} not found: build it with `python -m cbgbench_amd.build` "
+                "(there is no CPU / PyTorch fallback for the message-passing path)")
+        dll = ctypes.CDLL(LIBPATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(dll, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if dll.cbgx_abi_version() != 1:
+            raise NativeError(f"libcbgx ABI version {dll.cbgx_abi_version()} != 1")
+        _LIB = dll
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().cbgx_last_error().decode(errors="replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise NativeError(f"{what} failed ({rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("libcbgx needs contiguous tensors")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,102 @@
+"""Config surface of the reference: YAML with ``!include`` -> attribute dict, plus the derived
+``num_atomtype`` / ``mode`` fields.
+
+Mirrors ``load_config`` (repo/utils/misc.py:109-145) and ``set_num_atom_type``
+(repo/utils/configuration.py:13-38) so the reference's ``configs/{task}/{train,test}/{method}.yml``
+files load unchanged.  ``easydict`` is not installed here; ``Config`` provides the same attribute
+access and ``.get``.
+"""
+import json
+import os
+
+import yaml
+
+
+class Config(dict):
+    """dict with attribute access, recursively (stand-in for easydict.EasyDict)."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in dict(d or {}, **kw).items():
+            self[k] = v
+
+    @classmethod
+    def _wrap(cls, v):
+        if isinstance(v, dict) and not isinstance(v, Config):
+            return cls(v)
+        if isinstance(v, (list, tuple)):
+            return type(v)(cls._wrap(x) for x in v)
+        return v
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, self._wrap(v))
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __delattr__(self, k):
+        del self[k]
+
+
+class _Loader(yaml.SafeLoader):
+    def __init__(self, stream):
+        self._root = os.path.split(getattr(stream, "name", os.path.curdir + os.sep))[0]
+        super().__init__(stream)
+
+
+def _include(loader, node):
+    filename = os.path.abspath(os.path.join(loader._root, loader.construct_scalar(node)))
+    ext = os.path.splitext(filename)[1].lstrip(".")
+    with open(filename, "r") as f:
+        if ext in ("yaml", "yml"):
+            return yaml.load(f, _Loader)
+        if ext == "json":
+            return json.load(f)
+        return f.read()
+
+
+yaml.add_constructor("!include", _include, _Loader)
+
+
+def load_config(config_path):
+    """-> (Config, config_name); same contract as repo/utils/misc.py:141-145."""
+    with open(config_path, "r") as f:
+        config = Config(yaml.load(f, _Loader))
+    name = os.path.basename(config_path)
+    return config, name[: name.rfind(".")]
+
+
+# atom-type vocabulary sizes: len(map_atom_type_only_to_index) = 8 (repo/utils/molecule/constants.py:54-63),
+# len(map_atom_type_aromatic_to_index) = 13 (:65-79).
+NUM_ATOM_TYPES = {"basic": 8, "add_aromatic": 13}
+# transforms that carry a ``mode`` (repo/datasets/transforms: featurize_ligand*, assign_atomtype, ...)
+_MODE_KEYS = ("mode",)
+
+
+def set_num_atom_type(config, num_type=None):
+    """Inject ``config.model.num_atomtype`` (and ``config.mode``) from the transform list, like
+    repo/utils/configuration.py:13-38."""
+    if num_type is not None:
+        config.model.num_atomtype = num_type
+        return config
+    if "test" in config.data:
+        tsfm = config.data.test.transform
+    elif "train" in config.data:
+        tsfm = config.data.train.transform
+    else:
+        raise ValueError("no mode can be detected, please specific it.")
+    mode = None
+    for t in tsfm:
+        if "mode" in t and t.mode in NUM_ATOM_TYPES:
+            mode = t.mode
+    if mode is None:
+        raise ValueError("the mode cannot be inferred automatically, please specific it.")
+    config.model.num_atomtype = NUM_ATOM_TYPES[mode]
+    config.mode = mode
+    return config

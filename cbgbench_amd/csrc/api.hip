@@ -1,0 +1,242 @@
+// libcbgx C ABI (include/cbgx.h): argument checking, workspace carving, kernel sequencing.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/cbgx.h"
+#include "kernels.h"
+#include "layout.h"
+
+using namespace cbgx;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) return fail(CBGX_E_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Workspace {
+    int32_t* nbr;
+    int32_t* deg;
+    float* e_w;
+    float* P;
+    float* Qt;
+    float* hbuf[2];
+    float* xbuf[2];
+    size_t total;
+};
+
+static Workspace carve(void* base, int n) {
+    Workspace w;
+    size_t off = 0;
+    char* b = (char*)base;
+    auto take = [&](size_t bytes) { char* p = b + off; off += align_up(bytes); return p; };
+    size_t N = (size_t)(n > 0 ? n : 1);
+    w.nbr = (int32_t*)take(N * KNN * 4);
+    w.deg = (int32_t*)take(N * 4);
+    w.e_w = (float*)take(N * KNN * 4);
+    w.P = (float*)take(N * PROW * 4);
+    w.Qt = (float*)take(N * HEADS * H * 4);
+    w.hbuf[0] = (float*)take(N * H * 4);
+    w.hbuf[1] = (float*)take(N * H * 4);
+    w.xbuf[0] = (float*)take(N * 3 * 4);
+    w.xbuf[1] = (float*)take(N * 3 * 4);
+    w.total = off;
+    return w;
+}
+
+extern "C" {
+
+int cbgx_abi_version(void) { return CBGX_ABI_VERSION; }
+const char* cbgx_last_error(void) { return g_err; }
+
+size_t cbgx_packed_weights_floats(int num_layers, int num_classes) {
+    if (num_layers < 0 || num_classes < 1) return 0;
+    return packed_floats(num_layers, num_classes);
+}
+
+int cbgx_pack_weights(const float* const* t, int num_tensors, int L, int C, float* packed, void* stream) {
+    if (!t || !packed) return fail(CBGX_E_INVALID, "pack_weights: NULL pointer");
+    if (L < 1 || C < 1) return fail(CBGX_E_INVALID, "pack_weights: num_layers=%d num_classes=%d", L, C);
+    if (num_tensors != 6 + 36 * L + 4)
+        return fail(CBGX_E_INVALID, "pack_weights: expected %d tensors, got %d", 6 + 36 * L + 4, num_tensors);
+    for (int i = 0; i < num_tensors; ++i)
+        if (!t[i]) return fail(CBGX_E_INVALID, "pack_weights: tensor %d is NULL", i);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(packed, 0, packed_floats(L, C) * sizeof(float), s));
+#define CP(src, ld, off, tr, dst, dld, rows, cols) HIP_TRY(launch_pack_copy(src, ld, off, tr, dst, dld, rows, cols, s))
+    // gate MLP: net.0 [160,20], net.1 LN(160), net.3 [1,160]
+    CP(t[0], G, 0, 0, packed + GATE_W1, G, GH, G);
+    CP(t[1], GH, 0, 0, packed + GATE_B1, GH, 1, GH);
+    CP(t[2], GH, 0, 0, packed + GATE_LNG, GH, 1, GH);
+    CP(t[3], GH, 0, 0, packed + GATE_LNB, GH, 1, GH);
+    CP(t[4], GH, 0, 0, packed + GATE_W2, GH, 1, GH);
+    CP(t[5], 1, 0, 0, packed + GATE_B2, 1, 1, 1);
+    for (int l = 0; l < L; ++l) {
+        for (int blk = 0; blk < 2; ++blk) {
+            const float* const* p = t + 6 + 36 * l + 18 * blk;  // k(6) v(6) q(6)
+            float* a = packed + (blk == 0 ? x2h_off(l) : h2x_off(l));
+            const float *wk0 = p[0], *bk0 = p[1], *gk = p[2], *bek = p[3], *wk1 = p[4];
+            const float *wv0 = p[6], *bv0 = p[7], *gv = p[8], *bev = p[9], *wv1 = p[10], *bv1 = p[11];
+            const float *wq0 = p[12], *bq0 = p[13], *gq = p[14], *beq = p[15], *wq1 = p[16], *bq1 = p[17];
+            // node projection [k][c]: PDk | PDv | PSk | PSv | q hidden
+            CP(wk0, KV_IN, NT + NT * G, 1, a + A_WN + 0 * H, PROW, H, H);
+            CP(wv0, KV_IN, NT + NT * G, 1, a + A_WN + 1 * H, PROW, H, H);
+            CP(wk0, KV_IN, NT + NT * G + H, 1, a + A_WN + 2 * H, PROW, H, H);
+            CP(wv0, KV_IN, NT + NT * G + H, 1, a + A_WN + 3 * H, PROW, H, H);
+            CP(wq0, H, 0, 1, a + A_WN + 4 * H, PROW, H, H);
+            CP(bk0, H, 0, 0, a + A_BN + 0 * H, H, 1, H);
+            CP(bv0, H, 0, 0, a + A_BN + 1 * H, H, 1, H);
+            CP(bq0, H, 0, 0, a + A_BN + 4 * H, H, 1, H);
+            // edge-type one-hot columns and rbf columns of the first Linear
+            CP(wk0, KV_IN, 0, 1, a + A_WT, 2 * H, NT, H);
+            CP(wv0, KV_IN, 0, 1, a + A_WT + H, 2 * H, NT, H);
+            CP(wk0, KV_IN, NT, 1, a + A_WR, 2 * H, NT * G, H);
+            CP(wv0, KV_IN, NT, 1, a + A_WR + H, 2 * H, NT * G, H);
+            CP(gk, H, 0, 0, a + A_LNK_G, H, 1, H);
+            CP(bek, H, 0, 0, a + A_LNK_B, H, 1, H);
+            CP(gv, H, 0, 0, a + A_LNV_G, H, 1, H);
+            CP(bev, H, 0, 0, a + A_LNV_B, H, 1, H);
+            CP(gq, H, 0, 0, a + A_LNQ_G, H, 1, H);
+            CP(beq, H, 0, 0, a + A_LNQ_B, H, 1, H);
+            CP(wq1, H, 0, 1, a + A_WQ1T, H, H, H);
+            CP(bq1, H, 0, 0, a + A_BQ1, H, 1, H);
+            CP(wk1, H, 0, 0, a + A_WBK, H, H, H);
+            if (blk == 0) {
+                CP(wv1, H, 0, 1, a + A_WBV, H, H, H);   // [m][n]
+                CP(bv1, H, 0, 0, a + A_BBV, H, 1, H);
+            } else {
+                CP(wv1, H, 0, 0, a + A_WBV, H, HEADS, H);  // [head][m]
+                CP(bv1, HEADS, 0, 0, a + A_BBV, HEADS, 1, HEADS);
+            }
+        }
+    }
+    const float* const* c = t + 6 + 36 * L;
+    float* cp = packed + cls_off(L);
+    CP(c[0], H, 0, 1, cp + C_W0T, H, H, H);
+    CP(c[1], H, 0, 0, cp + C_B0, H, 1, H);
+    CP(c[2], H, 0, 1, cp + C_W1T, C, H, C);
+    CP(c[3], C, 0, 0, cp + cls_b1(C), C, 1, C);
+#undef CP
+    return CBGX_OK;
+}
+
+size_t cbgx_workspace_bytes(int n_nodes, int n_graphs) {
+    (void)n_graphs;
+    return carve(nullptr, n_nodes).total;
+}
+
+int cbgx_knn_graph(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, int k, int32_t* nbr,
+                   int32_t* deg, void* stream) {
+    if (k != KNN) return fail(CBGX_E_INVALID, "knn_graph: only k=%d is supported (got %d)", KNN, k);
+    if (n_nodes < 0 || n_graphs < 0) return fail(CBGX_E_INVALID, "knn_graph: negative size");
+    if (n_nodes == 0) return CBGX_OK;
+    if (!x || !graph_ptr || !nbr || !deg || n_graphs < 1) return fail(CBGX_E_INVALID, "knn_graph: NULL pointer");
+    HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, nbr, deg, (hipStream_t)stream));
+    return CBGX_OK;
+}
+
+int cbgx_edge_gate(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
+                   float* e_w, void* stream) {
+    if (n_nodes == 0) return CBGX_OK;
+    if (!packed || !x || !nbr || !deg || !e_w || n_nodes < 0) return fail(CBGX_E_INVALID, "edge_gate: bad argument");
+    HIP_TRY(launch_gate(packed, x, nbr, deg, n_nodes, e_w, (hipStream_t)stream));
+    return CBGX_OK;
+}
+
+int cbgx_x2h_attention(const float* packed, int layer, const float* x, const float* h, const int32_t* nbr,
+                       const int32_t* deg, const uint8_t* lig_flag, const float* e_w, int n_nodes, float* h_out,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (n_nodes == 0) return CBGX_OK;
+    if (!packed || !x || !h || !nbr || !deg || !lig_flag || !e_w || !h_out || !workspace || layer < 0 || n_nodes < 0)
+        return fail(CBGX_E_INVALID, "x2h_attention: bad argument");
+    Workspace w = carve(workspace, n_nodes);
+    if (workspace_bytes < w.total)
+        return fail(CBGX_E_WORKSPACE, "x2h_attention: workspace %zu < %zu", workspace_bytes, w.total);
+    HIP_TRY(launch_attention(true, packed + x2h_off(layer), x, h, nbr, deg, lig_flag, nullptr, e_w, n_nodes, w.P,
+                             w.Qt, h_out, nullptr, (hipStream_t)stream));
+    return CBGX_OK;
+}
+
+int cbgx_h2x_attention(const float* packed, int layer, const float* x, const float* h, const int32_t* nbr,
+                       const int32_t* deg, const uint8_t* lig_flag, const uint8_t* gen_flag, const float* e_w,
+                       int n_nodes, float* x_out, float* delta_x, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+    if (n_nodes == 0) return CBGX_OK;
+    if (!packed || !x || !h || !nbr || !deg || !lig_flag || !gen_flag || !e_w || !x_out || !workspace || layer < 0 ||
+        n_nodes < 0)
+        return fail(CBGX_E_INVALID, "h2x_attention: bad argument");
+    Workspace w = carve(workspace, n_nodes);
+    if (workspace_bytes < w.total)
+        return fail(CBGX_E_WORKSPACE, "h2x_attention: workspace %zu < %zu", workspace_bytes, w.total);
+    HIP_TRY(launch_attention(false, packed + h2x_off(layer), x, h, nbr, deg, lig_flag, gen_flag, e_w, n_nodes, w.P,
+                             w.Qt, x_out, delta_x, (hipStream_t)stream));
+    return CBGX_OK;
+}
+
+int cbgx_classifier(const float* packed, int num_layers, int num_classes, const float* h, int n_nodes, float* logits,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (n_nodes == 0) return CBGX_OK;
+    if (!packed || !h || !logits || !workspace || num_layers < 0 || num_classes < 1 || n_nodes < 0)
+        return fail(CBGX_E_INVALID, "classifier: bad argument");
+    Workspace w = carve(workspace, n_nodes);
+    if (workspace_bytes < w.total)
+        return fail(CBGX_E_WORKSPACE, "classifier: workspace %zu < %zu", workspace_bytes, w.total);
+    const float* c = packed + cls_off(num_layers);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(launch_node_gemm(h, H, c + C_W0T, c + C_B0, w.P, H, n_nodes, H, 1, s));
+    HIP_TRY(launch_node_gemm(w.P, H, c + C_W1T, c + cls_b1(num_classes), logits, num_classes, n_nodes, num_classes, 0, s));
+    return CBGX_OK;
+}
+
+int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_classes, const float* x, const float* h,
+                                const int32_t* graph_ptr, const uint8_t* lig_flag, const uint8_t* gen_flag,
+                                int n_nodes, int n_graphs, float* x_out, float* h_out, float* logits, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (n_nodes < 0 || n_graphs < 0 || num_layers < 1) return fail(CBGX_E_INVALID, "forward: bad sizes");
+    if (n_nodes == 0) return CBGX_OK;
+    if (!packed || !x || !h || !graph_ptr || !lig_flag || !gen_flag || !x_out || !h_out || !workspace)
+        return fail(CBGX_E_INVALID, "forward: NULL pointer");
+    if (logits && num_classes < 1) return fail(CBGX_E_INVALID, "forward: num_classes=%d", num_classes);
+    Workspace w = carve(workspace, n_nodes);
+    if (workspace_bytes < w.total)
+        return fail(CBGX_E_WORKSPACE, "forward: workspace %zu < %zu", workspace_bytes, w.total);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s));
+    HIP_TRY(launch_gate(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s));
+    const float* xc = x;
+    const float* hc = h;
+    for (int l = 0; l < num_layers; ++l) {
+        float* hn = (l == num_layers - 1) ? h_out : w.hbuf[l & 1];
+        float* xn = (l == num_layers - 1) ? x_out : w.xbuf[l & 1];
+        HIP_TRY(launch_attention(true, packed + x2h_off(l), xc, hc, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
+                                 w.P, w.Qt, hn, nullptr, s));
+        HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
+                                 w.P, w.Qt, xn, nullptr, s));
+        xc = xn;
+        hc = hn;
+    }
+    if (logits) {
+        const float* c = packed + cls_off(num_layers);
+        HIP_TRY(launch_node_gemm(hc, H, c + C_W0T, c + C_B0, w.P, H, n_nodes, H, 1, s));
+        HIP_TRY(launch_node_gemm(w.P, H, c + C_W1T, c + cls_b1(num_classes), logits, num_classes, n_nodes,
+                                 num_classes, 0, s));
+    }
+    return CBGX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,27 @@
+// internal launcher declarations (host side)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cbgx {
+
+// ---- optional per-kernel timing (cbgx_profile_begin / cbgx_profile_end) ----
+enum KernelClass { K_KNN = 0, K_GATE, K_NODE_GEMM, K_NODE_QUERY, K_EDGE_X2H, K_EDGE_H2X, K_NUM_CLASSES };
+void profile_mark_begin(int cls, hipStream_t s);
+void profile_mark_end(hipStream_t s);
+
+hipError_t launch_knn(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, int32_t* nbr,
+                      int32_t* deg, hipStream_t s);
+hipError_t launch_gate(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
+                       float* e_w, hipStream_t s);
+hipError_t launch_node_gemm(const float* A, int lda, const float* Wt, const float* bias, float* C, int ldc, int M,
+                            int nout, int act, hipStream_t s);
+// node projection + query fold + fused edge kernel of one attention block.
+// x2h: out = h_out[N,128]; h2x: out = x_out[N,3], dx_out optional.
+hipError_t launch_attention(bool x2h, const float* att, const float* x, const float* h, const int32_t* nbr,
+                            const int32_t* deg, const uint8_t* lig, const uint8_t* gen, const float* e_w, int n_nodes,
+                            float* P, float* Qt, float* out, float* dx_out, hipStream_t s);
+hipError_t launch_pack_copy(const float* src, int src_ld, int src_off, int transpose, float* dst, int dst_ld,
+                            int rows, int cols, hipStream_t s);
+
+}  // namespace cbgx

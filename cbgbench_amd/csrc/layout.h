@@ -1,0 +1,60 @@
+// Packed-weight layout of libcbgx (floats).  Built by cbgx_pack_weights from the reference
+// state_dict tensors; consumed by every kernel.  One place defines it.
+#pragma once
+#include <cstddef>
+
+namespace cbgx {
+
+constexpr int H = 128;        // node_feat_dim
+constexpr int HEADS = 16;     // n_heads
+constexpr int DH = 8;         // H / HEADS
+constexpr int G = 20;         // num_r_gaussian
+constexpr int KNN = 32;       // k
+constexpr int NT = 4;         // edge types
+constexpr int GH = 160;       // gate MLP hidden (8 * G)
+constexpr int KV_IN = 2 * H + NT + NT * G;  // 340
+constexpr int PROW = 5 * H;   // node projection row: [PDk | PDv | PSk | PSv | q_hidden]
+
+// ---- gate (denoiser.dist_emb.1) ----
+constexpr size_t GATE_W1 = 0;                    // [160][20] row-major (out, in)
+constexpr size_t GATE_B1 = GATE_W1 + GH * G;     // [160]
+constexpr size_t GATE_LNG = GATE_B1 + GH;        // [160]
+constexpr size_t GATE_LNB = GATE_LNG + GH;       // [160]
+constexpr size_t GATE_W2 = GATE_LNB + GH;        // [160]
+constexpr size_t GATE_B2 = GATE_W2 + GH;         // [1] (+3 pad)
+constexpr size_t GATE_SIZE = GATE_B2 + 4;
+
+// ---- one attention block (x2h or h2x) ----
+constexpr size_t A_WN = 0;                        // [128][640] K-major node projection
+constexpr size_t A_BN = A_WN + (size_t)H * PROW;  // [640]
+constexpr size_t A_WT = A_BN + PROW;              // [4][256]  type one-hot columns of W_a (k | v)
+constexpr size_t A_WR = A_WT + NT * 2 * H;        // [4][20][256] rbf columns of W_a (k | v)
+constexpr size_t A_LNK_G = A_WR + (size_t)NT * G * 2 * H;
+constexpr size_t A_LNK_B = A_LNK_G + H;
+constexpr size_t A_LNV_G = A_LNK_B + H;
+constexpr size_t A_LNV_B = A_LNV_G + H;
+constexpr size_t A_LNQ_G = A_LNV_B + H;
+constexpr size_t A_LNQ_B = A_LNQ_G + H;
+constexpr size_t A_WQ1T = A_LNQ_B + H;            // [128][128] K-major second q linear
+constexpr size_t A_BQ1 = A_WQ1T + (size_t)H * H;  // [128]
+constexpr size_t A_WBK = A_BQ1 + H;               // [128][128] (out n, in m) second k linear
+constexpr size_t A_WBV = A_WBK + (size_t)H * H;   // x2h: [128 m][128 n] K-major; h2x: [16][128] (head, m)
+constexpr size_t A_BBV = A_WBV + (size_t)H * H;   // [128] (h2x: first 16)
+constexpr size_t ATT_SIZE = A_BBV + H;
+
+constexpr size_t LAYER_SIZE = 2 * ATT_SIZE;       // x2h then h2x
+
+// ---- classifier ----
+constexpr size_t C_W0T = 0;                       // [128][128] K-major
+constexpr size_t C_B0 = C_W0T + (size_t)H * H;    // [128]
+constexpr size_t C_W1T = C_B0 + H;                // [128][C] K-major
+
+inline size_t cls_size(int C) { return C_W1T + (size_t)H * C + ((C + 3) / 4) * 4; }
+inline size_t cls_b1(int C) { return C_W1T + (size_t)H * C; }
+inline size_t layer_off(int l) { return GATE_SIZE + (size_t)l * LAYER_SIZE; }
+inline size_t x2h_off(int l) { return layer_off(l); }
+inline size_t h2x_off(int l) { return layer_off(l) + ATT_SIZE; }
+inline size_t cls_off(int L) { return GATE_SIZE + (size_t)L * LAYER_SIZE; }
+inline size_t packed_floats(int L, int C) { return cls_off(L) + cls_size(C); }
+
+}  // namespace cbgx

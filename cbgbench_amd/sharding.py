@@ -1,0 +1,44 @@
+"""Multi-GPU sampling = independent pockets sharded across ranks, no data-path collective
+(every pocket is an independent graph; the reference's outer loop is sample.py:159).
+One process per GPU; torch.distributed (backend 'nccl' = RCCL on ROCm, 'gloo' in CPU tests) is used
+only for the barrier and for reducing timing / throughput counters."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def shard_indices(n_items, rank, world):
+    """Pocket indices of this rank: i = rank (mod world) -- round-robin so ragged pocket sizes average out."""
+    return list(range(rank, n_items, world))
+
+
+def init_process_group(backend=None):
+    rank, world, local = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def reduce_max_sum(elapsed_s, units, device="cpu"):
+    """(max over ranks of elapsed, sum over ranks of units): whole-job throughput = units_sum / elapsed_max."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(elapsed_s), float(units)
+    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
+    u = torch.tensor([float(units)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(u.item())

@@ -1,0 +1,284 @@
+"""``targetdiff`` model class behind the reference's model registry
+(repo/models/diffusion/targetdiff.py:14-184): same constructor config, same state-dict keys
+(``pos_scheduler.*`` / ``type_scheduler.*`` frozen tables, ``context_embedder.*``, ``denoiser.*``),
+same ``sample(batch) -> traj`` contract.
+
+What differs by design:
+* the denoiser call runs in libcbgx (gfx950 kernels);
+* the static parts of a step (protein embedding, pocket+ligand composition permutation, CSR graph
+  offsets) are computed once per batch instead of once per step -- protein atoms never move
+  (unitransformer.py:182) and the shipped configs have no time embedding (context_emb.py:190-195);
+* the trajectory stays on the GPU and is copied to the host once at the end instead of one
+  ``.cpu()`` per step (targetdiff.py:182), preserving the returned structure
+  ``traj[t] = (pos, type_onehot, batch_idx)`` for t = T-1 .. -1.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .registry import get_e3_gnn, register_model
+from .unitransformer import graph_ptr_from_batch
+
+NUM_AA = 20          # len(aa_name_number), repo/utils/protein/constants.py:39
+PROTEIN_FEAT = 7     # len(atomic_numbers) + 1 (is_backbone), protein_featurizer.py:21-26
+
+
+def _frozen(a):
+    return nn.Parameter(torch.from_numpy(np.asarray(a)).float(), requires_grad=False)
+
+
+class VPSchedule(nn.Module):
+    """Frozen variance-preserving schedule tables, key-for-key the reference's ``VPScheduler``
+    (repo/models/diffusion/diffusion_scheduler.py:27-100), computed in float64 then cast to fp32."""
+
+    def __init__(self, num_timestep, beta_start=1e-7, beta_end=2e-3, type="sigmoid", cosine_s=0.008):
+        super().__init__()
+        betas = self.init_betas(beta_start, beta_end, num_timestep, type, cosine_s)
+        alphas = 1.0 - betas
+        ac = np.cumprod(alphas, axis=0)
+        ac_prev = np.append(1.0, ac[:-1])
+        self.betas = _frozen(betas)
+        self.alphas = _frozen(alphas)
+        self.alphas_cumprod = _frozen(ac)
+        self.alphas_cumprod_prev = _frozen(ac_prev)
+        self.sqrt_alphas_cumprod = _frozen(np.sqrt(ac))
+        self.sqrt_one_minus_alphas_cumprod = _frozen(np.sqrt(1.0 - ac))
+        self.sqrt_recip_alphas_cumprod = _frozen(np.sqrt(1.0 / ac))
+        self.sqrt_recipm1_alphas_cumprod = _frozen(np.sqrt(1.0 / ac - 1))
+        post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+        self.posterior_mean_c0_coef = _frozen(betas * np.sqrt(ac_prev) / (1.0 - ac))
+        self.posterior_mean_ct_coef = _frozen((1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac))
+        self.posterior_var = _frozen(post_var)
+        pv32 = post_var.astype(np.float32)  # the reference takes the log of the fp32 table (line 54)
+        self.posterior_logvar = _frozen(np.log(np.append(pv32[1], pv32[1:])))
+
+    @staticmethod
+    def init_betas(beta_start, beta_end, num_timestep, type, cosine_s):
+        if type == "sigmoid":
+            b = np.linspace(-6, 6, num_timestep)
+            betas = 1 / (np.exp(-b) + 1) * (beta_end - beta_start) + beta_start
+        elif type == "cosine":
+            steps = num_timestep + 1
+            t = np.linspace(0, steps, steps)
+            ac = np.cos(((t / steps) + cosine_s) / (1 + cosine_s) * np.pi * 0.5) ** 2
+            ac = ac / ac[0]
+            betas = 1.0 - np.sqrt(np.clip(ac[1:] / ac[:-1], a_min=0.001, a_max=1.0))
+        elif type == "linear":
+            betas = np.linspace(beta_start, beta_end, num_timestep, dtype=np.float64)
+        elif type == "quad":
+            betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_timestep, dtype=np.float64) ** 2
+        elif type == "const":
+            betas = beta_end * np.ones(num_timestep, dtype=np.float64)
+        else:
+            raise NotImplementedError(type)
+        assert betas.shape == (num_timestep,)
+        return betas
+
+
+class CTNVPScheduler(VPSchedule):
+    """Continuous (position) schedule; the posterior step is ``backward_remove_noise``."""
+
+    def backward_remove_noise(self, x_pred, x_noisy, t, batch_idx, gen_flag, type="denoise", noise=None):
+        """x_{t-1} ~ q(x_{t-1} | x_t, x0_pred) (diffusion_scheduler.py:144-165, type='denoise')."""
+        if type != "denoise":
+            raise NotImplementedError("only the x0-prediction ('denoise') posterior is used by targetdiff")
+        tb = t[batch_idx]
+        mean = self.posterior_mean_c0_coef[tb][:, None] * x_pred + self.posterior_mean_ct_coef[tb][:, None] * x_noisy
+        if noise is None:
+            noise = torch.randn_like(x_noisy)
+        nonzero = (tb != 0).to(x_noisy.dtype)[:, None]
+        xs = mean + nonzero * (0.5 * self.posterior_logvar[tb][:, None]).exp() * noise
+        return torch.where(gen_flag[:, None], xs, x_noisy)
+
+
+def _log_add_exp(a, b):
+    m = torch.max(a, b)
+    return m + torch.log(torch.exp(a - m) + torch.exp(b - m))
+
+
+class TypeVPScheduler(VPSchedule):
+    """Categorical (atom type) schedule (diffusion_scheduler.py:320-441)."""
+
+    def __init__(self, num_timestep, num_classes, beta_start=1e-7, beta_end=2e-3, type="sigmoid", cosine_s=0.008):
+        super().__init__(num_timestep, beta_start, beta_end, type, cosine_s)
+        self.num_classes = num_classes
+        log_alphas_v = np.log(self.alphas.numpy())          # fp32 like the reference
+        log_ac = np.cumsum(log_alphas_v)
+
+        def log_1_min_a(a):
+            return np.log(1 - np.exp(a) + 1e-40)
+
+        self.log_alphas_v = _frozen(log_alphas_v)
+        self.log_one_minus_alphas_v = _frozen(log_1_min_a(log_alphas_v))
+        self.log_alphas_cumprod_v = _frozen(log_ac)
+        self.log_one_minus_alphas_cumprod_v = _frozen(log_1_min_a(log_ac))
+
+    def backward_remove_noise(self, c_pred, ct, t, batch_idx, gen_flag, pred_logit=True, uniform=None):
+        """v_{t-1} ~ q(v_{t-1} | v_t, v0_pred) by Gumbel-argmax (diffusion_scheduler.py:367-378, 407-441;
+        models/utils/categorical.py:26-32). Returns (one-hot, index)."""
+        log_c_pred = F.log_softmax(c_pred, dim=-1) if pred_logit else torch.log(c_pred + 1e-8)
+        log_ct = torch.log(ct + 1e-8)
+        tb = t[batch_idx]
+        tm1 = torch.clamp(tb - 1, min=0)
+        lc = math.log(self.num_classes)
+        log_q0 = _log_add_exp(log_c_pred + self.log_alphas_cumprod_v[tm1][:, None],
+                              self.log_one_minus_alphas_cumprod_v[tm1][:, None] - lc)
+        log_q1 = _log_add_exp(log_ct + self.log_alphas_v[tb][:, None],
+                              self.log_one_minus_alphas_v[tb][:, None] - lc)
+        un = log_q0 + log_q1
+        logp = un - torch.logsumexp(un, dim=-1, keepdim=True)
+        if uniform is None:
+            uniform = torch.rand_like(logp)
+        gumbel = -torch.log(-torch.log(uniform + 1e-30) + 1e-30)
+        v_next = (gumbel + logp).argmax(dim=-1)
+        v_next = torch.where(gen_flag, v_next, ct.argmax(-1))
+        return F.one_hot(v_next, self.num_classes).to(ct.dtype), v_next
+
+
+class PLContextEmbedder(nn.Module):
+    """Linear atom / residue / ligand-indicator embeddings (repo/modules/context_emb.py:137-230) for the
+    shipped embedder config (atom: linear, residue: linear; no time, no vec)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.num_classes = cfg.get("num_atomtype", 14)
+        emb_dim = cfg.get("emb_dim", 128)
+        self.emb_dim = emb_dim
+        for key in ("time", "vec"):
+            if cfg.get(key, None) is not None:
+                raise ValueError(f"embedder.{key} is not used by any shipped diffusion config and is not supported")
+        atom, res = cfg.get("atom", None), cfg.get("residue", None)
+        if atom is None or atom.type != "linear" or res is None or res.type != "linear":
+            raise ValueError("embedder.atom / embedder.residue must be {type: linear}")
+        self.ligand_atom_emb = nn.Linear(self.num_classes, emb_dim)
+        self.protein_atom_emb = nn.Linear(PROTEIN_FEAT, emb_dim)
+        self.residue_emb = nn.Linear(NUM_AA, emb_dim)
+        self.ligand_indicator = nn.Linear(1, emb_dim)
+
+    def embed_protein(self, v_rec, aa_rec_onehot):
+        ind0 = self.ligand_indicator.bias  # indicator(0) = bias
+        return self.protein_atom_emb(v_rec) + self.residue_emb(aa_rec_onehot) + ind0
+
+    def embed_ligand(self, c_lig):
+        ind1 = self.ligand_indicator.weight[:, 0] + self.ligand_indicator.bias
+        return self.ligand_atom_emb(c_lig) + ind1
+
+
+@register_model("targetdiff")
+class TargetDiff(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        gen = cfg.generator
+        self.num_diffusion_timesteps = gen.num_diffusion_timesteps
+        self.denoise_structure = gen.get("denoise_structure", True)
+        self.denoise_atom = gen.get("denoise_atom", True)
+        self.time_sampler = gen.get("time_sampler", "symmetric")
+        self.num_classes = cfg.num_atomtype
+        ps = gen.pos_schedule
+        self.pos_scheduler = CTNVPScheduler(self.num_diffusion_timesteps, beta_start=ps.beta_start,
+                                            beta_end=ps.beta_end, type=ps.type)
+        at = gen.atom_schedule
+        self.type_scheduler = TypeVPScheduler(self.num_diffusion_timesteps, num_classes=self.num_classes,
+                                              type=at.type, cosine_s=at.cosine_s)
+        cfg.embedder.num_atomtype = cfg.num_atomtype
+        if cfg.embedder.get("type", "fa") != "fa":
+            raise ValueError("only the full-atom context embedder ('fa') is supported")
+        self.context_embedder = PLContextEmbedder(cfg.embedder)
+        self.denoiser = get_e3_gnn(cfg.encoder, num_classes=self.num_classes)
+
+    def forward(self, batch):
+        raise NotImplementedError(
+            "training loss (targetdiff.py:82-124) needs the backward kernels, which are scheduled after the "
+            "sampling path (DESIGN.md section 8); use sample() under torch.no_grad()")
+
+    # ---- static per-batch structure ------------------------------------------------------------
+    @staticmethod
+    def compose_plan(batch_idx_lig, batch_idx_rec, n_graphs=None):
+        """compose_context (repo/modules/common.py:189-214): cat(rec, lig) + stable sort by graph id.
+        Returns (sort_idx, batch_idx, lig_rows, graph_ptr); computed once per batch."""
+        batch_ctx = torch.cat([batch_idx_rec, batch_idx_lig], 0)
+        sort_idx = torch.sort(batch_ctx, stable=True).indices
+        batch_idx = batch_ctx[sort_idx]
+        n_rec = batch_idx_rec.shape[0]
+        lig_flag = sort_idx >= n_rec
+        lig_rows = torch.nonzero(lig_flag).flatten()   # composed rows of ligand atoms, in ligand order
+        return sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr_from_batch(batch_idx, n_graphs)
+
+    @torch.no_grad()
+    def begin_sampling(self, batch, keep_trajectory=True):
+        """Everything that is constant over the T steps of one batch: the composition permutation, CSR
+        offsets, flags, the protein half of x / h, trajectory buffers.  Returns a state dict."""
+        x_lig = batch["ligand_pos"].float()
+        dev = x_lig.device
+        v_lig_in = batch["ligand_atom_type"]
+        x_rec = batch["protein_pos"].float()
+        v_rec = batch["protein_atom_feature"].float()
+        lig_flag_l = batch["ligand_lig_flag"]
+        gen_l = batch.get("ligand_gen_flag", lig_flag_l).bool()
+        gen_r = batch.get("protein_gen_flag", torch.zeros_like(batch["protein_lig_flag"])).bool()
+        bl, br = batch["ligand_element_batch"], batch["protein_element_batch"]
+        T, C = self.num_diffusion_timesteps, self.num_classes
+        n_rec, n_lig = x_rec.shape[0], x_lig.shape[0]
+        B = int(bl.max().item()) + 1
+        aa = F.one_hot(batch["protein_aa_type"], NUM_AA).float()
+        c_lig = F.one_hot(v_lig_in, C).float() if v_lig_in.dim() == 1 else v_lig_in.float()
+        sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = self.compose_plan(bl, br, B)
+        gen_flag = torch.cat([gen_r, gen_l], 0)[sort_idx]
+        N = n_rec + n_lig
+        rec_rows = torch.nonzero(~lig_flag).flatten()
+        x = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        h = torch.empty(N, self.context_embedder.emb_dim, dtype=torch.float32, device=dev)
+        x[rec_rows] = x_rec
+        h[rec_rows] = self.context_embedder.embed_protein(v_rec, aa)
+        st = dict(x=x, h=h, x_lig=x_lig, c_lig=c_lig, bl=bl, gen_l=gen_l, batch_idx=batch_idx, lig_flag=lig_flag,
+                  gen_flag=gen_flag, lig_rows=lig_rows, graph_ptr=graph_ptr, B=B, n_lig=n_lig, N=N,
+                  traj_x=None, traj_c=None)
+        if keep_trajectory:
+            # slot s+1 holds the state entering step s; slot 0 = final state (key -1 of the reference's dict)
+            st["traj_x"] = torch.empty(T + 1, n_lig, 3, dtype=torch.float32, device=dev)
+            st["traj_c"] = torch.empty(T + 1, n_lig, C, dtype=torch.float32, device=dev)
+            st["traj_x"][T] = x_lig
+            st["traj_c"][T] = c_lig
+        return st
+
+    @torch.no_grad()
+    def denoise_step(self, st, t_idx, noise=None):
+        """One iteration of the reverse-diffusion loop (targetdiff.py:150-182) on the sampling state."""
+        dev = st["x"].device
+        t = torch.full((st["B"],), t_idx, dtype=torch.long, device=dev)
+        x, h, lig_rows = st["x"], st["h"], st["lig_rows"]
+        x[lig_rows] = st["x_lig"]
+        h[lig_rows] = self.context_embedder.embed_ligand(st["c_lig"])
+        xo, _, logits = self.denoiser(x=x, h=h, batch_idx=st["batch_idx"], lig_flag=st["lig_flag"],
+                                      gen_flag=st["gen_flag"], graph_ptr=st["graph_ptr"])
+        x_pred, c_pred = xo[lig_rows], logits[lig_rows]
+        eps, u = noise if noise is not None else (None, None)
+        if self.denoise_structure:
+            st["x_lig"] = self.pos_scheduler.backward_remove_noise(x_pred, st["x_lig"], t, st["bl"], st["gen_l"],
+                                                                   type="denoise", noise=eps)
+        if self.denoise_atom:
+            st["c_lig"], _ = self.type_scheduler.backward_remove_noise(c_pred, st["c_lig"], t, st["bl"], st["gen_l"],
+                                                                       pred_logit=True, uniform=u)
+        if st["traj_x"] is not None:
+            st["traj_x"][t_idx] = st["x_lig"]
+            st["traj_c"][t_idx] = st["c_lig"]
+        return st
+
+    @torch.no_grad()
+    def sample(self, batch, noise_tape=None, return_device=None):
+        """Reverse diffusion, T-1 .. 0 (targetdiff.py:127-184).
+
+        ``noise_tape`` (tests): dict t -> (eps [N_lig,3], u [N_lig,C]) replacing the torch RNG draws
+        (order per step in the reference: randn_like then rand_like).
+        ``return_device``: where the returned trajectory lives (default: CPU, like the reference)."""
+        T = self.num_diffusion_timesteps
+        st = self.begin_sampling(batch, keep_trajectory=True)
+        for t_idx in reversed(range(T)):
+            self.denoise_step(st, t_idx, noise_tape[t_idx] if noise_tape is not None else None)
+        out_dev = torch.device("cpu") if return_device is None else torch.device(return_device)
+        traj_x, traj_c, bl_out = st["traj_x"].to(out_dev), st["traj_c"].to(out_dev), st["bl"].to(out_dev)
+        return {t - 1: (traj_x[t], traj_c[t], bl_out) for t in range(T + 1)}

@@ -1,0 +1,120 @@
+/*
+ * cbgx.h -- C ABI of libcbgx.so: the MI355X (gfx950) implementation of CBGBench's
+ * per-diffusion-step E(3)-equivariant message passing.
+ *
+ * The reference is pure Python; the natives it calls on this path are the
+ * un-vendored torch_cluster / torch_scatter wheels and ATen.  Each entry point
+ * below names the reference interface it replaces (paths relative to the
+ * reference tree).  All pointers are DEVICE pointers unless said otherwise, all
+ * float tensors are contiguous fp32 row-major, `stream` is a hipStream_t passed
+ * as void* (NULL = default stream).  Every call is asynchronous on `stream`,
+ * re-entrant, keeps no pointer after it returns and never frees or allocates
+ * device memory: the caller owns inputs, outputs and the workspace.
+ *
+ * Return value: 0 on success, negative CBGX_E_* on failure (never abort());
+ * cbgx_last_error() gives a thread-local message.
+ *
+ * Node order (as produced by compose_context, repo/modules/common.py:189-214):
+ * nodes sorted by graph; graph g owns rows [graph_ptr[g], graph_ptr[g+1]).
+ */
+#ifndef CBGX_H
+#define CBGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBGX_ABI_VERSION 1
+
+#define CBGX_OK 0
+#define CBGX_E_INVALID (-1)   /* bad argument (shape, NULL pointer, unsupported hyper-parameter) */
+#define CBGX_E_WORKSPACE (-2) /* workspace too small */
+#define CBGX_E_HIP (-3)       /* a HIP runtime call / kernel launch failed */
+
+/* Fixed hyper-parameters of every shipped diffusion config
+ * (configs/{denovo,linker,frag,scaffold,sidechain}/train/{targetdiff,diffbp,diffsbdd}.yml:3-7 and the
+ * defaults at repo/modules/e3nn/unitransformer.py:17-39). The kernels are specialised for them. */
+#define CBGX_HIDDEN 128
+#define CBGX_HEADS 16
+#define CBGX_NUM_GAUSSIANS 20
+#define CBGX_KNN 32
+#define CBGX_EDGE_TYPES 4
+#define CBGX_GATE_HIDDEN 160
+
+int cbgx_abi_version(void);
+const char *cbgx_last_error(void);
+
+/* ---- weights -------------------------------------------------------------------------------
+ * The library consumes one packed fp32 blob built from the reference state_dict tensors
+ * (SURVEY.md A.2 key names).  `tensors` is a HOST array of DEVICE pointers in this order:
+ *   [0..5]   denoiser.dist_emb.1.net.{0.weight,0.bias,1.weight,1.bias,3.weight,3.bias}
+ *   then for each layer l, 36 pointers:
+ *     x2h_layers.0.hk_func.net.{0.weight,0.bias,1.weight,1.bias,3.weight,3.bias}, hv_func (6), hq_func (6),
+ *     h2x_layers.0.xk_func (6), xv_func (6), xq_func (6)
+ *   then classifier.{0.weight,0.bias,2.weight,2.bias}
+ * i.e. 6 + 36*num_layers + 4 pointers.  Re-pack whenever the parameters change. */
+size_t cbgx_packed_weights_floats(int num_layers, int num_classes);
+int cbgx_pack_weights(const float *const *tensors, int num_tensors, int num_layers, int num_classes,
+                      float *packed, void *stream);
+
+/* ---- whole denoiser call ---------------------------------------------------------------------
+ * Replaces UniTransformer.forward (repo/modules/e3nn/unitransformer.py:102-123) with
+ * cutoff_mode='knn', k=32, ew_type='global', num_blocks=1, num_x2h=num_h2x=1, relu+LayerNorm.
+ * x[N,3], h[N,128], graph_ptr[B+1] int32, lig_flag[N]/gen_flag[N] uint8 (0/1).
+ * Outputs x_out[N,3], h_out[N,128], logits[N,num_classes] (logits may be NULL). */
+size_t cbgx_workspace_bytes(int n_nodes, int n_graphs);
+int cbgx_unitransformer_forward(const float *packed, int num_layers, int num_classes,
+                                const float *x, const float *h, const int32_t *graph_ptr,
+                                const uint8_t *lig_flag, const uint8_t *gen_flag,
+                                int n_nodes, int n_graphs,
+                                float *x_out, float *h_out, float *logits,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- stages (also what the parity tests call one by one) ------------------------------------- */
+
+/* torch_cluster.knn_graph(x, k, batch, loop=False, flow='source_to_target') as called at
+ * unitransformer.py:80.  nbr[N,32] int32: neighbours of centre i in ascending (squared distance,
+ * index) order, -1 padded; deg[N] = min(k, n_graph-1).  Edge (src=nbr[i][s], dst=i). k must be 32. */
+int cbgx_knn_graph(const float *x, const int32_t *graph_ptr, int n_graphs, int n_nodes, int k,
+                   int32_t *nbr, int32_t *deg, void *stream);
+
+/* Global distance gate, unitransformer.py:109-112 + repo/modules/embs/dist_emb.py:6-9:
+ * e_w[N,32] = sigmoid(MLP_{20->160->1}(rbf(|x_i - x_nbr|))), 0 in padded slots. */
+int cbgx_edge_gate(const float *packed, const float *x, const int32_t *nbr, const int32_t *deg,
+                   int n_nodes, float *e_w, void *stream);
+
+/* X2HAttention.forward, repo/modules/attention/x2h_attention.py:43-97 (includes the residual):
+ * h_out = h + sum_e softmax_e(q_i.k_e/sqrt(8)) * v_e * e_w.  `layer` selects denoiser.blocks[layer]. */
+int cbgx_x2h_attention(const float *packed, int layer, const float *x, const float *h,
+                       const int32_t *nbr, const int32_t *deg, const uint8_t *lig_flag, const float *e_w,
+                       int n_nodes, float *h_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* H2XAttention.forward, repo/modules/attention/h2x_attention.py:34-73, plus the masked update of
+ * E3DualAttentionLayer.forward (unitransformer.py:178-184): x_out = x + delta_x * gen_flag.
+ * delta_x[N,3] (may be NULL) receives the raw attention output. */
+int cbgx_h2x_attention(const float *packed, int layer, const float *x, const float *h,
+                       const int32_t *nbr, const int32_t *deg, const uint8_t *lig_flag,
+                       const uint8_t *gen_flag, const float *e_w, int n_nodes,
+                       float *x_out, float *delta_x, void *workspace, size_t workspace_bytes, void *stream);
+
+/* classifier head, unitransformer.py:46-51,119-120: Linear -> softplus - ln2 -> Linear. */
+int cbgx_classifier(const float *packed, int num_layers, int num_classes, const float *h, int n_nodes,
+                    float *logits, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- measurement hook (bench.py) ----------------------------------------------------------------
+ * Between cbgx_profile_begin() and cbgx_profile_end() every kernel launch is bracketed by HIP events on
+ * its own stream.  cbgx_profile_end() synchronises them and returns, per kernel class, the summed
+ * device time in ms and the launch count.  Classes: 0 knn, 1 gate, 2 node GEMM, 3 node query fold,
+ * 4 x2h edge kernel, 5 h2x edge kernel (CBGX_PROFILE_CLASSES = 6).  Not thread-safe with concurrent
+ * launches from other threads; process-wide. */
+#define CBGX_PROFILE_CLASSES 6
+int cbgx_profile_begin(int max_launches);
+int cbgx_profile_end(double *ms_by_class, int *launches_by_class, int num_classes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CBGX_H */

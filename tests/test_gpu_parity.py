@@ -1,0 +1,230 @@
+"""Parity of the HIP path (through the C ABI) against golden vectors made by the reference itself and
+against the CPU oracle.  Tolerances: fp32, summation-order differences only -> 1e-4 relative + 1e-5
+absolute on x / h / delta_x / logits, identical atom-type argmax on ligand rows,
+bit-exact neighbour lists."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cbgbench_amd as C
+from cbgbench_amd import stages, synthetic
+from cbgbench_amd.unitransformer import graph_ptr_from_batch
+from oracle import targetdiff as OT
+from oracle import unitransformer as OU
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RTOL, ATOL = 1e-4, 1e-5
+DENOISER_CASES = ["denoiser_2graphs", "denoiser_small_graphs", "denoiser_linker", "denoiser_eg5_pocket10"]
+
+
+def close(a, b, what, scale=1.0):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs()
+    tol = ATOL * scale + RTOL * b.abs()
+    assert bool((err <= tol).all()), f"{what}: max abs err {err.max():.3e} (|ref| max {b.abs().max():.3e})"
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    return {k: torch.from_numpy(z[k]) if z[k].ndim else z[k].item() for k in z.files}
+
+
+@pytest.fixture(scope="module")
+def model(synthetic_sd):
+    m = C.get_model(C.default_targetdiff_config(13)).eval()
+    m.load_state_dict(synthetic_sd, strict=True)
+    return m.to(DEV)
+
+
+def dev_inputs(g):
+    x, h = g["x"].to(DEV), g["h"].to(DEV)
+    gp = graph_ptr_from_batch(g["batch_idx"].to(DEV))
+    lig = g["lig_flag"].to(DEV).to(torch.uint8)
+    gen = g["gen_flag"].to(DEV).to(torch.uint8)
+    return x, h, gp, lig, gen
+
+
+@pytest.mark.parametrize("case", DENOISER_CASES)
+def test_knn_graph_bitexact(golden_dir, case):
+    g = load(golden_dir, case)
+    x, h, gp, lig, gen = dev_inputs(g)
+    nbr, deg = stages.knn_graph(x, gp)
+    ei = stages.edge_index_from_nbr(nbr, deg).cpu()
+    assert torch.equal(ei.int(), g["edge_index"])
+    pad = nbr.cpu()[torch.arange(32)[None, :] >= deg.cpu()[:, None]]
+    assert bool((pad == -1).all())
+
+
+@pytest.mark.parametrize("case", DENOISER_CASES)
+def test_stages_match_reference(golden_dir, model, case):
+    g = load(golden_dir, case)
+    x, h, gp, lig, gen = dev_inputs(g)
+    packed = model.denoiser.packed_weights(torch.device(DEV))
+    nbr, deg = stages.knn_graph(x, gp)
+    e_w = stages.edge_gate(packed, x, nbr, deg)
+    mask = (torch.arange(32, device=DEV)[None, :] < deg[:, None])
+    close(e_w[mask], g["e_w"].flatten(), "e_w")
+    assert bool((e_w[~mask] == 0).all())
+    h1 = stages.x2h_attention(packed, 0, x, h, nbr, deg, lig, e_w)
+    close(h1, g["h_layer0"], "x2h layer 0")
+    x1, dx = stages.h2x_attention(packed, 0, x, h1, nbr, deg, lig, gen, e_w)
+    close(x1, g["x_layer0"], "h2x layer 0")
+    moved = (x1 != x).any(-1).cpu()
+    assert not bool(moved[~g["gen_flag"]].any()), "gen_flag=False atoms must not move (unitransformer.py:182)"
+    logits = stages.classifier(packed, 9, 13, g["h_out"].to(DEV))
+    close(logits, g["logits"], "classifier")
+
+
+@pytest.mark.parametrize("case", DENOISER_CASES)
+def test_full_denoiser_matches_reference(golden_dir, model, case):
+    g = load(golden_dir, case)
+    with torch.no_grad():
+        xo, ho, lo = model.denoiser(x=g["x"].to(DEV), h=g["h"].to(DEV), batch_idx=g["batch_idx"].to(DEV),
+                                    lig_flag=g["lig_flag"].to(DEV), gen_flag=g["gen_flag"].to(DEV))
+    close(xo, g["x_out"], "x_out")
+    close(ho, g["h_out"], "h_out", scale=10.0)   # |h| grows to O(10) over 9 residual layers
+    close(lo, g["logits"], "logits", scale=10.0)
+    lig = g["lig_flag"]
+    assert torch.equal(lo.cpu()[lig].argmax(-1), g["logits"][lig].argmax(-1))
+    assert torch.equal(xo.cpu()[~g["gen_flag"]], g["x"][~g["gen_flag"]])
+
+
+def test_sample_loop_matches_reference(golden_dir):
+    """TargetDiff.sample end to end on a 5-step model with the reference's noise replayed."""
+    g = load(golden_dir, "sample_T5")
+    T = int(g["T"])
+    m = C.get_model(C.default_targetdiff_config(13, num_diffusion_timesteps=T)).eval()
+    m.load_state_dict(W.synthetic_state_dict(13, 9, seed=0, num_timesteps=T), strict=True)
+    m = m.to(DEV)
+    batch = {k[len("batch_"):]: v for k, v in g.items() if k.startswith("batch_")}
+    n_lig = batch["ligand_pos"].shape[0]
+    torch.manual_seed(int(g["seed"]))
+    tape = {}
+    for t in reversed(range(T)):
+        tape[t] = (torch.randn(n_lig, 3).to(DEV), torch.rand(n_lig, 13).to(DEV))
+    traj = m.sample(synthetic.batch_to(batch, DEV), noise_tape=tape)
+    assert sorted(traj.keys()) == list(range(-1, T))
+    for t in range(-1, T):
+        close(traj[t][0], g[f"traj_x_{t}"], f"traj x[{t}]")
+        assert torch.equal(traj[t][1], g[f"traj_c_{t}"]), f"traj c[{t}]"
+        assert torch.equal(traj[t][2], batch["ligand_element_batch"])
+
+
+@pytest.mark.parametrize("case", ["step_t500", "step_t0", "step_t999_linker"])
+def test_teacher_forced_step(golden_dir, model, case):
+    g = load(golden_dir, case)
+    batch = {k[len("batch_"):]: v for k, v in g.items() if k.startswith("batch_")}
+    t_idx = int(g["t_idx"])
+    # run exactly one step of sample(): a 1000-step model teacher-forced at t_idx
+    b = synthetic.batch_to(batch, DEV)
+    bl, br = b["ligand_element_batch"], b["protein_element_batch"]
+    sort_idx, batch_idx, lig_flag, lig_rows, gp = model.compose_plan(bl, br)
+    gen_l = b.get("ligand_gen_flag", b["ligand_lig_flag"]).bool()
+    gen = torch.cat([torch.zeros_like(b["protein_lig_flag"]), gen_l])[sort_idx]
+    aa = torch.nn.functional.one_hot(b["protein_aa_type"], 20).float()
+    c_lig = torch.nn.functional.one_hot(b["ligand_atom_type"], 13).float()
+    with torch.no_grad():
+        h = torch.cat([model.context_embedder.embed_protein(b["protein_atom_feature"], aa),
+                       model.context_embedder.embed_ligand(c_lig)])[sort_idx]
+        x = torch.cat([b["protein_pos"], b["ligand_pos"]])[sort_idx]
+        xo, _, lo = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
+        x_pred, c_pred = xo[lig_rows], lo[lig_rows]
+        close(x_pred, g["x_pred"], "x0 prediction")
+        close(c_pred, g["c_pred"], "type logits", scale=10.0)
+        assert torch.equal(c_pred.argmax(-1).cpu(), g["c_pred"].argmax(-1))
+        B = int(bl.max()) + 1
+        t = torch.full((B,), t_idx, dtype=torch.long, device=DEV)
+        x_next = model.pos_scheduler.backward_remove_noise(x_pred, b["ligand_pos"], t, bl, gen_l, noise=g["eps"].to(DEV))
+        c_next, v_next = model.type_scheduler.backward_remove_noise(c_pred, c_lig, t, bl, gen_l, uniform=g["u"].to(DEV))
+    close(x_next, g["x_next"], "x_{t-1}")
+    assert torch.equal(v_next.cpu(), g["v_next"])
+
+
+# ---- bigger than the fixtures: oracle on the same seeded inputs --------------------------------------
+def _composed(model, batch):
+    b = synthetic.batch_to(batch, DEV)
+    bl, br = b["ligand_element_batch"], b["protein_element_batch"]
+    sort_idx, batch_idx, lig_flag, lig_rows, gp = model.compose_plan(bl, br)
+    gen_l = b.get("ligand_gen_flag", b["ligand_lig_flag"]).bool()
+    gen = torch.cat([torch.zeros_like(b["protein_lig_flag"]), gen_l])[sort_idx]
+    aa = torch.nn.functional.one_hot(b["protein_aa_type"], 20).float()
+    c_lig = torch.nn.functional.one_hot(b["ligand_atom_type"], 13).float()
+    with torch.no_grad():
+        h = torch.cat([model.context_embedder.embed_protein(b["protein_atom_feature"], aa),
+                       model.context_embedder.embed_ligand(c_lig)])[sort_idx]
+    x = torch.cat([b["protein_pos"], b["ligand_pos"]])[sort_idx]
+    return x, h, batch_idx, lig_flag, gen, gp
+
+
+@pytest.mark.parametrize("maker,n", [(synthetic.denovo_batch, 3), (synthetic.linker_batch, 4)])
+def test_config_sized_graphs_vs_oracle(model, synthetic_sd, maker, n):
+    """Full-size pockets (N_rec 350..650, ragged ligands, partial gen_flag for the linker batch)."""
+    x, h, batch_idx, lig_flag, gen, gp = _composed(model, maker(n, seed=3))
+    with torch.no_grad():
+        xo, ho, lo = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
+    rx, rh, rl = OU.unitransformer_forward(synthetic_sd, x.cpu(), h.cpu(), batch_idx.cpu(), lig_flag.cpu(), gen.cpu())
+    close(xo, rx, "x_out")
+    close(ho, rh, "h_out", scale=10.0)
+    close(lo, rl, "logits", scale=10.0)
+    lig = lig_flag.cpu()
+    assert torch.equal(lo.cpu()[lig].argmax(-1), rl[lig].argmax(-1))
+
+
+# ---- size-independent properties at config-2 / config-3 batch shapes -------------------------------
+def _rand_rotation(seed):
+    g = torch.Generator().manual_seed(seed)
+    q, r = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+    q = q * torch.sign(torch.diagonal(r))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q.float()
+
+
+def test_properties_at_full_batch(model):
+    """config 2 shape (10 samples of one pocket): E(3) equivariance, batch independence, determinism."""
+    batch = synthetic.denovo_batch(10, seed=5, same_pocket=True)
+    x, h, batch_idx, lig_flag, gen, gp = _composed(model, batch)
+    den = model.denoiser
+    with torch.no_grad():
+        xo, ho, lo = den(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
+        xo2, ho2, lo2 = den(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
+        assert torch.equal(xo, xo2) and torch.equal(ho, ho2) and torch.equal(lo, lo2), "not deterministic"
+        assert torch.isfinite(xo).all() and torch.isfinite(ho).all() and torch.isfinite(lo).all()
+        # rotation + translation
+        R = _rand_rotation(1).to(DEV)
+        tr = torch.tensor([3.0, -2.0, 5.0], device=DEV)
+        xr, hr, lr = den(x=x @ R.T + tr, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
+        close(xr, xo @ R.T + tr, "equivariance of x", scale=10.0)
+        close(hr, ho, "invariance of h", scale=10.0)
+        assert torch.equal(lr[lig_flag].argmax(-1), lo[lig_flag].argmax(-1))
+        # batch independence: graph 3 alone gives the same rows
+        s, e = int(gp[3]), int(gp[4])
+        gp1 = torch.tensor([0, e - s], dtype=torch.int32, device=DEV)
+        x1, h1, l1 = den(x=x[s:e].contiguous(), h=h[s:e].contiguous(), batch_idx=torch.zeros(e - s, dtype=torch.long, device=DEV),
+                         lig_flag=lig_flag[s:e].contiguous(), gen_flag=gen[s:e].contiguous(), graph_ptr=gp1)
+        assert torch.equal(x1, xo[s:e]) and torch.equal(h1, ho[s:e]) and torch.equal(l1, lo[s:e])
+        # protein atoms never move
+        assert torch.equal(xo[~gen], x[~gen])
+
+
+def test_linker_256_graphs_runs_and_freezes_context(model):
+    """config 3 shape: 256 ragged linker graphs in one batch (N ~ 1.3e5, E ~ 4e6)."""
+    batch = synthetic.linker_batch(256, seed=7)
+    x, h, batch_idx, lig_flag, gen, gp = _composed(model, batch)
+    with torch.no_grad():
+        xo, ho, lo = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
+    assert torch.isfinite(xo).all() and torch.isfinite(ho).all() and torch.isfinite(lo).all()
+    assert torch.equal(xo[~gen], x[~gen])
+    assert bool((xo[gen] != x[gen]).any())
+    # one of the 256 graphs against the oracle (the oracle on the whole batch would take minutes)
+    gidx = 17
+    s, e = int(gp[gidx]), int(gp[gidx + 1])
+    sd = W.synthetic_state_dict(13, 9)
+    rx, rh, rl = OU.unitransformer_forward(sd, x[s:e].cpu(), h[s:e].cpu(), torch.zeros(e - s, dtype=torch.long),
+                                           lig_flag[s:e].cpu(), gen[s:e].cpu())
+    close(xo[s:e], rx, "x_out (graph 17 of 256)")
+    close(ho[s:e], rh, "h_out (graph 17 of 256)", scale=10.0)

@@ -1,0 +1,176 @@
+"""Host logic + C-ABI surface, no GPU needed."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cbgbench_amd as C
+from cbgbench_amd import _native, sharding
+from oracle import targetdiff as OT
+from oracle import weights as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_include_and_num_atomtype():
+    cfg, name = C.load_config(os.path.join(ROOT, "tests", "fixtures", "targetdiff_test.yml"))
+    assert name == "targetdiff_test"
+    assert cfg.model.generator.pos_schedule.beta_end == pytest.approx(2e-3)
+    assert cfg.model.encoder.get("k", 32) == 32
+    C.set_num_atom_type(cfg)
+    assert cfg.model.num_atomtype == 13 and cfg.mode == "add_aromatic"
+    C.set_num_atom_type(cfg, 8)
+    assert cfg.model.num_atomtype == 8
+
+
+def test_registry_and_factory_errors():
+    assert "targetdiff" in C.registered_models()
+    with pytest.raises(KeyError):
+        C.get_model(C.Config(type="nope"))
+    with pytest.raises(ValueError, match="Unknown model type"):
+        C.get_e3_gnn(C.Config(type="gvptransformer"))
+    with pytest.raises(ValueError, match="Not supported cutoff mode"):
+        C.get_e3_gnn(C.Config(type="unitransformer", cutoff_mode="radius"), num_classes=13)
+    with pytest.raises(ValueError, match="n_heads"):
+        C.get_e3_gnn(C.Config(type="unitransformer", n_heads=8), num_classes=13)
+
+
+@pytest.mark.parametrize("tag,Cn", [("add_aromatic", 13), ("basic", 8)])
+def test_state_dict_is_reference_compatible(golden_dir, tag, Cn):
+    model = C.get_model(C.default_targetdiff_config(Cn))
+    with open(os.path.join(golden_dir, f"state_dict_keys_{tag}.json")) as f:
+        ref = json.load(f)
+    sd = model.state_dict()
+    assert set(sd) == set(ref)
+    for k, shp in ref.items():
+        assert list(sd[k].shape) == shp, k
+    model.load_state_dict(W.synthetic_state_dict(Cn, 9), strict=True)
+    # frozen tables are not trainable; 2 671 774 trainable parameters for C=13
+    if Cn == 13:
+        assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 2671774
+        assert sum(p.numel() for p in model.parameters()) == 2699774
+
+
+def test_schedule_tables_bitexact(golden_dir):
+    model = C.get_model(C.default_targetdiff_config(13))
+    z = np.load(os.path.join(golden_dir, "schedule_tables.npz"))
+    sd = model.state_dict()
+    for k in z.files:
+        assert np.array_equal(z[k], sd[k].numpy()), k
+
+
+@pytest.mark.parametrize("case", ["step_t500", "step_t0", "step_t999_linker"])
+def test_posterior_updates_match_reference(golden_dir, case):
+    """The host-side step update (pos + type posterior) on the reference's network outputs."""
+    z = np.load(os.path.join(golden_dir, case + ".npz"))
+    g = {k: torch.from_numpy(z[k]) if z[k].ndim else z[k].item() for k in z.files}
+    model = C.get_model(C.default_targetdiff_config(13))
+    bl = g["batch_ligand_element_batch"]
+    gen = g["batch_ligand_gen_flag"] if "batch_ligand_gen_flag" in g else g["batch_ligand_lig_flag"]
+    B = int(bl.max()) + 1
+    t = torch.full((B,), int(g["t_idx"]), dtype=torch.long)
+    c_lig = torch.nn.functional.one_hot(g["batch_ligand_atom_type"], 13).float()
+    x_next = model.pos_scheduler.backward_remove_noise(g["x_pred"], g["batch_ligand_pos"], t, bl, gen, noise=g["eps"])
+    c_next, v_next = model.type_scheduler.backward_remove_noise(g["c_pred"], c_lig, t, bl, gen, uniform=g["u"])
+    assert torch.equal(x_next, g["x_next"])
+    assert torch.equal(v_next, g["v_next"]) and torch.equal(c_next, g["c_next"])
+
+
+def test_compose_plan_matches_oracle():
+    bl = torch.tensor([0, 0, 1, 1, 1, 2])
+    br = torch.tensor([0, 0, 0, 1, 2, 2])
+    sort_idx, batch_idx, lig_flag, lig_rows, gp = C.TargetDiff.compose_plan(bl, br)
+    o_sort, o_batch = OT.compose(bl, br)
+    assert torch.equal(sort_idx, o_sort) and torch.equal(batch_idx, o_batch)
+    assert gp.tolist() == [0, 5, 9, 12] and gp.dtype == torch.int32
+    assert lig_rows.tolist() == [3, 4, 6, 7, 8, 11]
+    # protein rows first inside every graph
+    for g in range(3):
+        seg = lig_flag[gp[g]:gp[g + 1]]
+        assert torch.equal(seg, seg.sort().values)
+
+
+def test_embedder_matches_oracle():
+    torch.manual_seed(0)
+    model = C.get_model(C.default_targetdiff_config(13))
+    sd = W.synthetic_state_dict(13, 9)
+    model.load_state_dict(sd)
+    c = torch.nn.functional.one_hot(torch.randint(0, 13, (7,)), 13).float()
+    v = torch.rand(9, 7)
+    aa = torch.nn.functional.one_hot(torch.randint(0, 20, (9,)), 20).float()
+    hl, hr = OT.context_embed(sd, c, v, aa)
+    with torch.no_grad():
+        assert torch.allclose(model.context_embedder.embed_ligand(c), hl, atol=1e-6)
+        assert torch.allclose(model.context_embedder.embed_protein(v, aa), hr, atol=1e-6)
+
+
+def test_no_cpu_fallback():
+    model = C.get_model(C.default_targetdiff_config(13))
+    x = torch.zeros(4, 3); h = torch.zeros(4, 128)
+    b = torch.zeros(4, dtype=torch.long); f = torch.zeros(4, dtype=torch.bool)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.denoiser(x=x, h=h, batch_idx=b, lig_flag=f, gen_flag=f)
+    with pytest.raises(NotImplementedError):
+        model(dict())
+
+
+# ---- C ABI ---------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "cbgx.h")).read()
+    declared = set(re.findall(r"\b(cbgx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
+    lib = _native.lib()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.cbgx_abi_version() == 1
+
+
+def test_abi_argument_errors_without_gpu():
+    lib = _native.lib()
+    assert lib.cbgx_packed_weights_floats(9, 13) == 2798356
+    assert lib.cbgx_workspace_bytes(425, 1) > 425 * (640 + 16 * 128) * 4
+    one = ctypes.c_void_p(16)  # never dereferenced: argument checks come first
+    assert lib.cbgx_knn_graph(one, one, 1, 10, 16, one, one, None) == -1
+    assert b"k=32" in lib.cbgx_last_error()
+    assert lib.cbgx_knn_graph(None, None, 0, 0, 32, None, None, None) == 0       # empty input is a no-op
+    assert lib.cbgx_x2h_attention(one, 0, one, one, one, one, one, one, 10, one, one, 8, None) == -2
+    assert b"workspace" in lib.cbgx_last_error()
+    assert lib.cbgx_unitransformer_forward(one, 9, 13, None, one, one, one, one, 10, 1, one, one, one, one,
+                                           1 << 30, None) == -1
+    arr = (ctypes.c_void_p * 3)(16, 16, 16)
+    assert lib.cbgx_pack_weights(arr, 3, 9, 13, one, None) == -1
+    with pytest.raises(ValueError):
+        _native.check(-1, "x")
+    with pytest.raises(_native.NativeError):
+        _native.check(-3, "x")
+
+
+# ---- multi-GPU path: sharding + timing reduction over gloo, world_size 2 ------------------------------
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w, _ = sharding.init_process_group("gloo")
+    mine = sharding.shard_indices(11, r, w)
+    sharding.barrier()
+    elapsed, units = sharding.reduce_max_sum(1.0 + r, len(mine))
+    q.put((r, mine, elapsed, units))
+    torch.distributed.destroy_process_group()
+
+
+def test_pocket_sharding_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs: p.join(timeout=60)
+    assert res[0][1] == [0, 2, 4, 6, 8, 10] and res[1][1] == [1, 3, 5, 7, 9]
+    assert sorted(res[0][1] + res[1][1]) == list(range(11))      # a partition: no pocket lost or duplicated
+    for _, _, elapsed, units in res:
+        assert elapsed == 2.0 and units == 11.0                  # max over ranks, sum over ranks
