@@ -64,6 +64,13 @@ extern "C" {
 int cbgx_abi_version(void) { return CBGX_ABI_VERSION; }
 const char* cbgx_last_error(void) { return g_err; }
 
+int cbgx_debug_set_edge_kernel(int impl) {
+    if (impl != 0 && impl != 1) return fail(CBGX_E_INVALID, "debug_set_edge_kernel: impl must be 0 (mfma) or 1 (valu)");
+    int old = g_edge_impl;
+    g_edge_impl = impl;
+    return old;
+}
+
 size_t cbgx_packed_weights_floats(int num_layers, int num_classes) {
     if (num_layers < 0 || num_classes < 1) return 0;
     return packed_floats(num_layers, num_classes);
@@ -116,7 +123,18 @@ int cbgx_pack_weights(const float* const* t, int num_tensors, int L, int C, floa
             CP(wq1, H, 0, 1, a + A_WQ1T, H, H, H);
             CP(bq1, H, 0, 0, a + A_BQ1, H, 1, H);
             CP(wk1, H, 0, 0, a + A_WBK, H, H, H);
+            // LDS image of the MFMA edge kernel
+            float* img = a + A_IMG;
+            HIP_TRY(launch_pack_frag(wk0, 0, img + IMG_FRAG_K, s));
+            HIP_TRY(launch_pack_frag(wv0, blk == 0 ? 1 : 0, img + IMG_FRAG_V, s));
+            CP(wk0, KV_IN, 0, 1, img + IMG_WT, 2 * H, NT, H);
+            CP(wv0, KV_IN, 0, 1, img + IMG_WT + H, 2 * H, NT, H);
+            CP(gk, H, 0, 0, img + IMG_LN + 0 * H, H, 1, H);
+            CP(bek, H, 0, 0, img + IMG_LN + 1 * H, H, 1, H);
+            CP(gv, H, 0, 0, img + IMG_LN + 2 * H, H, 1, H);
+            CP(bev, H, 0, 0, img + IMG_LN + 3 * H, H, 1, H);
             if (blk == 0) {
+                CP(wv1, H, 0, 0, img + IMG_WBV, H, H, H);  // row-major (n, m)
                 CP(wv1, H, 0, 1, a + A_WBV, H, H, H);   // [m][n]
                 CP(bv1, H, 0, 0, a + A_BBV, H, 1, H);
             } else {

@@ -1,0 +1,400 @@
+// libcbgx -- fused x2h / h2x edge kernels on the gfx950 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).
+//
+// One wavefront owns one destination node i and its <= 32 incoming edges; a persistent workgroup keeps the
+// layer's rbf weight fragments (and, for x2h, the second v Linear) in LDS and loops over nodes.  Per node:
+//
+//   pre[e][m] = PD[i][m] + PS[j_e][m] + Wt[type_e][m] + sum_g Wr[type_e][g][m] rbf_g(|x_i - x_j|)   (k and v)
+//   hid       = ReLU(LayerNorm(pre))
+//   score[e][a] = Qt[i][a] . hid_k[e]          (the key's 2nd Linear and 1/sqrt(8) are folded into Qt)
+//   alpha     = softmax over the node's incoming edges, per head
+//   x2h:  S[a] = sum_e alpha e_w hid_v[e]  ->  h_out = h + Wbv_a S[a] + bbv * sum_e alpha e_w
+//   h2x:  wv[e][a] = Wbv[a] . hid_v[e] + bbv[a]  ->  dx = 1/16 sum_a sum_e alpha wv e_w (x_i - x_j)
+//
+// All four contractions are MFMAs and every accumulator is consumed in the layout it was produced in
+// (no LDS transposes): tests/lanesim.py is the lane-by-lane model of this file and is checked against the
+// reference on the CPU (tests/test_lanesim.py).  Lane l: c = l & 15, q = l >> 4.
+//   edge-major tile    (k; h2x v):  lane column = edge e16, C row 4q+r  <->  channel m = 32q + 4t + r
+//   channel-major tile (x2h v):     lane column = channel, m = 8c + t;   C row 4q+r <-> edge e = 4q + r + 16hf
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "layout.h"
+
+namespace cbgx {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__constant__ float c_mu[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.75f, 3.f,
+                              3.5f, 4.f, 4.5f, 5.f, 5.5f, 6.f, 7.f, 8.f, 9.f, 10.f};
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float xor_add(float v, int m) { return v + __shfl_xor(v, m, 64); }
+__device__ __forceinline__ float xor_max(float v, int m) { return fmaxf(v, __shfl_xor(v, m, 64)); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ floatx4 f4(float4 a) { floatx4 r = {a.x, a.y, a.z, a.w}; return r; }
+
+// edge type, unitransformer.py:92-97: (src lig, dst lig)->0, (lig, prot)->1, (prot, lig)->2, (prot, prot)->3
+__device__ __forceinline__ int etype(bool src_lig, int lig_i) { return src_lig ? (lig_i ? 0 : 1) : (lig_i ? 2 : 3); }
+
+// ---- edge-major path for one half (16 edges): pre-activation -> LayerNorm -> ReLU -> contraction with a
+// per-lane row of B (Qt[i][a] for scores, Wbv[a] for the h2x values).  Returns the 16x16 result tile:
+// lane (c = a, q), reg r <-> edge 4q + r + 16hf.  One half at a time keeps 32 accumulator registers live.
+__device__ __forceinline__ floatx4 edge_major_half(const float* __restrict__ P, int i, int j, bool lg, int pd_off,
+                                                   int ps_off, const float* lds_frag, const float* lds_wt,
+                                                   const float* lds_g, const float* lds_b, const float (&R)[5],
+                                                   bool has_prot, bool has_lig, int lig_i, int lane, int q,
+                                                   const float* __restrict__ Brow /* &B[c][32q] */) {
+    floatx4 acc[8];
+    {
+        const float* pd = P + (size_t)i * PROW + pd_off + 32 * q;
+        const float* ps = P + (size_t)j * PROW + ps_off + 32 * q;
+        const float* wt = lds_wt + etype(lg, lig_i) * 2 * H + 32 * q;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = f4(ld4(pd + 4 * t)) + f4(ld4(ps + 4 * t)) + f4(ld4(wt + 4 * t));
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (p == 0 ? !has_prot : !has_lig) continue;  // wave-uniform
+        const float* fa = lds_frag + (size_t)etype(p == 1, lig_i) * (8 * 5 * 64) + lane;
+        float Rm[5];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) Rm[s] = (lg == (p == 1)) ? R[s] : 0.f;
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = MFMA(fa[(t * 5 + s) * 64], Rm[s], acc[t]);
+    }
+    // LayerNorm over the 128 channels of each edge: 32 in-lane values x 4 lanes (q), then affine + ReLU
+    float sm = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) sm += (acc[t].x + acc[t].y) + (acc[t].z + acc[t].w);
+    sm = xor_add(xor_add(sm, 16), 32);
+    const float mean = sm * (1.f / H);
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        acc[t] -= mean;
+        v += (acc[t].x * acc[t].x + acc[t].y * acc[t].y) + (acc[t].z * acc[t].z + acc[t].w * acc[t].w);
+    }
+    v = xor_add(xor_add(v, 16), 32);
+    const float rstd = 1.f / sqrtf(v * (1.f / H) + 1e-5f);
+    // two interleaved accumulators: a dependent 16x16x4 MFMA needs 40 cycles, an independent one 32
+    floatx4 out0 = {0.f, 0.f, 0.f, 0.f}, out1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const floatx4 g = f4(ld4(lds_g + 32 * q + 4 * t)), b = f4(ld4(lds_b + 32 * q + 4 * t));
+        const floatx4 y = acc[t] * rstd * g + b;
+        const float4 bb = ld4(Brow + 4 * t);
+        out0 = MFMA(fmaxf(y.x, 0.f), bb.x, out0);
+        out1 = MFMA(fmaxf(y.y, 0.f), bb.y, out1);
+        out0 = MFMA(fmaxf(y.z, 0.f), bb.z, out0);
+        out1 = MFMA(fmaxf(y.w, 0.f), bb.w, out1);
+    }
+    return out0 + out1;
+}
+
+template <bool X2H, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
+    const float* __restrict__ att, const float* __restrict__ x, const float* __restrict__ h,
+    const float* __restrict__ P, const float* __restrict__ Qt, const int32_t* __restrict__ nbr,
+    const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig, const uint8_t* __restrict__ gen,
+    const float* __restrict__ e_w, int n_nodes, float* __restrict__ out, float* __restrict__ dx_out) {
+    constexpr int IMG = X2H ? (int)IMG_SIZE_X2H : (int)IMG_SIZE_H2X;
+    __shared__ __attribute__((aligned(16))) float lds[IMG];
+    {
+        const float4* src = reinterpret_cast<const float4*>(att + A_IMG);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int t = threadIdx.x; t < IMG / 4; t += WAVES * 64) dst[t] = src[t];
+    }
+    __syncthreads();
+    const float* lds_fk = lds + IMG_FRAG_K;
+    const float* lds_fv = lds + IMG_FRAG_V;
+    const float* lds_wt = lds + IMG_WT;
+    const float* lds_ln = lds + IMG_LN;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    float mu[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) mu[s] = c_mu[4 * s + q];
+
+    for (int i = blockIdx.x * WAVES + wave; i < n_nodes; i += gridDim.x * WAVES) {
+        const int d = deg[i];
+        const int lig_i = lig[i];
+        const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
+        // ---- stage 0: geometry, E0 mapping: lane (c, q) <-> edges c and c + 16 ---------------------------
+        int j0[2];
+        bool lg0[2];
+        float R[2][5];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int e = c + 16 * hf;
+            const bool valid = e < d;
+            const int j = valid ? nbr[(size_t)i * KNN + e] : i;
+            j0[hf] = j;
+            lg0[hf] = valid && lig[j];
+            const float rx = xi - x[3 * j], ry = yi - x[3 * j + 1], rz = zi - x[3 * j + 2];
+            const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const float u = dist - mu[s];
+                R[hf][s] = valid ? expf(-0.5f * (u * u)) : 0.f;
+            }
+        }
+        const unsigned long long b0 = __ballot(lg0[0]), b1 = __ballot(lg0[1]);
+        const unsigned mask_lig = (unsigned)(b0 & 0xffffull) | ((unsigned)(b1 & 0xffffull) << 16);
+        const unsigned mask_valid = d >= 32 ? 0xffffffffu : ((1u << d) - 1u);
+        const bool has_lig = (mask_lig & mask_valid) != 0;
+        const bool has_prot = ((~mask_lig) & mask_valid) != 0 || d == 0;
+
+        // ---- k path: hidden (edge-major) -> scores -> softmax ------------------------------------------
+        floatx4 sc[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            sc[hf] = edge_major_half(P, i, j0[hf], lg0[hf], 0, 2 * H, lds_fk, lds_wt, lds_ln, lds_ln + H, R[hf], has_prot,
+                                     has_lig, lig_i, lane, q, Qt + ((size_t)i * HEADS + c) * H + 32 * q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // E1 mapping: lane (c = head a, q), reg (hf, r) <-> edge e = 4q + r + 16hf
+        float al[2][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool valid = 4 * q + r + 16 * hf < d;
+                al[hf][r] = valid ? sc[hf][r] : -INFINITY;
+                mx = fmaxf(mx, al[hf][r]);
+            }
+        mx = xor_max(xor_max(mx, 16), 32);
+        float den = 0.f;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool valid = 4 * q + r + 16 * hf < d;
+                al[hf][r] = valid ? expf(al[hf][r] - mx) : 0.f;
+                den += al[hf][r];
+            }
+        den = xor_add(xor_add(den, 16), 32);
+        const float inv_den = den > 0.f ? 1.f / den : 0.f;
+        const float4 ew0 = ld4(e_w + (size_t)i * KNN + 4 * q), ew1 = ld4(e_w + (size_t)i * KNN + 16 + 4 * q);
+        const float ew[2][4] = {{ew0.x, ew0.y, ew0.z, ew0.w}, {ew1.x, ew1.y, ew1.z, ew1.w}};
+        // neighbours in the E1 mapping
+        const int4 nb0 = *reinterpret_cast<const int4*>(nbr + (size_t)i * KNN + 4 * q);
+        const int4 nb1 = *reinterpret_cast<const int4*>(nbr + (size_t)i * KNN + 16 + 4 * q);
+        const int nb[2][4] = {{nb0.x, nb0.y, nb0.z, nb0.w}, {nb1.x, nb1.y, nb1.z, nb1.w}};
+
+        if (X2H) {
+            float w[2][4];
+            float sw = 0.f;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // softmax first (alpha = ex / den, like scatter_softmax), then the gate
+                    w[hf][r] = (al[hf][r] * inv_den) * ew[hf][r];
+                    sw += w[hf][r];
+                }
+            sw = xor_add(xor_add(sw, 16), 32);   // sum_e alpha e_w for head a = c
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- v path, channel-major: lane (c, q) reg r <-> edge 4q + r + 16hf, channel m = 8c + t ------
+            floatx4 hv[8][2];
+            {
+                const float4 pa = ld4(P + (size_t)i * PROW + H + 8 * c), pb = ld4(P + (size_t)i * PROW + H + 8 * c + 4);
+                const float pdv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+                const float* wtp = lds_wt + etype(false, lig_i) * 2 * H + H + 8 * c;
+                const float* wtl = lds_wt + etype(true, lig_i) * 2 * H + H + 8 * c;
+                const float4 wpa = ld4(wtp), wpb = ld4(wtp + 4), wla = ld4(wtl), wlb = ld4(wtl + 4);
+                const float wP[8] = {wpa.x, wpa.y, wpa.z, wpa.w, wpb.x, wpb.y, wpb.z, wpb.w};
+                const float wL[8] = {wla.x, wla.y, wla.z, wla.w, wlb.x, wlb.y, wlb.z, wlb.w};
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = 4 * q + r + 16 * hf;
+                        const int j = e < d ? nb[hf][r] : i;
+                        const bool sl = (mask_lig >> e) & 1u;
+                        const float* ps = P + (size_t)j * PROW + 3 * H + 8 * c;
+                        const float4 sa = ld4(ps), sb = ld4(ps + 4);
+                        const float sv[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) hv[t][hf][r] = pdv[t] + sv[t] + (sl ? wL[t] : wP[t]);
+                    }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (p == 0 ? !has_prot : !has_lig) continue;
+                const float* fb = lds_fv + (size_t)etype(p == 1, lig_i) * (8 * 5 * 64) + lane;
+                float Rm[2][5];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int s = 0; s < 5; ++s) Rm[hf][s] = (lg0[hf] == (p == 1)) ? R[hf][s] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int s = 0; s < 5; ++s) {
+                        const float b = fb[(t * 5 + s) * 64];
+                        hv[t][0] = MFMA(Rm[0][s], b, hv[t][0]);
+                        hv[t][1] = MFMA(Rm[1][s], b, hv[t][1]);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {   // LayerNorm per edge (hf, r): in-lane over t, across the 16 lanes of the row
+                const float4 ga = ld4(lds_ln + 2 * H + 8 * c), gb = ld4(lds_ln + 2 * H + 8 * c + 4);
+                const float4 ba = ld4(lds_ln + 3 * H + 8 * c), bb = ld4(lds_ln + 3 * H + 8 * c + 4);
+                const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+                const float bv[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) s += hv[t][hf][r];
+                        s = xor_add(xor_add(xor_add(xor_add(s, 1), 2), 4), 8);
+                        const float mean = s * (1.f / H);
+                        float v = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) { hv[t][hf][r] -= mean; v += hv[t][hf][r] * hv[t][hf][r]; }
+                        v = xor_add(xor_add(xor_add(xor_add(v, 1), 2), 4), 8);
+                        const float rstd = 1.f / sqrtf(v * (1.f / H) + 1e-5f);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) hv[t][hf][r] = fmaxf(hv[t][hf][r] * rstd * gv[t] + bv[t], 0.f);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // v aggregation: s2[t] (lane (c, q) reg r' <-> head 4q + r', channel 8c + t)
+            floatx4 s2[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) s2[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) s2[t] = MFMA(w[hf][r], hv[t][hf][r], s2[t]);
+            __builtin_amdgcn_sched_barrier(0);
+            // epilogue: out[8a + cc] = sum_m Wbv[8a + cc][m] S[a][m]; 32 partials per lane, reduce-scatter over c
+            float part[32];
+            const float* lds_wbv = lds + IMG_WBV;
+#pragma unroll
+            for (int rp = 0; rp < 4; ++rp)
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    const float* wrow = lds_wbv + (size_t)(8 * (4 * q + rp) + cc) * H + 8 * c;
+                    const float4 wa = ld4(wrow), wb = ld4(wrow + 4);
+                    float a = wa.x * s2[0][rp];
+                    a = fmaf(wa.y, s2[1][rp], a); a = fmaf(wa.z, s2[2][rp], a); a = fmaf(wa.w, s2[3][rp], a);
+                    a = fmaf(wb.x, s2[4][rp], a); a = fmaf(wb.y, s2[5][rp], a); a = fmaf(wb.z, s2[6][rp], a);
+                    a = fmaf(wb.w, s2[7][rp], a);
+                    part[rp * 8 + cc] = a;
+                }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const bool up = c & 8;
+                const float keep = up ? part[16 + k] : part[k], send = up ? part[k] : part[16 + k];
+                part[k] = keep + __shfl_xor(send, 8, 64);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool up = c & 4;
+                const float keep = up ? part[8 + k] : part[k], send = up ? part[k] : part[8 + k];
+                part[k] = keep + __shfl_xor(send, 4, 64);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool up = c & 2;
+                const float keep = up ? part[4 + k] : part[k], send = up ? part[k] : part[4 + k];
+                part[k] = keep + __shfl_xor(send, 2, 64);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const bool up = c & 1;
+                const float keep = up ? part[2 + k] : part[k], send = up ? part[k] : part[2 + k];
+                part[k] = keep + __shfl_xor(send, 1, 64);
+            }
+            // lane (c, q) now owns outputs n = 32q + 2c, 32q + 2c + 1 (head a = 4q + (c >> 2))
+            const int n0 = 32 * q + 2 * c;
+            const float sw_a = __shfl(sw, 4 * q + (c >> 2), 64);
+            const float2 hres = *reinterpret_cast<const float2*>(h + (size_t)i * H + n0);
+            const float2 bb = *reinterpret_cast<const float2*>(att + A_BBV + n0);
+            float2 o;
+            o.x = hres.x + (part[0] + bb.x * sw_a);
+            o.y = hres.y + (part[1] + bb.y * sw_a);
+            *reinterpret_cast<float2*>(out + (size_t)i * H + n0) = o;
+        } else {
+            // ---- h2x: v hidden edge-major, wv[e][a] = Wbv[a] . hid_v[e] + bbv[a] -------------------------------
+            floatx4 wv[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                wv[hf] = edge_major_half(P, i, j0[hf], lg0[hf], H, 3 * H, lds_fv, lds_wt + H, lds_ln + 2 * H,
+                                         lds_ln + 3 * H, R[hf], has_prot, has_lig, lig_i, lane, q,
+                                         att + A_WBV + (size_t)c * H + 32 * q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float bbv = att[A_BBV + c];
+            float dx = 0.f, dy = 0.f, dz = 0.f;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = 4 * q + r + 16 * hf;
+                    if (e < d) {
+                        const int j = nb[hf][r];
+                        const float coef = (al[hf][r] * inv_den) * ((wv[hf][r] + bbv) * ew[hf][r]);
+                        dx = fmaf(coef, xi - x[3 * j], dx);
+                        dy = fmaf(coef, yi - x[3 * j + 1], dy);
+                        dz = fmaf(coef, zi - x[3 * j + 2], dz);
+                    }
+                }
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) { dx = xor_add(dx, m); dy = xor_add(dy, m); dz = xor_add(dz, m); }
+            if (lane < 3) {
+                const float v = (lane == 0 ? dx : (lane == 1 ? dy : dz)) * (1.f / HEADS);
+                const float xin = lane == 0 ? xi : (lane == 1 ? yi : zi);
+                if (dx_out) dx_out[3 * i + lane] = v;
+                out[3 * i + lane] = xin + (gen[i] ? v : 0.f);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_frag_kernel(const float* __restrict__ w_a, int mode, float* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // ((type*8 + t)*5 + s)*64 + lane
+    if (idx >= (int)FRAG) return;
+    const int lane = idx & 63, s = (idx >> 6) % 5, t = (idx / 320) & 7, type = idx / 2560;
+    const int c = lane & 15, kk = lane >> 4;
+    const int m = mode == 0 ? 32 * (c >> 2) + 4 * t + (c & 3) : 8 * c + t;
+    dst[idx] = w_a[(size_t)m * KV_IN + NT + G * type + 4 * s + kk];
+}
+
+hipError_t launch_pack_frag(const float* w_a, int mode, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((FRAG + 255) / 256), dim3(256), 0, s, w_a, mode, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,
+                            const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
+                            const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,
+                            hipStream_t s) {
+    if (n_nodes == 0) return hipSuccess;
+    constexpr int WAVES = 8;
+    int grid = (n_nodes + WAVES - 1) / WAVES;
+    if (grid > 256) grid = 256;   // persistent: one workgroup per CU (LDS-limited)
+    profile_mark_begin(x2h ? K_EDGE_X2H : K_EDGE_H2X, s);
+    if (x2h)
+        hipLaunchKernelGGL((edge_mfma_kernel<true, WAVES>), dim3(grid), dim3(WAVES * 64), 0, s, att, x, h, P, Qt, nbr,
+                           deg, lig, gen, e_w, n_nodes, out, dx_out);
+    else
+        hipLaunchKernelGGL((edge_mfma_kernel<false, WAVES>), dim3(grid), dim3(WAVES * 64), 0, s, att, x, h, P, Qt, nbr,
+                           deg, lig, gen, e_w, n_nodes, out, dx_out);
+    profile_mark_end(s);
+    return hipGetLastError();
+}
+
+}  // namespace cbgx

@@ -21,6 +21,14 @@ hipError_t launch_node_gemm(const float* A, int lda, const float* Wt, const floa
 hipError_t launch_attention(bool x2h, const float* att, const float* x, const float* h, const int32_t* nbr,
                             const int32_t* deg, const uint8_t* lig, const uint8_t* gen, const float* e_w, int n_nodes,
                             float* P, float* Qt, float* out, float* dx_out, hipStream_t s);
+extern int g_edge_impl;
+// fragment-ordered rbf weight table: mode 0 edge-major (A operand), 1 channel-major (B operand)
+hipError_t launch_pack_frag(const float* w_a, int mode, float* dst, hipStream_t s);
+// MFMA edge kernel (edge_mfma.hip)
+hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,
+                            const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
+                            const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,
+                            hipStream_t s);
 hipError_t launch_pack_copy(const float* src, int src_ld, int src_off, int transpose, float* dst, int dst_ld,
                             int rows, int cols, hipStream_t s);
 

@@ -423,6 +423,7 @@ __global__ void pack_copy_kernel(const float* __restrict__ src, int src_ld, int 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+int g_edge_impl = 0;  // 0: MFMA edge kernels (edge_mfma.hip); 1: first-generation VALU kernels (cross-check)
 #define CBGX_LAUNCH_CHECK()                            \
     do {                                               \
         hipError_t _e = hipGetLastError();             \
@@ -476,6 +477,8 @@ hipError_t launch_attention(bool x2h, const float* att, const float* x, const fl
     hipLaunchKernelGGL(node_query_kernel, dim3((n_nodes + 15) / 16), dim3(256), 0, s, att, P, Qt, n_nodes);
     profile_mark_end(s);
     CBGX_LAUNCH_CHECK();
+    if (g_edge_impl == 0)
+        return launch_edge_mfma(x2h, att, x, h, P, Qt, nbr, deg, lig, gen, e_w, n_nodes, out, dx_out, s);
     profile_mark_begin(x2h ? K_EDGE_X2H : K_EDGE_H2X, s);
     if (x2h)
         hipLaunchKernelGGL(edge_attention_kernel<true>, dim3(n_nodes), dim3(128), 0, s, att, x, h, P, Qt, nbr, deg,

@@ -40,7 +40,22 @@ constexpr size_t A_BQ1 = A_WQ1T + (size_t)H * H;  // [128]
 constexpr size_t A_WBK = A_BQ1 + H;               // [128][128] (out n, in m) second k linear
 constexpr size_t A_WBV = A_WBK + (size_t)H * H;   // x2h: [128 m][128 n] K-major; h2x: [16][128] (head, m)
 constexpr size_t A_BBV = A_WBV + (size_t)H * H;   // [128] (h2x: first 16)
-constexpr size_t ATT_SIZE = A_BBV + H;
+// LDS image of the MFMA edge kernel: one contiguous region copied verbatim into LDS.
+//   frag_k [4 types][8 t][5 s][64 lanes]  A-operand fragments of the rbf columns of W_a (k), edge-major
+//   frag_v [4][8][5][64]                  x2h: B-operand fragments (channel-major); h2x: A-operand (edge-major)
+//   wt     [4][256]                       type one-hot columns (k | v)
+//   ln     [4][128]                       gamma_k, beta_k, gamma_v, beta_v
+//   wbv_rm [128][128]                     x2h only: second v Linear, row-major (out n, in m)
+constexpr size_t FRAG = (size_t)NT * 8 * 5 * 64;   // 10240
+constexpr size_t A_IMG = A_BBV + H;
+constexpr size_t IMG_FRAG_K = 0;
+constexpr size_t IMG_FRAG_V = IMG_FRAG_K + FRAG;
+constexpr size_t IMG_WT = IMG_FRAG_V + FRAG;
+constexpr size_t IMG_LN = IMG_WT + NT * 2 * H;
+constexpr size_t IMG_WBV = IMG_LN + 4 * H;
+constexpr size_t IMG_SIZE_H2X = IMG_WBV;                 // 22016 floats
+constexpr size_t IMG_SIZE_X2H = IMG_WBV + (size_t)H * H; // 38400 floats = 153600 B
+constexpr size_t ATT_SIZE = A_IMG + IMG_SIZE_X2H;
 
 constexpr size_t LAYER_SIZE = 2 * ATT_SIZE;       // x2h then h2x
 

@@ -114,6 +114,12 @@ int cbgx_classifier(const float *packed, int num_layers, int num_classes, const 
 int cbgx_profile_begin(int max_launches);
 int cbgx_profile_end(double *ms_by_class, int *launches_by_class, int num_classes);
 
+/* ---- cross-check hook (tests only) ---------------------------------------------------------------
+ * The library carries two generations of the fused edge kernels: 0 = MFMA (default, edge_mfma.hip) and
+ * 1 = the first-generation VALU kernels kept as an on-device cross-check for sizes the CPU oracle cannot
+ * reach.  Returns the previous setting (>= 0) or CBGX_E_INVALID.  Process-wide. */
+int cbgx_debug_set_edge_kernel(int impl);
+
 #ifdef __cplusplus
 }
 #endif

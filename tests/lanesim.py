@@ -1,0 +1,236 @@
+"""Lane-level model of the MFMA edge kernels (cbgbench_amd/csrc/edge_mfma.hip).
+
+A numpy re-enactment of what each of the 64 lanes of a wavefront holds and feeds to
+``v_mfma_f32_16x16x4_f32`` in the fused x2h / h2x kernels.  It exists to pin the *index math* of the
+kernel (fragment layouts, K-permutation tricks, fragment-ordered weight tables) on the CPU, where it can
+be compared with the oracle; the HIP kernel mirrors it line by line.  ``tests/test_lanesim.py`` runs it.
+
+MFMA 16x16x4 f32 operand maps (cdna_hip_programming.md section 3): lane l, c = l & 15, q = l >> 4
+    A[i = c][k = q]      B[k = q][j = c]      C/D reg r: [row = 4q + r][col = c]
+"""
+import numpy as np
+
+L = np.arange(64)
+C_ = L & 15
+Q_ = L >> 4
+MU = np.array([0, 1, 1.25, 1.5, 1.75, 2, 2.25, 2.5, 2.75, 3, 3.5, 4, 4.5, 5, 5.5, 6, 7, 8, 9, 10], np.float32)
+
+
+def mfma(a, b, c):
+    """a[64], b[64], c[4][64] -> d[4][64]  (D = A.B + C, fp32)."""
+    A = np.zeros((16, 4), np.float32)
+    B = np.zeros((4, 16), np.float32)
+    A[C_, Q_] = a
+    B[Q_, C_] = b
+    D = (A.astype(np.float64) @ B.astype(np.float64)).astype(np.float32)
+    return np.stack([c[r] + D[4 * Q_ + r, C_] for r in range(4)])
+
+
+# ---- hidden-channel labelings ---------------------------------------------------------------------
+def m_edge(t, rho):
+    """'edge-major' tiles (lane column = edge): C row rho = 4q+r of tile t  <->  m = 32q + 4t + r."""
+    return 32 * (rho >> 2) + 4 * t + (rho & 3)
+
+
+def m_chan(t, c):
+    """'channel-major' tiles (lane column = channel): column c of tile t  <->  m = 8c + t."""
+    return 8 * c + t
+
+
+# ---- fragment-ordered weight tables (what cbgx_pack_weights writes, what the kernel copies to LDS) ----
+def frag_wr_edge(Wr):
+    """Wr[4 types][20 g][128 m] -> [type][t][s][lane]: A operand of the edge-major pre-activation MFMA.
+    lane (c = rho, q = kk):  Wr[type][4s + kk][m_edge(t, rho)]."""
+    out = np.zeros((4, 8, 5, 64), np.float32)
+    for t in range(8):
+        for s in range(5):
+            out[:, t, s, :] = Wr[:, 4 * s + Q_, m_edge(t, C_)]
+    return out
+
+
+def frag_wr_chan(Wr):
+    """-> [type][t][s][lane]: B operand of the channel-major MFMA. lane (c, q = kk): Wr[type][4s+kk][m_chan(t,c)]."""
+    out = np.zeros((4, 8, 5, 64), np.float32)
+    for t in range(8):
+        for s in range(5):
+            out[:, t, s, :] = Wr[:, 4 * s + Q_, m_chan(t, C_)]
+    return out
+
+
+def ln_relu(v, gamma, beta):
+    mean = v.mean(-1, keepdims=True, dtype=np.float32)
+    var = ((v - mean) ** 2).mean(-1, keepdims=True, dtype=np.float32)
+    return np.maximum((v - mean) / np.sqrt(var + np.float32(1e-5)) * gamma + beta, 0).astype(np.float32)
+
+
+class Weights:
+    """Per-attention weights in the packed (factored) form of csrc/layout.h, as numpy arrays."""
+
+    def __init__(self, sd, prefix, x2h):
+        kf, vf, qf = ("hk_func", "hv_func", "hq_func") if x2h else ("xk_func", "xv_func", "xq_func")
+        g = lambda n: sd[f"{prefix}.{n}"].numpy()
+        wk0, wv0 = g(f"{kf}.net.0.weight"), g(f"{vf}.net.0.weight")
+        self.Wt_k, self.Wt_v = wk0[:, :4].T.copy(), wv0[:, :4].T.copy()                 # [4][128]
+        self.Wr_k = wk0[:, 4:84].T.reshape(4, 20, 128).copy()                            # [type][g][m]
+        self.Wr_v = wv0[:, 4:84].T.reshape(4, 20, 128).copy()
+        self.Wd_k, self.Ws_k = wk0[:, 84:212], wk0[:, 212:340]
+        self.Wd_v, self.Ws_v = wv0[:, 84:212], wv0[:, 212:340]
+        self.b_k0, self.b_v0 = g(f"{kf}.net.0.bias"), g(f"{vf}.net.0.bias")
+        self.g_k, self.be_k = g(f"{kf}.net.1.weight"), g(f"{kf}.net.1.bias")
+        self.g_v, self.be_v = g(f"{vf}.net.1.weight"), g(f"{vf}.net.1.bias")
+        self.Wb_k = g(f"{kf}.net.3.weight")
+        self.Wb_v, self.bb_v = g(f"{vf}.net.3.weight"), g(f"{vf}.net.3.bias")
+        self.q = [g(f"{qf}.net.{i}.{w}") for i in (0, 1, 3) for w in ("weight", "bias")]
+        self.fragA_k = frag_wr_edge(self.Wr_k)
+        self.fragA_v = frag_wr_edge(self.Wr_v)
+        self.fragB_v = frag_wr_chan(self.Wr_v)
+
+    def node_tables(self, h):
+        """What the node kernels produce: P = [PDk | PDv | PSk | PSv] and the folded query Qt."""
+        PDk = h @ self.Wd_k.T + self.b_k0
+        PDv = h @ self.Wd_v.T + self.b_v0
+        PSk, PSv = h @ self.Ws_k.T, h @ self.Ws_v.T
+        w0, b0, gq, bq, w1, b1 = self.q
+        qv = ln_relu(h @ w0.T + b0, gq, bq) @ w1.T + b1                                   # [N,128]
+        Qt = np.einsum("nac,acm->nam", qv.reshape(-1, 16, 8), self.Wb_k.reshape(16, 8, 128)) / np.sqrt(8.0)
+        return (PDk.astype(np.float32), PDv.astype(np.float32), PSk.astype(np.float32), PSv.astype(np.float32),
+                Qt.astype(np.float32))
+
+
+def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
+    """One wavefront = one destination node i.  Returns h_out[i] (x2h) or delta_x[i] (h2x)."""
+    PDk, PDv, PSk, PSv, Qt = tables
+    d = int(deg[i])
+    lig_i = int(lig[i])
+    # ---- stage 0: edge geometry in the E0 mapping: lane (c, q) <-> edges e = c + 16 hf -------------------
+    e0 = [C_ + 16 * hf for hf in range(2)]
+    valid0 = [e < d for e in e0]
+    j0 = [np.where(v, nbr[i, e], i) for v, e in zip(valid0, e0)]
+    lg0 = [lig[j].astype(bool) & v for j, v in zip(j0, valid0)]
+    dist0 = [np.sqrt(((x[i] - x[j]) ** 2).sum(-1)).astype(np.float32) for j in j0]
+    # R[hf][s][lane] = rbf_{4s+q}(d_e): B operand (edge-major MFMA) and A operand (channel-major MFMA)
+    R = [[np.where(valid0[hf], np.exp(-0.5 * (dist0[hf] - MU[4 * s + Q_]) ** 2), 0).astype(np.float32)
+          for s in range(5)] for hf in range(2)]
+    mask_lig = 0
+    for hf in range(2):
+        for c in range(16):
+            if lg0[hf][c]:
+                mask_lig |= 1 << (c + 16 * hf)
+    mask_valid = (1 << d) - 1
+    passes = []
+    if (~mask_lig) & mask_valid or d == 0:
+        passes.append(False)
+    if mask_lig & mask_valid:
+        passes.append(True)
+
+    def etype(src_lig):
+        return (0 if lig_i else 1) if src_lig else (2 if lig_i else 3)
+
+    def pre_edge_major(PD, PS, Wt, frag):
+        """C[t][hf][r][lane]: lane (c = e16, q), m = 32q + 4t + r (edge-major)."""
+        Cacc = np.zeros((8, 2, 4, 64), np.float32)
+        for t in range(8):
+            for hf in range(2):
+                ty = np.where(lg0[hf], etype(True), etype(False))
+                for r in range(4):
+                    m = 32 * Q_ + 4 * t + r
+                    Cacc[t, hf, r] = PD[i, m] + PS[j0[hf], m] + Wt[ty, m]
+                for src_lig in passes:
+                    for s in range(5):
+                        Rm = np.where(lg0[hf] == src_lig, R[hf][s], 0).astype(np.float32)
+                        Cacc[t, hf] = mfma(frag[etype(src_lig), t, s], Rm, Cacc[t, hf])
+        return Cacc
+
+    def ln_edge_major(Cacc, gamma, beta):
+        out = np.zeros_like(Cacc)
+        for hf in range(2):
+            s = Cacc[:, hf].sum((0, 1))                      # in-lane over (t, r)
+            s = s + s[L ^ 16]; s = s + s[L ^ 32]             # across q
+            mean = s / 128
+            dv = Cacc[:, hf] - mean
+            v = (dv * dv).sum((0, 1))
+            v = v + v[L ^ 16]; v = v + v[L ^ 32]
+            rstd = 1.0 / np.sqrt(v / 128 + 1e-5)
+            for t in range(8):
+                for r in range(4):
+                    m = 32 * Q_ + 4 * t + r
+                    out[t, hf, r] = np.maximum(dv[t, r] * rstd * gamma[m] + beta[m], 0)
+        return out.astype(np.float32)
+
+    def contract_channels(Hd, Bsrc):
+        """C[hf][r][lane (c = a, q)] = sum_m hid[e = 4q + r + 16hf][m] * Bsrc[a][m]."""
+        out = np.zeros((2, 4, 64), np.float32)
+        for hf in range(2):
+            for t in range(8):
+                for r in range(4):
+                    out[hf] = mfma(Hd[t, hf, r], Bsrc[C_, 32 * Q_ + 4 * t + r], out[hf])
+        return out
+
+    # ---- k path (edge-major) -----------------------------------------------------------------------
+    Hk = ln_edge_major(pre_edge_major(PDk, PSk, W.Wt_k, W.fragA_k), W.g_k, W.be_k)
+    S = contract_channels(Hk, Qt[i])                           # scores: lane (a, q) reg r <-> e = 4q + r + 16hf
+    e1 = np.stack([[4 * Q_ + r + 16 * hf for r in range(4)] for hf in range(2)])   # [2][4][64]
+    valid1 = e1 < d
+    S = np.where(valid1, S, -np.inf)
+    mx = S.max((0, 1)); mx = np.maximum(mx, mx[L ^ 16]); mx = np.maximum(mx, mx[L ^ 32])
+    ex = np.where(valid1, np.exp(S - mx), 0).astype(np.float32)
+    den = ex.sum((0, 1)); den = den + den[L ^ 16]; den = den + den[L ^ 32]
+    alpha = np.where(valid1, ex / np.where(den > 0, den, 1), 0).astype(np.float32)
+    ew1 = np.where(valid1, e_w[i, np.minimum(e1, 31)], 0).astype(np.float32)
+
+    if x2h:
+        w = alpha * ew1
+        sw = w.sum((0, 1)); sw = sw + sw[L ^ 16]; sw = sw + sw[L ^ 32]           # sum_e alpha e_w, per head a = c
+        # ---- v path (channel-major): lane (c = m16, q) reg r <-> e = 4q + r + 16hf, m = 8c + t
+        j1 = np.where(valid1, nbr[i, np.minimum(e1, 31)], i)
+        lg1 = ((mask_lig >> e1) & 1).astype(bool)
+        Cv = np.zeros((8, 2, 4, 64), np.float32)
+        for t in range(8):
+            m = 8 * C_ + t
+            for hf in range(2):
+                for r in range(4):
+                    ty = np.where(lg1[hf, r], etype(True), etype(False))
+                    Cv[t, hf, r] = PDv[i, m] + PSv[j1[hf, r], m] + W.Wt_v[ty, m]
+                for src_lig in passes:
+                    for s in range(5):
+                        Rm = np.where(lg0[hf] == src_lig, R[hf][s], 0).astype(np.float32)
+                        Cv[t, hf] = mfma(Rm, W.fragB_v[etype(src_lig), t, s], Cv[t, hf])
+        # LN over m = (t, c): in-lane over t, across the 16 lanes of a row (xor 1,2,4,8)
+        Hv = np.zeros_like(Cv)
+        for hf in range(2):
+            for r in range(4):
+                s = Cv[:, hf, r].sum(0)
+                for o in (1, 2, 4, 8): s = s + s[L ^ o]
+                mean = s / 128
+                dv = Cv[:, hf, r] - mean
+                v = (dv * dv).sum(0)
+                for o in (1, 2, 4, 8): v = v + v[L ^ o]
+                rstd = 1.0 / np.sqrt(v / 128 + 1e-5)
+                for t in range(8):
+                    m = 8 * C_ + t
+                    Hv[t, hf, r] = np.maximum(dv[t] * rstd * W.g_v[m] + W.be_v[m], 0)
+        # v-agg: S2[t][r'][lane (c = m16, q)] <-> head a = 4q + r', m = 8c + t
+        S2 = np.zeros((8, 4, 64), np.float32)
+        for t in range(8):
+            for hf in range(2):
+                for r in range(4):
+                    S2[t] = mfma(w[hf, r], Hv[t, hf, r], S2[t])
+        # epilogue: out[8a+cc] = sum_m Wbv[8a+cc][m] S2[a][m] + bbv[8a+cc] * sw[a]
+        out = np.zeros(128, np.float32)
+        for lane in range(64):
+            c, q = lane & 15, lane >> 4
+            for rp in range(4):
+                a = 4 * q + rp
+                for cc in range(8):
+                    out[8 * a + cc] += sum(W.Wb_v[8 * a + cc, 8 * c + t] * S2[t, rp, lane] for t in range(8))
+        sw_head = np.array([sw[a] for a in range(16)])          # lane c = a (any q) holds sw[a]
+        out = out + W.bb_v * np.repeat(sw_head, 8)
+        return h[i] + out
+    # ---- h2x: v path edge-major as well; wv[e, a] = Wbv[a] . hid_v[e] + bbv[a] --------------------------
+    Hv = ln_edge_major(pre_edge_major(PDv, PSv, W.Wt_v, W.fragA_v), W.g_v, W.be_v)
+    WV = contract_channels(Hv, W.Wb_v) + W.bb_v[C_]
+    j1 = np.where(valid1, nbr[i, np.minimum(e1, 31)], i)
+    rel = x[i] - x[j1]                                           # [2][4][64][3]
+    coef = alpha * WV * ew1
+    dx = (coef[..., None] * rel).sum((0, 1))                     # per-lane partial [64][3]
+    return dx.sum(0) / 16.0                                      # wave reduction over heads and q

@@ -59,8 +59,17 @@ def test_knn_graph_bitexact(golden_dir, case):
     assert bool((pad == -1).all())
 
 
+@pytest.fixture(params=[0, 1], ids=["mfma", "valu"])
+def edge_impl(request):
+    """Both generations of the fused edge kernels are checked against the reference."""
+    from cbgbench_amd import _native
+    old = _native.lib().cbgx_debug_set_edge_kernel(request.param)
+    yield request.param
+    _native.lib().cbgx_debug_set_edge_kernel(old)
+
+
 @pytest.mark.parametrize("case", DENOISER_CASES)
-def test_stages_match_reference(golden_dir, model, case):
+def test_stages_match_reference(golden_dir, model, case, edge_impl):
     g = load(golden_dir, case)
     x, h, gp, lig, gen = dev_inputs(g)
     packed = model.denoiser.packed_weights(torch.device(DEV))
@@ -220,6 +229,17 @@ def test_linker_256_graphs_runs_and_freezes_context(model):
     assert torch.isfinite(xo).all() and torch.isfinite(ho).all() and torch.isfinite(lo).all()
     assert torch.equal(xo[~gen], x[~gen])
     assert bool((xo[gen] != x[gen]).any())
+    # the whole batch against the first-generation VALU kernels on the device (independent implementation)
+    from cbgbench_amd import _native
+    old = _native.lib().cbgx_debug_set_edge_kernel(1)
+    try:
+        with torch.no_grad():
+            xv, hv, lv = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
+    finally:
+        _native.lib().cbgx_debug_set_edge_kernel(old)
+    close(xo, xv, "x_out mfma vs valu kernels (256 graphs)")
+    close(ho, hv, "h_out mfma vs valu kernels (256 graphs)", scale=10.0)
+    assert torch.equal(lo[lig_flag].argmax(-1), lv[lig_flag].argmax(-1))
     # one of the 256 graphs against the oracle (the oracle on the whole batch would take minutes)
     gidx = 17
     s, e = int(gp[gidx]), int(gp[gidx + 1])

@@ -131,7 +131,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_argument_errors_without_gpu():
     lib = _native.lib()
-    assert lib.cbgx_packed_weights_floats(9, 13) == 2798356
+    assert lib.cbgx_packed_weights_floats(9, 13) >= 2666014   # at least every denoiser parameter
+    assert lib.cbgx_debug_set_edge_kernel(7) == -1
     assert lib.cbgx_workspace_bytes(425, 1) > 425 * (640 + 16 * 128) * 4
     one = ctypes.c_void_p(16)  # never dereferenced: argument checks come first
     assert lib.cbgx_knn_graph(one, one, 1, 10, 16, one, one, None) == -1
