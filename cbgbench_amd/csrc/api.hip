@@ -134,7 +134,7 @@ int cbgx_pack_weights(const float* const* t, int num_tensors, int L, int C, floa
             CP(gv, H, 0, 0, img + IMG_LN + 2 * H, H, 1, H);
             CP(bev, H, 0, 0, img + IMG_LN + 3 * H, H, 1, H);
             if (blk == 0) {
-                CP(wv1, H, 0, 0, img + IMG_WBV, H, H, H);  // row-major (n, m)
+                HIP_TRY(launch_pack_wbv_swz(wv1, img + IMG_WBV, s));  // row-major (n, m), chunk-swizzled
                 CP(wv1, H, 0, 1, a + A_WBV, H, H, H);   // [m][n]
                 CP(bv1, H, 0, 0, a + A_BBV, H, 1, H);
             } else {

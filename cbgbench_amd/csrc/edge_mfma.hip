@@ -30,8 +30,33 @@ __constant__ float c_mu[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-__device__ __forceinline__ float xor_add(float v, int m) { return v + __shfl_xor(v, m, 64); }
-__device__ __forceinline__ float xor_max(float v, int m) { return fmaxf(v, __shfl_xor(v, m, 64)); }
+// ---- cross-lane reductions without LDS traffic -----------------------------------------------------
+// within a 16-lane row: DPP quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror (every lane gets the sum)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+// across the 4 rows (q): v_permlane16_swap / v_permlane32_swap (gfx950); every lane gets the result
+__device__ __forceinline__ float xrow_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xrow_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float wave_sum(float v) { return xrow_sum(row16_sum(v)); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ floatx4 f4(float4 a) { floatx4 r = {a.x, a.y, a.z, a.w}; return r; }
 
@@ -70,7 +95,7 @@ __device__ __forceinline__ floatx4 edge_major_half(const float* __restrict__ P, 
     float sm = 0.f;
 #pragma unroll
     for (int t = 0; t < 8; ++t) sm += (acc[t].x + acc[t].y) + (acc[t].z + acc[t].w);
-    sm = xor_add(xor_add(sm, 16), 32);
+    sm = xrow_sum(sm);
     const float mean = sm * (1.f / H);
     float v = 0.f;
 #pragma unroll
@@ -78,7 +103,7 @@ __device__ __forceinline__ floatx4 edge_major_half(const float* __restrict__ P, 
         acc[t] -= mean;
         v += (acc[t].x * acc[t].x + acc[t].y * acc[t].y) + (acc[t].z * acc[t].z + acc[t].w * acc[t].w);
     }
-    v = xor_add(xor_add(v, 16), 32);
+    v = xrow_sum(v);
     const float rstd = 1.f / sqrtf(v * (1.f / H) + 1e-5f);
     // two interleaved accumulators: a dependent 16x16x4 MFMA needs 40 cycles, an independent one 32
     floatx4 out0 = {0.f, 0.f, 0.f, 0.f}, out1 = {0.f, 0.f, 0.f, 0.f};
@@ -155,8 +180,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         for (int hf = 0; hf < 2; ++hf) {
             sc[hf] = edge_major_half(P, i, j0[hf], lg0[hf], 0, 2 * H, lds_fk, lds_wt, lds_ln, lds_ln + H, R[hf], has_prot,
                                      has_lig, lig_i, lane, q, Qt + ((size_t)i * HEADS + c) * H + 32 * q);
-            __builtin_amdgcn_sched_barrier(0);
+            if (!X2H) __builtin_amdgcn_sched_barrier(0);  // h2x: keep the halves apart (register budget)
         }
+        __builtin_amdgcn_sched_barrier(0);
         // E1 mapping: lane (c = head a, q), reg (hf, r) <-> edge e = 4q + r + 16hf
         float al[2][4];
         float mx = -INFINITY;
@@ -168,7 +194,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                 al[hf][r] = valid ? sc[hf][r] : -INFINITY;
                 mx = fmaxf(mx, al[hf][r]);
             }
-        mx = xor_max(xor_max(mx, 16), 32);
+        mx = xrow_max(mx);
         float den = 0.f;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
@@ -178,7 +204,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                 al[hf][r] = valid ? expf(al[hf][r] - mx) : 0.f;
                 den += al[hf][r];
             }
-        den = xor_add(xor_add(den, 16), 32);
+        den = xrow_sum(den);
         const float inv_den = den > 0.f ? 1.f / den : 0.f;
         const float4 ew0 = ld4(e_w + (size_t)i * KNN + 4 * q), ew1 = ld4(e_w + (size_t)i * KNN + 16 + 4 * q);
         const float ew[2][4] = {{ew0.x, ew0.y, ew0.z, ew0.w}, {ew1.x, ew1.y, ew1.z, ew1.w}};
@@ -198,7 +224,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                     w[hf][r] = (al[hf][r] * inv_den) * ew[hf][r];
                     sw += w[hf][r];
                 }
-            sw = xor_add(xor_add(sw, 16), 32);   // sum_e alpha e_w for head a = c
+            sw = xrow_sum(sw);   // sum_e alpha e_w for head a = c
             __builtin_amdgcn_sched_barrier(0);
             // ---- v path, channel-major: lane (c, q) reg r <-> edge 4q + r + 16hf, channel m = 8c + t ------
             floatx4 hv[8][2];
@@ -255,19 +281,19 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                         float s = 0.f;
 #pragma unroll
                         for (int t = 0; t < 8; ++t) s += hv[t][hf][r];
-                        s = xor_add(xor_add(xor_add(xor_add(s, 1), 2), 4), 8);
+                        s = row16_sum(s);
                         const float mean = s * (1.f / H);
                         float v = 0.f;
 #pragma unroll
                         for (int t = 0; t < 8; ++t) { hv[t][hf][r] -= mean; v += hv[t][hf][r] * hv[t][hf][r]; }
-                        v = xor_add(xor_add(xor_add(xor_add(v, 1), 2), 4), 8);
+                        v = row16_sum(v);
                         const float rstd = 1.f / sqrtf(v * (1.f / H) + 1e-5f);
 #pragma unroll
                         for (int t = 0; t < 8; ++t) hv[t][hf][r] = fmaxf(hv[t][hf][r] * rstd * gv[t] + bv[t], 0.f);
                     }
             }
             __builtin_amdgcn_sched_barrier(0);
-            // v aggregation: s2[t] (lane (c, q) reg r' <-> head 4q + r', channel 8c + t)
+            // v aggregation, transposed: s2[t] = hid_v^T . w  ->  lane (c = head a, q) reg r' <-> channel 8(4q + r') + t
             floatx4 s2[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) s2[t] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -276,55 +302,37 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) s2[t] = MFMA(w[hf][r], hv[t][hf][r], s2[t]);
+                    for (int t = 0; t < 8; ++t) s2[t] = MFMA(hv[t][hf][r], w[hf][r], s2[t]);
             __builtin_amdgcn_sched_barrier(0);
-            // epilogue: out[8a + cc] = sum_m Wbv[8a + cc][m] S[a][m]; 32 partials per lane, reduce-scatter over c
-            float part[32];
+            // epilogue: out[8a + cc] = sum_m Wbv[8a + cc][m] S[a][m] + bbv[8a + cc] sum_e alpha e_w ; this lane holds
+            // S[a = c][32q .. 32q + 31]; Wbv rows live in LDS with their 16-byte chunks XOR-swizzled by the head index
+            // so the 16 lanes of a row (16 different Wbv rows, same columns) hit 16 different bank groups.
+            float o8[8];
             const float* lds_wbv = lds + IMG_WBV;
 #pragma unroll
-            for (int rp = 0; rp < 4; ++rp)
+            for (int cc = 0; cc < 8; ++cc) {
+                const float* wrow = lds_wbv + (size_t)(8 * c + cc) * H;
+                float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-                for (int cc = 0; cc < 8; ++cc) {
-                    const float* wrow = lds_wbv + (size_t)(8 * (4 * q + rp) + cc) * H + 8 * c;
-                    const float4 wa = ld4(wrow), wb = ld4(wrow + 4);
-                    float a = wa.x * s2[0][rp];
-                    a = fmaf(wa.y, s2[1][rp], a); a = fmaf(wa.z, s2[2][rp], a); a = fmaf(wa.w, s2[3][rp], a);
-                    a = fmaf(wb.x, s2[4][rp], a); a = fmaf(wb.y, s2[5][rp], a); a = fmaf(wb.z, s2[6][rp], a);
-                    a = fmaf(wb.w, s2[7][rp], a);
-                    part[rp * 8 + cc] = a;
+                for (int rp = 0; rp < 4; ++rp) {
+                    const float4 wa = ld4(wrow + (((8 * q + 2 * rp) ^ c) << 2));
+                    const float4 wb = ld4(wrow + (((8 * q + 2 * rp + 1) ^ c) << 2));
+                    a0 = fmaf(wa.x, s2[0][rp], a0); a1 = fmaf(wa.y, s2[1][rp], a1);
+                    a0 = fmaf(wa.z, s2[2][rp], a0); a1 = fmaf(wa.w, s2[3][rp], a1);
+                    a0 = fmaf(wb.x, s2[4][rp], a0); a1 = fmaf(wb.y, s2[5][rp], a1);
+                    a0 = fmaf(wb.z, s2[6][rp], a0); a1 = fmaf(wb.w, s2[7][rp], a1);
                 }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const bool up = c & 8;
-                const float keep = up ? part[16 + k] : part[k], send = up ? part[k] : part[16 + k];
-                part[k] = keep + __shfl_xor(send, 8, 64);
+                o8[cc] = xrow_sum(a0 + a1);
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const bool up = c & 4;
-                const float keep = up ? part[8 + k] : part[k], send = up ? part[k] : part[8 + k];
-                part[k] = keep + __shfl_xor(send, 4, 64);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool up = c & 2;
-                const float keep = up ? part[4 + k] : part[k], send = up ? part[k] : part[4 + k];
-                part[k] = keep + __shfl_xor(send, 2, 64);
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const bool up = c & 1;
-                const float keep = up ? part[2 + k] : part[k], send = up ? part[k] : part[2 + k];
-                part[k] = keep + __shfl_xor(send, 1, 64);
-            }
-            // lane (c, q) now owns outputs n = 32q + 2c, 32q + 2c + 1 (head a = 4q + (c >> 2))
-            const int n0 = 32 * q + 2 * c;
-            const float sw_a = __shfl(sw, 4 * q + (c >> 2), 64);
+            // lane (c, q) writes outputs n = 8c + 2q, 8c + 2q + 1
+            const float oa = q == 0 ? o8[0] : (q == 1 ? o8[2] : (q == 2 ? o8[4] : o8[6]));
+            const float ob = q == 0 ? o8[1] : (q == 1 ? o8[3] : (q == 2 ? o8[5] : o8[7]));
+            const int n0 = 8 * c + 2 * q;
             const float2 hres = *reinterpret_cast<const float2*>(h + (size_t)i * H + n0);
             const float2 bb = *reinterpret_cast<const float2*>(att + A_BBV + n0);
             float2 o;
-            o.x = hres.x + (part[0] + bb.x * sw_a);
-            o.y = hres.y + (part[1] + bb.y * sw_a);
+            o.x = hres.x + (oa + bb.x * sw);
+            o.y = hres.y + (ob + bb.y * sw);
             *reinterpret_cast<float2*>(out + (size_t)i * H + n0) = o;
         } else {
             // ---- h2x: v hidden edge-major, wv[e][a] = Wbv[a] . hid_v[e] + bbv[a] -------------------------------
@@ -351,8 +359,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                         dz = fmaf(coef, zi - x[3 * j + 2], dz);
                     }
                 }
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) { dx = xor_add(dx, m); dy = xor_add(dy, m); dz = xor_add(dz, m); }
+            dx = wave_sum(dx); dy = wave_sum(dy); dz = wave_sum(dz);
             if (lane < 3) {
                 const float v = (lane == 0 ? dx : (lane == 1 ? dy : dz)) * (1.f / HEADS);
                 const float xin = lane == 0 ? xi : (lane == 1 ? yi : zi);
@@ -371,6 +378,18 @@ __global__ void pack_frag_kernel(const float* __restrict__ w_a, int mode, float*
     const int c = lane & 15, kk = lane >> 4;
     const int m = mode == 0 ? 32 * (c >> 2) + 4 * t + (c & 3) : 8 * c + t;
     dst[idx] = w_a[(size_t)m * KV_IN + NT + G * type + 4 * s + kk];
+}
+
+__global__ void pack_wbv_swz_kernel(const float* __restrict__ w, float* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // n * 128 + m
+    if (idx >= H * H) return;
+    const int n = idx >> 7, m = idx & 127;
+    dst[n * H + ((((m >> 2) ^ ((n >> 3) & 15)) << 2) | (m & 3))] = w[idx];
+}
+
+hipError_t launch_pack_wbv_swz(const float* w, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(pack_wbv_swz_kernel, dim3(H * H / 256), dim3(256), 0, s, w, dst);
+    return hipGetLastError();
 }
 
 hipError_t launch_pack_frag(const float* w_a, int mode, float* dst, hipStream_t s) {

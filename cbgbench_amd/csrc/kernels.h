@@ -24,6 +24,8 @@ hipError_t launch_attention(bool x2h, const float* att, const float* x, const fl
 extern int g_edge_impl;
 // fragment-ordered rbf weight table: mode 0 edge-major (A operand), 1 channel-major (B operand)
 hipError_t launch_pack_frag(const float* w_a, int mode, float* dst, hipStream_t s);
+// x2h second v Linear [128 n][128 m] with 16-byte chunks XOR-swizzled by head (n >> 3)
+hipError_t launch_pack_wbv_swz(const float* w, float* dst, hipStream_t s);
 // MFMA edge kernel (edge_mfma.hip)
 hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,
                             const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,

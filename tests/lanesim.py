@@ -209,20 +209,26 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
                 for t in range(8):
                     m = 8 * C_ + t
                     Hv[t, hf, r] = np.maximum(dv[t] * rstd * W.g_v[m] + W.be_v[m], 0)
-        # v-agg: S2[t][r'][lane (c = m16, q)] <-> head a = 4q + r', m = 8c + t
+        # v-agg, transposed (hid_v as A operand, w as B): S2[t][r'][lane (c = a, q)] <-> channel m = 8(4q + r') + t
         S2 = np.zeros((8, 4, 64), np.float32)
         for t in range(8):
             for hf in range(2):
                 for r in range(4):
-                    S2[t] = mfma(w[hf, r], Hv[t, hf, r], S2[t])
-        # epilogue: out[8a+cc] = sum_m Wbv[8a+cc][m] S2[a][m] + bbv[8a+cc] * sw[a]
+                    S2[t] = mfma(Hv[t, hf, r], w[hf, r], S2[t])
+        # epilogue: lane (a, q) holds S[a][32q .. 32q+31]; Wbv image has its 16-byte chunks XOR-swizzled by the head
+        img = np.zeros(128 * 128, np.float32)
+        n_, m_ = np.meshgrid(np.arange(128), np.arange(128), indexing="ij")
+        img[n_ * 128 + ((((m_ >> 2) ^ ((n_ >> 3) & 15)) << 2) | (m_ & 3))] = W.Wb_v
         out = np.zeros(128, np.float32)
         for lane in range(64):
             c, q = lane & 15, lane >> 4
-            for rp in range(4):
-                a = 4 * q + rp
-                for cc in range(8):
-                    out[8 * a + cc] += sum(W.Wb_v[8 * a + cc, 8 * c + t] * S2[t, rp, lane] for t in range(8))
+            for cc in range(8):
+                acc = 0.0
+                for rp in range(4):
+                    for t in range(8):
+                        chunk = (8 * q + 2 * rp + (t >> 2)) ^ c
+                        acc += img[(8 * c + cc) * 128 + (chunk << 2) + (t & 3)] * S2[t, rp, lane]
+                out[8 * c + cc] += acc                                  # summed over q by xrow_sum in the kernel
         sw_head = np.array([sw[a] for a in range(16)])          # lane c = a (any q) holds sw[a]
         out = out + W.bb_v * np.repeat(sw_head, 8)
         return h[i] + out
