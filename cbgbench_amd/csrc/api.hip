@@ -35,6 +35,7 @@ struct Workspace {
     float* e_w;
     float* P;
     float* Qt;
+    float* q;
     float* hbuf[2];
     float* xbuf[2];
     size_t total;
@@ -51,6 +52,7 @@ static Workspace carve(void* base, int n) {
     w.e_w = (float*)take(N * KNN * 4);
     w.P = (float*)take(N * PROW * 4);
     w.Qt = (float*)take(N * HEADS * H * 4);
+    w.q = (float*)take(N * H * 4);
     w.hbuf[0] = (float*)take(N * H * 4);
     w.hbuf[1] = (float*)take(N * H * 4);
     w.xbuf[0] = (float*)take(N * 3 * 4);
@@ -123,6 +125,7 @@ int cbgx_pack_weights(const float* const* t, int num_tensors, int L, int C, floa
             CP(wq1, H, 0, 1, a + A_WQ1T, H, H, H);
             CP(bq1, H, 0, 0, a + A_BQ1, H, 1, H);
             CP(wk1, H, 0, 0, a + A_WBK, H, H, H);
+            HIP_TRY(launch_pack_node_frags(wk0, wv0, wq0, wq1, wk1, a, s));
             // LDS image of the MFMA edge kernel
             float* img = a + A_IMG;
             HIP_TRY(launch_pack_frag(wk0, 0, img + IMG_FRAG_K, s));
@@ -186,7 +189,7 @@ int cbgx_x2h_attention(const float* packed, int layer, const float* x, const flo
     if (workspace_bytes < w.total)
         return fail(CBGX_E_WORKSPACE, "x2h_attention: workspace %zu < %zu", workspace_bytes, w.total);
     HIP_TRY(launch_attention(true, packed + x2h_off(layer), x, h, nbr, deg, lig_flag, nullptr, e_w, n_nodes, w.P,
-                             w.Qt, h_out, nullptr, (hipStream_t)stream));
+                             w.Qt, w.q, h_out, nullptr, (hipStream_t)stream));
     return CBGX_OK;
 }
 
@@ -202,7 +205,7 @@ int cbgx_h2x_attention(const float* packed, int layer, const float* x, const flo
     if (workspace_bytes < w.total)
         return fail(CBGX_E_WORKSPACE, "h2x_attention: workspace %zu < %zu", workspace_bytes, w.total);
     HIP_TRY(launch_attention(false, packed + h2x_off(layer), x, h, nbr, deg, lig_flag, gen_flag, e_w, n_nodes, w.P,
-                             w.Qt, x_out, delta_x, (hipStream_t)stream));
+                             w.Qt, w.q, x_out, delta_x, (hipStream_t)stream));
     return CBGX_OK;
 }
 
@@ -242,9 +245,9 @@ int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_cla
         float* hn = (l == num_layers - 1) ? h_out : w.hbuf[l & 1];
         float* xn = (l == num_layers - 1) ? x_out : w.xbuf[l & 1];
         HIP_TRY(launch_attention(true, packed + x2h_off(l), xc, hc, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
-                                 w.P, w.Qt, hn, nullptr, s));
+                                 w.P, w.Qt, w.q, hn, nullptr, s));
         HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
-                                 w.P, w.Qt, xn, nullptr, s));
+                                 w.P, w.Qt, w.q, xn, nullptr, s));
         xc = xn;
         hc = hn;
     }

@@ -469,16 +469,19 @@ hipError_t launch_node_gemm(const float* A, int lda, const float* Wt, const floa
 
 hipError_t launch_attention(bool x2h, const float* att, const float* x, const float* h, const int32_t* nbr,
                             const int32_t* deg, const uint8_t* lig, const uint8_t* gen, const float* e_w, int n_nodes,
-                            float* P, float* Qt, float* out, float* dx_out, hipStream_t s) {
+                            float* P, float* Qt, float* qbuf, float* out, float* dx_out, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
+    if (g_edge_impl == 0) {
+        hipError_t e0 = launch_node_mfma(att, h, n_nodes, P, qbuf, Qt, s);
+        if (e0 != hipSuccess) return e0;
+        return launch_edge_mfma(x2h, att, x, h, P, Qt, nbr, deg, lig, gen, e_w, n_nodes, out, dx_out, s);
+    }
     hipError_t e = launch_node_gemm(h, H, att + A_WN, att + A_BN, P, PROW, n_nodes, PROW, 0, s);
     if (e != hipSuccess) return e;
     profile_mark_begin(K_NODE_QUERY, s);
     hipLaunchKernelGGL(node_query_kernel, dim3((n_nodes + 15) / 16), dim3(256), 0, s, att, P, Qt, n_nodes);
     profile_mark_end(s);
     CBGX_LAUNCH_CHECK();
-    if (g_edge_impl == 0)
-        return launch_edge_mfma(x2h, att, x, h, P, Qt, nbr, deg, lig, gen, e_w, n_nodes, out, dx_out, s);
     profile_mark_begin(x2h ? K_EDGE_X2H : K_EDGE_H2X, s);
     if (x2h)
         hipLaunchKernelGGL(edge_attention_kernel<true>, dim3(n_nodes), dim3(128), 0, s, att, x, h, P, Qt, nbr, deg,

@@ -55,7 +55,11 @@ constexpr size_t IMG_LN = IMG_WT + NT * 2 * H;
 constexpr size_t IMG_WBV = IMG_LN + 4 * H;
 constexpr size_t IMG_SIZE_H2X = IMG_WBV;                 // 22016 floats
 constexpr size_t IMG_SIZE_X2H = IMG_WBV + (size_t)H * H; // 38400 floats = 153600 B
-constexpr size_t ATT_SIZE = A_IMG + IMG_SIZE_X2H;
+// fragment-ordered tables of the MFMA node kernels (node_mfma.hip)
+constexpr size_t A_NPROJ_FRAG = A_IMG + IMG_SIZE_X2H;              // [10 ch][4 ct][8 s4][64 lanes][4]
+constexpr size_t A_WQ1_FRAG = A_NPROJ_FRAG + (size_t)H * PROW;     // [8 nt][8 s4][64][4]
+constexpr size_t A_WBK_FRAG = A_WQ1_FRAG + (size_t)H * H;          // [16 a][2 g][64][8], pre-scaled by 1/sqrt(8)
+constexpr size_t ATT_SIZE = A_WBK_FRAG + (size_t)H * H;
 
 constexpr size_t LAYER_SIZE = 2 * ATT_SIZE;       // x2h then h2x
 

@@ -1,0 +1,291 @@
+// libcbgx -- node-level GEMMs of one attention block on the gfx950 matrix cores (exact fp32 MFMA).
+//
+//   node_proj :  P[N,640]   = h[N,128] @ Wn + bn          (PDk | PDv | PSk | PSv | q-hidden), LDS-staged Wn chunks
+//   node_qmlp :  q[N,128]   = ReLU(LN(P[:,512:640])) @ Wq1^T + bq1
+//   node_qfold:  Qt[N,16,128] = (1/sqrt 8) * q[N, 8a:8a+8] @ Wbk[8a:8a+8, :]      (key's 2nd Linear folded into q)
+//
+// Common shape: one wavefront owns 16 rows (nodes); its A operand is read straight from global memory in
+// MFMA A layout using a K permutation (lane (c = row, q) holds k = 32q + s for step s, i.e. 128 contiguous
+// bytes of its row), the B operand comes from LDS in "fragment order" (written by cbgx_pack_weights so the
+// global->LDS copy is linear and every ds_read_b128 is conflict-free), and output tiles use a column
+// permutation (tile j of a group of four <-> column 4c + j) so each lane stores float4s.
+// MFMA 16x16x4 maps: A[i=c][k=q], B[k=q][j=c], C reg r: [row 4q+r][col c];  lane l: c = l & 15, q = l >> 4.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "layout.h"
+
+namespace cbgx {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float4 nld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__device__ __forceinline__ float nxrow_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// node_proj: 4 waves x 16 rows per workgroup; 10 column chunks of 64; chunk fragments double-buffered in LDS.
+// fragment order of a chunk: [ct 4][s4 8][lane 64][4]  = Wn[k = 32q + 4 s4 + j][col = 64 ch + 4c + ct]
+// ------------------------------------------------------------------------------------------------
+constexpr int NP_CHUNK = 4 * 8 * 64 * 4;  // 8192 floats = 32 KB
+constexpr int NP_CHUNKS = PROW / 64;      // 10
+
+__global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict__ att, const float* __restrict__ h,
+                                                        float* __restrict__ P, int n_nodes) {
+    __shared__ __attribute__((aligned(16))) float lds[2][NP_CHUNK];
+    const float* frag = att + A_NPROJ_FRAG;
+    const float* bias = att + A_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
+    const int n_tiles = (n_nodes + 63) / 64;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row0 = tile * 64 + wave * 16;
+        const int arow = min(row0 + c, n_nodes - 1);
+        float a[32];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 v = nld4(h + (size_t)arow * H + 32 * q + 4 * u);
+            a[4 * u] = v.x; a[4 * u + 1] = v.y; a[4 * u + 2] = v.z; a[4 * u + 3] = v.w;
+        }
+        __syncthreads();  // previous tile's readers of lds[0] are done
+        {
+            const float4* src = reinterpret_cast<const float4*>(frag);
+            float4* dst = reinterpret_cast<float4*>(lds[0]);
+#pragma unroll
+            for (int u = 0; u < NP_CHUNK / 4 / 256; ++u) dst[tid + 256 * u] = src[tid + 256 * u];
+        }
+        __syncthreads();
+        for (int ch = 0; ch < NP_CHUNKS; ++ch) {
+            float4 stage[NP_CHUNK / 4 / 256];
+            if (ch + 1 < NP_CHUNKS) {
+                const float4* src = reinterpret_cast<const float4*>(frag + (size_t)(ch + 1) * NP_CHUNK);
+#pragma unroll
+                for (int u = 0; u < NP_CHUNK / 4 / 256; ++u) stage[u] = src[tid + 256 * u];
+            }
+            const float* B = lds[ch & 1];
+            const float4 b4 = nld4(bias + 64 * ch + 4 * c);
+            floatx4 acc[4] = {{b4.x, b4.x, b4.x, b4.x}, {b4.y, b4.y, b4.y, b4.y}, {b4.z, b4.z, b4.z, b4.z},
+                              {b4.w, b4.w, b4.w, b4.w}};
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {
+                float4 bf[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) bf[ct] = nld4(B + ((ct * 8 + s4) * 64 + lane) * 4);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA(a[4 * s4 + 0], bf[ct].x, acc[ct]);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA(a[4 * s4 + 1], bf[ct].y, acc[ct]);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA(a[4 * s4 + 2], bf[ct].z, acc[ct]);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA(a[4 * s4 + 3], bf[ct].w, acc[ct]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * q + r;
+                if (row < n_nodes) {
+                    float4 o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                    *reinterpret_cast<float4*>(P + (size_t)row * PROW + 64 * ch + 4 * c) = o;
+                }
+            }
+            if (ch + 1 < NP_CHUNKS) {
+                float4* dst = reinterpret_cast<float4*>(lds[(ch + 1) & 1]);
+#pragma unroll
+                for (int u = 0; u < NP_CHUNK / 4 / 256; ++u) dst[tid + 256 * u] = stage[u];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// node_qmlp: LayerNorm + ReLU on the q-hidden quarter of P (A layout: LN is in-lane + across q), then
+// q = z @ Wq1^T + bq1.  Wq1 fragments [nt 8][s4 8][lane][4] = Wq1[n = 64(nt>>2) + 4c + (nt&3)][k = 32q + 4 s4 + j].
+// ------------------------------------------------------------------------------------------------
+constexpr int NQ_FRAG = 8 * 8 * 64 * 4;  // 16384 floats = 64 KB
+
+__global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict__ att, const float* __restrict__ P,
+                                                        float* __restrict__ qout, int n_nodes) {
+    __shared__ __attribute__((aligned(16))) float lds[NQ_FRAG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
+    {
+        const float4* src = reinterpret_cast<const float4*>(att + A_WQ1_FRAG);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int t = tid; t < NQ_FRAG / 4; t += 256) dst[t] = src[t];
+    }
+    __syncthreads();
+    const int n_tiles = (n_nodes + 63) / 64;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row0 = tile * 64 + wave * 16;
+        const int arow = min(row0 + c, n_nodes - 1);
+        float z[32];
+        float sm = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 v = nld4(P + (size_t)arow * PROW + 4 * H + 32 * q + 4 * u);
+            z[4 * u] = v.x; z[4 * u + 1] = v.y; z[4 * u + 2] = v.z; z[4 * u + 3] = v.w;
+            sm += (v.x + v.y) + (v.z + v.w);
+        }
+        const float mean = nxrow_sum(sm) * (1.f / H);
+        float var = 0.f;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { z[u] -= mean; var += z[u] * z[u]; }
+        const float rstd = 1.f / sqrtf(nxrow_sum(var) * (1.f / H) + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 g = nld4(att + A_LNQ_G + 32 * q + 4 * u), b = nld4(att + A_LNQ_B + 32 * q + 4 * u);
+            z[4 * u + 0] = fmaxf(z[4 * u + 0] * rstd * g.x + b.x, 0.f);
+            z[4 * u + 1] = fmaxf(z[4 * u + 1] * rstd * g.y + b.y, 0.f);
+            z[4 * u + 2] = fmaxf(z[4 * u + 2] * rstd * g.z + b.z, 0.f);
+            z[4 * u + 3] = fmaxf(z[4 * u + 3] * rstd * g.w + b.w, 0.f);
+        }
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+            const float4 b4 = nld4(att + A_BQ1 + 64 * grp + 4 * c);
+            floatx4 acc[4] = {{b4.x, b4.x, b4.x, b4.x}, {b4.y, b4.y, b4.y, b4.y}, {b4.z, b4.z, b4.z, b4.z},
+                              {b4.w, b4.w, b4.w, b4.w}};
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {
+                float4 bf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = nld4(lds + (((grp * 4 + j) * 8 + s4) * 64 + lane) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = MFMA(z[4 * s4 + 0], bf[j].x, acc[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = MFMA(z[4 * s4 + 1], bf[j].y, acc[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = MFMA(z[4 * s4 + 2], bf[j].z, acc[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = MFMA(z[4 * s4 + 3], bf[j].w, acc[j]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * q + r;
+                if (row < n_nodes) {
+                    float4 o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                    *reinterpret_cast<float4*>(qout + (size_t)row * H + 64 * grp + 4 * c) = o;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// node_qfold: Qt[row][a][m] = sum_cc q[row][8a+cc] * Wbk[8a+cc][m] / sqrt(8).  K = 8 per head = 2 MFMA steps with
+// cc = 2 kk + step.  Wbk fragments [a 16][g 2][lane][8: j*2+step] = Wbk[8a + 2q + step][64g + 4c + j] / sqrt(8).
+// ------------------------------------------------------------------------------------------------
+constexpr int NF_FRAG = 16 * 2 * 64 * 8;  // 16384 floats = 64 KB
+
+__global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict__ att, const float* __restrict__ qin,
+                                                         float* __restrict__ Qt, int n_nodes) {
+    __shared__ __attribute__((aligned(16))) float lds[NF_FRAG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
+    {
+        const float4* src = reinterpret_cast<const float4*>(att + A_WBK_FRAG);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int t = tid; t < NF_FRAG / 4; t += 256) dst[t] = src[t];
+    }
+    __syncthreads();
+    const int n_tiles = (n_nodes + 63) / 64;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row0 = tile * 64 + wave * 16;
+        const int arow = min(row0 + c, n_nodes - 1);
+        float2 qa[HEADS];
+#pragma unroll
+        for (int a = 0; a < HEADS; ++a) qa[a] = *reinterpret_cast<const float2*>(qin + (size_t)arow * H + 8 * a + 2 * q);
+#pragma unroll
+        for (int a = 0; a < HEADS; ++a) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float* fb = lds + ((a * 2 + g) * 64 + lane) * 8;
+                const float4 b0 = nld4(fb), b1 = nld4(fb + 4);
+                floatx4 acc[4];
+                const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+                acc[0] = MFMA(qa[a].x, b0.x, zero); acc[1] = MFMA(qa[a].x, b0.z, zero);
+                acc[2] = MFMA(qa[a].x, b1.x, zero); acc[3] = MFMA(qa[a].x, b1.z, zero);
+                acc[0] = MFMA(qa[a].y, b0.y, acc[0]); acc[1] = MFMA(qa[a].y, b0.w, acc[1]);
+                acc[2] = MFMA(qa[a].y, b1.y, acc[2]); acc[3] = MFMA(qa[a].y, b1.w, acc[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + 4 * q + r;
+                    if (row < n_nodes) {
+                        float4 o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                        *reinterpret_cast<float4*>(Qt + ((size_t)row * HEADS + a) * H + 64 * g + 4 * c) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fragment packing (from reference-layout tensors)
+// ------------------------------------------------------------------------------------------------
+// node projection: dst[ch][ct][s4][lane][j] = Wcat[col = 64ch + 4c + ct][k = 32q + 4 s4 + j]; Wcat rows are assembled
+// from W_a_k / W_a_v (dst and src thirds) and W_q0, exactly like the K-major A_WN table.
+__global__ void pack_nproj_kernel(const float* __restrict__ wk0, const float* __restrict__ wv0,
+                                  const float* __restrict__ wq0, float* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NP_CHUNKS * NP_CHUNK) return;
+    const int j = idx & 3, lane = (idx >> 2) & 63, s4 = (idx >> 8) & 7, ct = (idx >> 11) & 3, ch = idx >> 13;
+    const int c = lane & 15, q = lane >> 4;
+    const int col = 64 * ch + 4 * c + ct, k = 32 * q + 4 * s4 + j;
+    const int blk = col >> 7, n = col & 127;
+    float v;
+    if (blk == 0) v = wk0[(size_t)n * KV_IN + NT + NT * G + k];            // PDk
+    else if (blk == 1) v = wv0[(size_t)n * KV_IN + NT + NT * G + k];       // PDv
+    else if (blk == 2) v = wk0[(size_t)n * KV_IN + NT + NT * G + H + k];   // PSk
+    else if (blk == 3) v = wv0[(size_t)n * KV_IN + NT + NT * G + H + k];   // PSv
+    else v = wq0[(size_t)n * H + k];                                       // q hidden
+    dst[idx] = v;
+}
+
+__global__ void pack_wq1_kernel(const float* __restrict__ wq1, float* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // [nt][s4][lane][j]
+    if (idx >= NQ_FRAG) return;
+    const int j = idx & 3, lane = (idx >> 2) & 63, s4 = (idx >> 8) & 7, nt = idx >> 11;
+    const int c = lane & 15, q = lane >> 4;
+    dst[idx] = wq1[(size_t)(64 * (nt >> 2) + 4 * c + (nt & 3)) * H + 32 * q + 4 * s4 + j];
+}
+
+__global__ void pack_wbk_kernel(const float* __restrict__ wbk, float* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // [a][g][lane][j*2+step]
+    if (idx >= NF_FRAG) return;
+    const int step = idx & 1, j = (idx >> 1) & 3, lane = (idx >> 3) & 63, g = (idx >> 9) & 1, a = idx >> 10;
+    const int c = lane & 15, q = lane >> 4;
+    dst[idx] = wbk[(size_t)(8 * a + 2 * q + step) * H + 64 * g + 4 * c + j] * 0.35355339059327376220f;
+}
+
+hipError_t launch_pack_node_frags(const float* wk0, const float* wv0, const float* wq0, const float* wq1,
+                                  const float* wbk, float* att, hipStream_t s) {
+    hipLaunchKernelGGL(pack_nproj_kernel, dim3(NP_CHUNKS * NP_CHUNK / 256), dim3(256), 0, s, wk0, wv0, wq0,
+                       att + A_NPROJ_FRAG);
+    hipLaunchKernelGGL(pack_wq1_kernel, dim3(NQ_FRAG / 256), dim3(256), 0, s, wq1, att + A_WQ1_FRAG);
+    hipLaunchKernelGGL(pack_wbk_kernel, dim3(NF_FRAG / 256), dim3(256), 0, s, wbk, att + A_WBK_FRAG);
+    return hipGetLastError();
+}
+
+// node stage of one attention block: P, q (scratch), Qt
+hipError_t launch_node_mfma(const float* att, const float* h, int n_nodes, float* P, float* qbuf, float* Qt,
+                            hipStream_t s) {
+    if (n_nodes == 0) return hipSuccess;
+    const int tiles = (n_nodes + 63) / 64;
+    profile_mark_begin(K_NODE_GEMM, s);
+    hipLaunchKernelGGL(node_proj_kernel, dim3(min(tiles, 512)), dim3(256), 0, s, att, h, P, n_nodes);
+    profile_mark_end(s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    profile_mark_begin(K_NODE_QUERY, s);
+    hipLaunchKernelGGL(node_qmlp_kernel, dim3(min(tiles, 512)), dim3(256), 0, s, att, P, qbuf, n_nodes);
+    hipLaunchKernelGGL(node_qfold_kernel, dim3(min(tiles, 512)), dim3(256), 0, s, att, qbuf, Qt, n_nodes);
+    profile_mark_end(s);
+    return hipGetLastError();
+}
+
+}  // namespace cbgx
