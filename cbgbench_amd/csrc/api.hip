@@ -125,13 +125,17 @@ int cbgx_pack_weights(const float* const* t, int num_tensors, int L, int C, floa
             CP(wq1, H, 0, 1, a + A_WQ1T, H, H, H);
             CP(bq1, H, 0, 0, a + A_BQ1, H, 1, H);
             CP(wk1, H, 0, 0, a + A_WBK, H, H, H);
-            HIP_TRY(launch_pack_node_frags(wk0, wv0, wq0, wq1, wk1, a, s));
+            // centred copies of the first k / v Linears: every MFMA-path table below is built from them
+            HIP_TRY(launch_center_linear(wk0, bk0, KV_IN, a + A_WAKC, a + A_BAKC, s));
+            HIP_TRY(launch_center_linear(wv0, bv0, KV_IN, a + A_WAVC, a + A_BAVC, s));
+            const float *wkc = a + A_WAKC, *wvc = a + A_WAVC;
+            HIP_TRY(launch_pack_node_frags(wkc, wvc, wq0, wq1, wk1, a, s));
+            HIP_TRY(launch_pack_bn2(a, bq0, a, s));
             // LDS image of the MFMA edge kernel
             float* img = a + A_IMG;
-            HIP_TRY(launch_pack_frag(wk0, 0, img + IMG_FRAG_K, s));
-            HIP_TRY(launch_pack_frag(wv0, blk == 0 ? 1 : 0, img + IMG_FRAG_V, s));
-            CP(wk0, KV_IN, 0, 1, img + IMG_WT, 2 * H, NT, H);
-            CP(wv0, KV_IN, 0, 1, img + IMG_WT + H, 2 * H, NT, H);
+            HIP_TRY(launch_pack_frag(wkc, 0, img + IMG_FRAG_K, s));
+            HIP_TRY(launch_pack_frag(wvc, blk == 0 ? 1 : 0, img + IMG_FRAG_V, s));
+            HIP_TRY(launch_pack_dwt(wkc, wvc, img + IMG_WT, s));
             CP(gk, H, 0, 0, img + IMG_LN + 0 * H, H, 1, H);
             CP(bek, H, 0, 0, img + IMG_LN + 1 * H, H, 1, H);
             CP(gv, H, 0, 0, img + IMG_LN + 2 * H, H, 1, H);

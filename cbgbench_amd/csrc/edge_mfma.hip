@@ -1,22 +1,29 @@
 // libcbgx -- fused x2h / h2x edge kernels on the gfx950 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).
 //
-// One wavefront owns one destination node i and its <= 32 incoming edges; a persistent workgroup keeps the
-// layer's rbf weight fragments (and, for x2h, the second v Linear) in LDS and loops over nodes.  Per node:
+// One wavefront owns one destination node i and its <= 32 incoming edges; a persistent 16-wave workgroup
+// keeps the layer's rbf weight fragments (and, for x2h, the second v Linear) in LDS and loops over nodes.
 //
-//   pre[e][m] = PD[i][m] + PS[j_e][m] + Wt[type_e][m] + sum_g Wr[type_e][g][m] rbf_g(|x_i - x_j|)   (k and v)
+//   pre[e][m] = PD[i][m] + PS[j_e][m] + dWt[e][m] + sum_g Wr[type_e][g][m] rbf_g(|x_i - x_j|)     (k and v)
 //   hid       = ReLU(LayerNorm(pre))
 //   score[e][a] = Qt[i][a] . hid_k[e]          (the key's 2nd Linear and 1/sqrt(8) are folded into Qt)
 //   alpha     = softmax over the node's incoming edges, per head
 //   x2h:  S[a] = sum_e alpha e_w hid_v[e]  ->  h_out = h + Wbv_a S[a] + bbv * sum_e alpha e_w
 //   h2x:  wv[e][a] = Wbv[a] . hid_v[e] + bbv[a]  ->  dx = 1/16 sum_a sum_e alpha wv e_w (x_i - x_j)
 //
-// All four contractions are MFMAs and every accumulator is consumed in the layout it was produced in
-// (no LDS transposes): tests/lanesim.py is the lane-by-lane model of this file and is checked against the
-// reference on the CPU (tests/test_lanesim.py).  Lane l: c = l & 15, q = l >> 4.
+// Pack-time algebra that removes VALU work here (cbgx_pack_weights, node_mfma.hip):
+//   * the first Linear is centred over its 128 output channels (W - colmean(W), b - mean(b)), so pre[e][:]
+//     has zero mean by construction and LayerNorm only needs sum(pre^2);
+//   * PD already contains the bias and the type column of a protein source, Wt[type(src prot, dst i)];
+//     only ligand-source edges add dWt = Wt[type(src lig, dst i)] - Wt[type(src prot, dst i)].
+//
+// All contractions are MFMAs and every accumulator is consumed in the layout it was produced in (no LDS
+// transposes, no atomics -> deterministic).  tests/lanesim.py is the lane-by-lane model of this file and is
+// checked against the reference on the CPU (tests/test_lanesim.py).  Lane l: c = l & 15, q = l >> 4.
 //   edge-major tile    (k; h2x v):  lane column = edge e16, C row 4q+r  <->  channel m = 32q + 4t + r
 //   channel-major tile (x2h v):     lane column = channel, m = 8c + t;   C row 4q+r <-> edge e = 4q + r + 16hf
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 #include "layout.h"
@@ -65,19 +72,23 @@ __device__ __forceinline__ int etype(bool src_lig, int lig_i) { return src_lig ?
 
 // ---- edge-major path for one half (16 edges): pre-activation -> LayerNorm -> ReLU -> contraction with a
 // per-lane row of B (Qt[i][a] for scores, Wbv[a] for the h2x values).  Returns the 16x16 result tile:
-// lane (c = a, q), reg r <-> edge 4q + r + 16hf.  One half at a time keeps 32 accumulator registers live.
-__device__ __forceinline__ floatx4 edge_major_half(const float* __restrict__ P, int i, int j, bool lg, int pd_off,
-                                                   int ps_off, const float* lds_frag, const float* lds_wt,
-                                                   const float* lds_g, const float* lds_b, const float (&R)[5],
-                                                   bool has_prot, bool has_lig, int lig_i, int lane, int q,
-                                                   const float* __restrict__ Brow /* &B[c][32q] */) {
+// lane (c = a, q), reg r <-> edge 4q + r + 16hf.  `kv` selects the k (0) or v (1) quarter everywhere.
+__device__ __forceinline__ floatx4 edge_major_half(const float* __restrict__ P, int i, int j, bool lg, int kv,
+                                                   const float* lds_frag, const float* lds_dwt, const float* lds_ln,
+                                                   const float (&R)[5], bool has_prot, bool has_lig, int lig_i,
+                                                   int lane, int q, const float* __restrict__ Brow) {
     floatx4 acc[8];
     {
-        const float* pd = P + (size_t)i * PROW + pd_off + 32 * q;
-        const float* ps = P + (size_t)j * PROW + ps_off + 32 * q;
-        const float* wt = lds_wt + etype(lg, lig_i) * 2 * H + 32 * q;
+        const float* pd = P + (size_t)i * PROW + kv * H + 32 * q;
+        const float* ps = P + (size_t)j * PROW + (2 + kv) * H + 32 * q;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = f4(ld4(pd + 4 * t)) + f4(ld4(ps + 4 * t)) + f4(ld4(wt + 4 * t));
+        for (int t = 0; t < 8; ++t) acc[t] = f4(ld4(pd + 4 * t)) + f4(ld4(ps + 4 * t));
+        if (has_lig) {  // wave-uniform: only nodes with a ligand neighbour pay for the type correction
+            const float* dw = lds_dwt + lig_i * 2 * H + kv * H + 32 * q;
+            const float m = lg ? 1.f : 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] += f4(ld4(dw + 4 * t)) * m;
+        }
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -91,26 +102,22 @@ __device__ __forceinline__ floatx4 edge_major_half(const float* __restrict__ P, 
 #pragma unroll
             for (int t = 0; t < 8; ++t) acc[t] = MFMA(fa[(t * 5 + s) * 64], Rm[s], acc[t]);
     }
-    // LayerNorm over the 128 channels of each edge: 32 in-lane values x 4 lanes (q), then affine + ReLU
-    float sm = 0.f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) sm += (acc[t].x + acc[t].y) + (acc[t].z + acc[t].w);
-    sm = xrow_sum(sm);
-    const float mean = sm * (1.f / H);
+    __builtin_amdgcn_sched_barrier(0);  // keep the tail's operand loads (g, b, B row) below the MFMA block
+    // LayerNorm: the first Linear is centred, so mean(pre) == 0 and var = mean(pre^2)
     float v = 0.f;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        acc[t] -= mean;
+    for (int t = 0; t < 8; ++t)
         v += (acc[t].x * acc[t].x + acc[t].y * acc[t].y) + (acc[t].z * acc[t].z + acc[t].w * acc[t].w);
-    }
     v = xrow_sum(v);
     const float rstd = 1.f / sqrtf(v * (1.f / H) + 1e-5f);
+    const float* lg_ = lds_ln + (2 * kv) * H + 32 * q;
+    const float* lb_ = lds_ln + (2 * kv + 1) * H + 32 * q;
     // two interleaved accumulators: a dependent 16x16x4 MFMA needs 40 cycles, an independent one 32
     floatx4 out0 = {0.f, 0.f, 0.f, 0.f}, out1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const floatx4 g = f4(ld4(lds_g + 32 * q + 4 * t)), b = f4(ld4(lds_b + 32 * q + 4 * t));
-        const floatx4 y = acc[t] * rstd * g + b;
+        const floatx4 g = f4(ld4(lg_ + 4 * t)), b = f4(ld4(lb_ + 4 * t));
+        const floatx4 y = (acc[t] * rstd) * g + b;
         const float4 bb = ld4(Brow + 4 * t);
         out0 = MFMA(fmaxf(y.x, 0.f), bb.x, out0);
         out1 = MFMA(fmaxf(y.y, 0.f), bb.y, out1);
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     __syncthreads();
     const float* lds_fk = lds + IMG_FRAG_K;
     const float* lds_fv = lds + IMG_FRAG_V;
-    const float* lds_wt = lds + IMG_WT;
+    const float* lds_dwt = lds + IMG_WT;
     const float* lds_ln = lds + IMG_LN;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -145,7 +152,22 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
     for (int s = 0; s < 5; ++s) mu[s] = c_mu[4 * s + q];
 
-    for (int i = blockIdx.x * WAVES + wave; i < n_nodes; i += gridDim.x * WAVES) {
+    // XCD-aware persistent schedule: workgroup b runs on XCD b % 8 (observed dispatch order), so give every
+    // XCD one contiguous eighth of the node range: a graph's PS / Qt rows are then pulled into one L2 only.
+    int i_begin, i_end, i_step;
+    if ((gridDim.x & 7) == 0) {
+        const int per_xcd = (((n_nodes + 7) >> 3) + WAVES - 1) / WAVES * WAVES;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        i_begin = xcd * per_xcd + slot * WAVES + wave;
+        i_end = min(n_nodes, (xcd + 1) * per_xcd);
+        i_step = (gridDim.x >> 3) * WAVES;
+    } else {
+        i_begin = blockIdx.x * WAVES + wave;
+        i_end = n_nodes;
+        i_step = gridDim.x * WAVES;
+    }
+
+    for (int i = i_begin; i < i_end; i += i_step) {
         const int d = deg[i];
         const int lig_i = lig[i];
         const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
@@ -178,11 +200,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         floatx4 sc[2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            sc[hf] = edge_major_half(P, i, j0[hf], lg0[hf], 0, 2 * H, lds_fk, lds_wt, lds_ln, lds_ln + H, R[hf], has_prot,
-                                     has_lig, lig_i, lane, q, Qt + ((size_t)i * HEADS + c) * H + 32 * q);
-            if (!X2H) __builtin_amdgcn_sched_barrier(0);  // h2x: keep the halves apart (register budget)
+            sc[hf] = edge_major_half(P, i, j0[hf], lg0[hf], 0, lds_fk, lds_dwt, lds_ln, R[hf], has_prot, has_lig, lig_i,
+                                     lane, q, Qt + ((size_t)i * HEADS + c) * H + 32 * q);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         // E1 mapping: lane (c = head a, q), reg (hf, r) <-> edge e = 4q + r + 16hf
         float al[2][4];
         float mx = -INFINITY;
@@ -212,6 +233,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         const int4 nb0 = *reinterpret_cast<const int4*>(nbr + (size_t)i * KNN + 4 * q);
         const int4 nb1 = *reinterpret_cast<const int4*>(nbr + (size_t)i * KNN + 16 + 4 * q);
         const int nb[2][4] = {{nb0.x, nb0.y, nb0.z, nb0.w}, {nb1.x, nb1.y, nb1.z, nb1.w}};
+        __builtin_amdgcn_sched_barrier(0);
 
         if (X2H) {
             float w[2][4];
@@ -225,85 +247,69 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                     sw += w[hf][r];
                 }
             sw = xrow_sum(sw);   // sum_e alpha e_w for head a = c
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- v path, channel-major: lane (c, q) reg r <-> edge 4q + r + 16hf, channel m = 8c + t ------
-            floatx4 hv[8][2];
-            {
-                const float4 pa = ld4(P + (size_t)i * PROW + H + 8 * c), pb = ld4(P + (size_t)i * PROW + H + 8 * c + 4);
-                const float pdv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-                const float* wtp = lds_wt + etype(false, lig_i) * 2 * H + H + 8 * c;
-                const float* wtl = lds_wt + etype(true, lig_i) * 2 * H + H + 8 * c;
-                const float4 wpa = ld4(wtp), wpb = ld4(wtp + 4), wla = ld4(wtl), wlb = ld4(wtl + 4);
-                const float wP[8] = {wpa.x, wpa.y, wpa.z, wpa.w, wpb.x, wpb.y, wpb.z, wpb.w};
-                const float wL[8] = {wla.x, wla.y, wla.z, wla.w, wlb.x, wlb.y, wlb.z, wlb.w};
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int e = 4 * q + r + 16 * hf;
-                        const int j = e < d ? nb[hf][r] : i;
-                        const bool sl = (mask_lig >> e) & 1u;
-                        const float* ps = P + (size_t)j * PROW + 3 * H + 8 * c;
-                        const float4 sa = ld4(ps), sb = ld4(ps + 4);
-                        const float sv[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) hv[t][hf][r] = pdv[t] + sv[t] + (sl ? wL[t] : wP[t]);
-                    }
-            }
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                if (p == 0 ? !has_prot : !has_lig) continue;
-                const float* fb = lds_fv + (size_t)etype(p == 1, lig_i) * (8 * 5 * 64) + lane;
-                float Rm[2][5];
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                    for (int s = 0; s < 5; ++s) Rm[hf][s] = (lg0[hf] == (p == 1)) ? R[hf][s] : 0.f;
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                    for (int s = 0; s < 5; ++s) {
-                        const float b = fb[(t * 5 + s) * 64];
-                        hv[t][0] = MFMA(Rm[0][s], b, hv[t][0]);
-                        hv[t][1] = MFMA(Rm[1][s], b, hv[t][1]);
-                    }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {   // LayerNorm per edge (hf, r): in-lane over t, across the 16 lanes of the row
-                const float4 ga = ld4(lds_ln + 2 * H + 8 * c), gb = ld4(lds_ln + 2 * H + 8 * c + 4);
-                const float4 ba = ld4(lds_ln + 3 * H + 8 * c), bb = ld4(lds_ln + 3 * H + 8 * c + 4);
-                const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-                const float bv[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float s = 0.f;
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) s += hv[t][hf][r];
-                        s = row16_sum(s);
-                        const float mean = s * (1.f / H);
-                        float v = 0.f;
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) { hv[t][hf][r] -= mean; v += hv[t][hf][r] * hv[t][hf][r]; }
-                        v = row16_sum(v);
-                        const float rstd = 1.f / sqrtf(v * (1.f / H) + 1e-5f);
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) hv[t][hf][r] = fmaxf(hv[t][hf][r] * rstd * gv[t] + bv[t], 0.f);
-                    }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // v aggregation, transposed: s2[t] = hid_v^T . w  ->  lane (c = head a, q) reg r' <-> channel 8(4q + r') + t
+            // ---- v path, channel-major, one half at a time: lane (c, q) reg r <-> edge 4q + r + 16hf, m = 8c + t
+            // aggregated straight into s2[t] = hid_v^T . w : lane (c = head a, q) reg r' <-> channel 8(4q + r') + t
             floatx4 s2[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) s2[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+            const float4 pa = ld4(P + (size_t)i * PROW + H + 8 * c), pb = ld4(P + (size_t)i * PROW + H + 8 * c + 4);
+            const float pdv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+            const float4 ga = ld4(lds_ln + 2 * H + 8 * c), gb = ld4(lds_ln + 2 * H + 8 * c + 4);
+            const float4 ba = ld4(lds_ln + 3 * H + 8 * c), bb = ld4(lds_ln + 3 * H + 8 * c + 4);
+            const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+            const float bv[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
+            for (int hf = 0; hf < 2; ++hf) {
+                floatx4 hv[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = 4 * q + r + 16 * hf;
+                    const int j = e < d ? nb[hf][r] : i;
+                    const float* ps = P + (size_t)j * PROW + 3 * H + 8 * c;
+                    const float4 sa = ld4(ps), sb = ld4(ps + 4);
+                    hv[0][r] = pdv[0] + sa.x; hv[1][r] = pdv[1] + sa.y; hv[2][r] = pdv[2] + sa.z; hv[3][r] = pdv[3] + sa.w;
+                    hv[4][r] = pdv[4] + sb.x; hv[5][r] = pdv[5] + sb.y; hv[6][r] = pdv[6] + sb.z; hv[7][r] = pdv[7] + sb.w;
+                }
+                if (has_lig) {
+                    const float* dw = lds_dwt + lig_i * 2 * H + H + 8 * c;
+                    const float4 da = ld4(dw), db = ld4(dw + 4);
+                    const float dv[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m = ((mask_lig >> (4 * q + r + 16 * hf)) & 1u) ? 1.f : 0.f;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) hv[t][r] = fmaf(m, dv[t], hv[t][r]);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    if (p == 0 ? !has_prot : !has_lig) continue;
+                    const float* fb = lds_fv + (size_t)etype(p == 1, lig_i) * (8 * 5 * 64) + lane;
+                    float Rm[5];
+#pragma unroll
+                    for (int s = 0; s < 5; ++s) Rm[s] = (lg0[hf] == (p == 1)) ? R[hf][s] : 0.f;
+#pragma unroll
+                    for (int s = 0; s < 5; ++s)
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) hv[t] = MFMA(Rm[s], fb[(t * 5 + s) * 64], hv[t]);
+                }
+                // LayerNorm per edge r (zero mean by construction): in-lane over t, across the 16 lanes of the row
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) v = fmaf(hv[t][r], hv[t][r], v);
+                    v = row16_sum(v);
+                    const float rstd = 1.f / sqrtf(v * (1.f / H) + 1e-5f);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) hv[t][r] = fmaxf((hv[t][r] * rstd) * gv[t] + bv[t], 0.f);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) s2[t] = MFMA(hv[t][hf][r], w[hf][r], s2[t]);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int t = 0; t < 8; ++t) s2[t] = MFMA(hv[t][r], w[hf][r], s2[t]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // epilogue: out[8a + cc] = sum_m Wbv[8a + cc][m] S[a][m] + bbv[8a + cc] sum_e alpha e_w ; this lane holds
             // S[a = c][32q .. 32q + 31]; Wbv rows live in LDS with their 16-byte chunks XOR-swizzled by the head index
             // so the 16 lanes of a row (16 different Wbv rows, same columns) hit 16 different bank groups.
@@ -329,19 +335,18 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             const float ob = q == 0 ? o8[1] : (q == 1 ? o8[3] : (q == 2 ? o8[5] : o8[7]));
             const int n0 = 8 * c + 2 * q;
             const float2 hres = *reinterpret_cast<const float2*>(h + (size_t)i * H + n0);
-            const float2 bb = *reinterpret_cast<const float2*>(att + A_BBV + n0);
+            const float2 bias2 = *reinterpret_cast<const float2*>(att + A_BBV + n0);
             float2 o;
-            o.x = hres.x + (oa + bb.x * sw);
-            o.y = hres.y + (ob + bb.y * sw);
+            o.x = hres.x + (oa + bias2.x * sw);
+            o.y = hres.y + (ob + bias2.y * sw);
             *reinterpret_cast<float2*>(out + (size_t)i * H + n0) = o;
         } else {
             // ---- h2x: v hidden edge-major, wv[e][a] = Wbv[a] . hid_v[e] + bbv[a] -------------------------------
             floatx4 wv[2];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                wv[hf] = edge_major_half(P, i, j0[hf], lg0[hf], H, 3 * H, lds_fv, lds_wt + H, lds_ln + 2 * H,
-                                         lds_ln + 3 * H, R[hf], has_prot, has_lig, lig_i, lane, q,
-                                         att + A_WBV + (size_t)c * H + 32 * q);
+                wv[hf] = edge_major_half(P, i, j0[hf], lg0[hf], 1, lds_fv, lds_dwt, lds_ln, R[hf], has_prot, has_lig,
+                                         lig_i, lane, q, att + A_WBV + (size_t)c * H + 32 * q);
                 __builtin_amdgcn_sched_barrier(0);
             }
             const float bbv = att[A_BBV + c];
@@ -371,6 +376,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// packing helpers for the LDS image
+// ------------------------------------------------------------------------------------------------
+// fragment order [type][t][s][lane] of the rbf columns of a (centred) first Linear W_a [128][340]
 __global__ void pack_frag_kernel(const float* __restrict__ w_a, int mode, float* __restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // ((type*8 + t)*5 + s)*64 + lane
     if (idx >= (int)FRAG) return;
@@ -380,6 +388,16 @@ __global__ void pack_frag_kernel(const float* __restrict__ w_a, int mode, float*
     dst[idx] = w_a[(size_t)m * KV_IN + NT + G * type + 4 * s + kk];
 }
 
+// dWt[dst class lig_i][k|v][m] = Wt[type(src lig, lig_i)][m] - Wt[type(src prot, lig_i)][m]
+__global__ void pack_dwt_kernel(const float* __restrict__ wk, const float* __restrict__ wv, float* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // [lig_i][kv][m]
+    if (idx >= 2 * 2 * H) return;
+    const int m = idx & 127, kv = (idx >> 7) & 1, li = idx >> 8;
+    const float* w = kv ? wv : wk;
+    const int tl = li ? 0 : 1, tp = li ? 2 : 3;
+    dst[idx] = w[(size_t)m * KV_IN + tl] - w[(size_t)m * KV_IN + tp];
+}
+
 __global__ void pack_wbv_swz_kernel(const float* __restrict__ w, float* __restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // n * 128 + m
     if (idx >= H * H) return;
@@ -387,8 +405,35 @@ __global__ void pack_wbv_swz_kernel(const float* __restrict__ w, float* __restri
     dst[n * H + ((((m >> 2) ^ ((n >> 3) & 15)) << 2) | (m & 3))] = w[idx];
 }
 
+// centre a Linear over its 128 output channels: wc = w - colmean(w), bc = b - mean(b)   (w [128][cols])
+__global__ void center_linear_kernel(const float* __restrict__ w, const float* __restrict__ b, int cols,
+                                     float* __restrict__ wc, float* __restrict__ bc) {
+    const int col = blockIdx.x;  // col == cols -> the bias
+    __shared__ float red[128];
+    const int r = threadIdx.x;
+    const float v = col < cols ? w[(size_t)r * cols + col] : b[r];
+    red[r] = v;
+    __syncthreads();
+    for (int o = 64; o >= 1; o >>= 1) {
+        if (r < o) red[r] += red[r + o];
+        __syncthreads();
+    }
+    const float mean = red[0] * (1.f / 128.f);
+    if (col < cols) wc[(size_t)r * cols + col] = v - mean; else bc[r] = v - mean;
+}
+
+hipError_t launch_center_linear(const float* w, const float* b, int cols, float* wc, float* bc, hipStream_t s) {
+    hipLaunchKernelGGL(center_linear_kernel, dim3(cols + 1), dim3(128), 0, s, w, b, cols, wc, bc);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_wbv_swz(const float* w, float* dst, hipStream_t s) {
     hipLaunchKernelGGL(pack_wbv_swz_kernel, dim3(H * H / 256), dim3(256), 0, s, w, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_dwt(const float* wk, const float* wv, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(pack_dwt_kernel, dim3(2), dim3(256), 0, s, wk, wv, dst);
     return hipGetLastError();
 }
 
@@ -402,16 +447,25 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
                             const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,
                             hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
-    constexpr int WAVES = 8;
-    int grid = (n_nodes + WAVES - 1) / WAVES;
-    if (grid > 256) grid = 256;   // persistent: one workgroup per CU (LDS-limited)
+    // waves per (persistent, one-per-CU) workgroup: 8 -> 256 VGPRs, 12 -> 168, 16 -> 128 per lane.
+    static const int waves = [] {
+        const char* e = getenv("CBGX_EDGE_WAVES");
+        const int w = e ? atoi(e) : 12;
+        return (w == 8 || w == 12 || w == 16) ? w : 12;
+    }();
+    int grid = (n_nodes + waves - 1) / waves;
+    if (grid > 256) grid = 256;                 // persistent: one workgroup per CU (LDS-limited)
+    if (grid >= 64) grid &= ~7;                 // multiple of 8 -> XCD-aware node partition
     profile_mark_begin(x2h ? K_EDGE_X2H : K_EDGE_H2X, s);
-    if (x2h)
-        hipLaunchKernelGGL((edge_mfma_kernel<true, WAVES>), dim3(grid), dim3(WAVES * 64), 0, s, att, x, h, P, Qt, nbr,
-                           deg, lig, gen, e_w, n_nodes, out, dx_out);
-    else
-        hipLaunchKernelGGL((edge_mfma_kernel<false, WAVES>), dim3(grid), dim3(WAVES * 64), 0, s, att, x, h, P, Qt, nbr,
-                           deg, lig, gen, e_w, n_nodes, out, dx_out);
+#define CBGX_LAUNCH_EDGE(X2H_, W_)                                                                                  \
+    hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W_>), dim3(grid), dim3(W_ * 64), 0, s, att, x, h, P, Qt, nbr, deg, lig, \
+                       gen, e_w, n_nodes, out, dx_out)
+    if (x2h) {
+        if (waves == 8) CBGX_LAUNCH_EDGE(true, 8); else if (waves == 12) CBGX_LAUNCH_EDGE(true, 12); else CBGX_LAUNCH_EDGE(true, 16);
+    } else {
+        if (waves == 8) CBGX_LAUNCH_EDGE(false, 8); else if (waves == 12) CBGX_LAUNCH_EDGE(false, 12); else CBGX_LAUNCH_EDGE(false, 16);
+    }
+#undef CBGX_LAUNCH_EDGE
     profile_mark_end(s);
     return hipGetLastError();
 }

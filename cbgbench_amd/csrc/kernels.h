@@ -24,13 +24,16 @@ hipError_t launch_attention(bool x2h, const float* att, const float* x, const fl
 extern int g_edge_impl;
 // fragment-ordered rbf weight table: mode 0 edge-major (A operand), 1 channel-major (B operand)
 hipError_t launch_pack_frag(const float* w_a, int mode, float* dst, hipStream_t s);
+hipError_t launch_center_linear(const float* w, const float* b, int cols, float* wc, float* bc, hipStream_t s);
+hipError_t launch_pack_dwt(const float* wk, const float* wv, float* dst, hipStream_t s);
+hipError_t launch_pack_bn2(const float* att_wakc, const float* bq0, float* att, hipStream_t s);
 // x2h second v Linear [128 n][128 m] with 16-byte chunks XOR-swizzled by head (n >> 3)
 hipError_t launch_pack_wbv_swz(const float* w, float* dst, hipStream_t s);
 // MFMA node kernels (node_mfma.hip): P = h Wn + bn, q = MLP tail, Qt = folded query
 hipError_t launch_pack_node_frags(const float* wk0, const float* wv0, const float* wq0, const float* wq1,
                                   const float* wbk, float* att, hipStream_t s);
-hipError_t launch_node_mfma(const float* att, const float* h, int n_nodes, float* P, float* qbuf, float* Qt,
-                            hipStream_t s);
+hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,
+                            float* Qt, hipStream_t s);
 // MFMA edge kernel (edge_mfma.hip)
 hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,
                             const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,

@@ -472,7 +472,7 @@ hipError_t launch_attention(bool x2h, const float* att, const float* x, const fl
                             float* P, float* Qt, float* qbuf, float* out, float* dx_out, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
     if (g_edge_impl == 0) {
-        hipError_t e0 = launch_node_mfma(att, h, n_nodes, P, qbuf, Qt, s);
+        hipError_t e0 = launch_node_mfma(att, h, lig, n_nodes, P, qbuf, Qt, s);
         if (e0 != hipSuccess) return e0;
         return launch_edge_mfma(x2h, att, x, h, P, Qt, nbr, deg, lig, gen, e_w, n_nodes, out, dx_out, s);
     }

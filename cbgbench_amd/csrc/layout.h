@@ -43,7 +43,7 @@ constexpr size_t A_BBV = A_WBV + (size_t)H * H;   // [128] (h2x: first 16)
 // LDS image of the MFMA edge kernel: one contiguous region copied verbatim into LDS.
 //   frag_k [4 types][8 t][5 s][64 lanes]  A-operand fragments of the rbf columns of W_a (k), edge-major
 //   frag_v [4][8][5][64]                  x2h: B-operand fragments (channel-major); h2x: A-operand (edge-major)
-//   wt     [4][256]                       type one-hot columns (k | v)
+//   dwt    [2][256] (+512 unused)         dWt[lig_i][k|v] = Wt[type(src lig, i)] - Wt[type(src prot, i)]
 //   ln     [4][128]                       gamma_k, beta_k, gamma_v, beta_v
 //   wbv_rm [128][128]                     x2h only: second v Linear, row-major (out n, in m)
 constexpr size_t FRAG = (size_t)NT * 8 * 5 * 64;   // 10240
@@ -59,7 +59,15 @@ constexpr size_t IMG_SIZE_X2H = IMG_WBV + (size_t)H * H; // 38400 floats = 15360
 constexpr size_t A_NPROJ_FRAG = A_IMG + IMG_SIZE_X2H;              // [10 ch][4 ct][8 s4][64 lanes][4]
 constexpr size_t A_WQ1_FRAG = A_NPROJ_FRAG + (size_t)H * PROW;     // [8 nt][8 s4][64][4]
 constexpr size_t A_WBK_FRAG = A_WQ1_FRAG + (size_t)H * H;          // [16 a][2 g][64][8], pre-scaled by 1/sqrt(8)
-constexpr size_t ATT_SIZE = A_WBK_FRAG + (size_t)H * H;
+// centred first Linears (W - colmean(W), b - mean(b)) of k and v, reference layout [128][340]: the source of
+// every fragment table above; and the per-destination-class bias rows of the MFMA node projection
+//   bn2[lig_i][640] = [bkc + Wkc[:, type(src prot, lig_i)] | bvc + Wvc[:, type(src prot, lig_i)] | 0 | 0 | bq0]
+constexpr size_t A_WAKC = A_WBK_FRAG + (size_t)H * H;
+constexpr size_t A_BAKC = A_WAKC + (size_t)H * KV_IN;
+constexpr size_t A_WAVC = A_BAKC + H;
+constexpr size_t A_BAVC = A_WAVC + (size_t)H * KV_IN;
+constexpr size_t A_BN2 = A_BAVC + H;
+constexpr size_t ATT_SIZE = A_BN2 + 2 * PROW;
 
 constexpr size_t LAYER_SIZE = 2 * ATT_SIZE;       // x2h then h2x
 

@@ -38,15 +38,19 @@ constexpr int NP_CHUNK = 4 * 8 * 64 * 4;  // 8192 floats = 32 KB
 constexpr int NP_CHUNKS = PROW / 64;      // 10
 
 __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict__ att, const float* __restrict__ h,
-                                                        float* __restrict__ P, int n_nodes) {
+                                                        const uint8_t* __restrict__ lig, float* __restrict__ P,
+                                                        int n_nodes) {
     __shared__ __attribute__((aligned(16))) float lds[2][NP_CHUNK];
     const float* frag = att + A_NPROJ_FRAG;
-    const float* bias = att + A_BN;
+    const float* bias = att + A_BN2;  // [dst class][640]: bias + type column of a protein source
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
     const int n_tiles = (n_nodes + 63) / 64;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int row0 = tile * 64 + wave * 16;
         const int arow = min(row0 + c, n_nodes - 1);
+        bool lgr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lgr[r] = lig[min(row0 + 4 * q + r, n_nodes - 1)] != 0;
         float a[32];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -69,9 +73,13 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
                 for (int u = 0; u < NP_CHUNK / 4 / 256; ++u) stage[u] = src[tid + 256 * u];
             }
             const float* B = lds[ch & 1];
-            const float4 b4 = nld4(bias + 64 * ch + 4 * c);
-            floatx4 acc[4] = {{b4.x, b4.x, b4.x, b4.x}, {b4.y, b4.y, b4.y, b4.y}, {b4.z, b4.z, b4.z, b4.z},
-                              {b4.w, b4.w, b4.w, b4.w}};
+            const float4 bP = nld4(bias + 64 * ch + 4 * c), bL = nld4(bias + PROW + 64 * ch + 4 * c);
+            floatx4 acc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[0][r] = lgr[r] ? bL.x : bP.x; acc[1][r] = lgr[r] ? bL.y : bP.y;
+                acc[2][r] = lgr[r] ? bL.z : bP.z; acc[3][r] = lgr[r] ? bL.w : bP.w;
+            }
 #pragma unroll
             for (int s4 = 0; s4 < 8; ++s4) {
                 float4 bf[4];
@@ -262,6 +270,24 @@ __global__ void pack_wbk_kernel(const float* __restrict__ wbk, float* __restrict
     dst[idx] = wbk[(size_t)(8 * a + 2 * q + step) * H + 64 * g + 4 * c + j] * 0.35355339059327376220f;
 }
 
+// bn2[li][col]: PDk | PDv get the centred bias plus the type column of a protein source for destination class li
+__global__ void pack_bn2_kernel(const float* att_in, const float* bq0, float* att) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * PROW) return;
+    const int li = idx / PROW, col = idx % PROW, blk = col >> 7, n = col & 127;
+    const int tp = li ? 2 : 3;  // type(src prot, dst lig) = 2, type(src prot, dst prot) = 3
+    float v = 0.f;
+    if (blk == 0) v = att_in[A_BAKC + n] + att_in[A_WAKC + (size_t)n * KV_IN + tp];
+    else if (blk == 1) v = att_in[A_BAVC + n] + att_in[A_WAVC + (size_t)n * KV_IN + tp];
+    else if (blk == 4) v = bq0[n];
+    att[A_BN2 + idx] = v;
+}
+
+hipError_t launch_pack_bn2(const float* att_in, const float* bq0, float* att, hipStream_t s) {
+    hipLaunchKernelGGL(pack_bn2_kernel, dim3((2 * PROW + 255) / 256), dim3(256), 0, s, att_in, bq0, att);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_node_frags(const float* wk0, const float* wv0, const float* wq0, const float* wq1,
                                   const float* wbk, float* att, hipStream_t s) {
     hipLaunchKernelGGL(pack_nproj_kernel, dim3(NP_CHUNKS * NP_CHUNK / 256), dim3(256), 0, s, wk0, wv0, wq0,
@@ -272,12 +298,12 @@ hipError_t launch_pack_node_frags(const float* wk0, const float* wv0, const floa
 }
 
 // node stage of one attention block: P, q (scratch), Qt
-hipError_t launch_node_mfma(const float* att, const float* h, int n_nodes, float* P, float* qbuf, float* Qt,
-                            hipStream_t s) {
+hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,
+                            float* Qt, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
     const int tiles = (n_nodes + 63) / 64;
     profile_mark_begin(K_NODE_GEMM, s);
-    hipLaunchKernelGGL(node_proj_kernel, dim3(min(tiles, 512)), dim3(256), 0, s, att, h, P, n_nodes);
+    hipLaunchKernelGGL(node_proj_kernel, dim3(min(tiles, 512)), dim3(256), 0, s, att, h, lig, P, n_nodes);
     profile_mark_end(s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

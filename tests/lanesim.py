@@ -70,12 +70,17 @@ class Weights:
         kf, vf, qf = ("hk_func", "hv_func", "hq_func") if x2h else ("xk_func", "xv_func", "xq_func")
         g = lambda n: sd[f"{prefix}.{n}"].numpy()
         wk0, wv0 = g(f"{kf}.net.0.weight"), g(f"{vf}.net.0.weight")
+        # pack-time centring over the 128 output channels (cbgx_pack_weights / center_linear_kernel)
+        wk0 = (wk0 - wk0.mean(0, keepdims=True, dtype=np.float32)).astype(np.float32)
+        wv0 = (wv0 - wv0.mean(0, keepdims=True, dtype=np.float32)).astype(np.float32)
         self.Wt_k, self.Wt_v = wk0[:, :4].T.copy(), wv0[:, :4].T.copy()                 # [4][128]
         self.Wr_k = wk0[:, 4:84].T.reshape(4, 20, 128).copy()                            # [type][g][m]
         self.Wr_v = wv0[:, 4:84].T.reshape(4, 20, 128).copy()
         self.Wd_k, self.Ws_k = wk0[:, 84:212], wk0[:, 212:340]
         self.Wd_v, self.Ws_v = wv0[:, 84:212], wv0[:, 212:340]
         self.b_k0, self.b_v0 = g(f"{kf}.net.0.bias"), g(f"{vf}.net.0.bias")
+        self.b_k0 = self.b_k0 - self.b_k0.mean(dtype=np.float32)
+        self.b_v0 = self.b_v0 - self.b_v0.mean(dtype=np.float32)
         self.g_k, self.be_k = g(f"{kf}.net.1.weight"), g(f"{kf}.net.1.bias")
         self.g_v, self.be_v = g(f"{vf}.net.1.weight"), g(f"{vf}.net.1.bias")
         self.Wb_k = g(f"{kf}.net.3.weight")
@@ -85,10 +90,12 @@ class Weights:
         self.fragA_v = frag_wr_edge(self.Wr_v)
         self.fragB_v = frag_wr_chan(self.Wr_v)
 
-    def node_tables(self, h):
-        """What the node kernels produce: P = [PDk | PDv | PSk | PSv] and the folded query Qt."""
-        PDk = h @ self.Wd_k.T + self.b_k0
-        PDv = h @ self.Wd_v.T + self.b_v0
+    def node_tables(self, h, lig):
+        """What the node kernels produce: P = [PDk | PDv | PSk | PSv] and the folded query Qt.
+        PD carries the centred bias and the type column of a protein source for the node's class."""
+        tp = np.where(lig.astype(bool), 2, 3)
+        PDk = h @ self.Wd_k.T + self.b_k0 + self.Wt_k[tp]
+        PDv = h @ self.Wd_v.T + self.b_v0 + self.Wt_v[tp]
         PSk, PSv = h @ self.Ws_k.T, h @ self.Ws_v.T
         w0, b0, gq, bq, w1, b1 = self.q
         qv = ln_relu(h @ w0.T + b0, gq, bq) @ w1.T + b1                                   # [N,128]
@@ -131,10 +138,10 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
         Cacc = np.zeros((8, 2, 4, 64), np.float32)
         for t in range(8):
             for hf in range(2):
-                ty = np.where(lg0[hf], etype(True), etype(False))
+                dWt = Wt[etype(True)] - Wt[etype(False)]
                 for r in range(4):
                     m = 32 * Q_ + 4 * t + r
-                    Cacc[t, hf, r] = PD[i, m] + PS[j0[hf], m] + Wt[ty, m]
+                    Cacc[t, hf, r] = PD[i, m] + PS[j0[hf], m] + np.where(lg0[hf], dWt[m], 0)
                 for src_lig in passes:
                     for s in range(5):
                         Rm = np.where(lg0[hf] == src_lig, R[hf][s], 0).astype(np.float32)
@@ -144,11 +151,8 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
     def ln_edge_major(Cacc, gamma, beta):
         out = np.zeros_like(Cacc)
         for hf in range(2):
-            s = Cacc[:, hf].sum((0, 1))                      # in-lane over (t, r)
-            s = s + s[L ^ 16]; s = s + s[L ^ 32]             # across q
-            mean = s / 128
-            dv = Cacc[:, hf] - mean
-            v = (dv * dv).sum((0, 1))
+            dv = Cacc[:, hf]                                 # zero mean by construction (centred weights)
+            v = (dv * dv).sum((0, 1))                        # in-lane over (t, r), then across q
             v = v + v[L ^ 16]; v = v + v[L ^ 32]
             rstd = 1.0 / np.sqrt(v / 128 + 1e-5)
             for t in range(8):
@@ -188,9 +192,9 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
         for t in range(8):
             m = 8 * C_ + t
             for hf in range(2):
+                dWt = W.Wt_v[etype(True)] - W.Wt_v[etype(False)]
                 for r in range(4):
-                    ty = np.where(lg1[hf, r], etype(True), etype(False))
-                    Cv[t, hf, r] = PDv[i, m] + PSv[j1[hf, r], m] + W.Wt_v[ty, m]
+                    Cv[t, hf, r] = PDv[i, m] + PSv[j1[hf, r], m] + np.where(lg1[hf, r], dWt[m], 0)
                 for src_lig in passes:
                     for s in range(5):
                         Rm = np.where(lg0[hf] == src_lig, R[hf][s], 0).astype(np.float32)
@@ -199,10 +203,7 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
         Hv = np.zeros_like(Cv)
         for hf in range(2):
             for r in range(4):
-                s = Cv[:, hf, r].sum(0)
-                for o in (1, 2, 4, 8): s = s + s[L ^ o]
-                mean = s / 128
-                dv = Cv[:, hf, r] - mean
+                dv = Cv[:, hf, r]                             # zero mean by construction
                 v = (dv * dv).sum(0)
                 for o in (1, 2, 4, 8): v = v + v[L ^ o]
                 rstd = 1.0 / np.sqrt(v / 128 + 1e-5)

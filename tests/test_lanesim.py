@@ -38,10 +38,10 @@ def test_lane_model_matches_reference_layer0(golden_dir, synthetic_sd, case, nod
     nbr, deg, ew = _nbr(g)
     x, h, lig = g["x"], g["h"], g["lig_flag"]
     Wx = LS.Weights(synthetic_sd, "denoiser.blocks.0.x2h_layers.0", True)
-    tabs = Wx.node_tables(h)
+    tabs = Wx.node_tables(h, lig)
     Wh = LS.Weights(synthetic_sd, "denoiser.blocks.0.h2x_layers.0", False)
     h1 = g["h_layer0"]
-    tabs_h = Wh.node_tables(h1)
+    tabs_h = Wh.node_tables(h1, lig)
     for i in nodes:
         out = LS.simulate_node(Wx, True, i, x, h, nbr, deg, lig, ew, tabs)
         assert np.allclose(out, h1[i], rtol=1e-4, atol=2e-5), (i, np.abs(out - h1[i]).max())
