@@ -19,8 +19,10 @@
 // All contractions are MFMAs and every accumulator is consumed in the layout it was produced in (no LDS
 // transposes, no atomics -> deterministic).  tests/lanesim.py is the lane-by-lane model of this file and is
 // checked against the reference on the CPU (tests/test_lanesim.py).  Lane l: c = l & 15, q = l >> 4.
-//   edge-major tile    (k; h2x v):  lane column = edge e16, C row 4q+r  <->  channel m = 32q + 4t + r
-//   channel-major tile (x2h v):     lane column = channel, m = 8c + t;   C row 4q+r <-> edge e = 4q + r + 16hf
+//   edge-major tile t    (k; h2x v): lane column = edge e16, C row rho = 4q+r <-> channel m = 16t + rho
+//   channel-major tile t (x2h v):    lane column c <-> channel m = 64(t>>2) + 4c + (t&3); C row 4q+r <-> edge 4q+r+16hf
+// Both labelings make every gather instruction touch whole 64..256-byte runs of a row (16 cache lines per
+// wave instruction instead of 64): the texture addresser, not the ALUs, was the first bottleneck.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -79,15 +81,15 @@ __device__ __forceinline__ floatx4 edge_major_half(const float* __restrict__ P, 
                                                    int lane, int q, const float* __restrict__ Brow) {
     floatx4 acc[8];
     {
-        const float* pd = P + (size_t)i * PROW + kv * H + 32 * q;
-        const float* ps = P + (size_t)j * PROW + (2 + kv) * H + 32 * q;
+        const float* pd = P + (size_t)i * PROW + kv * H + 4 * q;
+        const float* ps = P + (size_t)j * PROW + (2 + kv) * H + 4 * q;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = f4(ld4(pd + 4 * t)) + f4(ld4(ps + 4 * t));
+        for (int t = 0; t < 8; ++t) acc[t] = f4(ld4(pd + 16 * t)) + f4(ld4(ps + 16 * t));
         if (has_lig) {  // wave-uniform: only nodes with a ligand neighbour pay for the type correction
-            const float* dw = lds_dwt + lig_i * 2 * H + kv * H + 32 * q;
+            const float* dw = lds_dwt + lig_i * 2 * H + kv * H + 4 * q;
             const float m = lg ? 1.f : 0.f;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) acc[t] += f4(ld4(dw + 4 * t)) * m;
+            for (int t = 0; t < 8; ++t) acc[t] += f4(ld4(dw + 16 * t)) * m;
         }
     }
 #pragma unroll
@@ -110,15 +112,15 @@ __device__ __forceinline__ floatx4 edge_major_half(const float* __restrict__ P, 
         v += (acc[t].x * acc[t].x + acc[t].y * acc[t].y) + (acc[t].z * acc[t].z + acc[t].w * acc[t].w);
     v = xrow_sum(v);
     const float rstd = 1.f / sqrtf(v * (1.f / H) + 1e-5f);
-    const float* lg_ = lds_ln + (2 * kv) * H + 32 * q;
-    const float* lb_ = lds_ln + (2 * kv + 1) * H + 32 * q;
+    const float* lg_ = lds_ln + (2 * kv) * H + 4 * q;
+    const float* lb_ = lds_ln + (2 * kv + 1) * H + 4 * q;
     // two interleaved accumulators: a dependent 16x16x4 MFMA needs 40 cycles, an independent one 32
     floatx4 out0 = {0.f, 0.f, 0.f, 0.f}, out1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const floatx4 g = f4(ld4(lg_ + 4 * t)), b = f4(ld4(lb_ + 4 * t));
+        const floatx4 g = f4(ld4(lg_ + 16 * t)), b = f4(ld4(lb_ + 16 * t));
         const floatx4 y = (acc[t] * rstd) * g + b;
-        const float4 bb = ld4(Brow + 4 * t);
+        const float4 bb = ld4(Brow + 16 * t);
         out0 = MFMA(fmaxf(y.x, 0.f), bb.x, out0);
         out1 = MFMA(fmaxf(y.y, 0.f), bb.y, out1);
         out0 = MFMA(fmaxf(y.z, 0.f), bb.z, out0);
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             sc[hf] = edge_major_half(P, i, j0[hf], lg0[hf], 0, lds_fk, lds_dwt, lds_ln, R[hf], has_prot, has_lig, lig_i,
-                                     lane, q, Qt + ((size_t)i * HEADS + c) * H + 32 * q);
+                                     lane, q, Qt + ((size_t)i * HEADS + c) * H + 4 * q);
             __builtin_amdgcn_sched_barrier(0);
         }
         // E1 mapping: lane (c = head a, q), reg (hf, r) <-> edge e = 4q + r + 16hf
@@ -248,14 +250,14 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                 }
             sw = xrow_sum(sw);   // sum_e alpha e_w for head a = c
             // ---- v path, channel-major, one half at a time: lane (c, q) reg r <-> edge 4q + r + 16hf, m = 8c + t
-            // aggregated straight into s2[t] = hid_v^T . w : lane (c = head a, q) reg r' <-> channel 8(4q + r') + t
+            // aggregated straight into s2[t] = hid_v^T . w : lane (c = head a, q) reg r' <-> channel 64(t>>2) + 16q + 4r' + (t&3)
             floatx4 s2[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) s2[t] = floatx4{0.f, 0.f, 0.f, 0.f};
-            const float4 pa = ld4(P + (size_t)i * PROW + H + 8 * c), pb = ld4(P + (size_t)i * PROW + H + 8 * c + 4);
+            const float4 pa = ld4(P + (size_t)i * PROW + H + 4 * c), pb = ld4(P + (size_t)i * PROW + H + 64 + 4 * c);
             const float pdv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-            const float4 ga = ld4(lds_ln + 2 * H + 8 * c), gb = ld4(lds_ln + 2 * H + 8 * c + 4);
-            const float4 ba = ld4(lds_ln + 3 * H + 8 * c), bb = ld4(lds_ln + 3 * H + 8 * c + 4);
+            const float4 ga = ld4(lds_ln + 2 * H + 4 * c), gb = ld4(lds_ln + 2 * H + 64 + 4 * c);
+            const float4 ba = ld4(lds_ln + 3 * H + 4 * c), bb = ld4(lds_ln + 3 * H + 64 + 4 * c);
             const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
             const float bv[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
@@ -265,14 +267,14 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                 for (int r = 0; r < 4; ++r) {
                     const int e = 4 * q + r + 16 * hf;
                     const int j = e < d ? nb[hf][r] : i;
-                    const float* ps = P + (size_t)j * PROW + 3 * H + 8 * c;
-                    const float4 sa = ld4(ps), sb = ld4(ps + 4);
+                    const float* ps = P + (size_t)j * PROW + 3 * H + 4 * c;
+                    const float4 sa = ld4(ps), sb = ld4(ps + 64);
                     hv[0][r] = pdv[0] + sa.x; hv[1][r] = pdv[1] + sa.y; hv[2][r] = pdv[2] + sa.z; hv[3][r] = pdv[3] + sa.w;
                     hv[4][r] = pdv[4] + sb.x; hv[5][r] = pdv[5] + sb.y; hv[6][r] = pdv[6] + sb.z; hv[7][r] = pdv[7] + sb.w;
                 }
                 if (has_lig) {
-                    const float* dw = lds_dwt + lig_i * 2 * H + H + 8 * c;
-                    const float4 da = ld4(dw), db = ld4(dw + 4);
+                    const float* dw = lds_dwt + lig_i * 2 * H + H + 4 * c;
+                    const float4 da = ld4(dw), db = ld4(dw + 64);
                     const float dv[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
             // epilogue: out[8a + cc] = sum_m Wbv[8a + cc][m] S[a][m] + bbv[8a + cc] sum_e alpha e_w ; this lane holds
-            // S[a = c][32q .. 32q + 31]; Wbv rows live in LDS with their 16-byte chunks XOR-swizzled by the head index
+            // S[a = c][16q .. 16q+15] and [64 + 16q .. 64 + 16q + 15]; Wbv rows live in LDS with their 16-byte chunks XOR-swizzled by the head index
             // so the 16 lanes of a row (16 different Wbv rows, same columns) hit 16 different bank groups.
             float o8[8];
             const float* lds_wbv = lds + IMG_WBV;
@@ -321,8 +323,8 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                 float a0 = 0.f, a1 = 0.f;
 #pragma unroll
                 for (int rp = 0; rp < 4; ++rp) {
-                    const float4 wa = ld4(wrow + (((8 * q + 2 * rp) ^ c) << 2));
-                    const float4 wb = ld4(wrow + (((8 * q + 2 * rp + 1) ^ c) << 2));
+                    const float4 wa = ld4(wrow + (((4 * q + rp) ^ c) << 2));        // channels 16q + 4rp .. +3
+                    const float4 wb = ld4(wrow + (((16 + 4 * q + rp) ^ c) << 2));   // channels 64 + 16q + 4rp .. +3
                     a0 = fmaf(wa.x, s2[0][rp], a0); a1 = fmaf(wa.y, s2[1][rp], a1);
                     a0 = fmaf(wa.z, s2[2][rp], a0); a1 = fmaf(wa.w, s2[3][rp], a1);
                     a0 = fmaf(wb.x, s2[4][rp], a0); a1 = fmaf(wb.y, s2[5][rp], a1);
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 wv[hf] = edge_major_half(P, i, j0[hf], lg0[hf], 1, lds_fv, lds_dwt, lds_ln, R[hf], has_prot, has_lig,
-                                         lig_i, lane, q, att + A_WBV + (size_t)c * H + 32 * q);
+                                         lig_i, lane, q, att + A_WBV + (size_t)c * H + 4 * q);
                 __builtin_amdgcn_sched_barrier(0);
             }
             const float bbv = att[A_BBV + c];
@@ -384,7 +386,7 @@ __global__ void pack_frag_kernel(const float* __restrict__ w_a, int mode, float*
     if (idx >= (int)FRAG) return;
     const int lane = idx & 63, s = (idx >> 6) % 5, t = (idx / 320) & 7, type = idx / 2560;
     const int c = lane & 15, kk = lane >> 4;
-    const int m = mode == 0 ? 32 * (c >> 2) + 4 * t + (c & 3) : 8 * c + t;
+    const int m = mode == 0 ? 16 * t + c : 64 * (t >> 2) + 4 * c + (t & 3);
     dst[idx] = w_a[(size_t)m * KV_IN + NT + G * type + 4 * s + kk];
 }
 

@@ -5,8 +5,8 @@
 //   node_qfold:  Qt[N,16,128] = (1/sqrt 8) * q[N, 8a:8a+8] @ Wbk[8a:8a+8, :]      (key's 2nd Linear folded into q)
 //
 // Common shape: one wavefront owns 16 rows (nodes); its A operand is read straight from global memory in
-// MFMA A layout using a K permutation (lane (c = row, q) holds k = 32q + s for step s, i.e. 128 contiguous
-// bytes of its row), the B operand comes from LDS in "fragment order" (written by cbgx_pack_weights so the
+// MFMA A layout using a K permutation (step (s4, j) uses k = 16 s4 + 4q + j, so the four q-lanes of a row read
+// one contiguous 64-byte run per load instruction), the B operand comes from LDS in "fragment order" (written by cbgx_pack_weights so the
 // global->LDS copy is linear and every ds_read_b128 is conflict-free), and output tiles use a column
 // permutation (tile j of a group of four <-> column 4c + j) so each lane stores float4s.
 // MFMA 16x16x4 maps: A[i=c][k=q], B[k=q][j=c], C reg r: [row 4q+r][col c];  lane l: c = l & 15, q = l >> 4.
@@ -32,7 +32,7 @@ __device__ __forceinline__ float nxrow_sum(float v) {
 
 // ------------------------------------------------------------------------------------------------
 // node_proj: 4 waves x 16 rows per workgroup; 10 column chunks of 64; chunk fragments double-buffered in LDS.
-// fragment order of a chunk: [ct 4][s4 8][lane 64][4]  = Wn[k = 32q + 4 s4 + j][col = 64 ch + 4c + ct]
+// fragment order of a chunk: [ct 4][s4 8][lane 64][4]  = Wn[k = 16 s4 + 4q + j][col = 64 ch + 4c + ct]
 // ------------------------------------------------------------------------------------------------
 constexpr int NP_CHUNK = 4 * 8 * 64 * 4;  // 8192 floats = 32 KB
 constexpr int NP_CHUNKS = PROW / 64;      // 10
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
         float a[32];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const float4 v = nld4(h + (size_t)arow * H + 32 * q + 4 * u);
+            const float4 v = nld4(h + (size_t)arow * H + 16 * u + 4 * q);
             a[4 * u] = v.x; a[4 * u + 1] = v.y; a[4 * u + 2] = v.z; a[4 * u + 3] = v.w;
         }
         __syncthreads();  // previous tile's readers of lds[0] are done
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------------
 // node_qmlp: LayerNorm + ReLU on the q-hidden quarter of P (A layout: LN is in-lane + across q), then
-// q = z @ Wq1^T + bq1.  Wq1 fragments [nt 8][s4 8][lane][4] = Wq1[n = 64(nt>>2) + 4c + (nt&3)][k = 32q + 4 s4 + j].
+// q = z @ Wq1^T + bq1.  Wq1 fragments [nt 8][s4 8][lane][4] = Wq1[n = 64(nt>>2) + 4c + (nt&3)][k = 16 s4 + 4q + j].
 // ------------------------------------------------------------------------------------------------
 constexpr int NQ_FRAG = 8 * 8 * 64 * 4;  // 16384 floats = 64 KB
 
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
         float sm = 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const float4 v = nld4(P + (size_t)arow * PROW + 4 * H + 32 * q + 4 * u);
+            const float4 v = nld4(P + (size_t)arow * PROW + 4 * H + 16 * u + 4 * q);
             z[4 * u] = v.x; z[4 * u + 1] = v.y; z[4 * u + 2] = v.z; z[4 * u + 3] = v.w;
             sm += (v.x + v.y) + (v.z + v.w);
         }
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
         const float rstd = 1.f / sqrtf(nxrow_sum(var) * (1.f / H) + 1e-5f);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const float4 g = nld4(att + A_LNQ_G + 32 * q + 4 * u), b = nld4(att + A_LNQ_B + 32 * q + 4 * u);
+            const float4 g = nld4(att + A_LNQ_G + 16 * u + 4 * q), b = nld4(att + A_LNQ_B + 16 * u + 4 * q);
             z[4 * u + 0] = fmaxf(z[4 * u + 0] * rstd * g.x + b.x, 0.f);
             z[4 * u + 1] = fmaxf(z[4 * u + 1] * rstd * g.y + b.y, 0.f);
             z[4 * u + 2] = fmaxf(z[4 * u + 2] * rstd * g.z + b.z, 0.f);
@@ -243,7 +243,7 @@ __global__ void pack_nproj_kernel(const float* __restrict__ wk0, const float* __
     if (idx >= NP_CHUNKS * NP_CHUNK) return;
     const int j = idx & 3, lane = (idx >> 2) & 63, s4 = (idx >> 8) & 7, ct = (idx >> 11) & 3, ch = idx >> 13;
     const int c = lane & 15, q = lane >> 4;
-    const int col = 64 * ch + 4 * c + ct, k = 32 * q + 4 * s4 + j;
+    const int col = 64 * ch + 4 * c + ct, k = 16 * s4 + 4 * q + j;
     const int blk = col >> 7, n = col & 127;
     float v;
     if (blk == 0) v = wk0[(size_t)n * KV_IN + NT + NT * G + k];            // PDk
@@ -259,7 +259,7 @@ __global__ void pack_wq1_kernel(const float* __restrict__ wq1, float* __restrict
     if (idx >= NQ_FRAG) return;
     const int j = idx & 3, lane = (idx >> 2) & 63, s4 = (idx >> 8) & 7, nt = idx >> 11;
     const int c = lane & 15, q = lane >> 4;
-    dst[idx] = wq1[(size_t)(64 * (nt >> 2) + 4 * c + (nt & 3)) * H + 32 * q + 4 * s4 + j];
+    dst[idx] = wq1[(size_t)(64 * (nt >> 2) + 4 * c + (nt & 3)) * H + 16 * s4 + 4 * q + j];
 }
 
 __global__ void pack_wbk_kernel(const float* __restrict__ wbk, float* __restrict__ dst) {

@@ -28,13 +28,13 @@ def mfma(a, b, c):
 
 # ---- hidden-channel labelings ---------------------------------------------------------------------
 def m_edge(t, rho):
-    """'edge-major' tiles (lane column = edge): C row rho = 4q+r of tile t  <->  m = 32q + 4t + r."""
-    return 32 * (rho >> 2) + 4 * t + (rho & 3)
+    """'edge-major' tiles (lane column = edge): C row rho = 4q+r of tile t  <->  m = 16t + rho."""
+    return 16 * t + rho
 
 
 def m_chan(t, c):
-    """'channel-major' tiles (lane column = channel): column c of tile t  <->  m = 8c + t."""
-    return 8 * c + t
+    """'channel-major' tiles (lane column = channel): column c of tile t  <->  m = 64(t>>2) + 4c + (t&3)."""
+    return 64 * (t >> 2) + 4 * c + (t & 3)
 
 
 # ---- fragment-ordered weight tables (what cbgx_pack_weights writes, what the kernel copies to LDS) ----
@@ -140,7 +140,7 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
             for hf in range(2):
                 dWt = Wt[etype(True)] - Wt[etype(False)]
                 for r in range(4):
-                    m = 32 * Q_ + 4 * t + r
+                    m = m_edge(t, 4 * Q_ + r)
                     Cacc[t, hf, r] = PD[i, m] + PS[j0[hf], m] + np.where(lg0[hf], dWt[m], 0)
                 for src_lig in passes:
                     for s in range(5):
@@ -157,7 +157,7 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
             rstd = 1.0 / np.sqrt(v / 128 + 1e-5)
             for t in range(8):
                 for r in range(4):
-                    m = 32 * Q_ + 4 * t + r
+                    m = m_edge(t, 4 * Q_ + r)
                     out[t, hf, r] = np.maximum(dv[t, r] * rstd * gamma[m] + beta[m], 0)
         return out.astype(np.float32)
 
@@ -167,7 +167,7 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
         for hf in range(2):
             for t in range(8):
                 for r in range(4):
-                    out[hf] = mfma(Hd[t, hf, r], Bsrc[C_, 32 * Q_ + 4 * t + r], out[hf])
+                    out[hf] = mfma(Hd[t, hf, r], Bsrc[C_, m_edge(t, 4 * Q_ + r)], out[hf])
         return out
 
     # ---- k path (edge-major) -----------------------------------------------------------------------
@@ -190,7 +190,7 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
         lg1 = ((mask_lig >> e1) & 1).astype(bool)
         Cv = np.zeros((8, 2, 4, 64), np.float32)
         for t in range(8):
-            m = 8 * C_ + t
+            m = m_chan(t, C_)
             for hf in range(2):
                 dWt = W.Wt_v[etype(True)] - W.Wt_v[etype(False)]
                 for r in range(4):
@@ -208,9 +208,9 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
                 for o in (1, 2, 4, 8): v = v + v[L ^ o]
                 rstd = 1.0 / np.sqrt(v / 128 + 1e-5)
                 for t in range(8):
-                    m = 8 * C_ + t
+                    m = m_chan(t, C_)
                     Hv[t, hf, r] = np.maximum(dv[t] * rstd * W.g_v[m] + W.be_v[m], 0)
-        # v-agg, transposed (hid_v as A operand, w as B): S2[t][r'][lane (c = a, q)] <-> channel m = 8(4q + r') + t
+        # v-agg, transposed (hid_v as A operand, w as B): S2[t][r'][lane (c = a, q)] <-> channel m_chan(t, 4q + r')
         S2 = np.zeros((8, 4, 64), np.float32)
         for t in range(8):
             for hf in range(2):
@@ -226,8 +226,8 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
             for cc in range(8):
                 acc = 0.0
                 for rp in range(4):
-                    for t in range(8):
-                        chunk = (8 * q + 2 * rp + (t >> 2)) ^ c
+                    for t in range(8):                                  # S2[t][rp] <-> channel m_chan(t, 4q + rp)
+                        chunk = (16 * (t >> 2) + 4 * q + rp) ^ c
                         acc += img[(8 * c + cc) * 128 + (chunk << 2) + (t & 3)] * S2[t, rp, lane]
                 out[8 * c + cc] += acc                                  # summed over q by xrow_sum in the kernel
         sw_head = np.array([sw[a] for a in range(16)])          # lane c = a (any q) holds sw[a]
