@@ -75,10 +75,12 @@ __device__ __forceinline__ int etype(bool src_lig, int lig_i) { return src_lig ?
 // ---- edge-major path for one half (16 edges): pre-activation -> LayerNorm -> ReLU -> contraction with a
 // per-lane row of B (Qt[i][a] for scores, Wbv[a] for the h2x values).  Returns the 16x16 result tile:
 // lane (c = a, q), reg r <-> edge 4q + r + 16hf.  `kv` selects the k (0) or v (1) quarter everywhere.
+template <bool PRE>
 __device__ __forceinline__ floatx4 edge_major_half(const float* __restrict__ P, int i, int j, bool lg, int kv,
                                                    const float* lds_frag, const float* lds_dwt, const float* lds_ln,
                                                    const float (&R)[5], bool has_prot, bool has_lig, int lig_i,
-                                                   int lane, int q, const float* __restrict__ Brow) {
+                                                   int lane, int q, const float* __restrict__ Brow,
+                                                   const float4 (&pre)[8]) {
     floatx4 acc[8];
     {
         const float* pd = P + (size_t)i * PROW + kv * H + 4 * q;
@@ -120,7 +122,7 @@ __device__ __forceinline__ floatx4 edge_major_half(const float* __restrict__ P, 
     for (int t = 0; t < 8; ++t) {
         const floatx4 g = f4(ld4(lg_ + 16 * t)), b = f4(ld4(lb_ + 16 * t));
         const floatx4 y = (acc[t] * rstd) * g + b;
-        const float4 bb = ld4(Brow + 16 * t);
+        const float4 bb = PRE ? pre[t] : ld4(Brow + 16 * t);
         out0 = MFMA(fmaxf(y.x, 0.f), bb.x, out0);
         out1 = MFMA(fmaxf(y.y, 0.f), bb.y, out1);
         out0 = MFMA(fmaxf(y.z, 0.f), bb.z, out0);
@@ -129,7 +131,9 @@ __device__ __forceinline__ floatx4 edge_major_half(const float* __restrict__ P, 
     return out0 + out1;
 }
 
-template <bool X2H, int WAVES>
+// ABL (timing ablations only, results are wrong when != 0): 1 no Qt streaming (row 0 for every node),
+// 2 no neighbour gathers (every neighbour row = own row), 3 no rbf pre-activation MFMAs, 4 = 1+2, 5 = 1+2+3
+template <bool X2H, int WAVES, int ABL>
 __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     const float* __restrict__ att, const float* __restrict__ x, const float* __restrict__ h,
     const float* __restrict__ P, const float* __restrict__ Qt, const int32_t* __restrict__ nbr,
@@ -169,41 +173,70 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         i_step = gridDim.x * WAVES;
     }
 
-    for (int i = i_begin; i < i_end; i += i_step) {
-        const int d = deg[i];
-        const int lig_i = lig[i];
-        const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
-        // ---- stage 0: geometry, E0 mapping: lane (c, q) <-> edges c and c + 16 ---------------------------
-        int j0[2];
-        bool lg0[2];
-        float R[2][5];
+    // ---- stage 0 is software-pipelined one node ahead: (a) deg / lig / x_i / neighbour ids, (b) neighbour
+    // coordinates and flags.  E0 mapping: lane (c, q) <-> edges c and c + 16.
+    int d = 0, lig_i = 0;
+    float xi = 0.f, yi = 0.f, zi = 0.f;
+    int j0[2] = {0, 0};
+    bool lg0[2] = {false, false};
+    float dist0[2] = {0.f, 0.f};
+    if (i_begin < i_end) {
+        const int i = i_begin;
+        d = deg[i]; lig_i = lig[i];
+        xi = x[3 * i]; yi = x[3 * i + 1]; zi = x[3 * i + 2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int e = c + 16 * hf;
             const bool valid = e < d;
-            const int j = valid ? nbr[(size_t)i * KNN + e] : i;
+            const int j = (valid && ABL != 2 && ABL < 4) ? nbr[(size_t)i * KNN + e] : i;
             j0[hf] = j;
             lg0[hf] = valid && lig[j];
             const float rx = xi - x[3 * j], ry = yi - x[3 * j + 1], rz = zi - x[3 * j + 2];
-            const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
+            dist0[hf] = sqrtf(rx * rx + ry * ry + rz * rz);
+        }
+    }
+
+    for (int i = i_begin; i < i_end; i += i_step) {
+        const int inext = i + i_step;
+        const bool more = inext < i_end;   // wave-uniform
+        // this node's folded query row (B operand of the score MFMAs): issue now, consume after the pre-activation
+        float4 qrow[8];
+        {
+            const float* qp = Qt + ((size_t)((ABL == 1 || ABL >= 4) ? 0 : i) * HEADS + c) * H + 4 * q;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) qrow[t] = ld4(qp + 16 * t);
+        }
+        // next node, stage (a)
+        int nd = 0, nlig = 0, njr[2] = {0, 0};
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        if (more) {
+            nd = deg[inext]; nlig = lig[inext];
+            nx = x[3 * inext]; ny = x[3 * inext + 1]; nz = x[3 * inext + 2];
+            njr[0] = nbr[(size_t)inext * KNN + c];
+            njr[1] = nbr[(size_t)inext * KNN + 16 + c];
+        }
+        float R[2][5];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const bool valid = c + 16 * hf < d;
 #pragma unroll
             for (int s = 0; s < 5; ++s) {
-                const float u = dist - mu[s];
+                const float u = dist0[hf] - mu[s];
                 R[hf][s] = valid ? expf(-0.5f * (u * u)) : 0.f;
             }
         }
         const unsigned long long b0 = __ballot(lg0[0]), b1 = __ballot(lg0[1]);
         const unsigned mask_lig = (unsigned)(b0 & 0xffffull) | ((unsigned)(b1 & 0xffffull) << 16);
         const unsigned mask_valid = d >= 32 ? 0xffffffffu : ((1u << d) - 1u);
-        const bool has_lig = (mask_lig & mask_valid) != 0;
-        const bool has_prot = ((~mask_lig) & mask_valid) != 0 || d == 0;
+        const bool has_lig = (mask_lig & mask_valid) != 0 && ABL != 3 && ABL != 5;
+        const bool has_prot = (((~mask_lig) & mask_valid) != 0 || d == 0) && ABL != 3 && ABL != 5;
 
         // ---- k path: hidden (edge-major) -> scores -> softmax ------------------------------------------
         floatx4 sc[2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            sc[hf] = edge_major_half(P, i, j0[hf], lg0[hf], 0, lds_fk, lds_dwt, lds_ln, R[hf], has_prot, has_lig, lig_i,
-                                     lane, q, Qt + ((size_t)i * HEADS + c) * H + 4 * q);
+            sc[hf] = edge_major_half<true>(P, i, j0[hf], lg0[hf], 0, lds_fk, lds_dwt, lds_ln, R[hf], has_prot, has_lig,
+                                           lig_i, lane, q, nullptr, qrow);
             __builtin_amdgcn_sched_barrier(0);
         }
         // E1 mapping: lane (c = head a, q), reg (hf, r) <-> edge e = 4q + r + 16hf
@@ -235,6 +268,21 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         const int4 nb0 = *reinterpret_cast<const int4*>(nbr + (size_t)i * KNN + 4 * q);
         const int4 nb1 = *reinterpret_cast<const int4*>(nbr + (size_t)i * KNN + 16 + 4 * q);
         const int nb[2][4] = {{nb0.x, nb0.y, nb0.z, nb0.w}, {nb1.x, nb1.y, nb1.z, nb1.w}};
+        // next node, stage (b): neighbour coordinates / flags (their ids arrived during the k path)
+        int nj[2] = {0, 0};
+        bool nlg[2] = {false, false};
+        float ndist[2] = {0.f, 0.f};
+        if (more) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const bool valid = c + 16 * hf < nd;
+                const int j = (valid && ABL != 2 && ABL < 4) ? njr[hf] : inext;
+                nj[hf] = j;
+                nlg[hf] = valid && lig[j];
+                const float rx = nx - x[3 * j], ry = ny - x[3 * j + 1], rz = nz - x[3 * j + 2];
+                ndist[hf] = sqrtf(rx * rx + ry * ry + rz * rz);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
 
         if (X2H) {
@@ -266,7 +314,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int e = 4 * q + r + 16 * hf;
-                    const int j = e < d ? nb[hf][r] : i;
+                    const int j = (e < d && ABL != 2 && ABL < 4) ? nb[hf][r] : i;
                     const float* ps = P + (size_t)j * PROW + 3 * H + 4 * c;
                     const float4 sa = ld4(ps), sb = ld4(ps + 64);
                     hv[0][r] = pdv[0] + sa.x; hv[1][r] = pdv[1] + sa.y; hv[2][r] = pdv[2] + sa.z; hv[3][r] = pdv[3] + sa.w;
@@ -347,8 +395,8 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             floatx4 wv[2];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                wv[hf] = edge_major_half(P, i, j0[hf], lg0[hf], 1, lds_fv, lds_dwt, lds_ln, R[hf], has_prot, has_lig,
-                                         lig_i, lane, q, att + A_WBV + (size_t)c * H + 4 * q);
+                wv[hf] = edge_major_half<false>(P, i, j0[hf], lg0[hf], 1, lds_fv, lds_dwt, lds_ln, R[hf], has_prot, has_lig,
+                                                lig_i, lane, q, att + A_WBV + (size_t)c * H + 4 * q, qrow);
                 __builtin_amdgcn_sched_barrier(0);
             }
             const float bbv = att[A_BBV + c];
@@ -374,6 +422,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                 out[3 * i + lane] = xin + (gen[i] ? v : 0.f);
             }
         }
+        // rotate the pipelined geometry
+        d = nd; lig_i = nlig; xi = nx; yi = ny; zi = nz;
+        j0[0] = nj[0]; j0[1] = nj[1]; lg0[0] = nlg[0]; lg0[1] = nlg[1]; dist0[0] = ndist[0]; dist0[1] = ndist[1];
     }
 }
 
@@ -449,24 +500,35 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
                             const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,
                             hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
-    // waves per (persistent, one-per-CU) workgroup: 8 -> 256 VGPRs, 12 -> 168, 16 -> 128 per lane.
+    // waves per (persistent, one-per-CU) workgroup: 8 -> 256 VGPRs, 12 -> 168 per lane.
     static const int waves = [] {
         const char* e = getenv("CBGX_EDGE_WAVES");
-        const int w = e ? atoi(e) : 12;
-        return (w == 8 || w == 12 || w == 16) ? w : 12;
+        const int w = e ? atoi(e) : 8;
+        return (w == 8 || w == 12) ? w : 8;
+    }();
+    static const int abl = [] {
+        const char* e = getenv("CBGX_EDGE_ABL");
+        const int a = e ? atoi(e) : 0;
+        return (a >= 0 && a <= 5) ? a : 0;
     }();
     int grid = (n_nodes + waves - 1) / waves;
     if (grid > 256) grid = 256;                 // persistent: one workgroup per CU (LDS-limited)
     if (grid >= 64) grid &= ~7;                 // multiple of 8 -> XCD-aware node partition
     profile_mark_begin(x2h ? K_EDGE_X2H : K_EDGE_H2X, s);
-#define CBGX_LAUNCH_EDGE(X2H_, W_)                                                                                  \
-    hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W_>), dim3(grid), dim3(W_ * 64), 0, s, att, x, h, P, Qt, nbr, deg, lig, \
-                       gen, e_w, n_nodes, out, dx_out)
-    if (x2h) {
-        if (waves == 8) CBGX_LAUNCH_EDGE(true, 8); else if (waves == 12) CBGX_LAUNCH_EDGE(true, 12); else CBGX_LAUNCH_EDGE(true, 16);
+#define CBGX_LAUNCH_EDGE(X2H_, W_, A_)                                                                                  \
+    hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W_, A_>), dim3(grid), dim3(W_ * 64), 0, s, att, x, h, P, Qt, nbr, deg,   \
+                       lig, gen, e_w, n_nodes, out, dx_out)
+#define CBGX_LAUNCH_ABL(X2H_, A_) case A_: CBGX_LAUNCH_EDGE(X2H_, 8, A_); break;
+    if (waves == 12) {
+        if (x2h) CBGX_LAUNCH_EDGE(true, 12, 0); else CBGX_LAUNCH_EDGE(false, 12, 0);
+    } else if (x2h) {
+        switch (abl) { CBGX_LAUNCH_ABL(true, 1) CBGX_LAUNCH_ABL(true, 2) CBGX_LAUNCH_ABL(true, 3) CBGX_LAUNCH_ABL(true, 4)
+                       CBGX_LAUNCH_ABL(true, 5) default: CBGX_LAUNCH_EDGE(true, 8, 0); }
     } else {
-        if (waves == 8) CBGX_LAUNCH_EDGE(false, 8); else if (waves == 12) CBGX_LAUNCH_EDGE(false, 12); else CBGX_LAUNCH_EDGE(false, 16);
+        switch (abl) { CBGX_LAUNCH_ABL(false, 1) CBGX_LAUNCH_ABL(false, 2) CBGX_LAUNCH_ABL(false, 3) CBGX_LAUNCH_ABL(false, 4)
+                       CBGX_LAUNCH_ABL(false, 5) default: CBGX_LAUNCH_EDGE(false, 8, 0); }
     }
+#undef CBGX_LAUNCH_ABL
 #undef CBGX_LAUNCH_EDGE
     profile_mark_end(s);
     return hipGetLastError();
