@@ -95,6 +95,7 @@ int cbgx_pack_weights(const float* const* t, int num_tensors, int L, int C, floa
     CP(t[3], GH, 0, 0, packed + GATE_LNB, GH, 1, GH);
     CP(t[4], GH, 0, 0, packed + GATE_W2, GH, 1, GH);
     CP(t[5], 1, 0, 0, packed + GATE_B2, 1, 1, 1);
+    HIP_TRY(launch_pack_gate_img(t[0], t[1], t[2], t[3], t[4], packed + GATE_IMG, s));
     for (int l = 0; l < L; ++l) {
         for (int blk = 0; blk < 2; ++blk) {
             const float* const* p = t + 6 + 36 * l + 18 * blk;  // k(6) v(6) q(6)

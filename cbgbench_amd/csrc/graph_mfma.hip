@@ -1,0 +1,259 @@
+// libcbgx -- once-per-step graph kernels, second generation:
+//   knn_graph_reg_kernel : kNN with the wave's candidate keys cached in registers (graphs up to 768 nodes)
+//   edge_gate_mfma_kernel: the global distance gate MLP (20 -> 160 -> LN -> ReLU -> 1 -> sigmoid) on MFMA
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "layout.h"
+
+namespace cbgx {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__constant__ float c_mu2[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.75f, 3.f,
+                               3.5f, 4.f, 4.5f, 5.f, 5.5f, 6.f, 7.f, 8.f, 9.f, 10.f};
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float g_xrow_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// lexicographic min of (hi, lo) pairs over the wave; every lane gets the result
+__device__ __forceinline__ void take_min(unsigned& hi, unsigned& lo, unsigned ohi, unsigned olo) {
+    const bool t = ohi < hi || (ohi == hi && olo < lo);
+    hi = t ? ohi : hi;
+    lo = t ? olo : lo;
+}
+__device__ __forceinline__ void wave_min_pair(unsigned& hi, unsigned& lo) {
+    take_min(hi, lo, dpp_u32<0xB1>(hi), dpp_u32<0xB1>(lo));     // quad_perm [1,0,3,2]
+    take_min(hi, lo, dpp_u32<0x4E>(hi), dpp_u32<0x4E>(lo));     // quad_perm [2,3,0,1]
+    take_min(hi, lo, dpp_u32<0x141>(hi), dpp_u32<0x141>(lo));   // row_half_mirror
+    take_min(hi, lo, dpp_u32<0x140>(hi), dpp_u32<0x140>(lo));   // row_mirror
+    {
+        auto a = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        auto b = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        unsigned h0 = a[0], l0 = b[0];
+        take_min(h0, l0, a[1], b[1]);
+        hi = h0; lo = l0;
+    }
+    {
+        auto a = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        auto b = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        unsigned h0 = a[0], l0 = b[0];
+        take_min(h0, l0, a[1], b[1]);
+        hi = h0; lo = l0;
+    }
+}
+
+__device__ __forceinline__ float dist2_exact2(float ax, float ay, float az, float bx, float by, float bz) {
+#pragma clang fp contract(off)
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float s = dx * dx;
+    float t = dy * dy;
+    s = s + t;
+    t = dz * dz;
+    s = s + t;
+    return s;
+}
+
+// One wave per centre node.  Each lane caches the keys (bits(d2), j) of its <= KNN_SLOTS candidates in registers;
+// 32 rounds of {lane-local min, wave min, retire the winner}.  Ordering = (squared distance, index), bit-identical
+// to the oracle (d2 computed with contraction off).  Graphs larger than 64 * KNN_SLOTS use knn_graph_kernel.
+constexpr int KNN_SLOTS = 12;
+
+__global__ __launch_bounds__(256) void knn_graph_reg_kernel(const float* __restrict__ x,
+                                                            const int32_t* __restrict__ graph_ptr, int n_graphs,
+                                                            int n_nodes, int32_t* __restrict__ nbr,
+                                                            int32_t* __restrict__ deg) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_nodes) return;
+    int lo_g = 0, hi_g = n_graphs;
+    while (hi_g - lo_g > 1) {
+        const int mid = (lo_g + hi_g) >> 1;
+        if (graph_ptr[mid] <= i) lo_g = mid; else hi_g = mid;
+    }
+    const int gs = graph_ptr[lo_g], ge = graph_ptr[lo_g + 1];
+    const int n = ge - gs;
+    const int d = min(KNN, n - 1);
+    const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
+    int mine = -1;   // lane r keeps the r-th neighbour
+    if (n <= 64 * KNN_SLOTS) {
+        unsigned khi[KNN_SLOTS], klo[KNN_SLOTS];
+#pragma unroll
+        for (int u = 0; u < KNN_SLOTS; ++u) {
+            const int j = gs + lane + 64 * u;
+            khi[u] = 0xffffffffu;
+            klo[u] = 0xffffffffu;
+            if (j < ge && j != i) {
+                khi[u] = __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * j], x[3 * j + 1], x[3 * j + 2]));
+                klo[u] = (unsigned)j;
+            }
+        }
+        for (int r = 0; r < KNN; ++r) {
+            if (r >= d) break;
+            unsigned bh = 0xffffffffu, bl = 0xffffffffu;
+#pragma unroll
+            for (int u = 0; u < KNN_SLOTS; ++u) take_min(bh, bl, khi[u], klo[u]);
+            wave_min_pair(bh, bl);
+#pragma unroll
+            for (int u = 0; u < KNN_SLOTS; ++u)
+                if (klo[u] == bl) { khi[u] = 0xffffffffu; klo[u] = 0xffffffffu; }   // indices are unique
+            if (lane == r) mine = (int)bl;
+        }
+    } else {
+        // large graph: rescan the candidates every round, keeping the smallest key greater than the previous one
+        unsigned ph = 0u, pl = 0u;
+        bool first = true;
+        for (int r = 0; r < KNN; ++r) {
+            if (r >= d) break;
+            unsigned bh = 0xffffffffu, bl = 0xffffffffu;
+            for (int j = gs + lane; j < ge; j += 64) {
+                if (j == i) continue;
+                const unsigned kh = __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * j], x[3 * j + 1], x[3 * j + 2]));
+                const unsigned kl = (unsigned)j;
+                const bool after = first || kh > ph || (kh == ph && kl > pl);
+                if (after) take_min(bh, bl, kh, kl);
+            }
+            wave_min_pair(bh, bl);
+            ph = bh; pl = bl; first = false;
+            if (lane == r) mine = (int)bl;
+        }
+    }
+    if (lane < KNN) nbr[(size_t)i * KNN + lane] = mine;
+    if (lane == 0) deg[i] = d < 0 ? 0 : d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gate: one wave per node; per half (16 edges) the hidden layer is 10 edge-major tiles: lane (c = edge, q),
+// C row rho = 4q + r <-> hidden unit u = 16t + rho.  W1 is centred over its 160 outputs at pack time, so
+// LayerNorm needs only sum(y^2).  Fragments [t 10][s 5][lane] = W1c[u = 16t + c][g = 4s + q].
+// ------------------------------------------------------------------------------------------------
+constexpr int GT = GH / 16;  // 10 tiles
+
+__global__ __launch_bounds__(256) void edge_gate_mfma_kernel(const float* __restrict__ wts,
+                                                             const float* __restrict__ x,
+                                                             const int32_t* __restrict__ nbr,
+                                                             const int32_t* __restrict__ deg, int n_nodes,
+                                                             float* __restrict__ e_w) {
+    __shared__ __attribute__((aligned(16))) float lds[GATE_IMG_SIZE];
+    for (int t = threadIdx.x; t < (int)GATE_IMG_SIZE / 4; t += 256)
+        reinterpret_cast<float4*>(lds)[t] = reinterpret_cast<const float4*>(wts + GATE_IMG)[t];
+    __syncthreads();
+    const float* l_frag = lds;                       // [10][5][64]
+    const float* l_b1 = lds + GT * 5 * 64;           // centred bias [160]
+    const float* l_g = l_b1 + GH;
+    const float* l_be = l_g + GH;
+    const float* l_w2 = l_be + GH;
+    const float b2 = wts[GATE_B2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    float mu[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) mu[s] = c_mu2[4 * s + q];
+    for (int i = blockIdx.x * 4 + wave; i < n_nodes; i += gridDim.x * 4) {
+        const int d = deg[i];
+        const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int e = c + 16 * hf;
+            const bool valid = e < d;
+            const int j = valid ? nbr[(size_t)i * KNN + e] : i;
+            const float rx = xi - x[3 * j], ry = yi - x[3 * j + 1], rz = zi - x[3 * j + 2];
+            const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
+            float R[5];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) { const float u = dist - mu[s]; R[s] = expf(-0.5f * (u * u)); }
+            floatx4 acc[GT];
+#pragma unroll
+            for (int t = 0; t < GT; ++t) {
+                const float4 b = *reinterpret_cast<const float4*>(l_b1 + 16 * t + 4 * q);
+                acc[t] = floatx4{b.x, b.y, b.z, b.w};
+            }
+#pragma unroll
+            for (int s = 0; s < 5; ++s)
+#pragma unroll
+                for (int t = 0; t < GT; ++t) acc[t] = MFMA(l_frag[(t * 5 + s) * 64 + lane], R[s], acc[t]);
+            float v = 0.f;
+#pragma unroll
+            for (int t = 0; t < GT; ++t)
+                v += (acc[t].x * acc[t].x + acc[t].y * acc[t].y) + (acc[t].z * acc[t].z + acc[t].w * acc[t].w);
+            v = g_xrow_sum(v);
+            const float rstd = 1.f / sqrtf(v * (1.f / GH) + 1e-5f);
+            float z = 0.f;
+#pragma unroll
+            for (int t = 0; t < GT; ++t) {
+                const float4 g = *reinterpret_cast<const float4*>(l_g + 16 * t + 4 * q);
+                const float4 be = *reinterpret_cast<const float4*>(l_be + 16 * t + 4 * q);
+                const float4 w2 = *reinterpret_cast<const float4*>(l_w2 + 16 * t + 4 * q);
+                z = fmaf(fmaxf((acc[t].x * rstd) * g.x + be.x, 0.f), w2.x, z);
+                z = fmaf(fmaxf((acc[t].y * rstd) * g.y + be.y, 0.f), w2.y, z);
+                z = fmaf(fmaxf((acc[t].z * rstd) * g.z + be.z, 0.f), w2.z, z);
+                z = fmaf(fmaxf((acc[t].w * rstd) * g.w + be.w, 0.f), w2.w, z);
+            }
+            z = g_xrow_sum(z) + b2;
+            if (q == 0) e_w[(size_t)i * KNN + e] = valid ? 1.f / (1.f + expf(-z)) : 0.f;
+        }
+    }
+}
+
+// gate LDS image: frag [10][5][64] | b1c [160] | gamma [160] | beta [160] | w2 [160]
+__global__ void pack_gate_img_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                     const float* __restrict__ g, const float* __restrict__ be,
+                                     const float* __restrict__ w2, float* __restrict__ img) {
+    __shared__ float colmean[G + 1];
+    if (threadIdx.x <= G) {
+        float s = 0.f;
+        for (int u = 0; u < GH; ++u) s += threadIdx.x < G ? w1[u * G + threadIdx.x] : b1[u];
+        colmean[threadIdx.x] = s * (1.f / GH);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < GT * 5 * 64; idx += blockDim.x) {
+        const int lane = idx & 63, s = (idx >> 6) % 5, t = idx / 320;
+        const int u = 16 * t + (lane & 15), gg = 4 * s + (lane >> 4);
+        img[idx] = w1[u * G + gg] - colmean[gg];
+    }
+    float* p = img + GT * 5 * 64;
+    for (int u = threadIdx.x; u < GH; u += blockDim.x) {
+        p[u] = b1[u] - colmean[G];
+        p[GH + u] = g[u];
+        p[2 * GH + u] = be[u];
+        p[3 * GH + u] = w2[u];
+    }
+}
+
+hipError_t launch_pack_gate_img(const float* w1, const float* b1, const float* g, const float* be, const float* w2,
+                                float* img, hipStream_t s) {
+    hipLaunchKernelGGL(pack_gate_img_kernel, dim3(1), dim3(256), 0, s, w1, b1, g, be, w2, img);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_reg(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, int32_t* nbr,
+                          int32_t* deg, hipStream_t s) {
+    if (n_nodes == 0) return hipSuccess;
+    profile_mark_begin(K_KNN, s);
+    hipLaunchKernelGGL(knn_graph_reg_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, x, graph_ptr, n_graphs, n_nodes,
+                       nbr, deg);
+    profile_mark_end(s);
+    return hipGetLastError();
+}
+
+hipError_t launch_gate_mfma(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
+                            float* e_w, hipStream_t s) {
+    if (n_nodes == 0) return hipSuccess;
+    int grid = (n_nodes + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    profile_mark_begin(K_GATE, s);
+    hipLaunchKernelGGL(edge_gate_mfma_kernel, dim3(grid), dim3(256), 0, s, packed, x, nbr, deg, n_nodes, e_w);
+    profile_mark_end(s);
+    return hipGetLastError();
+}
+
+}  // namespace cbgx

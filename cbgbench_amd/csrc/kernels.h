@@ -29,6 +29,13 @@ hipError_t launch_pack_dwt(const float* wk, const float* wv, float* dst, hipStre
 hipError_t launch_pack_bn2(const float* att_wakc, const float* bq0, float* att, hipStream_t s);
 // x2h second v Linear [128 n][128 m] with 16-byte chunks XOR-swizzled by head (n >> 3)
 hipError_t launch_pack_wbv_swz(const float* w, float* dst, hipStream_t s);
+// second-generation graph kernels (graph_mfma.hip)
+hipError_t launch_pack_gate_img(const float* w1, const float* b1, const float* g, const float* be, const float* w2,
+                                float* img, hipStream_t s);
+hipError_t launch_knn_reg(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, int32_t* nbr,
+                          int32_t* deg, hipStream_t s);
+hipError_t launch_gate_mfma(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
+                            float* e_w, hipStream_t s);
 // MFMA node kernels (node_mfma.hip): P = h Wn + bn, q = MLP tail, Qt = folded query
 hipError_t launch_pack_node_frags(const float* wk0, const float* wv0, const float* wq0, const float* wq1,
                                   const float* wbk, float* att, hipStream_t s);

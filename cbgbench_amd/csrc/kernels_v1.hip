@@ -433,6 +433,7 @@ int g_edge_impl = 0;  // 0: MFMA edge kernels (edge_mfma.hip); 1: first-generati
 hipError_t launch_knn(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, int32_t* nbr,
                       int32_t* deg, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
+    if (g_edge_impl == 0) return launch_knn_reg(x, graph_ptr, n_graphs, n_nodes, nbr, deg, s);
     profile_mark_begin(K_KNN, s);
     hipLaunchKernelGGL(knn_graph_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, x, graph_ptr, n_graphs, n_nodes,
                        nbr, deg);
@@ -444,6 +445,7 @@ hipError_t launch_knn(const float* x, const int32_t* graph_ptr, int n_graphs, in
 hipError_t launch_gate(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
                        float* e_w, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
+    if (g_edge_impl == 0) return launch_gate_mfma(packed, x, nbr, deg, n_nodes, e_w, s);
     long total = (long)n_nodes * KNN;
     profile_mark_begin(K_GATE, s);
     hipLaunchKernelGGL(edge_gate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, packed, x, nbr, deg,

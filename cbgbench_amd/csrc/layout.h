@@ -22,7 +22,10 @@ constexpr size_t GATE_LNG = GATE_B1 + GH;        // [160]
 constexpr size_t GATE_LNB = GATE_LNG + GH;       // [160]
 constexpr size_t GATE_W2 = GATE_LNB + GH;        // [160]
 constexpr size_t GATE_B2 = GATE_W2 + GH;         // [1] (+3 pad)
-constexpr size_t GATE_SIZE = GATE_B2 + 4;
+// LDS image of the MFMA gate kernel: W1 fragments (centred) [10][5][64] | b1c | gamma | beta | w2 (160 each)
+constexpr size_t GATE_IMG = GATE_B2 + 4;
+constexpr size_t GATE_IMG_SIZE = (size_t)(GH / 16) * 5 * 64 + 4 * GH;   // 3840 floats
+constexpr size_t GATE_SIZE = GATE_IMG + GATE_IMG_SIZE;
 
 // ---- one attention block (x2h or h2x) ----
 constexpr size_t A_WN = 0;                        // [128][640] K-major node projection

@@ -59,6 +59,17 @@ def test_knn_graph_bitexact(golden_dir, case):
     assert bool((pad == -1).all())
 
 
+@pytest.mark.parametrize("sizes", [[1000], [770, 3, 900], [768, 769]])
+def test_knn_large_graphs_bitexact(sizes):
+    """graphs above the register-cached limit (768 nodes) take the rescanning path; both must match the oracle."""
+    g = torch.Generator().manual_seed(sum(sizes))
+    x = torch.randn(sum(sizes), 3, generator=g) * 6
+    batch = torch.cat([torch.full((n,), b) for b, n in enumerate(sizes)])
+    ref = OU.knn_graph(x, batch, 32)
+    nbr, deg = stages.knn_graph(x.to(DEV), graph_ptr_from_batch(batch.to(DEV)))
+    assert torch.equal(stages.edge_index_from_nbr(nbr, deg).cpu(), ref)
+
+
 @pytest.fixture(params=[0, 1], ids=["mfma", "valu"])
 def edge_impl(request):
     """Both generations of the fused edge kernels are checked against the reference."""
