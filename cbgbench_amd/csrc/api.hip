@@ -36,6 +36,8 @@ struct Workspace {
     float* P;
     float* Qt;
     float* q;
+    int* act;        // indices of gen_flag nodes (h2x work list)
+    int* act_count;
     float* hbuf[2];
     float* xbuf[2];
     size_t total;
@@ -53,6 +55,8 @@ static Workspace carve(void* base, int n) {
     w.P = (float*)take(N * PROW * 4);
     w.Qt = (float*)take(N * HEADS * H * 4);
     w.q = (float*)take(N * H * 4);
+    w.act = (int*)take(N * 4);
+    w.act_count = (int*)take(256);
     w.hbuf[0] = (float*)take(N * H * 4);
     w.hbuf[1] = (float*)take(N * H * 4);
     w.xbuf[0] = (float*)take(N * 3 * 4);
@@ -194,7 +198,7 @@ int cbgx_x2h_attention(const float* packed, int layer, const float* x, const flo
     if (workspace_bytes < w.total)
         return fail(CBGX_E_WORKSPACE, "x2h_attention: workspace %zu < %zu", workspace_bytes, w.total);
     HIP_TRY(launch_attention(true, packed + x2h_off(layer), x, h, nbr, deg, lig_flag, nullptr, e_w, n_nodes, w.P,
-                             w.Qt, w.q, h_out, nullptr, (hipStream_t)stream));
+                             w.Qt, w.q, h_out, nullptr, nullptr, nullptr, (hipStream_t)stream));
     return CBGX_OK;
 }
 
@@ -209,8 +213,9 @@ int cbgx_h2x_attention(const float* packed, int layer, const float* x, const flo
     Workspace w = carve(workspace, n_nodes);
     if (workspace_bytes < w.total)
         return fail(CBGX_E_WORKSPACE, "h2x_attention: workspace %zu < %zu", workspace_bytes, w.total);
+    HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, (hipStream_t)stream));
     HIP_TRY(launch_attention(false, packed + h2x_off(layer), x, h, nbr, deg, lig_flag, gen_flag, e_w, n_nodes, w.P,
-                             w.Qt, w.q, x_out, delta_x, (hipStream_t)stream));
+                             w.Qt, w.q, x_out, delta_x, w.act, w.act_count, (hipStream_t)stream));
     return CBGX_OK;
 }
 
@@ -244,15 +249,17 @@ int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_cla
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s));
     HIP_TRY(launch_gate(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s));
+    // H2X only ever moves gen_flag nodes (x_out = x + dx * gen_flag): list them once, run every h2x block on the list
+    HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, s));
     const float* xc = x;
     const float* hc = h;
     for (int l = 0; l < num_layers; ++l) {
         float* hn = (l == num_layers - 1) ? h_out : w.hbuf[l & 1];
         float* xn = (l == num_layers - 1) ? x_out : w.xbuf[l & 1];
         HIP_TRY(launch_attention(true, packed + x2h_off(l), xc, hc, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
-                                 w.P, w.Qt, w.q, hn, nullptr, s));
+                                 w.P, w.Qt, w.q, hn, nullptr, nullptr, nullptr, s));
         HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
-                                 w.P, w.Qt, w.q, xn, nullptr, s));
+                                 w.P, w.Qt, w.q, xn, nullptr, w.act, w.act_count, s));
         xc = xn;
         hc = hn;
     }

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     const float* __restrict__ att, const float* __restrict__ x, const float* __restrict__ h,
     const float* __restrict__ P, const float* __restrict__ Qt, const int32_t* __restrict__ nbr,
     const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig, const uint8_t* __restrict__ gen,
-    const float* __restrict__ e_w, int n_nodes, float* __restrict__ out, float* __restrict__ dx_out) {
+    const float* __restrict__ e_w, int n_nodes, float* __restrict__ out, float* __restrict__ dx_out,
+    const int* __restrict__ act, const int* __restrict__ act_count) {
     constexpr int IMG = X2H ? (int)IMG_SIZE_X2H : (int)IMG_SIZE_H2X;
     __shared__ __attribute__((aligned(16))) float lds[IMG];
     {
@@ -158,18 +159,28 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
     for (int s = 0; s < 5; ++s) mu[s] = c_mu[4 * s + q];
 
+    // Work list: all nodes, or (h2x) only the nodes that can move -- `act` lists them, its length lives on the
+    // device (no host sync).  For every other node x_out = x exactly (unitransformer.py:182), so they are copied.
+    const int n_items = act ? *act_count : n_nodes;
+    if (!X2H && act) {
+        for (int n = blockIdx.x * (WAVES * 64) + threadIdx.x; n < n_nodes; n += gridDim.x * WAVES * 64)
+            if (!gen[n]) {
+                out[3 * n] = x[3 * n]; out[3 * n + 1] = x[3 * n + 1]; out[3 * n + 2] = x[3 * n + 2];
+                if (dx_out) { dx_out[3 * n] = 0.f; dx_out[3 * n + 1] = 0.f; dx_out[3 * n + 2] = 0.f; }
+            }
+    }
     // XCD-aware persistent schedule: workgroup b runs on XCD b % 8 (observed dispatch order), so give every
-    // XCD one contiguous eighth of the node range: a graph's PS / Qt rows are then pulled into one L2 only.
+    // XCD one contiguous eighth of the item range: a graph's PS / Qt rows are then pulled into one L2 only.
     int i_begin, i_end, i_step;
     if ((gridDim.x & 7) == 0) {
-        const int per_xcd = (((n_nodes + 7) >> 3) + WAVES - 1) / WAVES * WAVES;
+        const int per_xcd = (((n_items + 7) >> 3) + WAVES - 1) / WAVES * WAVES;
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         i_begin = xcd * per_xcd + slot * WAVES + wave;
-        i_end = min(n_nodes, (xcd + 1) * per_xcd);
+        i_end = min(n_items, (xcd + 1) * per_xcd);
         i_step = (gridDim.x >> 3) * WAVES;
     } else {
         i_begin = blockIdx.x * WAVES + wave;
-        i_end = n_nodes;
+        i_end = n_items;
         i_step = gridDim.x * WAVES;
     }
 
@@ -180,8 +191,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     int j0[2] = {0, 0};
     bool lg0[2] = {false, false};
     float dist0[2] = {0.f, 0.f};
+    int node = 0;   // node id of the current item
     if (i_begin < i_end) {
-        const int i = i_begin;
+        const int i = act ? act[i_begin] : i_begin;
+        node = i;
         d = deg[i]; lig_i = lig[i];
         xi = x[3 * i]; yi = x[3 * i + 1]; zi = x[3 * i + 2];
 #pragma unroll
@@ -196,9 +209,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         }
     }
 
-    for (int i = i_begin; i < i_end; i += i_step) {
-        const int inext = i + i_step;
-        const bool more = inext < i_end;   // wave-uniform
+    for (int k = i_begin; k < i_end; k += i_step) {
+        const int i = node;
+        const bool more = k + i_step < i_end;   // wave-uniform
+        const int inext = more ? (act ? act[k + i_step] : k + i_step) : 0;
         // this node's folded query row (B operand of the score MFMAs): issue now, consume after the pre-activation
         float4 qrow[8];
         {
@@ -423,6 +437,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             }
         }
         // rotate the pipelined geometry
+        node = inext;
         d = nd; lig_i = nlig; xi = nx; yi = ny; zi = nz;
         j0[0] = nj[0]; j0[1] = nj[1]; lg0[0] = nlg[0]; lg0[1] = nlg[1]; dist0[0] = ndist[0]; dist0[1] = ndist[1];
     }
@@ -498,7 +513,7 @@ hipError_t launch_pack_frag(const float* w_a, int mode, float* dst, hipStream_t 
 hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,
                             const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                             const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,
-                            hipStream_t s) {
+                            const int* act, const int* act_count, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
     // waves per (persistent, one-per-CU) workgroup: 8 -> 256 VGPRs, 12 -> 168 per lane.
     static const int waves = [] {
@@ -517,7 +532,7 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
     profile_mark_begin(x2h ? K_EDGE_X2H : K_EDGE_H2X, s);
 #define CBGX_LAUNCH_EDGE(X2H_, W_, A_)                                                                                  \
     hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W_, A_>), dim3(grid), dim3(W_ * 64), 0, s, att, x, h, P, Qt, nbr, deg,   \
-                       lig, gen, e_w, n_nodes, out, dx_out)
+                       lig, gen, e_w, n_nodes, out, dx_out, act, act_count)
 #define CBGX_LAUNCH_ABL(X2H_, A_) case A_: CBGX_LAUNCH_EDGE(X2H_, 8, A_); break;
     if (waves == 12) {
         if (x2h) CBGX_LAUNCH_EDGE(true, 12, 0); else CBGX_LAUNCH_EDGE(false, 12, 0);

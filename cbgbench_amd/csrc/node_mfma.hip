@@ -37,20 +37,36 @@ __device__ __forceinline__ float nxrow_sum(float v) {
 constexpr int NP_CHUNK = 4 * 8 * 64 * 4;  // 8192 floats = 32 KB
 constexpr int NP_CHUNKS = PROW / 64;      // 10
 
+// `rows` / `n_rows_ptr` (optional): compute only the listed rows (device-side count, no host sync); results are
+// written to their natural positions P[rows[k]].  `chunk_mask`: which of the 10 column chunks to produce.
 __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict__ att, const float* __restrict__ h,
                                                         const uint8_t* __restrict__ lig, float* __restrict__ P,
-                                                        int n_nodes) {
+                                                        int n_nodes, const int* __restrict__ rows,
+                                                        const int* __restrict__ n_rows_ptr, unsigned chunk_mask) {
     __shared__ __attribute__((aligned(16))) float lds[2][NP_CHUNK];
     const float* frag = att + A_NPROJ_FRAG;
     const float* bias = att + A_BN2;  // [dst class][640]: bias + type column of a protein source
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
-    const int n_tiles = (n_nodes + 63) / 64;
+    const int n_rows = rows ? *n_rows_ptr : n_nodes;
+    const int n_tiles = (n_rows + 63) / 64;
+    int sel[NP_CHUNKS + 1];
+    int n_sel = 0;
+#pragma unroll
+    for (int ch = 0; ch < NP_CHUNKS; ++ch)
+        if ((chunk_mask >> ch) & 1u) sel[n_sel++] = ch;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int row0 = tile * 64 + wave * 16;
-        const int arow = min(row0 + c, n_nodes - 1);
+        const int ak = min(row0 + c, n_rows - 1);
+        const int arow = rows ? rows[ak] : ak;
+        int orow[4];
         bool lgr[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lgr[r] = lig[min(row0 + 4 * q + r, n_nodes - 1)] != 0;
+        for (int r = 0; r < 4; ++r) {
+            const int k = row0 + 4 * q + r;
+            const int kk = min(k, n_rows - 1);
+            orow[r] = k < n_rows ? (rows ? rows[kk] : kk) : -1;
+            lgr[r] = lig[rows ? rows[kk] : kk] != 0;
+        }
         float a[32];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -59,20 +75,23 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
         }
         __syncthreads();  // previous tile's readers of lds[0] are done
         {
-            const float4* src = reinterpret_cast<const float4*>(frag);
+            const float4* src = reinterpret_cast<const float4*>(frag + (size_t)sel[0] * NP_CHUNK);
             float4* dst = reinterpret_cast<float4*>(lds[0]);
 #pragma unroll
             for (int u = 0; u < NP_CHUNK / 4 / 256; ++u) dst[tid + 256 * u] = src[tid + 256 * u];
         }
         __syncthreads();
-        for (int ch = 0; ch < NP_CHUNKS; ++ch) {
+        for (int is = 0; is < n_sel; ++is) {
+            int ch = 0, chn = 0;   // sel[] is indexed with compile-time constants only (no scratch)
+#pragma unroll
+            for (int u = 0; u < NP_CHUNKS; ++u) { if (u == is) ch = sel[u]; if (u == is + 1) chn = sel[u]; }
             float4 stage[NP_CHUNK / 4 / 256];
-            if (ch + 1 < NP_CHUNKS) {
-                const float4* src = reinterpret_cast<const float4*>(frag + (size_t)(ch + 1) * NP_CHUNK);
+            if (is + 1 < n_sel) {
+                const float4* src = reinterpret_cast<const float4*>(frag + (size_t)chn * NP_CHUNK);
 #pragma unroll
                 for (int u = 0; u < NP_CHUNK / 4 / 256; ++u) stage[u] = src[tid + 256 * u];
             }
-            const float* B = lds[ch & 1];
+            const float* B = lds[is & 1];
             const float4 bP = nld4(bias + 64 * ch + 4 * c), bL = nld4(bias + PROW + 64 * ch + 4 * c);
             floatx4 acc[4];
 #pragma unroll
@@ -96,14 +115,13 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 4 * q + r;
-                if (row < n_nodes) {
+                if (orow[r] >= 0) {
                     float4 o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-                    *reinterpret_cast<float4*>(P + (size_t)row * PROW + 64 * ch + 4 * c) = o;
+                    *reinterpret_cast<float4*>(P + (size_t)orow[r] * PROW + 64 * ch + 4 * c) = o;
                 }
             }
-            if (ch + 1 < NP_CHUNKS) {
-                float4* dst = reinterpret_cast<float4*>(lds[(ch + 1) & 1]);
+            if (is + 1 < n_sel) {
+                float4* dst = reinterpret_cast<float4*>(lds[(is + 1) & 1]);
 #pragma unroll
                 for (int u = 0; u < NP_CHUNK / 4 / 256; ++u) dst[tid + 256 * u] = stage[u];
             }
@@ -119,7 +137,8 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
 constexpr int NQ_FRAG = 8 * 8 * 64 * 4;  // 16384 floats = 64 KB
 
 __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict__ att, const float* __restrict__ P,
-                                                        float* __restrict__ qout, int n_nodes) {
+                                                        float* __restrict__ qout, int n_nodes,
+                                                        const int* __restrict__ rows, const int* __restrict__ n_rows_ptr) {
     __shared__ __attribute__((aligned(16))) float lds[NQ_FRAG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
     {
@@ -128,10 +147,18 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
         for (int t = tid; t < NQ_FRAG / 4; t += 256) dst[t] = src[t];
     }
     __syncthreads();
-    const int n_tiles = (n_nodes + 63) / 64;
+    const int n_rows = rows ? *n_rows_ptr : n_nodes;
+    const int n_tiles = (n_rows + 63) / 64;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int row0 = tile * 64 + wave * 16;
-        const int arow = min(row0 + c, n_nodes - 1);
+        const int ak = min(row0 + c, n_rows - 1);
+        const int arow = rows ? rows[ak] : ak;
+        int orow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = row0 + 4 * q + r;
+            orow[r] = k < n_rows ? (rows ? rows[k] : k) : -1;
+        }
         float z[32];
         float sm = 0.f;
 #pragma unroll
@@ -174,10 +201,9 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 4 * q + r;
-                if (row < n_nodes) {
+                if (orow[r] >= 0) {
                     float4 o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-                    *reinterpret_cast<float4*>(qout + (size_t)row * H + 64 * grp + 4 * c) = o;
+                    *reinterpret_cast<float4*>(qout + (size_t)orow[r] * H + 64 * grp + 4 * c) = o;
                 }
             }
         }
@@ -191,7 +217,8 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
 constexpr int NF_FRAG = 16 * 2 * 64 * 8;  // 16384 floats = 64 KB
 
 __global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict__ att, const float* __restrict__ qin,
-                                                         float* __restrict__ Qt, int n_nodes) {
+                                                         float* __restrict__ Qt, int n_nodes,
+                                                         const int* __restrict__ rows, const int* __restrict__ n_rows_ptr) {
     __shared__ __attribute__((aligned(16))) float lds[NF_FRAG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
     {
@@ -200,10 +227,18 @@ __global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict
         for (int t = tid; t < NF_FRAG / 4; t += 256) dst[t] = src[t];
     }
     __syncthreads();
-    const int n_tiles = (n_nodes + 63) / 64;
+    const int n_rows = rows ? *n_rows_ptr : n_nodes;
+    const int n_tiles = (n_rows + 63) / 64;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int row0 = tile * 64 + wave * 16;
-        const int arow = min(row0 + c, n_nodes - 1);
+        const int ak = min(row0 + c, n_rows - 1);
+        const int arow = rows ? rows[ak] : ak;
+        int orow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = row0 + 4 * q + r;
+            orow[r] = k < n_rows ? (rows ? rows[k] : k) : -1;
+        }
         float2 qa[HEADS];
 #pragma unroll
         for (int a = 0; a < HEADS; ++a) qa[a] = *reinterpret_cast<const float2*>(qin + (size_t)arow * H + 8 * a + 2 * q);
@@ -221,10 +256,9 @@ __global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict
                 acc[2] = MFMA(qa[a].y, b1.y, acc[2]); acc[3] = MFMA(qa[a].y, b1.w, acc[3]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = row0 + 4 * q + r;
-                    if (row < n_nodes) {
+                    if (orow[r] >= 0) {
                         float4 o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-                        *reinterpret_cast<float4*>(Qt + ((size_t)row * HEADS + a) * H + 64 * g + 4 * c) = o;
+                        *reinterpret_cast<float4*>(Qt + ((size_t)orow[r] * HEADS + a) * H + 64 * g + 4 * c) = o;
                     }
                 }
             }
@@ -297,19 +331,56 @@ hipError_t launch_pack_node_frags(const float* wk0, const float* wv0, const floa
     return hipGetLastError();
 }
 
-// node stage of one attention block: P, q (scratch), Qt
+// compact the indices of flagged nodes (gen_flag) -> list[0 .. *count); order is irrelevant (each node is computed
+// independently, so results are identical for any order).  *count must be zero on entry.
+__global__ void build_active_kernel(const uint8_t* __restrict__ flag, int n, int* __restrict__ list,
+                                    int* __restrict__ count) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool a = idx < n && flag[idx] != 0;
+    const unsigned long long m = __ballot(a);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (a) list[base + __popcll(m & ((1ull << lane) - 1ull))] = idx;
+}
+
+hipError_t launch_build_active(const uint8_t* flag, int n, int* list, int* count, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(build_active_kernel, dim3((n + 255) / 256), dim3(256), 0, s, flag, n, list, count);
+    return hipGetLastError();
+}
+
+constexpr unsigned CHUNKS_ALL = 0x3ffu;   // PDk PDv PSk PSv qh
+constexpr unsigned CHUNKS_PS = 0x0f0u;    // PSk | PSv  (columns 256..511): what *neighbours* contribute
+constexpr unsigned CHUNKS_OWN = 0x30fu;   // PDk | PDv | qh: what the destination node itself contributes
+
+// node stage of one attention block: P, q (scratch), Qt.
+// `act` / `act_count` (optional): only the listed destination nodes will be processed by the edge kernel (h2x: nodes
+// that can move).  Every node can still be a *source*, so PS is produced for all rows, PD / q / Qt only for the list.
 hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,
-                            float* Qt, hipStream_t s) {
+                            float* Qt, const int* act, const int* act_count, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
     const int tiles = (n_nodes + 63) / 64;
+    const int grid = min(tiles, 512);
     profile_mark_begin(K_NODE_GEMM, s);
-    hipLaunchKernelGGL(node_proj_kernel, dim3(min(tiles, 512)), dim3(256), 0, s, att, h, lig, P, n_nodes);
+    if (!act) {
+        hipLaunchKernelGGL(node_proj_kernel, dim3(grid), dim3(256), 0, s, att, h, lig, P, n_nodes, (const int*)nullptr,
+                           (const int*)nullptr, CHUNKS_ALL);
+    } else {
+        hipLaunchKernelGGL(node_proj_kernel, dim3(grid), dim3(256), 0, s, att, h, lig, P, n_nodes, (const int*)nullptr,
+                           (const int*)nullptr, CHUNKS_PS);
+        hipLaunchKernelGGL(node_proj_kernel, dim3(grid), dim3(256), 0, s, att, h, lig, P, n_nodes, act, act_count,
+                           CHUNKS_OWN);
+    }
     profile_mark_end(s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     profile_mark_begin(K_NODE_QUERY, s);
-    hipLaunchKernelGGL(node_qmlp_kernel, dim3(min(tiles, 512)), dim3(256), 0, s, att, P, qbuf, n_nodes);
-    hipLaunchKernelGGL(node_qfold_kernel, dim3(min(tiles, 512)), dim3(256), 0, s, att, qbuf, Qt, n_nodes);
+    hipLaunchKernelGGL(node_qmlp_kernel, dim3(grid), dim3(256), 0, s, att, P, qbuf, n_nodes, act, act_count);
+    hipLaunchKernelGGL(node_qfold_kernel, dim3(grid), dim3(256), 0, s, att, qbuf, Qt, n_nodes, act, act_count);
     profile_mark_end(s);
     return hipGetLastError();
 }

@@ -94,7 +94,8 @@ int cbgx_x2h_attention(const float *packed, int layer, const float *x, const flo
 
 /* H2XAttention.forward, repo/modules/attention/h2x_attention.py:34-73, plus the masked update of
  * E3DualAttentionLayer.forward (unitransformer.py:178-184): x_out = x + delta_x * gen_flag.
- * delta_x[N,3] (may be NULL) receives the raw attention output. */
+ * Only gen_flag nodes are computed (the others cannot move); delta_x[N,3] (may be NULL) receives the attention
+ * output for gen_flag nodes and 0 elsewhere. */
 int cbgx_h2x_attention(const float *packed, int layer, const float *x, const float *h,
                        const int32_t *nbr, const int32_t *deg, const uint8_t *lig_flag,
                        const uint8_t *gen_flag, const float *e_w, int n_nodes,
