@@ -142,6 +142,26 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     const int* __restrict__ act, const int* __restrict__ act_count) {
     constexpr int IMG = X2H ? (int)IMG_SIZE_X2H : (int)IMG_SIZE_H2X;
     __shared__ __attribute__((aligned(16))) float lds[IMG];
+    if (!X2H && act) {
+        // work list mode: x_out = x for every node that cannot move (done by all workgroups, before any early exit)
+        for (int n = blockIdx.x * (WAVES * 64) + threadIdx.x; n < n_nodes; n += gridDim.x * WAVES * 64)
+            if (!gen[n]) {
+                out[3 * n] = x[3 * n]; out[3 * n + 1] = x[3 * n + 1]; out[3 * n + 2] = x[3 * n + 2];
+                if (dx_out) { dx_out[3 * n] = 0.f; dx_out[3 * n + 1] = 0.f; dx_out[3 * n + 2] = 0.f; }
+            }
+    }
+    const int n_items = act ? *act_count : n_nodes;
+    {   // a workgroup with no item skips the LDS fill altogether
+        int first;
+        if ((gridDim.x & 7) == 0) {
+            const int per_xcd = (((n_items + 7) >> 3) + WAVES - 1) / WAVES * WAVES;
+            first = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) * WAVES;
+            if (first >= min(n_items, ((int)(blockIdx.x & 7) + 1) * per_xcd)) return;
+        } else {
+            first = blockIdx.x * WAVES;
+            if (first >= n_items) return;
+        }
+    }
     {
         const float4* src = reinterpret_cast<const float4*>(att + A_IMG);
         float4* dst = reinterpret_cast<float4*>(lds);
@@ -159,16 +179,6 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
     for (int s = 0; s < 5; ++s) mu[s] = c_mu[4 * s + q];
 
-    // Work list: all nodes, or (h2x) only the nodes that can move -- `act` lists them, its length lives on the
-    // device (no host sync).  For every other node x_out = x exactly (unitransformer.py:182), so they are copied.
-    const int n_items = act ? *act_count : n_nodes;
-    if (!X2H && act) {
-        for (int n = blockIdx.x * (WAVES * 64) + threadIdx.x; n < n_nodes; n += gridDim.x * WAVES * 64)
-            if (!gen[n]) {
-                out[3 * n] = x[3 * n]; out[3 * n + 1] = x[3 * n + 1]; out[3 * n + 2] = x[3 * n + 2];
-                if (dx_out) { dx_out[3 * n] = 0.f; dx_out[3 * n + 1] = 0.f; dx_out[3 * n + 2] = 0.f; }
-            }
-    }
     // XCD-aware persistent schedule: workgroup b runs on XCD b % 8 (observed dispatch order), so give every
     // XCD one contiguous eighth of the item range: a graph's PS / Qt rows are then pulled into one L2 only.
     int i_begin, i_end, i_step;

@@ -49,11 +49,8 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
     const int n_tiles = (n_rows + 63) / 64;
-    int sel[NP_CHUNKS + 1];
-    int n_sel = 0;
-#pragma unroll
-    for (int ch = 0; ch < NP_CHUNKS; ++ch)
-        if ((chunk_mask >> ch) & 1u) sel[n_sel++] = ch;
+    if ((int)blockIdx.x >= n_tiles || chunk_mask == 0) return;   // whole workgroup: nothing to do
+    const int first_chunk = __ffs(chunk_mask) - 1;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int row0 = tile * 64 + wave * 16;
         const int ak = min(row0 + c, n_rows - 1);
@@ -75,18 +72,21 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
         }
         __syncthreads();  // previous tile's readers of lds[0] are done
         {
-            const float4* src = reinterpret_cast<const float4*>(frag + (size_t)sel[0] * NP_CHUNK);
+            const float4* src = reinterpret_cast<const float4*>(frag + (size_t)first_chunk * NP_CHUNK);
             float4* dst = reinterpret_cast<float4*>(lds[0]);
 #pragma unroll
             for (int u = 0; u < NP_CHUNK / 4 / 256; ++u) dst[tid + 256 * u] = src[tid + 256 * u];
         }
         __syncthreads();
-        for (int is = 0; is < n_sel; ++is) {
-            int ch = 0, chn = 0;   // sel[] is indexed with compile-time constants only (no scratch)
-#pragma unroll
-            for (int u = 0; u < NP_CHUNKS; ++u) { if (u == is) ch = sel[u]; if (u == is + 1) chn = sel[u]; }
+        unsigned todo = chunk_mask;
+        for (int is = 0; todo != 0; ++is) {
+            const int ch = __ffs(todo) - 1;      // wave-uniform scalar bit scan over the selected chunks
+            todo &= todo - 1;
+            // prefetch the next selected chunk into registers (unconditional: the last iteration re-reads its own
+            // chunk and writes it to the idle buffer, which keeps `stage` in registers instead of scratch)
+            const int chn = todo != 0 ? __ffs(todo) - 1 : ch;
             float4 stage[NP_CHUNK / 4 / 256];
-            if (is + 1 < n_sel) {
+            {
                 const float4* src = reinterpret_cast<const float4*>(frag + (size_t)chn * NP_CHUNK);
 #pragma unroll
                 for (int u = 0; u < NP_CHUNK / 4 / 256; ++u) stage[u] = src[tid + 256 * u];
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
                     *reinterpret_cast<float4*>(P + (size_t)orow[r] * PROW + 64 * ch + 4 * c) = o;
                 }
             }
-            if (is + 1 < n_sel) {
+            {
                 float4* dst = reinterpret_cast<float4*>(lds[(is + 1) & 1]);
 #pragma unroll
                 for (int u = 0; u < NP_CHUNK / 4 / 256; ++u) dst[tid + 256 * u] = stage[u];
@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
                                                         const int* __restrict__ rows, const int* __restrict__ n_rows_ptr) {
     __shared__ __attribute__((aligned(16))) float lds[NQ_FRAG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
+    if ((int)blockIdx.x >= ((rows ? *n_rows_ptr : n_nodes) + 63) / 64) return;   // no tile for this workgroup
     {
         const float4* src = reinterpret_cast<const float4*>(att + A_WQ1_FRAG);
         float4* dst = reinterpret_cast<float4*>(lds);
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict
                                                          const int* __restrict__ rows, const int* __restrict__ n_rows_ptr) {
     __shared__ __attribute__((aligned(16))) float lds[NF_FRAG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
+    if ((int)blockIdx.x >= ((rows ? *n_rows_ptr : n_nodes) + 63) / 64) return;   // no tile for this workgroup
     {
         const float4* src = reinterpret_cast<const float4*>(att + A_WBK_FRAG);
         float4* dst = reinterpret_cast<float4*>(lds);
