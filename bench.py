@@ -46,6 +46,17 @@ H2X_BYTES_PER_EDGE, H2X_BYTES_PER_NODE = 596, 536
 FLOPS_PER_EDGE_LAYER, FLOPS_PER_NODE_LAYER = 122880, 8 * 32768 + 131072
 
 
+def measured_traffic(n_nodes):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, profiles/traffic_x2h.json), scaled per node; None if absent."""
+    path = os.path.join(ROOT, "profiles", "traffic_x2h.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    return int(round((t["fetch_bytes_per_node"] + t["write_bytes_per_node"]) * n_nodes))
+
+
 def build_batch(pockets, samples, seed, num_classes=13):
     """P distinct pockets, each replicated S times with fresh ligand priors (sample.py:177-183)."""
     rng = np.random.default_rng(seed)
@@ -132,6 +143,9 @@ def main():
     rank, world, local = sharding.init_process_group()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
+    # one process per GPU; LOCAL_RANK -> device (modulo the visible devices so the multi-rank path can also be
+    # exercised on a 1-GPU box with CBGX_DIST_BACKEND=gloo)
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     model, sd = make_model(dev)
@@ -185,8 +199,9 @@ def main():
         layer_flops = FLOPS_PER_EDGE_LAYER * deg_edges + FLOPS_PER_NODE_LAYER * N
         dev_s_layer = 1e-3 * (ms[2] + ms[3] + ms[4] + ms[5]) / max(cnt[4], 1)
         out["roofline"] = {
-            "bound": "hbm", "kernel": "edge_attention_kernel<x2h>", "achieved": round(achieved, 2),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "bound": "hbm", "kernel": "cbgx::edge_mfma_kernel<x2h> (fused x2h edge kernel)", "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": measured_traffic(N),
             "algorithmic_bytes_per_launch": x2h_bytes, "avg_launch_us": round(1e6 * x2h_s, 3),
             "note": "algorithmic bytes = SURVEY.md 8d message-passing stage at the reference tensor boundary "
                     "(1032 B/edge + 1536 B/node) x edges/nodes per launch; the kernel is fused (edge MLP + "

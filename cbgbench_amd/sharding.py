@@ -23,7 +23,7 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("CBGX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -37,6 +37,8 @@ def reduce_max_sum(elapsed_s, units, device="cpu"):
     """(max over ranks of elapsed, sum over ranks of units): whole-job throughput = units_sum / elapsed_max."""
     if not (dist.is_available() and dist.is_initialized()):
         return float(elapsed_s), float(units)
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
     u = torch.tensor([float(units)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

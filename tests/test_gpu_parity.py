@@ -259,3 +259,22 @@ def test_linker_256_graphs_runs_and_freezes_context(model):
                                            lig_flag[s:e].cpu(), gen[s:e].cpu())
     close(xo[s:e], rx, "x_out (graph 17 of 256)")
     close(ho[s:e], rh, "h_out (graph 17 of 256)", scale=10.0)
+
+
+def test_no_movable_nodes(model, golden_dir):
+    """gen_flag all False: the h2x work list is empty, x must come back bit-identical, h / logits unaffected by that."""
+    g = load(golden_dir, "denoiser_2graphs")
+    x, h = g["x"].to(DEV), g["h"].to(DEV)
+    none = torch.zeros_like(g["gen_flag"]).to(DEV)
+    with torch.no_grad():
+        xo, ho, lo = model.denoiser(x=x, h=h, batch_idx=g["batch_idx"].to(DEV), lig_flag=g["lig_flag"].to(DEV),
+                                    gen_flag=none)
+    assert torch.equal(xo, x)
+    assert torch.isfinite(ho).all() and torch.isfinite(lo).all()
+    # layer-0 features do not depend on gen_flag at all
+    packed = model.denoiser.packed_weights(torch.device(DEV))
+    gp = graph_ptr_from_batch(g["batch_idx"].to(DEV))
+    nbr, deg = stages.knn_graph(x, gp)
+    e_w = stages.edge_gate(packed, x, nbr, deg)
+    h1 = stages.x2h_attention(packed, 0, x, h, nbr, deg, g["lig_flag"].to(DEV).to(torch.uint8), e_w)
+    close(h1, g["h_layer0"], "x2h layer 0")
