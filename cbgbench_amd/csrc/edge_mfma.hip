@@ -75,18 +75,18 @@ __device__ __forceinline__ int etype(bool src_lig, int lig_i) { return src_lig ?
 // ---- edge-major path for one half (16 edges): pre-activation -> LayerNorm -> ReLU -> contraction with a
 // per-lane row of B (Qt[i][a] for scores, Wbv[a] for the h2x values).  Returns the 16x16 result tile:
 // lane (c = a, q), reg r <-> edge 4q + r + 16hf.  `kv` selects the k (0) or v (1) quarter everywhere.
+// `pd` / `ps`: this node's and the neighbour's projection rows (8 float4 = channels 16t + 4q .. +3), loaded by the
+// caller so that the gathers of the second half are in flight while the first half computes.
 template <bool PRE>
-__device__ __forceinline__ floatx4 edge_major_half(const float* __restrict__ P, int i, int j, bool lg, int kv,
+__device__ __forceinline__ floatx4 edge_major_half(const float4 (&pd)[8], const float4 (&ps)[8], bool lg, int kv,
                                                    const float* lds_frag, const float* lds_dwt, const float* lds_ln,
                                                    const float (&R)[5], bool has_prot, bool has_lig, int lig_i,
                                                    int lane, int q, const float* __restrict__ Brow,
                                                    const float4 (&pre)[8]) {
     floatx4 acc[8];
     {
-        const float* pd = P + (size_t)i * PROW + kv * H + 4 * q;
-        const float* ps = P + (size_t)j * PROW + (2 + kv) * H + 4 * q;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = f4(ld4(pd + 16 * t)) + f4(ld4(ps + 16 * t));
+        for (int t = 0; t < 8; ++t) acc[t] = f4(pd[t]) + f4(ps[t]);
         if (has_lig) {  // wave-uniform: only nodes with a ligand neighbour pay for the type correction
             const float* dw = lds_dwt + lig_i * 2 * H + kv * H + 4 * q;
             const float m = lg ? 1.f : 0.f;
@@ -257,10 +257,20 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 
         // ---- k path: hidden (edge-major) -> scores -> softmax ------------------------------------------
         floatx4 sc[2];
+        {
+            float4 pd[8], ps0[8], ps1[8];
+            const float* pdp = P + (size_t)i * PROW + 4 * q;
+            const float* p0 = P + (size_t)j0[0] * PROW + 2 * H + 4 * q;
+            const float* p1 = P + (size_t)j0[1] * PROW + 2 * H + 4 * q;
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            sc[hf] = edge_major_half<true>(P, i, j0[hf], lg0[hf], 0, lds_fk, lds_dwt, lds_ln, R[hf], has_prot, has_lig,
-                                           lig_i, lane, q, nullptr, qrow);
+            for (int t = 0; t < 8; ++t) { pd[t] = ld4(pdp + 16 * t); ps0[t] = ld4(p0 + 16 * t); }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) ps1[t] = ld4(p1 + 16 * t);   // second half's gather flies during the first half
+            sc[0] = edge_major_half<true>(pd, ps0, lg0[0], 0, lds_fk, lds_dwt, lds_ln, R[0], has_prot, has_lig, lig_i, lane,
+                                          q, nullptr, qrow);
+            __builtin_amdgcn_sched_barrier(0);
+            sc[1] = edge_major_half<true>(pd, ps1, lg0[1], 0, lds_fk, lds_dwt, lds_ln, R[1], has_prot, has_lig, lig_i, lane,
+                                          q, nullptr, qrow);
             __builtin_amdgcn_sched_barrier(0);
         }
         // E1 mapping: lane (c = head a, q), reg (hf, r) <-> edge e = 4q + r + 16hf
@@ -332,15 +342,24 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             const float4 ba = ld4(lds_ln + 3 * H + 4 * c), bb = ld4(lds_ln + 3 * H + 64 + 4 * c);
             const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
             const float bv[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+            // PS_v rows of both halves are requested up front: the second half's gather flies during the first half
+            float4 sva[2][4], svb[2][4];
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                floatx4 hv[8];
+            for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int e = 4 * q + r + 16 * hf;
                     const int j = (e < d && ABL != 2 && ABL < 4) ? nb[hf][r] : i;
                     const float* ps = P + (size_t)j * PROW + 3 * H + 4 * c;
-                    const float4 sa = ld4(ps), sb = ld4(ps + 64);
+                    sva[hf][r] = ld4(ps);
+                    svb[hf][r] = ld4(ps + 64);
+                }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                floatx4 hv[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 sa = sva[hf][r], sb = svb[hf][r];
                     hv[0][r] = pdv[0] + sa.x; hv[1][r] = pdv[1] + sa.y; hv[2][r] = pdv[2] + sa.z; hv[3][r] = pdv[3] + sa.w;
                     hv[4][r] = pdv[4] + sb.x; hv[5][r] = pdv[5] + sb.y; hv[6][r] = pdv[6] + sb.z; hv[7][r] = pdv[7] + sb.w;
                 }
@@ -417,10 +436,21 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         } else {
             // ---- h2x: v hidden edge-major, wv[e][a] = Wbv[a] . hid_v[e] + bbv[a] -------------------------------
             floatx4 wv[2];
+            {
+                float4 pd[8], ps0[8], ps1[8];
+                const float* pdp = P + (size_t)i * PROW + H + 4 * q;
+                const float* p0 = P + (size_t)j0[0] * PROW + 3 * H + 4 * q;
+                const float* p1 = P + (size_t)j0[1] * PROW + 3 * H + 4 * q;
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                wv[hf] = edge_major_half<false>(P, i, j0[hf], lg0[hf], 1, lds_fv, lds_dwt, lds_ln, R[hf], has_prot, has_lig,
-                                                lig_i, lane, q, att + A_WBV + (size_t)c * H + 4 * q, qrow);
+                for (int t = 0; t < 8; ++t) { pd[t] = ld4(pdp + 16 * t); ps0[t] = ld4(p0 + 16 * t); }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) ps1[t] = ld4(p1 + 16 * t);
+                const float* wrow = att + A_WBV + (size_t)c * H + 4 * q;
+                wv[0] = edge_major_half<false>(pd, ps0, lg0[0], 1, lds_fv, lds_dwt, lds_ln, R[0], has_prot, has_lig, lig_i,
+                                               lane, q, wrow, qrow);
+                __builtin_amdgcn_sched_barrier(0);
+                wv[1] = edge_major_half<false>(pd, ps1, lg0[1], 1, lds_fv, lds_dwt, lds_ln, R[1], has_prot, has_lig, lig_i,
+                                               lane, q, wrow, qrow);
                 __builtin_amdgcn_sched_barrier(0);
             }
             const float bbv = att[A_BBV + c];
