@@ -49,6 +49,11 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
     const int n_tiles = (n_rows + 63) / 64;
+    if (gridDim.y > 1) {   // small inputs: one workgroup per (row tile, column chunk) instead of looping over chunks
+        unsigned m = chunk_mask;
+        for (unsigned k = 0; k < blockIdx.y; ++k) m &= m - 1;
+        chunk_mask = m & (0u - m);
+    }
     if ((int)blockIdx.x >= n_tiles || chunk_mask == 0) return;   // whole workgroup: nothing to do
     const int first_chunk = __ffs(chunk_mask) - 1;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -142,10 +147,11 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
     __shared__ __attribute__((aligned(16))) float lds[NQ_FRAG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
     if ((int)blockIdx.x >= ((rows ? *n_rows_ptr : n_nodes) + 63) / 64) return;   // no tile for this workgroup
+    const int grp_begin = gridDim.y > 1 ? blockIdx.y : 0, grp_end = gridDim.y > 1 ? blockIdx.y + 1 : 2;
     {
         const float4* src = reinterpret_cast<const float4*>(att + A_WQ1_FRAG);
         float4* dst = reinterpret_cast<float4*>(lds);
-        for (int t = tid; t < NQ_FRAG / 4; t += 256) dst[t] = src[t];
+        for (int t = grp_begin * (NQ_FRAG / 8) + tid; t < grp_end * (NQ_FRAG / 8); t += 256) dst[t] = src[t];
     }
     __syncthreads();
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
@@ -181,8 +187,7 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
             z[4 * u + 2] = fmaxf(z[4 * u + 2] * rstd * g.z + b.z, 0.f);
             z[4 * u + 3] = fmaxf(z[4 * u + 3] * rstd * g.w + b.w, 0.f);
         }
-#pragma unroll
-        for (int grp = 0; grp < 2; ++grp) {
+        for (int grp = grp_begin; grp < grp_end; ++grp) {
             const float4 b4 = nld4(att + A_BQ1 + 64 * grp + 4 * c);
             floatx4 acc[4] = {{b4.x, b4.x, b4.x, b4.x}, {b4.y, b4.y, b4.y, b4.y}, {b4.z, b4.z, b4.z, b4.z},
                               {b4.w, b4.w, b4.w, b4.w}};
@@ -223,10 +228,11 @@ __global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict
     __shared__ __attribute__((aligned(16))) float lds[NF_FRAG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
     if ((int)blockIdx.x >= ((rows ? *n_rows_ptr : n_nodes) + 63) / 64) return;   // no tile for this workgroup
+    const int heads_per = HEADS / gridDim.y, a_begin = blockIdx.y * heads_per, a_end = a_begin + heads_per;
     {
         const float4* src = reinterpret_cast<const float4*>(att + A_WBK_FRAG);
         float4* dst = reinterpret_cast<float4*>(lds);
-        for (int t = tid; t < NF_FRAG / 4; t += 256) dst[t] = src[t];
+        for (int t = a_begin * (NF_FRAG / 64) + tid; t < a_end * (NF_FRAG / 64); t += 256) dst[t] = src[t];
     }
     __syncthreads();
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
@@ -241,21 +247,18 @@ __global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict
             const int k = row0 + 4 * q + r;
             orow[r] = k < n_rows ? (rows ? rows[k] : k) : -1;
         }
-        float2 qa[HEADS];
-#pragma unroll
-        for (int a = 0; a < HEADS; ++a) qa[a] = *reinterpret_cast<const float2*>(qin + (size_t)arow * H + 8 * a + 2 * q);
-#pragma unroll
-        for (int a = 0; a < HEADS; ++a) {
+        for (int a = a_begin; a < a_end; ++a) {
+            const float2 qa = *reinterpret_cast<const float2*>(qin + (size_t)arow * H + 8 * a + 2 * q);
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const float* fb = lds + ((a * 2 + g) * 64 + lane) * 8;
                 const float4 b0 = nld4(fb), b1 = nld4(fb + 4);
                 floatx4 acc[4];
                 const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-                acc[0] = MFMA(qa[a].x, b0.x, zero); acc[1] = MFMA(qa[a].x, b0.z, zero);
-                acc[2] = MFMA(qa[a].x, b1.x, zero); acc[3] = MFMA(qa[a].x, b1.z, zero);
-                acc[0] = MFMA(qa[a].y, b0.y, acc[0]); acc[1] = MFMA(qa[a].y, b0.w, acc[1]);
-                acc[2] = MFMA(qa[a].y, b1.y, acc[2]); acc[3] = MFMA(qa[a].y, b1.w, acc[3]);
+                acc[0] = MFMA(qa.x, b0.x, zero); acc[1] = MFMA(qa.x, b0.z, zero);
+                acc[2] = MFMA(qa.x, b1.x, zero); acc[3] = MFMA(qa.x, b1.z, zero);
+                acc[0] = MFMA(qa.y, b0.y, acc[0]); acc[1] = MFMA(qa.y, b0.w, acc[1]);
+                acc[2] = MFMA(qa.y, b1.y, acc[2]); acc[3] = MFMA(qa.y, b1.w, acc[3]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (orow[r] >= 0) {
@@ -367,22 +370,26 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
     if (n_nodes == 0) return hipSuccess;
     const int tiles = (n_nodes + 63) / 64;
     const int grid = min(tiles, 512);
+    // few row tiles (small batches, or the h2x work list): spread the column chunks / heads over workgroups too
+    const bool small = tiles <= 128 || act != nullptr;
+    auto py = [&](unsigned mask) { return small ? (unsigned)__builtin_popcount(mask) : 1u; };
     profile_mark_begin(K_NODE_GEMM, s);
     if (!act) {
-        hipLaunchKernelGGL(node_proj_kernel, dim3(grid), dim3(256), 0, s, att, h, lig, P, n_nodes, (const int*)nullptr,
-                           (const int*)nullptr, CHUNKS_ALL);
+        hipLaunchKernelGGL(node_proj_kernel, dim3(grid, py(CHUNKS_ALL)), dim3(256), 0, s, att, h, lig, P, n_nodes,
+                           (const int*)nullptr, (const int*)nullptr, CHUNKS_ALL);
     } else {
-        hipLaunchKernelGGL(node_proj_kernel, dim3(grid), dim3(256), 0, s, att, h, lig, P, n_nodes, (const int*)nullptr,
-                           (const int*)nullptr, CHUNKS_PS);
-        hipLaunchKernelGGL(node_proj_kernel, dim3(grid), dim3(256), 0, s, att, h, lig, P, n_nodes, act, act_count,
-                           CHUNKS_OWN);
+        hipLaunchKernelGGL(node_proj_kernel, dim3(grid, tiles <= 128 ? py(CHUNKS_PS) : 1u), dim3(256), 0, s, att, h, lig, P,
+                           n_nodes, (const int*)nullptr, (const int*)nullptr, CHUNKS_PS);
+        hipLaunchKernelGGL(node_proj_kernel, dim3(grid, py(CHUNKS_OWN)), dim3(256), 0, s, att, h, lig, P, n_nodes, act,
+                           act_count, CHUNKS_OWN);
     }
     profile_mark_end(s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     profile_mark_begin(K_NODE_QUERY, s);
-    hipLaunchKernelGGL(node_qmlp_kernel, dim3(grid), dim3(256), 0, s, att, P, qbuf, n_nodes, act, act_count);
-    hipLaunchKernelGGL(node_qfold_kernel, dim3(grid), dim3(256), 0, s, att, qbuf, Qt, n_nodes, act, act_count);
+    hipLaunchKernelGGL(node_qmlp_kernel, dim3(grid, small ? 2 : 1), dim3(256), 0, s, att, P, qbuf, n_nodes, act, act_count);
+    hipLaunchKernelGGL(node_qfold_kernel, dim3(grid, small ? 4 : 1), dim3(256), 0, s, att, qbuf, Qt, n_nodes, act,
+                       act_count);
     profile_mark_end(s);
     return hipGetLastError();
 }
