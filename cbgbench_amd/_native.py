@@ -23,6 +23,9 @@ EXPORTS = {
     "cbgx_x2h_attention": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "cbgx_h2x_attention": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "cbgx_classifier": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "cbgx_targetdiff_prologue": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cbgx_targetdiff_epilogue": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp,
+                                      _vp, _vp]),
     "cbgx_debug_set_edge_kernel": (_i, [_i]),
     "cbgx_profile_begin": (_i, [_i]),
     "cbgx_profile_end": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i), _i]),

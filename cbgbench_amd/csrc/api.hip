@@ -1,6 +1,7 @@
 // libcbgx C ABI (include/cbgx.h): argument checking, workspace carving, kernel sequencing.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -269,6 +270,34 @@ int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_cla
         HIP_TRY(launch_node_gemm(w.P, H, c + C_W1T, c + cls_b1(num_classes), logits, num_classes, n_nodes,
                                  num_classes, 0, s));
     }
+    return CBGX_OK;
+}
+
+int cbgx_targetdiff_prologue(const float* x_lig, const float* c_lig, const int32_t* lig_rows, int n_lig, int num_classes,
+                             const float* lig_emb_w, const float* lig_emb_b, const float* ind_w, const float* ind_b,
+                             float* x, float* h, void* stream) {
+    if (n_lig == 0) return CBGX_OK;
+    if (n_lig < 0 || num_classes < 1 || num_classes > 32) return fail(CBGX_E_INVALID, "prologue: bad sizes");
+    if (!x_lig || !c_lig || !lig_rows || !lig_emb_w || !lig_emb_b || !ind_w || !ind_b || !x || !h)
+        return fail(CBGX_E_INVALID, "prologue: NULL pointer");
+    HIP_TRY(launch_step_prologue(x_lig, c_lig, lig_rows, n_lig, num_classes, lig_emb_w, lig_emb_b, ind_w, ind_b, x, h,
+                                 (hipStream_t)stream));
+    return CBGX_OK;
+}
+
+int cbgx_targetdiff_epilogue(const float* x_den, const float* logits, const int32_t* lig_rows, const float* x_lig,
+                             const float* c_lig, const uint8_t* gen_lig, int n_lig, int num_classes, int t,
+                             int num_timesteps, const float* const* tables, const float* eps, const float* u,
+                             float* x_next, float* c_next, int32_t* v_next, void* stream) {
+    if (n_lig == 0) return CBGX_OK;
+    if (n_lig < 0 || num_classes < 1 || num_classes > 32 || t < 0 || t >= num_timesteps)
+        return fail(CBGX_E_INVALID, "epilogue: bad sizes (n_lig=%d C=%d t=%d T=%d)", n_lig, num_classes, t, num_timesteps);
+    if (!x_den || !logits || !lig_rows || !x_lig || !c_lig || !gen_lig || !tables || !eps || !u || !x_next || !c_next)
+        return fail(CBGX_E_INVALID, "epilogue: NULL pointer");
+    for (int i = 0; i < 7; ++i)
+        if (!tables[i]) return fail(CBGX_E_INVALID, "epilogue: table %d is NULL", i);
+    HIP_TRY(launch_step_epilogue(x_den, logits, lig_rows, x_lig, c_lig, gen_lig, n_lig, num_classes, t, tables,
+                                 (float)log((double)num_classes), eps, u, x_next, c_next, v_next, (hipStream_t)stream));
     return CBGX_OK;
 }
 

@@ -1,0 +1,116 @@
+// libcbgx -- the parts of one TargetDiff reverse-diffusion step that surround the denoiser, as two kernels:
+//   prologue: scatter the current ligand state into the composed node arrays
+//             x[row] = x_lig ; h[row] = ligand_atom_emb(c_lig) + ligand_indicator(1)     (context_emb.py:179-230)
+//   epilogue: posterior sampling of the next ligand state from the denoiser output
+//             positions  CTNVPScheduler.backward_remove_noise(type='denoise')   diffusion_scheduler.py:144-165
+//             atom types TypeVPScheduler.backward_remove_noise(pred_logit=True) :367-378, 407-441 + Gumbel argmax
+//                        (models/utils/categorical.py:26-32)
+// Noise (eps ~ N(0,1), u ~ U(0,1)) is an input, so the host decides the generator and tests can replay a tape.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "layout.h"
+
+namespace cbgx {
+
+constexpr int MAXC = 32;
+
+__global__ __launch_bounds__(128) void step_prologue_kernel(const float* __restrict__ x_lig, const float* __restrict__ c_lig,
+                                                            const int32_t* __restrict__ lig_rows, int n_lig, int C,
+                                                            const float* __restrict__ emb_w /*[128][C]*/,
+                                                            const float* __restrict__ emb_b, const float* __restrict__ ind_w,
+                                                            const float* __restrict__ ind_b, float* __restrict__ x,
+                                                            float* __restrict__ h) {
+    const int a = blockIdx.x, m = threadIdx.x;
+    if (a >= n_lig) return;
+    const int row = lig_rows[a];
+    float acc = 0.f;
+    for (int k = 0; k < C; ++k) acc = fmaf(emb_w[m * C + k], c_lig[(size_t)a * C + k], acc);
+    h[(size_t)row * H + m] = (acc + emb_b[m]) + (ind_w[m] + ind_b[m]);
+    if (m < 3) x[3 * row + m] = x_lig[3 * a + m];
+}
+
+__device__ __forceinline__ float log_add_exp(float a, float b) {
+    const float mx = fmaxf(a, b);
+    return mx + logf(expf(a - mx) + expf(b - mx));
+}
+
+__global__ __launch_bounds__(256) void step_epilogue_kernel(
+    const float* __restrict__ x_den, const float* __restrict__ logits, const int32_t* __restrict__ lig_rows,
+    const float* __restrict__ x_lig, const float* __restrict__ c_lig, const uint8_t* __restrict__ gen_lig, int n_lig, int C,
+    int t, const float* __restrict__ c0_tab, const float* __restrict__ ct_tab, const float* __restrict__ logvar_tab,
+    const float* __restrict__ log_alpha, const float* __restrict__ log_1m_alpha, const float* __restrict__ log_acp,
+    const float* __restrict__ log_1m_acp, float log_c, const float* __restrict__ eps, const float* __restrict__ u,
+    float* __restrict__ x_next, float* __restrict__ c_next, int32_t* __restrict__ v_next) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_lig) return;
+    const int row = lig_rows[a];
+    const bool gen = gen_lig[a] != 0;
+    // ---- positions
+    const float c0 = c0_tab[t], ct = ct_tab[t];
+    const float sigma = t > 0 ? expf(0.5f * logvar_tab[t]) : 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float xt = x_lig[3 * a + k];
+        const float xs = (c0 * x_den[3 * row + k] + ct * xt) + sigma * eps[3 * a + k];
+        x_next[3 * a + k] = gen ? xs : xt;
+    }
+    // ---- atom types
+    const float* lg = logits + (size_t)row * C;
+    float mx = -INFINITY;
+    for (int k = 0; k < C; ++k) mx = fmaxf(mx, lg[k]);
+    float se = 0.f;
+    for (int k = 0; k < C; ++k) se += expf(lg[k] - mx);
+    const float lse = mx + logf(se);
+    const int tm1 = t > 0 ? t - 1 : 0;
+    const float a0 = log_acp[tm1], b0 = log_1m_acp[tm1] - log_c;
+    const float a1 = log_alpha[t], b1 = log_1m_alpha[t] - log_c;
+    float un[MAXC];
+    float umx = -INFINITY;
+    int cur = 0;
+    float cur_v = -INFINITY;
+    for (int k = 0; k < C; ++k) {
+        const float ck = c_lig[(size_t)a * C + k];
+        if (ck > cur_v) { cur_v = ck; cur = k; }
+        const float lq0 = log_add_exp((lg[k] - lse) + a0, b0);
+        const float lq1 = log_add_exp(logf(ck + 1e-8f) + a1, b1);
+        un[k] = lq0 + lq1;
+        umx = fmaxf(umx, un[k]);
+    }
+    float us = 0.f;
+    for (int k = 0; k < C; ++k) us += expf(un[k] - umx);
+    const float ulse = umx + logf(us);
+    int best = 0;
+    float best_v = -INFINITY;
+    for (int k = 0; k < C; ++k) {
+        const float g = -logf(-logf(u[(size_t)a * C + k] + 1e-30f) + 1e-30f);
+        const float s = g + (un[k] - ulse);
+        if (s > best_v) { best_v = s; best = k; }
+    }
+    const int v = gen ? best : cur;
+    for (int k = 0; k < C; ++k) c_next[(size_t)a * C + k] = k == v ? 1.f : 0.f;
+    if (v_next) v_next[a] = v;
+}
+
+hipError_t launch_step_prologue(const float* x_lig, const float* c_lig, const int32_t* lig_rows, int n_lig, int C,
+                                const float* emb_w, const float* emb_b, const float* ind_w, const float* ind_b, float* x,
+                                float* h, hipStream_t s) {
+    if (n_lig == 0) return hipSuccess;
+    hipLaunchKernelGGL(step_prologue_kernel, dim3(n_lig), dim3(128), 0, s, x_lig, c_lig, lig_rows, n_lig, C, emb_w, emb_b,
+                       ind_w, ind_b, x, h);
+    return hipGetLastError();
+}
+
+hipError_t launch_step_epilogue(const float* x_den, const float* logits, const int32_t* lig_rows, const float* x_lig,
+                                const float* c_lig, const uint8_t* gen_lig, int n_lig, int C, int t,
+                                const float* const* tabs, float log_c, const float* eps, const float* u, float* x_next,
+                                float* c_next, int32_t* v_next, hipStream_t s) {
+    if (n_lig == 0) return hipSuccess;
+    hipLaunchKernelGGL(step_epilogue_kernel, dim3((n_lig + 255) / 256), dim3(256), 0, s, x_den, logits, lig_rows, x_lig,
+                       c_lig, gen_lig, n_lig, C, t, tabs[0], tabs[1], tabs[2], tabs[3], tabs[4], tabs[5], tabs[6], log_c, eps,
+                       u, x_next, c_next, v_next);
+    return hipGetLastError();
+}
+
+}  // namespace cbgx

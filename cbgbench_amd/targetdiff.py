@@ -19,6 +19,9 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+import ctypes
+
+from . import _native
 from .registry import get_e3_gnn, register_model
 from .unitransformer import graph_ptr_from_batch
 
@@ -234,9 +237,17 @@ class TargetDiff(nn.Module):
         h = torch.empty(N, self.context_embedder.emb_dim, dtype=torch.float32, device=dev)
         x[rec_rows] = x_rec
         h[rec_rows] = self.context_embedder.embed_protein(v_rec, aa)
-        st = dict(x=x, h=h, x_lig=x_lig, c_lig=c_lig, bl=bl, gen_l=gen_l, batch_idx=batch_idx, lig_flag=lig_flag,
-                  gen_flag=gen_flag, lig_rows=lig_rows, graph_ptr=graph_ptr, B=B, n_lig=n_lig, N=N,
+        st = dict(x=x, h=h, x_lig=x_lig.contiguous(), c_lig=c_lig.contiguous(), bl=bl, gen_l=gen_l, batch_idx=batch_idx,
+                  lig_flag=lig_flag, gen_flag=gen_flag, lig_rows=lig_rows, graph_ptr=graph_ptr, B=B, n_lig=n_lig, N=N,
                   traj_x=None, traj_c=None)
+        if dev.type == "cuda":
+            # operands of the native prologue / epilogue kernels (include/cbgx.h)
+            st["lig_rows32"] = lig_rows.to(torch.int32).contiguous()
+            st["gen_l8"] = gen_l.to(torch.uint8).contiguous()
+            ps, ts = self.pos_scheduler, self.type_scheduler
+            tabs = [ps.posterior_mean_c0_coef, ps.posterior_mean_ct_coef, ps.posterior_logvar, ts.log_alphas_v,
+                    ts.log_one_minus_alphas_v, ts.log_alphas_cumprod_v, ts.log_one_minus_alphas_cumprod_v]
+            st["tables"] = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in tabs])
         if keep_trajectory:
             # slot s+1 holds the state entering step s; slot 0 = final state (key -1 of the reference's dict)
             st["traj_x"] = torch.empty(T + 1, n_lig, 3, dtype=torch.float32, device=dev)
@@ -247,8 +258,12 @@ class TargetDiff(nn.Module):
 
     @torch.no_grad()
     def denoise_step(self, st, t_idx, noise=None):
-        """One iteration of the reverse-diffusion loop (targetdiff.py:150-182) on the sampling state."""
+        """One iteration of the reverse-diffusion loop (targetdiff.py:150-182) on the sampling state.
+        On the GPU the whole step is native: prologue kernel -> denoiser -> epilogue kernel (cbgx_targetdiff_*);
+        only the noise draw is a torch call (or the replayed tape)."""
         dev = st["x"].device
+        if dev.type == "cuda" and self.denoise_structure and self.denoise_atom:
+            return self._denoise_step_native(st, t_idx, noise)
         t = torch.full((st["B"],), t_idx, dtype=torch.long, device=dev)
         x, h, lig_rows = st["x"], st["h"], st["lig_rows"]
         x[lig_rows] = st["x_lig"]
@@ -266,6 +281,37 @@ class TargetDiff(nn.Module):
         if st["traj_x"] is not None:
             st["traj_x"][t_idx] = st["x_lig"]
             st["traj_c"][t_idx] = st["c_lig"]
+        return st
+
+    def _denoise_step_native(self, st, t_idx, noise):
+        lib = _native.lib()
+        dev = st["x"].device
+        stream = _native.current_stream(dev)
+        n_lig, C = st["n_lig"], self.num_classes
+        x_lig, c_lig = st["x_lig"], st["c_lig"]
+        emb = self.context_embedder
+        _native.check(lib.cbgx_targetdiff_prologue(
+            _native.ptr(x_lig), _native.ptr(c_lig), _native.ptr(st["lig_rows32"]), n_lig, C,
+            _native.ptr(emb.ligand_atom_emb.weight), _native.ptr(emb.ligand_atom_emb.bias),
+            _native.ptr(emb.ligand_indicator.weight), _native.ptr(emb.ligand_indicator.bias),
+            _native.ptr(st["x"]), _native.ptr(st["h"]), stream), "cbgx_targetdiff_prologue")
+        xo, _, logits = self.denoiser(x=st["x"], h=st["h"], batch_idx=st["batch_idx"], lig_flag=st["lig_flag"],
+                                      gen_flag=st["gen_flag"], graph_ptr=st["graph_ptr"])
+        if noise is not None:
+            eps, u = noise[0].float().contiguous(), noise[1].float().contiguous()
+        else:   # same draw order as the reference: randn_like(x_lig) then rand_like(log-probs)
+            eps = torch.randn(n_lig, 3, dtype=torch.float32, device=dev)
+            u = torch.rand(n_lig, C, dtype=torch.float32, device=dev)
+        if st["traj_x"] is not None:
+            x_next, c_next = st["traj_x"][t_idx], st["traj_c"][t_idx]
+        else:
+            x_next, c_next = torch.empty_like(x_lig), torch.empty_like(c_lig)
+        _native.check(lib.cbgx_targetdiff_epilogue(
+            _native.ptr(xo), _native.ptr(logits), _native.ptr(st["lig_rows32"]), _native.ptr(x_lig), _native.ptr(c_lig),
+            _native.ptr(st["gen_l8"]), n_lig, C, int(t_idx), self.num_diffusion_timesteps, st["tables"],
+            _native.ptr(eps), _native.ptr(u), _native.ptr(x_next), _native.ptr(c_next), None, stream),
+            "cbgx_targetdiff_epilogue")
+        st["x_lig"], st["c_lig"] = x_next, c_next
         return st
 
     @torch.no_grad()

@@ -105,6 +105,29 @@ int cbgx_h2x_attention(const float *packed, int layer, const float *x, const flo
 int cbgx_classifier(const float *packed, int num_layers, int num_classes, const float *h, int n_nodes,
                     float *logits, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- TargetDiff step prologue / epilogue ----------------------------------------------------------
+ * The per-step work around the denoiser in TargetDiff.sample (repo/models/diffusion/targetdiff.py:150-182).
+ * prologue: x[lig_rows[a]] = x_lig[a];  h[lig_rows[a]] = ligand_atom_emb(c_lig[a]) + ligand_indicator(1)
+ *           (PLContextEmbedder.forward, repo/modules/context_emb.py:179-230; no time embedding in shipped configs).
+ *           lig_emb_w [128,C], lig_emb_b [128], ind_w [128,1], ind_b [128] are the reference parameters
+ *           context_embedder.{ligand_atom_emb,ligand_indicator}.{weight,bias}; c_lig [n_lig,C] float (one-hot).
+ * epilogue: x_next = posterior sample of positions (CTNVPScheduler.backward_remove_noise 'denoise',
+ *           diffusion_scheduler.py:144-165), c_next / v_next = posterior sample of atom types by Gumbel-argmax
+ *           (TypeVPScheduler.backward_remove_noise, :367-378, 407-441; categorical.py:26-32); atoms with
+ *           gen_lig == 0 keep position and type.  x_den [N,3] / logits [N,C] are the denoiser outputs, read at
+ *           lig_rows.  `tables` = HOST array of 7 DEVICE pointers into the reference's frozen schedule tables:
+ *           pos_scheduler.{posterior_mean_c0_coef, posterior_mean_ct_coef, posterior_logvar},
+ *           type_scheduler.{log_alphas_v, log_one_minus_alphas_v, log_alphas_cumprod_v,
+ *           log_one_minus_alphas_cumprod_v}.  t is the (batch-uniform) step index; eps ~ N(0,1) [n_lig,3] and
+ *           u ~ U(0,1) [n_lig,C] are the noise draws (the reference draws randn_like then rand_like). */
+int cbgx_targetdiff_prologue(const float *x_lig, const float *c_lig, const int32_t *lig_rows, int n_lig,
+                             int num_classes, const float *lig_emb_w, const float *lig_emb_b, const float *ind_w,
+                             const float *ind_b, float *x, float *h, void *stream);
+int cbgx_targetdiff_epilogue(const float *x_den, const float *logits, const int32_t *lig_rows, const float *x_lig,
+                             const float *c_lig, const uint8_t *gen_lig, int n_lig, int num_classes, int t,
+                             int num_timesteps, const float *const *tables, const float *eps, const float *u,
+                             float *x_next, float *c_next, int32_t *v_next, void *stream);
+
 /* ---- measurement hook (bench.py) ----------------------------------------------------------------
  * Between cbgx_profile_begin() and cbgx_profile_end() every kernel launch is bracketed by HIP events on
  * its own stream.  cbgx_profile_end() synchronises them and returns, per kernel class, the summed

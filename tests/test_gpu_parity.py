@@ -278,3 +278,17 @@ def test_no_movable_nodes(model, golden_dir):
     e_w = stages.edge_gate(packed, x, nbr, deg)
     h1 = stages.x2h_attention(packed, 0, x, h, nbr, deg, g["lig_flag"].to(DEV).to(torch.uint8), e_w)
     close(h1, g["h_layer0"], "x2h layer 0")
+
+
+@pytest.mark.parametrize("case", ["step_t500", "step_t0", "step_t999_linker"])
+def test_native_step_kernels(golden_dir, model, case):
+    """begin_sampling + one native denoise_step (prologue kernel, denoiser, epilogue kernel) against the reference."""
+    g = load(golden_dir, case)
+    batch = {k[len("batch_"):]: v for k, v in g.items() if k.startswith("batch_")}
+    st = model.begin_sampling(synthetic.batch_to(batch, DEV), keep_trajectory=False)
+    model.denoise_step(st, int(g["t_idx"]), noise=(g["eps"].to(DEV), g["u"].to(DEV)))
+    close(st["x_lig"], g["x_next"], "x_{t-1}")
+    assert torch.equal(st["c_lig"].cpu(), g["c_next"])
+    if "ligand_gen_flag" in batch:
+        keep = ~batch["ligand_gen_flag"]
+        assert torch.equal(st["x_lig"].cpu()[keep], batch["ligand_pos"][keep])
