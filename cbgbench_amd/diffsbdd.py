@@ -1,0 +1,170 @@
+"""``diffsbdd`` model class behind the model registry (repo/models/diffusion/diffsbdd.py:23-361): same
+constructor config, same state-dict keys (``pos_scheduler.gamma.gamma``, ``type_scheduler.gamma.gamma``,
+``context_embedder.*``, ``denoiser.*``), same ``sample(batch) -> traj`` contract.  The denoiser call -- the
+hot path -- is the same libcbgx ``UniTransformer`` as TargetDiff; the variational (gamma-schedule) sampler
+around it is element-wise work on [N_lig,3] / [N_lig,C] and stays PyTorch on the device.
+
+Sampler semantics reproduced from the reference (quirks included, see oracle/diffsbdd.py): continuous atom
+types normalised by 4, the pocket re-centred on the ligand mean at every Gaussian draw (COM-free subspace), every
+ligand atom updated, ``traj[0]`` overwritten by the final ``sample_p_xh_given_z0`` result."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .registry import get_e3_gnn, register_model
+from .targetdiff import NUM_AA, PLContextEmbedder, TargetDiff
+
+
+class PredefinedNoiseSchedule(nn.Module):
+    """Frozen gamma lookup table, key ``gamma`` (repo/models/diffusion/schedule_utils.py:60-96)."""
+
+    def __init__(self, noise_schedule, timesteps, precision):
+        super().__init__()
+        self.timesteps = timesteps
+        if "polynomial" not in noise_schedule:
+            raise ValueError(noise_schedule)
+        splits = noise_schedule.split("_")
+        assert len(splits) == 2
+        power = float(splits[1])
+        steps = timesteps + 1
+        x = np.linspace(0, steps, steps)
+        alphas2 = (1 - np.power(x / steps, power)) ** 2
+        a2 = np.concatenate([np.ones(1), alphas2], axis=0)
+        alphas2 = np.cumprod(np.clip(a2[1:] / a2[:-1], a_min=0.001, a_max=1.0), axis=0)
+        alphas2 = (1 - 2 * precision) * alphas2 + precision
+        gamma = -(np.log(alphas2) - np.log(1 - alphas2))
+        self.gamma = nn.Parameter(torch.from_numpy(gamma).float(), requires_grad=False)
+
+    def forward(self, t):
+        return self.gamma[torch.round(t * self.timesteps).long()]
+
+
+class DiffsbddVariationalScheduler(nn.Module):
+    """The sampling half of the reference scheduler (diffusion_scheduler.py:577-760, 965-1040)."""
+
+    def __init__(self, num_timestep, type="polynomial_2"):
+        super().__init__()
+        self.num_timestep = num_timestep
+        if type == "learned":
+            raise NotImplementedError("learned gamma network is not used by any shipped config")
+        self.gamma = PredefinedNoiseSchedule(type, timesteps=num_timestep, precision=5e-4)
+
+    @staticmethod
+    def scatter_mean(src, index, n):
+        s = torch.zeros((n,) + src.shape[1:], dtype=src.dtype, device=src.device).index_add_(0, index, src)
+        cnt = torch.zeros(n, dtype=src.dtype, device=src.device).index_add_(
+            0, index, torch.ones(index.shape[0], dtype=src.dtype, device=src.device))
+        return s / cnt.clamp(min=1).view(-1, *[1] * (src.dim() - 1))
+
+    def remove_mean_batch(self, x_lig, x_rec, bl, br, B):
+        mean = self.scatter_mean(x_lig, bl, B)
+        return x_lig - mean[bl], x_rec - mean[br]
+
+    def sample_normal_zero_com(self, mu_lig, xh0_pocket, sigma, bl, br, B, com=False, eps=None):
+        if eps is None:
+            eps = torch.randn((bl.shape[0], mu_lig.size(1)), device=mu_lig.device)
+        out = mu_lig + sigma[bl] * eps
+        if com:
+            return self.remove_mean_batch(out, xh0_pocket, bl, br, B)
+        return out
+
+    def sample_p_zs_given_zt(self, s, t, zt_lig, xh0_pocket, bl, br, B, eps_t_lig, com=False, eps=None):
+        gs, gt = self.gamma(s), self.gamma(t)
+        sigma2_ts = (-torch.expm1(F.softplus(gs) - F.softplus(gt))).view(-1, 1)
+        alpha_ts = torch.exp(0.5 * (F.logsigmoid(-gt) - F.logsigmoid(-gs))).view(-1, 1)
+        sigma_s = torch.sqrt(torch.sigmoid(gs)).view(-1, 1)
+        sigma_t = torch.sqrt(torch.sigmoid(gt)).view(-1, 1)
+        mu = zt_lig / alpha_ts[bl] - (sigma2_ts / alpha_ts / sigma_t)[bl] * eps_t_lig
+        sigma = torch.sqrt(sigma2_ts) * sigma_s / sigma_t
+        if com:
+            return self.sample_normal_zero_com(mu, xh0_pocket, sigma, bl, br, B, com=True, eps=eps)
+        return self.sample_normal_zero_com(mu, xh0_pocket, sigma, bl, br, B, com=False, eps=eps), xh0_pocket
+
+
+@register_model("diffsbdd")
+class DiffSBDD(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        gen = cfg.generator
+        self.num_diffusion_timesteps = gen.num_diffusion_timesteps
+        self.denoise_structure = gen.get("denoise_structure", True)
+        self.denoise_atom = gen.get("denoise_atom", True)
+        self.num_classes = cfg.num_atomtype
+        self.pos_scheduler = DiffsbddVariationalScheduler(self.num_diffusion_timesteps, type=gen.pos_schedule.type)
+        self.type_scheduler = DiffsbddVariationalScheduler(self.num_diffusion_timesteps, type=gen.atom_schedule.type)
+        cfg.embedder.num_atomtype = cfg.num_atomtype
+        self.context_embedder = PLContextEmbedder(cfg.embedder)
+        self.denoiser = get_e3_gnn(cfg.encoder, num_classes=self.num_classes)
+        self.intersect_reg = cfg.get("intersect_reg", True)
+
+    def forward(self, batch):
+        raise NotImplementedError("training loss (diffsbdd.py:100-234) needs the backward kernels (DESIGN.md section 8)")
+
+    @torch.no_grad()
+    def sample(self, batch, noise_draws=None, return_device=None):
+        """diffsbdd.py:240-319. ``noise_draws`` (tests): list of the randn tensors in the reference's draw order."""
+        sch = self.pos_scheduler
+        x_rec = batch["protein_pos"].float()
+        dev = x_rec.device
+        v_rec = batch["protein_atom_feature"].float() / 4.0
+        bl, br = batch["ligand_element_batch"], batch["protein_element_batch"]
+        lig_flag_l = batch["ligand_lig_flag"]
+        gen_l = batch.get("ligand_gen_flag", lig_flag_l).bool()
+        gen_r = batch.get("protein_gen_flag", torch.zeros_like(batch["protein_lig_flag"])).bool()
+        T, C = self.num_diffusion_timesteps, self.num_classes
+        B = int(bl.max().item()) + 1
+        n_lig, n_rec = bl.shape[0], x_rec.shape[0]
+        draws = iter(noise_draws) if noise_draws is not None else None
+        nxt = (lambda: next(draws).to(dev)) if draws is not None else (lambda: None)
+
+        aa = F.one_hot(batch["protein_aa_type"], NUM_AA).float()
+        sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = TargetDiff.compose_plan(bl, br, B)
+        gen_flag = torch.cat([gen_r, gen_l], 0)[sort_idx]
+        rec_rows = torch.nonzero(~lig_flag).flatten()
+        x = torch.empty(n_rec + n_lig, 3, dtype=torch.float32, device=dev)
+        h = torch.empty(n_rec + n_lig, self.context_embedder.emb_dim, dtype=torch.float32, device=dev)
+        h[rec_rows] = self.context_embedder.embed_protein(v_rec, aa)          # step-invariant
+
+        def denoise(x_lig, c_lig, x_rec_now):
+            x[rec_rows] = x_rec_now                                          # the pocket is translated every draw
+            x[lig_rows] = x_lig
+            h[lig_rows] = self.context_embedder.embed_ligand(c_lig)
+            xo, _, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
+                                          graph_ptr=graph_ptr)
+            return xo[lig_rows], logits[lig_rows]
+
+        mu_x = sch.scatter_mean(x_rec, br, B)[bl]
+        mu_h = torch.zeros(B, C, device=dev)[bl]
+        sigma1 = torch.ones(B, 1, device=dev)
+        x_lig, x_rec = sch.sample_normal_zero_com(mu_x, x_rec, sigma1, bl, br, B, com=True, eps=nxt())
+        c_lig = sch.sample_normal_zero_com(mu_h, v_rec, sigma1, bl, br, B, com=False, eps=nxt())
+
+        traj_x = torch.empty(T + 1, n_lig, 3, dtype=torch.float32, device=dev)
+        traj_c = torch.empty(T + 1, n_lig, C, dtype=torch.float32, device=dev)
+        traj_x[T], traj_c[T] = x_lig, c_lig
+        for t_idx in reversed(range(T)):
+            s = torch.full((B,), t_idx, device=dev) / T
+            t = (torch.full((B,), t_idx, device=dev) + 1) / T
+            x_pred, c_out = denoise(x_lig, c_lig, x_rec)
+            if self.denoise_structure:
+                x_lig, x_rec = sch.sample_p_zs_given_zt(s, t, x_lig, x_rec, bl, br, B, x_pred, com=True, eps=nxt())
+            if self.denoise_atom:
+                c_lig, _ = sch.sample_p_zs_given_zt(s, t, c_lig, v_rec, bl, br, B, c_out, com=False, eps=nxt())
+            traj_x[t_idx], traj_c[t_idx] = x_lig, c_lig
+
+        # sample_p_xh_given_z0 (diffsbdd.py:321-352)
+        g0 = sch.gamma(torch.zeros(B, device=dev))
+        sigma0 = torch.exp(0.5 * g0).unsqueeze(1)
+        x_pred, c_out = denoise(x_lig, c_lig, x_rec)
+        sig_t = torch.sqrt(torch.sigmoid(g0)).view(-1, 1)
+        alp_t = torch.sqrt(torch.sigmoid(-g0)).view(-1, 1)
+        mu_x = 1.0 / alp_t[bl] * (x_lig - sig_t[bl] * x_pred)
+        x_fin, _ = sch.sample_normal_zero_com(mu_x, x_rec, sigma0, bl, br, B, com=True, eps=nxt())
+        nxt() if draws is not None else torch.randn(n_lig, C, device=dev)   # the reference draws and discards it
+        out_dev = torch.device("cpu") if return_device is None else torch.device(return_device)
+        traj_x, traj_c, bl_out = traj_x.to(out_dev), traj_c.to(out_dev), bl.to(out_dev)
+        traj = {t - 1: (traj_x[t], traj_c[t], bl_out) for t in range(T + 1)}
+        traj[0] = (x_fin.to(out_dev), (c_lig * 4.0).to(out_dev), bl_out)
+        return traj

@@ -124,6 +124,39 @@ def sample_case(name, batch, T, seed):
     print(name, "keys", sorted(traj.keys()))
 
 
+def diffsbdd_case(name, batch, T, seed):
+    """Full ``DiffSBDD.sample`` (diffsbdd.py:240-319) of a T-step model, torch RNG seeded; also dumps the state-dict
+    key listing and the reference's own gamma table."""
+    M = ref_shim.load_reference()
+    cfg = ref_shim.AttrDict(
+        type="diffsbdd", num_atomtype=8,
+        encoder=dict(type="unitransformer", node_feat_dim=128, n_heads=16, num_layers=9),
+        generator=dict(pos_schedule=dict(type="polynomial_2"), atom_schedule=dict(type="polynomial_2"),
+                       num_diffusion_timesteps=T, time_sampler="random"),
+        embedder=dict(emb_dim=128, atom=dict(type="linear"), residue=dict(type="linear")))
+    model = M.get_model(cfg).eval()
+    ref_sd = model.state_dict()
+    with open(os.path.join(OUT, "state_dict_keys_diffsbdd.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in ref_sd.items()}, f, indent=0)
+    sd = W.synthetic_state_dict_diffsbdd(8, 9, seed=0, num_timesteps=T)
+    assert torch.equal(sd["pos_scheduler.gamma.gamma"], ref_sd["pos_scheduler.gamma.gamma"])
+    model.load_state_dict(sd, strict=True)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        traj = model.sample(batch)
+    out = {"T": T, "seed": seed, "gamma": _np(ref_sd["pos_scheduler.gamma.gamma"])}
+    for k, (xx, cc, bb) in traj.items():
+        out[f"traj_x_{k}"] = _np(xx)
+        out[f"traj_c_{k}"] = _np(cc)
+    out.update({"batch_" + k: _np(v) for k, v in batch.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    # and the 1000-step gamma table of a freshly built reference model
+    cfg.generator.num_diffusion_timesteps = 1000
+    np.savez_compressed(os.path.join(OUT, "diffsbdd_gamma_T1000.npz"),
+                        gamma=_np(M.get_model(cfg).state_dict()["pos_scheduler.gamma.gamma"]))
+    print(name, "keys", sorted(traj.keys()))
+
+
 def eg5_pocket(radius=10.0):
     """scripts/example/Eg5 (PDB 3ZCW) heavy atoms of residues with any atom within ``radius`` A of
     a ligand heavy atom -- the pocket criterion of datasets/parsers/protein_parser.py:167-177 --
@@ -200,6 +233,7 @@ def main():
     step_case(model, "step_t0", small_batch([(64, 10), (50, 12)], seed=22), 0, seed=6)
     step_case(model, "step_t999_linker", small_batch([(58, 15), (44, 12)], seed=23, ctx=[10, 8]), 999, seed=7)
     sample_case("sample_T5", small_batch([(40, 8), (36, 6)], seed=31), T=5, seed=9)
+    diffsbdd_case("diffsbdd_sample_T5", small_batch([(42, 9), (38, 7)], seed=41, num_classes=8), T=5, seed=11)
 
 
 if __name__ == "__main__":

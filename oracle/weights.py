@@ -104,3 +104,15 @@ def synthetic_state_dict(num_classes=13, num_layers=9, seed=0, num_timesteps=100
     for key, shape, kind in embedder_spec(num_classes) + denoiser_spec(num_classes, num_layers):
         sd[key] = _gen(key, shape, kind, seed)
     return sd
+
+
+def synthetic_state_dict_diffsbdd(num_classes=8, num_layers=9, seed=0, num_timesteps=1000):
+    """DiffSBDD: same denoiser / embedder keys; the schedules are two gamma tables (schedule_utils.py:60-90)."""
+    from . import diffsbdd as D
+    sd = {}
+    g = D.polynomial_gamma(num_timesteps, 2.0, 5e-4)
+    sd["pos_scheduler.gamma.gamma"] = g.clone()
+    sd["type_scheduler.gamma.gamma"] = g.clone()
+    for key, shape, kind in embedder_spec(num_classes) + denoiser_spec(num_classes, num_layers):
+        sd[key] = _gen(key, shape, kind, seed)
+    return sd

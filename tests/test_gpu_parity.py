@@ -292,3 +292,23 @@ def test_native_step_kernels(golden_dir, model, case):
     if "ligand_gen_flag" in batch:
         keep = ~batch["ligand_gen_flag"]
         assert torch.equal(st["x_lig"].cpu()[keep], batch["ligand_pos"][keep])
+
+
+def test_diffsbdd_sample_matches_reference(golden_dir):
+    """DiffSBDD.sample (5-step model) on the GPU with the reference's Gaussian draws replayed."""
+    g = load(golden_dir, "diffsbdd_sample_T5")
+    T, Cn = int(g["T"]), 8
+    m = C.get_model(C.default_diffsbdd_config(Cn, num_diffusion_timesteps=T)).eval()
+    m.load_state_dict(W.synthetic_state_dict_diffsbdd(Cn, 9, seed=0, num_timesteps=T), strict=True)
+    m = m.to(DEV)
+    batch = {k[len("batch_"):]: v for k, v in g.items() if k.startswith("batch_")}
+    n_lig = batch["ligand_element_batch"].shape[0]
+    torch.manual_seed(int(g["seed"]))
+    draws = []
+    for _ in range(T + 2):
+        draws += [torch.randn(n_lig, 3), torch.randn(n_lig, Cn)]
+    traj = m.sample(synthetic.batch_to(batch, DEV), noise_draws=draws)
+    assert sorted(traj.keys()) == list(range(-1, T))
+    for t in range(-1, T):
+        close(traj[t][0], g[f"traj_x_{t}"], f"diffsbdd traj x[{t}]", scale=10.0)
+        close(traj[t][1], g[f"traj_c_{t}"], f"diffsbdd traj c[{t}]", scale=10.0)

@@ -175,3 +175,30 @@ def test_pocket_sharding_gloo_world2():
     assert sorted(res[0][1] + res[1][1]) == list(range(11))      # a partition: no pocket lost or duplicated
     for _, _, elapsed, units in res:
         assert elapsed == 2.0 and units == 11.0                  # max over ranks, sum over ranks
+
+
+def test_diffsbdd_model_class(golden_dir):
+    """registry entry, reference-compatible state dict, bit-identical gamma table, scheduler maths vs the oracle."""
+    from oracle import diffsbdd as OD
+    model = C.get_model(C.default_diffsbdd_config(8))
+    with open(os.path.join(golden_dir, "state_dict_keys_diffsbdd.json")) as f:
+        ref = json.load(f)
+    sd = model.state_dict()
+    sd5 = C.get_model(C.default_diffsbdd_config(8, num_diffusion_timesteps=5)).state_dict()   # the listing is of a T=5 model
+    assert set(sd) == set(ref) and all(list(sd5[k].shape) == v for k, v in ref.items())
+    z = np.load(os.path.join(golden_dir, "diffsbdd_gamma_T1000.npz"))
+    assert np.array_equal(z["gamma"], sd["pos_scheduler.gamma.gamma"].numpy())
+    model.load_state_dict(W.synthetic_state_dict_diffsbdd(8, 9), strict=True)
+    g = torch.Generator().manual_seed(0)
+    bl = torch.tensor([0, 0, 0, 1, 1]); br = torch.tensor([0, 0, 1, 1, 1, 1])
+    zt = torch.randn(5, 3, generator=g); pocket = torch.randn(6, 3, generator=g)
+    pred = torch.randn(5, 3, generator=g); eps = torch.randn(5, 3, generator=g)
+    s, t = torch.full((2,), 400) / 1000, torch.full((2,), 401) / 1000
+    sch = model.pos_scheduler
+    with torch.no_grad():
+        a, b = sch.sample_p_zs_given_zt(s, t, zt, pocket, bl, br, 2, pred, com=True, eps=eps)
+    oa, ob = OD.sample_p_zs_given_zt(sd["pos_scheduler.gamma.gamma"], 1000, s, t, zt, pocket, bl, br, 2, pred, eps, True)
+    assert torch.equal(a, oa) and torch.equal(b, ob)
+    assert torch.allclose(OD.scatter_mean(a, bl, 2), torch.zeros(2, 3), atol=1e-6)   # COM-free after the draw
+    with pytest.raises(NotImplementedError):
+        model(dict())

@@ -90,3 +90,29 @@ def test_sample_loop_matches_reference(golden_dir):
         u = torch.rand(x.shape[0], 13)
         x, c = T.denoise_step(sd, batch, x, c, t, eps, u, 13)
     assert torch.equal(x, g["traj_x_-1"]) and torch.equal(c, g["traj_c_-1"])
+
+
+def test_diffsbdd_sample_matches_reference(golden_dir):
+    """oracle/diffsbdd.py replays the reference's full 5-step DiffSBDD.sample (draw order, COM projection, the
+    translated pocket, the final p(x,h | z0) call) bit-exactly."""
+    from oracle import diffsbdd as D
+    g = load(golden_dir, "diffsbdd_sample_T5")
+    Tn, C = int(g["T"]), 8
+    sd = W.synthetic_state_dict_diffsbdd(C, 9, seed=0, num_timesteps=Tn)
+    assert torch.equal(sd["pos_scheduler.gamma.gamma"], g["gamma"])
+    batch = {k[len("batch_"):]: v for k, v in g.items() if k.startswith("batch_")}
+    n_lig = batch["ligand_element_batch"].shape[0]
+    torch.manual_seed(int(g["seed"]))
+    draws = []
+    for _ in range(Tn + 2):
+        draws += [torch.randn(n_lig, 3), torch.randn(n_lig, C)]
+    traj = D.sample(sd, batch, C, Tn, draws)
+    for t in range(-1, Tn):
+        assert torch.equal(traj[t][0], g[f"traj_x_{t}"]), t
+        assert torch.equal(traj[t][1], g[f"traj_c_{t}"]), t
+
+
+def test_diffsbdd_gamma_table_matches_reference(golden_dir):
+    from oracle import diffsbdd as D
+    z = np.load(os.path.join(golden_dir, "diffsbdd_gamma_T1000.npz"))
+    assert np.array_equal(z["gamma"], D.polynomial_gamma(1000).numpy())
