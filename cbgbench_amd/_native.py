@@ -23,6 +23,9 @@ EXPORTS = {
     "cbgx_x2h_attention": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "cbgx_h2x_attention": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "cbgx_classifier": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "cbgx_packed_h2x_stack_floats": (_sz, [_i]),
+    "cbgx_pack_h2x_stack": (_i, [ctypes.POINTER(_vp), _i, _i, _vp, _vp]),
+    "cbgx_h2x_stack_forward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "cbgx_targetdiff_prologue": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cbgx_targetdiff_epilogue": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp,
                                       _vp, _vp]),

@@ -83,6 +83,75 @@ size_t cbgx_packed_weights_floats(int num_layers, int num_classes) {
     return packed_floats(num_layers, num_classes);
 }
 
+#define CP(src, ld, off, tr, dst, dld, rows, cols) HIP_TRY(launch_pack_copy(src, ld, off, tr, dst, dld, rows, cols, s))
+
+// gate section (GATE_* offsets) from dist_emb.1.net.{0.weight,0.bias,1.weight,1.bias,3.weight,3.bias}
+static int pack_gate_section(const float* const* t, float* packed, hipStream_t s) {
+    // gate MLP: net.0 [160,20], net.1 LN(160), net.3 [1,160]
+    CP(t[0], G, 0, 0, packed + GATE_W1, G, GH, G);
+    CP(t[1], GH, 0, 0, packed + GATE_B1, GH, 1, GH);
+    CP(t[2], GH, 0, 0, packed + GATE_LNG, GH, 1, GH);
+    CP(t[3], GH, 0, 0, packed + GATE_LNB, GH, 1, GH);
+    CP(t[4], GH, 0, 0, packed + GATE_W2, GH, 1, GH);
+    CP(t[5], 1, 0, 0, packed + GATE_B2, 1, 1, 1);
+    HIP_TRY(launch_pack_gate_img(t[0], t[1], t[2], t[3], t[4], packed + GATE_IMG, s));
+    return CBGX_OK;
+}
+
+// one attention block (ATT layout) from k(6) v(6) q(6) MLP tensors; blk 0 = x2h, 1 = h2x
+static int pack_attention_block(const float* const* p, int blk, float* a, hipStream_t s) {
+    const float *wk0 = p[0], *bk0 = p[1], *gk = p[2], *bek = p[3], *wk1 = p[4];
+    const float *wv0 = p[6], *bv0 = p[7], *gv = p[8], *bev = p[9], *wv1 = p[10], *bv1 = p[11];
+    const float *wq0 = p[12], *bq0 = p[13], *gq = p[14], *beq = p[15], *wq1 = p[16], *bq1 = p[17];
+    // node projection [k][c]: PDk | PDv | PSk | PSv | q hidden
+    CP(wk0, KV_IN, NT + NT * G, 1, a + A_WN + 0 * H, PROW, H, H);
+    CP(wv0, KV_IN, NT + NT * G, 1, a + A_WN + 1 * H, PROW, H, H);
+    CP(wk0, KV_IN, NT + NT * G + H, 1, a + A_WN + 2 * H, PROW, H, H);
+    CP(wv0, KV_IN, NT + NT * G + H, 1, a + A_WN + 3 * H, PROW, H, H);
+    CP(wq0, H, 0, 1, a + A_WN + 4 * H, PROW, H, H);
+    CP(bk0, H, 0, 0, a + A_BN + 0 * H, H, 1, H);
+    CP(bv0, H, 0, 0, a + A_BN + 1 * H, H, 1, H);
+    CP(bq0, H, 0, 0, a + A_BN + 4 * H, H, 1, H);
+    // edge-type one-hot columns and rbf columns of the first Linear
+    CP(wk0, KV_IN, 0, 1, a + A_WT, 2 * H, NT, H);
+    CP(wv0, KV_IN, 0, 1, a + A_WT + H, 2 * H, NT, H);
+    CP(wk0, KV_IN, NT, 1, a + A_WR, 2 * H, NT * G, H);
+    CP(wv0, KV_IN, NT, 1, a + A_WR + H, 2 * H, NT * G, H);
+    CP(gk, H, 0, 0, a + A_LNK_G, H, 1, H);
+    CP(bek, H, 0, 0, a + A_LNK_B, H, 1, H);
+    CP(gv, H, 0, 0, a + A_LNV_G, H, 1, H);
+    CP(bev, H, 0, 0, a + A_LNV_B, H, 1, H);
+    CP(gq, H, 0, 0, a + A_LNQ_G, H, 1, H);
+    CP(beq, H, 0, 0, a + A_LNQ_B, H, 1, H);
+    CP(wq1, H, 0, 1, a + A_WQ1T, H, H, H);
+    CP(bq1, H, 0, 0, a + A_BQ1, H, 1, H);
+    CP(wk1, H, 0, 0, a + A_WBK, H, H, H);
+    // centred copies of the first k / v Linears: every MFMA-path table below is built from them
+    HIP_TRY(launch_center_linear(wk0, bk0, KV_IN, a + A_WAKC, a + A_BAKC, s));
+    HIP_TRY(launch_center_linear(wv0, bv0, KV_IN, a + A_WAVC, a + A_BAVC, s));
+    const float *wkc = a + A_WAKC, *wvc = a + A_WAVC;
+    HIP_TRY(launch_pack_node_frags(wkc, wvc, wq0, wq1, wk1, a, s));
+    HIP_TRY(launch_pack_bn2(a, bq0, a, s));
+    // LDS image of the MFMA edge kernel
+    float* img = a + A_IMG;
+    HIP_TRY(launch_pack_frag(wkc, 0, img + IMG_FRAG_K, s));
+    HIP_TRY(launch_pack_frag(wvc, blk == 0 ? 1 : 0, img + IMG_FRAG_V, s));
+    HIP_TRY(launch_pack_dwt(wkc, wvc, img + IMG_WT, s));
+    CP(gk, H, 0, 0, img + IMG_LN + 0 * H, H, 1, H);
+    CP(bek, H, 0, 0, img + IMG_LN + 1 * H, H, 1, H);
+    CP(gv, H, 0, 0, img + IMG_LN + 2 * H, H, 1, H);
+    CP(bev, H, 0, 0, img + IMG_LN + 3 * H, H, 1, H);
+    if (blk == 0) {
+        HIP_TRY(launch_pack_wbv_swz(wv1, img + IMG_WBV, s));  // row-major (n, m), chunk-swizzled
+        CP(wv1, H, 0, 1, a + A_WBV, H, H, H);   // [m][n]
+        CP(bv1, H, 0, 0, a + A_BBV, H, 1, H);
+    } else {
+        CP(wv1, H, 0, 0, a + A_WBV, H, HEADS, H);  // [head][m]
+        CP(bv1, HEADS, 0, 0, a + A_BBV, HEADS, 1, HEADS);
+    }
+    return CBGX_OK;
+}
+
 int cbgx_pack_weights(const float* const* t, int num_tensors, int L, int C, float* packed, void* stream) {
     if (!t || !packed) return fail(CBGX_E_INVALID, "pack_weights: NULL pointer");
     if (L < 1 || C < 1) return fail(CBGX_E_INVALID, "pack_weights: num_layers=%d num_classes=%d", L, C);
@@ -92,68 +161,13 @@ int cbgx_pack_weights(const float* const* t, int num_tensors, int L, int C, floa
         if (!t[i]) return fail(CBGX_E_INVALID, "pack_weights: tensor %d is NULL", i);
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(packed, 0, packed_floats(L, C) * sizeof(float), s));
-#define CP(src, ld, off, tr, dst, dld, rows, cols) HIP_TRY(launch_pack_copy(src, ld, off, tr, dst, dld, rows, cols, s))
-    // gate MLP: net.0 [160,20], net.1 LN(160), net.3 [1,160]
-    CP(t[0], G, 0, 0, packed + GATE_W1, G, GH, G);
-    CP(t[1], GH, 0, 0, packed + GATE_B1, GH, 1, GH);
-    CP(t[2], GH, 0, 0, packed + GATE_LNG, GH, 1, GH);
-    CP(t[3], GH, 0, 0, packed + GATE_LNB, GH, 1, GH);
-    CP(t[4], GH, 0, 0, packed + GATE_W2, GH, 1, GH);
-    CP(t[5], 1, 0, 0, packed + GATE_B2, 1, 1, 1);
-    HIP_TRY(launch_pack_gate_img(t[0], t[1], t[2], t[3], t[4], packed + GATE_IMG, s));
+    { int rc = pack_gate_section(t, packed, s); if (rc) return rc; }
     for (int l = 0; l < L; ++l) {
         for (int blk = 0; blk < 2; ++blk) {
             const float* const* p = t + 6 + 36 * l + 18 * blk;  // k(6) v(6) q(6)
             float* a = packed + (blk == 0 ? x2h_off(l) : h2x_off(l));
-            const float *wk0 = p[0], *bk0 = p[1], *gk = p[2], *bek = p[3], *wk1 = p[4];
-            const float *wv0 = p[6], *bv0 = p[7], *gv = p[8], *bev = p[9], *wv1 = p[10], *bv1 = p[11];
-            const float *wq0 = p[12], *bq0 = p[13], *gq = p[14], *beq = p[15], *wq1 = p[16], *bq1 = p[17];
-            // node projection [k][c]: PDk | PDv | PSk | PSv | q hidden
-            CP(wk0, KV_IN, NT + NT * G, 1, a + A_WN + 0 * H, PROW, H, H);
-            CP(wv0, KV_IN, NT + NT * G, 1, a + A_WN + 1 * H, PROW, H, H);
-            CP(wk0, KV_IN, NT + NT * G + H, 1, a + A_WN + 2 * H, PROW, H, H);
-            CP(wv0, KV_IN, NT + NT * G + H, 1, a + A_WN + 3 * H, PROW, H, H);
-            CP(wq0, H, 0, 1, a + A_WN + 4 * H, PROW, H, H);
-            CP(bk0, H, 0, 0, a + A_BN + 0 * H, H, 1, H);
-            CP(bv0, H, 0, 0, a + A_BN + 1 * H, H, 1, H);
-            CP(bq0, H, 0, 0, a + A_BN + 4 * H, H, 1, H);
-            // edge-type one-hot columns and rbf columns of the first Linear
-            CP(wk0, KV_IN, 0, 1, a + A_WT, 2 * H, NT, H);
-            CP(wv0, KV_IN, 0, 1, a + A_WT + H, 2 * H, NT, H);
-            CP(wk0, KV_IN, NT, 1, a + A_WR, 2 * H, NT * G, H);
-            CP(wv0, KV_IN, NT, 1, a + A_WR + H, 2 * H, NT * G, H);
-            CP(gk, H, 0, 0, a + A_LNK_G, H, 1, H);
-            CP(bek, H, 0, 0, a + A_LNK_B, H, 1, H);
-            CP(gv, H, 0, 0, a + A_LNV_G, H, 1, H);
-            CP(bev, H, 0, 0, a + A_LNV_B, H, 1, H);
-            CP(gq, H, 0, 0, a + A_LNQ_G, H, 1, H);
-            CP(beq, H, 0, 0, a + A_LNQ_B, H, 1, H);
-            CP(wq1, H, 0, 1, a + A_WQ1T, H, H, H);
-            CP(bq1, H, 0, 0, a + A_BQ1, H, 1, H);
-            CP(wk1, H, 0, 0, a + A_WBK, H, H, H);
-            // centred copies of the first k / v Linears: every MFMA-path table below is built from them
-            HIP_TRY(launch_center_linear(wk0, bk0, KV_IN, a + A_WAKC, a + A_BAKC, s));
-            HIP_TRY(launch_center_linear(wv0, bv0, KV_IN, a + A_WAVC, a + A_BAVC, s));
-            const float *wkc = a + A_WAKC, *wvc = a + A_WAVC;
-            HIP_TRY(launch_pack_node_frags(wkc, wvc, wq0, wq1, wk1, a, s));
-            HIP_TRY(launch_pack_bn2(a, bq0, a, s));
-            // LDS image of the MFMA edge kernel
-            float* img = a + A_IMG;
-            HIP_TRY(launch_pack_frag(wkc, 0, img + IMG_FRAG_K, s));
-            HIP_TRY(launch_pack_frag(wvc, blk == 0 ? 1 : 0, img + IMG_FRAG_V, s));
-            HIP_TRY(launch_pack_dwt(wkc, wvc, img + IMG_WT, s));
-            CP(gk, H, 0, 0, img + IMG_LN + 0 * H, H, 1, H);
-            CP(bek, H, 0, 0, img + IMG_LN + 1 * H, H, 1, H);
-            CP(gv, H, 0, 0, img + IMG_LN + 2 * H, H, 1, H);
-            CP(bev, H, 0, 0, img + IMG_LN + 3 * H, H, 1, H);
-            if (blk == 0) {
-                HIP_TRY(launch_pack_wbv_swz(wv1, img + IMG_WBV, s));  // row-major (n, m), chunk-swizzled
-                CP(wv1, H, 0, 1, a + A_WBV, H, H, H);   // [m][n]
-                CP(bv1, H, 0, 0, a + A_BBV, H, 1, H);
-            } else {
-                CP(wv1, H, 0, 0, a + A_WBV, H, HEADS, H);  // [head][m]
-                CP(bv1, HEADS, 0, 0, a + A_BBV, HEADS, 1, HEADS);
-            }
+            int rc = pack_attention_block(p, blk, a, s);
+            if (rc) return rc;
         }
     }
     const float* const* c = t + 6 + 36 * L;
@@ -163,6 +177,52 @@ int cbgx_pack_weights(const float* const* t, int num_tensors, int L, int C, floa
     CP(c[2], H, 0, 1, cp + C_W1T, C, H, C);
     CP(c[3], C, 0, 0, cp + cls_b1(C), C, 1, C);
 #undef CP
+    return CBGX_OK;
+}
+
+// ---- a stack of H2X blocks on its own kNN graph + gate (DiffBP's CoMPredictor) ---------------------
+size_t cbgx_packed_h2x_stack_floats(int num_layers) {
+    if (num_layers < 1) return 0;
+    return GATE_SIZE + (size_t)num_layers * ATT_SIZE;
+}
+
+int cbgx_pack_h2x_stack(const float* const* t, int num_tensors, int L, float* packed, void* stream) {
+    if (!t || !packed) return fail(CBGX_E_INVALID, "pack_h2x_stack: NULL pointer");
+    if (L < 1 || num_tensors != 6 + 18 * L)
+        return fail(CBGX_E_INVALID, "pack_h2x_stack: expected %d tensors for %d layers, got %d", 6 + 18 * L, L, num_tensors);
+    for (int i = 0; i < num_tensors; ++i)
+        if (!t[i]) return fail(CBGX_E_INVALID, "pack_h2x_stack: tensor %d is NULL", i);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(packed, 0, cbgx_packed_h2x_stack_floats(L) * sizeof(float), s));
+    { int rc = pack_gate_section(t, packed, s); if (rc) return rc; }
+    for (int l = 0; l < L; ++l) {
+        int rc = pack_attention_block(t + 6 + 18 * l, 1, packed + GATE_SIZE + (size_t)l * ATT_SIZE, s);
+        if (rc) return rc;
+    }
+    return CBGX_OK;
+}
+
+int cbgx_h2x_stack_forward(const float* packed, int num_layers, const float* x, const float* h,
+                           const int32_t* graph_ptr, const uint8_t* lig_flag, const uint8_t* gen_flag, int n_nodes,
+                           int n_graphs, float* x_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n_nodes < 0 || n_graphs < 0 || num_layers < 1) return fail(CBGX_E_INVALID, "h2x_stack: bad sizes");
+    if (n_nodes == 0) return CBGX_OK;
+    if (!packed || !x || !h || !graph_ptr || !lig_flag || !gen_flag || !x_out || !workspace)
+        return fail(CBGX_E_INVALID, "h2x_stack: NULL pointer");
+    Workspace w = carve(workspace, n_nodes);
+    if (workspace_bytes < w.total)
+        return fail(CBGX_E_WORKSPACE, "h2x_stack: workspace %zu < %zu", workspace_bytes, w.total);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s));
+    HIP_TRY(launch_gate(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s));
+    HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, s));
+    const float* xc = x;
+    for (int l = 0; l < num_layers; ++l) {
+        float* xn = (l == num_layers - 1) ? x_out : w.xbuf[l & 1];
+        HIP_TRY(launch_attention(false, packed + GATE_SIZE + (size_t)l * ATT_SIZE, xc, h, w.nbr, w.deg, lig_flag, gen_flag,
+                                 w.e_w, n_nodes, w.P, w.Qt, w.q, xn, nullptr, w.act, w.act_count, s));
+        xc = xn;
+    }
     return CBGX_OK;
 }
 

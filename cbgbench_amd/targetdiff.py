@@ -84,16 +84,24 @@ class VPSchedule(nn.Module):
 class CTNVPScheduler(VPSchedule):
     """Continuous (position) schedule; the posterior step is ``backward_remove_noise``."""
 
-    def backward_remove_noise(self, x_pred, x_noisy, t, batch_idx, gen_flag, type="denoise", noise=None):
-        """x_{t-1} ~ q(x_{t-1} | x_t, x0_pred) (diffusion_scheduler.py:144-165, type='denoise')."""
-        if type != "denoise":
-            raise NotImplementedError("only the x0-prediction ('denoise') posterior is used by targetdiff")
+    def backward_remove_noise(self, x_pred, x_noisy, t, batch_idx, gen_flag, type="score", noise=None):
+        """x_{t-1} from x_t (diffusion_scheduler.py:144-165).  type='denoise': x_pred is x0, sample the Gaussian
+        posterior q(x_{t-1} | x_t, x0); type='score' (the reference's default; DiffBP): x_pred is the noise
+        estimate, ancestral step (x_t - beta * eps / sqrt(1 - abar)) / sqrt(1 - beta) + sqrt(beta) * z."""
         tb = t[batch_idx]
-        mean = self.posterior_mean_c0_coef[tb][:, None] * x_pred + self.posterior_mean_ct_coef[tb][:, None] * x_noisy
         if noise is None:
             noise = torch.randn_like(x_noisy)
         nonzero = (tb != 0).to(x_noisy.dtype)[:, None]
-        xs = mean + nonzero * (0.5 * self.posterior_logvar[tb][:, None]).exp() * noise
+        if type == "score":
+            a = self.alphas_cumprod[tb][:, None]
+            b = self.betas[tb][:, None]
+            score = -x_pred / (1 - a).sqrt()
+            xs = (x_noisy + b * score) / (1 - b).sqrt()
+            xs = xs + nonzero * b.sqrt() * noise
+        else:
+            mean = (self.posterior_mean_c0_coef[tb][:, None] * x_pred
+                    + self.posterior_mean_ct_coef[tb][:, None] * x_noisy)
+            xs = mean + nonzero * (0.5 * self.posterior_logvar[tb][:, None]).exp() * noise
         return torch.where(gen_flag[:, None], xs, x_noisy)
 
 

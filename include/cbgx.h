@@ -105,6 +105,18 @@ int cbgx_h2x_attention(const float *packed, int layer, const float *x, const flo
 int cbgx_classifier(const float *packed, int num_layers, int num_classes, const float *h, int n_nodes,
                     float *logits, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- a stack of H2X blocks on its own graph: DiffBP's CoMPredictor -----------------------------------
+ * CoMPredictor.forward (repo/models/diffusion/diffbp.py:79-101): kNN graph + gate from x, then num_layers
+ * H2XAttention blocks with x_out = x_out + delta_x * gen_flag, h fixed.  `tensors` for the pack: HOST array of
+ * DEVICE pointers com_head.dist_emb.1.net.{0.weight,0.bias,1.weight,1.bias,3.weight,3.bias} followed, per layer,
+ * by com_head.h2xattentions.{l}.{xk_func,xv_func,xq_func}.net.{0.weight,...,3.bias} (6 + 18*num_layers). */
+size_t cbgx_packed_h2x_stack_floats(int num_layers);
+int cbgx_pack_h2x_stack(const float *const *tensors, int num_tensors, int num_layers, float *packed, void *stream);
+int cbgx_h2x_stack_forward(const float *packed, int num_layers, const float *x, const float *h,
+                           const int32_t *graph_ptr, const uint8_t *lig_flag, const uint8_t *gen_flag,
+                           int n_nodes, int n_graphs, float *x_out, void *workspace, size_t workspace_bytes,
+                           void *stream);
+
 /* ---- TargetDiff step prologue / epilogue ----------------------------------------------------------
  * The per-step work around the denoiser in TargetDiff.sample (repo/models/diffusion/targetdiff.py:150-182).
  * prologue: x[lig_rows[a]] = x_lig[a];  h[lig_rows[a]] = ligand_atom_emb(c_lig[a]) + ligand_indicator(1)

@@ -157,6 +157,32 @@ def diffsbdd_case(name, batch, T, seed):
     print(name, "keys", sorted(traj.keys()))
 
 
+def diffbp_case(name, batch, T, seed):
+    """Full ``DiffBP.sample`` (diffbp.py:240-299) of a T-step model, torch RNG seeded."""
+    M = ref_shim.load_reference()
+    cfg = ref_shim.AttrDict(
+        type="diffbp", num_atomtype=13,
+        encoder=dict(type="unitransformer", node_feat_dim=128, n_heads=16, num_layers=9),
+        generator=dict(pos_schedule=dict(type="sigmoid", beta_start=1.0e-7, beta_end=2.0e-3),
+                       atom_schedule=dict(type="uniform"), num_diffusion_timesteps=T, time_sampler="symmetric",
+                       com_schedule=dict(type="log", sigma_min=1.0e-7, sigma_max=5.0)),
+        embedder=dict(emb_dim=128, atom=dict(type="linear"), residue=dict(type="linear")))
+    model = M.get_model(cfg).eval()
+    with open(os.path.join(OUT, "state_dict_keys_diffbp.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in model.state_dict().items()}, f, indent=0)
+    model.load_state_dict(W.synthetic_state_dict_diffbp(13, 9, seed=0, num_timesteps=T), strict=True)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        traj = model.sample(batch)
+    out = {"T": T, "seed": seed}
+    for k, (xx, cc, bb) in traj.items():
+        out[f"traj_x_{k}"] = _np(xx)
+        out[f"traj_c_{k}"] = _np(cc)
+    out.update({"batch_" + k: _np(v) for k, v in batch.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "keys", sorted(traj.keys()))
+
+
 def eg5_pocket(radius=10.0):
     """scripts/example/Eg5 (PDB 3ZCW) heavy atoms of residues with any atom within ``radius`` A of
     a ligand heavy atom -- the pocket criterion of datasets/parsers/protein_parser.py:167-177 --
@@ -233,6 +259,9 @@ def main():
     step_case(model, "step_t0", small_batch([(64, 10), (50, 12)], seed=22), 0, seed=6)
     step_case(model, "step_t999_linker", small_batch([(58, 15), (44, 12)], seed=23, ctx=[10, 8]), 999, seed=7)
     sample_case("sample_T5", small_batch([(40, 8), (36, 6)], seed=31), T=5, seed=9)
+    b = small_batch([(44, 9), (37, 8)], seed=51)
+    b["ligand_atom_type"] = torch.zeros_like(b["ligand_atom_type"])        # absorbing-state prior (assign_atomtype: absorbing)
+    diffbp_case("diffbp_sample_T5", b, T=5, seed=13)
     diffsbdd_case("diffsbdd_sample_T5", small_batch([(42, 9), (38, 7)], seed=41, num_classes=8), T=5, seed=11)
 
 

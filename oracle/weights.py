@@ -116,3 +116,28 @@ def synthetic_state_dict_diffsbdd(num_classes=8, num_layers=9, seed=0, num_times
     for key, shape, kind in embedder_spec(num_classes) + denoiser_spec(num_classes, num_layers):
         sd[key] = _gen(key, shape, kind, seed)
     return sd
+
+
+def com_head_spec(num_layers_com=3, H=128, heads=16, G=20, prefix="com_head"):
+    kv_in = 2 * H + 4 + 4 * G
+    spec = []
+    for l in range(num_layers_com):
+        p = f"{prefix}.h2xattentions.{l}"
+        spec.append((f"{p}.distance_expansion.offset", (G,), "offset"))
+        spec += _mlp_spec(f"{p}.xk_func", kv_in, H, H)
+        spec += _mlp_spec(f"{p}.xv_func", kv_in, H, heads)
+        spec += _mlp_spec(f"{p}.xq_func", H, H, H)
+    spec.append((f"{prefix}.dist_emb.0.offset", (G,), "offset"))
+    spec += _mlp_spec(f"{prefix}.dist_emb.1", G, 8 * G, 1)
+    return spec
+
+
+def synthetic_state_dict_diffbp(num_classes=13, num_layers=9, seed=0, num_timesteps=1000):
+    """DiffBP: VP position tables only (MaskTypeSchedule has no parameters) + denoiser + embedder + com_head."""
+    sd = {}
+    pb = T.vp_betas(num_timesteps, 1e-7, 2e-3, "sigmoid")
+    for k, v in T.vp_tables(pb).items():
+        sd[f"pos_scheduler.{k}"] = v
+    for key, shape, kind in embedder_spec(num_classes) + denoiser_spec(num_classes, num_layers) + com_head_spec():
+        sd[key] = _gen(key, shape, kind, seed)
+    return sd

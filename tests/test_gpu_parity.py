@@ -158,7 +158,8 @@ def test_teacher_forced_step(golden_dir, model, case):
         assert torch.equal(c_pred.argmax(-1).cpu(), g["c_pred"].argmax(-1))
         B = int(bl.max()) + 1
         t = torch.full((B,), t_idx, dtype=torch.long, device=DEV)
-        x_next = model.pos_scheduler.backward_remove_noise(x_pred, b["ligand_pos"], t, bl, gen_l, noise=g["eps"].to(DEV))
+        x_next = model.pos_scheduler.backward_remove_noise(x_pred, b["ligand_pos"], t, bl, gen_l, type="denoise",
+                                                           noise=g["eps"].to(DEV))
         c_next, v_next = model.type_scheduler.backward_remove_noise(c_pred, c_lig, t, bl, gen_l, uniform=g["u"].to(DEV))
     close(x_next, g["x_next"], "x_{t-1}")
     assert torch.equal(v_next.cpu(), g["v_next"])
@@ -312,3 +313,23 @@ def test_diffsbdd_sample_matches_reference(golden_dir):
     for t in range(-1, T):
         close(traj[t][0], g[f"traj_x_{t}"], f"diffsbdd traj x[{t}]", scale=10.0)
         close(traj[t][1], g[f"traj_c_{t}"], f"diffsbdd traj c[{t}]", scale=10.0)
+
+
+def test_diffbp_sample_matches_reference(golden_dir):
+    """DiffBP.sample (5-step model): denoiser + CoMPredictor (cbgx_h2x_stack_forward) + samplers, noise replayed."""
+    g = load(golden_dir, "diffbp_sample_T5")
+    T, Cn = int(g["T"]), 13
+    m = C.get_model(C.default_diffbp_config(Cn, num_diffusion_timesteps=T)).eval()
+    m.load_state_dict(W.synthetic_state_dict_diffbp(Cn, 9, seed=0, num_timesteps=T), strict=True)
+    m = m.to(DEV)
+    batch = {k[len("batch_"):]: v for k, v in g.items() if k.startswith("batch_")}
+    n_lig = batch["ligand_pos"].shape[0]
+    torch.manual_seed(int(g["seed"]))
+    tape = {}
+    for t in reversed(range(T)):
+        tape[t] = (torch.randn(n_lig, 3).to(DEV), torch.rand(n_lig).to(DEV))
+    traj = m.sample(synthetic.batch_to(batch, DEV), noise_tape=tape)
+    assert sorted(traj.keys()) == list(range(-1, T))
+    for t in range(-1, T):
+        close(traj[t][0], g[f"traj_x_{t}"], f"diffbp traj x[{t}]")
+        assert torch.equal(traj[t][1], g[f"traj_c_{t}"]), f"diffbp traj c[{t}]"

@@ -74,7 +74,8 @@ def test_posterior_updates_match_reference(golden_dir, case):
     B = int(bl.max()) + 1
     t = torch.full((B,), int(g["t_idx"]), dtype=torch.long)
     c_lig = torch.nn.functional.one_hot(g["batch_ligand_atom_type"], 13).float()
-    x_next = model.pos_scheduler.backward_remove_noise(g["x_pred"], g["batch_ligand_pos"], t, bl, gen, noise=g["eps"])
+    x_next = model.pos_scheduler.backward_remove_noise(g["x_pred"], g["batch_ligand_pos"], t, bl, gen, type="denoise",
+                                                       noise=g["eps"])
     c_next, v_next = model.type_scheduler.backward_remove_noise(g["c_pred"], c_lig, t, bl, gen, uniform=g["u"])
     assert torch.equal(x_next, g["x_next"])
     assert torch.equal(v_next, g["v_next"]) and torch.equal(c_next, g["c_next"])
@@ -202,3 +203,35 @@ def test_diffsbdd_model_class(golden_dir):
     assert torch.allclose(OD.scatter_mean(a, bl, 2), torch.zeros(2, 3), atol=1e-6)   # COM-free after the draw
     with pytest.raises(NotImplementedError):
         model(dict())
+
+
+def test_diffbp_model_class(golden_dir):
+    from oracle import diffbp as OD
+    assert "diffbp" in C.registered_models()
+    model = C.get_model(C.default_diffbp_config(13, num_diffusion_timesteps=5))
+    with open(os.path.join(golden_dir, "state_dict_keys_diffbp.json")) as f:
+        ref = json.load(f)
+    sd = model.state_dict()
+    assert set(sd) == set(ref) and all(list(sd[k].shape) == v for k, v in ref.items())
+    wsd = W.synthetic_state_dict_diffbp(13, 9, num_timesteps=5)
+    model.load_state_dict(wsd, strict=True)
+    # element-wise sampler maths vs the oracle
+    g = torch.Generator().manual_seed(1)
+    bl = torch.tensor([0, 0, 0, 1, 1]); gen = torch.tensor([True, True, False, True, True])
+    xt, pred, eps = (torch.randn(5, 3, generator=g) for _ in range(3))
+    t = torch.tensor([3, 0])
+    pos_tb = {k[len("pos_scheduler."):]: v for k, v in wsd.items() if k.startswith("pos_scheduler.")}
+    with torch.no_grad():
+        a = model.pos_scheduler.backward_remove_noise(pred, xt, t, bl, gen, type="score", noise=eps)
+    assert torch.allclose(a, OD.pos_backward_score(pos_tb, pred, xt, t, bl, gen, eps), atol=1e-6)
+    assert torch.equal(a[2], xt[2])
+    logits = torch.randn(5, 13, generator=g); ct = torch.nn.functional.one_hot(torch.tensor([0, 4, 0, 0, 7]), 13).float()
+    u = torch.tensor([0.1, 0.1, 0.1, 0.99, 0.0])
+    c1, v1 = model.type_scheduler.backward_remove_noise(logits, ct, t, bl, gen, uniform=u)
+    c2, v2 = OD.type_backward_mask(5, 13, logits, ct, t, bl, gen, u)
+    assert torch.equal(v1, v2) and torch.equal(c1, c2)
+    assert v1[1] == 4 and v1[2] == 0 and v1[4] == 7      # unmasked / non-generated atoms keep their type
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.com_head(torch.zeros(2, 3), torch.zeros(2, dtype=torch.long), torch.zeros(4, 3), torch.zeros(4, 128),
+                       torch.zeros(4, dtype=torch.bool), torch.tensor([0, 0, 1, 1], dtype=torch.bool),
+                       torch.zeros(4, dtype=torch.long))

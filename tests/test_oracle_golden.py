@@ -116,3 +116,23 @@ def test_diffsbdd_gamma_table_matches_reference(golden_dir):
     from oracle import diffsbdd as D
     z = np.load(os.path.join(golden_dir, "diffsbdd_gamma_T1000.npz"))
     assert np.array_equal(z["gamma"], D.polynomial_gamma(1000).numpy())
+
+
+def test_diffbp_sample_matches_reference(golden_dir):
+    """oracle/diffbp.py replays the reference's full 5-step DiffBP.sample (denoiser + CoMPredictor + score-type
+    position step + absorbing-state type step) bit-exactly."""
+    from oracle import diffbp as D
+    g = load(golden_dir, "diffbp_sample_T5")
+    Tn, C = int(g["T"]), 13
+    sd = W.synthetic_state_dict_diffbp(C, 9, seed=0, num_timesteps=Tn)
+    batch = {k[len("batch_"):]: v for k, v in g.items() if k.startswith("batch_")}
+    x = batch["ligand_pos"]
+    c = torch.nn.functional.one_hot(batch["ligand_atom_type"], C).float()
+    torch.manual_seed(int(g["seed"]))
+    for t in reversed(range(Tn)):
+        assert torch.equal(x, g[f"traj_x_{t}"]) and torch.equal(c, g[f"traj_c_{t}"]), t
+        eps = torch.randn_like(x)
+        u = torch.rand(x.shape[0])
+        x, c = D.denoise_step(sd, batch, x, c, t, eps, u, C, Tn)
+    assert torch.equal(x, g["traj_x_-1"]) and torch.equal(c, g["traj_c_-1"])
+    assert bool((c.argmax(-1) != 0).any()), "some atoms must have left the absorbing state"
