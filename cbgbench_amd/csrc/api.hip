@@ -39,6 +39,9 @@ struct Workspace {
     float* q;
     int* act;        // indices of gen_flag nodes (h2x work list)
     int* act_count;
+    uint8_t* mask;   // receptive-field pruning: reachability mask and the three node lists derived from it
+    int* rf_list[3];
+    int* rf_count;   // [3], 64 B apart
     float* hbuf[2];
     float* xbuf[2];
     size_t total;
@@ -58,6 +61,9 @@ static Workspace carve(void* base, int n) {
     w.q = (float*)take(N * H * 4);
     w.act = (int*)take(N * 4);
     w.act_count = (int*)take(256);
+    w.mask = (uint8_t*)take(N);
+    for (int k = 0; k < 3; ++k) w.rf_list[k] = (int*)take(N * 4);
+    w.rf_count = (int*)take(256);
     w.hbuf[0] = (float*)take(N * H * 4);
     w.hbuf[1] = (float*)take(N * H * 4);
     w.xbuf[0] = (float*)take(N * 3 * 4);
@@ -220,7 +226,7 @@ int cbgx_h2x_stack_forward(const float* packed, int num_layers, const float* x, 
     for (int l = 0; l < num_layers; ++l) {
         float* xn = (l == num_layers - 1) ? x_out : w.xbuf[l & 1];
         HIP_TRY(launch_attention(false, packed + GATE_SIZE + (size_t)l * ATT_SIZE, xc, h, w.nbr, w.deg, lig_flag, gen_flag,
-                                 w.e_w, n_nodes, w.P, w.Qt, w.q, xn, nullptr, w.act, w.act_count, s));
+                                 w.e_w, n_nodes, w.P, w.Qt, w.q, xn, nullptr, w.act, w.act_count, nullptr, nullptr, s));
         xc = xn;
     }
     return CBGX_OK;
@@ -259,7 +265,7 @@ int cbgx_x2h_attention(const float* packed, int layer, const float* x, const flo
     if (workspace_bytes < w.total)
         return fail(CBGX_E_WORKSPACE, "x2h_attention: workspace %zu < %zu", workspace_bytes, w.total);
     HIP_TRY(launch_attention(true, packed + x2h_off(layer), x, h, nbr, deg, lig_flag, nullptr, e_w, n_nodes, w.P,
-                             w.Qt, w.q, h_out, nullptr, nullptr, nullptr, (hipStream_t)stream));
+                             w.Qt, w.q, h_out, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream));
     return CBGX_OK;
 }
 
@@ -276,7 +282,7 @@ int cbgx_h2x_attention(const float* packed, int layer, const float* x, const flo
         return fail(CBGX_E_WORKSPACE, "h2x_attention: workspace %zu < %zu", workspace_bytes, w.total);
     HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, (hipStream_t)stream));
     HIP_TRY(launch_attention(false, packed + h2x_off(layer), x, h, nbr, deg, lig_flag, gen_flag, e_w, n_nodes, w.P,
-                             w.Qt, w.q, x_out, delta_x, w.act, w.act_count, (hipStream_t)stream));
+                             w.Qt, w.q, x_out, delta_x, w.act, w.act_count, nullptr, nullptr, (hipStream_t)stream));
     return CBGX_OK;
 }
 
@@ -301,7 +307,7 @@ int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_cla
                                 size_t workspace_bytes, void* stream) {
     if (n_nodes < 0 || n_graphs < 0 || num_layers < 1) return fail(CBGX_E_INVALID, "forward: bad sizes");
     if (n_nodes == 0) return CBGX_OK;
-    if (!packed || !x || !h || !graph_ptr || !lig_flag || !gen_flag || !x_out || !h_out || !workspace)
+    if (!packed || !x || !h || !graph_ptr || !lig_flag || !gen_flag || !x_out || !workspace)
         return fail(CBGX_E_INVALID, "forward: NULL pointer");
     if (logits && num_classes < 1) return fail(CBGX_E_INVALID, "forward: num_classes=%d", num_classes);
     Workspace w = carve(workspace, n_nodes);
@@ -312,15 +318,35 @@ int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_cla
     HIP_TRY(launch_gate(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s));
     // H2X only ever moves gen_flag nodes (x_out = x + dx * gen_flag): list them once, run every h2x block on the list
     HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, s));
+    // Receptive-field pruning (only when the caller does not ask for h_out): the outputs that remain are x_out and the
+    // logits of ligand rows, so the last x2h blocks only have to produce features that can still reach them:
+    //   A1 = gen | lig | nbr(gen)      destinations of the last x2h (classifier rows, the last h2x's own + source rows)
+    //   A2 = A1 | nbr(A1)              its sources = destinations of the x2h before it;   A3 = A2 | nbr(A2) its sources
+    // Rows outside these sets are simply not written in the last two feature buffers (and never read).
+    const bool prune = (h_out == nullptr) && num_layers >= 3;
+    if (prune) {
+        HIP_TRY(launch_mark_seed(gen_flag, lig_flag, n_nodes, w.mask, s));
+        HIP_TRY(launch_mark_nbr(w.act, w.act_count, n_nodes, w.nbr, w.deg, w.mask, s));
+        for (int k = 0; k < 3; ++k) {
+            HIP_TRY(launch_build_active(w.mask, n_nodes, w.rf_list[k], w.rf_count + 16 * k, s));
+            if (k < 2) HIP_TRY(launch_mark_nbr(w.rf_list[k], w.rf_count + 16 * k, n_nodes, w.nbr, w.deg, w.mask, s));
+        }
+    }
     const float* xc = x;
     const float* hc = h;
     for (int l = 0; l < num_layers; ++l) {
-        float* hn = (l == num_layers - 1) ? h_out : w.hbuf[l & 1];
+        float* hn = (l == num_layers - 1 && h_out) ? h_out : w.hbuf[l & 1];
         float* xn = (l == num_layers - 1) ? x_out : w.xbuf[l & 1];
+        const int *dst = nullptr, *dst_n = nullptr, *src = nullptr, *src_n = nullptr;
+        if (prune && l >= num_layers - 2) {
+            const int k = num_layers - 1 - l;   // 0 for the last layer, 1 for the one before
+            dst = w.rf_list[k]; dst_n = w.rf_count + 16 * k;
+            src = w.rf_list[k + 1]; src_n = w.rf_count + 16 * (k + 1);
+        }
         HIP_TRY(launch_attention(true, packed + x2h_off(l), xc, hc, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
-                                 w.P, w.Qt, w.q, hn, nullptr, nullptr, nullptr, s));
+                                 w.P, w.Qt, w.q, hn, nullptr, dst, dst_n, src, src_n, s));
         HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
-                                 w.P, w.Qt, w.q, xn, nullptr, w.act, w.act_count, s));
+                                 w.P, w.Qt, w.q, xn, nullptr, w.act, w.act_count, nullptr, nullptr, s));
         xc = xn;
         hc = hn;
     }

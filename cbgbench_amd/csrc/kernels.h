@@ -21,7 +21,7 @@ hipError_t launch_node_gemm(const float* A, int lda, const float* Wt, const floa
 hipError_t launch_attention(bool x2h, const float* att, const float* x, const float* h, const int32_t* nbr,
                             const int32_t* deg, const uint8_t* lig, const uint8_t* gen, const float* e_w, int n_nodes,
                             float* P, float* Qt, float* qbuf, float* out, float* dx_out, const int* act, const int* act_count,
-                            hipStream_t s);
+                            const int* src, const int* src_count, hipStream_t s);
 extern int g_edge_impl;
 // fragment-ordered rbf weight table: mode 0 edge-major (A operand), 1 channel-major (B operand)
 hipError_t launch_pack_frag(const float* w_a, int mode, float* dst, hipStream_t s);
@@ -41,8 +41,12 @@ hipError_t launch_gate_mfma(const float* packed, const float* x, const int32_t* 
 hipError_t launch_pack_node_frags(const float* wk0, const float* wv0, const float* wq0, const float* wq1,
                                   const float* wbk, float* att, hipStream_t s);
 hipError_t launch_build_active(const uint8_t* flag, int n, int* list, int* count, hipStream_t s);
+hipError_t launch_mark_seed(const uint8_t* a, const uint8_t* b, int n, uint8_t* m, hipStream_t s);
+hipError_t launch_mark_nbr(const int* list, const int* count, int n_upper, const int32_t* nbr, const int32_t* deg,
+                           uint8_t* m, hipStream_t s);
 hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,
-                            float* Qt, const int* act, const int* act_count, hipStream_t s);
+                            float* Qt, const int* act, const int* act_count, const int* src, const int* src_count,
+                            hipStream_t s);
 // MFMA edge kernel (edge_mfma.hip)
 hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,
                             const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,

@@ -472,10 +472,10 @@ hipError_t launch_node_gemm(const float* A, int lda, const float* Wt, const floa
 hipError_t launch_attention(bool x2h, const float* att, const float* x, const float* h, const int32_t* nbr,
                             const int32_t* deg, const uint8_t* lig, const uint8_t* gen, const float* e_w, int n_nodes,
                             float* P, float* Qt, float* qbuf, float* out, float* dx_out, const int* act, const int* act_count,
-                            hipStream_t s) {
+                            const int* src, const int* src_count, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
     if (g_edge_impl == 0) {
-        hipError_t e0 = launch_node_mfma(att, h, lig, n_nodes, P, qbuf, Qt, act, act_count, s);
+        hipError_t e0 = launch_node_mfma(att, h, lig, n_nodes, P, qbuf, Qt, act, act_count, src, src_count, s);
         if (e0 != hipSuccess) return e0;
         return launch_edge_mfma(x2h, att, x, h, P, Qt, nbr, deg, lig, gen, e_w, n_nodes, out, dx_out, act, act_count, s);
     }

@@ -350,6 +350,38 @@ __global__ void build_active_kernel(const uint8_t* __restrict__ flag, int n, int
     if (a) list[base + __popcll(m & ((1ull << lane) - 1ull))] = idx;
 }
 
+// ---- receptive-field pruning helpers ---------------------------------------------------------------
+__global__ void mark_seed_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int n,
+                                 uint8_t* __restrict__ m) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) m[i] = (a[i] | b[i]) ? 1 : 0;
+}
+
+// m[j] = 1 for every in-neighbour j of the listed nodes (benign write race: every writer stores 1)
+__global__ void mark_nbr_kernel(const int* __restrict__ list, const int* __restrict__ count,
+                                const int32_t* __restrict__ nbr, const int32_t* __restrict__ deg,
+                                uint8_t* __restrict__ m) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = t >> 5, e = t & 31;
+    if (k >= *count) return;
+    const int i = list[k];
+    if (e < deg[i]) m[nbr[(size_t)i * KNN + e]] = 1;
+}
+
+hipError_t launch_mark_seed(const uint8_t* a, const uint8_t* b, int n, uint8_t* m, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(mark_seed_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, n, m);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_nbr(const int* list, const int* count, int n_upper, const int32_t* nbr, const int32_t* deg,
+                           uint8_t* m, hipStream_t s) {
+    if (n_upper == 0) return hipSuccess;
+    const long threads = (long)n_upper * 32;
+    hipLaunchKernelGGL(mark_nbr_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, list, count, nbr, deg, m);
+    return hipGetLastError();
+}
+
 hipError_t launch_build_active(const uint8_t* flag, int n, int* list, int* count, hipStream_t s) {
     hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
@@ -364,13 +396,15 @@ constexpr unsigned CHUNKS_OWN = 0x30fu;   // PDk | PDv | qh: what the destinatio
 
 // node stage of one attention block: P, q (scratch), Qt.
 // `act` / `act_count` (optional): only the listed destination nodes will be processed by the edge kernel (h2x: nodes
-// that can move).  Every node can still be a *source*, so PS is produced for all rows, PD / q / Qt only for the list.
+// that can move; x2h in the last layers: nodes whose features can still reach an output).  `src` / `src_count`
+// (optional): the nodes that can be *sources* of those destinations; without it PS is produced for every node.
 hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,
-                            float* Qt, const int* act, const int* act_count, hipStream_t s) {
+                            float* Qt, const int* act, const int* act_count, const int* src, const int* src_count,
+                            hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
     const int tiles = (n_nodes + 63) / 64;
     const int grid = min(tiles, 512);
-    // few row tiles (small batches, or the h2x work list): spread the column chunks / heads over workgroups too
+    // few row tiles (small batches, or a work list): spread the column chunks / heads over workgroups too
     const bool small = tiles <= 128 || act != nullptr;
     auto py = [&](unsigned mask) { return small ? (unsigned)__builtin_popcount(mask) : 1u; };
     profile_mark_begin(K_NODE_GEMM, s);
@@ -378,8 +412,8 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
         hipLaunchKernelGGL(node_proj_kernel, dim3(grid, py(CHUNKS_ALL)), dim3(256), 0, s, att, h, lig, P, n_nodes,
                            (const int*)nullptr, (const int*)nullptr, CHUNKS_ALL);
     } else {
-        hipLaunchKernelGGL(node_proj_kernel, dim3(grid, tiles <= 128 ? py(CHUNKS_PS) : 1u), dim3(256), 0, s, att, h, lig, P,
-                           n_nodes, (const int*)nullptr, (const int*)nullptr, CHUNKS_PS);
+        hipLaunchKernelGGL(node_proj_kernel, dim3(grid, (tiles <= 128 || src) ? py(CHUNKS_PS) : 1u), dim3(256), 0, s, att, h,
+                           lig, P, n_nodes, src, src_count, CHUNKS_PS);
         hipLaunchKernelGGL(node_proj_kernel, dim3(grid, py(CHUNKS_OWN)), dim3(256), 0, s, att, h, lig, P, n_nodes, act,
                            act_count, CHUNKS_OWN);
     }

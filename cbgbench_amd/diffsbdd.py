@@ -132,7 +132,7 @@ class DiffSBDD(nn.Module):
             x[lig_rows] = x_lig
             h[lig_rows] = self.context_embedder.embed_ligand(c_lig)
             xo, _, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
-                                          graph_ptr=graph_ptr)
+                                          graph_ptr=graph_ptr, need_h=False)
             return xo[lig_rows], logits[lig_rows]
 
         mu_x = sch.scatter_mean(x_rec, br, B)[bl]

@@ -304,7 +304,7 @@ class TargetDiff(nn.Module):
             _native.ptr(emb.ligand_indicator.weight), _native.ptr(emb.ligand_indicator.bias),
             _native.ptr(st["x"]), _native.ptr(st["h"]), stream), "cbgx_targetdiff_prologue")
         xo, _, logits = self.denoiser(x=st["x"], h=st["h"], batch_idx=st["batch_idx"], lig_flag=st["lig_flag"],
-                                      gen_flag=st["gen_flag"], graph_ptr=st["graph_ptr"])
+                                      gen_flag=st["gen_flag"], graph_ptr=st["graph_ptr"], need_h=False)
         if noise is not None:
             eps, u = noise[0].float().contiguous(), noise[1].float().contiguous()
         else:   # same draw order as the reference: randn_like(x_lig) then rand_like(log-probs)

@@ -177,10 +177,12 @@ class UniTransformer(nn.Module):
         return ws
 
     # ---- forward -----------------------------------------------------------------------------
-    def forward(self, x, h, batch_idx, lig_flag, gen_flag, graph_ptr=None):
+    def forward(self, x, h, batch_idx, lig_flag, gen_flag, graph_ptr=None, need_h=True):
         """Same contract as the reference (unitransformer.py:102-123): returns (x', h', logits).
         ``batch_idx`` must be sorted (compose_context guarantees it).  ``graph_ptr`` (int32 CSR
-        offsets) may be passed to avoid recomputing it from ``batch_idx`` every call."""
+        offsets) may be passed to avoid recomputing it from ``batch_idx`` every call.  ``need_h=False`` (samplers that
+        only read ``x'`` and the logits of ligand rows): ``h'`` is returned as None, logits are defined on
+        ``lig_flag`` rows only, and the library prunes the last layers to the nodes that can still reach them."""
         if not x.is_cuda:
             raise RuntimeError("UniTransformer.forward runs on an MI355X through libcbgx; got a CPU tensor "
                                "(no CPU fallback exists; use oracle/ for CPU reference results)")
@@ -198,7 +200,7 @@ class UniTransformer(nn.Module):
         packed = self.packed_weights(device)
         ws = self.workspace(N, B, device)
         x_out = torch.empty_like(x)
-        h_out = torch.empty_like(h)
+        h_out = torch.empty_like(h) if need_h else None
         logits = torch.empty(N, self.out_classes, dtype=torch.float32, device=device)
         lib = _native.lib()
         rc = lib.cbgx_unitransformer_forward(

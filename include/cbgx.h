@@ -64,7 +64,10 @@ int cbgx_pack_weights(const float *const *tensors, int num_tensors, int num_laye
  * Replaces UniTransformer.forward (repo/modules/e3nn/unitransformer.py:102-123) with
  * cutoff_mode='knn', k=32, ew_type='global', num_blocks=1, num_x2h=num_h2x=1, relu+LayerNorm.
  * x[N,3], h[N,128], graph_ptr[B+1] int32, lig_flag[N]/gen_flag[N] uint8 (0/1).
- * Outputs x_out[N,3], h_out[N,128], logits[N,num_classes] (logits may be NULL). */
+ * Outputs x_out[N,3], h_out[N,128], logits[N,num_classes] (logits may be NULL).
+ * h_out may be NULL when the caller only consumes x_out and the logits of ligand rows (what the samplers do,
+ * targetdiff.py:164-165): the last two x2h blocks are then restricted to the nodes whose features can still reach
+ * those outputs (receptive-field pruning) and logits are defined on lig_flag rows only. */
 size_t cbgx_workspace_bytes(int n_nodes, int n_graphs);
 int cbgx_unitransformer_forward(const float *packed, int num_layers, int num_classes,
                                 const float *x, const float *h, const int32_t *graph_ptr,

@@ -333,3 +333,17 @@ def test_diffbp_sample_matches_reference(golden_dir):
     for t in range(-1, T):
         close(traj[t][0], g[f"traj_x_{t}"], f"diffbp traj x[{t}]")
         assert torch.equal(traj[t][1], g[f"traj_c_{t}"]), f"diffbp traj c[{t}]"
+
+
+@pytest.mark.parametrize("maker,n", [(synthetic.denovo_batch, 6), (synthetic.linker_batch, 5)])
+def test_receptive_field_pruning_is_exact(model, maker, n):
+    """need_h=False restricts the last two x2h blocks to the nodes that can still reach x' / ligand logits:
+    those outputs must be bit-identical to the full computation."""
+    x, h, batch_idx, lig_flag, gen, gp = _composed(model, maker(n, seed=9))
+    with torch.no_grad():
+        xf, hf, lf = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
+        xp, hp, lp = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp,
+                                    need_h=False)
+    assert hp is None
+    assert torch.equal(xp, xf)
+    assert torch.equal(lp[lig_flag], lf[lig_flag])
