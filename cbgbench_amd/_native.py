@@ -34,7 +34,7 @@ EXPORTS = {
     "cbgx_profile_end": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i), _i]),
 }
 
-PROFILE_CLASSES = ("knn", "gate", "node_gemm", "node_query", "edge_x2h", "edge_h2x")
+PROFILE_CLASSES = ("knn", "gate", "node_gemm", "node_query", "edge_x2h", "edge_h2x", "edge_x2h_listed")
 
 
 class NativeError(RuntimeError):

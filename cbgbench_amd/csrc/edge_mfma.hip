@@ -133,13 +133,16 @@ __device__ __forceinline__ floatx4 edge_major_half(const float4 (&pd)[8], const 
 
 // ABL (timing ablations only, results are wrong when != 0): 1 no Qt streaming (row 0 for every node),
 // 2 no neighbour gathers (every neighbour row = own row), 3 no rbf pre-activation MFMAs, 4 = 1+2, 5 = 1+2+3
-template <bool X2H, int WAVES, int ABL>
+// LISTED: the launch iterates over a device-side node list (h2x always; x2h in the pruned last layers) -- a separate
+// instantiation so that profilers report full-graph and listed launches under different kernel names.
+template <bool X2H, int WAVES, int ABL, bool LISTED>
 __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     const float* __restrict__ att, const float* __restrict__ x, const float* __restrict__ h,
     const float* __restrict__ P, const float* __restrict__ Qt, const int32_t* __restrict__ nbr,
     const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig, const uint8_t* __restrict__ gen,
     const float* __restrict__ e_w, int n_nodes, float* __restrict__ out, float* __restrict__ dx_out,
-    const int* __restrict__ act, const int* __restrict__ act_count) {
+    const int* __restrict__ act_arg, const int* __restrict__ act_count) {
+    const int* __restrict__ act = LISTED ? act_arg : nullptr;
     constexpr int IMG = X2H ? (int)IMG_SIZE_X2H : (int)IMG_SIZE_H2X;
     __shared__ __attribute__((aligned(16))) float lds[IMG];
     if (!X2H && act) {
@@ -569,19 +572,21 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
     int grid = (n_nodes + waves - 1) / waves;
     if (grid > 256) grid = 256;                 // persistent: one workgroup per CU (LDS-limited)
     if (grid >= 64) grid &= ~7;                 // multiple of 8 -> XCD-aware node partition
-    profile_mark_begin(x2h ? K_EDGE_X2H : K_EDGE_H2X, s);
-#define CBGX_LAUNCH_EDGE(X2H_, W_, A_)                                                                                  \
-    hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W_, A_>), dim3(grid), dim3(W_ * 64), 0, s, att, x, h, P, Qt, nbr, deg,   \
+    profile_mark_begin(x2h ? (act ? K_EDGE_X2H_LISTED : K_EDGE_X2H) : K_EDGE_H2X, s);
+#define CBGX_LAUNCH_EDGE(X2H_, W_, A_, L_)                                                                            \
+    hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W_, A_, L_>), dim3(grid), dim3(W_ * 64), 0, s, att, x, h, P, Qt, nbr, deg, \
                        lig, gen, e_w, n_nodes, out, dx_out, act, act_count)
-#define CBGX_LAUNCH_ABL(X2H_, A_) case A_: CBGX_LAUNCH_EDGE(X2H_, 8, A_); break;
-    if (waves == 12) {
-        if (x2h) CBGX_LAUNCH_EDGE(true, 12, 0); else CBGX_LAUNCH_EDGE(false, 12, 0);
+#define CBGX_LAUNCH_ABL(X2H_, A_) case A_: CBGX_LAUNCH_EDGE(X2H_, 8, A_, false); break;
+    if (act) {
+        if (x2h) CBGX_LAUNCH_EDGE(true, 8, 0, true); else CBGX_LAUNCH_EDGE(false, 8, 0, true);
+    } else if (waves == 12) {
+        if (x2h) CBGX_LAUNCH_EDGE(true, 12, 0, false); else CBGX_LAUNCH_EDGE(false, 12, 0, false);
     } else if (x2h) {
         switch (abl) { CBGX_LAUNCH_ABL(true, 1) CBGX_LAUNCH_ABL(true, 2) CBGX_LAUNCH_ABL(true, 3) CBGX_LAUNCH_ABL(true, 4)
-                       CBGX_LAUNCH_ABL(true, 5) default: CBGX_LAUNCH_EDGE(true, 8, 0); }
+                       CBGX_LAUNCH_ABL(true, 5) default: CBGX_LAUNCH_EDGE(true, 8, 0, false); }
     } else {
         switch (abl) { CBGX_LAUNCH_ABL(false, 1) CBGX_LAUNCH_ABL(false, 2) CBGX_LAUNCH_ABL(false, 3) CBGX_LAUNCH_ABL(false, 4)
-                       CBGX_LAUNCH_ABL(false, 5) default: CBGX_LAUNCH_EDGE(false, 8, 0); }
+                       CBGX_LAUNCH_ABL(false, 5) default: CBGX_LAUNCH_EDGE(false, 8, 0, false); }
     }
 #undef CBGX_LAUNCH_ABL
 #undef CBGX_LAUNCH_EDGE

@@ -147,9 +147,9 @@ int cbgx_targetdiff_epilogue(const float *x_den, const float *logits, const int3
  * Between cbgx_profile_begin() and cbgx_profile_end() every kernel launch is bracketed by HIP events on
  * its own stream.  cbgx_profile_end() synchronises them and returns, per kernel class, the summed
  * device time in ms and the launch count.  Classes: 0 knn, 1 gate, 2 node GEMM, 3 node query fold,
- * 4 x2h edge kernel, 5 h2x edge kernel (CBGX_PROFILE_CLASSES = 6).  Not thread-safe with concurrent
- * launches from other threads; process-wide. */
-#define CBGX_PROFILE_CLASSES 6
+ * 4 x2h edge kernel over all nodes, 5 h2x edge kernel (node list), 6 x2h edge kernel over a node list (pruned last
+ * layers) (CBGX_PROFILE_CLASSES = 7).  Not thread-safe with concurrent launches from other threads; process-wide. */
+#define CBGX_PROFILE_CLASSES 7
 int cbgx_profile_begin(int max_launches);
 int cbgx_profile_end(double *ms_by_class, int *launches_by_class, int num_classes);
 
