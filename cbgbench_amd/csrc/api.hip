@@ -324,12 +324,15 @@ int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_cla
     //   A2 = A1 | nbr(A1)              its sources = destinations of the x2h before it;   A3 = A2 | nbr(A2) its sources
     // Rows outside these sets are simply not written in the last two feature buffers (and never read).
     const bool prune = (h_out == nullptr) && num_layers >= 3;
+    // A1 is built in every call: it is also the set of possible *sources* of an H2X block (gen | nbr(gen), plus the
+    // non-generated ligand rows), so the h2x node projection PS is produced for those rows only.
+    HIP_TRY(launch_mark_seed(gen_flag, lig_flag, n_nodes, w.mask, s));
+    HIP_TRY(launch_mark_nbr(w.act, w.act_count, n_nodes, w.nbr, w.deg, w.mask, s));
+    HIP_TRY(launch_build_active(w.mask, n_nodes, w.rf_list[0], w.rf_count, s));
     if (prune) {
-        HIP_TRY(launch_mark_seed(gen_flag, lig_flag, n_nodes, w.mask, s));
-        HIP_TRY(launch_mark_nbr(w.act, w.act_count, n_nodes, w.nbr, w.deg, w.mask, s));
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 1; k < 3; ++k) {
+            HIP_TRY(launch_mark_nbr(w.rf_list[k - 1], w.rf_count + 16 * (k - 1), n_nodes, w.nbr, w.deg, w.mask, s));
             HIP_TRY(launch_build_active(w.mask, n_nodes, w.rf_list[k], w.rf_count + 16 * k, s));
-            if (k < 2) HIP_TRY(launch_mark_nbr(w.rf_list[k], w.rf_count + 16 * k, n_nodes, w.nbr, w.deg, w.mask, s));
         }
     }
     const float* xc = x;
@@ -346,7 +349,7 @@ int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_cla
         HIP_TRY(launch_attention(true, packed + x2h_off(l), xc, hc, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
                                  w.P, w.Qt, w.q, hn, nullptr, dst, dst_n, src, src_n, s));
         HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
-                                 w.P, w.Qt, w.q, xn, nullptr, w.act, w.act_count, nullptr, nullptr, s));
+                                 w.P, w.Qt, w.q, xn, nullptr, w.act, w.act_count, w.rf_list[0], w.rf_count, s));
         xc = xn;
         hc = hn;
     }
