@@ -1,0 +1,124 @@
+"""Sampling driver: the role of the reference's ``sample.py`` (config -> model -> per-pocket batches ->
+``model.sample`` -> one result file per pocket), minus dataset parsing and RDKit reconstruction (out of scope,
+SURVEY.md section 2), plus rank sharding of the pocket loop (``sample.py:159`` is embarrassingly parallel).
+
+    python -m cbgbench_amd.sample_cli --config cfg.yml --out_root results [--checkpoint ckpt.pt]
+                                      [--pockets pockets.pt | --synthetic 16] [--num_samples 10] [--pockets_per_batch 10]
+    torchrun --nproc-per-node 8 -m cbgbench_amd.sample_cli ...      # rank r takes pockets r, r+W, ...
+
+Pocket input: a ``torch.save``d list of dicts with ``protein_pos [n,3]``, ``protein_atom_feature [n,7]``,
+``protein_aa_type [n]`` (what ``featurize_protein_fa`` + ``center_pos`` produce, protein_featurizer.py:21-30),
+or synthetic pockets.  Output: ``{out_root}/{tag}/pocket_{i:05d}.pt`` with the final ligand positions, atom types and
+(optionally) the trajectory for each sample -- the tensors ``sample.py:198-206`` hands to reconstruction.
+A checkpoint is the reference's format: ``{'config': ..., 'model': state_dict}`` (``sample.py:153-156``)."""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import get_model, load_config, set_num_atom_type, sharding, synthetic
+
+
+def build_pocket_batch(pockets, num_samples, rng, num_classes, prior_types="uniform"):
+    """num_samples replicas of every pocket with fresh priors (sample.py:177-183; init_lig.py:392-400, 424-425)."""
+    plist, nlig = [], []
+    for p in pockets:
+        for _ in range(num_samples):
+            plist.append(p)
+            nlig.append(int(rng.integers(10, 46)))
+    batch = synthetic.make_batch(plist, nlig, rng, num_classes)
+    if prior_types == "absorbing":
+        batch["ligand_atom_type"] = torch.zeros_like(batch["ligand_atom_type"])
+    return batch
+
+
+def split_samples(x, c, batch_idx, n_graphs):
+    """per-graph (pos, atom type index) like ``split_batch_into_samples`` (sample.py:203-206)."""
+    out = []
+    for g in range(n_graphs):
+        m = batch_idx == g
+        out.append({"pos": x[m].clone(), "atom_type": c[m].argmax(-1).clone(), "type_vector": c[m].clone()})
+    return out
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", required=True)
+    ap.add_argument("--out_root", default="./results")
+    ap.add_argument("--tag", default="")
+    ap.add_argument("--checkpoint", default=None)
+    ap.add_argument("--device", default="cuda")
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--pockets", default=None, help="torch file with a list of pocket dicts")
+    ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic pockets when --pockets is not given")
+    ap.add_argument("--num_samples", type=int, default=None)
+    ap.add_argument("--pockets_per_batch", type=int, default=10)
+    ap.add_argument("--save_traj", action="store_true")
+    args = ap.parse_args(argv)
+
+    rank, world, local = sharding.init_process_group()
+    config, config_name = load_config(args.config)
+    set_num_atom_type(config)
+    if args.device.startswith("cuda"):
+        if not torch.cuda.is_available():
+            raise SystemExit("sampling needs an MI355X: the message-passing path has no CPU fallback")
+        local = local % torch.cuda.device_count()
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    else:
+        dev = torch.device(args.device)
+
+    ckpt_path = args.checkpoint or config.model.get("checkpoint", None)
+    if ckpt_path and os.path.exists(ckpt_path):
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        model_cfg = ckpt["config"].model if "config" in ckpt else config.model
+        model_cfg.num_atomtype = config.model.num_atomtype
+        model = get_model(model_cfg)
+        model.load_state_dict(ckpt["model"])            # strict, like sample.py:156
+    else:
+        model = get_model(config.model)                 # random init (no checkpoints ship with the reference)
+    model = model.to(dev).eval()
+
+    if args.pockets:
+        raw = torch.load(args.pockets, map_location="cpu", weights_only=False)
+        pockets = [(np.asarray(p["protein_pos"], np.float32), np.asarray(p["protein_atom_feature"], np.float32),
+                    np.asarray(p["protein_aa_type"], np.int64)) for p in raw]
+    else:
+        rng0 = np.random.default_rng(args.seed)
+        pockets = [synthetic.make_pocket(rng0, int(rng0.integers(350, 651))) for _ in range(max(args.synthetic, 1))]
+    num_samples = args.num_samples or config.get("sampling", {}).get("num_samples", 10)
+    prior = "absorbing" if config.model.type == "diffbp" else "uniform"
+
+    mine = sharding.shard_indices(len(pockets), rank, world)
+    out_dir = os.path.join(args.out_root, args.tag or config_name)
+    os.makedirs(out_dir, exist_ok=True)
+    torch.manual_seed(args.seed + rank)                 # independent noise streams per shard
+    rng = np.random.default_rng([args.seed, rank])
+    t0, graph_steps = time.perf_counter(), 0
+    for b0 in range(0, len(mine), args.pockets_per_batch):
+        ids = mine[b0:b0 + args.pockets_per_batch]
+        batch = build_pocket_batch([pockets[i] for i in ids], num_samples, rng, config.model.num_atomtype, prior)
+        batch = synthetic.batch_to(batch, dev)
+        traj = model.sample(batch)
+        x, c, bidx = traj[-1] if config.model.type != "diffsbdd" else traj[0]
+        samples = split_samples(x.cpu(), c.cpu(), bidx.cpu(), len(ids) * num_samples)
+        for k, pid in enumerate(ids):
+            rec = {"pocket_index": pid, "samples": samples[k * num_samples:(k + 1) * num_samples]}
+            if args.save_traj:
+                rec["traj_keys"] = sorted(traj.keys())
+            torch.save(rec, os.path.join(out_dir, f"pocket_{pid:05d}.pt"))
+        graph_steps += len(ids) * num_samples * model.num_diffusion_timesteps
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    sharding.barrier()
+    el, gs = sharding.reduce_max_sum(time.perf_counter() - t0, graph_steps, device=dev)
+    if rank == 0:
+        print(f"sampled {len(pockets)} pockets x {num_samples} samples on {world} rank(s): "
+              f"{gs / el:.1f} graph-steps/s, results in {out_dir}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -347,3 +347,19 @@ def test_receptive_field_pruning_is_exact(model, maker, n):
     assert hp is None
     assert torch.equal(xp, xf)
     assert torch.equal(lp[lig_flag], lf[lig_flag])
+
+
+def test_sampling_driver_end_to_end(tmp_path):
+    """config YAML -> registry -> model.sample on sharded pockets -> one result file per pocket (the sample.py role)."""
+    import os as _os
+    from cbgbench_amd import sample_cli
+    cfg = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "fixtures", "targetdiff_T20.yml")
+    rc = sample_cli.main(["--config", cfg, "--out_root", str(tmp_path), "--synthetic", "3", "--pockets_per_batch", "2"])
+    assert rc == 0
+    files = sorted(_os.listdir(tmp_path / "targetdiff_T20"))
+    assert files == ["pocket_00000.pt", "pocket_00001.pt", "pocket_00002.pt"]
+    rec = torch.load(tmp_path / "targetdiff_T20" / files[1], weights_only=False)
+    assert len(rec["samples"]) == 4
+    for s in rec["samples"]:
+        assert s["pos"].shape[1] == 3 and torch.isfinite(s["pos"]).all()
+        assert s["atom_type"].min() >= 0 and s["atom_type"].max() < 13
