@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pockets", type=int, default=10, help="distinct pockets per batch")
     ap.add_argument("--samples", type=int, default=10, help="samples (graphs) per pocket")
+    ap.add_argument("--workload", choices=["denovo", "linker"], default="denovo",
+                    help="denovo = BASELINE configs[1] (default); linker = configs[2]: --pockets distinct pockets, one "
+                         "graph each, fixed context atoms + a few generated linker atoms (partial gen_flag)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -151,7 +154,11 @@ def main():
     model, sd = make_model(dev)
     T = model.num_diffusion_timesteps
 
-    batch = synthetic.batch_to(build_batch(args.pockets, args.samples, seed=1000 + rank), dev)
+    if args.workload == "linker":
+        args.samples = 1
+        batch = synthetic.batch_to(synthetic.linker_batch(args.pockets, seed=1000 + rank), dev)
+    else:
+        batch = synthetic.batch_to(build_batch(args.pockets, args.samples, seed=1000 + rank), dev)
     n_graphs = args.pockets * args.samples
     st = model.begin_sampling(batch, keep_trajectory=True)
     N, E = st["N"], None
@@ -173,9 +180,12 @@ def main():
         "value": round(graph_steps / el_max, 2), "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * el_max / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs/denovo targetdiff sampling (BASELINE configs[1]): {args.pockets} pockets x "
-                               f"{args.samples} samples per batch per GPU, N_rec~U[350,650], N_lig~U[10,45], "
-                               f"k=32, 9 layers, fp32, random-init synthetic weights",
+        "config": {"workload": (f"configs/denovo targetdiff sampling (BASELINE configs[1]): {args.pockets} pockets x "
+                                f"{args.samples} samples per batch per GPU, N_rec~U[350,650], N_lig~U[10,45], "
+                                f"k=32, 9 layers, fp32, random-init synthetic weights") if args.workload == "denovo" else
+                               (f"configs/linker targetdiff sampling (BASELINE configs[2]): {args.pockets} fragment-pair "
+                                f"pockets per batch per GPU, N_rec~U[350,650], 10-35 fixed context atoms + 3-14 generated "
+                                f"atoms per graph (partial gen_flag), k=32, 9 layers, fp32, synthetic weights"),
                    "graphs_per_batch_per_gpu": n_graphs, "nodes_per_batch": N, "sharding": f"pockets x{world} ranks"},
     }
 
