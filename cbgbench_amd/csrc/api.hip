@@ -355,9 +355,12 @@ int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_cla
     }
     if (logits) {
         const float* c = packed + cls_off(num_layers);
-        HIP_TRY(launch_node_gemm(hc, H, c + C_W0T, c + C_B0, w.P, H, n_nodes, H, 1, s));
+        // pruned mode: logits are only defined on ligand rows, which are a subset of A1 (rf_list[0])
+        const int* rows = prune ? w.rf_list[0] : nullptr;
+        const int* n_rows = prune ? w.rf_count : nullptr;
+        HIP_TRY(launch_node_gemm(hc, H, c + C_W0T, c + C_B0, w.P, H, n_nodes, H, 1, s, rows, n_rows));
         HIP_TRY(launch_node_gemm(w.P, H, c + C_W1T, c + cls_b1(num_classes), logits, num_classes, n_nodes,
-                                 num_classes, 0, s));
+                                 num_classes, 0, s, rows, n_rows));
     }
     return CBGX_OK;
 }

@@ -15,7 +15,7 @@ hipError_t launch_knn(const float* x, const int32_t* graph_ptr, int n_graphs, in
 hipError_t launch_gate(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
                        float* e_w, hipStream_t s);
 hipError_t launch_node_gemm(const float* A, int lda, const float* Wt, const float* bias, float* C, int ldc, int M,
-                            int nout, int act, hipStream_t s);
+                            int nout, int act, hipStream_t s, const int* rows = nullptr, const int* n_rows = nullptr);
 // node projection + query fold + fused edge kernel of one attention block.
 // x2h: out = h_out[N,128]; h2x: out = x_out[N,3], dx_out optional.
 hipError_t launch_attention(bool x2h, const float* att, const float* x, const float* h, const int32_t* nbr,

@@ -140,12 +140,18 @@ __global__ __launch_bounds__(256) void edge_gate_kernel(const float* __restrict_
 template <int ACT>
 __global__ __launch_bounds__(256) void node_gemm_kernel(const float* __restrict__ A, int lda,
                                                         const float* __restrict__ Wt, const float* __restrict__ bias,
-                                                        float* __restrict__ C, int ldc, int M, int nout) {
+                                                        float* __restrict__ C, int ldc, int M_all, int nout,
+                                                        const int* __restrict__ rows, const int* __restrict__ n_rows_ptr) {
     __shared__ __attribute__((aligned(16))) float sA[H][16];
+    __shared__ int sRow[16];
+    const int M = rows ? *n_rows_ptr : M_all;   // optional row list: A / C rows rows[k], k < *n_rows_ptr
     const int row0 = blockIdx.x * 16;
+    if (row0 >= M) return;
+    if (threadIdx.x < 16) sRow[threadIdx.x] = row0 + threadIdx.x < M ? (rows ? rows[row0 + threadIdx.x] : row0 + threadIdx.x) : -1;
+    __syncthreads();
     for (int t = threadIdx.x; t < 16 * H; t += 256) {
         int r = t >> 7, k = t & 127;
-        sA[k][r] = (row0 + r < M) ? A[(size_t)(row0 + r) * lda + k] : 0.f;
+        sA[k][r] = (sRow[r] >= 0) ? A[(size_t)sRow[r] * lda + k] : 0.f;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < nout; c += 256) {
@@ -167,10 +173,10 @@ __global__ __launch_bounds__(256) void node_gemm_kernel(const float* __restrict_
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if (row0 + r < M) {
+            if (sRow[r] >= 0) {
                 float v = acc[r];
                 if (ACT == 1) v = (v > 20.f ? v : log1pf(expf(v))) - 0.69314718055994530942f;
-                C[(size_t)(row0 + r) * ldc + c] = v;
+                C[(size_t)sRow[r] * ldc + c] = v;
             }
         }
     }
@@ -456,14 +462,14 @@ hipError_t launch_gate(const float* packed, const float* x, const int32_t* nbr, 
 }
 
 hipError_t launch_node_gemm(const float* A, int lda, const float* Wt, const float* bias, float* C, int ldc, int M,
-                            int nout, int act, hipStream_t s) {
+                            int nout, int act, hipStream_t s, const int* rows, const int* n_rows) {
     if (M == 0) return hipSuccess;
     dim3 grid((M + 15) / 16), block(256);
     profile_mark_begin(K_NODE_GEMM, s);
     if (act == 0)
-        hipLaunchKernelGGL(node_gemm_kernel<0>, grid, block, 0, s, A, lda, Wt, bias, C, ldc, M, nout);
+        hipLaunchKernelGGL(node_gemm_kernel<0>, grid, block, 0, s, A, lda, Wt, bias, C, ldc, M, nout, rows, n_rows);
     else
-        hipLaunchKernelGGL(node_gemm_kernel<1>, grid, block, 0, s, A, lda, Wt, bias, C, ldc, M, nout);
+        hipLaunchKernelGGL(node_gemm_kernel<1>, grid, block, 0, s, A, lda, Wt, bias, C, ldc, M, nout, rows, n_rows);
     profile_mark_end(s);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
