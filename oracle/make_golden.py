@@ -56,7 +56,7 @@ def small_batch(sizes, seed, num_classes=13, ctx=None):
     return S.make_batch(pockets, [nl for _, nl in sizes], rng, num_classes, n_ctx_list=ctx)
 
 
-def denoiser_case(model, name, batch):
+def _denoiser_case(model, name, batch):
     c_lig = F.one_hot(batch["ligand_atom_type"], model.num_classes).float()
     ctx, batch_idx = compose_inputs(model, batch, batch["ligand_pos"], c_lig)
     with torch.no_grad():
@@ -78,7 +78,7 @@ def denoiser_case(model, name, batch):
     print(name, "N =", x.shape[0], "E =", edge_index.shape[1])
 
 
-def step_case(model, name, batch, t_idx, seed):
+def _step_case(model, name, batch, t_idx, seed):
     """One pass of the loop body targetdiff.py:150-180 with torch RNG seeded so that the
     scheduler's randn_like / rand_like draws can be replayed as explicit eps / u."""
     C = model.num_classes
@@ -105,7 +105,54 @@ def step_case(model, name, batch, t_idx, seed):
     print(name, "t =", t_idx)
 
 
-def sample_case(name, batch, T, seed):
+def _train_case(model, name, batch, seed, t_override=None):
+    """``model.train(); loss_dict, _ = model(batch); sum_weighted_losses(...).backward()`` (train.py:185-189) on the
+    unmodified reference, torch RNG seeded so that sample_time's randint, forward_add_noise's randn_like and
+    log_sample_categorical's rand_like can be replayed as explicit draws / eps / u.  Stores the two losses, the
+    gradient norm of every trainable tensor, full gradients of the small tensors and a strided sample of the
+    large ones."""
+    C = model.num_classes
+    T = model.num_diffusion_timesteps
+    bl = batch["ligand_element_batch"]
+    B = int(bl.max()) + 1
+    model.train()
+    model.zero_grad()
+    torch.manual_seed(seed)
+    if t_override is None:
+        loss_dict, _ = model(batch)
+    else:   # get_loss with a fixed t (covers the t == 0 decoder-NLL branch deterministically)
+        lig_flag, rec_flag = batch["ligand_lig_flag"], batch["protein_lig_flag"]
+        loss_dict, _ = model.get_loss(batch["ligand_pos"], batch["protein_pos"], batch["ligand_atom_type"],
+                                      batch["protein_atom_feature"], batch["protein_aa_type"], lig_flag, rec_flag,
+                                      bl, batch["protein_element_batch"], batch.get("ligand_gen_flag", lig_flag),
+                                      torch.zeros_like(rec_flag), t_override)
+    loss = 1.0 * loss_dict["pos"] + 100.0 * loss_dict["atom"]
+    loss.backward()
+    torch.manual_seed(seed)
+    if t_override is None:
+        draws = torch.randint(0, T, size=(B // 2 + 1,))
+        t = torch.cat([draws, T - draws - 1], 0)[:B]
+    else:
+        draws, t = torch.zeros(0, dtype=torch.long), t_override
+    eps = torch.randn_like(batch["ligand_pos"])
+    u = torch.rand(batch["ligand_pos"].shape[0], C)
+    out = {"seed": seed, "draws": _np(draws), "t": _np(t), "eps": _np(eps), "u": _np(u),
+           "loss_pos": _np(loss_dict["pos"]), "loss_atom": _np(loss_dict["atom"])}
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        out["gnorm/" + k] = np.float64(g.double().norm().item())
+        flat = g.reshape(-1)
+        out["g/" + k] = _np(flat if flat.numel() <= 2048 else flat[::61])
+    out.update({"batch_" + k: _np(v) for k, v in batch.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    model.eval()
+    model.zero_grad()
+    print(name, "loss", float(loss_dict["pos"]), float(loss_dict["atom"]), "t", t.tolist())
+
+
+def _sample_case(name, batch, T, seed):
     """Full ``TargetDiff.sample`` (targetdiff.py:127-184) of a T-step model, torch RNG seeded."""
     M = ref_shim.load_reference()
     cfg = ref_shim.targetdiff_config(13, 9)
@@ -124,7 +171,7 @@ def sample_case(name, batch, T, seed):
     print(name, "keys", sorted(traj.keys()))
 
 
-def diffsbdd_case(name, batch, T, seed):
+def _diffsbdd_case(name, batch, T, seed):
     """Full ``DiffSBDD.sample`` (diffsbdd.py:240-319) of a T-step model, torch RNG seeded; also dumps the state-dict
     key listing and the reference's own gamma table."""
     M = ref_shim.load_reference()
@@ -157,7 +204,7 @@ def diffsbdd_case(name, batch, T, seed):
     print(name, "keys", sorted(traj.keys()))
 
 
-def diffbp_case(name, batch, T, seed):
+def _diffbp_case(name, batch, T, seed):
     """Full ``DiffBP.sample`` (diffbp.py:240-299) of a T-step model, torch RNG seeded."""
     M = ref_shim.load_reference()
     cfg = ref_shim.AttrDict(
@@ -226,6 +273,42 @@ def eg5_pocket(radius=10.0):
     return (pos - centre).astype(np.float32), feat, aa, (lig - centre).astype(np.float32)
 
 
+def denoiser_case(model, name, *a, **k):
+    if _selected(name):
+        _denoiser_case(model, name, *a, **k)
+
+
+def step_case(model, name, *a, **k):
+    if _selected(name):
+        _step_case(model, name, *a, **k)
+
+
+def train_case(model, name, *a, **k):
+    if _selected(name):
+        _train_case(model, name, *a, **k)
+
+
+def sample_case(name, *a, **k):
+    if _selected(name):
+        _sample_case(name, *a, **k)
+
+
+def diffbp_case(name, *a, **k):
+    if _selected(name):
+        _diffbp_case(name, *a, **k)
+
+
+def diffsbdd_case(name, *a, **k):
+    if _selected(name):
+        _diffsbdd_case(name, *a, **k)
+
+
+def _selected(name):
+    """``python -m oracle.make_golden train_`` regenerates only the fixtures whose name contains an argument."""
+    sel = sys.argv[1:]
+    return not sel or any(a in name for a in sel)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     M = ref_shim.load_reference()
@@ -258,6 +341,9 @@ def main():
     step_case(model, "step_t500", small_batch([(64, 10), (50, 12)], seed=21), 500, seed=5)
     step_case(model, "step_t0", small_batch([(64, 10), (50, 12)], seed=22), 0, seed=6)
     step_case(model, "step_t999_linker", small_batch([(58, 15), (44, 12)], seed=23, ctx=[10, 8]), 999, seed=7)
+    train_case(model, "train_loss_denovo", small_batch([(64, 10), (50, 12), (57, 9)], seed=61), seed=15)
+    train_case(model, "train_loss_t0_linker", small_batch([(58, 15), (44, 12)], seed=62, ctx=[10, 8]), seed=16,
+               t_override=torch.tensor([0, 700]))
     sample_case("sample_T5", small_batch([(40, 8), (36, 6)], seed=31), T=5, seed=9)
     b = small_batch([(44, 9), (37, 8)], seed=51)
     b["ligand_atom_type"] = torch.zeros_like(b["ligand_atom_type"])        # absorbing-state prior (assign_atomtype: absorbing)
