@@ -29,12 +29,23 @@ EXPORTS = {
     "cbgx_targetdiff_prologue": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cbgx_targetdiff_epilogue": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp,
                                       _vp, _vp]),
+    "cbgx_train_tape_bytes": (_sz, [_i, _i]),
+    "cbgx_train_workspace_bytes": (_sz, [_i]),
+    "cbgx_unitransformer_forward_train": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz,
+                                               _vp, _sz, _vp]),
+    "cbgx_unitransformer_backward": (_i, [_vp, _i, _i, _vp, _sz, _vp, _vp, _i, _vp, _vp, _vp, ctypes.POINTER(_vp), _i,
+                                          _vp, _vp, _sz, _vp]),
+    "cbgx_x2h_attention_backward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
+                                         ctypes.POINTER(_vp), _vp, _sz, _vp]),
+    "cbgx_h2x_attention_backward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
+                                         ctypes.POINTER(_vp), _vp, _sz, _vp]),
     "cbgx_debug_set_edge_kernel": (_i, [_i]),
     "cbgx_profile_begin": (_i, [_i]),
     "cbgx_profile_end": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i), _i]),
 }
 
-PROFILE_CLASSES = ("knn", "gate", "node_gemm", "node_query", "edge_x2h", "edge_h2x", "edge_x2h_listed")
+PROFILE_CLASSES = ("knn", "gate", "node_gemm", "node_query", "edge_x2h", "edge_h2x", "edge_x2h_listed",
+                   "edge_x2h_bwd", "edge_h2x_bwd", "train_gemm")
 
 
 class NativeError(RuntimeError):

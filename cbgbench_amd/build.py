@@ -43,14 +43,20 @@ def build_native(force=False, verbose=False):
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []
-    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    # -munsafe-fp-atomics: fp32 atomicAdd of the backward kernels compiles to the hardware global_atomic_add_f32
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+             "-munsafe-fp-atomics"]
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "cbgx.h")]
+    newest_header = max(os.path.getmtime(p) for p in headers)
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+            continue
         cmd = [hipcc()] + flags + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
-        objs.append(obj)
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", LIBPATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))

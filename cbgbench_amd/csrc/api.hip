@@ -22,6 +22,17 @@ static int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+namespace cbgx {
+// same thread-local message for the entry points that live in other translation units (api_train.hip)
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace cbgx
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
@@ -132,6 +143,8 @@ static int pack_attention_block(const float* const* p, int blk, float* a, hipStr
     CP(wq1, H, 0, 1, a + A_WQ1T, H, H, H);
     CP(bq1, H, 0, 0, a + A_BQ1, H, 1, H);
     CP(wk1, H, 0, 0, a + A_WBK, H, H, H);
+    CP(wk1, H, 0, 1, a + A_WBKT, H, H, H);
+    CP(wq1, H, 0, 0, a + A_WQ1O, H, H, H);
     // centred copies of the first k / v Linears: every MFMA-path table below is built from them
     HIP_TRY(launch_center_linear(wk0, bk0, KV_IN, a + A_WAKC, a + A_BAKC, s));
     HIP_TRY(launch_center_linear(wv0, bv0, KV_IN, a + A_WAVC, a + A_BAVC, s));

@@ -1,0 +1,384 @@
+// libcbgx C ABI, training half (include/cbgx.h "training" section): taped forward, backward of single
+// attention blocks (what the parity tests call) and of the whole denoiser.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/cbgx.h"
+#include "kernels.h"
+#include "layout.h"
+#include "train.h"
+
+using namespace cbgx;
+
+namespace cbgx { int set_error(int code, const char* fmt, ...); }
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) return set_error(CBGX_E_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+#define RC_TRY(expr)         \
+    do {                     \
+        int _rc = (expr);    \
+        if (_rc) return _rc; \
+    } while (0)
+
+static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+constexpr int EDGE_GRID = 256;    // persistent workgroups of the edge backward (one per CU: ~97 KB LDS each)
+constexpr int NODE_GRID = 128;    // persistent workgroups of the node-level reductions
+constexpr int GATE_GRID = 256;
+constexpr int MAX_SPLITS = 32;
+
+// ---- tape: what the taped forward keeps for the backward ------------------------------------------------
+struct Tape {
+    int32_t* nbr;
+    int32_t* deg;
+    float* e_w;
+    float* xs;   // [(L+1)][N][3]   xs[l] = coordinates entering layer l
+    float* hs;   // [(L+1)][N][128] hs[l] = features entering layer l (hs[l+1] = x2h output = h2x input)
+    size_t total;
+};
+
+static Tape carve_tape(void* base, int n, int L) {
+    Tape t;
+    size_t off = 0;
+    char* b = (char*)base;
+    auto take = [&](size_t bytes) { char* p = b + off; off += align_up(bytes); return p; };
+    const size_t N = (size_t)(n > 0 ? n : 1);
+    t.nbr = (int32_t*)take(N * KNN * 4);
+    t.deg = (int32_t*)take(N * 4);
+    t.e_w = (float*)take(N * KNN * 4);
+    t.xs = (float*)take((size_t)(L + 1) * N * 3 * 4);
+    t.hs = (float*)take((size_t)(L + 1) * N * H * 4);
+    t.total = off;
+    return t;
+}
+
+// ---- backward workspace -----------------------------------------------------------------------------------
+struct TrainWs {
+    float *P, *Qt, *Gt, *T, *S, *gb, *sw, *qs, *dqb, *zb, *dP, *gh, *gx[2], *de_w, *E8, *tmp, *partial;
+    int *act, *act_count;
+    size_t partial_floats;
+    size_t total;
+};
+
+static size_t partial_floats_needed() {
+    size_t a = (size_t)EDGE_GRID * PB_SIZE;
+    size_t b = (size_t)NODE_GRID * H * H;
+    size_t c = (size_t)MAX_SPLITS * H * PROW;
+    size_t d = (size_t)GATE_GRID * GB_SIZE;
+    size_t m = a > b ? a : b;
+    m = m > c ? m : c;
+    return m > d ? m : d;
+}
+
+static TrainWs carve_train(void* base, int n) {
+    TrainWs w;
+    size_t off = 0;
+    char* b = (char*)base;
+    auto take = [&](size_t bytes) { char* p = b + off; off += align_up(bytes); return p; };
+    const size_t N = (size_t)(n > 0 ? n : 1);
+    w.P = (float*)take(N * PROW * 4);
+    w.Qt = (float*)take(N * HEADS * H * 4);
+    w.Gt = (float*)take(N * HEADS * H * 4);
+    w.T = (float*)take(N * HEADS * H * 4);
+    w.S = (float*)take(N * HEADS * H * 4);
+    w.gb = (float*)take(N * HEADS * 4);
+    w.sw = (float*)take(N * HEADS * 4);
+    w.qs = (float*)take(N * H * 4);
+    w.dqb = (float*)take(N * H * 4);
+    w.zb = (float*)take(N * H * 4);
+    w.dP = (float*)take(N * PROW * 4);
+    w.gh = (float*)take(N * H * 4);
+    w.gx[0] = (float*)take(N * 3 * 4);
+    w.gx[1] = (float*)take(N * 3 * 4);
+    w.de_w = (float*)take(N * KNN * 4);
+    w.E8 = (float*)take(N * KNN * 8 * 4);
+    w.tmp = (float*)take(N * H * 4);
+    w.act = (int*)take(N * 4);
+    w.act_count = (int*)take(256);
+    w.partial_floats = partial_floats_needed();
+    w.partial = (float*)take(w.partial_floats * 4);
+    w.total = off;
+    return w;
+}
+
+static inline int edge_grid(int n) { return n < EDGE_GRID ? (n > 0 ? n : 1) : EDGE_GRID; }
+static inline int node_grid(int n) { return n < NODE_GRID ? (n > 0 ? n : 1) : NODE_GRID; }
+static inline int splits_for(int n) {
+    int s = (n + 511) / 512;
+    return s < 1 ? 1 : (s > MAX_SPLITS ? MAX_SPLITS : s);
+}
+
+#define RS(src, nsl, stride, ld, rows, cols, dst, dld, tr) \
+    HIP_TRY(launch_reduce_store(src, nsl, stride, ld, rows, cols, dst, dld, tr, s))
+
+// Backward of one attention block.
+//   x2h: g_out = dL/dh_out [N,128];   h2x: g_out = dL/dx_out [N,3] (only gen rows matter; rows = gen list)
+// Effects: gh [N,128] += dL/dh_in contributions (x2h: gh must already hold g_out -- the residual path -- and is
+// updated in place; h2x: gh += ...), dx [N,3] += coordinate gradients (atomics), de_w += gate gradients,
+// grads[18] (k6 v6 q6 tensors, reference layouts) overwritten.
+static int attention_block_backward(bool x2h, const float* att, const float* x, const float* h_in, const float* g_out,
+                                    const int32_t* nbr, const int32_t* deg, const uint8_t* lig, const float* e_w,
+                                    const int* rows, const int* n_rows, int n, TrainWs& w, float* gh, float* dx,
+                                    float* de_w, float* const* grads, hipStream_t s) {
+    const int eg = edge_grid(n), ng = node_grid(n);
+    // recompute the node stage of the forward (first-generation kernels: uncentred projection)
+    HIP_TRY(launch_node_gemm(h_in, H, att + A_WN, att + A_BN, w.P, PROW, n, PROW, 0, s));
+    HIP_TRY(launch_node_query_v1(att, w.P, w.Qt, n, s));
+    if (x2h) HIP_TRY(launch_fold_grad(att, g_out, n, w.Gt, w.gb, s));
+    HIP_TRY(hipMemsetAsync(w.dP, 0, (size_t)n * PROW * sizeof(float), s));
+    HIP_TRY(launch_edge_backward(x2h, att, x, w.P, w.Qt, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n, w.T,
+                                 w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s));
+    float *k0w = grads[0], *k0b = grads[1], *kg = grads[2], *kb = grads[3], *k1w = grads[4], *k1b = grads[5];
+    float *v0w = grads[6], *v0b = grads[7], *vg = grads[8], *vb = grads[9], *v1w = grads[10], *v1b = grads[11];
+    float *q0w = grads[12], *q0b = grads[13], *qg = grads[14], *qb = grads[15], *q1w = grads[16], *q1b = grads[17];
+    {   // edge-indexed weight gradients: type / rbf columns of the first Linears, LayerNorm affine
+        const float* pz = w.partial;
+        RS(pz + PB_WT, eg, PB_SIZE, 2 * H, NT, H, k0w, KV_IN, 1);
+        RS(pz + PB_WT + H, eg, PB_SIZE, 2 * H, NT, H, v0w, KV_IN, 1);
+        RS(pz + PB_WR, eg, PB_SIZE, 2 * H, NT * G, H, k0w + NT, KV_IN, 1);
+        RS(pz + PB_WR + H, eg, PB_SIZE, 2 * H, NT * G, H, v0w + NT, KV_IN, 1);
+        RS(pz + PB_LNG, eg, PB_SIZE, H, 1, H, kg, H, 0);
+        RS(pz + PB_LNG + H, eg, PB_SIZE, H, 1, H, vg, H, 0);
+        RS(pz + PB_LNB, eg, PB_SIZE, H, 1, H, kb, H, 0);
+        RS(pz + PB_LNB + H, eg, PB_SIZE, H, 1, H, vb, H, 0);
+        if (!x2h) {
+            RS(pz + PB_WBV16, eg, PB_SIZE, H, HEADS, H, v1w, H, 0);
+            RS(pz + PB_BBV16, eg, PB_SIZE, HEADS, 1, HEADS, v1b, HEADS, 0);
+        }
+    }
+    // query MLP backward (fills dP[:, 512:640]) and its LayerNorm affine gradients
+    HIP_TRY(launch_q_backward(att, w.P, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, w.partial, ng, s));
+    RS(w.partial, ng, 2 * H, H, 1, H, qg, H, 0);
+    RS(w.partial + H, ng, 2 * H, H, 1, H, qb, H, 0);
+    // second Linears: dWbk = sum_i (q_i / sqrt 8) (x) T_i ;  x2h: dWbv = sum_i G_i (x) S_i ;  dWq1 = sum_i dq_i (x) z_i
+    HIP_TRY(launch_outer_accum(true, w.qs, w.T, rows, n_rows, n, w.partial, ng, s));
+    RS(w.partial, ng, (size_t)H * H, H, H, H, k1w, H, 0);
+    HIP_TRY(hipMemsetAsync(k1b, 0, H * sizeof(float), s));   // the key bias cancels in the softmax
+    if (x2h) {
+        HIP_TRY(launch_outer_accum(true, g_out, w.S, rows, n_rows, n, w.partial, ng, s));
+        RS(w.partial, ng, (size_t)H * H, H, H, H, v1w, H, 0);
+        HIP_TRY(launch_colsum(g_out, H, H, w.sw, rows, n_rows, n, w.partial, ng, s));
+        RS(w.partial, ng, H, H, 1, H, v1b, H, 0);
+    }
+    HIP_TRY(launch_outer_accum(false, w.dqb, w.zb, rows, n_rows, n, w.partial, ng, s));
+    RS(w.partial, ng, (size_t)H * H, H, H, H, q1w, H, 0);
+    HIP_TRY(launch_colsum(w.dqb, H, H, nullptr, rows, n_rows, n, w.partial, ng, s));
+    RS(w.partial, ng, H, H, 1, H, q1b, H, 0);
+    // first-Linear biases = column sums of dP (k | v | - | - | q hidden)
+    HIP_TRY(launch_colsum(w.dP, PROW, PROW, nullptr, nullptr, nullptr, n, w.partial, ng, s));
+    RS(w.partial, ng, PROW, PROW, 1, H, k0b, H, 0);
+    RS(w.partial + H, ng, PROW, PROW, 1, H, v0b, H, 0);
+    RS(w.partial + 4 * H, ng, PROW, PROW, 1, H, q0b, H, 0);
+    // dense projection: dWn[k][n] = sum_i h_in[i][k] dP[i][n]  -> h_dst / h_src / q columns of the first Linears
+    const int sp = splits_for(n);
+    HIP_TRY(launch_sgemm(true, false, h_in, H, w.dP, PROW, w.partial, PROW, H, PROW, n, sp, (size_t)H * PROW, 0, s));
+    {
+        const size_t st = (size_t)H * PROW;
+        RS(w.partial + 0 * H, sp, st, PROW, H, H, k0w + NT + NT * G, KV_IN, 1);
+        RS(w.partial + 1 * H, sp, st, PROW, H, H, v0w + NT + NT * G, KV_IN, 1);
+        RS(w.partial + 2 * H, sp, st, PROW, H, H, k0w + NT + NT * G + H, KV_IN, 1);
+        RS(w.partial + 3 * H, sp, st, PROW, H, H, v0w + NT + NT * G + H, KV_IN, 1);
+        RS(w.partial + 4 * H, sp, st, PROW, H, H, q0w, H, 1);
+    }
+    // dL/dh_in += dP Wn^T
+    HIP_TRY(launch_sgemm(false, true, w.dP, PROW, att + A_WN, PROW, gh, H, n, H, PROW, 1, 0, 1, s));
+    return CBGX_OK;
+}
+
+static int check_grads(float* const* g, int count, const char* who) {
+    if (!g) return set_error(CBGX_E_INVALID, "%s: grads is NULL", who);
+    for (int i = 0; i < count; ++i)
+        if (!g[i]) return set_error(CBGX_E_INVALID, "%s: grads[%d] is NULL", who, i);
+    return CBGX_OK;
+}
+
+extern "C" {
+
+size_t cbgx_train_tape_bytes(int n_nodes, int num_layers) {
+    if (n_nodes < 0 || num_layers < 1) return 0;
+    return carve_tape(nullptr, n_nodes, num_layers).total;
+}
+
+size_t cbgx_train_workspace_bytes(int n_nodes) {
+    if (n_nodes < 0) return 0;
+    return carve_train(nullptr, n_nodes).total;
+}
+
+int cbgx_unitransformer_forward_train(const float* packed, int num_layers, int num_classes, const float* x,
+                                      const float* h, const int32_t* graph_ptr, const uint8_t* lig_flag,
+                                      const uint8_t* gen_flag, int n_nodes, int n_graphs, float* x_out, float* h_out,
+                                      float* logits, void* tape, size_t tape_bytes, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    if (n_nodes < 0 || n_graphs < 0 || num_layers < 1) return set_error(CBGX_E_INVALID, "forward_train: bad sizes");
+    if (n_nodes == 0) return CBGX_OK;
+    if (!packed || !x || !h || !graph_ptr || !lig_flag || !gen_flag || !x_out || !tape || !workspace)
+        return set_error(CBGX_E_INVALID, "forward_train: NULL pointer");
+    Tape tp = carve_tape(tape, n_nodes, num_layers);
+    if (tape_bytes < tp.total) return set_error(CBGX_E_WORKSPACE, "forward_train: tape %zu < %zu", tape_bytes, tp.total);
+    TrainWs w = carve_train(workspace, n_nodes);
+    if (workspace_bytes < w.total)
+        return set_error(CBGX_E_WORKSPACE, "forward_train: workspace %zu < %zu", workspace_bytes, w.total);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nx = (size_t)n_nodes * 3, nh = (size_t)n_nodes * H;
+    HIP_TRY(hipMemcpyAsync(tp.xs, x, nx * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(tp.hs, h, nh * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, tp.nbr, tp.deg, s));
+    HIP_TRY(launch_gate(packed, x, tp.nbr, tp.deg, n_nodes, tp.e_w, s));
+    HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, s));
+    for (int l = 0; l < num_layers; ++l) {
+        const float* xc = tp.xs + (size_t)l * nx;
+        const float* hc = tp.hs + (size_t)l * nh;
+        float* xn = tp.xs + (size_t)(l + 1) * nx;
+        float* hn = tp.hs + (size_t)(l + 1) * nh;
+        HIP_TRY(launch_attention(true, packed + x2h_off(l), xc, hc, tp.nbr, tp.deg, lig_flag, gen_flag, tp.e_w, n_nodes,
+                                 w.P, w.Qt, w.qs, hn, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+        HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, tp.nbr, tp.deg, lig_flag, gen_flag, tp.e_w, n_nodes,
+                                 w.P, w.Qt, w.qs, xn, nullptr, w.act, w.act_count, nullptr, nullptr, s));
+    }
+    const float* hl = tp.hs + (size_t)num_layers * nh;
+    HIP_TRY(hipMemcpyAsync(x_out, tp.xs + (size_t)num_layers * nx, nx * 4, hipMemcpyDeviceToDevice, s));
+    if (h_out) HIP_TRY(hipMemcpyAsync(h_out, hl, nh * 4, hipMemcpyDeviceToDevice, s));
+    if (logits) {
+        if (num_classes < 1) return set_error(CBGX_E_INVALID, "forward_train: num_classes=%d", num_classes);
+        const float* c = packed + cls_off(num_layers);
+        HIP_TRY(launch_node_gemm(hl, H, c + C_W0T, c + C_B0, w.P, H, n_nodes, H, 1, s));
+        HIP_TRY(launch_node_gemm(w.P, H, c + C_W1T, c + cls_b1(num_classes), logits, num_classes, n_nodes, num_classes,
+                                 0, s));
+    }
+    return CBGX_OK;
+}
+
+int cbgx_x2h_attention_backward(const float* packed, int layer, const float* x, const float* h, const int32_t* nbr,
+                                const int32_t* deg, const uint8_t* lig_flag, const float* e_w, int n_nodes,
+                                const float* grad_h_out, float* grad_h, float* grad_x, float* grad_e_w,
+                                float* const* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n_nodes <= 0 || layer < 0) return set_error(CBGX_E_INVALID, "x2h_backward: bad sizes");
+    if (!packed || !x || !h || !nbr || !deg || !lig_flag || !e_w || !grad_h_out || !grad_h || !grad_x || !grad_e_w ||
+        !workspace)
+        return set_error(CBGX_E_INVALID, "x2h_backward: NULL pointer");
+    RC_TRY(check_grads(grads, 18, "x2h_backward"));
+    TrainWs w = carve_train(workspace, n_nodes);
+    if (workspace_bytes < w.total)
+        return set_error(CBGX_E_WORKSPACE, "x2h_backward: workspace %zu < %zu", workspace_bytes, w.total);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(grad_h, grad_h_out, (size_t)n_nodes * H * 4, hipMemcpyDeviceToDevice, s));   // residual
+    HIP_TRY(hipMemsetAsync(grad_x, 0, (size_t)n_nodes * 3 * 4, s));
+    HIP_TRY(hipMemsetAsync(grad_e_w, 0, (size_t)n_nodes * KNN * 4, s));
+    return attention_block_backward(true, packed + x2h_off(layer), x, h, grad_h_out, nbr, deg, lig_flag, e_w, nullptr,
+                                    nullptr, n_nodes, w, grad_h, grad_x, grad_e_w, grads, s);
+}
+
+int cbgx_h2x_attention_backward(const float* packed, int layer, const float* x, const float* h, const int32_t* nbr,
+                                const int32_t* deg, const uint8_t* lig_flag, const uint8_t* gen_flag, const float* e_w,
+                                int n_nodes, const float* grad_x_out, float* grad_h, float* grad_x, float* grad_e_w,
+                                float* const* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n_nodes <= 0 || layer < 0) return set_error(CBGX_E_INVALID, "h2x_backward: bad sizes");
+    if (!packed || !x || !h || !nbr || !deg || !lig_flag || !gen_flag || !e_w || !grad_x_out || !grad_h || !grad_x ||
+        !grad_e_w || !workspace)
+        return set_error(CBGX_E_INVALID, "h2x_backward: NULL pointer");
+    RC_TRY(check_grads(grads, 18, "h2x_backward"));
+    TrainWs w = carve_train(workspace, n_nodes);
+    if (workspace_bytes < w.total)
+        return set_error(CBGX_E_WORKSPACE, "h2x_backward: workspace %zu < %zu", workspace_bytes, w.total);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, s));
+    HIP_TRY(hipMemsetAsync(grad_h, 0, (size_t)n_nodes * H * 4, s));
+    HIP_TRY(hipMemcpyAsync(grad_x, grad_x_out, (size_t)n_nodes * 3 * 4, hipMemcpyDeviceToDevice, s));   // x_out = x + ...
+    HIP_TRY(hipMemsetAsync(grad_e_w, 0, (size_t)n_nodes * KNN * 4, s));
+    return attention_block_backward(false, packed + h2x_off(layer), x, h, grad_x_out, nbr, deg, lig_flag, e_w, w.act,
+                                    w.act_count, n_nodes, w, grad_h, grad_x, grad_e_w, grads, s);
+}
+
+int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_classes, const void* tape,
+                                 size_t tape_bytes, const uint8_t* lig_flag, const uint8_t* gen_flag, int n_nodes,
+                                 const float* grad_x_out, const float* grad_h_out, const float* grad_logits,
+                                 float* const* grads, int num_grads, float* grad_h_in, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (n_nodes <= 0 || num_layers < 1 || num_classes < 1) return set_error(CBGX_E_INVALID, "backward: bad sizes");
+    if (!packed || !tape || !lig_flag || !gen_flag || !workspace) return set_error(CBGX_E_INVALID, "backward: NULL pointer");
+    if (num_grads != 6 + 36 * num_layers + 4)
+        return set_error(CBGX_E_INVALID, "backward: expected %d gradient tensors, got %d", 6 + 36 * num_layers + 4, num_grads);
+    RC_TRY(check_grads(grads, num_grads, "backward"));
+    Tape tp = carve_tape((void*)tape, n_nodes, num_layers);
+    if (tape_bytes < tp.total) return set_error(CBGX_E_WORKSPACE, "backward: tape %zu < %zu", tape_bytes, tp.total);
+    TrainWs w = carve_train(workspace, n_nodes);
+    if (workspace_bytes < w.total)
+        return set_error(CBGX_E_WORKSPACE, "backward: workspace %zu < %zu", workspace_bytes, w.total);
+    hipStream_t s = (hipStream_t)stream;
+    const int n = n_nodes, L = num_layers, C = num_classes;
+    const size_t nx = (size_t)n * 3, nh = (size_t)n * H;
+    const int ng = node_grid(n), sp = splits_for(n);
+
+    // dL/dh_L: the caller's gradient plus the classifier head
+    if (grad_h_out) HIP_TRY(hipMemcpyAsync(w.gh, grad_h_out, nh * 4, hipMemcpyDeviceToDevice, s));
+    else HIP_TRY(hipMemsetAsync(w.gh, 0, nh * 4, s));
+    float* const* cg = grads + 6 + 36 * L;
+    if (grad_logits) {
+        const float* c = packed + cls_off(L);
+        const float* hl = tp.hs + (size_t)L * nh;
+        float* pre = w.qs;    // [N,128] scratch
+        float* act = w.zb;
+        float* dact = w.dqb;
+        HIP_TRY(launch_node_gemm(hl, H, c + C_W0T, c + C_B0, pre, H, n, H, 0, s));
+        HIP_TRY(launch_node_gemm(hl, H, c + C_W0T, c + C_B0, act, H, n, H, 1, s));
+        // classifier.2: dW1[c][k] = sum_i dlogits[i][c] act[i][k];  db1 = colsum(dlogits)
+        HIP_TRY(launch_sgemm(true, false, grad_logits, C, act, H, w.partial, H, C, H, n, sp, (size_t)C * H, 0, s));
+        RS(w.partial, sp, (size_t)C * H, H, C, H, cg[2], H, 0);
+        HIP_TRY(launch_colsum(grad_logits, C, C, nullptr, nullptr, nullptr, n, w.partial, ng, s));
+        RS(w.partial, ng, C, C, 1, C, cg[3], C, 0);
+        // d(act) = dlogits W1  (C_W1T is [128][C]);  d(pre) = d(act) sigmoid(pre)
+        HIP_TRY(launch_sgemm(false, true, grad_logits, C, c + C_W1T, C, dact, H, n, H, C, 1, 0, 0, s));
+        HIP_TRY(launch_ssp_backward(pre, dact, (long)nh, w.tmp, s));
+        // classifier.0: dW0[n][k] = sum_i dpre[i][n] h[i][k];  db0 = colsum(dpre);  dh += dpre W0
+        HIP_TRY(launch_sgemm(true, false, w.tmp, H, hl, H, w.partial, H, H, H, n, sp, (size_t)H * H, 0, s));
+        RS(w.partial, sp, (size_t)H * H, H, H, H, cg[0], H, 0);
+        HIP_TRY(launch_colsum(w.tmp, H, H, nullptr, nullptr, nullptr, n, w.partial, ng, s));
+        RS(w.partial, ng, H, H, 1, H, cg[1], H, 0);
+        HIP_TRY(launch_sgemm(false, true, w.tmp, H, c + C_W0T, H, w.gh, H, n, H, H, 1, 0, 1, s));
+    } else {
+        HIP_TRY(hipMemsetAsync(cg[0], 0, (size_t)H * H * 4, s));
+        HIP_TRY(hipMemsetAsync(cg[1], 0, H * 4, s));
+        HIP_TRY(hipMemsetAsync(cg[2], 0, (size_t)C * H * 4, s));
+        HIP_TRY(hipMemsetAsync(cg[3], 0, C * 4, s));
+    }
+    int cur = 0;
+    if (grad_x_out) HIP_TRY(hipMemcpyAsync(w.gx[cur], grad_x_out, nx * 4, hipMemcpyDeviceToDevice, s));
+    else HIP_TRY(hipMemsetAsync(w.gx[cur], 0, nx * 4, s));
+    HIP_TRY(hipMemsetAsync(w.de_w, 0, (size_t)n * KNN * 4, s));
+    HIP_TRY(launch_build_active(gen_flag, n, w.act, w.act_count, s));
+
+    for (int l = L - 1; l >= 0; --l) {
+        const float* xl = tp.xs + (size_t)l * nx;
+        const float* h_in = tp.hs + (size_t)l * nh;
+        const float* h_mid = tp.hs + (size_t)(l + 1) * nh;
+        float* const* g = grads + 6 + 36 * l;
+        // x_{l+1} = x_l + gen * H2X(x_l, h_mid): identity path first, then the block's own contributions
+        const int nxt = cur ^ 1;
+        HIP_TRY(hipMemcpyAsync(w.gx[nxt], w.gx[cur], nx * 4, hipMemcpyDeviceToDevice, s));
+        RC_TRY(attention_block_backward(false, packed + h2x_off(l), xl, h_mid, w.gx[cur], tp.nbr, tp.deg, lig_flag, tp.e_w,
+                                        w.act, w.act_count, n, w, w.gh, w.gx[nxt], w.de_w, g + 18, s));
+        // h_mid = h_in + X2H(x_l, h_in): w.gh holds dL/dh_mid, which is also the residual part of dL/dh_in.  The edge
+        // kernel reads it (through the fold) before the final GEMM accumulates into it, so a snapshot is needed.
+        HIP_TRY(hipMemcpyAsync(w.tmp, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
+        RC_TRY(attention_block_backward(true, packed + x2h_off(l), xl, h_in, w.tmp, tp.nbr, tp.deg, lig_flag, tp.e_w,
+                                        nullptr, nullptr, n, w, w.gh, w.gx[nxt], w.de_w, g, s));
+        cur = nxt;
+    }
+    if (grad_h_in) HIP_TRY(hipMemcpyAsync(grad_h_in, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
+    // distance gate (computed once from the input coordinates, used by all 2L blocks)
+    HIP_TRY(launch_gate_backward(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.E8, w.partial, GATE_GRID, s));
+    RS(w.partial + GB_W1, GATE_GRID, GB_SIZE, G, GH, G, grads[0], G, 0);
+    RS(w.partial + GB_B1, GATE_GRID, GB_SIZE, GH, 1, GH, grads[1], GH, 0);
+    RS(w.partial + GB_LNG, GATE_GRID, GB_SIZE, GH, 1, GH, grads[2], GH, 0);
+    RS(w.partial + GB_LNB, GATE_GRID, GB_SIZE, GH, 1, GH, grads[3], GH, 0);
+    RS(w.partial + GB_W2, GATE_GRID, GB_SIZE, GH, 1, GH, grads[4], GH, 0);
+    RS(w.partial + GB_B2, GATE_GRID, GB_SIZE, 1, 1, 1, grads[5], 1, 0);
+    return CBGX_OK;
+}
+
+}  // extern "C"

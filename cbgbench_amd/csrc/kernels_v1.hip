@@ -6,6 +6,7 @@
 
 #include "kernels.h"
 #include "layout.h"
+#include "train.h"
 
 namespace cbgx {
 
@@ -498,6 +499,15 @@ hipError_t launch_attention(bool x2h, const float* att, const float* x, const fl
     else
         hipLaunchKernelGGL(edge_attention_kernel<false>, dim3(n_nodes), dim3(128), 0, s, att, x, h, P, Qt, nbr, deg,
                            lig, gen, e_w, n_nodes, out, dx_out);
+    profile_mark_end(s);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_node_query_v1(const float* att, const float* P, float* Qt, int n_nodes, hipStream_t s) {
+    if (n_nodes == 0) return hipSuccess;
+    profile_mark_begin(K_NODE_QUERY, s);
+    hipLaunchKernelGGL(node_query_kernel, dim3((n_nodes + 15) / 16), dim3(256), 0, s, att, P, Qt, n_nodes);
     profile_mark_end(s);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;

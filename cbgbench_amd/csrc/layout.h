@@ -70,7 +70,10 @@ constexpr size_t A_BAKC = A_WAKC + (size_t)H * KV_IN;
 constexpr size_t A_WAVC = A_BAKC + H;
 constexpr size_t A_BAVC = A_WAVC + (size_t)H * KV_IN;
 constexpr size_t A_BN2 = A_BAVC + H;
-constexpr size_t ATT_SIZE = A_BN2 + 2 * PROW;
+// backward-only copies: Wbk transposed [m][n] and the second q Linear in the reference layout [n][k]
+constexpr size_t A_WBKT = A_BN2 + 2 * PROW;
+constexpr size_t A_WQ1O = A_WBKT + (size_t)H * H;
+constexpr size_t ATT_SIZE = A_WQ1O + (size_t)H * H;
 
 constexpr size_t LAYER_SIZE = 2 * ATT_SIZE;       // x2h then h2x
 

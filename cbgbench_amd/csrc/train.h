@@ -1,0 +1,54 @@
+// internal declarations of the training (backward) kernels, train_bwd.hip / api_train.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "layout.h"
+
+namespace cbgx {
+
+// per-workgroup partial gradient slab of edge_backward_kernel (floats)
+constexpr int PB_WR = 0;                          // [4][20][256]  rbf columns of the first Linear (k | v)
+constexpr int PB_WT = PB_WR + NT * G * 2 * H;     // [4][256]      type columns
+constexpr int PB_LNG = PB_WT + NT * 2 * H;        // [256]         LayerNorm gamma (k | v)
+constexpr int PB_LNB = PB_LNG + 2 * H;            // [256]         LayerNorm beta
+constexpr int PB_WBV16 = PB_LNB + 2 * H;          // h2x: [16][128] second v Linear
+constexpr int PB_BBV16 = PB_WBV16 + HEADS * H;    // h2x: [16]
+constexpr int PB_SIZE = PB_BBV16 + HEADS;
+
+// partial slab of gate_bwd_weight_kernel
+constexpr int GB_W1 = 0;                 // [160][20]
+constexpr int GB_B1 = GB_W1 + GH * G;
+constexpr int GB_LNG = GB_B1 + GH;
+constexpr int GB_LNB = GB_LNG + GH;
+constexpr int GB_W2 = GB_LNB + GH;
+constexpr int GB_B2 = GB_W2 + GH;
+constexpr int GB_SIZE = GB_B2 + 4;
+
+hipError_t launch_edge_backward(bool x2h, const float* att, const float* x, const float* P, const float* Qt,
+                                const float* Gt, const float* gb, const float* gx_out, const int32_t* nbr,
+                                const int32_t* deg, const uint8_t* lig, const float* e_w, const int* rows,
+                                const int* n_rows, int n_nodes, float* T, float* S, float* sw, float* dP, float* dx,
+                                float* de_w, float* partial, int grid, hipStream_t s);
+hipError_t launch_fold_grad(const float* att, const float* Gr, int n_nodes, float* Gt, float* gb, hipStream_t s);
+hipError_t launch_q_backward(const float* att, const float* P, const float* T, const int* rows, const int* n_rows,
+                             int n_nodes, float* qs, float* dqb, float* zb, float* dP, float* partial, int grid,
+                             hipStream_t s);
+hipError_t launch_outer_accum(bool headed, const float* Lm, const float* R, const int* rows, const int* n_rows,
+                              int n_nodes, float* partial, int grid, hipStream_t s);
+hipError_t launch_colsum(const float* A, int lda, int cols, const float* scale, const int* rows, const int* n_rows_ptr,
+                         int n_rows, float* partial, int grid, hipStream_t s);
+hipError_t launch_reduce_store(const float* src, int n_slabs, size_t slab_stride, int src_ld, int rows, int cols,
+                               float* dst, int dst_ld, int transpose, hipStream_t s);
+// C[z] (+)= op(A) op(B); A is [M,K] (ta: stored [K,M]), B is [K,N] (tb: stored [N,K]); `splits` partitions K and
+// writes split z to C + z * c_split_stride (accumulate must be 0 when splits > 1)
+hipError_t launch_sgemm(bool ta, bool tb, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
+                        int N, int K, int splits, size_t c_split_stride, int accumulate, hipStream_t s);
+hipError_t launch_gate_backward(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
+                                const float* de_w, float* E8, float* partial, int grid, hipStream_t s);
+hipError_t launch_ssp_backward(const float* pre, const float* dact, long n, float* dpre, hipStream_t s);
+hipError_t launch_add_inplace(float* dst, const float* src, long n, hipStream_t s);
+// first-generation forward node kernels, used by the backward's recomputation (kernels_v1.hip)
+hipError_t launch_node_query_v1(const float* att, const float* P, float* Qt, int n_nodes, hipStream_t s);
+
+}  // namespace cbgx

@@ -75,3 +75,52 @@ def classifier(packed, num_layers, num_classes, h):
                                        _native.ptr(logits), _native.ptr(ws), ws.numel(), _stream(h))
     _native.check(rc, "cbgx_classifier")
     return logits
+
+
+# ---- backward of single attention blocks (training; include/cbgx.h "training" section) ---------------------
+_MLP_SHAPES_X2H = [(128, 340), (128,), (128,), (128,), (128, 128), (128,)] * 2 + \
+                  [(128, 128), (128,), (128,), (128,), (128, 128), (128,)]
+_MLP_SHAPES_H2X = [(128, 340), (128,), (128,), (128,), (128, 128), (128,)] + \
+                  [(128, 340), (128,), (128,), (128,), (16, 128), (16,)] + \
+                  [(128, 128), (128,), (128,), (128,), (128, 128), (128,)]
+
+
+def _train_ws(n, device):
+    return torch.empty(_native.lib().cbgx_train_workspace_bytes(n), dtype=torch.uint8, device=device)
+
+
+def _grad_tensors(shapes, device):
+    import ctypes
+    gs = [torch.empty(s, dtype=torch.float32, device=device) for s in shapes]
+    arr = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+    return gs, arr
+
+
+def x2h_attention_backward(packed, layer, x, h, nbr, deg, lig_flag, e_w, grad_h_out):
+    """-> (grad_h, grad_x, grad_e_w, [18 parameter gradients: hk_func(6), hv_func(6), hq_func(6)])."""
+    N = x.shape[0]
+    gh, gx = torch.empty_like(h), torch.empty_like(x)
+    gew = torch.empty_like(e_w)
+    grads, arr = _grad_tensors(_MLP_SHAPES_X2H, x.device)
+    ws = _train_ws(N, x.device)
+    rc = _native.lib().cbgx_x2h_attention_backward(
+        _native.ptr(packed), layer, _native.ptr(x), _native.ptr(h), _native.ptr(nbr), _native.ptr(deg),
+        _native.ptr(lig_flag), _native.ptr(e_w), N, _native.ptr(grad_h_out.contiguous()), _native.ptr(gh),
+        _native.ptr(gx), _native.ptr(gew), arr, _native.ptr(ws), ws.numel(), _stream(x))
+    _native.check(rc, "cbgx_x2h_attention_backward")
+    return gh, gx, gew, grads
+
+
+def h2x_attention_backward(packed, layer, x, h, nbr, deg, lig_flag, gen_flag, e_w, grad_x_out):
+    """-> (grad_h, grad_x, grad_e_w, [18 parameter gradients: xk_func(6), xv_func(6), xq_func(6)])."""
+    N = x.shape[0]
+    gh, gx = torch.empty_like(h), torch.empty_like(x)
+    gew = torch.empty_like(e_w)
+    grads, arr = _grad_tensors(_MLP_SHAPES_H2X, x.device)
+    ws = _train_ws(N, x.device)
+    rc = _native.lib().cbgx_h2x_attention_backward(
+        _native.ptr(packed), layer, _native.ptr(x), _native.ptr(h), _native.ptr(nbr), _native.ptr(deg),
+        _native.ptr(lig_flag), _native.ptr(gen_flag), _native.ptr(e_w), N, _native.ptr(grad_x_out.contiguous()),
+        _native.ptr(gh), _native.ptr(gx), _native.ptr(gew), arr, _native.ptr(ws), ws.numel(), _stream(x))
+    _native.check(rc, "cbgx_h2x_attention_backward")
+    return gh, gx, gew, grads

@@ -81,8 +81,39 @@ class VPSchedule(nn.Module):
         return betas
 
 
+def scatter_mean(src, index, dim_size=None):
+    """torch_scatter.scatter_mean over dim 0 (count clamped to >= 1), as called by the reference's losses."""
+    n = int(index.max().item()) + 1 if dim_size is None else dim_size
+    out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device).index_add(0, index, src)
+    cnt = torch.zeros(n, dtype=src.dtype, device=src.device).index_add(0, index, torch.ones_like(index, dtype=src.dtype))
+    return out / cnt.clamp(min=1).view((n,) + (1,) * (src.dim() - 1))
+
+
 class CTNVPScheduler(VPSchedule):
     """Continuous (position) schedule; the posterior step is ``backward_remove_noise``."""
+
+    def forward_add_noise(self, x, t, batch_idx, gen_flag, noise=None, zero_center=False):
+        """q(x_t | x_0) (diffusion_scheduler.py:117-134): returns (x_t, noise); gen_flag=False rows keep x."""
+        if noise is None:
+            noise = torch.randn_like(x)
+        a = self.alphas_cumprod.index_select(0, t)[batch_idx].unsqueeze(-1)
+        x_noisy = a.sqrt() * x + (1.0 - a).sqrt() * noise
+        out = torch.where(gen_flag.unsqueeze(-1), x_noisy, x)
+        if zero_center:
+            com = scatter_mean(noise, batch_idx, int(t.shape[0]))[batch_idx]
+            return out, noise - com, com
+        return out, noise
+
+    def get_loss(self, x_pred, x0, xt, t, gen_flag, batch_idx, type="score"):
+        """per-graph mean squared error, averaged over graphs (diffusion_scheduler.py:185-201)."""
+        if type == "score":
+            a = self.alphas_cumprod.index_select(0, t)[batch_idx][:, None].expand_as(x_pred)
+            tgt = (x0 - xt) / (1 - a).sqrt()
+        else:
+            tgt = x0
+        mse = ((x_pred - tgt) ** 2).sum(-1)
+        loss = scatter_mean(mse[gen_flag], batch_idx[gen_flag])
+        return loss.mean(), {"x0": x0, "xt": xt, "x_pred": x_pred, "mask_gen": gen_flag}
 
     def backward_remove_noise(self, x_pred, x_noisy, t, batch_idx, gen_flag, type="score", noise=None):
         """x_{t-1} from x_t (diffusion_scheduler.py:144-165).  type='denoise': x_pred is x0, sample the Gaussian
@@ -103,6 +134,10 @@ class CTNVPScheduler(VPSchedule):
                     + self.posterior_mean_ct_coef[tb][:, None] * x_noisy)
             xs = mean + nonzero * (0.5 * self.posterior_logvar[tb][:, None]).exp() * noise
         return torch.where(gen_flag[:, None], xs, x_noisy)
+
+
+def _index_to_log_onehot(v, num_classes):
+    return torch.log(F.one_hot(v, num_classes).float().clamp(min=1e-30))   # models/utils/categorical.py:5-11
 
 
 def _log_add_exp(a, b):
@@ -126,6 +161,44 @@ class TypeVPScheduler(VPSchedule):
         self.log_one_minus_alphas_v = _frozen(log_1_min_a(log_alphas_v))
         self.log_alphas_cumprod_v = _frozen(log_ac)
         self.log_one_minus_alphas_cumprod_v = _frozen(log_1_min_a(log_ac))
+
+    # ---- training side (diffusion_scheduler.py:339-365, 380-441) ----
+    def q_v_pred(self, log_v0, t, batch):
+        return _log_add_exp(log_v0 + self.log_alphas_cumprod_v[t][batch].unsqueeze(-1),
+                            self.log_one_minus_alphas_cumprod_v[t][batch].unsqueeze(-1) - math.log(self.num_classes))
+
+    def q_v_pred_one_timestep(self, log_vt_1, t, batch):
+        return _log_add_exp(log_vt_1 + self.log_alphas_v[t][batch].unsqueeze(-1),
+                            self.log_one_minus_alphas_v[t][batch].unsqueeze(-1) - math.log(self.num_classes))
+
+    def q_v_posterior(self, log_v0, log_vt, t, batch):
+        tm1 = torch.where(t - 1 < 0, torch.zeros_like(t), t - 1)
+        un = self.q_v_pred(log_v0, tm1, batch) + self.q_v_pred_one_timestep(log_vt, t, batch)
+        return un - torch.logsumexp(un, dim=-1, keepdim=True)
+
+    def forward_add_noise(self, v0, t, batch_idx, gen_flag, uniform=None):
+        """v_t ~ q(v_t | v_0) by Gumbel-argmax; returns (one-hot float, index)."""
+        log_q = self.q_v_pred(_index_to_log_onehot(v0, self.num_classes), t, batch_idx)
+        if uniform is None:
+            uniform = torch.rand_like(log_q)
+        gumbel = -torch.log(-torch.log(uniform + 1e-30) + 1e-30)
+        v_noisy = torch.where(gen_flag, (gumbel + log_q).argmax(-1), v0)
+        return F.one_hot(v_noisy, self.num_classes).float(), v_noisy
+
+    def compute_loss(self, log_c_pred_prob, log_c_true_prob, log_v0, t, batch, mask_generate):
+        kl = (log_c_true_prob.exp() * (log_c_true_prob - log_c_pred_prob)).sum(1)
+        nll = -(log_v0.exp() * log_c_pred_prob).sum(1)
+        mask = (t == 0).float()[batch]
+        return scatter_mean((mask * nll + (1.0 - mask) * kl)[mask_generate], batch[mask_generate]).mean()
+
+    def get_loss(self, c_pred, v0, vt, t, gen_flag, batch_idx, pred_logit=True):
+        log_c0 = _index_to_log_onehot(v0, self.num_classes)
+        log_ct = _index_to_log_onehot(vt, self.num_classes)
+        log_c_pred = F.log_softmax(c_pred, dim=-1) if pred_logit else torch.log(c_pred + 1e-8)
+        log_p = self.q_v_posterior(log_c_pred, log_ct, t, batch_idx)
+        log_q = self.q_v_posterior(log_c0, log_ct, t, batch_idx)
+        loss = self.compute_loss(log_p, log_q, log_c0, t, batch_idx, gen_flag)
+        return loss, {"v0": v0, "vt": vt, "c_pred": log_c_pred.exp(), "mask_gen": gen_flag}
 
     def backward_remove_noise(self, c_pred, ct, t, batch_idx, gen_flag, pred_logit=True, uniform=None):
         """v_{t-1} ~ q(v_{t-1} | v_t, v0_pred) by Gumbel-argmax (diffusion_scheduler.py:367-378, 407-441;
@@ -201,10 +274,75 @@ class TargetDiff(nn.Module):
         self.context_embedder = PLContextEmbedder(cfg.embedder)
         self.denoiser = get_e3_gnn(cfg.encoder, num_classes=self.num_classes)
 
-    def forward(self, batch):
-        raise NotImplementedError(
-            "training loss (targetdiff.py:82-124) needs the backward kernels, which are scheduled after the "
-            "sampling path (DESIGN.md section 8); use sample() under torch.no_grad()")
+    # ---- training (targetdiff.py:40-124) ---------------------------------------------------------
+    def sample_time(self, batch_size, device="cuda", draws=None):
+        """_base.py:13-33; ``draws`` replays the integers of the 'symmetric' sampler in tests."""
+        T = self.num_diffusion_timesteps
+        if self.time_sampler == "symmetric":
+            if draws is None:
+                draws = torch.randint(0, T, size=(batch_size // 2 + 1,), device=device)
+            draws = draws.to(device)
+            return torch.cat([draws, T - draws - 1], 0)[:batch_size]
+        if self.time_sampler == "uniform":
+            return torch.round((torch.rand(batch_size) * T).clip(0, T - 1)).long().to(device)
+        raise ValueError(f"time_sampler {self.time_sampler!r} is not supported")
+
+    def forward(self, batch, t=None, noise=None):
+        """``loss_dict, results = model(batch)`` of train.py:185.  Training mode: one sampled time per graph;
+        eval mode: the average over ``eval_interval`` evenly spaced times (targetdiff.py:62-78).  ``t`` /
+        ``noise=(eps, u)`` replay the random draws in tests."""
+        bl = batch["ligand_element_batch"]
+        B = int(bl.max().item()) + 1
+        dev = batch["ligand_pos"].device
+        if self.training or t is not None:
+            if t is None:
+                t = self.sample_time(B, device=dev)
+            return self.get_loss(batch, t, noise)
+        dicts, results = [], []
+        for tv in np.linspace(0, self.num_diffusion_timesteps - 1, self.cfg.get("eval_interval", 10)):
+            ld, res = self.get_loss(batch, torch.tensor([tv] * B).long().to(dev), None)
+            dicts.append(ld)
+            results.append(res)
+        mean = {k: torch.stack([d[k] for d in dicts]).mean() for k in dicts[0]}
+        return mean, results
+
+    def get_loss(self, batch, t, noise=None):
+        """targetdiff.py:82-124: forward noising, embedding + composition, denoiser, position / type losses."""
+        x0 = batch["ligand_pos"].float()
+        v0 = batch["ligand_atom_type"]
+        x_rec = batch["protein_pos"].float()
+        lig_flag_l = batch["ligand_lig_flag"]
+        gen_l = batch.get("ligand_gen_flag", lig_flag_l).bool()
+        gen_r = batch.get("protein_gen_flag", torch.zeros_like(batch["protein_lig_flag"])).bool()
+        bl, br = batch["ligand_element_batch"], batch["protein_element_batch"]
+        eps, u = noise if noise is not None else (None, None)
+        x_t = self.pos_scheduler.forward_add_noise(x0, t, bl, gen_l, noise=eps)[0] if self.denoise_structure else x0
+        if self.denoise_atom:
+            c_t, v_t = self.type_scheduler.forward_add_noise(v0, t, bl, gen_l, uniform=u)
+        else:
+            c_t, v_t = F.one_hot(v0, self.num_classes).float(), v0
+        aa = F.one_hot(batch["protein_aa_type"], NUM_AA).float()
+        h_lig = self.context_embedder.embed_ligand(c_t)
+        h_rec = self.context_embedder.embed_protein(batch["protein_atom_feature"].float(), aa)
+        sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = self.compose_plan(bl, br, int(t.shape[0]))
+        x = torch.cat([x_rec, x_t], 0)[sort_idx]
+        h = torch.cat([h_rec, h_lig], 0)[sort_idx]
+        gen_flag = torch.cat([gen_r, gen_l], 0)[sort_idx]
+        xo, _, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
+                                      graph_ptr=graph_ptr)
+        x_pred, c_pred = xo[lig_rows], logits[lig_rows]
+        results = {}
+        if self.denoise_structure:
+            loss_pos, info = self.pos_scheduler.get_loss(x_pred, x0, x_t, t, gen_l, bl, type="denoise")
+            results.update(info)
+        else:
+            loss_pos = torch.tensor(0.0, device=x0.device)
+        if self.denoise_atom:
+            loss_atom, info = self.type_scheduler.get_loss(c_pred, v0, v_t, t, gen_l, bl, pred_logit=True)
+            results.update(info)
+        else:
+            loss_atom = torch.tensor(0.0, device=x0.device)
+        return {"pos": loss_pos, "atom": loss_atom}, results
 
     # ---- static per-batch structure ------------------------------------------------------------
     @staticmethod

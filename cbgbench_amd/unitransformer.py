@@ -2,7 +2,8 @@
 (repo/modules/e3nn/unitransformer.py:12-123): same constructor config, same parameter tree (so the
 reference's checkpoints ``load_state_dict(strict=True)``), same ``forward`` signature -- but
 ``forward`` runs entirely in libcbgx (hand-written gfx950 kernels) through the C ABI of
-include/cbgx.h.  There is no PyTorch / CPU implementation of the math here: a CPU tensor or a missing
+include/cbgx.h; with gradients enabled it goes through ``_DenoiserFunction``, whose backward is
+libcbgx's hand-written backward (``cbgx_unitransformer_backward``).  There is no PyTorch / CPU implementation of the math here: a CPU tensor or a missing
 library raises.
 
 The sub-modules below are *parameter containers* whose names reproduce the reference state-dict keys
@@ -82,6 +83,56 @@ def graph_ptr_from_batch(batch_idx, n_graphs=None):
     return ptr
 
 
+class _DenoiserFunction(torch.autograd.Function):
+    """autograd bridge of the training path: forward = cbgx_unitransformer_forward_train (keeps a tape of the
+    per-layer inputs), backward = cbgx_unitransformer_backward (hand-written gfx950 backward kernels).  The
+    parameters are passed as inputs so that autograd routes their gradients; no gradient is produced for the
+    coordinates (they are data in every training loss of the reference, targetdiff.py:87-101)."""
+
+    @staticmethod
+    def forward(ctx, module, x, h, graph_ptr, lig, gen, *params):
+        device = x.device
+        N, B = x.shape[0], graph_ptr.numel() - 1
+        L, C = module.num_layers, module.out_classes
+        lib = _native.lib()
+        packed = module.packed_weights(device)
+        tape = torch.empty(lib.cbgx_train_tape_bytes(N, L), dtype=torch.uint8, device=device)
+        ws = module.train_workspace(N, device)
+        x_out, h_out = torch.empty_like(x), torch.empty_like(h)
+        logits = torch.empty(N, C, dtype=torch.float32, device=device)
+        rc = lib.cbgx_unitransformer_forward_train(
+            _native.ptr(packed), L, C, _native.ptr(x), _native.ptr(h), _native.ptr(graph_ptr), _native.ptr(lig),
+            _native.ptr(gen), N, B, _native.ptr(x_out), _native.ptr(h_out), _native.ptr(logits), _native.ptr(tape),
+            tape.numel(), _native.ptr(ws), ws.numel(), _native.current_stream(device))
+        _native.check(rc, "cbgx_unitransformer_forward_train")
+        ctx.module, ctx.tape, ctx.packed, ctx.flags, ctx.n = module, tape, packed, (lig, gen), N
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        return x_out, h_out, logits
+
+    @staticmethod
+    def backward(ctx, gx, gh, gl):
+        module, N = ctx.module, ctx.n
+        lig, gen = ctx.flags
+        device = ctx.tape.device
+        L, C = module.num_layers, module.out_classes
+        sizes = [int(torch.Size(s).numel()) for s in ctx.param_shapes]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+        views = list(flat.split(sizes))
+        arr = (ctypes.c_void_p * len(views))(*[v.data_ptr() for v in views])
+        need_h = ctx.needs_input_grad[2]
+        gh_in = torch.empty(N, module.hidden_dim, dtype=torch.float32, device=device) if need_h else None
+        ws = module.train_workspace(N, device)
+        cont = lambda g: None if g is None else g.contiguous().float()
+        gx, gh, gl = cont(gx), cont(gh), cont(gl)
+        rc = _native.lib().cbgx_unitransformer_backward(
+            _native.ptr(ctx.packed), L, C, _native.ptr(ctx.tape), ctx.tape.numel(), _native.ptr(lig),
+            _native.ptr(gen), N, _native.ptr(gx), _native.ptr(gh), _native.ptr(gl), arr, len(views),
+            _native.ptr(gh_in), _native.ptr(ws), ws.numel(), _native.current_stream(device))
+        _native.check(rc, "cbgx_unitransformer_backward")
+        grads = [v.view(s) for v, s in zip(views, ctx.param_shapes)]
+        return (None, None, gh_in, None, None, None, *grads)
+
+
 class UniTransformer(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -129,6 +180,7 @@ class UniTransformer(nn.Module):
         self._packed = None
         self._packed_key = None
         self._workspace = None
+        self._train_workspace = None
 
     def __repr__(self):
         return (f"UniTransformer[libcbgx/gfx950](num_layers={self.num_layers}, n_heads={self.n_heads}, "
@@ -176,6 +228,14 @@ class UniTransformer(nn.Module):
             self._workspace = ws
         return ws
 
+    def train_workspace(self, n_nodes, device):
+        need = _native.lib().cbgx_train_workspace_bytes(n_nodes)
+        ws = self._train_workspace
+        if ws is None or ws.numel() < need or ws.device != device:
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._train_workspace = ws
+        return ws
+
     # ---- forward -----------------------------------------------------------------------------
     def forward(self, x, h, batch_idx, lig_flag, gen_flag, graph_ptr=None, need_h=True):
         """Same contract as the reference (unitransformer.py:102-123): returns (x', h', logits).
@@ -186,17 +246,20 @@ class UniTransformer(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("UniTransformer.forward runs on an MI355X through libcbgx; got a CPU tensor "
                                "(no CPU fallback exists; use oracle/ for CPU reference results)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError("libcbgx forward is inference-only in this round: call under torch.no_grad()")
         device = x.device
         N = x.shape[0]
         if graph_ptr is None:
             graph_ptr = graph_ptr_from_batch(batch_idx)
         B = graph_ptr.numel() - 1
-        x = x.detach().to(torch.float32).contiguous()
-        h = h.detach().to(torch.float32).contiguous()
         lig = lig_flag.to(torch.uint8).contiguous()
         gen = gen_flag.to(torch.uint8).contiguous()
+        if torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # training: taped forward + hand-written backward behind torch.autograd
+            return _DenoiserFunction.apply(self, x.detach().to(torch.float32).contiguous(),
+                                           h.to(torch.float32).contiguous(), graph_ptr, lig, gen,
+                                           *self._ordered_params())
+        x = x.detach().to(torch.float32).contiguous()
+        h = h.detach().to(torch.float32).contiguous()
         packed = self.packed_weights(device)
         ws = self.workspace(N, B, device)
         x_out = torch.empty_like(x)

@@ -143,13 +143,52 @@ int cbgx_targetdiff_epilogue(const float *x_den, const float *logits, const int3
                              int num_timesteps, const float *const *tables, const float *eps, const float *u,
                              float *x_next, float *c_next, int32_t *v_next, void *stream);
 
+/* ---- training: taped forward and backward -----------------------------------------------------------
+ * train.py:185-189 runs `loss_dict, _ = model(batch); loss.backward()`; autograd walks UniTransformer.forward
+ * (unitransformer.py:102-123) backwards through every X2HAttention / H2XAttention (x2h_attention.py:43-97,
+ * h2x_attention.py:34-73), the gate and the classifier.  libcbgx replaces that pair with
+ *   cbgx_unitransformer_forward_train : same outputs as cbgx_unitransformer_forward (no pruning) and a *tape*
+ *       (caller-owned, cbgx_train_tape_bytes) holding the kNN lists, the gate and the per-layer x / h inputs;
+ *   cbgx_unitransformer_backward      : given dL/dx_out [N,3], dL/dh_out [N,128], dL/dlogits [N,C] (each may be
+ *       NULL = zero) it recomputes the per-edge intermediates block by block (nothing per-edge is ever stored) and
+ *       writes dL/dh_in [N,128] (may be NULL) and the gradient of every parameter tensor: `grads` is a HOST array
+ *       of DEVICE pointers, same order and shapes as the `tensors` of cbgx_pack_weights (6 + 36*L + 4), each
+ *       OVERWRITTEN.  No gradient is produced for the input coordinates (they are data: targetdiff.py:87-101).
+ * Both take the larger training workspace (cbgx_train_workspace_bytes).  Neighbour-row gradients are accumulated with
+ * fp32 atomics, so results are reproducible only up to summation order (as with the reference's torch_scatter on GPU). */
+size_t cbgx_train_tape_bytes(int n_nodes, int num_layers);
+size_t cbgx_train_workspace_bytes(int n_nodes);
+int cbgx_unitransformer_forward_train(const float *packed, int num_layers, int num_classes,
+                                      const float *x, const float *h, const int32_t *graph_ptr,
+                                      const uint8_t *lig_flag, const uint8_t *gen_flag, int n_nodes, int n_graphs,
+                                      float *x_out, float *h_out, float *logits, void *tape, size_t tape_bytes,
+                                      void *workspace, size_t workspace_bytes, void *stream);
+int cbgx_unitransformer_backward(const float *packed, int num_layers, int num_classes, const void *tape,
+                                 size_t tape_bytes, const uint8_t *lig_flag, const uint8_t *gen_flag, int n_nodes,
+                                 const float *grad_x_out, const float *grad_h_out, const float *grad_logits,
+                                 float *const *grads, int num_grads, float *grad_h_in, void *workspace,
+                                 size_t workspace_bytes, void *stream);
+/* Backward of one attention block (stage-level parity tests).  Inputs as the forward stage; `grads` = 18 DEVICE
+ * pointers {hk,hv,hq}_func (x2h) / {xk,xv,xq}_func (h2x) x net.{0.weight,0.bias,1.weight,1.bias,3.weight,3.bias}.
+ * x2h: grad_h includes the residual path.  h2x: grad_x includes the identity path of x_out = x + delta_x * gen_flag.
+ * grad_e_w [N,32] is the gradient with respect to the gate values. */
+int cbgx_x2h_attention_backward(const float *packed, int layer, const float *x, const float *h,
+                                const int32_t *nbr, const int32_t *deg, const uint8_t *lig_flag, const float *e_w,
+                                int n_nodes, const float *grad_h_out, float *grad_h, float *grad_x, float *grad_e_w,
+                                float *const *grads, void *workspace, size_t workspace_bytes, void *stream);
+int cbgx_h2x_attention_backward(const float *packed, int layer, const float *x, const float *h,
+                                const int32_t *nbr, const int32_t *deg, const uint8_t *lig_flag,
+                                const uint8_t *gen_flag, const float *e_w, int n_nodes, const float *grad_x_out,
+                                float *grad_h, float *grad_x, float *grad_e_w, float *const *grads, void *workspace,
+                                size_t workspace_bytes, void *stream);
+
 /* ---- measurement hook (bench.py) ----------------------------------------------------------------
  * Between cbgx_profile_begin() and cbgx_profile_end() every kernel launch is bracketed by HIP events on
  * its own stream.  cbgx_profile_end() synchronises them and returns, per kernel class, the summed
  * device time in ms and the launch count.  Classes: 0 knn, 1 gate, 2 node GEMM, 3 node query fold,
  * 4 x2h edge kernel over all nodes, 5 h2x edge kernel (node list), 6 x2h edge kernel over a node list (pruned last
- * layers) (CBGX_PROFILE_CLASSES = 7).  Not thread-safe with concurrent launches from other threads; process-wide. */
-#define CBGX_PROFILE_CLASSES 7
+ * layers), 7 x2h edge backward, 8 h2x edge backward, 9 training GEMMs (CBGX_PROFILE_CLASSES = 10).  Not thread-safe with concurrent launches from other threads; process-wide. */
+#define CBGX_PROFILE_CLASSES 10
 int cbgx_profile_begin(int max_launches);
 int cbgx_profile_end(double *ms_by_class, int *launches_by_class, int num_classes);
 

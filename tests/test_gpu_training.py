@@ -1,0 +1,164 @@
+"""Training path: the hand-written backward kernels of libcbgx against torch.autograd on the
+CPU oracle (which tests/test_oracle_golden.py pins to the reference's own loss.backward()).
+
+Tolerances: gradients are sums of up to ~1e5 fp32 products with different association orders (and fp32 atomics for
+the neighbour rows), so each tensor is compared with rtol 2e-4 and an absolute floor of 2e-5 x its largest entry."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cbgbench_amd as C
+from cbgbench_amd import stages
+from cbgbench_amd.unitransformer import graph_ptr_from_batch
+from oracle import training as TR
+from oracle import unitransformer as OU
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+MLP_KEYS = ("net.0.weight", "net.0.bias", "net.1.weight", "net.1.bias", "net.3.weight", "net.3.bias")
+
+
+def gclose(a, b, what, rtol=2e-4, floor=2e-5):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs()
+    tol = floor * max(float(b.abs().max()), 1e-12) + rtol * b.abs()
+    assert bool((err <= tol).all()), f"{what}: max abs err {err.max():.3e}, |ref| max {b.abs().max():.3e}"
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    return {k: torch.from_numpy(z[k]) if z[k].ndim else z[k].item() for k in z.files}
+
+
+@pytest.fixture(scope="module")
+def model(synthetic_sd):
+    m = C.get_model(C.default_targetdiff_config(13)).eval()
+    m.load_state_dict(synthetic_sd, strict=True)
+    return m.to(DEV)
+
+
+def _oracle_block(sd, g, layer, kind, seed):
+    """autograd through one oracle attention block; returns inputs, upstream gradient and all gradients."""
+    x = g["x"].clone().requires_grad_(True)
+    h = (g["h"] if kind == "x2h" else g["h_layer0"]).clone().requires_grad_(True)
+    ei = OU.knn_graph(g["x"], g["batch_idx"], 32)
+    et = OU.build_edge_type(ei, g["lig_flag"])
+    e_w = OU.edge_gate(sd, "denoiser", g["x"], ei).detach().clone().requires_grad_(True)
+    fns = ("hk_func", "hv_func", "hq_func") if kind == "x2h" else ("xk_func", "xv_func", "xq_func")
+    prefix = f"denoiser.blocks.{layer}.{kind}_layers.0"
+    keys = [f"{prefix}.{fn}.{k}" for fn in fns for k in MLP_KEYS]
+    sd = dict(sd)
+    for k in keys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    gen = torch.Generator().manual_seed(seed)
+    if kind == "x2h":
+        out = OU.x2h_attention(sd, prefix, x, h, et, ei, e_w)
+        gout = torch.randn(out.shape, generator=gen)
+    else:
+        out = x + OU.h2x_attention(sd, prefix, x, h, et, ei, e_w) * g["gen_flag"].unsqueeze(-1).float()
+        gout = torch.randn(out.shape, generator=gen)
+    out.backward(gout)
+    return h.detach(), gout, x.grad, h.grad, e_w.grad, [sd[k].grad for k in keys], keys, ei
+
+
+@pytest.mark.parametrize("case,kind", [("denoiser_2graphs", "x2h"), ("denoiser_2graphs", "h2x"),
+                                       ("denoiser_linker", "x2h"), ("denoiser_linker", "h2x"),
+                                       ("denoiser_small_graphs", "x2h"), ("denoiser_small_graphs", "h2x")])
+def test_attention_block_backward(golden_dir, synthetic_sd, model, case, kind):
+    g = load(golden_dir, case)
+    h_in, gout, gx_ref, gh_ref, gew_ref, pg_ref, keys, ei = _oracle_block(synthetic_sd, g, 0, kind, seed=3)
+    x = g["x"].to(DEV)
+    gp = graph_ptr_from_batch(g["batch_idx"].to(DEV))
+    lig = g["lig_flag"].to(DEV).to(torch.uint8)
+    gen = g["gen_flag"].to(DEV).to(torch.uint8)
+    packed = model.denoiser.packed_weights(torch.device(DEV))
+    nbr, deg = stages.knn_graph(x, gp)
+    assert torch.equal(stages.edge_index_from_nbr(nbr, deg).cpu(), ei)
+    e_w = stages.edge_gate(packed, x, nbr, deg)
+    if kind == "x2h":
+        gh, gx, gew, pg = stages.x2h_attention_backward(packed, 0, x, h_in.to(DEV), nbr, deg, lig, e_w, gout.to(DEV))
+    else:
+        gh, gx, gew, pg = stages.h2x_attention_backward(packed, 0, x, h_in.to(DEV), nbr, deg, lig, gen, e_w,
+                                                        gout.to(DEV))
+    torch.cuda.synchronize()
+    mask = (torch.arange(32, device=DEV)[None, :] < deg[:, None])
+    gclose(gh, gh_ref, f"{kind} grad_h")
+    gclose(gx, gx_ref, f"{kind} grad_x")
+    gclose(gew[mask], gew_ref.flatten(), f"{kind} grad_e_w")
+    for k, a, b in zip(keys, pg, pg_ref):
+        if k.endswith("k_func.net.3.bias"):
+            assert float(a.abs().max()) == 0.0    # exactly zero here, round-off noise in autograd
+            continue
+        gclose(a, b, k)
+
+
+def golden_batch(g, device):
+    return {k[len("batch_"):]: v.to(device) for k, v in g.items() if k.startswith("batch_")}
+
+
+@pytest.mark.parametrize("case", ["train_loss_denovo", "train_loss_t0_linker"])
+def test_training_step_matches_reference_gradients(golden_dir, synthetic_sd, case):
+    """model(batch) + loss.backward() through libcbgx against the losses and parameter gradients recorded from the
+    unmodified reference (tests/golden/train_loss_*.npz, oracle/make_golden.py::train_case)."""
+    g = load(golden_dir, case)
+    m = C.get_model(C.default_targetdiff_config(13))
+    m.load_state_dict(synthetic_sd, strict=True)
+    m = m.to(DEV).train()
+    batch = golden_batch(g, DEV)
+    if g["draws"].numel():
+        B = int(batch["ligand_element_batch"].max()) + 1
+        assert torch.equal(m.sample_time(B, DEV, draws=g["draws"]).cpu(), g["t"])
+    loss_dict, _ = m(batch, t=g["t"].to(DEV), noise=(g["eps"].to(DEV), g["u"].to(DEV)))
+    assert abs(float(loss_dict["pos"].detach()) - g["loss_pos"]) <= 1e-4 * abs(g["loss_pos"]) + 1e-6
+    assert abs(float(loss_dict["atom"].detach()) - g["loss_atom"]) <= 2e-4 * abs(g["loss_atom"]) + 1e-7
+    (1.0 * loss_dict["pos"] + 100.0 * loss_dict["atom"]).backward()
+    torch.cuda.synchronize()
+    n = 0
+    for k, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        ref_norm = float(g["gnorm/" + k])
+        assert p.grad is not None, k
+        flat = p.grad.detach().cpu().reshape(-1)
+        if ref_norm < 1e-7:      # key biases of the attentions: no gradient
+            assert float(flat.abs().max()) < 1e-6, k
+            n += 1
+            continue
+        assert abs(float(flat.double().norm()) - ref_norm) <= 1e-3 * ref_norm, (k, float(flat.double().norm()), ref_norm)
+        sample = flat if flat.numel() <= 2048 else flat[::61]
+        ref = g["g/" + k]
+        err = (sample.double() - ref.double()).abs()
+        tol = 1e-3 * ref.double().abs() + 2e-3 * ref_norm / max(flat.numel(), 1) ** 0.5   # 0.2 % of the tensor's RMS
+        assert bool((err <= tol).all()), f"{k}: max err {err.max():.3e} vs norm {ref_norm:.3e}"
+        n += 1
+    assert n == 8 + 6 + 9 * 36 + 4
+
+
+def test_training_loss_decreases_with_adam(synthetic_sd):
+    """a few optimiser steps on one fixed batch and fixed noise: the weighted loss must go down (train.py:173-190)."""
+    from cbgbench_amd import synthetic
+    rng = np.random.default_rng(5)
+    pockets = [synthetic.make_pocket(rng, 80, radius=7.0) for _ in range(4)]
+    batch = synthetic.make_batch(pockets, [9, 11, 8, 10], rng, 13)
+    batch = synthetic.batch_to(batch, DEV)
+    m = C.get_model(C.default_targetdiff_config(13))
+    m.load_state_dict(synthetic_sd, strict=True)
+    m = m.to(DEV).train()
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    n_lig = batch["ligand_pos"].shape[0]
+    t = torch.tensor([100, 400, 700, 900], device=DEV)
+    eps = torch.randn(n_lig, 3, device=DEV, generator=gen)
+    u = torch.rand(n_lig, 13, device=DEV, generator=gen)
+    losses = []
+    for _ in range(6):
+        ld, _ = m(batch, t=t, noise=(eps, u))
+        loss = ld["pos"] + 100.0 * ld["atom"]
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 8.0)
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

@@ -115,8 +115,13 @@ def test_no_cpu_fallback():
     b = torch.zeros(4, dtype=torch.long); f = torch.zeros(4, dtype=torch.bool)
     with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
         model.denoiser(x=x, h=h, batch_idx=b, lig_flag=f, gen_flag=f)
-    with pytest.raises(NotImplementedError):
-        model(dict())
+    # the training entry point (targetdiff.py:40-60) reaches the same denoiser: no CPU path either
+    import numpy as np
+    from cbgbench_amd import synthetic
+    rng = np.random.default_rng(0)
+    batch = synthetic.make_batch([synthetic.make_pocket(rng, 40, radius=6.0)], [6], rng, 13)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.train()(batch)
 
 
 # ---- C ABI ---------------------------------------------------------------------------------------
@@ -235,3 +240,35 @@ def test_diffbp_model_class(golden_dir):
         model.com_head(torch.zeros(2, 3), torch.zeros(2, dtype=torch.long), torch.zeros(4, 3), torch.zeros(4, 128),
                        torch.zeros(4, dtype=torch.bool), torch.tensor([0, 0, 1, 1], dtype=torch.bool),
                        torch.zeros(4, dtype=torch.long))
+
+
+def test_training_schedulers_match_oracle():
+    """host mirrors of forward_add_noise / get_loss (diffusion_scheduler.py:117-134,185-201,339-365) vs the oracle."""
+    import torch
+    import cbgbench_amd as C
+    from oracle import training as TR, targetdiff as OT, weights as W
+    m = C.get_model(C.default_targetdiff_config(13))
+    sd = W.synthetic_state_dict(13, 9, seed=0)
+    m.load_state_dict(sd, strict=True)
+    pos_tb, typ_tb = OT.tables_from_state_dict(sd)
+    g = torch.Generator().manual_seed(0)
+    n, B, Cn = 40, 4, 13
+    bl = torch.sort(torch.randint(0, B, (n,), generator=g)).values
+    bl[0], bl[-1] = 0, B - 1
+    gen = torch.rand(n, generator=g) > 0.2
+    x0, eps = torch.randn(n, 3, generator=g), torch.randn(n, 3, generator=g)
+    v0, u = torch.randint(0, Cn, (n,), generator=g), torch.rand(n, Cn, generator=g)
+    t = torch.tensor([0, 17, 500, 999])
+    xt, _ = m.pos_scheduler.forward_add_noise(x0, t, bl, gen, noise=eps)
+    assert torch.equal(xt, TR.pos_forward_add_noise(pos_tb, x0, t, bl, gen, eps))
+    ct, vt = m.type_scheduler.forward_add_noise(v0, t, bl, gen, uniform=u)
+    ct_o, vt_o = TR.type_forward_add_noise(typ_tb, Cn, v0, t, bl, gen, u)
+    assert torch.equal(vt, vt_o) and torch.equal(ct, ct_o)
+    x_pred, logits = torch.randn(n, 3, generator=g), torch.randn(n, Cn, generator=g)
+    nl = int(bl[gen].max()) + 1
+    lp, _ = m.pos_scheduler.get_loss(x_pred, x0, xt, t, gen, bl, type="denoise")
+    assert torch.equal(lp, TR.pos_loss(x_pred, x0, gen, bl, nl))
+    la, _ = m.type_scheduler.get_loss(logits, v0, vt, t, gen, bl)
+    assert torch.equal(la, TR.type_loss(typ_tb, Cn, logits, v0, vt, t, gen, bl, nl))
+    assert torch.equal(m.sample_time(5, "cpu", draws=torch.tensor([3, 10, 999])),
+                       TR.sample_time_symmetric(5, 1000, [3, 10, 999]))
