@@ -129,16 +129,115 @@ def cpu_baseline(sd, seed, max_seconds=20.0):
             f"{threads} threads (best of 4..64 on this {os.cpu_count()}-core host), {el:.1f} s"}
 
 
+# backward of the message-passing stage at the reference's tensor boundary (autograd of x2h_attention.py:80-97):
+# per edge read k, v (512 B each), e_w, index and write dk, dv (512 B each); per node read q, dL/dh_out and write dq, dL/dh
+X2H_BWD_BYTES_PER_EDGE = 4 * 512 + 4 + 4
+X2H_BWD_BYTES_PER_NODE = 4 * 512
+
+
+def cpu_train_baseline(sd, seed, max_seconds=25.0):
+    """The CPU oracle's training step (oracle/training.py: reference formulation, torch.autograd backward) on a
+    bounded sample: 4-graph batches, forward + backward (no optimiser), at its best thread count."""
+    from oracle import training as TR
+    threads = _pick_cpu_threads(sd, seed)
+    torch.set_num_threads(threads)
+    batch = build_batch(4, 1, seed)
+    g = torch.Generator().manual_seed(seed)
+    n_lig = batch["ligand_pos"].shape[0]
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        t = torch.randint(0, 1000, (4,), generator=g)
+        TR.loss_and_grads(sd, batch, t, torch.randn(n_lig, 3, generator=g), torch.rand(n_lig, 13, generator=g), 13)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > max_seconds or steps >= 4:
+            break
+    return {"value": round(4 * steps / el, 4), "unit": "graph-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} forward+backward passes (no optimiser step) of one 4-graph batch, oracle/training.py "
+                      f"with torch.autograd on PyTorch-CPU fp32, {threads} threads (best of 4..64 on this "
+                      f"{os.cpu_count()}-core host), {el:.1f} s"}
+
+
+def bench_train(args, rank, world, dev):
+    """BASELINE configs[4] shape on the GPUs at hand: train.py semantics (forward, backward, gradient all-reduce, clip,
+    Adam) with `--pockets` graphs per GPU per step (default 32)."""
+    from cbgbench_amd import train as TRN
+    model, sd = make_model(dev)
+    model.train()
+    TRN.broadcast_parameters(model)
+    fg = TRN.FlatGradients(model)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.95, 0.999))   # configs/denovo/train/targetdiff.yml:42-47
+    weights = {"pos": 1.0, "atom": 100.0}
+    n_graphs = args.pockets
+    batch = synthetic.batch_to(build_batch(n_graphs, 1, seed=3000 + rank), dev)
+    N = batch["protein_pos"].shape[0] + batch["ligand_pos"].shape[0]
+    torch.manual_seed(2022 + rank)
+    t_ar = 0.0
+    for _ in range(args.warmup):
+        TRN.train_step(model, batch, opt, fg, weights, 8.0)
+    sharding.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t_ar += TRN.train_step(model, batch, opt, fg, weights, 8.0)[3]
+    torch.cuda.synchronize(); sharding.barrier()
+    elapsed = time.perf_counter() - t0
+    el_max, units = sharding.reduce_max_sum(elapsed, n_graphs * args.steps, device=dev)
+    out = {
+        "metric": "training graph-steps/s (pocket+ligand graphs x optimiser steps per second: forward + backward + "
+                  "gradient all-reduce + clip + Adam)",
+        "value": round(units / el_max, 2), "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * el_max / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs/denovo targetdiff training (BASELINE configs[4] shape): {n_graphs} graphs per GPU "
+                               f"per step, N_rec~U[350,650], N_lig~U[10,45], symmetric time sampler, loss weights pos 1 / "
+                               f"atom 100, Adam lr 5e-4, clip 8.0, one flat-buffer gradient all-reduce "
+                               f"({fg.flat.numel()} fp32) per step",
+                   "graphs_per_batch_per_gpu": n_graphs, "nodes_per_batch": N, "sharding": f"data-parallel x{world} ranks",
+                   "allreduce_ms_per_step": round(1e3 * t_ar / max(args.steps, 1), 4)},
+    }
+    if rank == 0 and not args.no_roofline:
+        lib = _native.lib()
+        names = _native.PROFILE_CLASSES
+        prof_steps = min(args.steps, 3)
+        _native.check(lib.cbgx_profile_begin(400 * prof_steps + 64), "cbgx_profile_begin")
+        for _ in range(prof_steps):
+            TRN.train_step(model, batch, opt, fg, weights, 8.0)
+        NCLS = len(names)
+        ms = (ctypes.c_double * NCLS)(); cnt = (ctypes.c_int * NCLS)()
+        _native.check(lib.cbgx_profile_end(ms, cnt, NCLS), "cbgx_profile_end")
+        per = {n: {"ms_total": round(ms[i], 4), "launches": cnt[i],
+                   "us_avg": round(1e3 * ms[i] / max(cnt[i], 1), 3)} for i, n in enumerate(names)}
+        k = names.index("edge_x2h_bwd")
+        bwd_bytes = X2H_BWD_BYTES_PER_EDGE * 32 * N + X2H_BWD_BYTES_PER_NODE * N
+        bwd_s = 1e-3 * ms[k] / max(cnt[k], 1)
+        achieved = bwd_bytes / bwd_s / 1e9 if bwd_s > 0 else 0.0
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "cbgx::edge_backward_kernel<x2h> (first-generation VALU backward of the x2h block)",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": None, "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_us": round(1e6 * bwd_s, 3),
+            "note": "algorithmic bytes = backward of the message-passing stage at the reference tensor boundary "
+                    "(2056 B/edge + 2048 B/node); the kernel recomputes the per-edge forward instead of reading it",
+            "per_kernel": per,
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_train_baseline(sd, seed=3000)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pockets", type=int, default=10, help="distinct pockets per batch")
+    ap.add_argument("--pockets", type=int, default=None, help="distinct pockets per batch (default 10; train: 32)")
     ap.add_argument("--samples", type=int, default=10, help="samples (graphs) per pocket")
-    ap.add_argument("--workload", choices=["denovo", "linker"], default="denovo",
+    ap.add_argument("--workload", choices=["denovo", "linker", "train"], default="denovo",
                     help="denovo = BASELINE configs[1] (default); linker = configs[2]: --pockets distinct pockets, one "
-                         "graph each, fixed context atoms + a few generated linker atoms (partial gen_flag)")
+                         "graph each, fixed context atoms + a few generated linker atoms (partial gen_flag); train = "
+                         "configs[4] shape: forward + backward + all-reduce + Adam on --pockets graphs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -151,6 +250,10 @@ def main():
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.pockets is None:
+        args.pockets = 32 if args.workload == "train" else 10
+    if args.workload == "train":
+        return bench_train(args, rank, world, dev)
     model, sd = make_model(dev)
     T = model.num_diffusion_timesteps
 

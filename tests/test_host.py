@@ -272,3 +272,70 @@ def test_training_schedulers_match_oracle():
     assert torch.equal(la, TR.type_loss(typ_tb, Cn, logits, v0, vt, t, gen, bl, nl))
     assert torch.equal(m.sample_time(5, "cpu", draws=torch.tensor([3, 10, 999])),
                        TR.sample_time_symmetric(5, 1000, [3, 10, 999]))
+
+
+# ---- data-parallel training step over gloo, world_size 2 (the GPU run uses the same code over RCCL) ---------
+class _ToyModel(torch.nn.Module):
+    """stands in for a model class: forward(batch) -> (loss_dict, results), like targetdiff.py:40-60"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.lin = torch.nn.Linear(5, 3)
+        self.frozen = torch.nn.Parameter(torch.ones(2), requires_grad=False)
+
+    def forward(self, batch):
+        out = self.lin(batch["x"])
+        return {"pos": ((out - batch["y"]) ** 2).mean(), "atom": out.abs().mean()}, {}
+
+
+def _toy_batch(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return {"x": torch.randn(8, 5, generator=g), "y": torch.randn(8, 3, generator=g)}
+
+
+def _train_worker(rank, world, port, q):
+    from cbgbench_amd import train as TRN
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sharding.init_process_group("gloo")
+    model = _ToyModel()
+    with torch.no_grad():
+        model.lin.weight.add_(float(rank))          # ranks start different; broadcast must fix it
+    TRN.broadcast_parameters(model)
+    fg = TRN.FlatGradients(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    w = {"pos": 1.0, "atom": 100.0}
+    for _ in range(3):
+        loss, ld, gn, t_ar = TRN.train_step(model, _toy_batch(rank), opt, fg, w, max_grad_norm=8.0)
+    val = TRN.validate(model, [_toy_batch(rank)], w)
+    q.put((rank, model.lin.weight.detach().numpy().tolist(), fg.flat.numpy().tolist(), float(gn), val))
+    torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_train_step_gloo_world2():
+    import torch.multiprocessing as mp
+    from cbgbench_amd import train as TRN
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs: p.join(timeout=60)
+    # both ranks hold identical weights and identical (averaged) gradients after every step
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    assert res[0][3] == res[1][3] and res[0][4] == res[1][4]
+    # and they equal a single process stepping on the mean of the two per-rank losses
+    model = _ToyModel()
+    fg = TRN.FlatGradients(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    w = {"pos": 1.0, "atom": 100.0}
+    for _ in range(3):
+        fg.zero()
+        loss = sum(TRN.sum_weighted_losses(model(_toy_batch(r))[0], w) for r in range(2)) / 2
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(fg.params, 8.0)
+        opt.step()
+    assert torch.allclose(model.lin.weight, torch.tensor(res[0][1]), atol=1e-6)
+    assert model.lin.weight.grad.data_ptr() == fg.flat.data_ptr()     # gradients live in the one flat buffer
