@@ -28,7 +28,8 @@ namespace cbgx { int set_error(int code, const char* fmt, ...); }
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 constexpr int EDGE_GRID = 256;    // persistent workgroups of the edge backward (one per CU: ~97 KB LDS each)
-constexpr int NODE_GRID = 128;    // persistent workgroups of the node-level reductions
+constexpr int NODE_GRID = 256;    // persistent workgroups of the node-level reductions
+constexpr int FOLD = 8;           // slab reductions are two-level: n_slabs -> FOLD (slab_fold_kernel) -> 1 (reduce_store)
 constexpr int GATE_GRID = 256;
 constexpr int MAX_SPLITS = 32;
 
@@ -59,7 +60,7 @@ static Tape carve_tape(void* base, int n, int L) {
 
 // ---- backward workspace -----------------------------------------------------------------------------------
 struct TrainWs {
-    float *P, *Qt, *Gt, *T, *S, *gb, *sw, *qs, *dqb, *zb, *dP, *gh, *gx[2], *de_w, *E8, *tmp, *partial;
+    float *P, *Qt, *Gt, *T, *S, *gb, *sw, *qs, *dqb, *zb, *dP, *gh, *gx[2], *de_w, *E8, *tmp, *partial, *folded;
     int *act, *act_count;
     size_t partial_floats;
     size_t total;
@@ -68,6 +69,7 @@ struct TrainWs {
 static size_t partial_floats_needed() {
     size_t a = (size_t)EDGE_GRID * PB_SIZE;
     size_t b = (size_t)NODE_GRID * H * H;
+    if (b < (size_t)2 * NODE_GRID * PROW) b = (size_t)2 * NODE_GRID * PROW;
     size_t c = (size_t)MAX_SPLITS * H * PROW;
     size_t d = (size_t)GATE_GRID * GB_SIZE;
     size_t m = a > b ? a : b;
@@ -102,6 +104,7 @@ static TrainWs carve_train(void* base, int n) {
     w.act_count = (int*)take(256);
     w.partial_floats = partial_floats_needed();
     w.partial = (float*)take(w.partial_floats * 4);
+    w.folded = (float*)take((size_t)FOLD * H * PROW * 4);
     w.total = off;
     return w;
 }
@@ -115,6 +118,18 @@ static inline int splits_for(int n) {
 
 #define RS(src, nsl, stride, ld, rows, cols, dst, dld, tr) \
     HIP_TRY(launch_reduce_store(src, nsl, stride, ld, rows, cols, dst, dld, tr, s))
+
+// two-level reduction of `n_slabs` partial slabs of `size` floats: returns the FOLD-slab buffer (stride = size) through
+// *out / *n_out, or the input itself when it is already small
+static int fold_slabs(const float* src, int n_slabs, size_t stride, int size, TrainWs& w, const float** out, int* n_out,
+                      size_t* stride_out, hipStream_t s) {
+    if (n_slabs <= FOLD) { *out = src; *n_out = n_slabs; *stride_out = stride; return CBGX_OK; }
+    HIP_TRY(launch_slab_fold(src, n_slabs, stride, size, FOLD, w.folded, s));
+    *out = w.folded; *n_out = FOLD; *stride_out = (size_t)size;
+    return CBGX_OK;
+}
+#define FOLDED(src, nsl, stride, size) \
+    const float* fz; int fn; size_t fs; RC_TRY(fold_slabs(src, nsl, stride, size, w, &fz, &fn, &fs, s))
 
 // Backward of one attention block.
 //   x2h: g_out = dL/dh_out [N,128];   h2x: g_out = dL/dx_out [N,3] (only gen rows matter; rows = gen list)
@@ -137,53 +152,60 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     float *v0w = grads[6], *v0b = grads[7], *vg = grads[8], *vb = grads[9], *v1w = grads[10], *v1b = grads[11];
     float *q0w = grads[12], *q0b = grads[13], *qg = grads[14], *qb = grads[15], *q1w = grads[16], *q1b = grads[17];
     {   // edge-indexed weight gradients: type / rbf columns of the first Linears, LayerNorm affine
-        const float* pz = w.partial;
-        RS(pz + PB_WT, eg, PB_SIZE, 2 * H, NT, H, k0w, KV_IN, 1);
-        RS(pz + PB_WT + H, eg, PB_SIZE, 2 * H, NT, H, v0w, KV_IN, 1);
-        RS(pz + PB_WR, eg, PB_SIZE, 2 * H, NT * G, H, k0w + NT, KV_IN, 1);
-        RS(pz + PB_WR + H, eg, PB_SIZE, 2 * H, NT * G, H, v0w + NT, KV_IN, 1);
-        RS(pz + PB_LNG, eg, PB_SIZE, H, 1, H, kg, H, 0);
-        RS(pz + PB_LNG + H, eg, PB_SIZE, H, 1, H, vg, H, 0);
-        RS(pz + PB_LNB, eg, PB_SIZE, H, 1, H, kb, H, 0);
-        RS(pz + PB_LNB + H, eg, PB_SIZE, H, 1, H, vb, H, 0);
+        FOLDED(w.partial, eg, PB_SIZE, PB_SIZE);
+        RS(fz + PB_WT, fn, fs, 2 * H, NT, H, k0w, KV_IN, 1);
+        RS(fz + PB_WT + H, fn, fs, 2 * H, NT, H, v0w, KV_IN, 1);
+        RS(fz + PB_WR, fn, fs, 2 * H, NT * G, H, k0w + NT, KV_IN, 1);
+        RS(fz + PB_WR + H, fn, fs, 2 * H, NT * G, H, v0w + NT, KV_IN, 1);
+        RS(fz + PB_LNG, fn, fs, H, 1, H, kg, H, 0);
+        RS(fz + PB_LNG + H, fn, fs, H, 1, H, vg, H, 0);
+        RS(fz + PB_LNB, fn, fs, H, 1, H, kb, H, 0);
+        RS(fz + PB_LNB + H, fn, fs, H, 1, H, vb, H, 0);
         if (!x2h) {
-            RS(pz + PB_WBV16, eg, PB_SIZE, H, HEADS, H, v1w, H, 0);
-            RS(pz + PB_BBV16, eg, PB_SIZE, HEADS, 1, HEADS, v1b, HEADS, 0);
+            RS(fz + PB_WBV16, fn, fs, H, HEADS, H, v1w, H, 0);
+            RS(fz + PB_BBV16, fn, fs, HEADS, 1, HEADS, v1b, HEADS, 0);
         }
     }
     // query MLP backward (fills dP[:, 512:640]) and its LayerNorm affine gradients
-    HIP_TRY(launch_q_backward(att, w.P, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, w.partial, ng, s));
-    RS(w.partial, ng, 2 * H, H, 1, H, qg, H, 0);
-    RS(w.partial + H, ng, 2 * H, H, 1, H, qb, H, 0);
+    {
+        const int tiles = (n + 15) / 16, qgrid = tiles < NODE_GRID ? tiles : NODE_GRID;
+        HIP_TRY(launch_q_backward(att, w.P, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, w.partial, qgrid, s));
+        FOLDED(w.partial, 2 * qgrid, 2 * H, 2 * H);
+        RS(fz, fn, fs, H, 1, H, qg, H, 0);
+        RS(fz + H, fn, fs, H, 1, H, qb, H, 0);
+    }
     // second Linears: dWbk = sum_i (q_i / sqrt 8) (x) T_i ;  x2h: dWbv = sum_i G_i (x) S_i ;  dWq1 = sum_i dq_i (x) z_i
     HIP_TRY(launch_outer_accum(true, w.qs, w.T, rows, n_rows, n, w.partial, ng, s));
-    RS(w.partial, ng, (size_t)H * H, H, H, H, k1w, H, 0);
+    { FOLDED(w.partial, ng, (size_t)H * H, H * H); RS(fz, fn, fs, H, H, H, k1w, H, 0); }
     HIP_TRY(hipMemsetAsync(k1b, 0, H * sizeof(float), s));   // the key bias cancels in the softmax
     if (x2h) {
         HIP_TRY(launch_outer_accum(true, g_out, w.S, rows, n_rows, n, w.partial, ng, s));
-        RS(w.partial, ng, (size_t)H * H, H, H, H, v1w, H, 0);
+        { FOLDED(w.partial, ng, (size_t)H * H, H * H); RS(fz, fn, fs, H, H, H, v1w, H, 0); }
         HIP_TRY(launch_colsum(g_out, H, H, w.sw, rows, n_rows, n, w.partial, ng, s));
-        RS(w.partial, ng, H, H, 1, H, v1b, H, 0);
+        { FOLDED(w.partial, ng, H, H); RS(fz, fn, fs, H, 1, H, v1b, H, 0); }
     }
     HIP_TRY(launch_outer_accum(false, w.dqb, w.zb, rows, n_rows, n, w.partial, ng, s));
-    RS(w.partial, ng, (size_t)H * H, H, H, H, q1w, H, 0);
+    { FOLDED(w.partial, ng, (size_t)H * H, H * H); RS(fz, fn, fs, H, H, H, q1w, H, 0); }
     HIP_TRY(launch_colsum(w.dqb, H, H, nullptr, rows, n_rows, n, w.partial, ng, s));
-    RS(w.partial, ng, H, H, 1, H, q1b, H, 0);
+    { FOLDED(w.partial, ng, H, H); RS(fz, fn, fs, H, 1, H, q1b, H, 0); }
     // first-Linear biases = column sums of dP (k | v | - | - | q hidden)
     HIP_TRY(launch_colsum(w.dP, PROW, PROW, nullptr, nullptr, nullptr, n, w.partial, ng, s));
-    RS(w.partial, ng, PROW, PROW, 1, H, k0b, H, 0);
-    RS(w.partial + H, ng, PROW, PROW, 1, H, v0b, H, 0);
-    RS(w.partial + 4 * H, ng, PROW, PROW, 1, H, q0b, H, 0);
+    {
+        FOLDED(w.partial, ng, PROW, PROW);
+        RS(fz, fn, fs, PROW, 1, H, k0b, H, 0);
+        RS(fz + H, fn, fs, PROW, 1, H, v0b, H, 0);
+        RS(fz + 4 * H, fn, fs, PROW, 1, H, q0b, H, 0);
+    }
     // dense projection: dWn[k][n] = sum_i h_in[i][k] dP[i][n]  -> h_dst / h_src / q columns of the first Linears
     const int sp = splits_for(n);
     HIP_TRY(launch_sgemm(true, false, h_in, H, w.dP, PROW, w.partial, PROW, H, PROW, n, sp, (size_t)H * PROW, 0, s));
     {
-        const size_t st = (size_t)H * PROW;
-        RS(w.partial + 0 * H, sp, st, PROW, H, H, k0w + NT + NT * G, KV_IN, 1);
-        RS(w.partial + 1 * H, sp, st, PROW, H, H, v0w + NT + NT * G, KV_IN, 1);
-        RS(w.partial + 2 * H, sp, st, PROW, H, H, k0w + NT + NT * G + H, KV_IN, 1);
-        RS(w.partial + 3 * H, sp, st, PROW, H, H, v0w + NT + NT * G + H, KV_IN, 1);
-        RS(w.partial + 4 * H, sp, st, PROW, H, H, q0w, H, 1);
+        FOLDED(w.partial, sp, (size_t)H * PROW, H * PROW);
+        RS(fz + 0 * H, fn, fs, PROW, H, H, k0w + NT + NT * G, KV_IN, 1);
+        RS(fz + 1 * H, fn, fs, PROW, H, H, v0w + NT + NT * G, KV_IN, 1);
+        RS(fz + 2 * H, fn, fs, PROW, H, H, k0w + NT + NT * G + H, KV_IN, 1);
+        RS(fz + 3 * H, fn, fs, PROW, H, H, v0w + NT + NT * G + H, KV_IN, 1);
+        RS(fz + 4 * H, fn, fs, PROW, H, H, q0w, H, 1);
     }
     // dL/dh_in += dP Wn^T
     HIP_TRY(launch_sgemm(false, true, w.dP, PROW, att + A_WN, PROW, gh, H, n, H, PROW, 1, 0, 1, s));
@@ -328,17 +350,17 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         HIP_TRY(launch_node_gemm(hl, H, c + C_W0T, c + C_B0, act, H, n, H, 1, s));
         // classifier.2: dW1[c][k] = sum_i dlogits[i][c] act[i][k];  db1 = colsum(dlogits)
         HIP_TRY(launch_sgemm(true, false, grad_logits, C, act, H, w.partial, H, C, H, n, sp, (size_t)C * H, 0, s));
-        RS(w.partial, sp, (size_t)C * H, H, C, H, cg[2], H, 0);
+        { FOLDED(w.partial, sp, (size_t)C * H, C * H); RS(fz, fn, fs, H, C, H, cg[2], H, 0); }
         HIP_TRY(launch_colsum(grad_logits, C, C, nullptr, nullptr, nullptr, n, w.partial, ng, s));
-        RS(w.partial, ng, C, C, 1, C, cg[3], C, 0);
+        { FOLDED(w.partial, ng, C, C); RS(fz, fn, fs, C, 1, C, cg[3], C, 0); }
         // d(act) = dlogits W1  (C_W1T is [128][C]);  d(pre) = d(act) sigmoid(pre)
         HIP_TRY(launch_sgemm(false, true, grad_logits, C, c + C_W1T, C, dact, H, n, H, C, 1, 0, 0, s));
         HIP_TRY(launch_ssp_backward(pre, dact, (long)nh, w.tmp, s));
         // classifier.0: dW0[n][k] = sum_i dpre[i][n] h[i][k];  db0 = colsum(dpre);  dh += dpre W0
         HIP_TRY(launch_sgemm(true, false, w.tmp, H, hl, H, w.partial, H, H, H, n, sp, (size_t)H * H, 0, s));
-        RS(w.partial, sp, (size_t)H * H, H, H, H, cg[0], H, 0);
+        { FOLDED(w.partial, sp, (size_t)H * H, H * H); RS(fz, fn, fs, H, H, H, cg[0], H, 0); }
         HIP_TRY(launch_colsum(w.tmp, H, H, nullptr, nullptr, nullptr, n, w.partial, ng, s));
-        RS(w.partial, ng, H, H, 1, H, cg[1], H, 0);
+        { FOLDED(w.partial, ng, H, H); RS(fz, fn, fs, H, 1, H, cg[1], H, 0); }
         HIP_TRY(launch_sgemm(false, true, w.tmp, H, c + C_W0T, H, w.gh, H, n, H, H, 1, 0, 1, s));
     } else {
         HIP_TRY(hipMemsetAsync(cg[0], 0, (size_t)H * H * 4, s));
@@ -372,12 +394,13 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
     if (grad_h_in) HIP_TRY(hipMemcpyAsync(grad_h_in, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
     // distance gate (computed once from the input coordinates, used by all 2L blocks)
     HIP_TRY(launch_gate_backward(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.E8, w.partial, GATE_GRID, s));
-    RS(w.partial + GB_W1, GATE_GRID, GB_SIZE, G, GH, G, grads[0], G, 0);
-    RS(w.partial + GB_B1, GATE_GRID, GB_SIZE, GH, 1, GH, grads[1], GH, 0);
-    RS(w.partial + GB_LNG, GATE_GRID, GB_SIZE, GH, 1, GH, grads[2], GH, 0);
-    RS(w.partial + GB_LNB, GATE_GRID, GB_SIZE, GH, 1, GH, grads[3], GH, 0);
-    RS(w.partial + GB_W2, GATE_GRID, GB_SIZE, GH, 1, GH, grads[4], GH, 0);
-    RS(w.partial + GB_B2, GATE_GRID, GB_SIZE, 1, 1, 1, grads[5], 1, 0);
+    FOLDED(w.partial, GATE_GRID, GB_SIZE, GB_SIZE);
+    RS(fz + GB_W1, fn, fs, G, GH, G, grads[0], G, 0);
+    RS(fz + GB_B1, fn, fs, GH, 1, GH, grads[1], GH, 0);
+    RS(fz + GB_LNG, fn, fs, GH, 1, GH, grads[2], GH, 0);
+    RS(fz + GB_LNB, fn, fs, GH, 1, GH, grads[3], GH, 0);
+    RS(fz + GB_W2, fn, fs, GH, 1, GH, grads[4], GH, 0);
+    RS(fz + GB_B2, fn, fs, 1, 1, 1, grads[5], 1, 0);
     return CBGX_OK;
 }
 

@@ -38,6 +38,8 @@ hipError_t launch_outer_accum(bool headed, const float* Lm, const float* R, cons
                               int n_nodes, float* partial, int grid, hipStream_t s);
 hipError_t launch_colsum(const float* A, int lda, int cols, const float* scale, const int* rows, const int* n_rows_ptr,
                          int n_rows, float* partial, int grid, hipStream_t s);
+hipError_t launch_slab_fold(const float* src, int n_slabs, size_t slab_stride, int size, int groups, float* dst,
+                            hipStream_t s);
 hipError_t launch_reduce_store(const float* src, int n_slabs, size_t slab_stride, int src_ld, int rows, int cols,
                                float* dst, int dst_ld, int transpose, hipStream_t s);
 // C[z] (+)= op(A) op(B); A is [M,K] (ta: stored [K,M]), B is [K,N] (tb: stored [N,K]); `splits` partitions K and

@@ -367,62 +367,142 @@ __global__ __launch_bounds__(128) void fold_grad_kernel(const float* __restrict_
 //   recompute z = ReLU(LN(P[:,512:640])), q = Wq1 z + bq1;  dq = (1/sqrt 8) Wbk_a^T-fold of T;
 //   outputs qs = q/sqrt(8), dq, z (for the outer-product weight gradients) and dP[:,512:640].
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float block128_sum(float v, float* red) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1];
-}
-
-__global__ __launch_bounds__(128) void q_backward_kernel(const float* __restrict__ att, const float* __restrict__ P,
+__global__ __launch_bounds__(256) void q_backward_kernel(const float* __restrict__ att, const float* __restrict__ P,
                                                          const float* __restrict__ T, const int* __restrict__ rows,
                                                          const int* __restrict__ n_rows_ptr, int n_nodes,
                                                          float* __restrict__ qs, float* __restrict__ dqb,
                                                          float* __restrict__ zb, float* __restrict__ dP,
                                                          float* __restrict__ partial) {
-    __shared__ float sT[HEADS][EP];
-    __shared__ float sZ[H], sDq[H], red[2];
+    // 16 nodes per tile, 256 threads.  Phases: LayerNorm (16 threads per row) -> q (thread = column, 8 rows) ->
+    // dq (T streamed through LDS in chunks of 32 m) -> dz -> LayerNorm backward.
+    __shared__ float sZ[H][17];            // hidden (post ReLU), transposed [k][row]
+    __shared__ float sNq[16][H + 1];       // normalised pre-activation
+    __shared__ float sDq[16][H + 1];       // dq, then d(normalised)
+    __shared__ float sT[16][HEADS][33];    // chunk of the per-node fold T: [row][head][32 m]
+    __shared__ float sRstd[16];
+    __shared__ int sRow[16];
     const int t = threadIdx.x;
+    const int n = t & 127, half = t >> 7;
     const float s8 = 0.35355339059327376220f;
-    const float gq = att[A_LNQ_G + t], bq = att[A_LNQ_B + t], b1 = att[A_BQ1 + t];
+    const float gq = att[A_LNQ_G + n], b1 = att[A_BQ1 + n];
     float aG = 0.f, aB = 0.f;
     const int count = rows ? *n_rows_ptr : n_nodes;
-    for (int it = blockIdx.x; it < count; it += gridDim.x) {
-        const int i = rows ? rows[it] : it;
-        const float v = P[(size_t)i * PROW + 4 * H + t];
-        const float mean = block128_sum(v, red) * (1.f / H);
-        const float cv = v - mean;
-        const float rstd = 1.f / sqrtf(block128_sum(cv * cv, red) * (1.f / H) + 1e-5f);
-        const float nq = cv * rstd;
-        const float z = fmaxf(nq * gq + bq, 0.f);
+    const int tiles = (count + 15) / 16;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         __syncthreads();
-        sZ[t] = z;
-        for (int u = t; u < HEADS * H; u += 128) sT[u >> 7][u & 127] = T[(size_t)i * HEADS * H + u];
+        if (t < 16) { const int it = tile * 16 + t; sRow[t] = it < count ? (rows ? rows[it] : it) : -1; }
         __syncthreads();
-        float q = b1, dq = 0.f;
-        for (int k = 0; k < H; ++k) q = fmaf(sZ[k], att[A_WQ1T + (size_t)k * H + t], q);
-        const int a = t >> 3;
-        for (int k = 0; k < H; ++k) dq = fmaf(att[A_WBKT + (size_t)k * H + t], sT[a][k], dq);
-        dq *= s8;
-        qs[(size_t)i * H + t] = q * s8;
-        dqb[(size_t)i * H + t] = dq;
-        zb[(size_t)i * H + t] = z;
-        sDq[t] = dq;
+        {
+            const int r = t >> 4, part = t & 15, i = sRow[r];
+            float v[8], s = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v[u] = i >= 0 ? P[(size_t)i * PROW + 4 * H + part + 16 * u] : 0.f; s += v[u]; }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+            const float mean = s * (1.f / H);
+            float q = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q += (v[u] - mean) * (v[u] - mean);
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+            const float rstd = 1.f / sqrtf(q * (1.f / H) + 1e-5f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = part + 16 * u;
+                const float nq = (v[u] - mean) * rstd;
+                const float z = fmaxf(nq * att[A_LNQ_G + k] + att[A_LNQ_B + k], 0.f);
+                sNq[r][k] = nq;
+                sZ[k][r] = z;
+                if (i >= 0) zb[(size_t)i * H + k] = z;
+            }
+            if (part == 0) sRstd[r] = rstd;
+        }
         __syncthreads();
-        float dz = 0.f;
-        for (int n = 0; n < H; ++n) dz = fmaf(sDq[n], att[A_WQ1O + (size_t)n * H + t], dz);
-        const float dy = z > 0.f ? dz : 0.f;
-        aG = fmaf(dy, nq, aG);
-        aB += dy;
-        const float dn = dy * gq;
-        const float m1 = block128_sum(dn, red) * (1.f / H);
-        const float m2 = block128_sum(dn * nq, red) * (1.f / H);
-        dP[(size_t)i * PROW + 4 * H + t] = rstd * (dn - m1 - nq * m2);
+        {   // q = Wq1 z + bq1 (stored pre-scaled by 1/sqrt(8) for the Wbk gradient)
+            float acc[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = b1;
+            for (int k = 0; k < H; ++k) {
+                const float w = att[A_WQ1T + (size_t)k * H + n];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) acc[r] = fmaf(sZ[k][half * 8 + r], w, acc[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const int i = sRow[half * 8 + r]; if (i >= 0) qs[(size_t)i * H + n] = acc[r] * s8; }
+        }
+        {   // dq[n] = (1/sqrt 8) sum_m Wbk[n][m] T[n >> 3][m]
+            float acc[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+            const int a = n >> 3;
+            for (int m0 = 0; m0 < H; m0 += 32) {
+                __syncthreads();
+#pragma unroll 4
+                for (int j = 0; j < 32; ++j) {
+                    const int idx = t + 256 * j, mm = idx & 31, aa = (idx >> 5) & 15, rr = idx >> 9;
+                    const int i = sRow[rr];
+                    sT[rr][aa][mm] = i >= 0 ? T[((size_t)i * HEADS + aa) * H + m0 + mm] : 0.f;
+                }
+                __syncthreads();
+                for (int mm = 0; mm < 32; ++mm) {
+                    const float w = att[A_WBKT + (size_t)(m0 + mm) * H + n];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) acc[r] = fmaf(w, sT[half * 8 + r][a][mm], acc[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float dq = acc[r] * s8;
+                sDq[half * 8 + r][n] = dq;
+                const int i = sRow[half * 8 + r];
+                if (i >= 0) dqb[(size_t)i * H + n] = dq;
+            }
+        }
+        __syncthreads();
+        {   // dz[k] = sum_n dq[n] Wq1[n][k]  ->  d(normalised)
+            float acc[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+            for (int nn = 0; nn < H; ++nn) {
+                const float w = att[A_WQ1O + (size_t)nn * H + n];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) acc[r] = fmaf(sDq[half * 8 + r][nn], w, acc[r]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int rr = half * 8 + r;
+                const float dy = sZ[n][rr] > 0.f ? acc[r] : 0.f;
+                aG = fmaf(dy, sNq[rr][n], aG);
+                aB += dy;
+                sDq[rr][n] = dy * gq;
+            }
+        }
+        __syncthreads();
+        {
+            const int r = t >> 4, part = t & 15, i = sRow[r];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float dn = sDq[r][part + 16 * u];
+                s1 += dn;
+                s2 = fmaf(dn, sNq[r][part + 16 * u], s2);
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+            const float m1 = s1 * (1.f / H), m2 = s2 * (1.f / H), rstd = sRstd[r];
+            if (i >= 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = part + 16 * u;
+                    dP[(size_t)i * PROW + 4 * H + k] = rstd * (sDq[r][k] - m1 - sNq[r][k] * m2);
+                }
+            }
+        }
     }
-    partial[(size_t)blockIdx.x * 2 * H + t] = aG;
-    partial[(size_t)blockIdx.x * 2 * H + H + t] = aB;
+    // two partial rows per workgroup (one per thread half): [gamma | beta]
+    partial[((size_t)blockIdx.x * 2 + half) * 2 * H + n] = aG;
+    partial[((size_t)blockIdx.x * 2 + half) * 2 * H + H + n] = aB;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -433,28 +513,41 @@ template <bool HEADED>
 __global__ __launch_bounds__(256) void outer_accum_kernel(const float* __restrict__ Lm, const float* __restrict__ R,
                                                           const int* __restrict__ rows, const int* __restrict__ n_rows_ptr,
                                                           int n_nodes, float* __restrict__ partial) {
-    __shared__ float sL[H];
+    __shared__ float sL[4][H];
+    __shared__ int sI[4];
     const int t = threadIdx.x, m = t & 127, nh = t >> 7;
     float acc[64];
 #pragma unroll
     for (int k = 0; k < 64; ++k) acc[k] = 0.f;
     const int count = rows ? *n_rows_ptr : n_nodes;
-    for (int it = blockIdx.x; it < count; it += gridDim.x) {
-        const int i = rows ? rows[it] : it;
+    for (int base = blockIdx.x * 4; base < count; base += gridDim.x * 4) {
         __syncthreads();
-        if (t < H) sL[t] = Lm[(size_t)i * H + t];
+        if (t < 4) { const int it = base + t; sI[t] = it < count ? (rows ? rows[it] : it) : -1; }
         __syncthreads();
-        if (HEADED) {
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const float r = R[((size_t)i * HEADS + nh * 8 + a) * H + m];
+        for (int j = 0; j < 2; ++j) {
+            const int idx = t + 256 * j, qn = idx >> 7, i = sI[qn];
+            sL[qn][idx & 127] = i >= 0 ? Lm[(size_t)i * H + (idx & 127)] : 0.f;
+        }
+        __syncthreads();
 #pragma unroll
-                for (int cc = 0; cc < DH; ++cc) acc[a * DH + cc] = fmaf(sL[nh * 64 + a * DH + cc], r, acc[a * DH + cc]);
+        for (int qn = 0; qn < 4; ++qn) {
+            const int i = sI[qn];
+            if (i < 0) continue;
+            if (HEADED) {
+                float r[8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) r[a] = R[((size_t)i * HEADS + nh * 8 + a) * H + m];
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int cc = 0; cc < DH; ++cc)
+                        acc[a * DH + cc] = fmaf(sL[qn][nh * 64 + a * DH + cc], r[a], acc[a * DH + cc]);
+            } else {
+                const float r = R[(size_t)i * H + m];
+#pragma unroll
+                for (int k = 0; k < 64; ++k) acc[k] = fmaf(sL[qn][nh * 64 + k], r, acc[k]);
             }
-        } else {
-            const float r = R[(size_t)i * H + m];
-#pragma unroll
-            for (int k = 0; k < 64; ++k) acc[k] = fmaf(sL[nh * 64 + k], r, acc[k]);
         }
     }
     float* slab = partial + (size_t)blockIdx.x * H * H;
@@ -470,14 +563,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
     const int count = rows ? *n_rows_ptr : n_rows;
     for (int c0 = threadIdx.x; c0 < cols; c0 += 256) {
         float acc = 0.f;
-        for (int it = blockIdx.x; it < count; it += gridDim.x) {
-            const int i = rows ? rows[it] : it;
-            float v = A[(size_t)i * lda + c0];
-            if (scale) v *= scale[(size_t)i * HEADS + (c0 >> 3)];
-            acc += v;
+        for (int it = blockIdx.x; it < count; it += 4 * gridDim.x) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int itj = it + j * gridDim.x;
+                v[j] = 0.f;
+                if (itj < count) {
+                    const int i = rows ? rows[itj] : itj;
+                    v[j] = A[(size_t)i * lda + c0];
+                    if (scale) v[j] *= scale[(size_t)i * HEADS + (c0 >> 3)];
+                }
+            }
+            acc += (v[0] + v[1]) + (v[2] + v[3]);
         }
         partial[(size_t)blockIdx.x * cols + c0] = acc;
     }
+}
+
+// first level of a two-level slab reduction: dst[g][c] = sum over slabs s = g (mod groups) of src[s][c]
+__global__ __launch_bounds__(256) void slab_fold_kernel(const float* __restrict__ src, int n_slabs, size_t slab_stride,
+                                                        int size, int groups, float* __restrict__ dst) {
+    const int c = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (c >= size) return;
+    float acc = 0.f;
+    for (int s = g; s < n_slabs; s += groups) acc += src[(size_t)s * slab_stride + c];
+    dst[(size_t)g * size + c] = acc;
 }
 
 // dst[r][c] (or dst[c][r] if transpose) = sum_s src[s * slab_stride + r * src_ld + c]
@@ -730,7 +841,7 @@ hipError_t launch_fold_grad(const float* att, const float* Gr, int n_nodes, floa
 hipError_t launch_q_backward(const float* att, const float* P, const float* T, const int* rows, const int* n_rows,
                              int n_nodes, float* qs, float* dqb, float* zb, float* dP, float* partial, int grid,
                              hipStream_t s) {
-    hipLaunchKernelGGL(q_backward_kernel, dim3(grid), dim3(128), 0, s, att, P, T, rows, n_rows, n_nodes, qs, dqb, zb, dP,
+    hipLaunchKernelGGL(q_backward_kernel, dim3(grid), dim3(256), 0, s, att, P, T, rows, n_rows, n_nodes, qs, dqb, zb, dP,
                        partial);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
@@ -749,6 +860,14 @@ hipError_t launch_outer_accum(bool headed, const float* Lm, const float* R, cons
 hipError_t launch_colsum(const float* A, int lda, int cols, const float* scale, const int* rows, const int* n_rows_ptr,
                          int n_rows, float* partial, int grid, hipStream_t s) {
     hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, s, A, lda, cols, scale, rows, n_rows_ptr, n_rows, partial);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_slab_fold(const float* src, int n_slabs, size_t slab_stride, int size, int groups, float* dst,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(slab_fold_kernel, dim3((size + 255) / 256, groups), dim3(256), 0, s, src, n_slabs, slab_stride, size,
+                       groups, dst);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }
