@@ -145,6 +145,10 @@ static int pack_attention_block(const float* const* p, int blk, float* a, hipStr
     CP(wk1, H, 0, 0, a + A_WBK, H, H, H);
     CP(wk1, H, 0, 1, a + A_WBKT, H, H, H);
     CP(wq1, H, 0, 0, a + A_WQ1O, H, H, H);
+    for (int ty = 0; ty < NT; ++ty) {   // WRT[ty][c][g] = W_a[c][4 + 20 ty + g]  (g 20..31 stay zero)
+        CP(wk0, KV_IN, NT + G * ty, 0, a + A_WRT + (size_t)ty * 2 * H * 32, 32, H, G);
+        CP(wv0, KV_IN, NT + G * ty, 0, a + A_WRT + ((size_t)ty * 2 * H + H) * 32, 32, H, G);
+    }
     // centred copies of the first k / v Linears: every MFMA-path table below is built from them
     HIP_TRY(launch_center_linear(wk0, bk0, KV_IN, a + A_WAKC, a + A_BAKC, s));
     HIP_TRY(launch_center_linear(wv0, bv0, KV_IN, a + A_WAVC, a + A_BAVC, s));

@@ -69,7 +69,7 @@ struct TrainWs {
 static size_t partial_floats_needed() {
     size_t a = (size_t)EDGE_GRID * PB_SIZE;
     size_t b = (size_t)NODE_GRID * H * H;
-    if (b < (size_t)2 * NODE_GRID * PROW) b = (size_t)2 * NODE_GRID * PROW;
+    if (b < (size_t)8 * NODE_GRID * 2 * H) b = (size_t)8 * NODE_GRID * 2 * H;
     size_t c = (size_t)MAX_SPLITS * H * PROW;
     size_t d = (size_t)GATE_GRID * GB_SIZE;
     size_t m = a > b ? a : b;
@@ -146,8 +146,13 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     HIP_TRY(launch_node_query_v1(att, w.P, w.Qt, n, s));
     if (x2h) HIP_TRY(launch_fold_grad(att, g_out, n, w.Gt, w.gb, s));
     HIP_TRY(hipMemsetAsync(w.dP, 0, (size_t)n * PROW * sizeof(float), s));
-    HIP_TRY(launch_edge_backward(x2h, att, x, w.P, w.Qt, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n, w.T,
-                                 w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s));
+    // cbgx_debug_set_edge_kernel(1) selects the first-generation (VALU) backward kernel as an on-device cross-check
+    if (g_edge_impl == 0)
+        HIP_TRY(launch_edge_backward_mfma(x2h, att, x, w.P, w.Qt, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n,
+                                          w.T, w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s));
+    else
+        HIP_TRY(launch_edge_backward(x2h, att, x, w.P, w.Qt, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n, w.T,
+                                     w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s));
     float *k0w = grads[0], *k0b = grads[1], *kg = grads[2], *kb = grads[3], *k1w = grads[4], *k1b = grads[5];
     float *v0w = grads[6], *v0b = grads[7], *vg = grads[8], *vb = grads[9], *v1w = grads[10], *v1b = grads[11];
     float *q0w = grads[12], *q0b = grads[13], *qg = grads[14], *qb = grads[15], *q1w = grads[16], *q1b = grads[17];
@@ -168,7 +173,7 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     }
     // query MLP backward (fills dP[:, 512:640]) and its LayerNorm affine gradients
     {
-        const int tiles = (n + 15) / 16, qgrid = tiles < NODE_GRID ? tiles : NODE_GRID;
+        const int tiles = (n + 15) / 16, qgrid = tiles < 4 * NODE_GRID ? tiles : 4 * NODE_GRID;   // 59 KB LDS: 2 per CU
         HIP_TRY(launch_q_backward(att, w.P, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, w.partial, qgrid, s));
         FOLDED(w.partial, 2 * qgrid, 2 * H, 2 * H);
         RS(fz, fn, fs, H, 1, H, qg, H, 0);

@@ -73,7 +73,9 @@ constexpr size_t A_BN2 = A_BAVC + H;
 // backward-only copies: Wbk transposed [m][n] and the second q Linear in the reference layout [n][k]
 constexpr size_t A_WBKT = A_BN2 + 2 * PROW;
 constexpr size_t A_WQ1O = A_WBKT + (size_t)H * H;
-constexpr size_t ATT_SIZE = A_WQ1O + (size_t)H * H;
+// rbf columns of the first Linears, transposed and padded for the backward's B operand: [4 types][256 c][32 g]
+constexpr size_t A_WRT = A_WQ1O + (size_t)H * H;
+constexpr size_t ATT_SIZE = A_WRT + (size_t)NT * 2 * H * 32;
 
 constexpr size_t LAYER_SIZE = 2 * ATT_SIZE;       // x2h then h2x
 

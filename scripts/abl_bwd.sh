@@ -1,0 +1,9 @@
+#!/bin/bash
+# timing ablations of the MFMA edge backward kernel (CBGX_BWD_ABL bits: 1 no neighbour atomics, 2 no neighbour
+# gathers, 4 no rbf-column / rbf gradient MFMAs, 8 no softmax, 16 no T/S stores).  Results are WRONG by design.
+for a in 0 1 2 4 8 16 31; do
+  CBGX_BWD_ABL=$a python bench.py --workload train --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); k=d['roofline']['per_kernel']
+print('abl=$a', 'x2h_bwd us', k['edge_x2h_bwd']['us_avg'], 'h2x_bwd us', k['edge_h2x_bwd']['us_avg'], 'ms/step', d['ms_per_step'])"
+done

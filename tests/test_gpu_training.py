@@ -39,6 +39,15 @@ def model(synthetic_sd):
     return m.to(DEV)
 
 
+@pytest.fixture(params=[0, 1], ids=["mfma", "valu"])
+def edge_impl(request):
+    """both generations of the edge backward kernel (cbgx_debug_set_edge_kernel) are checked against autograd"""
+    from cbgbench_amd import _native
+    old = _native.lib().cbgx_debug_set_edge_kernel(request.param)
+    yield request.param
+    _native.lib().cbgx_debug_set_edge_kernel(old)
+
+
 def _oracle_block(sd, g, layer, kind, seed):
     """autograd through one oracle attention block; returns inputs, upstream gradient and all gradients."""
     x = g["x"].clone().requires_grad_(True)
@@ -66,7 +75,7 @@ def _oracle_block(sd, g, layer, kind, seed):
 @pytest.mark.parametrize("case,kind", [("denoiser_2graphs", "x2h"), ("denoiser_2graphs", "h2x"),
                                        ("denoiser_linker", "x2h"), ("denoiser_linker", "h2x"),
                                        ("denoiser_small_graphs", "x2h"), ("denoiser_small_graphs", "h2x")])
-def test_attention_block_backward(golden_dir, synthetic_sd, model, case, kind):
+def test_attention_block_backward(golden_dir, synthetic_sd, model, case, kind, edge_impl):
     g = load(golden_dir, case)
     h_in, gout, gx_ref, gh_ref, gew_ref, pg_ref, keys, ei = _oracle_block(synthetic_sd, g, 0, kind, seed=3)
     x = g["x"].to(DEV)
