@@ -60,7 +60,7 @@ static Tape carve_tape(void* base, int n, int L) {
 
 // ---- backward workspace -----------------------------------------------------------------------------------
 struct TrainWs {
-    float *P, *Qt, *Gt, *T, *S, *gb, *sw, *qs, *dqb, *zb, *dP, *gh, *gx[2], *de_w, *E8, *tmp, *partial, *folded;
+    float *P, *Qt, *Gt, *T, *S, *gb, *sw, *qs, *dqb, *zb, *dP, *gh, *gx[2], *de_w, *E8, *tmp, *partial, *folded, *qln;
     int *act, *act_count;
     size_t partial_floats;
     size_t total;
@@ -68,8 +68,7 @@ struct TrainWs {
 
 static size_t partial_floats_needed() {
     size_t a = (size_t)EDGE_GRID * PB_SIZE;
-    size_t b = (size_t)NODE_GRID * H * H;
-    if (b < (size_t)8 * NODE_GRID * 2 * H) b = (size_t)8 * NODE_GRID * 2 * H;
+    size_t b = (size_t)NODE_GRID * NS_SIZE;
     size_t c = (size_t)MAX_SPLITS * H * PROW;
     size_t d = (size_t)GATE_GRID * GB_SIZE;
     size_t m = a > b ? a : b;
@@ -105,6 +104,7 @@ static TrainWs carve_train(void* base, int n) {
     w.partial_floats = partial_floats_needed();
     w.partial = (float*)take(w.partial_floats * 4);
     w.folded = (float*)take((size_t)FOLD * H * PROW * 4);
+    w.qln = (float*)take(2 * H * 4);
     w.total = off;
     return w;
 }
@@ -156,61 +156,75 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     float *k0w = grads[0], *k0b = grads[1], *kg = grads[2], *kb = grads[3], *k1w = grads[4], *k1b = grads[5];
     float *v0w = grads[6], *v0b = grads[7], *vg = grads[8], *vb = grads[9], *v1w = grads[10], *v1b = grads[11];
     float *q0w = grads[12], *q0b = grads[13], *qg = grads[14], *qb = grads[15], *q1w = grads[16], *q1b = grads[17];
+    RsBatch rb;
+    rb.n = 0;
+    auto piece = [&](const float* src, int nsl, size_t stride, int ld, int rws, int cls, float* dst, int dld, int tr) {
+        rb.p[rb.n++] = RsPiece{src, dst, stride, nsl, ld, rws, cls, dld, tr};
+    };
     {   // edge-indexed weight gradients: type / rbf columns of the first Linears, LayerNorm affine
         FOLDED(w.partial, eg, PB_SIZE, PB_SIZE);
-        RS(fz + PB_WT, fn, fs, 2 * H, NT, H, k0w, KV_IN, 1);
-        RS(fz + PB_WT + H, fn, fs, 2 * H, NT, H, v0w, KV_IN, 1);
-        RS(fz + PB_WR, fn, fs, 2 * H, NT * G, H, k0w + NT, KV_IN, 1);
-        RS(fz + PB_WR + H, fn, fs, 2 * H, NT * G, H, v0w + NT, KV_IN, 1);
-        RS(fz + PB_LNG, fn, fs, H, 1, H, kg, H, 0);
-        RS(fz + PB_LNG + H, fn, fs, H, 1, H, vg, H, 0);
-        RS(fz + PB_LNB, fn, fs, H, 1, H, kb, H, 0);
-        RS(fz + PB_LNB + H, fn, fs, H, 1, H, vb, H, 0);
+        piece(fz + PB_WT, fn, fs, 2 * H, NT, H, k0w, KV_IN, 1);
+        piece(fz + PB_WT + H, fn, fs, 2 * H, NT, H, v0w, KV_IN, 1);
+        piece(fz + PB_WR, fn, fs, 2 * H, NT * G, H, k0w + NT, KV_IN, 1);
+        piece(fz + PB_WR + H, fn, fs, 2 * H, NT * G, H, v0w + NT, KV_IN, 1);
+        piece(fz + PB_LNG, fn, fs, H, 1, H, kg, H, 0);
+        piece(fz + PB_LNG + H, fn, fs, H, 1, H, vg, H, 0);
+        piece(fz + PB_LNB, fn, fs, H, 1, H, kb, H, 0);
+        piece(fz + PB_LNB + H, fn, fs, H, 1, H, vb, H, 0);
         if (!x2h) {
-            RS(fz + PB_WBV16, fn, fs, H, HEADS, H, v1w, H, 0);
-            RS(fz + PB_BBV16, fn, fs, HEADS, 1, HEADS, v1b, HEADS, 0);
+            piece(fz + PB_WBV16, fn, fs, H, HEADS, H, v1w, H, 0);
+            piece(fz + PB_BBV16, fn, fs, HEADS, 1, HEADS, v1b, HEADS, 0);
         }
+        HIP_TRY(launch_reduce_store_multi(rb, s));
+        rb.n = 0;
     }
-    // query MLP backward (fills dP[:, 512:640]) and its LayerNorm affine gradients
+    // query MLP backward (fills dP[:, 512:640]); its LayerNorm affine gradients are accumulated into w.qln by atomics
     {
-        const int tiles = (n + 15) / 16, qgrid = tiles < 4 * NODE_GRID ? tiles : 4 * NODE_GRID;   // 59 KB LDS: 2 per CU
-        HIP_TRY(launch_q_backward(att, w.P, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, w.partial, qgrid, s));
-        FOLDED(w.partial, 2 * qgrid, 2 * H, 2 * H);
-        RS(fz, fn, fs, H, 1, H, qg, H, 0);
-        RS(fz + H, fn, fs, H, 1, H, qb, H, 0);
+        const int tiles = (n + 15) / 16, qgrid = tiles < 4 * NODE_GRID ? tiles : 4 * NODE_GRID;   // ~43 KB LDS: 3 per CU
+        HIP_TRY(hipMemsetAsync(w.qln, 0, 2 * H * sizeof(float), s));
+        HIP_TRY(launch_q_backward(att, w.P, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, w.qln, qgrid, s));
     }
-    // second Linears: dWbk = sum_i (q_i / sqrt 8) (x) T_i ;  x2h: dWbv = sum_i G_i (x) S_i ;  dWq1 = sum_i dq_i (x) z_i
-    HIP_TRY(launch_outer_accum(true, w.qs, w.T, rows, n_rows, n, w.partial, ng, s));
-    { FOLDED(w.partial, ng, (size_t)H * H, H * H); RS(fz, fn, fs, H, H, H, k1w, H, 0); }
-    HIP_TRY(hipMemsetAsync(k1b, 0, H * sizeof(float), s));   // the key bias cancels in the softmax
+    // node-level reductions, all into one slab per workgroup (NS_* layout), folded and scattered once:
+    //   second Linears: dWbk = sum_i (q_i / sqrt 8) (x) T_i ;  x2h: dWbv = sum_i G_i (x) S_i ;  dWq1 = sum_i dq_i (x) z_i
+    //   biases: second v / q Linears, and the first Linears = column sums of dP (k | v | - | - | q hidden)
+    HIP_TRY(launch_outer_accum(true, w.qs, w.T, rows, n_rows, n, w.partial + NS_WBK, NS_SIZE, ng, s));
     if (x2h) {
-        HIP_TRY(launch_outer_accum(true, g_out, w.S, rows, n_rows, n, w.partial, ng, s));
-        { FOLDED(w.partial, ng, (size_t)H * H, H * H); RS(fz, fn, fs, H, H, H, v1w, H, 0); }
-        HIP_TRY(launch_colsum(g_out, H, H, w.sw, rows, n_rows, n, w.partial, ng, s));
-        { FOLDED(w.partial, ng, H, H); RS(fz, fn, fs, H, 1, H, v1b, H, 0); }
+        HIP_TRY(launch_outer_accum(true, g_out, w.S, rows, n_rows, n, w.partial + NS_WBV, NS_SIZE, ng, s));
+        HIP_TRY(launch_colsum(g_out, H, H, w.sw, rows, n_rows, n, w.partial + NS_V1B, NS_SIZE, ng, s));
     }
-    HIP_TRY(launch_outer_accum(false, w.dqb, w.zb, rows, n_rows, n, w.partial, ng, s));
-    { FOLDED(w.partial, ng, (size_t)H * H, H * H); RS(fz, fn, fs, H, H, H, q1w, H, 0); }
-    HIP_TRY(launch_colsum(w.dqb, H, H, nullptr, rows, n_rows, n, w.partial, ng, s));
-    { FOLDED(w.partial, ng, H, H); RS(fz, fn, fs, H, 1, H, q1b, H, 0); }
-    // first-Linear biases = column sums of dP (k | v | - | - | q hidden)
-    HIP_TRY(launch_colsum(w.dP, PROW, PROW, nullptr, nullptr, nullptr, n, w.partial, ng, s));
+    HIP_TRY(launch_outer_accum(false, w.dqb, w.zb, rows, n_rows, n, w.partial + NS_WQ1, NS_SIZE, ng, s));
+    HIP_TRY(launch_colsum(w.dqb, H, H, nullptr, rows, n_rows, n, w.partial + NS_Q1B, NS_SIZE, ng, s));
+    HIP_TRY(launch_colsum(w.dP, PROW, PROW, nullptr, nullptr, nullptr, n, w.partial + NS_DP, NS_SIZE, ng, s));
+    HIP_TRY(hipMemsetAsync(k1b, 0, H * sizeof(float), s));   // the key bias cancels in the softmax
     {
-        FOLDED(w.partial, ng, PROW, PROW);
-        RS(fz, fn, fs, PROW, 1, H, k0b, H, 0);
-        RS(fz + H, fn, fs, PROW, 1, H, v0b, H, 0);
-        RS(fz + 4 * H, fn, fs, PROW, 1, H, q0b, H, 0);
+        FOLDED(w.partial, ng, NS_SIZE, NS_SIZE);
+        piece(fz + NS_WBK, fn, fs, H, H, H, k1w, H, 0);
+        piece(fz + NS_WQ1, fn, fs, H, H, H, q1w, H, 0);
+        piece(fz + NS_Q1B, fn, fs, H, 1, H, q1b, H, 0);
+        piece(fz + NS_DP, fn, fs, PROW, 1, H, k0b, H, 0);
+        piece(fz + NS_DP + H, fn, fs, PROW, 1, H, v0b, H, 0);
+        piece(fz + NS_DP + 4 * H, fn, fs, PROW, 1, H, q0b, H, 0);
+        if (x2h) {
+            piece(fz + NS_WBV, fn, fs, H, H, H, v1w, H, 0);
+            piece(fz + NS_V1B, fn, fs, H, 1, H, v1b, H, 0);
+        }
+        piece(w.qln, 1, 0, H, 1, H, qg, H, 0);
+        piece(w.qln + H, 1, 0, H, 1, H, qb, H, 0);
+        HIP_TRY(launch_reduce_store_multi(rb, s));
+        rb.n = 0;
     }
     // dense projection: dWn[k][n] = sum_i h_in[i][k] dP[i][n]  -> h_dst / h_src / q columns of the first Linears
     const int sp = splits_for(n);
     HIP_TRY(launch_sgemm(true, false, h_in, H, w.dP, PROW, w.partial, PROW, H, PROW, n, sp, (size_t)H * PROW, 0, s));
     {
         FOLDED(w.partial, sp, (size_t)H * PROW, H * PROW);
-        RS(fz + 0 * H, fn, fs, PROW, H, H, k0w + NT + NT * G, KV_IN, 1);
-        RS(fz + 1 * H, fn, fs, PROW, H, H, v0w + NT + NT * G, KV_IN, 1);
-        RS(fz + 2 * H, fn, fs, PROW, H, H, k0w + NT + NT * G + H, KV_IN, 1);
-        RS(fz + 3 * H, fn, fs, PROW, H, H, v0w + NT + NT * G + H, KV_IN, 1);
-        RS(fz + 4 * H, fn, fs, PROW, H, H, q0w, H, 1);
+        piece(fz + 0 * H, fn, fs, PROW, H, H, k0w + NT + NT * G, KV_IN, 1);
+        piece(fz + 1 * H, fn, fs, PROW, H, H, v0w + NT + NT * G, KV_IN, 1);
+        piece(fz + 2 * H, fn, fs, PROW, H, H, k0w + NT + NT * G + H, KV_IN, 1);
+        piece(fz + 3 * H, fn, fs, PROW, H, H, v0w + NT + NT * G + H, KV_IN, 1);
+        piece(fz + 4 * H, fn, fs, PROW, H, H, q0w, H, 1);
+        HIP_TRY(launch_reduce_store_multi(rb, s));
+        rb.n = 0;
     }
     // dL/dh_in += dP Wn^T
     HIP_TRY(launch_sgemm(false, true, w.dP, PROW, att + A_WN, PROW, gh, H, n, H, PROW, 1, 0, 1, s));
@@ -356,7 +370,7 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         // classifier.2: dW1[c][k] = sum_i dlogits[i][c] act[i][k];  db1 = colsum(dlogits)
         HIP_TRY(launch_sgemm(true, false, grad_logits, C, act, H, w.partial, H, C, H, n, sp, (size_t)C * H, 0, s));
         { FOLDED(w.partial, sp, (size_t)C * H, C * H); RS(fz, fn, fs, H, C, H, cg[2], H, 0); }
-        HIP_TRY(launch_colsum(grad_logits, C, C, nullptr, nullptr, nullptr, n, w.partial, ng, s));
+        HIP_TRY(launch_colsum(grad_logits, C, C, nullptr, nullptr, nullptr, n, w.partial, C, ng, s));
         { FOLDED(w.partial, ng, C, C); RS(fz, fn, fs, C, 1, C, cg[3], C, 0); }
         // d(act) = dlogits W1  (C_W1T is [128][C]);  d(pre) = d(act) sigmoid(pre)
         HIP_TRY(launch_sgemm(false, true, grad_logits, C, c + C_W1T, C, dact, H, n, H, C, 1, 0, 0, s));
@@ -364,7 +378,7 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         // classifier.0: dW0[n][k] = sum_i dpre[i][n] h[i][k];  db0 = colsum(dpre);  dh += dpre W0
         HIP_TRY(launch_sgemm(true, false, w.tmp, H, hl, H, w.partial, H, H, H, n, sp, (size_t)H * H, 0, s));
         { FOLDED(w.partial, sp, (size_t)H * H, H * H); RS(fz, fn, fs, H, H, H, cg[0], H, 0); }
-        HIP_TRY(launch_colsum(w.tmp, H, H, nullptr, nullptr, nullptr, n, w.partial, ng, s));
+        HIP_TRY(launch_colsum(w.tmp, H, H, nullptr, nullptr, nullptr, n, w.partial, H, ng, s));
         { FOLDED(w.partial, ng, H, H); RS(fz, fn, fs, H, 1, H, cg[1], H, 0); }
         HIP_TRY(launch_sgemm(false, true, w.tmp, H, c + C_W0T, H, w.gh, H, n, H, H, 1, 0, 1, s));
     } else {

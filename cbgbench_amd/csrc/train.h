@@ -16,6 +16,15 @@ constexpr int PB_WBV16 = PB_LNB + 2 * H;          // h2x: [16][128] second v Lin
 constexpr int PB_BBV16 = PB_WBV16 + HEADS * H;    // h2x: [16]
 constexpr int PB_SIZE = PB_BBV16 + HEADS;
 
+// per-workgroup slab of the node-level reductions of one attention block
+constexpr int NS_WBK = 0;                      // [128][128] second k Linear
+constexpr int NS_WBV = NS_WBK + H * H;         // [128][128] x2h second v Linear
+constexpr int NS_WQ1 = NS_WBV + H * H;         // [128][128] second q Linear
+constexpr int NS_V1B = NS_WQ1 + H * H;         // [128] x2h second v bias
+constexpr int NS_Q1B = NS_V1B + H;             // [128]
+constexpr int NS_DP = NS_Q1B + H;              // [640] column sums of dP (first-Linear biases)
+constexpr int NS_SIZE = NS_DP + PROW;
+
 // partial slab of gate_bwd_weight_kernel
 constexpr int GB_W1 = 0;                 // [160][20]
 constexpr int GB_B1 = GB_W1 + GH * G;
@@ -40,9 +49,18 @@ hipError_t launch_q_backward(const float* att, const float* P, const float* T, c
                              int n_nodes, float* qs, float* dqb, float* zb, float* dP, float* partial, int grid,
                              hipStream_t s);
 hipError_t launch_outer_accum(bool headed, const float* Lm, const float* R, const int* rows, const int* n_rows,
-                              int n_nodes, float* partial, int grid, hipStream_t s);
+                              int n_nodes, float* partial, size_t slab_stride, int grid, hipStream_t s);
 hipError_t launch_colsum(const float* A, int lda, int cols, const float* scale, const int* rows, const int* n_rows_ptr,
-                         int n_rows, float* partial, int grid, hipStream_t s);
+                         int n_rows, float* partial, size_t slab_stride, int grid, hipStream_t s);
+// up to RS_MAX reduce_store pieces in one launch
+constexpr int RS_MAX = 12;
+struct RsPiece {
+    const float* src; float* dst; size_t stride; int n_slabs, src_ld, rows, cols, dst_ld, transpose;
+};
+struct RsBatch {
+    RsPiece p[RS_MAX]; int n;
+};
+hipError_t launch_reduce_store_multi(const RsBatch& b, hipStream_t s);
 hipError_t launch_slab_fold(const float* src, int n_slabs, size_t slab_stride, int size, int groups, float* dst,
                             hipStream_t s);
 hipError_t launch_reduce_store(const float* src, int n_slabs, size_t slab_stride, int src_ld, int rows, int cols,

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void q_backward_kernel(const float* __restrict
     __shared__ float sZ[H][17];            // hidden (post ReLU), transposed [k][row]
     __shared__ float sNq[16][H + 1];       // normalised pre-activation
     __shared__ float sDq[16][H + 1];       // dq, then d(normalised)
-    __shared__ float sT[16][HEADS][33];    // chunk of the per-node fold T: [row][head][32 m]
+    __shared__ float sT[16][HEADS][17];    // chunk of the per-node fold T: [row][head][16 m]
     __shared__ float sRstd[16];
     __shared__ int sRow[16];
     const int t = threadIdx.x;
@@ -422,6 +422,7 @@ __global__ __launch_bounds__(256) void q_backward_kernel(const float* __restrict
             float acc[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[r] = b1;
+#pragma unroll 16
             for (int k = 0; k < H; ++k) {
                 const float w = att[A_WQ1T + (size_t)k * H + n];
 #pragma unroll
@@ -435,16 +436,17 @@ __global__ __launch_bounds__(256) void q_backward_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[r] = 0.f;
             const int a = n >> 3;
-            for (int m0 = 0; m0 < H; m0 += 32) {
+            for (int m0 = 0; m0 < H; m0 += 16) {
                 __syncthreads();
-#pragma unroll 4
-                for (int j = 0; j < 32; ++j) {
-                    const int idx = t + 256 * j, mm = idx & 31, aa = (idx >> 5) & 15, rr = idx >> 9;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int idx = t + 256 * j, mm = idx & 15, aa = (idx >> 4) & 15, rr = idx >> 8;
                     const int i = sRow[rr];
                     sT[rr][aa][mm] = i >= 0 ? T[((size_t)i * HEADS + aa) * H + m0 + mm] : 0.f;
                 }
                 __syncthreads();
-                for (int mm = 0; mm < 32; ++mm) {
+#pragma unroll
+                for (int mm = 0; mm < 16; ++mm) {
                     const float w = att[A_WBKT + (size_t)(m0 + mm) * H + n];
 #pragma unroll
                     for (int r = 0; r < 8; ++r) acc[r] = fmaf(w, sT[half * 8 + r][a][mm], acc[r]);
@@ -463,6 +465,7 @@ __global__ __launch_bounds__(256) void q_backward_kernel(const float* __restrict
             float acc[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+#pragma unroll 16
             for (int nn = 0; nn < H; ++nn) {
                 const float w = att[A_WQ1O + (size_t)nn * H + n];
 #pragma unroll
@@ -500,9 +503,9 @@ __global__ __launch_bounds__(256) void q_backward_kernel(const float* __restrict
             }
         }
     }
-    // two partial rows per workgroup (one per thread half): [gamma | beta]
-    partial[((size_t)blockIdx.x * 2 + half) * 2 * H + n] = aG;
-    partial[((size_t)blockIdx.x * 2 + half) * 2 * H + H + n] = aB;
+    // LayerNorm affine gradients: [gamma | beta], accumulated over workgroups (partial must be zeroed by the caller)
+    atomicAdd(&partial[n], aG);
+    atomicAdd(&partial[H + n], aB);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(256) void q_backward_kernel(const float* __restrict
 template <bool HEADED>
 __global__ __launch_bounds__(256) void outer_accum_kernel(const float* __restrict__ Lm, const float* __restrict__ R,
                                                           const int* __restrict__ rows, const int* __restrict__ n_rows_ptr,
-                                                          int n_nodes, float* __restrict__ partial) {
+                                                          int n_nodes, float* __restrict__ partial, size_t slab_stride) {
     __shared__ float sL[4][H];
     __shared__ int sI[4];
     const int t = threadIdx.x, m = t & 127, nh = t >> 7;
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(256) void outer_accum_kernel(const float* __restric
             }
         }
     }
-    float* slab = partial + (size_t)blockIdx.x * H * H;
+    float* slab = partial + (size_t)blockIdx.x * slab_stride;
 #pragma unroll
     for (int k = 0; k < 64; ++k) slab[(size_t)(nh * 64 + k) * H + m] = acc[k];
 }
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(256) void outer_accum_kernel(const float* __restric
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int lda, int cols,
                                                      const float* __restrict__ scale, const int* __restrict__ rows,
                                                      const int* __restrict__ n_rows_ptr, int n_rows,
-                                                     float* __restrict__ partial) {
+                                                     float* __restrict__ partial, size_t slab_stride) {
     const int count = rows ? *n_rows_ptr : n_rows;
     for (int c0 = threadIdx.x; c0 < cols; c0 += 256) {
         float acc = 0.f;
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
             }
             acc += (v[0] + v[1]) + (v[2] + v[3]);
         }
-        partial[(size_t)blockIdx.x * cols + c0] = acc;
+        partial[(size_t)blockIdx.x * slab_stride + c0] = acc;
     }
 }
 
@@ -600,6 +603,17 @@ __global__ void reduce_store_kernel(const float* __restrict__ src, int n_slabs, 
     float acc = 0.f;
     for (int s = 0; s < n_slabs; ++s) acc += src[(size_t)s * slab_stride + (size_t)r * src_ld + c];
     if (transpose) dst[(size_t)c * dst_ld + r] = acc; else dst[(size_t)r * dst_ld + c] = acc;
+}
+
+// several reduce_store pieces in one launch (blockIdx.y = piece)
+__global__ void reduce_store_multi_kernel(RsBatch b) {
+    const RsPiece& pc = b.p[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= pc.rows * pc.cols) return;
+    const int r = idx / pc.cols, c = idx % pc.cols;
+    float acc = 0.f;
+    for (int s = 0; s < pc.n_slabs; ++s) acc += pc.src[(size_t)s * pc.stride + (size_t)r * pc.src_ld + c];
+    if (pc.transpose) pc.dst[(size_t)c * pc.dst_ld + r] = acc; else pc.dst[(size_t)r * pc.dst_ld + c] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -848,18 +862,21 @@ hipError_t launch_q_backward(const float* att, const float* P, const float* T, c
 }
 
 hipError_t launch_outer_accum(bool headed, const float* Lm, const float* R, const int* rows, const int* n_rows,
-                              int n_nodes, float* partial, int grid, hipStream_t s) {
+                              int n_nodes, float* partial, size_t slab_stride, int grid, hipStream_t s) {
     if (headed)
-        hipLaunchKernelGGL(outer_accum_kernel<true>, dim3(grid), dim3(256), 0, s, Lm, R, rows, n_rows, n_nodes, partial);
+        hipLaunchKernelGGL(outer_accum_kernel<true>, dim3(grid), dim3(256), 0, s, Lm, R, rows, n_rows, n_nodes, partial,
+                           slab_stride);
     else
-        hipLaunchKernelGGL(outer_accum_kernel<false>, dim3(grid), dim3(256), 0, s, Lm, R, rows, n_rows, n_nodes, partial);
+        hipLaunchKernelGGL(outer_accum_kernel<false>, dim3(grid), dim3(256), 0, s, Lm, R, rows, n_rows, n_nodes, partial,
+                           slab_stride);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }
 
 hipError_t launch_colsum(const float* A, int lda, int cols, const float* scale, const int* rows, const int* n_rows_ptr,
-                         int n_rows, float* partial, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, s, A, lda, cols, scale, rows, n_rows_ptr, n_rows, partial);
+                         int n_rows, float* partial, size_t slab_stride, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, s, A, lda, cols, scale, rows, n_rows_ptr, n_rows, partial,
+                       slab_stride);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -878,6 +895,15 @@ hipError_t launch_reduce_store(const float* src, int n_slabs, size_t slab_stride
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(reduce_store_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, n_slabs, slab_stride, src_ld,
                        rows, cols, dst, dst_ld, transpose);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_reduce_store_multi(const RsBatch& b, hipStream_t s) {
+    if (b.n == 0) return hipSuccess;
+    int mx = 0;
+    for (int k = 0; k < b.n; ++k) mx = b.p[k].rows * b.p[k].cols > mx ? b.p[k].rows * b.p[k].cols : mx;
+    hipLaunchKernelGGL(reduce_store_multi_kernel, dim3((mx + 255) / 256, b.n), dim3(256), 0, s, b);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }
