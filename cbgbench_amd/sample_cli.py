@@ -18,20 +18,16 @@ import time
 import numpy as np
 import torch
 
-from . import get_model, load_config, set_num_atom_type, sharding, synthetic
+from . import get_model, load_config, priors, set_num_atom_type, sharding, synthetic
 
 
-def build_pocket_batch(pockets, num_samples, rng, num_classes, prior_types="uniform"):
-    """num_samples replicas of every pocket with fresh priors (sample.py:177-183; init_lig.py:392-400, 424-425)."""
-    plist, nlig = [], []
-    for p in pockets:
-        for _ in range(num_samples):
-            plist.append(p)
-            nlig.append(int(rng.integers(10, 46)))
-    batch = synthetic.make_batch(plist, nlig, rng, num_classes)
-    if prior_types == "absorbing":
-        batch["ligand_atom_type"] = torch.zeros_like(batch["ligand_atom_type"])
-    return batch
+def build_pocket_batch(pockets, num_samples, rng, num_classes, prior_types="uniform", device="cpu", num_dist=None,
+                       generator=None):
+    """num_samples replicas of every pocket with fresh priors (sample.py:177-183; init_lig.py:232-258, 376-432), built
+    for the whole batch at once on ``device`` (cbgbench_amd/priors.py)."""
+    ps = priors.PocketSet(pockets, device=device, center=False)   # pocket files are already centred (center_pos)
+    return priors.build_sampling_batch(ps, num_samples, num_classes, num_dist=num_dist, rng=rng, generator=generator,
+                                       type_prior=prior_types)
 
 
 def split_samples(x, c, batch_idx, n_graphs):
@@ -56,6 +52,9 @@ def main(argv=None):
     ap.add_argument("--num_samples", type=int, default=None)
     ap.add_argument("--pockets_per_batch", type=int, default=10)
     ap.add_argument("--save_traj", action="store_true")
+    ap.add_argument("--atom_num_dist", default=None,
+                    help="the reference's size-conditioned ligand-size histogram (repo/datasets/transforms/_atom_num_dist.npy); "
+                         "without it ligand sizes are U{10..45}")
     args = ap.parse_args(argv)
 
     rank, world, local = sharding.init_process_group()
@@ -89,7 +88,8 @@ def main(argv=None):
         rng0 = np.random.default_rng(args.seed)
         pockets = [synthetic.make_pocket(rng0, int(rng0.integers(350, 651))) for _ in range(max(args.synthetic, 1))]
     num_samples = args.num_samples or config.get("sampling", {}).get("num_samples", 10)
-    prior = "absorbing" if config.model.type == "diffbp" else "uniform"
+    prior = {"diffbp": "absorbing", "diffsbdd": "zeros"}.get(config.model.type, "uniform")   # configs/denovo/test/*.yml
+    num_dist = priors.NumDist.from_npy(args.atom_num_dist) if args.atom_num_dist else None
 
     mine = sharding.shard_indices(len(pockets), rank, world)
     out_dir = os.path.join(args.out_root, args.tag or config_name)
@@ -99,8 +99,8 @@ def main(argv=None):
     t0, graph_steps = time.perf_counter(), 0
     for b0 in range(0, len(mine), args.pockets_per_batch):
         ids = mine[b0:b0 + args.pockets_per_batch]
-        batch = build_pocket_batch([pockets[i] for i in ids], num_samples, rng, config.model.num_atomtype, prior)
-        batch = synthetic.batch_to(batch, dev)
+        batch = build_pocket_batch([pockets[i] for i in ids], num_samples, rng, config.model.num_atomtype, prior,
+                                   device=dev, num_dist=num_dist)
         traj = model.sample(batch)
         x, c, bidx = traj[-1] if config.model.type != "diffsbdd" else traj[0]
         samples = split_samples(x.cpu(), c.cpu(), bidx.cpu(), len(ids) * num_samples)

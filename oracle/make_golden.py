@@ -303,6 +303,37 @@ def diffsbdd_case(name, *a, **k):
         _diffsbdd_case(name, *a, **k)
 
 
+def priors_case(name):
+    """Ligand-size prior of the reference (repo/datasets/transforms/init_lig.py:28-52,232-258): pocket size function and
+    bin lookup on seeded pockets, the bin edges, and per-bin mean / support of the histogram table (the table itself is
+    the reference's data file and is NOT stored), plus 4000 draws of sample_atom_num per pocket under a fixed numpy seed
+    for a distribution check of the vectorised sampler."""
+    if not _selected(name):
+        return
+    ref_shim.load_reference()
+    import repo.datasets.transforms.init_lig as IL
+    rng = np.random.default_rng(71)
+    out = {}
+    sizes, bins = [], []
+    for k, (n, rad) in enumerate([(350, 12.0), (500, 12.0), (650, 12.0), (120, 7.0), (40, 5.0), (600, 16.0), (450, 14.0)]):
+        pos, _, _ = S.make_pocket(rng, n, radius=rad)
+        out[f"pos_{k}"] = pos
+        sz = IL.AssignMolSize().get_space_size(torch.from_numpy(pos))
+        sizes.append(float(sz))
+        bins.append(IL._get_bin_idx(float(sz), IL.config_atom_num))
+    out["space_size"] = np.array(sizes, np.float64)
+    out["bin_idx"] = np.array(bins, np.int64)
+    cfg = IL.config_atom_num
+    out["bounds"] = np.array(cfg["bounds"], np.float64)
+    out["bin_mean"] = np.array([float(np.dot(v, p)) for v, p in cfg["bins"]])
+    out["bin_min"] = np.array([int(np.min(v)) for v, _ in cfg["bins"]])
+    out["bin_max"] = np.array([int(np.max(v)) for v, _ in cfg["bins"]])
+    np.random.seed(5)
+    out["draw_mean"] = np.array([np.mean([IL.sample_atom_num(sz) for _ in range(4000)]) for sz in sizes])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, sizes, bins)
+
+
 def _selected(name):
     """``python -m oracle.make_golden train_`` regenerates only the fixtures whose name contains an argument."""
     sel = sys.argv[1:]
@@ -344,6 +375,7 @@ def main():
     train_case(model, "train_loss_denovo", small_batch([(64, 10), (50, 12), (57, 9)], seed=61), seed=15)
     train_case(model, "train_loss_t0_linker", small_batch([(58, 15), (44, 12)], seed=62, ctx=[10, 8]), seed=16,
                t_override=torch.tensor([0, 700]))
+    priors_case("priors_atom_num")
     sample_case("sample_T5", small_batch([(40, 8), (36, 6)], seed=31), T=5, seed=9)
     b = small_batch([(44, 9), (37, 8)], seed=51)
     b["ligand_atom_type"] = torch.zeros_like(b["ligand_atom_type"])        # absorbing-state prior (assign_atomtype: absorbing)

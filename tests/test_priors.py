@@ -1,0 +1,107 @@
+"""Vectorised prior sampling / batch construction (cbgbench_amd/priors.py) against the reference's transforms
+(golden: tests/golden/priors_atom_num.npz, made by oracle/make_golden.py from repo/datasets/transforms/init_lig.py) and
+against the per-sample collate of cbgbench_amd/synthetic.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cbgbench_amd import priors, synthetic
+
+REF_TABLE = "/root/reference/repo/datasets/transforms/_atom_num_dist.npy"
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    z = np.load(os.path.join(golden_dir, "priors_atom_num.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def test_space_size_matches_reference(gold):
+    for k in range(7):
+        pos = torch.from_numpy(gold[f"pos_{k}"])
+        assert float(priors.space_size(pos)) == pytest.approx(gold["space_size"][k], rel=0, abs=1e-6)
+
+
+def test_bin_lookup_matches_reference(gold):
+    dist = priors.NumDist(gold["bounds"], [([1], [1.0])] * (len(gold["bounds"]) + 1))
+    assert dist.bin_index(gold["space_size"]).tolist() == gold["bin_idx"].tolist()
+    # edges: a size equal to a bound belongs to the next bin (bounds[i] > size is strict, init_lig.py:47-52)
+    assert dist.bin_index(gold["bounds"][3]) == 4 and dist.bin_index(gold["bounds"][3] - 1e-9) == 3
+    assert dist.bin_index(1e9) == len(gold["bounds"])
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TABLE), reason="the reference's histogram table is only in the build container")
+def test_sampler_distribution_matches_reference_table(gold):
+    dist = priors.NumDist.from_npy(REF_TABLE)
+    assert np.allclose(dist.bounds, gold["bounds"])
+    rng = np.random.default_rng(0)
+    draws = dist.sample(gold["space_size"], 20000, rng)
+    for k in range(7):
+        b = int(gold["bin_idx"][k])
+        assert draws[k].min() >= gold["bin_min"][b] and draws[k].max() <= gold["bin_max"][b]
+        sd = draws[k].std() / np.sqrt(draws.shape[1])
+        assert abs(draws[k].mean() - gold["bin_mean"][b]) < 5 * sd + 1e-9          # exact table mean
+        assert abs(draws[k].mean() - gold["draw_mean"][k]) < 0.5                   # the reference's own 4000 draws
+
+
+def _pockets(rng, sizes):
+    return [synthetic.make_pocket(rng, n, radius=8.0) for n in sizes]
+
+
+def test_batch_layout_equals_per_sample_collate():
+    """same atoms, same order, same ids as collating P x S replicas one by one (sample.py:177-183 + PyG collate)"""
+    rng = np.random.default_rng(3)
+    pk = _pockets(rng, [60, 45, 70])
+    S = 4
+    n_lig = rng.integers(5, 12, size=(3, S))
+    ps = priors.PocketSet(pk, center=True)
+    g = torch.Generator().manual_seed(0)
+    b = priors.build_sampling_batch(ps, S, 13, n_lig=n_lig, generator=g)
+    ref = synthetic.make_batch([pk[p] for p in range(3) for _ in range(S)], n_lig.reshape(-1), rng, 13)
+    for k in ("protein_pos", "protein_atom_feature", "protein_aa_type", "protein_lig_flag", "protein_element_batch",
+              "ligand_lig_flag", "ligand_element_batch"):
+        assert torch.equal(b[k], ref[k]) or torch.allclose(b[k].float(), ref[k].float(), atol=1e-6), k
+    assert b["ligand_pos"].shape == ref["ligand_pos"].shape and b["ligand_atom_type"].shape == ref["ligand_atom_type"].shape
+    assert int(b["ligand_atom_type"].max()) < 13 and abs(float(b["ligand_pos"].mean())) < 0.3
+    # translation restores the original frame
+    back = priors.translate(b["protein_pos"], b["protein_element_batch"], ps, S)
+    orig = torch.cat([torch.from_numpy(pk[p][0]) for p in range(3) for _ in range(S)])
+    assert torch.allclose(back, orig, atol=1e-5)
+
+
+def test_priors_and_context_atoms():
+    rng = np.random.default_rng(4)
+    pk = _pockets(rng, [50, 64])
+    ps = priors.PocketSet(pk)
+    ctx = [(rng.standard_normal((6, 3)).astype(np.float32), rng.integers(0, 13, 6)),
+           (rng.standard_normal((9, 3)).astype(np.float32), rng.integers(0, 13, 9))]
+    n_lig = np.array([[4, 10, 6], [20, 9, 12]])       # 4 <= 6, 6 <= 6, 9 <= 9 must be enlarged to ctx + U{1..7}
+    b = priors.build_sampling_batch(ps, 3, 13, n_lig=n_lig, context=ctx, rng=rng, generator=torch.Generator().manual_seed(1))
+    cnt = torch.bincount(b["ligand_element_batch"])
+    assert cnt.tolist()[1] == 10 and cnt.tolist()[3] == 20 and cnt.tolist()[5] == 12
+    for gidx, c in ((0, 6), (2, 6), (4, 9)):
+        assert c + 1 <= int(cnt[gidx]) <= c + 7
+    gen = b["ligand_gen_flag"]
+    for gidx in range(6):
+        sel = b["ligand_element_batch"] == gidx
+        c = 6 if gidx < 3 else 9
+        assert gen[sel].tolist() == [False] * c + [True] * (int(sel.sum()) - c)          # context atoms first
+        cpos, ctyp = ctx[0 if gidx < 3 else 1]
+        centre = ps.center[0 if gidx < 3 else 1]
+        assert torch.allclose(b["ligand_pos"][sel][:c], torch.from_numpy(cpos) - centre, atol=1e-6)
+        assert b["ligand_atom_type"][sel][:c].tolist() == list(ctyp)
+    a = priors.build_sampling_batch(ps, 2, 13, type_prior="absorbing")
+    assert int(a["ligand_atom_type"].abs().max()) == 0
+    z = priors.build_sampling_batch(ps, 2, 8, type_prior="zeros")           # DiffSBDD's float one-hot prior
+    assert z["ligand_atom_type"].shape[1] == 8 and float(z["ligand_atom_type"].abs().max()) == 0.0
+    zm = priors.build_sampling_batch(ps, 2, 13, pos_prior="zero_mean_gaussian")
+    m = torch.zeros(4, 3).index_add_(0, zm["ligand_element_batch"], zm["ligand_pos"])
+    assert float(m.abs().max()) < 1e-4
+    with pytest.raises(ValueError, match="Unknown distribution type"):
+        priors.build_sampling_batch(ps, 2, 13, type_prior="posterior")
+    # default size prior: fallback U{10..45} when no table is given
+    d = priors.build_sampling_batch(ps, 50, 13)
+    c = torch.bincount(d["ligand_element_batch"])
+    assert int(c.min()) >= 10 and int(c.max()) <= 45
