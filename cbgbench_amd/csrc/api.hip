@@ -53,6 +53,9 @@ struct Workspace {
     uint8_t* mask;   // receptive-field pruning: reachability mask and the three node lists derived from it
     int* rf_list[3];
     int* rf_count;   // [3], 64 B apart
+    uint8_t* fmask[2];   // static-context cache: "differs from the ligand-free pocket" masks (ping-pong)
+    int* fw_list[4];     // D1, S1 = D1 | nbr(D1), D2, S2
+    int* fw_count;       // [4], 64 B apart
     float* hbuf[2];
     float* xbuf[2];
     size_t total;
@@ -75,6 +78,10 @@ static Workspace carve(void* base, int n) {
     w.mask = (uint8_t*)take(N);
     for (int k = 0; k < 3; ++k) w.rf_list[k] = (int*)take(N * 4);
     w.rf_count = (int*)take(256);
+    w.fmask[0] = (uint8_t*)take(N);
+    w.fmask[1] = (uint8_t*)take(N);
+    for (int k = 0; k < 4; ++k) w.fw_list[k] = (int*)take(N * 4);
+    w.fw_count = (int*)take(256);
     w.hbuf[0] = (float*)take(N * H * 4);
     w.hbuf[1] = (float*)take(N * H * 4);
     w.xbuf[0] = (float*)take(N * 3 * 4);
@@ -318,10 +325,10 @@ int cbgx_classifier(const float* packed, int num_layers, int num_classes, const 
     return CBGX_OK;
 }
 
-int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_classes, const float* x, const float* h,
-                                const int32_t* graph_ptr, const uint8_t* lig_flag, const uint8_t* gen_flag,
-                                int n_nodes, int n_graphs, float* x_out, float* h_out, float* logits, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+static int forward_impl(const float* packed, int num_layers, int num_classes, const float* x, const float* h,
+                        const int32_t* graph_ptr, const uint8_t* lig_flag, const uint8_t* gen_flag, int n_nodes,
+                        int n_graphs, float* x_out, float* h_out, float* logits, const float* static_h1,
+                        const float* static_h2, void* workspace, size_t workspace_bytes, void* stream) {
     if (n_nodes < 0 || n_graphs < 0 || num_layers < 1) return fail(CBGX_E_INVALID, "forward: bad sizes");
     if (n_nodes == 0) return CBGX_OK;
     if (!packed || !x || !h || !graph_ptr || !lig_flag || !gen_flag || !x_out || !workspace)
@@ -352,12 +359,34 @@ int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_cla
             HIP_TRY(launch_build_active(w.mask, n_nodes, w.rf_list[k], w.rf_count + 16 * k, s));
         }
     }
+    // Static-context cache (optional): static_h1 / static_h2 [N,128] hold the features that leave layer 0 / layer 1 in
+    // the ligand-free pocket (rows of ligand atoms unused).  A protein node with no ligand atom among its neighbours sees
+    // exactly that pocket in layer 0, so its output is the cached row; the set that differs grows by one hop per layer:
+    //   D1 = lig | {i : nbr(i) has a ligand atom},   D2 = D1 | {i : nbr(i) meets D1};   sources S_k = D_k | nbr(D_k).
+    // Layers 0 and 1 then run on D1 / D2 only, every other row of their output is a copy of the cache.
+    const bool cached = static_h1 && static_h2 && num_layers >= 4;
+    if (cached) {
+        HIP_TRY(launch_mark_from_nbr(lig_flag, w.nbr, w.deg, n_nodes, w.fmask[0], s));                       // D1
+        HIP_TRY(launch_build_active(w.fmask[0], n_nodes, w.fw_list[0], w.fw_count, s));
+        HIP_TRY(launch_mark_from_nbr(w.fmask[0], w.nbr, w.deg, n_nodes, w.fmask[1], s));                    // D2
+        HIP_TRY(launch_build_active(w.fmask[1], n_nodes, w.fw_list[2], w.fw_count + 32, s));
+        HIP_TRY(launch_mark_nbr(w.fw_list[0], w.fw_count, n_nodes, w.nbr, w.deg, w.fmask[0], s));           // S1
+        HIP_TRY(launch_build_active(w.fmask[0], n_nodes, w.fw_list[1], w.fw_count + 16, s));
+        HIP_TRY(launch_mark_nbr(w.fw_list[2], w.fw_count + 32, n_nodes, w.nbr, w.deg, w.fmask[1], s));      // S2
+        HIP_TRY(launch_build_active(w.fmask[1], n_nodes, w.fw_list[3], w.fw_count + 48, s));
+    }
     const float* xc = x;
     const float* hc = h;
     for (int l = 0; l < num_layers; ++l) {
         float* hn = (l == num_layers - 1 && h_out) ? h_out : w.hbuf[l & 1];
         float* xn = (l == num_layers - 1) ? x_out : w.xbuf[l & 1];
         const int *dst = nullptr, *dst_n = nullptr, *src = nullptr, *src_n = nullptr;
+        if (cached && l < 2) {
+            HIP_TRY(hipMemcpyAsync(hn, l == 0 ? static_h1 : static_h2, (size_t)n_nodes * H * sizeof(float),
+                                   hipMemcpyDeviceToDevice, s));
+            dst = w.fw_list[2 * l]; dst_n = w.fw_count + 32 * l;
+            src = w.fw_list[2 * l + 1]; src_n = w.fw_count + 32 * l + 16;
+        }
         if (prune && l >= num_layers - 2) {
             const int k = num_layers - 1 - l;   // 0 for the last layer, 1 for the one before
             dst = w.rf_list[k]; dst_n = w.rf_count + 16 * k;
@@ -380,6 +409,24 @@ int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_cla
                                  num_classes, 0, s, rows, n_rows));
     }
     return CBGX_OK;
+}
+
+int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_classes, const float* x, const float* h,
+                                const int32_t* graph_ptr, const uint8_t* lig_flag, const uint8_t* gen_flag,
+                                int n_nodes, int n_graphs, float* x_out, float* h_out, float* logits, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    return forward_impl(packed, num_layers, num_classes, x, h, graph_ptr, lig_flag, gen_flag, n_nodes, n_graphs, x_out,
+                        h_out, logits, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+int cbgx_unitransformer_forward_cached(const float* packed, int num_layers, int num_classes, const float* x,
+                                       const float* h, const int32_t* graph_ptr, const uint8_t* lig_flag,
+                                       const uint8_t* gen_flag, int n_nodes, int n_graphs, const float* static_h1,
+                                       const float* static_h2, float* x_out, float* h_out, float* logits,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (!static_h1 || !static_h2) return fail(CBGX_E_INVALID, "forward_cached: NULL static context");
+    return forward_impl(packed, num_layers, num_classes, x, h, graph_ptr, lig_flag, gen_flag, n_nodes, n_graphs, x_out,
+                        h_out, logits, static_h1, static_h2, workspace, workspace_bytes, stream);
 }
 
 int cbgx_targetdiff_prologue(const float* x_lig, const float* c_lig, const int32_t* lig_rows, int n_lig, int num_classes,

@@ -43,6 +43,8 @@ hipError_t launch_pack_node_frags(const float* wk0, const float* wv0, const floa
                                   const float* wbk, float* att, hipStream_t s);
 hipError_t launch_build_active(const uint8_t* flag, int n, int* list, int* count, hipStream_t s);
 hipError_t launch_mark_seed(const uint8_t* a, const uint8_t* b, int n, uint8_t* m, hipStream_t s);
+hipError_t launch_mark_from_nbr(const uint8_t* flag, const int32_t* nbr, const int32_t* deg, int n, uint8_t* out,
+                                hipStream_t s);
 hipError_t launch_mark_nbr(const int* list, const int* count, int n_upper, const int32_t* nbr, const int32_t* deg,
                            uint8_t* m, hipStream_t s);
 hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,

@@ -368,6 +368,26 @@ __global__ void mark_nbr_kernel(const int* __restrict__ list, const int* __restr
     if (e < deg[i]) m[nbr[(size_t)i * KNN + e]] = 1;
 }
 
+// out[i] |= 1 if any in-neighbour of i is flagged (forward propagation of "differs from the ligand-free pocket");
+// out must already hold the flags themselves.  One thread per (node, slot); benign write race (every writer stores 1).
+__global__ void mark_from_nbr_kernel(const uint8_t* __restrict__ flag, const int32_t* __restrict__ nbr,
+                                     const int32_t* __restrict__ deg, int n, uint8_t* __restrict__ out) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(t >> 5), e = (int)(t & 31);
+    if (i >= n || e >= deg[i]) return;
+    if (flag[nbr[(size_t)i * KNN + e]]) out[i] = 1;
+}
+
+hipError_t launch_mark_from_nbr(const uint8_t* flag, const int32_t* nbr, const int32_t* deg, int n, uint8_t* out,
+                                hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMemcpyAsync(out, flag, (size_t)n, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return e;
+    const long threads = (long)n * 32;
+    hipLaunchKernelGGL(mark_from_nbr_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, flag, nbr, deg, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_mark_seed(const uint8_t* a, const uint8_t* b, int n, uint8_t* m, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(mark_seed_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, n, m);

@@ -358,7 +358,7 @@ class TargetDiff(nn.Module):
         return sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr_from_batch(batch_idx, n_graphs)
 
     @torch.no_grad()
-    def begin_sampling(self, batch, keep_trajectory=True):
+    def begin_sampling(self, batch, keep_trajectory=True, static_cache=True):
         """Everything that is constant over the T steps of one batch: the composition permutation, CSR
         offsets, flags, the protein half of x / h, trajectory buffers.  Returns a state dict."""
         x_lig = batch["ligand_pos"].float()
@@ -386,6 +386,10 @@ class TargetDiff(nn.Module):
         st = dict(x=x, h=h, x_lig=x_lig.contiguous(), c_lig=c_lig.contiguous(), bl=bl, gen_l=gen_l, batch_idx=batch_idx,
                   lig_flag=lig_flag, gen_flag=gen_flag, lig_rows=lig_rows, graph_ptr=graph_ptr, B=B, n_lig=n_lig, N=N,
                   traj_x=None, traj_c=None)
+        st["static_h"] = None
+        if dev.type == "cuda" and static_cache and not bool(gen_r.any()):
+            # protein rows of (x, h) are the same in all T denoiser calls: cache the ligand-free first two layers once
+            st["static_h"] = self.denoiser.static_context(x_rec, h[rec_rows], br, rec_rows, N)
         if dev.type == "cuda":
             # operands of the native prologue / epilogue kernels (include/cbgx.h)
             st["lig_rows32"] = lig_rows.to(torch.int32).contiguous()
@@ -442,7 +446,8 @@ class TargetDiff(nn.Module):
             _native.ptr(emb.ligand_indicator.weight), _native.ptr(emb.ligand_indicator.bias),
             _native.ptr(st["x"]), _native.ptr(st["h"]), stream), "cbgx_targetdiff_prologue")
         xo, _, logits = self.denoiser(x=st["x"], h=st["h"], batch_idx=st["batch_idx"], lig_flag=st["lig_flag"],
-                                      gen_flag=st["gen_flag"], graph_ptr=st["graph_ptr"], need_h=False)
+                                      gen_flag=st["gen_flag"], graph_ptr=st["graph_ptr"], need_h=False,
+                                      static_h=st["static_h"])
         if noise is not None:
             eps, u = noise[0].float().contiguous(), noise[1].float().contiguous()
         else:   # same draw order as the reference: randn_like(x_lig) then rand_like(log-probs)

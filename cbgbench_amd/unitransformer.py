@@ -237,12 +237,44 @@ class UniTransformer(nn.Module):
         return ws
 
     # ---- forward -----------------------------------------------------------------------------
-    def forward(self, x, h, batch_idx, lig_flag, gen_flag, graph_ptr=None, need_h=True):
+    @torch.no_grad()
+    def static_context(self, x_rec, h_rec, batch_idx_rec, rec_rows, n_nodes, graph_ptr_rec=None):
+        """The cache ``forward(..., static_h=...)`` consumes (include/cbgx.h, cbgx_unitransformer_forward_cached): the
+        features leaving layers 0 and 1 on the ligand-free pockets, scattered to the composed row order.  Valid for as
+        long as the protein rows of (x, h) and the weights do not change -- i.e. for all steps of one sampling run."""
+        if self.num_layers < 4:
+            return None
+        device = x_rec.device
+        n = x_rec.shape[0]
+        if graph_ptr_rec is None:
+            graph_ptr_rec = graph_ptr_from_batch(batch_idx_rec)
+        B = graph_ptr_rec.numel() - 1
+        x_rec = x_rec.detach().float().contiguous()
+        h_rec = h_rec.detach().float().contiguous()
+        zeros = torch.zeros(n, dtype=torch.uint8, device=device)
+        packed, ws = self.packed_weights(device), self.workspace(n, B, device)
+        lib = _native.lib()
+        out = []
+        for L in (1, 2):
+            x_o, h_o = torch.empty_like(x_rec), torch.empty_like(h_rec)
+            rc = lib.cbgx_unitransformer_forward(
+                _native.ptr(packed), L, self.out_classes, _native.ptr(x_rec), _native.ptr(h_rec),
+                _native.ptr(graph_ptr_rec), _native.ptr(zeros), _native.ptr(zeros), n, B, _native.ptr(x_o),
+                _native.ptr(h_o), None, _native.ptr(ws), ws.numel(), _native.current_stream(device))
+            _native.check(rc, "cbgx_unitransformer_forward (static context)")
+            full = torch.zeros(n_nodes, self.hidden_dim, dtype=torch.float32, device=device)
+            full[rec_rows] = h_o
+            out.append(full)
+        return tuple(out)
+
+    def forward(self, x, h, batch_idx, lig_flag, gen_flag, graph_ptr=None, need_h=True, static_h=None):
         """Same contract as the reference (unitransformer.py:102-123): returns (x', h', logits).
         ``batch_idx`` must be sorted (compose_context guarantees it).  ``graph_ptr`` (int32 CSR
         offsets) may be passed to avoid recomputing it from ``batch_idx`` every call.  ``need_h=False`` (samplers that
         only read ``x'`` and the logits of ligand rows): ``h'`` is returned as None, logits are defined on
-        ``lig_flag`` rows only, and the library prunes the last layers to the nodes that can still reach them."""
+        ``lig_flag`` rows only, and the library prunes the last layers to the nodes that can still reach them.
+        ``static_h`` (from ``static_context``): lets the library skip, in the first two layers, the protein rows that
+        cannot yet have seen a ligand atom (bit-identical results)."""
         if not x.is_cuda:
             raise RuntimeError("UniTransformer.forward runs on an MI355X through libcbgx; got a CPU tensor "
                                "(no CPU fallback exists; use oracle/ for CPU reference results)")
@@ -266,10 +298,17 @@ class UniTransformer(nn.Module):
         h_out = torch.empty_like(h) if need_h else None
         logits = torch.empty(N, self.out_classes, dtype=torch.float32, device=device)
         lib = _native.lib()
-        rc = lib.cbgx_unitransformer_forward(
-            _native.ptr(packed), self.num_layers, self.out_classes, _native.ptr(x), _native.ptr(h),
-            _native.ptr(graph_ptr), _native.ptr(lig), _native.ptr(gen), N, B,
-            _native.ptr(x_out), _native.ptr(h_out), _native.ptr(logits),
-            _native.ptr(ws), ws.numel(), _native.current_stream(device))
+        if static_h is not None:
+            rc = lib.cbgx_unitransformer_forward_cached(
+                _native.ptr(packed), self.num_layers, self.out_classes, _native.ptr(x), _native.ptr(h),
+                _native.ptr(graph_ptr), _native.ptr(lig), _native.ptr(gen), N, B, _native.ptr(static_h[0]),
+                _native.ptr(static_h[1]), _native.ptr(x_out), _native.ptr(h_out), _native.ptr(logits),
+                _native.ptr(ws), ws.numel(), _native.current_stream(device))
+        else:
+            rc = lib.cbgx_unitransformer_forward(
+                _native.ptr(packed), self.num_layers, self.out_classes, _native.ptr(x), _native.ptr(h),
+                _native.ptr(graph_ptr), _native.ptr(lig), _native.ptr(gen), N, B,
+                _native.ptr(x_out), _native.ptr(h_out), _native.ptr(logits),
+                _native.ptr(ws), ws.numel(), _native.current_stream(device))
         _native.check(rc, "cbgx_unitransformer_forward")
         return x_out, h_out, logits

@@ -76,6 +76,21 @@ int cbgx_unitransformer_forward(const float *packed, int num_layers, int num_cla
                                 float *x_out, float *h_out, float *logits,
                                 void *workspace, size_t workspace_bytes, void *stream);
 
+/* Same call with a *static-context cache* for samplers, where the protein half of (x, h) is identical in every one of
+ * the T denoiser calls of a run (protein atoms never move, unitransformer.py:182; no time embedding in the shipped
+ * configs).  static_h1 / static_h2 [N,128]: the features leaving layer 0 / layer 1 when the same call is made on the
+ * ligand-free pockets (rows of ligand atoms are ignored) -- obtain them with two cbgx_unitransformer_forward calls of
+ * num_layers = 1 and 2 on the protein rows alone and scatter to the composed row order.  A protein node whose 32
+ * neighbours contain no ligand atom sees exactly the ligand-free pocket in layer 0 (and, one hop further, in layer 1),
+ * so those rows are copied from the cache and the first two x2h blocks run only on the rows that differ.  Results are
+ * bit-identical to cbgx_unitransformer_forward.  Requires num_layers >= 4 (otherwise the cache is ignored). */
+int cbgx_unitransformer_forward_cached(const float *packed, int num_layers, int num_classes,
+                                       const float *x, const float *h, const int32_t *graph_ptr,
+                                       const uint8_t *lig_flag, const uint8_t *gen_flag, int n_nodes, int n_graphs,
+                                       const float *static_h1, const float *static_h2,
+                                       float *x_out, float *h_out, float *logits,
+                                       void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- stages (also what the parity tests call one by one) ------------------------------------- */
 
 /* torch_cluster.knn_graph(x, k, batch, loop=False, flow='source_to_target') as called at

@@ -363,3 +363,26 @@ def test_sampling_driver_end_to_end(tmp_path):
     for s in rec["samples"]:
         assert s["pos"].shape[1] == 3 and torch.isfinite(s["pos"]).all()
         assert s["atom_type"].min() >= 0 and s["atom_type"].max() < 13
+
+
+def test_static_context_cache_is_exact(model):
+    """the ligand-free cache of the first two layers (cbgx_unitransformer_forward_cached) must not change a single bit of
+    a sampling step, on real-size pockets where most protein atoms are far from the ligand"""
+    batch = synthetic.batch_to(synthetic.denovo_batch(5, seed=77), DEV)
+    n_lig = batch["ligand_pos"].shape[0]
+    g = torch.Generator(device=DEV).manual_seed(3)
+    noise = [(torch.randn(n_lig, 3, device=DEV, generator=g), torch.rand(n_lig, 13, device=DEV, generator=g)) for _ in range(3)]
+    outs = []
+    for cache in (True, False):
+        st = model.begin_sampling(batch, keep_trajectory=False, static_cache=cache)
+        assert (st["static_h"] is not None) == cache
+        for k, t in enumerate((999, 998, 400)):
+            model.denoise_step(st, t, noise=noise[k])
+        outs.append((st["x_lig"].clone(), st["c_lig"].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # and the cache really prunes: count the rows that differ from the ligand-free pocket after one / two hops
+    st = model.begin_sampling(batch, keep_trajectory=False)
+    nbr, deg = stages.knn_graph(st["x"], st["graph_ptr"])
+    lig = st["lig_flag"]
+    has_lig_nbr = (lig[nbr.clamp(min=0).long()] & (nbr >= 0)).any(1) | lig
+    assert 0.02 < float(has_lig_nbr.float().mean()) < 0.6
