@@ -328,7 +328,9 @@ int cbgx_classifier(const float* packed, int num_layers, int num_classes, const 
 static int forward_impl(const float* packed, int num_layers, int num_classes, const float* x, const float* h,
                         const int32_t* graph_ptr, const uint8_t* lig_flag, const uint8_t* gen_flag, int n_nodes,
                         int n_graphs, float* x_out, float* h_out, float* logits, const float* static_h1,
-                        const float* static_h2, void* workspace, size_t workspace_bytes, void* stream) {
+                        const float* static_h2, const int32_t* static_nbr, const int32_t* static_deg,
+                        const float* static_ew, const float* static_r32sq, void* workspace, size_t workspace_bytes,
+                        void* stream) {
     if (n_nodes < 0 || n_graphs < 0 || num_layers < 1) return fail(CBGX_E_INVALID, "forward: bad sizes");
     if (n_nodes == 0) return CBGX_OK;
     if (!packed || !x || !h || !graph_ptr || !lig_flag || !gen_flag || !x_out || !workspace)
@@ -338,8 +340,22 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
     if (workspace_bytes < w.total)
         return fail(CBGX_E_WORKSPACE, "forward: workspace %zu < %zu", workspace_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s));
-    HIP_TRY(launch_gate(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s));
+    const bool cached = static_h1 && static_h2 && num_layers >= 4;
+    // with the graph part of the cache, only the nodes that have a ligand atom within reach get a fresh neighbour list
+    // and gate: everything else about the pocket's own graph was computed once (same order, same bits)
+    const bool graph_cached = cached && static_nbr && static_deg && static_ew && static_r32sq && g_edge_impl == 0;
+    if (graph_cached) {
+        HIP_TRY(launch_lig_proximity(x, graph_ptr, n_graphs, lig_flag, static_r32sq, n_nodes, w.fmask[0], s));   // D1
+        HIP_TRY(launch_build_active(w.fmask[0], n_nodes, w.fw_list[0], w.fw_count, s));
+        HIP_TRY(hipMemcpyAsync(w.nbr, static_nbr, (size_t)n_nodes * KNN * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(w.deg, static_deg, (size_t)n_nodes * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(w.e_w, static_ew, (size_t)n_nodes * KNN * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(launch_knn_reg(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s, w.fw_list[0], w.fw_count));
+        HIP_TRY(launch_gate_mfma(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s, w.fw_list[0], w.fw_count));
+    } else {
+        HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s));
+        HIP_TRY(launch_gate(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s));
+    }
     // H2X only ever moves gen_flag nodes (x_out = x + dx * gen_flag): list them once, run every h2x block on the list
     HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, s));
     // Receptive-field pruning (only when the caller does not ask for h_out): the outputs that remain are x_out and the
@@ -364,10 +380,11 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
     // exactly that pocket in layer 0, so its output is the cached row; the set that differs grows by one hop per layer:
     //   D1 = lig | {i : nbr(i) has a ligand atom},   D2 = D1 | {i : nbr(i) meets D1};   sources S_k = D_k | nbr(D_k).
     // Layers 0 and 1 then run on D1 / D2 only, every other row of their output is a copy of the cache.
-    const bool cached = static_h1 && static_h2 && num_layers >= 4;
     if (cached) {
-        HIP_TRY(launch_mark_from_nbr(lig_flag, w.nbr, w.deg, n_nodes, w.fmask[0], s));                       // D1
-        HIP_TRY(launch_build_active(w.fmask[0], n_nodes, w.fw_list[0], w.fw_count, s));
+        if (!graph_cached) {
+            HIP_TRY(launch_mark_from_nbr(lig_flag, w.nbr, w.deg, n_nodes, w.fmask[0], s));                   // D1
+            HIP_TRY(launch_build_active(w.fmask[0], n_nodes, w.fw_list[0], w.fw_count, s));
+        }
         HIP_TRY(launch_mark_from_nbr(w.fmask[0], w.nbr, w.deg, n_nodes, w.fmask[1], s));                    // D2
         HIP_TRY(launch_build_active(w.fmask[1], n_nodes, w.fw_list[2], w.fw_count + 32, s));
         HIP_TRY(launch_mark_nbr(w.fw_list[0], w.fw_count, n_nodes, w.nbr, w.deg, w.fmask[0], s));           // S1
@@ -416,17 +433,20 @@ int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_cla
                                 int n_nodes, int n_graphs, float* x_out, float* h_out, float* logits, void* workspace,
                                 size_t workspace_bytes, void* stream) {
     return forward_impl(packed, num_layers, num_classes, x, h, graph_ptr, lig_flag, gen_flag, n_nodes, n_graphs, x_out,
-                        h_out, logits, nullptr, nullptr, workspace, workspace_bytes, stream);
+                        h_out, logits, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes,
+                        stream);
 }
 
 int cbgx_unitransformer_forward_cached(const float* packed, int num_layers, int num_classes, const float* x,
                                        const float* h, const int32_t* graph_ptr, const uint8_t* lig_flag,
                                        const uint8_t* gen_flag, int n_nodes, int n_graphs, const float* static_h1,
-                                       const float* static_h2, float* x_out, float* h_out, float* logits,
-                                       void* workspace, size_t workspace_bytes, void* stream) {
+                                       const float* static_h2, const int32_t* static_nbr, const int32_t* static_deg,
+                                       const float* static_ew, const float* static_r32sq, float* x_out, float* h_out,
+                                       float* logits, void* workspace, size_t workspace_bytes, void* stream) {
     if (!static_h1 || !static_h2) return fail(CBGX_E_INVALID, "forward_cached: NULL static context");
     return forward_impl(packed, num_layers, num_classes, x, h, graph_ptr, lig_flag, gen_flag, n_nodes, n_graphs, x_out,
-                        h_out, logits, static_h1, static_h2, workspace, workspace_bytes, stream);
+                        h_out, logits, static_h1, static_h2, static_nbr, static_deg, static_ew, static_r32sq, workspace,
+                        workspace_bytes, stream);
 }
 
 int cbgx_targetdiff_prologue(const float* x_lig, const float* c_lig, const int32_t* lig_rows, int n_lig, int num_classes,

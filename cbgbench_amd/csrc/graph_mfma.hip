@@ -72,10 +72,12 @@ constexpr int KNN_SLOTS = 12;
 __global__ __launch_bounds__(256) void knn_graph_reg_kernel(const float* __restrict__ x,
                                                             const int32_t* __restrict__ graph_ptr, int n_graphs,
                                                             int n_nodes, int32_t* __restrict__ nbr,
-                                                            int32_t* __restrict__ deg) {
+                                                            int32_t* __restrict__ deg, const int* __restrict__ rows,
+                                                            const int* __restrict__ n_rows_ptr) {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n_nodes) return;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= (rows ? *n_rows_ptr : n_nodes)) return;
+    const int i = rows ? rows[idx] : idx;      // optional centre list (static-context cache: only the nodes near a ligand)
     int lo_g = 0, hi_g = n_graphs;
     while (hi_g - lo_g > 1) {
         const int mid = (lo_g + hi_g) >> 1;
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(256) void edge_gate_mfma_kernel(const float* __rest
                                                              const float* __restrict__ x,
                                                              const int32_t* __restrict__ nbr,
                                                              const int32_t* __restrict__ deg, int n_nodes,
-                                                             float* __restrict__ e_w) {
+                                                             float* __restrict__ e_w, const int* __restrict__ rows,
+                                                             const int* __restrict__ n_rows_ptr) {
     __shared__ __attribute__((aligned(16))) float lds[GATE_IMG_SIZE];
     for (int t = threadIdx.x; t < (int)GATE_IMG_SIZE / 4; t += 256)
         reinterpret_cast<float4*>(lds)[t] = reinterpret_cast<const float4*>(wts + GATE_IMG)[t];
@@ -158,7 +161,9 @@ __global__ __launch_bounds__(256) void edge_gate_mfma_kernel(const float* __rest
     float mu[5];
 #pragma unroll
     for (int s = 0; s < 5; ++s) mu[s] = c_mu2[4 * s + q];
-    for (int i = blockIdx.x * 4 + wave; i < n_nodes; i += gridDim.x * 4) {
+    const int count = rows ? *n_rows_ptr : n_nodes;
+    for (int idx = blockIdx.x * 4 + wave; idx < count; idx += gridDim.x * 4) {
+        const int i = rows ? rows[idx] : idx;
         const int d = deg[i];
         const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
 #pragma unroll
@@ -235,23 +240,54 @@ hipError_t launch_pack_gate_img(const float* w1, const float* b1, const float* g
     return hipGetLastError();
 }
 
+// dirty[i] = 1 for ligand atoms and for protein atoms that have a ligand atom among their 32 nearest neighbours:
+// the nearest ligand atom of the graph (ligand rows close every graph, common.py:200) is closer than the cached distance
+// to the 32nd protein neighbour.  Ties go to the protein atom (smaller index), hence the strict comparison.
+__global__ void lig_proximity_kernel(const float* __restrict__ x, const int32_t* __restrict__ graph_ptr, int n_graphs,
+                                     const uint8_t* __restrict__ lig, const float* __restrict__ r32sq, int n_nodes,
+                                     uint8_t* __restrict__ dirty) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    if (lig[i]) { dirty[i] = 1; return; }
+    int lo_g = 0, hi_g = n_graphs;
+    while (hi_g - lo_g > 1) {
+        const int mid = (lo_g + hi_g) >> 1;
+        if (graph_ptr[mid] <= i) lo_g = mid; else hi_g = mid;
+    }
+    const int gs = graph_ptr[lo_g], ge = graph_ptr[lo_g + 1];
+    const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
+    const float lim = r32sq[i];
+    bool near = false;
+    for (int j = ge - 1; j >= gs && lig[j]; --j)
+        near |= dist2_exact2(xi, yi, zi, x[3 * j], x[3 * j + 1], x[3 * j + 2]) < lim;
+    dirty[i] = near ? 1 : 0;
+}
+
+hipError_t launch_lig_proximity(const float* x, const int32_t* graph_ptr, int n_graphs, const uint8_t* lig,
+                                const float* r32sq, int n_nodes, uint8_t* dirty, hipStream_t s) {
+    if (n_nodes == 0) return hipSuccess;
+    hipLaunchKernelGGL(lig_proximity_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, x, graph_ptr, n_graphs, lig,
+                       r32sq, n_nodes, dirty);
+    return hipGetLastError();
+}
+
 hipError_t launch_knn_reg(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, int32_t* nbr,
-                          int32_t* deg, hipStream_t s) {
+                          int32_t* deg, hipStream_t s, const int* rows, const int* n_rows) {
     if (n_nodes == 0) return hipSuccess;
     profile_mark_begin(K_KNN, s);
     hipLaunchKernelGGL(knn_graph_reg_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, x, graph_ptr, n_graphs, n_nodes,
-                       nbr, deg);
+                       nbr, deg, rows, n_rows);
     profile_mark_end(s);
     return hipGetLastError();
 }
 
 hipError_t launch_gate_mfma(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
-                            float* e_w, hipStream_t s) {
+                            float* e_w, hipStream_t s, const int* rows, const int* n_rows) {
     if (n_nodes == 0) return hipSuccess;
     int grid = (n_nodes + 3) / 4;
     if (grid > 2048) grid = 2048;
     profile_mark_begin(K_GATE, s);
-    hipLaunchKernelGGL(edge_gate_mfma_kernel, dim3(grid), dim3(256), 0, s, packed, x, nbr, deg, n_nodes, e_w);
+    hipLaunchKernelGGL(edge_gate_mfma_kernel, dim3(grid), dim3(256), 0, s, packed, x, nbr, deg, n_nodes, e_w, rows, n_rows);
     profile_mark_end(s);
     return hipGetLastError();
 }

@@ -35,9 +35,11 @@ hipError_t launch_pack_wbv_swz(const float* w, float* dst, hipStream_t s);
 hipError_t launch_pack_gate_img(const float* w1, const float* b1, const float* g, const float* be, const float* w2,
                                 float* img, hipStream_t s);
 hipError_t launch_knn_reg(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, int32_t* nbr,
-                          int32_t* deg, hipStream_t s);
+                          int32_t* deg, hipStream_t s, const int* rows = nullptr, const int* n_rows = nullptr);
 hipError_t launch_gate_mfma(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
-                            float* e_w, hipStream_t s);
+                            float* e_w, hipStream_t s, const int* rows = nullptr, const int* n_rows = nullptr);
+hipError_t launch_lig_proximity(const float* x, const int32_t* graph_ptr, int n_graphs, const uint8_t* lig,
+                                const float* r32sq, int n_nodes, uint8_t* dirty, hipStream_t s);
 // MFMA node kernels (node_mfma.hip): P = h Wn + bn, q = MLP tail, Qt = folded query
 hipError_t launch_pack_node_frags(const float* wk0, const float* wv0, const float* wq0, const float* wq1,
                                   const float* wbk, float* att, hipStream_t s);

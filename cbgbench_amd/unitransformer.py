@@ -265,7 +265,25 @@ class UniTransformer(nn.Module):
             full = torch.zeros(n_nodes, self.hidden_dim, dtype=torch.float32, device=device)
             full[rec_rows] = h_o
             out.append(full)
-        return tuple(out)
+        # graph part: the pockets' own neighbour lists (renumbered to composed rows), gate values and the squared distance
+        # to the last neighbour, computed exactly like the kNN kernel does (((dx*dx)+(dy*dy))+(dz*dz), no contraction)
+        from . import stages
+        nbr_r, deg_r = stages.knn_graph(x_rec, graph_ptr_rec)
+        ew_r = stages.edge_gate(packed, x_rec, nbr_r, deg_r)
+        last = x_rec[nbr_r[:, 31].clamp(min=0).long()]
+        dx, dy, dz = (x_rec[:, 0] - last[:, 0]), (x_rec[:, 1] - last[:, 1]), (x_rec[:, 2] - last[:, 2])
+        r32 = (dx * dx + dy * dy) + dz * dz
+        r32 = torch.where(deg_r >= 32, r32, torch.full_like(r32, float("inf")))
+        rows32 = rec_rows.to(torch.int32)
+        nbr = torch.full((n_nodes, 32), -1, dtype=torch.int32, device=device)
+        nbr[rec_rows] = torch.where(nbr_r >= 0, rows32[nbr_r.clamp(min=0).long()], nbr_r)
+        deg = torch.zeros(n_nodes, dtype=torch.int32, device=device)
+        deg[rec_rows] = deg_r
+        ew = torch.zeros(n_nodes, 32, dtype=torch.float32, device=device)
+        ew[rec_rows] = ew_r
+        r32sq = torch.full((n_nodes,), float("inf"), dtype=torch.float32, device=device)
+        r32sq[rec_rows] = r32
+        return (out[0], out[1], nbr.contiguous(), deg, ew, r32sq)
 
     def forward(self, x, h, batch_idx, lig_flag, gen_flag, graph_ptr=None, need_h=True, static_h=None):
         """Same contract as the reference (unitransformer.py:102-123): returns (x', h', logits).
@@ -302,8 +320,8 @@ class UniTransformer(nn.Module):
             rc = lib.cbgx_unitransformer_forward_cached(
                 _native.ptr(packed), self.num_layers, self.out_classes, _native.ptr(x), _native.ptr(h),
                 _native.ptr(graph_ptr), _native.ptr(lig), _native.ptr(gen), N, B, _native.ptr(static_h[0]),
-                _native.ptr(static_h[1]), _native.ptr(x_out), _native.ptr(h_out), _native.ptr(logits),
-                _native.ptr(ws), ws.numel(), _native.current_stream(device))
+                _native.ptr(static_h[1]), *[_native.ptr(t) for t in static_h[2:6]], _native.ptr(x_out),
+                _native.ptr(h_out), _native.ptr(logits), _native.ptr(ws), ws.numel(), _native.current_stream(device))
         else:
             rc = lib.cbgx_unitransformer_forward(
                 _native.ptr(packed), self.num_layers, self.out_classes, _native.ptr(x), _native.ptr(h),

@@ -82,12 +82,18 @@ int cbgx_unitransformer_forward(const float *packed, int num_layers, int num_cla
  * ligand-free pockets (rows of ligand atoms are ignored) -- obtain them with two cbgx_unitransformer_forward calls of
  * num_layers = 1 and 2 on the protein rows alone and scatter to the composed row order.  A protein node whose 32
  * neighbours contain no ligand atom sees exactly the ligand-free pocket in layer 0 (and, one hop further, in layer 1),
- * so those rows are copied from the cache and the first two x2h blocks run only on the rows that differ.  Results are
- * bit-identical to cbgx_unitransformer_forward.  Requires num_layers >= 4 (otherwise the cache is ignored). */
+ * so those rows are copied from the cache and the first two x2h blocks run only on the rows that differ.
+ * Optional graph part (all four or none; NULL = recompute): static_nbr [N,32] / static_deg [N] / static_ew [N,32] = the
+ * ligand-free pockets' cbgx_knn_graph lists (in composed row numbers) and cbgx_edge_gate values, static_r32sq [N] = squared
+ * distance to the last (32nd) of those neighbours, +inf where deg < 32.  A protein node whose nearest ligand atom is not
+ * closer than that keeps its cached list and gate; only the others get fresh ones.
+ * Results are bit-identical to cbgx_unitransformer_forward.  Requires num_layers >= 4 (otherwise the cache is ignored). */
 int cbgx_unitransformer_forward_cached(const float *packed, int num_layers, int num_classes,
                                        const float *x, const float *h, const int32_t *graph_ptr,
                                        const uint8_t *lig_flag, const uint8_t *gen_flag, int n_nodes, int n_graphs,
                                        const float *static_h1, const float *static_h2,
+                                       const int32_t *static_nbr, const int32_t *static_deg,
+                                       const float *static_ew, const float *static_r32sq,
                                        float *x_out, float *h_out, float *logits,
                                        void *workspace, size_t workspace_bytes, void *stream);
 
