@@ -1,6 +1,7 @@
 // libcbgx -- second-generation backward of one attention block: same algorithm and LDS staging as
 // edge_backward_kernel (train_bwd.hip), with the six inner products that carry ~98 % of its FLOPs issued as
-// v_mfma_f32_16x16x4_f32 tiles fed from LDS (one workgroup = 4 waves = one destination node at a time):
+// v_mfma_f32_16x16x4_f32 tiles fed from LDS.  One workgroup = 8 waves (two per SIMD, so one wave's LDS / memory waits
+// overlap the other's matrix work) = one destination node at a time; wave w owns the 32 k|v columns [32 w, 32 w + 32).
 //   1  pre-activations      [32 e x 20 g] x [20 g x 256 c]    per source class present  (B = rbf columns, from L2)
 //   4  scores / values      [32 e x 128 m] x [128 m x 16 a]   (k path: Qt, v path: Gt or the h2x value matrix)
 //   6  folds T / S          [16 a x 32 e] x [32 e x 128 m]
@@ -8,7 +9,8 @@
 //   9  d(rbf columns)       [20 g x 32 e] x [32 e x 256 c]    accumulated in registers across the nodes of a workgroup
 //   10 d(rbf)               [32 e x 256 c] x [256 c x 20 g]
 // LayerNorm statistics, softmax, the dpre pass (atomics to the neighbours' projection rows) and the final coordinate
-// scatter stay on the vector ALU: they are O(32 x 256) per node.
+// scatter stay on the vector ALU: they are O(32 x 256) per node.  Operands of every MFMA block are loaded into
+// registers first (explicit scheduling fences): the compiler otherwise serialises load -> wait -> 2 MFMAs.
 // MFMA 16x16x4 fp32 operand layout (lane l: i = l & 15, kq = l >> 4): A[i][kq], B[kq][i], D regs r: D[4 kq + r][i].
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,41 +24,43 @@ namespace cbgx {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 __constant__ float c_mu_m[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.75f, 3.f,
                                 3.5f, 4.f, 4.5f, 5.f, 5.5f, 6.f, 7.f, 8.f, 9.f, 10.f};
 
 constexpr int EPM = H + 4;   // pitch of the [32][128] arrays
 constexpr int HP2 = 20;      // pitch of the [32][16] arrays (conflict-free when a lane group walks rows)
+constexpr int BWD_THREADS = 512;
 
 struct EdgeBwdMfmaLds {
-    float N[2][KNN][EPM];
-    float U[2][KNN][EPM];
+    float N[2][KNN][EPM];      // pre-activation -> normalised -> dpre        (path 0 = k, 1 = v)
+    float U[2][KNN][EPM];      // hidden (post ReLU) -> d(normalised)
     float QG[2][HEADS][EPM];   // [0] folded query; [1] x2h: folded output gradient, h2x: second v Linear [16][128]
     float rbf[KNN][G];
+    float rbfc[2][KNN][33];    // rbf masked by source class (0 outside the class, in padded slots and for g >= 20)
     float rel[KNN][4];
     float ew[KNN];
-    float sc[KNN][HP2];
-    float gv[KNN][HP2];
+    float scp[2][2][KNN][HP2]; // [scores | values][half of the m range][edge][head]: partial sums of step 4
+    float sc[KNN][HP2];        // alpha
+    float gv[KNN][HP2];        // x2h: G_i,a . vraw_e,a ; h2x: raw per-head value
     float cf[2][KNN][HP2];     // [0] ds (score gradient); [1] x2h: alpha e_w, h2x: d(raw value)
     float stat[2][KNN][2];
     float stat2[2][KNN][2];
     float me[KNN];
-    float ddp[2][KNN];      // partial d(dist) of the two halves of the rbf index
+    float ddp[2][2][KNN];      // partial d(dist): [half of the column range][half of the rbf index][edge]
     float D[4];
     float bb[HEADS];
+    float fl[2 * H * 6];       // end-of-kernel fold of the per-thread accumulators of the two edge halves
     int nb[KNN];
-    int nbs[KNN];           // nb, with the node itself in padded slots (safe to gather from / add zeros to)
+    int nbs[KNN];              // nb, with the node itself in padded slots (safe to gather from / add zeros to)
     int ty[KNN];
-    int cls[KNN];           // 1 = ligand source, 0 = protein source, -1 = padded slot
-    float rbfc[2][KNN][33];  // rbf masked by source class (0 outside the class, in padded slots and for g >= 20)
-    // the transposed rbf columns of the dominant edge type (3: protein -> protein): B operand of step 10 from LDS
-    float wrt3[2 * H][G];    // [c][g]
+    int cls[KNN];              // 1 = ligand source, 0 = protein source, -1 = padded slot
+    float wrt3[2 * H][G];      // transposed rbf columns of the dominant edge type 3: B operand of step 10 from LDS
 };
-#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 template <bool X2H>
-__global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
+__global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
     const float* __restrict__ att, const float* __restrict__ x, const float* __restrict__ P,
     const float* __restrict__ Qt, const float* __restrict__ Gt, const float* __restrict__ gb,
     const float* __restrict__ gx_out, const int32_t* __restrict__ nbr, const int32_t* __restrict__ deg,
@@ -66,41 +70,41 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
     float* __restrict__ partial, int abl) {
     __shared__ EdgeBwdMfmaLds L;
     const int t = threadIdx.x;
-    const int p = t >> 7, m = t & 127, c = t;          // vector-ALU view: path, hidden channel, k|v column
-    const int w = t >> 6, l = t & 63, li = l & 15, kq = l >> 4;   // matrix view: wave, lane, tile index, k quarter
-    const int pw = w >> 1;                              // the path whose 64 channels [64 (w&1), +64) this wave owns
-    const int mbase = 64 * (w & 1);                     // first channel (within the path) of the wave's 4 column tiles
-    const int cbase = 64 * w;                           // same, as a k|v column
+    // vector-ALU view: column c of the k|v pair (path p, channel m), edges [16 eh, 16 eh + 16)
+    const int c = t & 255, eh = t >> 8, p = c >> 7, m = c & 127;
+    // matrix view: wave w owns columns [32 w, +32) = channels [mbase, +32) of path pw
+    const int w = t >> 6, l = t & 63, li = l & 15, kq = l >> 4;
+    const int pw = w >> 2, mbase = 32 * (w & 3), cbase = 32 * w;
     const float gamma = att[(p == 0 ? A_LNK_G : A_LNV_G) + m];
     const float beta = att[(p == 0 ? A_LNK_B : A_LNV_B) + m];
-    float gam4[4];
+    float gam2[2];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) gam4[ct] = att[(pw == 0 ? A_LNK_G : A_LNV_G) + mbase + 16 * ct + li];
+    for (int ct = 0; ct < 2; ++ct) gam2[ct] = att[(pw == 0 ? A_LNK_G : A_LNV_G) + mbase + 16 * ct + li];
 
     // d(rbf columns) of the dominant edge type 3 (protein -> protein) lives in registers across the nodes of the
     // workgroup: [g tile][column tile], rows g = 16 gt + 4 kq + r.  The other three types (an endpoint is a ligand atom,
     // ~10 % of the edges) are added to the workgroup's private slab in memory node by node.
-    floatx4 aWr3[2][4];
+    floatx4 aWr3[2][2];
 #pragma unroll
     for (int gt = 0; gt < 2; ++gt)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) aWr3[gt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < 2; ++ct) aWr3[gt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
     float* slab = partial + (size_t)blockIdx.x * PB_SIZE;
-    for (int u = t; u < 3 * G * 2 * H; u += 256) slab[PB_WR + u] = 0.f;     // types 0..2
+    for (int u = t; u < 3 * G * 2 * H; u += BWD_THREADS) slab[PB_WR + u] = 0.f;     // types 0..2
     float aWt[NT] = {0.f, 0.f, 0.f, 0.f};
-    float aG4[4] = {0.f, 0.f, 0.f, 0.f}, aB4[4] = {0.f, 0.f, 0.f, 0.f};
+    float aG2[2] = {0.f, 0.f}, aB2[2] = {0.f, 0.f};
     float aBb = 0.f;
-    floatx4 aV16[4];            // h2x: second v Linear gradient [16 heads][the wave's 64 channels]
+    floatx4 aV16[2];            // h2x: second v Linear gradient [16 heads][the wave's 32 channels]
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) aV16[ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < 2; ++ct) aV16[ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
-    for (int u = t; u < 2 * KNN * EPM; u += 256) { (&L.N[0][0][0])[u] = 0.f; (&L.U[0][0][0])[u] = 0.f; }
-    for (int u = t; u < 2 * KNN * HP2; u += 256) (&L.cf[0][0][0])[u] = 0.f;
+    for (int u = t; u < 2 * KNN * EPM; u += BWD_THREADS) { (&L.N[0][0][0])[u] = 0.f; (&L.U[0][0][0])[u] = 0.f; }
+    for (int u = t; u < 2 * KNN * HP2; u += BWD_THREADS) (&L.cf[0][0][0])[u] = 0.f;
     if (!X2H) {
-        for (int u = t; u < HEADS * H; u += 256) L.QG[1][u >> 7][u & 127] = att[A_WBV + u];
+        for (int u = t; u < HEADS * H; u += BWD_THREADS) L.QG[1][u >> 7][u & 127] = att[A_WBV + u];
     }
-    for (int u = t; u < G * 2 * H; u += 256) L.wrt3[u & 255][u >> 8] = att[A_WR + (size_t)3 * G * 2 * H + u];   // [g][c] -> [c][g]
-    for (int u = t; u < 2 * KNN * 33; u += 256) (&L.rbfc[0][0][0])[u] = 0.f;
+    for (int u = t; u < G * 2 * H; u += BWD_THREADS) L.wrt3[u & 255][u >> 8] = att[A_WR + (size_t)3 * G * 2 * H + u];
+    for (int u = t; u < 2 * KNN * 33; u += BWD_THREADS) (&L.rbfc[0][0][0])[u] = 0.f;
     const int count = rows ? *n_rows_ptr : n_nodes;
     for (int it = blockIdx.x; it < count; it += gridDim.x) {
         const int i = rows ? rows[it] : it;
@@ -137,61 +141,57 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
             }
             L.cls[t] = cl;
         }
-        for (int u = t; u < HEADS * H; u += 256) {
+        for (int u = t; u < HEADS * H; u += BWD_THREADS) {
             L.QG[0][u >> 7][u & 127] = Qt[(size_t)i * HEADS * H + u];
             if (X2H) L.QG[1][u >> 7][u & 127] = Gt[(size_t)i * HEADS * H + u];
         }
         if (!X2H && t < 3) L.D[t] = gx_out[3 * i + t];
         __syncthreads();
         // which source classes occur among the node's edges (uniform over the workgroup)
-        bool has_cls[2] = {false, false};
-        {
-            const unsigned long long bp = __ballot(l < KNN && L.cls[l & 31] == 0);
-            const unsigned long long bl = __ballot(l < KNN && L.cls[l & 31] == 1);
-            has_cls[0] = bp != 0ull;
-            has_cls[1] = bl != 0ull;
-        }
+        bool has_cls[2];
+        has_cls[0] = __ballot(l < KNN && L.cls[l & 31] == 0) != 0ull;
+        has_cls[1] = __ballot(l < KNN && L.cls[l & 31] == 1) != 0ull;
 
-        {   // 1. pre-activations: the wave's 64 columns x 32 edges
-            floatx4 acc[2][4];
+        {   // 1. pre-activations: the wave's 32 columns x 32 edges
+            floatx4 acc[2][2];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
+                for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int cl = 0; cl < 2; ++cl) {
                 if (!has_cls[cl]) continue;
                 const float* wr = att + A_WR + (size_t)(cl ? ty_lig : ty_prot) * G * 2 * H + cbase + li;
-                float a0[G / 4], a1[G / 4], bq[G / 4][4];
+                float a0[G / 4], a1[G / 4], bq[G / 4][2];
 #pragma unroll
                 for (int s = 0; s < G / 4; ++s) {
                     const int g = 4 * s + kq;
                     a0[s] = L.rbfc[cl][li][g];
                     a1[s] = L.rbfc[cl][16 + li][g];
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) bq[s][ct] = wr[(size_t)g * 2 * H + 16 * ct];
+                    for (int ct = 0; ct < 2; ++ct) bq[s][ct] = wr[(size_t)g * 2 * H + 16 * ct];
                 }
                 SCHED_FENCE();
 #pragma unroll
                 for (int s = 0; s < G / 4; ++s)
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
+                    for (int ct = 0; ct < 2; ++ct) {
                         acc[0][ct] = MFMA(a0[s], bq[s][ct], acc[0][ct]);
                         acc[1][ct] = MFMA(a1[s], bq[s][ct], acc[1][ct]);
                     }
                 SCHED_FENCE();
             }
-            // epilogue without data-dependent branches (so all 32 gathers are in flight together): padded slots gather
-            // the node's own row and are zeroed again in step 3
-            float pd[4], wtv[2][4];
+            // epilogue without data-dependent branches (so all gathers are in flight together): padded slots gather the
+            // node's own row and are zeroed again in step 3
+            float pd[2], wtv[2][2];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
+            for (int ct = 0; ct < 2; ++ct) {
                 const int cc = cbase + 16 * ct + li;
                 pd[ct] = P[(size_t)i * PROW + cc];
                 wtv[0][ct] = att[A_WT + ty_prot * 2 * H + cc];
                 wtv[1][ct] = att[A_WT + ty_lig * 2 * H + cc];
             }
-            float ps[2][4][4];
+            float ps[2][4][2];
             int clv[2][4];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
                     const int j = L.nbs[e];
                     clv[rt][r] = L.cls[e];
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
+                    for (int ct = 0; ct < 2; ++ct)
                         ps[rt][r][ct] = (abl & 2) ? 0.f : P[(size_t)j * PROW + 2 * H + cbase + 16 * ct + li];
                 }
 #pragma unroll
@@ -210,26 +210,33 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
                 for (int r = 0; r < 4; ++r) {
                     const int e = 16 * rt + 4 * kq + r;
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
+                    for (int ct = 0; ct < 2; ++ct)
                         L.N[pw][e][mbase + 16 * ct + li] =
                             acc[rt][ct][r] + pd[ct] + ps[rt][r][ct] + (clv[rt][r] == 1 ? wtv[1][ct] : wtv[0][ct]);
                 }
         }
         __syncthreads();
-        {   // 2. LayerNorm statistics: 4 threads per (path, edge)
-            const int pe = t >> 2, part = t & 3, pp = pe >> 5, e = pe & 31;
+        {   // 2. LayerNorm statistics: 8 threads per (path, edge)
+            const int pe = t >> 3, part = t & 7, pp = pe >> 5, e = pe & 31;
             float s = 0.f;
-            if (e < d) for (int u = 0; u < 32; ++u) s += L.N[pp][e][part + 4 * u];
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+            if (e < d) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s += L.N[pp][e][part + 8 * u];
+            }
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
             const float mean = s * (1.f / H);
             float q = 0.f;
-            if (e < d) for (int u = 0; u < 32; ++u) { const float a = L.N[pp][e][part + 4 * u] - mean; q += a * a; }
-            q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
+            if (e < d) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const float a = L.N[pp][e][part + 8 * u] - mean; q += a * a; }
+            }
+            q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
             if (part == 0) { L.stat[pp][e][0] = mean; L.stat[pp][e][1] = 1.f / sqrtf(q * (1.f / H) + 1e-5f); }
         }
         __syncthreads();
 #pragma unroll 8
-        for (int e = 0; e < KNN; ++e) {   // 3. normalise, affine, ReLU (padded slots: exact zeros, they enter the K sums below)
+        for (int k = 0; k < 16; ++k) {   // 3. normalise, affine, ReLU (padded slots: exact zeros, they enter the K sums below)
+            const int e = 16 * eh + k;
             float n = 0.f, u = 0.f;
             if (e < d) {
                 n = (L.N[p][e][m] - L.stat[p][e][0]) * L.stat[p][e][1];
@@ -239,81 +246,57 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
             L.U[p][e][m] = u;
         }
         __syncthreads();
-        {   // 4. scores (waves 0,1) and per-head values (waves 2,3): rows 16 (w&1) .. +16
-            const int rt = w & 1, which = w >> 1;
-            const float* ua = &L.U[which][16 * rt + li][kq];
-            const float* qb = &L.QG[which][li][kq];
+        {   // 4. scores (which = 0) and per-head values (which = 1): wave = (which, row tile, half of the m range)
+            const int rt = w & 1, which = (w >> 1) & 1, kh = w >> 2;
+            const float* ua = &L.U[which][16 * rt + li][64 * kh + kq];
+            const float* qb = &L.QG[which][li][64 * kh + kq];
             floatx4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
             float av[2][8], bv[2][8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) { av[0][k] = ua[4 * k]; bv[0][k] = qb[4 * k]; }
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch) {      // 4 chunks of 8 k-steps, operands of the next chunk loaded ahead
-                if (ch < 3) {
+            for (int k = 0; k < 8; ++k) { av[1][k] = ua[4 * (8 + k)]; bv[1][k] = qb[4 * (8 + k)]; }
+            SCHED_FENCE();
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        av[(ch + 1) & 1][k] = ua[4 * (8 * (ch + 1) + k)];
-                        bv[(ch + 1) & 1][k] = qb[4 * (8 * (ch + 1) + k)];
-                    }
-                }
-                SCHED_FENCE();
+            for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
                 for (int k = 0; k < 8; k += 2) {
-                    a0 = MFMA(av[ch & 1][k], bv[ch & 1][k], a0);
-                    a1 = MFMA(av[ch & 1][k + 1], bv[ch & 1][k + 1], a1);
+                    a0 = MFMA(av[ch][k], bv[ch][k], a0);
+                    a1 = MFMA(av[ch][k + 1], bv[ch][k + 1], a1);
                 }
-                SCHED_FENCE();
-            }
-            const float bias = which ? (X2H ? gb[(size_t)i * HEADS + li] : att[A_BBV + li]) : 0.f;
+            SCHED_FENCE();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int e = 16 * rt + 4 * kq + r;
-                const float v = a0[r] + a1[r] + bias;
-                if (which) L.gv[e][li] = v; else L.sc[e][li] = v;
-            }
+            for (int r = 0; r < 4; ++r) L.scp[which][kh][16 * rt + 4 * kq + r][li] = a0[r] + a1[r];
         }
         __syncthreads();
-        if (!(abl & 8)) {   // 5. softmax over the incoming edges and its backward: 16 lanes per head, 2 edges per lane
-            const int a = t >> 4, e2 = t & 15;
-            float sv[2], al[2], dal[2], rho[2];
+        if (!(abl & 8)) {   // 5. softmax over the incoming edges and its backward: thread = (head, edge), 32 lanes per head
+            const int a = t >> 5, e = t & 31;
+            const bool on = e < d;
+            const float sv = on ? L.scp[0][0][e][a] + L.scp[0][1][e][a] : -INFINITY;
+            const float gvv = L.scp[1][0][e][a] + L.scp[1][1][e][a] + (X2H ? gb[(size_t)i * HEADS + a] : att[A_BBV + a]);
+            const float rho = X2H ? 1.f : (L.D[0] * L.rel[e][0] + L.D[1] * L.rel[e][1] + L.D[2] * L.rel[e][2]);
+            const float ewe = L.ew[e];
+            float mx = sv;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int e = e2 + 16 * k;
-                sv[k] = e < d ? L.sc[e][a] : -INFINITY;
-                rho[k] = X2H ? 1.f : (L.D[0] * L.rel[e][0] + L.D[1] * L.rel[e][1] + L.D[2] * L.rel[e][2]);
-            }
-            float mx = fmaxf(sv[0], sv[1]);
+            for (int off = 16; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            const float ex = on ? expf(sv - mx) : 0.f;
+            float den = ex;
 #pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-            float ex0 = e2 < d ? expf(sv[0] - mx) : 0.f, ex1 = e2 + 16 < d ? expf(sv[1] - mx) : 0.f;
-            float den = ex0 + ex1;
+            for (int off = 16; off >= 1; off >>= 1) den += __shfl_xor(den, off, 64);
+            const float al = d > 0 ? ex / den : 0.f;
+            const float dal = X2H ? ewe * gvv : rho * gvv * ewe * (1.f / HEADS);
+            float cacc = al * dal;
 #pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) den += __shfl_xor(den, off, 64);
-            al[0] = d > 0 ? ex0 / den : 0.f;
-            al[1] = d > 0 ? ex1 / den : 0.f;
-            float cacc = 0.f;
+            for (int off = 16; off >= 1; off >>= 1) cacc += __shfl_xor(cacc, off, 64);
+            const float wv = X2H ? al * ewe : rho * al * (1.f / HEADS) * ewe;
+            L.sc[e][a] = al;
+            L.gv[e][a] = gvv;
+            L.cf[0][e][a] = on ? al * (dal - cacc) : 0.f;
+            L.cf[1][e][a] = on ? wv : 0.f;
+            float swacc = on ? wv : 0.f;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int e = e2 + 16 * k;
-                dal[k] = X2H ? L.ew[e] * L.gv[e][a] : rho[k] * L.gv[e][a] * L.ew[e] * (1.f / HEADS);
-                cacc = fmaf(al[k], dal[k], cacc);
-            }
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) cacc += __shfl_xor(cacc, off, 64);
-            float swacc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int e = e2 + 16 * k;
-                const bool on = e < d;
-                const float wv = X2H ? al[k] * L.ew[e] : rho[k] * al[k] * (1.f / HEADS) * L.ew[e];
-                L.sc[e][a] = al[k];
-                L.cf[0][e][a] = on ? al[k] * (dal[k] - cacc) : 0.f;
-                L.cf[1][e][a] = on ? wv : 0.f;
-                swacc += on ? wv : 0.f;
-            }
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) swacc += __shfl_xor(swacc, off, 64);
-            if (e2 == 0) { if (X2H) sw[(size_t)i * HEADS + a] = swacc; else L.bb[a] = swacc; }
+            for (int off = 16; off >= 1; off >>= 1) swacc += __shfl_xor(swacc, off, 64);
+            if (e == 0) { if (X2H) sw[(size_t)i * HEADS + a] = swacc; else L.bb[a] = swacc; }
         }
         __syncthreads();
         if (!X2H && t < HEADS) aBb += L.bb[t];
@@ -321,10 +304,12 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
             const int e = t;
             float de = 0.f, me = 0.f;
             if (X2H) {
+#pragma unroll
                 for (int a = 0; a < HEADS; ++a) de = fmaf(L.sc[e][a], L.gv[e][a], de);
             } else {
                 const float rho = L.D[0] * L.rel[e][0] + L.D[1] * L.rel[e][1] + L.D[2] * L.rel[e][2];
                 float av = 0.f;
+#pragma unroll
                 for (int a = 0; a < HEADS; ++a) av = fmaf(L.sc[e][a], L.gv[e][a], av);
                 de = rho * av * (1.f / HEADS);
                 me = av * L.ew[e] * (1.f / HEADS);
@@ -332,59 +317,56 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
             de_w[(size_t)i * KNN + e] += de;
             L.me[e] = me;
         }
-        {   // 6. folds over the edges, the wave's 64 channels: T (k path) / S or the h2x value-matrix gradient (v path)
-            floatx4 acc[4];
+        {   // 6. folds over the edges, the wave's 32 channels: T (k path) / S or the h2x value-matrix gradient (v path)
+            floatx4 acc[2];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = (!X2H && pw == 1) ? aV16[ct] : (floatx4){0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < 2; ++ct) acc[ct] = (!X2H && pw == 1) ? aV16[ct] : (floatx4){0.f, 0.f, 0.f, 0.f};
+            float av[8], bv[8][2];
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                float av[4], bv[4][4];
+            for (int s = 0; s < 8; ++s) {
+                const int e = 4 * s + kq;
+                av[s] = L.cf[pw][e][li];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int e = 4 * (4 * hf + s) + kq;
-                    av[s] = L.cf[pw][e][li];
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) bv[s][ct] = L.U[pw][e][mbase + 16 * ct + li];
-                }
-                SCHED_FENCE();
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA(av[s], bv[s][ct], acc[ct]);
-                SCHED_FENCE();
+                for (int ct = 0; ct < 2; ++ct) bv[s][ct] = L.U[pw][e][mbase + 16 * ct + li];
             }
+            SCHED_FENCE();
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[ct] = MFMA(av[s], bv[s][ct], acc[ct]);
+            SCHED_FENCE();
             if (!X2H && pw == 1) {
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) aV16[ct] = acc[ct];
+                for (int ct = 0; ct < 2; ++ct) aV16[ct] = acc[ct];
             } else if (!(abl & 16)) {
                 float* dst = (pw == 0 ? T : S) + (size_t)i * HEADS * H;
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
+                for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dst[(size_t)(4 * kq + r) * H + mbase + 16 * ct + li] = acc[ct][r];
             }
         }
-        {   // 7. d(hidden) -> d(normalised pre-activation), the wave's 64 channels x 32 edges
-            floatx4 acc[2][4];
+        {   // 7. d(hidden) -> d(normalised pre-activation), the wave's 32 channels x 32 edges
+            floatx4 acc[2][2];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
+                for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
             {
-                float a0[4], a1[4], bv[4][4];
+                float a0[4], a1[4], bv[4][2];
 #pragma unroll
                 for (int s = 0; s < HEADS / 4; ++s) {
                     const int a = 4 * s + kq;
                     a0[s] = L.cf[pw][li][a];
                     a1[s] = L.cf[pw][16 + li][a];
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) bv[s][ct] = L.QG[pw][a][mbase + 16 * ct + li];
+                    for (int ct = 0; ct < 2; ++ct) bv[s][ct] = L.QG[pw][a][mbase + 16 * ct + li];
                 }
                 SCHED_FENCE();
 #pragma unroll
                 for (int s = 0; s < HEADS / 4; ++s)
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
+                    for (int ct = 0; ct < 2; ++ct) {
                         acc[0][ct] = MFMA(a0[s], bv[s][ct], acc[0][ct]);
                         acc[1][ct] = MFMA(a1[s], bv[s][ct], acc[1][ct]);
                     }
@@ -396,39 +378,42 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
                 for (int r = 0; r < 4; ++r) {
                     const int e = 16 * rt + 4 * kq + r;
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
+                    for (int ct = 0; ct < 2; ++ct) {
                         const int mm = mbase + 16 * ct + li;
                         const float dy = L.U[pw][e][mm] > 0.f ? acc[rt][ct][r] : 0.f;
-                        aG4[ct] = fmaf(dy, L.N[pw][e][mm], aG4[ct]);
-                        aB4[ct] += dy;
-                        L.U[pw][e][mm] = dy * gam4[ct];
+                        aG2[ct] = fmaf(dy, L.N[pw][e][mm], aG2[ct]);
+                        aB2[ct] += dy;
+                        L.U[pw][e][mm] = dy * gam2[ct];
                     }
                 }
         }
         __syncthreads();
-        {   // 8. LayerNorm backward statistics
-            const int pe = t >> 2, part = t & 3, pp = pe >> 5, e = pe & 31;
+        {   // 8. LayerNorm backward statistics: 8 threads per (path, edge)
+            const int pe = t >> 3, part = t & 7, pp = pe >> 5, e = pe & 31;
             float s1 = 0.f, s2 = 0.f;
-            if (e < d) for (int u = 0; u < 32; ++u) {
-                const float dn = L.U[pp][e][part + 4 * u];
-                s1 += dn;
-                s2 = fmaf(dn, L.N[pp][e][part + 4 * u], s2);
+            if (e < d) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const float dn = L.U[pp][e][part + 8 * u];
+                    s1 += dn;
+                    s2 = fmaf(dn, L.N[pp][e][part + 8 * u], s2);
+                }
             }
-            s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
-            s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+            s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
+            s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64);
             if (part == 0) { L.stat2[pp][e][0] = s1 * (1.f / H); L.stat2[pp][e][1] = s2 * (1.f / H); }
         }
         __syncthreads();
-        {   // 9a. dpre; own projection row, neighbour rows (atomics), type columns of the first Linear
+        {   // 9a. dpre; own projection row, neighbour rows (atomics), type columns of the first Linear.
             // branch-free: padded slots carry exact zeros (N, U, stat2) and add 0 to the node's own row
             float accpd = 0.f;
 #pragma unroll
-            for (int e0 = 0; e0 < KNN; e0 += 8) {
+            for (int e0 = 0; e0 < 16; e0 += 8) {
                 float dpv[8];
                 int jv[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int e = e0 + k;
+                    const int e = 16 * eh + e0 + k;
                     const float n = L.N[p][e][m];
                     dpv[k] = L.stat[p][e][1] * (L.U[p][e][m] - L.stat2[p][e][0] - n * L.stat2[p][e][1]);
                     jv[k] = L.nbs[e];
@@ -441,26 +426,26 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    L.N[p][e0 + k][m] = dpv[k];
+                    L.N[p][16 * eh + e0 + k][m] = dpv[k];
                     if (!(abl & 1)) atomicAdd(&dP[(size_t)jv[k] * PROW + 2 * H + c], dpv[k]);
                 }
             }
-            dP[(size_t)i * PROW + c] = accpd;      // padded slots of N already hold zeros
+            atomicAdd(&dP[(size_t)i * PROW + c], accpd);      // two edge halves per column; dP is zeroed by the caller
         }
         __syncthreads();
         // 9b. rbf columns of the first Linear: dWr[type][g][c] += sum_e rbf[e][g] dpre[e][c], per source class present
 #define CBGX_ACC_WR(DST, CL)                                                                       \
         _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                         \
-            float a0[4], a1[4], bv[4][4];                                                          \
+            float a0[4], a1[4], bv[4][2];                                                          \
             _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                        \
                 const int e = 4 * (4 * hf + s) + kq;                                               \
                 a0[s] = L.rbfc[CL][e][li];                                                         \
                 a1[s] = L.rbfc[CL][e][16 + li];                                                    \
-                _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) bv[s][ct] = L.N[pw][e][mbase + 16 * ct + li]; \
+                _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) bv[s][ct] = L.N[pw][e][mbase + 16 * ct + li]; \
             }                                                                                      \
             SCHED_FENCE();                                                                         \
             _Pragma("unroll") for (int s = 0; s < 4; ++s)                                          \
-                _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) {                                 \
+                _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                 \
                     DST[0][ct] = MFMA(a0[s], bv[s][ct], DST[0][ct]);                               \
                     DST[1][ct] = MFMA(a1[s], bv[s][ct], DST[1][ct]);                               \
                 }                                                                                  \
@@ -473,11 +458,11 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
                 if (cl == 0 && !lig_i) {
                     CBGX_ACC_WR(aWr3, 0)
                 } else {
-                    floatx4 tmp[2][4];
+                    floatx4 tmp[2][2];
 #pragma unroll
                     for (int gt = 0; gt < 2; ++gt)
 #pragma unroll
-                        for (int ct = 0; ct < 4; ++ct) tmp[gt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
+                        for (int ct = 0; ct < 2; ++ct) tmp[gt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
                     if (cl == 0) { CBGX_ACC_WR(tmp, 0) } else { CBGX_ACC_WR(tmp, 1) }
                     const int tyc = cl ? ty_lig : ty_prot;
 #pragma unroll
@@ -487,37 +472,36 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
                             const int g = 16 * gt + 4 * kq + r;
                             if (g < G) {
 #pragma unroll
-                                for (int ct = 0; ct < 4; ++ct)
-                                    slab[PB_WR + (tyc * G + g) * 2 * H + cbase + 16 * ct + li] += tmp[gt][ct][r];
+                                for (int ct = 0; ct < 2; ++ct)
+                                    atomicAdd(&slab[PB_WR + (tyc * G + g) * 2 * H + cbase + 16 * ct + li], tmp[gt][ct][r]);   // no-return atomic: nothing to wait for
                             }
                         }
                 }
             }
         }
 #undef CBGX_ACC_WR
-        if (!(abl & 4)) {   // 10. through the radial basis: drbf[e][g] = sum_c dpre[e][c] Wr[type_e][g][c]; wave = (row tile, g tile)
-            // The product is formed for every source class present with unmasked inputs; each output row then takes the
-            // result of its own edge's class.  8 chunks of 8 k-steps per class, next chunk's operands loaded ahead.
-            const int rt = w & 1, gt = w >> 1, e_a = 16 * rt + li, gl = 16 * gt + li;
+        if (!(abl & 4)) {   // 10. through the radial basis: drbf[e][g] = sum_c dpre[e][c] Wr[type_e][g][c]
+            // wave = (row tile, g tile, half of the column range).  The product is formed for every source class present
+            // with unmasked inputs; each output row then takes the result of its own edge's class.
+            const int rt = w & 1, gt = (w >> 1) & 1, kh = w >> 2, e_a = 16 * rt + li, gl = 16 * gt + li;
             floatx4 dr[2][2];
 #pragma unroll
             for (int cl = 0; cl < 2; ++cl) { dr[cl][0] = (floatx4){0.f, 0.f, 0.f, 0.f}; dr[cl][1] = (floatx4){0.f, 0.f, 0.f, 0.f}; }
 #define CBGX_LOAD_CH(BUF, CH, BEXPR)                                                   \
     _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                    \
-        const int c4 = 4 * (8 * (CH) + k);                                             \
-        av[BUF][k] = L.N[c4 >> 7][e_a][(c4 & 127) + kq];                               \
+        const int c4 = 128 * kh + 4 * (8 * (CH) + k);                                  \
+        av[BUF][k] = L.N[kh][e_a][4 * (8 * (CH) + k) + kq];                            \
         bv[BUF][k] = BEXPR;                                                            \
     }
 #define CBGX_DRBF_CLASS(CL, BEXPR)                                                     \
     {                                                                                  \
-        float av[2][8], bv[2][8];                                                      \
-        CBGX_LOAD_CH(0, 0, BEXPR)                                                      \
-        _Pragma("unroll") for (int ch = 0; ch < 8; ++ch) {                             \
-            if (ch < 7) { CBGX_LOAD_CH((ch + 1) & 1, ch + 1, BEXPR) }                  \
+        _Pragma("unroll 1") for (int ch = 0; ch < 4; ++ch) {                           \
+            float av[1][8], bv[1][8];                                                  \
+            CBGX_LOAD_CH(0, ch, BEXPR)                                                 \
             SCHED_FENCE();                                                             \
             _Pragma("unroll") for (int k = 0; k < 8; k += 2) {                         \
-                dr[CL][0] = MFMA(av[ch & 1][k], bv[ch & 1][k], dr[CL][0]);             \
-                dr[CL][1] = MFMA(av[ch & 1][k + 1], bv[ch & 1][k + 1], dr[CL][1]);     \
+                dr[CL][0] = MFMA(av[0][k], bv[0][k], dr[CL][0]);                       \
+                dr[CL][1] = MFMA(av[0][k + 1], bv[0][k + 1], dr[CL][1]);               \
             }                                                                          \
             SCHED_FENCE();                                                             \
         }                                                                              \
@@ -546,14 +530,14 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
                     v = dsum * (-(L.rel[e][3] - c_mu_m[gl]) * L.rbf[e][gl]);
                 }
                 v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                if (li == 0) L.ddp[gt][e] = v;
+                if (li == 0) L.ddp[kh][gt][e] = v;
             }
         }
         __syncthreads();
         if (t < KNN && t < d) {
             const int e = t;
             const float dist = L.rel[e][3];
-            const float dd = L.ddp[0][e] + L.ddp[1][e];
+            const float dd = (L.ddp[0][0][e] + L.ddp[0][1][e]) + (L.ddp[1][0][e] + L.ddp[1][1][e]);
             const float cf = dist > 0.f ? dd / dist : 0.f;
             const int j = L.nb[e];
 #pragma unroll
@@ -566,8 +550,16 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
         }
     }
     // per-workgroup partial sums of the edge-indexed weight gradients
+    __syncthreads();
+    if (eh == 1) {
 #pragma unroll
-    for (int a = 0; a < NT; ++a) slab[PB_WT + a * 2 * H + c] = aWt[a];
+        for (int a = 0; a < NT; ++a) L.fl[a * 2 * H + c] = aWt[a];
+    }
+    __syncthreads();
+    if (eh == 0) {
+#pragma unroll
+        for (int a = 0; a < NT; ++a) slab[PB_WT + a * 2 * H + c] = aWt[a] + L.fl[a * 2 * H + c];
+    }
 #pragma unroll
     for (int gt = 0; gt < 2; ++gt)
 #pragma unroll
@@ -575,12 +567,12 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
             const int g = 16 * gt + 4 * kq + r;
             if (g < G) {
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) slab[PB_WR + (3 * G + g) * 2 * H + cbase + 16 * ct + li] = aWr3[gt][ct][r];
+                for (int ct = 0; ct < 2; ++ct) slab[PB_WR + (3 * G + g) * 2 * H + cbase + 16 * ct + li] = aWr3[gt][ct][r];
             }
         }
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {   // the 4 k-quarters of a column hold partial sums: fold them, lanes 0..15 store
-        float g4 = aG4[ct], b4 = aB4[ct];
+    for (int ct = 0; ct < 2; ++ct) {   // the 4 k-quarters of a column hold partial sums: fold them, lanes 0..15 store
+        float g4 = aG2[ct], b4 = aB2[ct];
         g4 += __shfl_xor(g4, 16, 64); g4 += __shfl_xor(g4, 32, 64);
         b4 += __shfl_xor(b4, 16, 64); b4 += __shfl_xor(b4, 32, 64);
         if (kq == 0) { slab[PB_LNG + cbase + 16 * ct + li] = g4; slab[PB_LNB + cbase + 16 * ct + li] = b4; }
@@ -588,7 +580,7 @@ __global__ __launch_bounds__(256) void edge_backward_mfma_kernel(
     if (!X2H) {
         if (pw == 1) {
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) slab[PB_WBV16 + (4 * kq + r) * H + mbase + 16 * ct + li] = aV16[ct][r];
         }
@@ -610,11 +602,11 @@ hipError_t launch_edge_backward_mfma(bool x2h, const float* att, const float* x,
     static const int abl = getenv("CBGX_BWD_ABL") ? atoi(getenv("CBGX_BWD_ABL")) : 0;   // timing ablations (wrong results)
     profile_mark_begin(x2h ? K_EDGE_X2H_BWD : K_EDGE_H2X_BWD, s);
     if (x2h)
-        hipLaunchKernelGGL(edge_backward_mfma_kernel<true>, dim3(grid), dim3(256), 0, s, att, x, P, Qt, Gt, gb, gx_out,
-                           nbr, deg, lig, e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl);
+        hipLaunchKernelGGL(edge_backward_mfma_kernel<true>, dim3(grid), dim3(BWD_THREADS), 0, s, att, x, P, Qt, Gt, gb,
+                           gx_out, nbr, deg, lig, e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl);
     else
-        hipLaunchKernelGGL(edge_backward_mfma_kernel<false>, dim3(grid), dim3(256), 0, s, att, x, P, Qt, Gt, gb, gx_out,
-                           nbr, deg, lig, e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl);
+        hipLaunchKernelGGL(edge_backward_mfma_kernel<false>, dim3(grid), dim3(BWD_THREADS), 0, s, att, x, P, Qt, Gt, gb,
+                           gx_out, nbr, deg, lig, e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl);
     profile_mark_end(s);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
