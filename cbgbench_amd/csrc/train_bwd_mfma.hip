@@ -51,7 +51,7 @@ struct EdgeBwdMfmaLds {
     float ddp[2][2][KNN];      // partial d(dist): [half of the column range][half of the rbf index][edge]
     float D[4];
     float bb[HEADS];
-    float fl[2 * H * 6];       // end-of-kernel fold of the per-thread accumulators of the two edge halves
+    float dwr3[G][2 * H];      // d(rbf columns) of the dominant edge type 3, accumulated across the nodes of the workgroup
     int nb[KNN];
     int nbs[KNN];              // nb, with the node itself in padded slots (safe to gather from / add zeros to)
     int ty[KNN];
@@ -71,26 +71,25 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
     __shared__ EdgeBwdMfmaLds L;
     const int t = threadIdx.x;
     // vector-ALU view: column c of the k|v pair (path p, channel m), edges [16 eh, 16 eh + 16)
-    const int c = t & 255, eh = t >> 8, p = c >> 7, m = c & 127;
-    // matrix view: wave w owns columns [32 w, +32) = channels [mbase, +32) of path pw
-    const int w = t >> 6, l = t & 63, li = l & 15, kq = l >> 4;
+    const int c0 = t & 255, eh = __builtin_amdgcn_readfirstlane(t >> 8), p = __builtin_amdgcn_readfirstlane((t & 255) >> 7);
+    const int m0 = c0 & 127;
+    // matrix view: wave w owns columns [32 w, +32) = channels [mbase, +32) of path pw   (wave-uniform -> scalar registers)
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63, li0 = l & 15, kq0 = l >> 4;
     const int pw = w >> 2, mbase = 32 * (w & 3), cbase = 32 * w;
+    int c = c0, m = m0, li = li0, kq = kq0;
     const float gamma = att[(p == 0 ? A_LNK_G : A_LNV_G) + m];
     const float beta = att[(p == 0 ? A_LNK_B : A_LNV_B) + m];
     float gam2[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) gam2[ct] = att[(pw == 0 ? A_LNK_G : A_LNV_G) + mbase + 16 * ct + li];
 
-    // d(rbf columns) of the dominant edge type 3 (protein -> protein) lives in registers across the nodes of the
-    // workgroup: [g tile][column tile], rows g = 16 gt + 4 kq + r.  The other three types (an endpoint is a ligand atom,
-    // ~10 % of the edges) are added to the workgroup's private slab in memory node by node.
-    floatx4 aWr3[2][2];
-#pragma unroll
-    for (int gt = 0; gt < 2; ++gt)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) aWr3[gt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    // d(rbf columns) of the dominant edge type 3 (protein -> protein) is accumulated in LDS across the nodes of the
+    // workgroup (each element is owned by one lane: plain read-modify-write).  The other three types (an endpoint is a
+    // ligand atom, ~10 % of the edges) are added to the workgroup's private slab in memory node by node.
     float* slab = partial + (size_t)blockIdx.x * PB_SIZE;
     for (int u = t; u < 3 * G * 2 * H; u += BWD_THREADS) slab[PB_WR + u] = 0.f;     // types 0..2
+    for (int u = t; u < NT * 2 * H; u += BWD_THREADS) slab[PB_WT + u] = 0.f;
+    for (int u = t; u < G * 2 * H; u += BWD_THREADS) (&L.dwr3[0][0])[u] = 0.f;
     float aWt[NT] = {0.f, 0.f, 0.f, 0.f};
     float aG2[2] = {0.f, 0.f}, aB2[2] = {0.f, 0.f};
     float aBb = 0.f;
@@ -106,40 +105,57 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
     for (int u = t; u < G * 2 * H; u += BWD_THREADS) L.wrt3[u & 255][u >> 8] = att[A_WR + (size_t)3 * G * 2 * H + u];
     for (int u = t; u < 2 * KNN * 33; u += BWD_THREADS) (&L.rbfc[0][0][0])[u] = 0.f;
     const int count = rows ? *n_rows_ptr : n_nodes;
+    // geometry of a node is built by all 512 threads: thread = (edge ge, rbf group gg); the (neighbour, coordinates, flags)
+    // of the NEXT node are fetched one iteration ahead so their latency is hidden behind the current node's work
+    const int ge = t & 31, gg = t >> 5;
+    int pj = -1, plig = 0, pdeg = 0, pligi = 0;
+    float pxj = 0.f, pyj = 0.f, pzj = 0.f, pxi = 0.f, pyi = 0.f, pzi = 0.f, pew = 0.f;
+    auto prefetch_geometry = [&](int node) {
+        pdeg = deg[node];
+        pligi = lig[node];
+        pxi = x[3 * node]; pyi = x[3 * node + 1]; pzi = x[3 * node + 2];
+        pj = ge < pdeg ? nbr[(size_t)node * KNN + ge] : -1;
+        const int js = pj >= 0 ? pj : node;
+        pxj = x[3 * js]; pyj = x[3 * js + 1]; pzj = x[3 * js + 2];
+        plig = lig[js];
+        pew = e_w[(size_t)node * KNN + ge];
+    };
+    if ((int)blockIdx.x < count) prefetch_geometry(rows ? rows[blockIdx.x] : (int)blockIdx.x);
     for (int it = blockIdx.x; it < count; it += gridDim.x) {
         const int i = rows ? rows[it] : it;
-        const int d = deg[i];
-        const int lig_i = lig[i];
+        // the lane coordinates are re-materialised every iteration: otherwise every LDS address below is loop-invariant,
+        // gets hoisted out of the node loop and the ~100 hoisted addresses are spilled to scratch
+        c = c0; m = m0; li = li0; kq = kq0;
+        asm volatile("" : "+v"(c), "+v"(m), "+v"(li), "+v"(kq));
+        const int d = pdeg;
+        const int lig_i = pligi;
         const int ty_prot = lig_i ? 2 : 3, ty_lig = lig_i ? 0 : 1;   // edge type by source class (unitransformer.py:92-97)
         __syncthreads();
-        if (t < KNN) {
-            const int j = t < d ? nbr[(size_t)i * KNN + t] : -1;
-            L.nb[t] = j;
-            L.nbs[t] = j >= 0 ? j : i;
-            int cl = -1;
-            if (j >= 0) {
-                const float rx = x[3 * i] - x[3 * j], ry = x[3 * i + 1] - x[3 * j + 1], rz = x[3 * i + 2] - x[3 * j + 2];
-                const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
-                L.rel[t][0] = rx; L.rel[t][1] = ry; L.rel[t][2] = rz; L.rel[t][3] = dist;
-                cl = lig[j] ? 1 : 0;
+        {
+            const int j = pj;
+            const int cl = j >= 0 ? (plig ? 1 : 0) : -1;
+            const float rx = pxi - pxj, ry = pyi - pyj, rz = pzi - pzj;
+            const float dist = j >= 0 ? sqrtf(rx * rx + ry * ry + rz * rz) : 0.f;
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
+            for (int k = 0; k < 2; ++k) {
+                const int g = gg + 16 * k;
+                if (g < G) {
                     const float u = dist - c_mu_m[g];
-                    const float r = expf(-0.5f * (u * u));
-                    L.rbf[t][g] = r;
-                    L.rbfc[cl][t][g] = r;
-                    L.rbfc[cl ^ 1][t][g] = 0.f;
+                    const float r = j >= 0 ? expf(-0.5f * (u * u)) : 0.f;
+                    L.rbf[ge][g] = r;
+                    L.rbfc[0][ge][g] = cl == 0 ? r : 0.f;
+                    L.rbfc[1][ge][g] = cl == 1 ? r : 0.f;
                 }
-                L.ty[t] = cl ? ty_lig : ty_prot;
-                L.ew[t] = e_w[(size_t)i * KNN + t];
-            } else {
-#pragma unroll
-                for (int g = 0; g < G; ++g) { L.rbf[t][g] = 0.f; L.rbfc[0][t][g] = 0.f; L.rbfc[1][t][g] = 0.f; }
-                L.rel[t][0] = 0.f; L.rel[t][1] = 0.f; L.rel[t][2] = 0.f; L.rel[t][3] = 0.f;
-                L.ty[t] = 3;
-                L.ew[t] = 0.f;
             }
-            L.cls[t] = cl;
+            if (gg == 0) {
+                L.nb[ge] = j;
+                L.nbs[ge] = j >= 0 ? j : i;
+                L.rel[ge][0] = j >= 0 ? rx : 0.f; L.rel[ge][1] = j >= 0 ? ry : 0.f; L.rel[ge][2] = j >= 0 ? rz : 0.f;
+                L.rel[ge][3] = dist;
+                L.ty[ge] = cl == 1 ? ty_lig : (cl == 0 ? ty_prot : 3);
+                L.ew[ge] = j >= 0 ? pew : 0.f;
+                L.cls[ge] = cl;
+            }
         }
         for (int u = t; u < HEADS * H; u += BWD_THREADS) {
             L.QG[0][u >> 7][u & 127] = Qt[(size_t)i * HEADS * H + u];
@@ -147,6 +163,7 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
         }
         if (!X2H && t < 3) L.D[t] = gx_out[3 * i + t];
         __syncthreads();
+        if (it + (int)gridDim.x < count) prefetch_geometry(rows ? rows[it + gridDim.x] : it + (int)gridDim.x);
         // which source classes occur among the node's edges (uniform over the workgroup)
         bool has_cls[2];
         has_cls[0] = __ballot(l < KNN && L.cls[l & 31] == 0) != 0ull;
@@ -455,9 +472,7 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
 #pragma unroll
             for (int cl = 0; cl < 2; ++cl) {
                 if (!has_cls[cl]) continue;
-                if (cl == 0 && !lig_i) {
-                    CBGX_ACC_WR(aWr3, 0)
-                } else {
+                {
                     floatx4 tmp[2][2];
 #pragma unroll
                     for (int gt = 0; gt < 2; ++gt)
@@ -472,8 +487,11 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
                             const int g = 16 * gt + 4 * kq + r;
                             if (g < G) {
 #pragma unroll
-                                for (int ct = 0; ct < 2; ++ct)
-                                    atomicAdd(&slab[PB_WR + (tyc * G + g) * 2 * H + cbase + 16 * ct + li], tmp[gt][ct][r]);   // no-return atomic: nothing to wait for
+                                for (int ct = 0; ct < 2; ++ct) {
+                                    const int cc = cbase + 16 * ct + li;
+                                    if (tyc == 3) L.dwr3[g][cc] += tmp[gt][ct][r];
+                                    else atomicAdd(&slab[PB_WR + (tyc * G + g) * 2 * H + cc], tmp[gt][ct][r]);   // no-return atomic
+                                }
                             }
                         }
                 }
@@ -551,25 +569,9 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
     }
     // per-workgroup partial sums of the edge-indexed weight gradients
     __syncthreads();
-    if (eh == 1) {
 #pragma unroll
-        for (int a = 0; a < NT; ++a) L.fl[a * 2 * H + c] = aWt[a];
-    }
-    __syncthreads();
-    if (eh == 0) {
-#pragma unroll
-        for (int a = 0; a < NT; ++a) slab[PB_WT + a * 2 * H + c] = aWt[a] + L.fl[a * 2 * H + c];
-    }
-#pragma unroll
-    for (int gt = 0; gt < 2; ++gt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int g = 16 * gt + 4 * kq + r;
-            if (g < G) {
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) slab[PB_WR + (3 * G + g) * 2 * H + cbase + 16 * ct + li] = aWr3[gt][ct][r];
-            }
-        }
+    for (int a = 0; a < NT; ++a) atomicAdd(&slab[PB_WT + a * 2 * H + c], aWt[a]);      // two edge halves per column
+    for (int u = t; u < G * 2 * H; u += BWD_THREADS) slab[PB_WR + 3 * G * 2 * H + u] = (&L.dwr3[0][0])[u];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {   // the 4 k-quarters of a column hold partial sums: fold them, lanes 0..15 store
         float g4 = aG2[ct], b4 = aB2[ct];
