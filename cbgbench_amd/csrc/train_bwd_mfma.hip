@@ -120,7 +120,19 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
         plig = lig[js];
         pew = e_w[(size_t)node * KNN + ge];
     };
-    if ((int)blockIdx.x < count) prefetch_geometry(rows ? rows[blockIdx.x] : (int)blockIdx.x);
+    // the node's folded query / folded output gradient (16 KB) are fetched one iteration ahead as well
+    float pq[4], pg[4];
+    auto prefetch_qg = [&](int node) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pq[k] = Qt[(size_t)node * HEADS * H + t + BWD_THREADS * k];
+            if (X2H) pg[k] = Gt[(size_t)node * HEADS * H + t + BWD_THREADS * k];
+        }
+    };
+    if ((int)blockIdx.x < count) {
+        prefetch_geometry(rows ? rows[blockIdx.x] : (int)blockIdx.x);
+        prefetch_qg(rows ? rows[blockIdx.x] : (int)blockIdx.x);
+    }
     for (int it = blockIdx.x; it < count; it += gridDim.x) {
         const int i = rows ? rows[it] : it;
         // the lane coordinates are re-materialised every iteration: otherwise every LDS address below is loop-invariant,
@@ -157,13 +169,19 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
                 L.cls[ge] = cl;
             }
         }
-        for (int u = t; u < HEADS * H; u += BWD_THREADS) {
-            L.QG[0][u >> 7][u & 127] = Qt[(size_t)i * HEADS * H + u];
-            if (X2H) L.QG[1][u >> 7][u & 127] = Gt[(size_t)i * HEADS * H + u];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = t + BWD_THREADS * k;
+            L.QG[0][u >> 7][u & 127] = pq[k];
+            if (X2H) L.QG[1][u >> 7][u & 127] = pg[k];
         }
         if (!X2H && t < 3) L.D[t] = gx_out[3 * i + t];
         __syncthreads();
-        if (it + (int)gridDim.x < count) prefetch_geometry(rows ? rows[it + gridDim.x] : it + (int)gridDim.x);
+        if (it + (int)gridDim.x < count) {
+            const int nxt = rows ? rows[it + gridDim.x] : it + (int)gridDim.x;
+            prefetch_geometry(nxt);
+            prefetch_qg(nxt);
+        }
         // which source classes occur among the node's edges (uniform over the workgroup)
         bool has_cls[2];
         has_cls[0] = __ballot(l < KNN && L.cls[l & 31] == 0) != 0ull;
