@@ -125,8 +125,8 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
     auto prefetch_qg = [&](int node) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            pq[k] = Qt[(size_t)node * HEADS * H + t + BWD_THREADS * k];
-            if (X2H) pg[k] = Gt[(size_t)node * HEADS * H + t + BWD_THREADS * k];
+            pq[k] = Qt[(unsigned)node * HEADS * H + t + BWD_THREADS * k];
+            if (X2H) pg[k] = Gt[(unsigned)node * HEADS * H + t + BWD_THREADS * k];
         }
     };
     if ((int)blockIdx.x < count) {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
 #pragma unroll
             for (int cl = 0; cl < 2; ++cl) {
                 if (!has_cls[cl]) continue;
-                const float* wr = att + A_WR + (size_t)(cl ? ty_lig : ty_prot) * G * 2 * H + cbase + li;
+                const float* wr = att + A_WR + (unsigned)(cl ? ty_lig : ty_prot) * G * 2 * H + cbase + li;
                 float a0[G / 4], a1[G / 4], bq[G / 4][2];
 #pragma unroll
                 for (int s = 0; s < G / 4; ++s) {
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
                     a0[s] = L.rbfc[cl][li][g];
                     a1[s] = L.rbfc[cl][16 + li][g];
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) bq[s][ct] = wr[(size_t)g * 2 * H + 16 * ct];
+                    for (int ct = 0; ct < 2; ++ct) bq[s][ct] = wr[(unsigned)g * 2 * H + 16 * ct];
                 }
                 SCHED_FENCE();
 #pragma unroll
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 const int cc = cbase + 16 * ct + li;
-                pd[ct] = P[(size_t)i * PROW + cc];
+                pd[ct] = P[(unsigned)i * PROW + cc];
                 wtv[0][ct] = att[A_WT + ty_prot * 2 * H + cc];
                 wtv[1][ct] = att[A_WT + ty_lig * 2 * H + cc];
             }
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
                     clv[rt][r] = L.cls[e];
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct)
-                        ps[rt][r][ct] = (abl & 2) ? 0.f : P[(size_t)j * PROW + 2 * H + cbase + 16 * ct + li];
+                        ps[rt][r][ct] = (abl & 2) ? 0.f : P[(unsigned)j * PROW + 2 * H + cbase + 16 * ct + li];
                 }
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -374,11 +374,11 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) aV16[ct] = acc[ct];
             } else if (!(abl & 16)) {
-                float* dst = (pw == 0 ? T : S) + (size_t)i * HEADS * H;
+                float* dst = (pw == 0 ? T : S) + (unsigned)i * HEADS * H;
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[(size_t)(4 * kq + r) * H + mbase + 16 * ct + li] = acc[ct][r];
+                    for (int r = 0; r < 4; ++r) dst[(unsigned)(4 * kq + r) * H + mbase + 16 * ct + li] = acc[ct][r];
             }
         }
         {   // 7. d(hidden) -> d(normalised pre-activation), the wave's 32 channels x 32 edges
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
         __syncthreads();
         {   // 9a. dpre; own projection row, neighbour rows (atomics), type columns of the first Linear.
             // branch-free: padded slots carry exact zeros (N, U, stat2) and add 0 to the node's own row
-            float accpd = 0.f;
+            float accpd = 0.f, acclig = 0.f;
 #pragma unroll
             for (int e0 = 0; e0 < 16; e0 += 8) {
                 float dpv[8];
@@ -452,20 +452,18 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
                     const float n = L.N[p][e][m];
                     dpv[k] = L.stat[p][e][1] * (L.U[p][e][m] - L.stat2[p][e][0] - n * L.stat2[p][e][1]);
                     jv[k] = L.nbs[e];
-                    const int ty = L.ty[e];
-                    aWt[0] += ty == 0 ? dpv[k] : 0.f;
-                    aWt[1] += ty == 1 ? dpv[k] : 0.f;
-                    aWt[2] += ty == 2 ? dpv[k] : 0.f;
-                    aWt[3] += ty == 3 ? dpv[k] : 0.f;
+                    acclig += L.cls[e] == 1 ? dpv[k] : 0.f;
                     accpd += dpv[k];
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     L.N[p][16 * eh + e0 + k][m] = dpv[k];
-                    if (!(abl & 1)) atomicAdd(&dP[(size_t)jv[k] * PROW + 2 * H + c], dpv[k]);
+                    if (!(abl & 1)) atomicAdd(&dP[(unsigned)jv[k] * PROW + 2 * H + c], dpv[k]);
                 }
             }
-            atomicAdd(&dP[(size_t)i * PROW + c], accpd);      // two edge halves per column; dP is zeroed by the caller
+            atomicAdd(&dP[(unsigned)i * PROW + c], accpd);      // two edge halves per column; dP is zeroed by the caller
+            // type columns: a node's edges have one of two types, by source class (padded slots contribute zeros)
+            if (lig_i) { aWt[0] += acclig; aWt[2] += accpd - acclig; } else { aWt[1] += acclig; aWt[3] += accpd - acclig; }
         }
         __syncthreads();
         // 9b. rbf columns of the first Linear: dWr[type][g][c] += sum_e rbf[e][g] dpre[e][c], per source class present
@@ -619,6 +617,7 @@ hipError_t launch_edge_backward_mfma(bool x2h, const float* att, const float* x,
                                      const int32_t* deg, const uint8_t* lig, const float* e_w, const int* rows,
                                      const int* n_rows, int n_nodes, float* T, float* S, float* sw, float* dP, float* dx,
                                      float* de_w, float* partial, int grid, hipStream_t s) {
+    if ((long)n_nodes * HEADS * H >= (1L << 32)) return hipErrorInvalidValue;   // 32-bit element offsets inside the kernel
     static const int abl = getenv("CBGX_BWD_ABL") ? atoi(getenv("CBGX_BWD_ABL")) : 0;   // timing ablations (wrong results)
     profile_mark_begin(x2h ? K_EDGE_X2H_BWD : K_EDGE_H2X_BWD, s);
     if (x2h)
