@@ -224,6 +224,7 @@ def bench_train(args, rank, world, dev):
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        sharding.barrier()      # rank 0 may still be in its (untimed) roofline pass: leave together
         torch.distributed.destroy_process_group()
 
 
@@ -332,6 +333,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        sharding.barrier()      # rank 0 may still be in its (untimed) roofline pass: leave together
         torch.distributed.destroy_process_group()
 
 
