@@ -239,6 +239,9 @@ def main():
                     help="denovo = BASELINE configs[1] (default); linker = configs[2]: --pockets distinct pockets, one "
                          "graph each, fixed context atoms + a few generated linker atoms (partial gen_flag); train = "
                          "configs[4] shape: forward + backward + all-reduce + Adam on --pockets graphs per GPU")
+    ap.add_argument("--graph", choices=["on", "off"], default="off",
+                    help="replay one captured hipGraph per denoising step instead of stream launches (no gain measured: "
+                         "small batches are bound by the dependent-kernel chain on the device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -269,14 +272,30 @@ def main():
     torch.manual_seed(2024 + rank)   # sample.py:106 seed (+rank: independent streams per shard)
 
     t_idx = T - 1
-    for _ in range(args.warmup):
-        model.denoise_step(st, t_idx); t_idx = (t_idx - 1) % T
-    sharding.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.denoise_step(st, t_idx); t_idx = (t_idx - 1) % T
-    torch.cuda.synchronize(); sharding.barrier()
-    elapsed = time.perf_counter() - t0
+    use_graph = args.graph == "on"
+    if use_graph and args.warmup + args.steps + 2 >= T:
+        use_graph = False
+    if use_graph:
+        replay, done = model.make_step_graph(st, warmup=2)
+        for _ in range(args.warmup):
+            replay()
+        sharding.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            replay()
+        torch.cuda.synchronize(); sharding.barrier()
+        elapsed = time.perf_counter() - t0
+        t_idx = T - 1 - done - args.warmup - args.steps
+        st["x_lig"], st["c_lig"] = st["traj_x"][t_idx + 1].clone(), st["traj_c"][t_idx + 1].clone()
+    else:
+        for _ in range(args.warmup):
+            model.denoise_step(st, t_idx); t_idx = (t_idx - 1) % T
+        sharding.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model.denoise_step(st, t_idx); t_idx = (t_idx - 1) % T
+        torch.cuda.synchronize(); sharding.barrier()
+        elapsed = time.perf_counter() - t0
     el_max, graph_steps = sharding.reduce_max_sum(elapsed, n_graphs * args.steps, device=dev)
 
     out = {
@@ -290,7 +309,8 @@ def main():
                                (f"configs/linker targetdiff sampling (BASELINE configs[2]): {args.pockets} fragment-pair "
                                 f"pockets per batch per GPU, N_rec~U[350,650], 10-35 fixed context atoms + 3-14 generated "
                                 f"atoms per graph (partial gen_flag), k=32, 9 layers, fp32, synthetic weights"),
-                   "graphs_per_batch_per_gpu": n_graphs, "nodes_per_batch": N, "sharding": f"pockets x{world} ranks"},
+                   "graphs_per_batch_per_gpu": n_graphs, "nodes_per_batch": N, "sharding": f"pockets x{world} ranks",
+                   "launch": "one hipGraph replay per step" if use_graph else "stream launches"},
     }
 
     if rank == 0 and not args.no_roofline:

@@ -477,4 +477,32 @@ int cbgx_targetdiff_epilogue(const float* x_den, const float* logits, const int3
     return CBGX_OK;
 }
 
+// ---- trajectory-resident variants (one captured hipGraph can then be replayed for every step) ---------------------
+int cbgx_targetdiff_prologue_traj(const float* traj_x, const float* traj_c, const int32_t* t_dev, const int32_t* lig_rows,
+                                  int n_lig, int num_classes, const float* lig_emb_w, const float* lig_emb_b,
+                                  const float* ind_w, const float* ind_b, float* x, float* h, void* stream) {
+    if (n_lig == 0) return CBGX_OK;
+    if (n_lig < 0 || num_classes < 1 || num_classes > 32) return fail(CBGX_E_INVALID, "prologue_traj: bad sizes");
+    if (!traj_x || !traj_c || !t_dev || !lig_rows || !lig_emb_w || !lig_emb_b || !ind_w || !ind_b || !x || !h)
+        return fail(CBGX_E_INVALID, "prologue_traj: NULL pointer");
+    HIP_TRY(launch_step_prologue(traj_x, traj_c, lig_rows, n_lig, num_classes, lig_emb_w, lig_emb_b, ind_w, ind_b, x, h,
+                                 (hipStream_t)stream, t_dev));
+    return CBGX_OK;
+}
+
+int cbgx_targetdiff_epilogue_traj(const float* x_den, const float* logits, const int32_t* lig_rows, float* traj_x,
+                                  float* traj_c, const uint8_t* gen_lig, int n_lig, int num_classes, int32_t* t_dev,
+                                  const float* const* tables, const float* eps, const float* u, void* stream) {
+    if (n_lig == 0) return CBGX_OK;
+    if (n_lig < 0 || num_classes < 1 || num_classes > 32) return fail(CBGX_E_INVALID, "epilogue_traj: bad sizes");
+    if (!x_den || !logits || !lig_rows || !traj_x || !traj_c || !gen_lig || !t_dev || !tables || !eps || !u)
+        return fail(CBGX_E_INVALID, "epilogue_traj: NULL pointer");
+    for (int i = 0; i < 7; ++i)
+        if (!tables[i]) return fail(CBGX_E_INVALID, "epilogue_traj: table %d is NULL", i);
+    HIP_TRY(launch_step_epilogue(x_den, logits, lig_rows, traj_x, traj_c, gen_lig, n_lig, num_classes, 0, tables,
+                                 (float)log((double)num_classes), eps, u, traj_x, traj_c, nullptr, (hipStream_t)stream,
+                                 t_dev));
+    return CBGX_OK;
+}
+
 }  // extern "C"

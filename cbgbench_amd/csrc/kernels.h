@@ -60,11 +60,11 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
 // TargetDiff step prologue / epilogue (step.hip)
 hipError_t launch_step_prologue(const float* x_lig, const float* c_lig, const int32_t* lig_rows, int n_lig, int C,
                                 const float* emb_w, const float* emb_b, const float* ind_w, const float* ind_b, float* x,
-                                float* h, hipStream_t s);
+                                float* h, hipStream_t s, const int32_t* t_ptr = nullptr);
 hipError_t launch_step_epilogue(const float* x_den, const float* logits, const int32_t* lig_rows, const float* x_lig,
                                 const float* c_lig, const uint8_t* gen_lig, int n_lig, int C, int t,
                                 const float* const* tabs, float log_c, const float* eps, const float* u, float* x_next,
-                                float* c_next, int32_t* v_next, hipStream_t s);
+                                float* c_next, int32_t* v_next, hipStream_t s, int32_t* t_ptr = nullptr);
 hipError_t launch_pack_copy(const float* src, int src_ld, int src_off, int transpose, float* dst, int dst_ld,
                             int rows, int cols, hipStream_t s);
 

@@ -21,9 +21,14 @@ __global__ __launch_bounds__(128) void step_prologue_kernel(const float* __restr
                                                             const float* __restrict__ emb_w /*[128][C]*/,
                                                             const float* __restrict__ emb_b, const float* __restrict__ ind_w,
                                                             const float* __restrict__ ind_b, float* __restrict__ x,
-                                                            float* __restrict__ h) {
+                                                            float* __restrict__ h, const int32_t* __restrict__ t_ptr) {
     const int a = blockIdx.x, m = threadIdx.x;
     if (a >= n_lig) return;
+    if (t_ptr) {   // trajectory mode: x_lig / c_lig are the bases of [T+1] slot arrays; the current state is slot t + 1
+        const size_t slot = (size_t)(*t_ptr + 1);
+        x_lig += slot * n_lig * 3;
+        c_lig += slot * n_lig * C;
+    }
     const int row = lig_rows[a];
     float acc = 0.f;
     for (int k = 0; k < C; ++k) acc = fmaf(emb_w[m * C + k], c_lig[(size_t)a * C + k], acc);
@@ -42,9 +47,17 @@ __global__ __launch_bounds__(256) void step_epilogue_kernel(
     int t, const float* __restrict__ c0_tab, const float* __restrict__ ct_tab, const float* __restrict__ logvar_tab,
     const float* __restrict__ log_alpha, const float* __restrict__ log_1m_alpha, const float* __restrict__ log_acp,
     const float* __restrict__ log_1m_acp, float log_c, const float* __restrict__ eps, const float* __restrict__ u,
-    float* __restrict__ x_next, float* __restrict__ c_next, int32_t* __restrict__ v_next) {
+    float* __restrict__ x_next, float* __restrict__ c_next, int32_t* __restrict__ v_next,
+    const int32_t* __restrict__ t_ptr) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n_lig) return;
+    if (t_ptr) {   // trajectory mode: state of slot t + 1 -> slot t of the same [T+1] arrays
+        t = *t_ptr;
+        x_lig += (size_t)(t + 1) * n_lig * 3;
+        c_lig += (size_t)(t + 1) * n_lig * C;
+        x_next += (size_t)t * n_lig * 3;
+        c_next += (size_t)t * n_lig * C;
+    }
     const int row = lig_rows[a];
     const bool gen = gen_lig[a] != 0;
     // ---- positions
@@ -95,21 +108,24 @@ __global__ __launch_bounds__(256) void step_epilogue_kernel(
 
 hipError_t launch_step_prologue(const float* x_lig, const float* c_lig, const int32_t* lig_rows, int n_lig, int C,
                                 const float* emb_w, const float* emb_b, const float* ind_w, const float* ind_b, float* x,
-                                float* h, hipStream_t s) {
+                                float* h, hipStream_t s, const int32_t* t_ptr) {
     if (n_lig == 0) return hipSuccess;
     hipLaunchKernelGGL(step_prologue_kernel, dim3(n_lig), dim3(128), 0, s, x_lig, c_lig, lig_rows, n_lig, C, emb_w, emb_b,
-                       ind_w, ind_b, x, h);
+                       ind_w, ind_b, x, h, t_ptr);
     return hipGetLastError();
 }
+
+__global__ void step_counter_kernel(int32_t* t_ptr) { *t_ptr -= 1; }
 
 hipError_t launch_step_epilogue(const float* x_den, const float* logits, const int32_t* lig_rows, const float* x_lig,
                                 const float* c_lig, const uint8_t* gen_lig, int n_lig, int C, int t,
                                 const float* const* tabs, float log_c, const float* eps, const float* u, float* x_next,
-                                float* c_next, int32_t* v_next, hipStream_t s) {
+                                float* c_next, int32_t* v_next, hipStream_t s, int32_t* t_ptr) {
     if (n_lig == 0) return hipSuccess;
     hipLaunchKernelGGL(step_epilogue_kernel, dim3((n_lig + 255) / 256), dim3(256), 0, s, x_den, logits, lig_rows, x_lig,
                        c_lig, gen_lig, n_lig, C, t, tabs[0], tabs[1], tabs[2], tabs[3], tabs[4], tabs[5], tabs[6], log_c, eps,
-                       u, x_next, c_next, v_next);
+                       u, x_next, c_next, v_next, t_ptr);
+    if (t_ptr) hipLaunchKernelGGL(step_counter_kernel, dim3(1), dim3(1), 0, s, t_ptr);   // next step: t - 1
     return hipGetLastError();
 }
 

@@ -465,16 +465,73 @@ class TargetDiff(nn.Module):
         st["x_lig"], st["c_lig"] = x_next, c_next
         return st
 
+    # ---- one captured graph replayed for every step (small batches are launch-bound: ~100 short kernels per step) ----
+    def _traj_step(self, st):
+        """One step with every argument static: the ligand state lives in the trajectory slots, the step index on the
+        device (cbgx_targetdiff_prologue_traj / epilogue_traj).  Capturable in a hipGraph."""
+        lib = _native.lib()
+        dev = st["x"].device
+        stream = _native.current_stream(dev)
+        n_lig, C = st["n_lig"], self.num_classes
+        emb = self.context_embedder
+        _native.check(lib.cbgx_targetdiff_prologue_traj(
+            _native.ptr(st["traj_x"]), _native.ptr(st["traj_c"]), _native.ptr(st["t_dev"]), _native.ptr(st["lig_rows32"]),
+            n_lig, C, _native.ptr(emb.ligand_atom_emb.weight), _native.ptr(emb.ligand_atom_emb.bias),
+            _native.ptr(emb.ligand_indicator.weight), _native.ptr(emb.ligand_indicator.bias),
+            _native.ptr(st["x"]), _native.ptr(st["h"]), stream), "cbgx_targetdiff_prologue_traj")
+        xo, _, logits = self.denoiser(x=st["x"], h=st["h"], batch_idx=st["batch_idx"], lig_flag=st["lig_flag"],
+                                      gen_flag=st["gen_flag"], graph_ptr=st["graph_ptr"], need_h=False,
+                                      static_h=st["static_h"])
+        eps = torch.randn(n_lig, 3, dtype=torch.float32, device=dev)      # reference draw order: randn then rand
+        u = torch.rand(n_lig, C, dtype=torch.float32, device=dev)
+        _native.check(lib.cbgx_targetdiff_epilogue_traj(
+            _native.ptr(xo), _native.ptr(logits), _native.ptr(st["lig_rows32"]), _native.ptr(st["traj_x"]),
+            _native.ptr(st["traj_c"]), _native.ptr(st["gen_l8"]), n_lig, C, _native.ptr(st["t_dev"]), st["tables"],
+            _native.ptr(eps), _native.ptr(u), stream), "cbgx_targetdiff_epilogue_traj")
+        st["_noise"] = (eps, u)     # under capture these are the graph's static buffers: readable after every replay
+
     @torch.no_grad()
-    def sample(self, batch, noise_tape=None, return_device=None):
+    def make_step_graph(self, st, warmup=2):
+        """Capture one reverse-diffusion step as a hipGraph.  ``st`` must come from ``begin_sampling(keep_trajectory=True)``
+        on the GPU.  Runs ``warmup`` eager steps first (they count: the step index advances), then returns
+        ``(replay, steps_done)``; every ``replay()`` advances the state by one step.  The step index lives in
+        ``st['t_dev']``; after the last step the final state is trajectory slot 0."""
+        dev = st["x"].device
+        T = self.num_diffusion_timesteps
+        if dev.type != "cuda" or st["traj_x"] is None or not (self.denoise_structure and self.denoise_atom):
+            raise RuntimeError("make_step_graph needs a GPU sampling state with the trajectory kept on the device")
+        st["t_dev"] = torch.full((1,), T - 1, dtype=torch.int32, device=dev)
+        for _ in range(min(warmup, T)):     # eager steps on the current stream: workspaces and weight packs get allocated
+            self._traj_step(st)
+        torch.cuda.synchronize(dev)
+        done = min(warmup, T)
+        if done >= T:
+            return (lambda: None), done
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._traj_step(st)
+        st["_graph"] = graph        # keeps the graph's private memory pool alive as long as the state
+        return graph.replay, done
+
+    @torch.no_grad()
+    def sample(self, batch, noise_tape=None, return_device=None, use_graph=None):
         """Reverse diffusion, T-1 .. 0 (targetdiff.py:127-184).
 
         ``noise_tape`` (tests): dict t -> (eps [N_lig,3], u [N_lig,C]) replacing the torch RNG draws
         (order per step in the reference: randn_like then rand_like).
-        ``return_device``: where the returned trajectory lives (default: CPU, like the reference)."""
+        ``return_device``: where the returned trajectory lives (default: CPU, like the reference).
+        ``use_graph``: replay one captured hipGraph per step instead of ~100 stream launches.  Off by default: measured on
+        MI355X it changes nothing (1.22 ms per step at 445 nodes either way) -- small batches are bound by the
+        dependent-kernel chain on the device, not by host launches."""
         T = self.num_diffusion_timesteps
         st = self.begin_sampling(batch, keep_trajectory=True)
-        for t_idx in reversed(range(T)):
+        use_graph = bool(use_graph) and noise_tape is None
+        if use_graph:
+            replay, done = self.make_step_graph(st)
+            for _ in range(T - done):
+                replay()
+            st["x_lig"], st["c_lig"] = st["traj_x"][0], st["traj_c"][0]
+        for t_idx in (reversed(range(T)) if not use_graph else ()):
             self.denoise_step(st, t_idx, noise_tape[t_idx] if noise_tape is not None else None)
         out_dev = torch.device("cpu") if return_device is None else torch.device(return_device)
         traj_x, traj_c, bl_out = st["traj_x"].to(out_dev), st["traj_c"].to(out_dev), st["bl"].to(out_dev)

@@ -164,6 +164,19 @@ int cbgx_targetdiff_epilogue(const float *x_den, const float *logits, const int3
                              int num_timesteps, const float *const *tables, const float *eps, const float *u,
                              float *x_next, float *c_next, int32_t *v_next, void *stream);
 
+/* Trajectory-resident variants: the ligand state lives in traj_x [T+1, n_lig, 3] / traj_c [T+1, n_lig, C] (slot s+1 = the
+ * state entering step s, slot 0 = the final state) and the step index in a device int (*t_dev).  The prologue reads slot
+ * *t_dev + 1; the epilogue reads slot *t_dev + 1, writes slot *t_dev and then decrements *t_dev.  No argument changes
+ * from step to step, so one captured hipGraph of {prologue_traj, forward, noise draw, epilogue_traj} can be replayed for
+ * all T steps -- the launch-bound regime of small batches (TargetDiff.sample(..., use_graph=True)). */
+int cbgx_targetdiff_prologue_traj(const float *traj_x, const float *traj_c, const int32_t *t_dev,
+                                  const int32_t *lig_rows, int n_lig, int num_classes, const float *lig_emb_w,
+                                  const float *lig_emb_b, const float *ind_w, const float *ind_b, float *x, float *h,
+                                  void *stream);
+int cbgx_targetdiff_epilogue_traj(const float *x_den, const float *logits, const int32_t *lig_rows, float *traj_x,
+                                  float *traj_c, const uint8_t *gen_lig, int n_lig, int num_classes, int32_t *t_dev,
+                                  const float *const *tables, const float *eps, const float *u, void *stream);
+
 /* ---- training: taped forward and backward -----------------------------------------------------------
  * train.py:185-189 runs `loss_dict, _ = model(batch); loss.backward()`; autograd walks UniTransformer.forward
  * (unitransformer.py:102-123) backwards through every X2HAttention / H2XAttention (x2h_attention.py:43-97,
