@@ -107,7 +107,26 @@ size_t cbgx_packed_weights_floats(int num_layers, int num_classes) {
     return packed_floats(num_layers, num_classes);
 }
 
-#define CP(src, ld, off, tr, dst, dld, rows, cols) HIP_TRY(launch_pack_copy(src, ld, off, tr, dst, dld, rows, cols, s))
+// strided / transposed copies are collected and issued as one launch per batch (they only read the caller's tensors and
+// are only consumed by later forward calls, so deferring them to the next flush on the same stream is safe)
+static thread_local PackBatch g_pack;
+static int flush_pack(hipStream_t s) {
+    if (g_pack.n) {
+        HIP_TRY(launch_pack_copy_multi(g_pack, s));
+        g_pack.n = 0;
+    }
+    return CBGX_OK;
+}
+static int queue_pack(const float* src, int ld, int off, int tr, float* dst, int dld, int rows, int cols, hipStream_t s) {
+    if (g_pack.n == PACK_MAX) { int rc = flush_pack(s); if (rc) return rc; }
+    g_pack.p[g_pack.n++] = PackPiece{src, dst, ld, off, tr, dld, rows, cols};
+    return CBGX_OK;
+}
+#define CP(src, ld, off, tr, dst, dld, rows, cols)                                 \
+    do {                                                                           \
+        int _rc = queue_pack(src, ld, off, tr, dst, dld, rows, cols, s);           \
+        if (_rc) return _rc;                                                       \
+    } while (0)
 
 // gate section (GATE_* offsets) from dist_emb.1.net.{0.weight,0.bias,1.weight,1.bias,3.weight,3.bias}
 static int pack_gate_section(const float* const* t, float* packed, hipStream_t s) {
@@ -119,7 +138,7 @@ static int pack_gate_section(const float* const* t, float* packed, hipStream_t s
     CP(t[4], GH, 0, 0, packed + GATE_W2, GH, 1, GH);
     CP(t[5], 1, 0, 0, packed + GATE_B2, 1, 1, 1);
     HIP_TRY(launch_pack_gate_img(t[0], t[1], t[2], t[3], t[4], packed + GATE_IMG, s));
-    return CBGX_OK;
+    return flush_pack(s);
 }
 
 // one attention block (ATT layout) from k(6) v(6) q(6) MLP tensors; blk 0 = x2h, 1 = h2x
@@ -179,7 +198,7 @@ static int pack_attention_block(const float* const* p, int blk, float* a, hipStr
         CP(wv1, H, 0, 0, a + A_WBV, H, HEADS, H);  // [head][m]
         CP(bv1, HEADS, 0, 0, a + A_BBV, HEADS, 1, HEADS);
     }
-    return CBGX_OK;
+    return flush_pack(s);
 }
 
 int cbgx_pack_weights(const float* const* t, int num_tensors, int L, int C, float* packed, void* stream) {
@@ -206,8 +225,7 @@ int cbgx_pack_weights(const float* const* t, int num_tensors, int L, int C, floa
     CP(c[1], H, 0, 0, cp + C_B0, H, 1, H);
     CP(c[2], H, 0, 1, cp + C_W1T, C, H, C);
     CP(c[3], C, 0, 0, cp + cls_b1(C), C, 1, C);
-#undef CP
-    return CBGX_OK;
+    return flush_pack(s);
 }
 
 // ---- a stack of H2X blocks on its own kNN graph + gate (DiffBP's CoMPredictor) ---------------------
@@ -229,7 +247,7 @@ int cbgx_pack_h2x_stack(const float* const* t, int num_tensors, int L, float* pa
         int rc = pack_attention_block(t + 6 + 18 * l, 1, packed + GATE_SIZE + (size_t)l * ATT_SIZE, s);
         if (rc) return rc;
     }
-    return CBGX_OK;
+    return flush_pack(s);
 }
 
 int cbgx_h2x_stack_forward(const float* packed, int num_layers, const float* x, const float* h,

@@ -65,6 +65,14 @@ hipError_t launch_step_epilogue(const float* x_den, const float* logits, const i
                                 const float* c_lig, const uint8_t* gen_lig, int n_lig, int C, int t,
                                 const float* const* tabs, float log_c, const float* eps, const float* u, float* x_next,
                                 float* c_next, int32_t* v_next, hipStream_t s, int32_t* t_ptr = nullptr);
+constexpr int PACK_MAX = 64;
+struct PackPiece {
+    const float* src; float* dst; int src_ld, src_off, transpose, dst_ld, rows, cols;
+};
+struct PackBatch {
+    PackPiece p[PACK_MAX]; int n;
+};
+hipError_t launch_pack_copy_multi(const PackBatch& b, hipStream_t s);
 hipError_t launch_pack_copy(const float* src, int src_ld, int src_off, int transpose, float* dst, int dst_ld,
                             int rows, int cols, hipStream_t s);
 

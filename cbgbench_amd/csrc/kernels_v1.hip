@@ -513,6 +513,28 @@ hipError_t launch_node_query_v1(const float* att, const float* P, float* Qt, int
     return hipSuccess;
 }
 
+// many strided / transposed copies in one launch (blockIdx.y = piece): weight packing is ~40 small copies per block
+__global__ void pack_copy_multi_kernel(PackBatch b) {
+    const PackPiece& pc = b.p[blockIdx.y];
+    const int total = pc.rows * pc.cols;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int i = idx / pc.cols, j = idx % pc.cols;
+        pc.dst[(size_t)i * pc.dst_ld + j] =
+            pc.transpose ? pc.src[(size_t)j * pc.src_ld + i + pc.src_off] : pc.src[(size_t)i * pc.src_ld + j + pc.src_off];
+    }
+}
+
+hipError_t launch_pack_copy_multi(const PackBatch& b, hipStream_t s) {
+    if (b.n == 0) return hipSuccess;
+    int mx = 0;
+    for (int k = 0; k < b.n; ++k) mx = b.p[k].rows * b.p[k].cols > mx ? b.p[k].rows * b.p[k].cols : mx;
+    int gx = (mx + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(pack_copy_multi_kernel, dim3(gx, b.n), dim3(256), 0, s, b);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t launch_pack_copy(const float* src, int src_ld, int src_off, int transpose, float* dst, int dst_ld,
                             int rows, int cols, hipStream_t s) {
     int total = rows * cols;

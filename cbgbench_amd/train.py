@@ -51,6 +51,11 @@ class FlatGradients:
         self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         for p, v in zip(self.params, self.flat.split(sizes)):
             p.grad = v.view_as(p)
+        # libcbgx-backed encoders write their gradients straight into these views (one backward per step, zeroed by
+        # zero() before it) instead of returning tensors for autograd to accumulate
+        for mod in model.modules():
+            if hasattr(mod, "_direct_grads"):
+                mod._direct_grads = True
 
     def zero(self):
         self.flat.zero_()

@@ -116,8 +116,18 @@ class _DenoiserFunction(torch.autograd.Function):
         device = ctx.tape.device
         L, C = module.num_layers, module.out_classes
         sizes = [int(torch.Size(s).numel()) for s in ctx.param_shapes]
-        flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
-        views = list(flat.split(sizes))
+        direct = module._direct_grads
+        if direct:
+            # write straight into the parameters' .grad storage (cbgbench_amd.train.FlatGradients owns it and zeroes it
+            # every step): saves one accumulate kernel per parameter tensor.  The library overwrites, so this mode is only
+            # for one backward per optimiser step.
+            params = module._ordered_params()
+            views = [p.grad for p in params]
+            if any(v is None or not v.is_contiguous() or v.dtype != torch.float32 or v.device != device for v in views):
+                direct = False
+        if not direct:
+            flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+            views = list(flat.split(sizes))
         arr = (ctypes.c_void_p * len(views))(*[v.data_ptr() for v in views])
         need_h = ctx.needs_input_grad[2]
         gh_in = torch.empty(N, module.hidden_dim, dtype=torch.float32, device=device) if need_h else None
@@ -129,6 +139,8 @@ class _DenoiserFunction(torch.autograd.Function):
             _native.ptr(gen), N, _native.ptr(gx), _native.ptr(gh), _native.ptr(gl), arr, len(views),
             _native.ptr(gh_in), _native.ptr(ws), ws.numel(), _native.current_stream(device))
         _native.check(rc, "cbgx_unitransformer_backward")
+        if direct:
+            return (None, None, gh_in, None, None, None) + (None,) * len(views)
         grads = [v.view(s) for v, s in zip(views, ctx.param_shapes)]
         return (None, None, gh_in, None, None, None, *grads)
 
@@ -181,6 +193,7 @@ class UniTransformer(nn.Module):
         self._packed_key = None
         self._workspace = None
         self._train_workspace = None
+        self._direct_grads = False     # set by cbgbench_amd.train.FlatGradients
 
     def __repr__(self):
         return (f"UniTransformer[libcbgx/gfx950](num_layers={self.num_layers}, n_heads={self.n_heads}, "
