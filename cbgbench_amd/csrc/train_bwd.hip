@@ -620,20 +620,25 @@ __global__ void reduce_store_multi_kernel(RsBatch b) {
 // generic fp32 GEMM for the node-level products of the backward (sizes are small: N_nodes x 640 x 128):
 //   C[z] (+)= op(A) op(B) over the K range of split z.  64x64 tile, 256 threads, 4x4 per thread.
 // ------------------------------------------------------------------------------------------------
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                     int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
                                                     int k_chunk, size_t c_split_stride, int accumulate) {
+    // 64 x 64 output tile per workgroup, K staged 16 at a time through LDS; wave (wr, wc) of the 2 x 2 wave grid owns a
+    // 32 x 32 sub-tile = 2 x 2 MFMA tiles (v_mfma_f32_16x16x4_f32: lane (li, kq) feeds A[row li][k kq], B[k kq][col li]).
     __shared__ float sA[16][68];
     __shared__ float sB[16][68];
     const int bm = blockIdx.y * 64, bn = blockIdx.x * 64, z = blockIdx.z;
     const int k0 = z * k_chunk, k1 = min(K, k0 + k_chunk);
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    float acc[4][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    floatx4_t acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        for (int j = 0; j < 2; ++j) acc[i][j] = (floatx4_t){0.f, 0.f, 0.f, 0.f};
     for (int kb = k0; kb < k1; kb += 16) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -656,33 +661,37 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
             }
         }
         __syncthreads();
+        float a[4][2], b[4][2];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            float a[4], b[4];
+        for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = sA[kk][ty * 4 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = sB[kk][tx * 4 + j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+            for (int i = 0; i < 2; ++i) {
+                a[kk][i] = sA[4 * kk + kq][32 * wr + 16 * i + li];
+                b[kk][i] = sB[4 * kk + kq][32 * wc + 16 * i + li];
+            }
         }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
         __syncthreads();
     }
     float* Cz = C + (size_t)z * c_split_stride;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = bm + ty * 4 + i;
-        if (r >= M) continue;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int cc = bn + tx * 4 + j;
-            if (cc >= N) continue;
-            float* o = Cz + (size_t)r * ldc + cc;
-            *o = accumulate ? *o + acc[i][j] : acc[i][j];
-        }
-    }
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = bm + 32 * wr + 16 * i + 4 * kq + r, col = bn + 32 * wc + 16 * j + li;
+                if (row < M && col < N) {
+                    float* o = Cz + (size_t)row * ldc + col;
+                    *o = accumulate ? *o + acc[i][j][r] : acc[i][j][r];
+                }
+            }
 }
 
 // ------------------------------------------------------------------------------------------------
