@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 #include "../../include/cbgx.h"
 #include "kernels.h"
@@ -48,6 +49,12 @@ struct Workspace {
     float* P;
     float* Qt;
     float* q;
+    float* P2;       // second / third node-stage buffer sets: the x2h node stage of layer l+1 runs on an auxiliary
+    float* Qt2;      // stream while the h2x block of layer l runs on the caller's stream
+    float* q2;
+    float* P3;
+    float* Qt3;
+    float* q3;
     int* act;        // indices of gen_flag nodes (h2x work list)
     int* act_count;
     uint8_t* mask;   // receptive-field pruning: reachability mask and the three node lists derived from it
@@ -73,6 +80,12 @@ static Workspace carve(void* base, int n) {
     w.P = (float*)take(N * PROW * 4);
     w.Qt = (float*)take(N * HEADS * H * 4);
     w.q = (float*)take(N * H * 4);
+    w.P2 = (float*)take(N * PROW * 4);
+    w.Qt2 = (float*)take(N * HEADS * H * 4);
+    w.q2 = (float*)take(N * H * 4);
+    w.P3 = (float*)take(N * PROW * 4);
+    w.Qt3 = (float*)take(N * HEADS * H * 4);
+    w.q3 = (float*)take(N * H * 4);
     w.act = (int*)take(N * 4);
     w.act_count = (int*)take(256);
     w.mask = (uint8_t*)take(N);
@@ -88,6 +101,30 @@ static Workspace carve(void* base, int n) {
     w.xbuf[1] = (float*)take(N * 3 * 4);
     w.total = off;
     return w;
+}
+
+// Auxiliary stream (one per host thread and device, created on first use) with the two events that fork it from and
+// join it back into the caller's stream.  The library stays re-entrant: nothing here is shared between host threads.
+struct AuxStream {
+    int dev = -1;
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static thread_local AuxStream g_aux;
+static bool aux_ready() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (g_aux.s && g_aux.dev == dev) return true;
+    if (g_aux.s) return false;   // one device per host thread (one process per GPU); otherwise stay serial
+    if (hipStreamCreateWithFlags(&g_aux.s, hipStreamNonBlocking) != hipSuccess) { g_aux.s = nullptr; return false; }
+    if (hipEventCreateWithFlags(&g_aux.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_aux.join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(g_aux.s);
+        g_aux.s = nullptr;
+        return false;
+    }
+    g_aux.dev = dev;
+    return true;
 }
 
 extern "C" {
@@ -410,15 +447,15 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
         HIP_TRY(launch_mark_nbr(w.fw_list[2], w.fw_count + 32, n_nodes, w.nbr, w.deg, w.fmask[1], s));      // S2
         HIP_TRY(launch_build_active(w.fmask[1], n_nodes, w.fw_list[3], w.fw_count + 48, s));
     }
-    const float* xc = x;
-    const float* hc = h;
-    for (int l = 0; l < num_layers; ++l) {
-        float* hn = (l == num_layers - 1 && h_out) ? h_out : w.hbuf[l & 1];
-        float* xn = (l == num_layers - 1) ? x_out : w.xbuf[l & 1];
-        const int *dst = nullptr, *dst_n = nullptr, *src = nullptr, *src_n = nullptr;
+    // Two-stream schedule (MFMA kernels, profiling off): the node stage of x2h(l+1) only needs h_{l+1}, which exists as
+    // soon as the x2h edge kernel of layer l has run, while the h2x block of layer l (which only moves coordinates) is
+    // still to come -- so it runs on an auxiliary stream next to that h2x block.  Three node-stage buffer sets: x2h
+    // alternates between two, h2x has its own.
+    static const bool overlap_env = [] { const char* e = getenv("CBGX_OVERLAP"); return !e || atoi(e) != 0; }();
+    const bool overlap = overlap_env && g_edge_impl == 0 && !profile_is_on() && num_layers > 1 && aux_ready();
+    auto layer_lists = [&](int l, const int*& dst, const int*& dst_n, const int*& src, const int*& src_n) {
+        dst = dst_n = src = src_n = nullptr;
         if (cached && l < 2) {
-            HIP_TRY(hipMemcpyAsync(hn, l == 0 ? static_h1 : static_h2, (size_t)n_nodes * H * sizeof(float),
-                                   hipMemcpyDeviceToDevice, s));
             dst = w.fw_list[2 * l]; dst_n = w.fw_count + 32 * l;
             src = w.fw_list[2 * l + 1]; src_n = w.fw_count + 32 * l + 16;
         }
@@ -427,10 +464,48 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
             dst = w.rf_list[k]; dst_n = w.rf_count + 16 * k;
             src = w.rf_list[k + 1]; src_n = w.rf_count + 16 * (k + 1);
         }
-        HIP_TRY(launch_attention(true, packed + x2h_off(l), xc, hc, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
-                                 w.P, w.Qt, w.q, hn, nullptr, dst, dst_n, src, src_n, s));
-        HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
-                                 w.P, w.Qt, w.q, xn, nullptr, w.act, w.act_count, w.rf_list[0], w.rf_count, s));
+    };
+    float* Pset[2] = {w.P, w.P2};
+    float* Qtset[2] = {w.Qt, w.Qt2};
+    float* qset[2] = {w.q, w.q2};
+    const float* xc = x;
+    const float* hc = h;
+    if (overlap) {
+        const int *dst, *dst_n, *src, *src_n;
+        layer_lists(0, dst, dst_n, src, src_n);
+        HIP_TRY(launch_node_mfma(packed + x2h_off(0), h, lig_flag, n_nodes, Pset[0], qset[0], Qtset[0], dst, dst_n, src,
+                                 src_n, s));
+    }
+    for (int l = 0; l < num_layers; ++l) {
+        float* hn = (l == num_layers - 1 && h_out) ? h_out : w.hbuf[l & 1];
+        float* xn = (l == num_layers - 1) ? x_out : w.xbuf[l & 1];
+        const int *dst, *dst_n, *src, *src_n;
+        layer_lists(l, dst, dst_n, src, src_n);
+        if (cached && l < 2)
+            HIP_TRY(hipMemcpyAsync(hn, l == 0 ? static_h1 : static_h2, (size_t)n_nodes * H * sizeof(float),
+                                   hipMemcpyDeviceToDevice, s));
+        if (!overlap) {
+            HIP_TRY(launch_attention(true, packed + x2h_off(l), xc, hc, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
+                                     w.P, w.Qt, w.q, hn, nullptr, dst, dst_n, src, src_n, s));
+            HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
+                                     w.P, w.Qt, w.q, xn, nullptr, w.act, w.act_count, w.rf_list[0], w.rf_count, s));
+        } else {
+            const int set = l & 1;
+            if (l > 0) HIP_TRY(hipStreamWaitEvent(s, g_aux.join, 0));       // node stage of this layer (aux stream) done
+            HIP_TRY(launch_edge_mfma(true, packed + x2h_off(l), xc, hc, Pset[set], Qtset[set], w.nbr, w.deg, lig_flag,
+                                     gen_flag, w.e_w, n_nodes, hn, nullptr, dst, dst_n, s));
+            if (l + 1 < num_layers) {
+                const int *d2, *d2n, *s2, *s2n;
+                layer_lists(l + 1, d2, d2n, s2, s2n);
+                HIP_TRY(hipEventRecord(g_aux.fork, s));
+                HIP_TRY(hipStreamWaitEvent(g_aux.s, g_aux.fork, 0));
+                HIP_TRY(launch_node_mfma(packed + x2h_off(l + 1), hn, lig_flag, n_nodes, Pset[set ^ 1], qset[set ^ 1],
+                                         Qtset[set ^ 1], d2, d2n, s2, s2n, g_aux.s));
+                HIP_TRY(hipEventRecord(g_aux.join, g_aux.s));
+            }
+            HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
+                                     w.P3, w.Qt3, w.q3, xn, nullptr, w.act, w.act_count, w.rf_list[0], w.rf_count, s));
+        }
         xc = xn;
         hc = hn;
     }

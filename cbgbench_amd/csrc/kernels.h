@@ -10,6 +10,7 @@ enum KernelClass { K_KNN = 0, K_GATE, K_NODE_GEMM, K_NODE_QUERY, K_EDGE_X2H, K_E
                    K_TRAIN_GEMM, K_NUM_CLASSES };
 void profile_mark_begin(int cls, hipStream_t s);
 void profile_mark_end(hipStream_t s);
+bool profile_is_on();
 
 hipError_t launch_knn(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, int32_t* nbr,
                       int32_t* deg, hipStream_t s);

@@ -31,6 +31,8 @@ void profile_mark_begin(int cls, hipStream_t s) {
     g_open = true;
 }
 
+bool profile_is_on() { return g_on.load(std::memory_order_relaxed) != 0; }
+
 void profile_mark_end(hipStream_t s) {
     if (!g_on.load(std::memory_order_relaxed)) return;
     std::lock_guard<std::mutex> lk(g_mu);
