@@ -70,11 +70,16 @@ def build_batch(pockets, samples, seed, num_classes=13):
 
 
 def make_model(device, T=1000):
-    from oracle import weights  # weight *generation* only (shared with the golden fixtures)
+    from cbgbench_amd import synthetic_weights
     model = C.get_model(C.default_targetdiff_config(13, 9, T)).eval()
-    sd = weights.synthetic_state_dict(13, 9, seed=0, num_timesteps=T)
-    model.load_state_dict(sd, strict=True)
-    return model.to(device), sd
+    synthetic_weights.fill_(model, seed=0)      # deterministic random-init weights (no checkpoints ship with the reference)
+    return model.to(device)
+
+
+def oracle_state_dict(T=1000):
+    """cpu_baseline leg only: the same synthetic weights in the oracle's state-dict form"""
+    from oracle import weights
+    return weights.synthetic_state_dict(13, 9, seed=0, num_timesteps=T)
 
 
 def _pick_cpu_threads(sd, seed):
@@ -162,7 +167,7 @@ def bench_train(args, rank, world, dev):
     """BASELINE configs[4] shape on the GPUs at hand: train.py semantics (forward, backward, gradient all-reduce, clip,
     Adam) with `--pockets` graphs per GPU per step (default 32)."""
     from cbgbench_amd import train as TRN
-    model, sd = make_model(dev)
+    model = make_model(dev)
     model.train()
     TRN.broadcast_parameters(model)
     fg = TRN.FlatGradients(model)
@@ -220,7 +225,7 @@ def bench_train(args, rank, world, dev):
             "per_kernel": per,
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_train_baseline(sd, seed=3000)
+        out["cpu_baseline"] = cpu_train_baseline(oracle_state_dict(), seed=3000)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -258,7 +263,7 @@ def main():
         args.pockets = 32 if args.workload == "train" else 10
     if args.workload == "train":
         return bench_train(args, rank, world, dev)
-    model, sd = make_model(dev)
+    model = make_model(dev)
     T = model.num_diffusion_timesteps
 
     if args.workload == "linker":
@@ -349,7 +354,7 @@ def main():
             "per_kernel": per,
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(sd, seed=1000)
+        out["cpu_baseline"] = cpu_baseline(oracle_state_dict(), seed=1000)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

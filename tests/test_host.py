@@ -339,3 +339,16 @@ def test_data_parallel_train_step_gloo_world2():
         opt.step()
     assert torch.allclose(model.lin.weight, torch.tensor(res[0][1]), atol=1e-6)
     assert model.lin.weight.grad.data_ptr() == fg.flat.data_ptr()     # gradients live in the one flat buffer
+
+
+def test_product_side_synthetic_weights_equal_the_oracle_generator():
+    """bench.py / smoke fill the GPU model with cbgbench_amd.synthetic_weights (no oracle import on the product side);
+    the oracle's own generator must give the same tensors, otherwise the cpu_baseline would time a different model"""
+    from cbgbench_amd import synthetic_weights
+    model = C.get_model(C.default_targetdiff_config(13))
+    synthetic_weights.fill_(model, seed=0)
+    sd = W.synthetic_state_dict(13, 9, seed=0)
+    msd = model.state_dict()
+    assert set(msd) == set(sd)
+    for k, v in sd.items():
+        assert torch.equal(msd[k], v), k
