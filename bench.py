@@ -10,7 +10,8 @@ pocket+ligand graphs.  Workload = BASELINE.json configs[1] ("configs/denovo, 100
 1000 steps, fp32, 1 MI355X"): each batch holds P pockets x S=10 samples of that pocket (sample.py:177
 replicates one pocket num_samples times; independent pockets are additionally batched together because
 one pocket's 10 graphs cannot fill 256 CUs).  Synthetic pockets (cbgbench_amd/synthetic.py), deterministic
-synthetic weights (oracle/weights.py generates them; they are *loaded*, the oracle does no compute here).
+synthetic weights (cbgbench_amd/synthetic_weights.py).  Default batch: 20 pockets x 10 samples = 200 graphs, ~100 k
+nodes per step (--pockets 10 for the 100-graph batches of the earlier profile rows).
 
 With N > 1 every rank owns its own pockets (weak scaling, no data-path collective); the
 timed region is bracketed by barrier + synchronize and the MAX over ranks is reported.
@@ -238,7 +239,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pockets", type=int, default=None, help="distinct pockets per batch (default 10; train: 32)")
+    ap.add_argument("--pockets", type=int, default=None,
+                    help="distinct pockets per batch (default 20 -> 200 graphs, ~100 k nodes per step; train: 32 graphs)")
     ap.add_argument("--samples", type=int, default=10, help="samples (graphs) per pocket")
     ap.add_argument("--workload", choices=["denovo", "linker", "train"], default="denovo",
                     help="denovo = BASELINE configs[1] (default); linker = configs[2]: --pockets distinct pockets, one "
@@ -260,7 +262,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.pockets is None:
-        args.pockets = 32 if args.workload == "train" else 10
+        args.pockets = 32 if args.workload == "train" else 20
     if args.workload == "train":
         return bench_train(args, rank, world, dev)
     model = make_model(dev)

@@ -12,8 +12,10 @@ echo "== pytest -m gpu =="
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -40 | tee $OUT/pytest_gpu_$TAG.log
 echo "== smoke =="
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke_$TAG.log
-echo "== bench default (10 pockets x 10 samples) =="
+echo "== bench default (20 pockets x 10 samples) =="
 timeout 600 python bench.py 2>&1 | tail -3 | tee $OUT/bench_$TAG.json
+echo "== bench 10 pockets x 10 samples (the batch most earlier rows were measured on) =="
+timeout 300 python bench.py --pockets 10 --no-cpu-baseline 2>&1 | tail -1 | tee $OUT/bench_p10_$TAG.json
 echo "== bench 1 pocket x 10 samples =="
 timeout 300 python bench.py --pockets 1 --no-cpu-baseline 2>&1 | tail -1 | tee $OUT/bench_p1_$TAG.json
 echo "== bench 1 pocket x 1 sample (config 1 shape) =="
