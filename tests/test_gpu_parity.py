@@ -418,3 +418,23 @@ def test_graph_replay_equals_eager_steps(golden_dir):
     # and sample(use_graph=True) returns the full trajectory
     traj = m.sample(batch, use_graph=True)
     assert sorted(traj.keys()) == list(range(-1, T)) and torch.isfinite(traj[-1][0]).all()
+
+
+def test_static_context_cache_edge_cases(model):
+    """cache exactness where its branches differ: a graph above the register-cached kNN size (900 atoms), a pocket with
+    fewer than 33 atoms (every atom keeps a fresh neighbour list), a graph without any ligand atom (fully cached)"""
+    rng = np.random.default_rng(123)
+    pockets = [synthetic.make_pocket(rng, 900, radius=14.0), synthetic.make_pocket(rng, 60, radius=6.0),
+               synthetic.make_pocket(rng, 20, radius=4.0), synthetic.make_pocket(rng, 400)]
+    batch = synthetic.batch_to(synthetic.make_batch(pockets, [12, 0, 5, 30], rng, 13), DEV)
+    n_lig = batch["ligand_pos"].shape[0]
+    g = torch.Generator(device=DEV).manual_seed(8)
+    noise = [(torch.randn(n_lig, 3, device=DEV, generator=g), torch.rand(n_lig, 13, device=DEV, generator=g)) for _ in range(2)]
+    outs = []
+    for cache in (True, False):
+        st = model.begin_sampling(batch, keep_trajectory=False, static_cache=cache)
+        for k, t in enumerate((999, 3)):
+            model.denoise_step(st, t, noise=noise[k])
+        outs.append((st["x_lig"].clone(), st["c_lig"].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[0][0]).all()
