@@ -303,6 +303,49 @@ def diffsbdd_case(name, *a, **k):
         _diffsbdd_case(name, *a, **k)
 
 
+def diffbp_train_case(name, batch, seed):
+    """DiffBP training step of the unmodified reference (diffbp.py:154-231; loss weights all 1,
+    configs/denovo/train/diffbp.yml:37-41): the four losses and the gradient of every trainable tensor."""
+    if not _selected(name):
+        return
+    M = ref_shim.load_reference()
+    T = 1000
+    cfg = ref_shim.AttrDict(
+        type="diffbp", num_atomtype=13,
+        encoder=dict(type="unitransformer", node_feat_dim=128, n_heads=16, num_layers=9),
+        generator=dict(pos_schedule=dict(type="sigmoid", beta_start=1.0e-7, beta_end=2.0e-3),
+                       atom_schedule=dict(type="uniform"), num_diffusion_timesteps=T, time_sampler="symmetric",
+                       com_schedule=dict(type="log", sigma_min=1.0e-7, sigma_max=5.0)),
+        embedder=dict(emb_dim=128, atom=dict(type="linear"), residue=dict(type="linear")))
+    model = M.get_model(cfg)
+    model.load_state_dict(W.synthetic_state_dict_diffbp(13, 9, seed=0, num_timesteps=T), strict=True)
+    model.train()
+    model.zero_grad()
+    bl = batch["ligand_element_batch"]
+    B = int(bl.max()) + 1
+    torch.manual_seed(seed)
+    loss_dict, _ = model(batch)
+    sum(loss_dict.values()).backward()
+    torch.manual_seed(seed)
+    draws = torch.randint(0, T, size=(B // 2 + 1,))
+    t = torch.cat([draws, T - draws - 1], 0)[:B]
+    eps = torch.randn_like(batch["ligand_pos"])
+    u = torch.rand(batch["ligand_pos"].shape[0])
+    out = {"seed": seed, "t": _np(t), "eps": _np(eps), "u": _np(u)}
+    for k, v in loss_dict.items():
+        out["loss_" + k] = _np(v)
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        out["gnorm/" + k] = np.float64(g.double().norm().item())
+        flat = g.reshape(-1)
+        out["g/" + k] = _np(flat if flat.numel() <= 2048 else flat[::61])
+    out.update({"batch_" + k: _np(v) for k, v in batch.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, {k: float(v) for k, v in loss_dict.items()}, "t", t.tolist())
+
+
 def priors_case(name):
     """Ligand-size prior of the reference (repo/datasets/transforms/init_lig.py:28-52,232-258): pocket size function and
     bin lookup on seeded pockets, the bin edges, and per-bin mean / support of the histogram table (the table itself is
@@ -376,6 +419,7 @@ def main():
     train_case(model, "train_loss_t0_linker", small_batch([(58, 15), (44, 12)], seed=62, ctx=[10, 8]), seed=16,
                t_override=torch.tensor([0, 700]))
     priors_case("priors_atom_num")
+    diffbp_train_case("train_loss_diffbp", small_batch([(64, 10), (50, 12), (57, 9)], seed=63), seed=17)
     sample_case("sample_T5", small_batch([(40, 8), (36, 6)], seed=31), T=5, seed=9)
     b = small_batch([(44, 9), (37, 8)], seed=51)
     b["ligand_atom_type"] = torch.zeros_like(b["ligand_atom_type"])        # absorbing-state prior (assign_atomtype: absorbing)

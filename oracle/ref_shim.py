@@ -165,8 +165,16 @@ def load_reference():
         assert flow == "source_to_target" and not loop
         return _knn(x, batch, k)
 
+    from oracle.diffbp import knn_cross as _knn_cross
+
+    def knn(x, y, k, batch_x=None, batch_y=None, **kw):
+        """torch_cluster.knn as called by interior_loss (diffbp.py:19): for every y the k nearest x of the same graph;
+        row 0 = y index, row 1 = x index"""
+        return _knn_cross(x, y, batch_x, batch_y, k)
+
     U.knn_graph = knn_graph
     DB.knn_graph = knn_graph
+    DB.knn = knn
     _LOADED = M
     return M
 

@@ -164,3 +164,24 @@ def test_training_loss_and_gradients_match_reference(golden_dir, synthetic_sd, c
     assert n == 8 + 6 + 9 * 36 + 4     # embedder, gate MLP, 9 layers x 6 MLPs x 6 tensors, classifier
     # the key bias of every attention cannot influence a softmax over the edges of one node
     assert float(g["gnorm/denoiser.blocks.3.x2h_layers.0.hk_func.net.3.bias"]) < 1e-6
+
+
+def test_diffbp_training_loss_and_gradients_match_reference(golden_dir):
+    """DiffBP training objective (diffbp.py:154-231 incl. CoMPredictor and interior_loss): the reference's four losses and
+    the gradients of all 400+ tensors vs autograd on the restatement"""
+    from oracle import diffbp as OD
+    g = load(golden_dir, "train_loss_diffbp")
+    batch = golden_batch(g)
+    sd = W.synthetic_state_dict_diffbp(13, 9, seed=0, num_timesteps=1000)
+    losses, grads = OD.loss_and_grads(sd, batch, g["t"], g["eps"], g["u"], 13, 1000)
+    for k in ("pos", "atom", "com", "inter"):
+        assert abs(float(losses[k]) - g["loss_" + k]) <= 1e-6 * abs(g["loss_" + k]) + 1e-7, k
+    n = 0
+    for k, gr in grads.items():
+        ref_norm = float(g["gnorm/" + k])
+        assert abs(gr.double().norm().item() - ref_norm) <= 1e-5 * ref_norm + 1e-8, k
+        flat = gr.reshape(-1)
+        sample = flat if flat.numel() <= 2048 else flat[::61]
+        torch.testing.assert_close(sample, g["g/" + k], rtol=1e-4, atol=1e-8 + 1e-5 * ref_norm / max(flat.numel(), 1) ** 0.5)
+        n += 1
+    assert n == 8 + 6 + 9 * 36 + 4 + (6 + 3 * 18)
