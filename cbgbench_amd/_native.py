@@ -43,6 +43,10 @@ EXPORTS = {
                                          ctypes.POINTER(_vp), _vp, _sz, _vp]),
     "cbgx_h2x_attention_backward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
                                          ctypes.POINTER(_vp), _vp, _sz, _vp]),
+    "cbgx_h2x_stack_tape_bytes": (_sz, [_i, _i]),
+    "cbgx_h2x_stack_forward_train": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "cbgx_h2x_stack_backward": (_i, [_vp, _i, _vp, _sz, _vp, _vp, _vp, _i, _vp, ctypes.POINTER(_vp), _i, _vp, _vp, _sz,
+                                     _vp]),
     "cbgx_debug_set_edge_kernel": (_i, [_i]),
     "cbgx_profile_begin": (_i, [_i]),
     "cbgx_profile_end": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i), _i]),

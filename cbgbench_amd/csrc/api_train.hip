@@ -423,4 +423,95 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
     return CBGX_OK;
 }
 
+// ---- a stack of H2X blocks on its own graph (DiffBP's CoMPredictor, diffbp.py:30-101): taped forward + backward -------
+size_t cbgx_h2x_stack_tape_bytes(int n_nodes, int num_layers) {
+    if (n_nodes < 0 || num_layers < 1) return 0;
+    const size_t N = (size_t)(n_nodes > 0 ? n_nodes : 1);
+    return align_up(N * KNN * 4) + align_up(N * 4) + align_up(N * KNN * 4) + align_up((size_t)(num_layers + 1) * N * 3 * 4);
+}
+
+struct StackTape { int32_t* nbr; int32_t* deg; float* e_w; float* xs; };
+static StackTape carve_stack_tape(void* base, int n) {
+    StackTape t;
+    char* b = (char*)base;
+    size_t off = 0;
+    const size_t N = (size_t)(n > 0 ? n : 1);
+    t.nbr = (int32_t*)(b + off); off += align_up(N * KNN * 4);
+    t.deg = (int32_t*)(b + off); off += align_up(N * 4);
+    t.e_w = (float*)(b + off); off += align_up(N * KNN * 4);
+    t.xs = (float*)(b + off);
+    return t;
+}
+
+int cbgx_h2x_stack_forward_train(const float* packed, int num_layers, const float* x, const float* h,
+                                 const int32_t* graph_ptr, const uint8_t* lig_flag, const uint8_t* gen_flag, int n_nodes,
+                                 int n_graphs, float* x_out, void* tape, size_t tape_bytes, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (n_nodes <= 0 || n_graphs < 1 || num_layers < 1) return set_error(CBGX_E_INVALID, "h2x_stack_forward_train: bad sizes");
+    if (!packed || !x || !h || !graph_ptr || !lig_flag || !gen_flag || !x_out || !tape || !workspace)
+        return set_error(CBGX_E_INVALID, "h2x_stack_forward_train: NULL pointer");
+    if (tape_bytes < cbgx_h2x_stack_tape_bytes(n_nodes, num_layers))
+        return set_error(CBGX_E_WORKSPACE, "h2x_stack_forward_train: tape too small");
+    TrainWs w = carve_train(workspace, n_nodes);
+    if (workspace_bytes < w.total)
+        return set_error(CBGX_E_WORKSPACE, "h2x_stack_forward_train: workspace %zu < %zu", workspace_bytes, w.total);
+    StackTape tp = carve_stack_tape(tape, n_nodes);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nx = (size_t)n_nodes * 3;
+    HIP_TRY(hipMemcpyAsync(tp.xs, x, nx * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, tp.nbr, tp.deg, s));
+    HIP_TRY(launch_gate(packed, x, tp.nbr, tp.deg, n_nodes, tp.e_w, s));
+    HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, s));
+    for (int l = 0; l < num_layers; ++l)
+        HIP_TRY(launch_attention(false, packed + GATE_SIZE + (size_t)l * ATT_SIZE, tp.xs + (size_t)l * nx, h, tp.nbr, tp.deg,
+                                 lig_flag, gen_flag, tp.e_w, n_nodes, w.P, w.Qt, w.qs, tp.xs + (size_t)(l + 1) * nx, nullptr,
+                                 w.act, w.act_count, nullptr, nullptr, s));
+    HIP_TRY(hipMemcpyAsync(x_out, tp.xs + (size_t)num_layers * nx, nx * 4, hipMemcpyDeviceToDevice, s));
+    return CBGX_OK;
+}
+
+int cbgx_h2x_stack_backward(const float* packed, int num_layers, const void* tape, size_t tape_bytes, const float* h,
+                            const uint8_t* lig_flag, const uint8_t* gen_flag, int n_nodes, const float* grad_x_out,
+                            float* const* grads, int num_grads, float* grad_h, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+    if (n_nodes <= 0 || num_layers < 1) return set_error(CBGX_E_INVALID, "h2x_stack_backward: bad sizes");
+    if (!packed || !tape || !h || !lig_flag || !gen_flag || !grad_x_out || !grad_h || !workspace)
+        return set_error(CBGX_E_INVALID, "h2x_stack_backward: NULL pointer");
+    if (num_grads != 6 + 18 * num_layers)
+        return set_error(CBGX_E_INVALID, "h2x_stack_backward: expected %d gradient tensors, got %d", 6 + 18 * num_layers, num_grads);
+    RC_TRY(check_grads(grads, num_grads, "h2x_stack_backward"));
+    if (tape_bytes < cbgx_h2x_stack_tape_bytes(n_nodes, num_layers))
+        return set_error(CBGX_E_WORKSPACE, "h2x_stack_backward: tape too small");
+    TrainWs w = carve_train(workspace, n_nodes);
+    if (workspace_bytes < w.total)
+        return set_error(CBGX_E_WORKSPACE, "h2x_stack_backward: workspace %zu < %zu", workspace_bytes, w.total);
+    StackTape tp = carve_stack_tape((void*)tape, n_nodes);
+    hipStream_t s = (hipStream_t)stream;
+    const int n = n_nodes;
+    const size_t nx = (size_t)n * 3, nh = (size_t)n * H;
+    HIP_TRY(hipMemsetAsync(w.gh, 0, nh * 4, s));
+    int cur = 0;
+    HIP_TRY(hipMemcpyAsync(w.gx[cur], grad_x_out, nx * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(w.de_w, 0, (size_t)n * KNN * 4, s));
+    HIP_TRY(launch_build_active(gen_flag, n, w.act, w.act_count, s));
+    for (int l = num_layers - 1; l >= 0; --l) {
+        const int nxt = cur ^ 1;
+        HIP_TRY(hipMemcpyAsync(w.gx[nxt], w.gx[cur], nx * 4, hipMemcpyDeviceToDevice, s));      // x_out = x + gen * delta
+        RC_TRY(attention_block_backward(false, packed + GATE_SIZE + (size_t)l * ATT_SIZE, tp.xs + (size_t)l * nx, h, w.gx[cur],
+                                        tp.nbr, tp.deg, lig_flag, tp.e_w, w.act, w.act_count, n, w, w.gh, w.gx[nxt], w.de_w,
+                                        grads + 6 + 18 * l, s));
+        cur = nxt;
+    }
+    HIP_TRY(hipMemcpyAsync(grad_h, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(launch_gate_backward(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.E8, w.partial, GATE_GRID, s));
+    FOLDED(w.partial, GATE_GRID, GB_SIZE, GB_SIZE);
+    RS(fz + GB_W1, fn, fs, G, GH, G, grads[0], G, 0);
+    RS(fz + GB_B1, fn, fs, GH, 1, GH, grads[1], GH, 0);
+    RS(fz + GB_LNG, fn, fs, GH, 1, GH, grads[2], GH, 0);
+    RS(fz + GB_LNB, fn, fs, GH, 1, GH, grads[3], GH, 0);
+    RS(fz + GB_W2, fn, fs, GH, 1, GH, grads[4], GH, 0);
+    RS(fz + GB_B2, fn, fs, 1, 1, 1, grads[5], 1, 0);
+    return CBGX_OK;
+}
+
 }  // extern "C"

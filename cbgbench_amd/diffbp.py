@@ -15,7 +15,7 @@ from torch import nn
 
 from . import _native
 from .registry import get_e3_gnn, register_model
-from .targetdiff import NUM_AA, CTNVPScheduler, PLContextEmbedder, TargetDiff
+from .targetdiff import NUM_AA, CTNVPScheduler, PLContextEmbedder, TargetDiff, scatter_mean
 from .unitransformer import GaussianSmearing, H2XAttention, MLP, _MLP_KEYS
 
 ABSORBING_STATE = 0   # repo/utils/molecule/constants.py:8
@@ -31,6 +31,27 @@ class MaskTypeSchedule(nn.Module):
         self.absorbing_state = absorbing_state
         self.schedule_type = type
 
+    def forward_add_noise(self, v_0, t, batch_idx, gen_flag, eps=None, uniform=None):
+        """mask with probability t / T (:452-473).  Returns (v_t, c_t, diff_mask) -- in this order, which DiffBP.get_loss
+        unpacks as (c, v, flag); the embedder accepts either indices or one-hot."""
+        tb = t[batch_idx]
+        prob = eps if eps is not None else tb.view(-1).float().clamp(min=0.0) / self.num_timestep
+        if uniform is None:
+            uniform = torch.rand_like(v_0.float())
+        diff_mask = (uniform < prob) & gen_flag.bool()
+        v_t = torch.where(diff_mask, torch.full_like(v_0, self.absorbing_state), v_0)
+        return v_t, F.one_hot(v_t, num_classes=self.num_classes).float(), diff_mask
+
+    def get_loss(self, c_pred, v0, vt, t, gen_flag, batch_idx, pred_logit=True):
+        """:499-511 -- note the reference feeds the softmax *output* to cross_entropy; reproduced as is."""
+        if pred_logit:
+            c_pred = F.softmax(c_pred, dim=-1)
+        loss_v = F.cross_entropy(c_pred, v0, reduction="none")
+        info = {"v0": v0, "vt": vt, "c_pred": c_pred, "mask_gen": gen_flag}
+        if not bool(gen_flag.any()):
+            return torch.zeros_like(v0).float().mean(), info
+        return scatter_mean(loss_v[gen_flag], batch_idx[gen_flag]).mean(), info
+
     def backward_remove_noise(self, c_pred, ct, t, batch_idx, gen_flag, pred_logit=True, fix_pred=True, uniform=None):
         """Unmask with probability (T - t) / T: masked, generated atoms take the predicted argmax (:475-496)."""
         if pred_logit:
@@ -45,6 +66,54 @@ class MaskTypeSchedule(nn.Module):
             change = change & (vt == self.absorbing_state)
         v_next = torch.where(change, c_pred.argmax(-1), vt)
         return F.one_hot(v_next, num_classes=self.num_classes).float(), v_next
+
+
+class _H2XStackFunction(torch.autograd.Function):
+    """taped forward / hand-written backward of the H2X stack (cbgx_h2x_stack_forward_train / _backward); gradients flow
+    to h (the denoiser's output features) and to the stack's parameters, not to the input coordinates (data)."""
+
+    @staticmethod
+    def forward(ctx, module, x, h, graph_ptr, lig, gen, *params):
+        dev = x.device
+        N, B, L = x.shape[0], graph_ptr.numel() - 1, module.num_layers
+        lib = _native.lib()
+        packed = module.packed_weights(dev)
+        tape = torch.empty(lib.cbgx_h2x_stack_tape_bytes(N, L), dtype=torch.uint8, device=dev)
+        ws = module.train_workspace(N, dev)
+        x_out = torch.empty_like(x)
+        rc = lib.cbgx_h2x_stack_forward_train(
+            _native.ptr(packed), L, _native.ptr(x), _native.ptr(h), _native.ptr(graph_ptr), _native.ptr(lig),
+            _native.ptr(gen), N, B, _native.ptr(x_out), _native.ptr(tape), tape.numel(), _native.ptr(ws), ws.numel(),
+            _native.current_stream(dev))
+        _native.check(rc, "cbgx_h2x_stack_forward_train")
+        ctx.module, ctx.tape, ctx.packed, ctx.flags, ctx.h = module, tape, packed, (lig, gen), h
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        return x_out
+
+    @staticmethod
+    def backward(ctx, gx):
+        module, dev = ctx.module, ctx.tape.device
+        lig, gen = ctx.flags
+        N, L = ctx.h.shape[0], module.num_layers
+        sizes = [int(torch.Size(s).numel()) for s in ctx.param_shapes]
+        direct = module._direct_grads
+        if direct:
+            views = [p.grad for p in module._ordered_params()]
+            if any(v is None or not v.is_contiguous() or v.dtype != torch.float32 or v.device != dev for v in views):
+                direct = False
+        if not direct:
+            views = list(torch.empty(sum(sizes), dtype=torch.float32, device=dev).split(sizes))
+        arr = (ctypes.c_void_p * len(views))(*[v.data_ptr() for v in views])
+        gh = torch.empty(N, module.hidden_dim, dtype=torch.float32, device=dev)
+        ws = module.train_workspace(N, dev)
+        rc = _native.lib().cbgx_h2x_stack_backward(
+            _native.ptr(ctx.packed), L, _native.ptr(ctx.tape), ctx.tape.numel(), _native.ptr(ctx.h), _native.ptr(lig),
+            _native.ptr(gen), N, _native.ptr(gx.contiguous().float()), arr, len(views), _native.ptr(gh), _native.ptr(ws),
+            ws.numel(), _native.current_stream(dev))
+        _native.check(rc, "cbgx_h2x_stack_backward")
+        if direct:
+            return (None, None, gh, None, None, None) + (None,) * len(views)
+        return (None, None, gh, None, None, None, *[v.view(s) for v, s in zip(views, ctx.param_shapes)])
 
 
 class CoMPredictor(nn.Module):
@@ -70,6 +139,16 @@ class CoMPredictor(nn.Module):
         self._packed = None
         self._packed_key = None
         self._workspace = None
+        self._train_workspace = None
+        self._direct_grads = False     # set by cbgbench_amd.train.FlatGradients
+
+    def train_workspace(self, n_nodes, device):
+        need = _native.lib().cbgx_train_workspace_bytes(n_nodes)
+        ws = self._train_workspace
+        if ws is None or ws.numel() < need or ws.device != device:
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._train_workspace = ws
+        return ws
 
     def _ordered_params(self):
         sd = dict(self.named_parameters())
@@ -112,6 +191,12 @@ class CoMPredictor(nn.Module):
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
         x_in = x_composed.detach().float().contiguous()
+        if torch.is_grad_enabled() and (h_composed.requires_grad or any(p.requires_grad for p in self.parameters())):
+            x_out = _H2XStackFunction.apply(self, x_in, h_composed.float().contiguous(), graph_ptr,
+                                            lig_flag_composed.to(torch.uint8).contiguous(),
+                                            gen_flag_composed.to(torch.uint8).contiguous(), *self._ordered_params())
+            delta = (x_out - x_in)[lig_flag_composed]
+            return noise, _S.scatter_mean(delta, batch_idx_lig, B)[batch_idx_lig]
         h_in = h_composed.detach().float().contiguous()
         x_out = torch.empty_like(x_in)
         rc = lib.cbgx_h2x_stack_forward(
@@ -146,8 +231,85 @@ class DiffBP(nn.Module):
         self.com_head = CoMPredictor(cfg.encoder)
         self.intersect_reg = cfg.get("intersect_reg", True)
 
-    def forward(self, batch):
-        raise NotImplementedError("training loss (diffbp.py:131-234) needs the backward kernels (DESIGN.md section 8)")
+    # ---- training (diffbp.py:131-234) -------------------------------------------------------------------------
+    def sample_time(self, batch_size, device="cuda", draws=None):
+        T = self.num_diffusion_timesteps
+        if draws is None:
+            draws = torch.randint(0, T, size=(batch_size // 2 + 1,), device=device)
+        draws = draws.to(device)
+        return torch.cat([draws, T - draws - 1], 0)[:batch_size]         # 'symmetric' (_base.py:21-28)
+
+    def forward(self, batch, t=None, noise=None):
+        """``loss_dict, results = model(batch)``: {'pos', 'atom', 'com', 'inter'} (all weights 1 in
+        configs/denovo/train/diffbp.yml:37-41).  ``t`` / ``noise=(eps [N_lig,3], u [N_lig])`` replay the draws in tests."""
+        bl = batch["ligand_element_batch"]
+        B = int(bl.max().item()) + 1
+        dev = batch["ligand_pos"].device
+        if self.training or t is not None:
+            if t is None:
+                t = self.sample_time(B, device=dev)
+            return self.get_loss(batch, t, noise)
+        import numpy as np
+        dicts, results = [], []
+        for tv in np.linspace(0, self.num_diffusion_timesteps - 1, self.cfg.get("eval_interval", 10)):
+            ld, res = self.get_loss(batch, torch.tensor([tv] * B).long().to(dev), None)
+            dicts.append(ld)
+            results.append(res)
+        return {k: torch.stack([d[k] for d in dicts]).mean() for k in dicts[0]}, results
+
+    @staticmethod
+    def interior_loss(x_ligand, x_protein, batch_ligand, batch_protein, k=48, rho=2.0, gamma=5.0):
+        """diffbp.py:18-28: every protein atom looks at its k nearest ligand atoms of the same graph (all of them when the
+        ligand has at most k atoms); dense [N_rec, max ligand size] distances instead of torch_cluster.knn."""
+        n_lig = x_ligand.shape[0]
+        B = int(max(batch_ligand.max(), batch_protein.max()).item()) + 1
+        counts = torch.bincount(batch_ligand, minlength=B)
+        start = torch.cumsum(counts, 0) - counts
+        lmax = int(counts.max().item())
+        slot = torch.arange(lmax, device=x_ligand.device)[None, :]
+        cnt_p = counts[batch_protein][:, None]
+        valid = slot < cnt_p
+        idx = (start[batch_protein][:, None] + slot).clamp(max=n_lig - 1)
+        d2 = ((x_ligand[idx] - x_protein[:, None, :]) ** 2).sum(-1)
+        d2 = torch.where(valid, d2, torch.full_like(d2, float("inf")))
+        if lmax > k:
+            kth = torch.topk(d2, k, dim=1, largest=False).values[:, -1:]
+            valid = valid & (d2 <= kth)
+        e = torch.where(valid, (-d2 / rho).exp(), torch.zeros_like(d2))
+        acc = torch.zeros(n_lig, dtype=x_ligand.dtype, device=x_ligand.device).index_add(0, idx.reshape(-1), e.reshape(-1))
+        loss_per_ligand = -rho * (acc + 1e-3).log()
+        return torch.clamp(gamma - loss_per_ligand, min=0.0).mean()
+
+    def get_loss(self, batch, t, noise=None):
+        x0 = batch["ligand_pos"].float()
+        v0 = batch["ligand_atom_type"]
+        x_rec = batch["protein_pos"].float()
+        lig_flag_l = batch["ligand_lig_flag"]
+        gen_l = batch.get("ligand_gen_flag", lig_flag_l).bool()
+        gen_r = batch.get("protein_gen_flag", torch.zeros_like(batch["protein_lig_flag"])).bool()
+        bl, br = batch["ligand_element_batch"], batch["protein_element_batch"]
+        eps, u = noise if noise is not None else (None, None)
+        x_t, pos_noise, com_noise = self.pos_scheduler.forward_add_noise(x0, t, bl, gen_l, noise=eps, zero_center=True)
+        v_t, c_t, type_flag = self.type_scheduler.forward_add_noise(v0, t, bl, gen_l, uniform=u)
+        aa = F.one_hot(batch["protein_aa_type"], NUM_AA).float()
+        h_lig = self.context_embedder.embed_ligand(c_t)
+        h_rec = self.context_embedder.embed_protein(batch["protein_atom_feature"].float(), aa)
+        sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = TargetDiff.compose_plan(bl, br, int(t.shape[0]))
+        x = torch.cat([x_rec, x_t], 0)[sort_idx]
+        h = torch.cat([h_rec, h_lig], 0)[sort_idx]
+        gen_flag = torch.cat([gen_r, gen_l], 0)[sort_idx]
+        xo, ho, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
+                                       graph_ptr=graph_ptr)
+        x_lig_pred, x_com_pred = self.com_head(xo[lig_rows], bl, x, ho, gen_flag, lig_flag, batch_idx, graph_ptr=graph_ptr)
+        loss_pos, pos_info = self.pos_scheduler.get_score_loss(x_lig_pred, pos_noise, t, gen_l, bl, score_in=False)
+        loss_com, com_info = self.pos_scheduler.get_score_loss(x_com_pred, com_noise, t, gen_l, bl, score_in=False,
+                                                               info_tag="com")
+        loss_atom, atom_info = self.type_scheduler.get_loss(logits[lig_rows], v0, c_t, t, type_flag, bl, pred_logit=True)
+        xs = self.pos_scheduler.xs_mean(x_lig_pred + x_com_pred, x_t, t, bl, gen_flag=gen_l)
+        loss_inter = self.interior_loss(xs, x_rec, bl, br)
+        results = {}
+        results.update(pos_info); results.update(atom_info); results.update(com_info)
+        return {"pos": loss_pos, "atom": loss_atom, "com": loss_com, "inter": loss_inter}, results
 
     @torch.no_grad()
     def sample(self, batch, noise_tape=None, return_device=None):

@@ -104,6 +104,29 @@ class CTNVPScheduler(VPSchedule):
             return out, noise - com, com
         return out, noise
 
+    def get_score_loss(self, pred, tgt, t, gen_flag, batch_idx, score_in=False, info_tag=None):
+        """noise-prediction loss of DiffBP (diffusion_scheduler.py:203-218)"""
+        a = self.alphas_cumprod.index_select(0, t)[batch_idx][:, None].expand_as(pred)
+        sigma = (1 - a).sqrt()
+        noise = tgt / sigma if score_in else tgt
+        mse = ((pred - noise) ** 2).sum(-1)
+        loss = scatter_mean(mse[gen_flag], batch_idx[gen_flag])
+        info = {"eps_0": noise, "eps_pred": pred, "score_0": noise * sigma, "score_pred": pred * sigma, "mask_gen": gen_flag}
+        if info_tag is not None:
+            info = {k + "_{}".format(info_tag): v for k, v in info.items()}
+        return loss.mean(), info
+
+    def xs_mean(self, x_pred, x_noisy, t, batch_idx, gen_flag, type="score"):
+        """mean of the reverse step (diffusion_scheduler.py:166-183)"""
+        a = self.alphas_cumprod.index_select(0, t)[:, None][batch_idx].expand_as(x_noisy)
+        b = self.betas.index_select(0, t)[:, None][batch_idx].expand_as(x_noisy)
+        if type == "score":
+            xs = (x_noisy + b * (-x_pred / (1 - a).sqrt())) / (1 - b).sqrt()
+        else:
+            xs = (self.posterior_mean_c0_coef[t][batch_idx][:, None] * x_pred
+                  + self.posterior_mean_ct_coef[t][batch_idx][:, None] * x_noisy)
+        return torch.where(gen_flag.unsqueeze(-1), xs, x_noisy)
+
     def get_loss(self, x_pred, x0, xt, t, gen_flag, batch_idx, type="score"):
         """per-graph mean squared error, averaged over graphs (diffusion_scheduler.py:185-201)."""
         if type == "score":

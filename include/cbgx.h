@@ -216,6 +216,21 @@ int cbgx_h2x_attention_backward(const float *packed, int layer, const float *x, 
                                 float *grad_h, float *grad_x, float *grad_e_w, float *const *grads, void *workspace,
                                 size_t workspace_bytes, void *stream);
 
+/* The same pair for a stack of H2X blocks on its own graph: DiffBP's CoMPredictor inside `DiffBP.get_loss`
+ * (repo/models/diffusion/diffbp.py:79-101, 195-198).  The tape holds the stack's kNN lists, gate and per-layer
+ * coordinates; h is the same tensor in every layer.  backward: grad_x_out [N,3] -> grad_h [N,128] (overwritten) and
+ * `grads` = 6 + 18*L DEVICE pointers in the order of cbgx_pack_h2x_stack's `tensors`, each overwritten.  No gradient for the
+ * input coordinates (they are the noised data). */
+size_t cbgx_h2x_stack_tape_bytes(int n_nodes, int num_layers);
+int cbgx_h2x_stack_forward_train(const float *packed, int num_layers, const float *x, const float *h,
+                                 const int32_t *graph_ptr, const uint8_t *lig_flag, const uint8_t *gen_flag,
+                                 int n_nodes, int n_graphs, float *x_out, void *tape, size_t tape_bytes,
+                                 void *workspace, size_t workspace_bytes, void *stream);
+int cbgx_h2x_stack_backward(const float *packed, int num_layers, const void *tape, size_t tape_bytes, const float *h,
+                            const uint8_t *lig_flag, const uint8_t *gen_flag, int n_nodes, const float *grad_x_out,
+                            float *const *grads, int num_grads, float *grad_h, void *workspace,
+                            size_t workspace_bytes, void *stream);
+
 /* ---- measurement hook (bench.py) ----------------------------------------------------------------
  * Between cbgx_profile_begin() and cbgx_profile_end() every kernel launch is bracketed by HIP events on
  * its own stream.  cbgx_profile_end() synchronises them and returns, per kernel class, the summed

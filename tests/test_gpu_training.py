@@ -197,3 +197,38 @@ def test_direct_gradient_write_equals_autograd_accumulation(synthetic_sd):
         grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.requires_grad]).clone())
     # identical kernels either way; only the atomics' summation order can differ between two runs
     assert torch.allclose(grads[0], grads[1], rtol=1e-4, atol=1e-6 * float(grads[0].abs().max()))
+
+
+def test_diffbp_training_step_matches_reference_gradients(golden_dir):
+    """DiffBP: denoiser + CoMPredictor (H2X stack with its own graph) + score / mask-type / COM / interior losses;
+    losses and the gradients of all 404 tensors against the unmodified reference's ``model(batch); loss.backward()``"""
+    from oracle import weights as W
+    g = load(golden_dir, "train_loss_diffbp")
+    m = C.get_model(C.default_diffbp_config(13))
+    m.load_state_dict(W.synthetic_state_dict_diffbp(13, 9, seed=0, num_timesteps=1000), strict=True)
+    m = m.to(DEV).train()
+    batch = golden_batch(g, DEV)
+    ld, _ = m(batch, t=g["t"].to(DEV), noise=(g["eps"].to(DEV), g["u"].to(DEV)))
+    for k in ("pos", "atom", "com", "inter"):
+        assert abs(float(ld[k].detach()) - g["loss_" + k]) <= 2e-4 * abs(g["loss_" + k]) + 1e-6, (k, float(ld[k].detach()), g["loss_" + k])
+    sum(ld.values()).backward()
+    torch.cuda.synchronize()
+    n = 0
+    for k, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        ref_norm = float(g["gnorm/" + k])
+        assert p.grad is not None, k
+        flat = p.grad.detach().cpu().reshape(-1)
+        if ref_norm < 1e-7:
+            assert float(flat.abs().max()) < 1e-6, k
+            n += 1
+            continue
+        assert abs(float(flat.double().norm()) - ref_norm) <= 1e-3 * ref_norm, (k, float(flat.double().norm()), ref_norm)
+        sample = flat if flat.numel() <= 2048 else flat[::61]
+        ref = g["g/" + k]
+        err = (sample.double() - ref.double()).abs()
+        tol = 1e-3 * ref.double().abs() + 5e-3 * ref_norm / max(flat.numel(), 1) ** 0.5   # 0.5 % of the tensor's RMS
+        assert bool((err <= tol).all()), f"{k}: max err {err.max():.3e} vs norm {ref_norm:.3e}"
+        n += 1
+    assert n == 8 + 6 + 9 * 36 + 4 + (6 + 3 * 18)
