@@ -7,6 +7,8 @@ around it is element-wise work on [N_lig,3] / [N_lig,C] and stays PyTorch on the
 Sampler semantics reproduced from the reference (quirks included, see oracle/diffsbdd.py): continuous atom
 types normalised by 4, the pocket re-centred on the ligand mean at every Gaussian draw (COM-free subspace), every
 ligand atom updated, ``traj[0]`` overwritten by the final ``sample_p_xh_given_z0`` result."""
+import math
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -41,7 +43,7 @@ class PredefinedNoiseSchedule(nn.Module):
 
 
 class DiffsbddVariationalScheduler(nn.Module):
-    """The sampling half of the reference scheduler (diffusion_scheduler.py:577-760, 965-1040)."""
+    """The reference scheduler (diffusion_scheduler.py:577-1040): sampling half and the training loss."""
 
     def __init__(self, num_timestep, type="polynomial_2"):
         super().__init__()
@@ -60,6 +62,63 @@ class DiffsbddVariationalScheduler(nn.Module):
     def remove_mean_batch(self, x_lig, x_rec, bl, br, B):
         mean = self.scatter_mean(x_lig, bl, B)
         return x_lig - mean[bl], x_rec - mean[br]
+
+    # ---- training side (diffusion_scheduler.py:740-960) ----
+    def alpha(self, gamma):
+        return torch.sqrt(torch.sigmoid(-gamma))
+
+    def sigma(self, gamma):
+        return torch.sqrt(torch.sigmoid(gamma))
+
+    def forward_pos_center_noise(self, x_lig, x_rec, t, bl, br, B, gen_flag, noise=None):
+        """q(z_t | x) for the coordinates with the pocket re-centred on the noisy ligand (:740-763, zero_center=False)"""
+        if noise is None:
+            noise = torch.randn_like(x_lig)
+        g = self.gamma(t).view(B, 1)
+        x_noisy = self.alpha(g)[bl] * x_lig + self.sigma(g)[bl] * noise
+        x_noisy, x_rec = self.remove_mean_batch(x_noisy, x_rec.detach().clone(), bl, br, B)
+        return torch.where(gen_flag.unsqueeze(-1), x_noisy, x_lig), noise, x_rec
+
+    def forward_type_add_noise(self, c, t, bl, B, gen_flag, noise=None):
+        if noise is None:
+            noise = torch.randn_like(c)
+        g = self.gamma(t).view(B, 1)
+        c_noisy = self.alpha(g)[bl] * c + self.sigma(g)[bl] * noise
+        return torch.where(gen_flag.unsqueeze(-1), c_noisy, c), noise
+
+    @staticmethod
+    def sum_except_batch(x, index, n):
+        return torch.zeros(n, dtype=x.dtype, device=x.device).index_add(0, index, x.sum(-1))
+
+    def kl_prior(self, x, bl, B, dimensions):
+        g_T = self.gamma(torch.ones(B, 1, device=x.device)).view(B, 1)
+        mu = self.alpha(g_T)[bl] * x
+        sigma_T = self.sigma(g_T).view(B)
+        mu2 = self.sum_except_batch(mu ** 2, bl, B)
+        d = dimensions
+        return d * torch.log(1.0 / sigma_T) + 0.5 * (d * sigma_T ** 2 + mu2) - 0.5 * d
+
+    def get_score_loss(self, pred, tgt, t, gen_flag, batch_idx, B, t_is_zero, x_lig_0=None, c_lig_0=None, c_lig_t=None):
+        """training-mode loss (:886-900, 930-945): per graph  0.5 sum(err^2) [t != 0] / (n dim)  +  -log p(. | z_0) [t == 0]
+        + KL prior;  mean over graphs.  Continuous reconstruction term for coordinates, discretised Gaussian for types."""
+        bl = batch_idx
+        n = torch.bincount(bl, minlength=B)
+        err = self.sum_except_batch((tgt - pred) ** 2, bl, B)
+        loss_t = 0.5 * err * (1.0 - t_is_zero) / (n * pred.shape[-1])
+        if x_lig_0 is not None:
+            loss_0 = 0.5 * err * t_is_zero
+            kl = self.kl_prior(x_lig_0, bl, B, (n - 1) * 3)
+        else:
+            g_t = self.gamma(t).view(B, 1)
+            sigma0 = self.sigma(g_t) * 4.0
+            centred = c_lig_t * 4.0 - 1.0
+            cdf = lambda v: 0.5 * (1.0 + torch.erf(v / math.sqrt(2.0)))
+            logp = torch.log(cdf((centred + 0.5) / sigma0[bl]) - cdf((centred - 0.5) / sigma0[bl]) + 1e-10)
+            logp = logp - torch.logsumexp(logp, dim=1, keepdim=True)
+            loss_0 = -self.sum_except_batch(logp * (c_lig_0 * 4.0), bl, B) * t_is_zero
+            kl = self.kl_prior(c_lig_0, bl, B, 1)
+        info = {"eps_0": tgt, "eps_pred": pred, "mask_gen": gen_flag}
+        return (loss_t + loss_0 + kl).mean(), info
 
     def sample_normal_zero_com(self, mu_lig, xh0_pocket, sigma, bl, br, B, com=False, eps=None):
         if eps is None:
@@ -99,8 +158,54 @@ class DiffSBDD(nn.Module):
         self.denoiser = get_e3_gnn(cfg.encoder, num_classes=self.num_classes)
         self.intersect_reg = cfg.get("intersect_reg", True)
 
-    def forward(self, batch):
-        raise NotImplementedError("training loss (diffsbdd.py:100-234) needs the backward kernels (DESIGN.md section 8)")
+    # ---- training (diffsbdd.py:45-195, training mode) ----------------------------------------------------------
+    def sample_time(self, batch_size, device="cuda"):
+        """time_sampler 'random' (_base.py:30-33): integers 0..T as floats"""
+        return torch.randint(0, self.num_diffusion_timesteps + 1, size=(batch_size,), device=device).float()
+
+    def forward(self, batch, t=None, noise=None):
+        """``loss_dict, results = model(batch)`` in training mode: {'pos', 'atom'} (the variational loss with the
+        reference's training-time weighting).  ``t`` [B] float in {0..T} / ``noise=(eps_x [N_lig,3], eps_c [N_lig,C])``
+        replay the draws in tests.  Evaluation mode (the exact VLB with a second denoiser call at t = 0) is not built."""
+        if not (self.training or t is not None):
+            raise NotImplementedError("DiffSBDD evaluation-mode loss (diffsbdd.py:66-84, 131-153) is not built")
+        bl = batch["ligand_element_batch"]
+        B = int(bl.max().item()) + 1
+        if t is None:
+            t = self.sample_time(B, device=batch["ligand_pos"].device)
+        return self.get_loss(batch, t, noise)
+
+    def get_loss(self, batch, t_int, noise=None):
+        T, C = self.num_diffusion_timesteps, self.num_classes
+        x0 = batch["ligand_pos"].float()
+        bl, br = batch["ligand_element_batch"], batch["protein_element_batch"]
+        lig_flag_l = batch["ligand_lig_flag"]
+        gen_l = batch.get("ligand_gen_flag", lig_flag_l).bool()
+        gen_r = batch.get("protein_gen_flag", torch.zeros_like(batch["protein_lig_flag"])).bool()
+        B = int(t_int.shape[0])
+        c0 = F.one_hot(batch["ligand_atom_type"], C).float() / 4.0
+        v_rec = batch["protein_atom_feature"].float() / 4.0
+        t_is_zero = (t_int == 0).float()
+        t = t_int / T
+        eps_x, eps_c = noise if noise is not None else (None, None)
+        x0c, xr0 = self.pos_scheduler.remove_mean_batch(x0, batch["protein_pos"].float(), bl, br, B)
+        x_t, pos_noise, xr_t = self.pos_scheduler.forward_pos_center_noise(x0c, xr0, t, bl, br, B, gen_l, noise=eps_x)
+        c_t, type_noise = self.type_scheduler.forward_type_add_noise(c0, t, bl, B, gen_l, noise=eps_c)
+        aa = F.one_hot(batch["protein_aa_type"], NUM_AA).float()
+        h_lig = self.context_embedder.embed_ligand(c_t)
+        h_rec = self.context_embedder.embed_protein(v_rec, aa)
+        sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = TargetDiff.compose_plan(bl, br, B)
+        x = torch.cat([xr_t, x_t], 0)[sort_idx]
+        h = torch.cat([h_rec, h_lig], 0)[sort_idx]
+        gen_flag = torch.cat([gen_r, gen_l], 0)[sort_idx]
+        xo, _, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
+                                      graph_ptr=graph_ptr)
+        loss_pos, pos_info = self.pos_scheduler.get_score_loss(xo[lig_rows], pos_noise, t, gen_l, bl, B, t_is_zero, x_lig_0=x0c)
+        loss_atom, atom_info = self.type_scheduler.get_score_loss(logits[lig_rows], type_noise, t, gen_l, bl, B, t_is_zero,
+                                                                  c_lig_0=c0, c_lig_t=c_t)
+        results = {k + "_pos": v for k, v in pos_info.items()}
+        results.update({k + "_atom": v for k, v in atom_info.items()})
+        return {"pos": loss_pos, "atom": loss_atom}, results
 
     @torch.no_grad()
     def sample(self, batch, noise_draws=None, return_device=None):

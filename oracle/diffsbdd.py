@@ -122,3 +122,81 @@ def sample(sd, batch, num_classes, Tn, draws):
     next(it)                                              # the type draw is made and discarded
     traj[0] = (x_fin * 1.0, c_lig * 4.0)
     return traj
+
+
+# ---- training objective (diffsbdd.py:91-195; DiffsbddVariationalScheduler diffusion_scheduler.py:670-960) ----------
+def _sum_per_graph(x, index, n):
+    return torch.zeros(n, dtype=x.dtype).index_add(0, index, x.sum(-1))
+
+
+def _cdf(x):
+    return 0.5 * (1.0 + torch.erf(x / np.sqrt(2.0)))
+
+
+def kl_prior(gamma_tab, Tn, x, bl, B, dimensions):
+    """diffusion_scheduler.py:783-800 with gaussian_KL :693-706 (p = standard normal)"""
+    g_T = gamma_at(gamma_tab, torch.ones(B, 1), Tn)
+    alpha_T = torch.sqrt(torch.sigmoid(-g_T)).view(B, 1)
+    mu = alpha_T[bl] * x
+    sigma_T = torch.sqrt(torch.sigmoid(g_T)).view(B)
+    mu2 = _sum_per_graph(mu ** 2, bl, B)
+    d = dimensions
+    return d * torch.log(1.0 / sigma_T) + 0.5 * (d * sigma_T ** 2 + mu2) - 0.5 * d
+
+
+def score_loss_training(gamma_tab, Tn, pred, tgt, t, bl, B, t_is_zero, x0=None, c0=None, c_t=None):
+    """get_score_loss in training mode (diffusion_scheduler.py:886-900, 930-945): per graph
+    0.5 * sum(err^2) * [t != 0] / (n * dim)  +  (-log p(. | z_0)) * [t == 0]  +  KL prior; then the mean over graphs."""
+    n = torch.bincount(bl, minlength=B)
+    err = _sum_per_graph((tgt - pred) ** 2, bl, B)
+    loss_t = 0.5 * err * (1.0 - t_is_zero) / (n * pred.shape[-1])
+    g_t = gamma_at(gamma_tab, t, Tn).view(B, 1)
+    if x0 is not None:
+        loss_0 = -(-0.5 * err) * t_is_zero
+        kl = kl_prior(gamma_tab, Tn, x0, bl, B, (n - 1) * 3)
+    else:
+        sigma0 = torch.sqrt(torch.sigmoid(g_t)) * 4.0
+        onehot = c0 * 4.0
+        centred = c_t * 4.0 - 1.0
+        logp = torch.log(_cdf((centred + 0.5) / sigma0[bl]) - _cdf((centred - 0.5) / sigma0[bl]) + 1e-10)
+        logp = logp - torch.logsumexp(logp, dim=1, keepdim=True)
+        loss_0 = -_sum_per_graph(logp * onehot, bl, B) * t_is_zero
+        kl = kl_prior(gamma_tab, Tn, c0, bl, B, 1)
+    return (loss_t + loss_0 + kl).mean()
+
+
+def get_loss(sd, batch, t_int, eps_x, eps_c, num_classes, Tn):
+    """DiffSBDD.get_loss in training mode (diffsbdd.py:91-195).  ``t_int`` [B] float in {0..T} (the 'random' time sampler,
+    _base.py:30-33); draws: randn_like(x) then randn_like(c)."""
+    x0 = batch["ligand_pos"]
+    bl, br = batch["ligand_element_batch"], batch["protein_element_batch"]
+    n_lig = x0.shape[0]
+    gen_l = batch.get("ligand_gen_flag", torch.ones(n_lig, dtype=torch.bool))
+    B = int(bl.max()) + 1
+    c0 = F.one_hot(batch["ligand_atom_type"], num_classes) / 4.0
+    v_rec = batch["protein_atom_feature"] / 4.0
+    t_is_zero = (t_int == 0).float()
+    t = t_int / Tn
+    gp, gt_ = sd["pos_scheduler.gamma.gamma"], sd["type_scheduler.gamma.gamma"]
+    x0c, xr0 = remove_mean_batch(x0, batch["protein_pos"], bl, br, B)
+    g = gamma_at(gp, t, Tn).view(B, 1)
+    x_noisy = torch.sqrt(torch.sigmoid(-g))[bl] * x0c + torch.sqrt(torch.sigmoid(g))[bl] * eps_x
+    x_noisy, xr_t = remove_mean_batch(x_noisy, xr0.detach().clone(), bl, br, B)
+    x_t = torch.where(gen_l.unsqueeze(-1), x_noisy, x0c)
+    g2 = gamma_at(gt_, t, Tn).view(B, 1)
+    c_t = torch.where(gen_l.unsqueeze(-1), torch.sqrt(torch.sigmoid(-g2))[bl] * c0 + torch.sqrt(torch.sigmoid(g2))[bl] * eps_c, c0)
+    x_pred, c_pred = denoise(sd, batch, x_t, c_t, xr_t, v_rec)
+    return {"pos": score_loss_training(gp, Tn, x_pred, eps_x, t, bl, B, t_is_zero, x0=x0c),
+            "atom": score_loss_training(gt_, Tn, c_pred, eps_c, t, bl, B, t_is_zero, c0=c0, c_t=c_t)}
+
+
+def loss_and_grads(sd, batch, t_int, eps_x, eps_c, num_classes, Tn, weights=None):
+    sd = {k: v.clone() for k, v in sd.items()}
+    keys = [k for k in sd if "scheduler" not in k and not k.endswith(".offset")]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    losses = get_loss(sd, batch, t_int, eps_x, eps_c, num_classes, Tn)
+    w = weights or {"pos": 1.0, "atom": 1.0}
+    sum(w[k] * v for k, v in losses.items()).backward()
+    grads = {k: (sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])) for k in keys}
+    return {k: v.detach() for k, v in losses.items()}, grads

@@ -346,6 +346,53 @@ def diffbp_train_case(name, batch, seed):
     print(name, {k: float(v) for k, v in loss_dict.items()}, "t", t.tolist())
 
 
+def diffsbdd_train_case(name, batch, seed, t_override=None):
+    """DiffSBDD training step of the unmodified reference (diffsbdd.py:45-195): the two losses and all gradients."""
+    if not _selected(name):
+        return
+    M = ref_shim.load_reference()
+    T = 1000
+    cfg = ref_shim.AttrDict(
+        type="diffsbdd", num_atomtype=8,
+        encoder=dict(type="unitransformer", node_feat_dim=128, n_heads=16, num_layers=9),
+        generator=dict(pos_schedule=dict(type="polynomial_2"), atom_schedule=dict(type="polynomial_2"),
+                       num_diffusion_timesteps=T, time_sampler="random"),
+        embedder=dict(emb_dim=128, atom=dict(type="linear"), residue=dict(type="linear")))
+    model = M.get_model(cfg)
+    model.load_state_dict(W.synthetic_state_dict_diffsbdd(8, 9, seed=0, num_timesteps=T), strict=True)
+    model.train()
+    model.zero_grad()
+    bl = batch["ligand_element_batch"]
+    B = int(bl.max()) + 1
+    torch.manual_seed(seed)
+    if t_override is None:
+        loss_dict, _ = model(batch)
+    else:
+        lig_flag, rec_flag = batch["ligand_lig_flag"], batch["protein_lig_flag"]
+        loss_dict, _ = model.get_loss(batch["ligand_pos"], batch["protein_pos"], batch["ligand_atom_type"],
+                                      batch["protein_atom_feature"], batch["protein_aa_type"], lig_flag, rec_flag, bl,
+                                      batch["protein_element_batch"], batch.get("ligand_gen_flag", lig_flag),
+                                      torch.zeros_like(rec_flag), t_override)
+    sum(loss_dict.values()).backward()
+    torch.manual_seed(seed)
+    t = torch.randint(0, T + 1, size=(B,)).float() if t_override is None else t_override
+    eps_x = torch.randn_like(batch["ligand_pos"])
+    eps_c = torch.randn(batch["ligand_pos"].shape[0], 8)
+    out = {"seed": seed, "t": _np(t), "eps_x": _np(eps_x), "eps_c": _np(eps_c)}
+    for k, v in loss_dict.items():
+        out["loss_" + k] = _np(v)
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        out["gnorm/" + k] = np.float64(g.double().norm().item())
+        flat = g.reshape(-1)
+        out["g/" + k] = _np(flat if flat.numel() <= 2048 else flat[::61])
+    out.update({"batch_" + k: _np(v) for k, v in batch.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, {k: float(v) for k, v in loss_dict.items()}, "t", t.tolist())
+
+
 def priors_case(name):
     """Ligand-size prior of the reference (repo/datasets/transforms/init_lig.py:28-52,232-258): pocket size function and
     bin lookup on seeded pockets, the bin edges, and per-bin mean / support of the histogram table (the table itself is
@@ -419,6 +466,11 @@ def main():
     train_case(model, "train_loss_t0_linker", small_batch([(58, 15), (44, 12)], seed=62, ctx=[10, 8]), seed=16,
                t_override=torch.tensor([0, 700]))
     priors_case("priors_atom_num")
+    diffsbdd_train_case("train_loss_diffsbdd", small_batch([(64, 10), (50, 12), (57, 9)], seed=64, num_classes=8), seed=18)
+    # (seed chosen so that no ReLU of the t = 0 graph sits within rounding of zero: with the unnormalised t = 0 term such
+    # a unit makes two fp32 evaluation orders differ by 0.5 % in one tensor -- seen with seed 65)
+    diffsbdd_train_case("train_loss_diffsbdd_t0", small_batch([(58, 11), (44, 8)], seed=67, num_classes=8), seed=19,
+                        t_override=torch.tensor([0.0, 640.0]))
     diffbp_train_case("train_loss_diffbp", small_batch([(64, 10), (50, 12), (57, 9)], seed=63), seed=17)
     sample_case("sample_T5", small_batch([(40, 8), (36, 6)], seed=31), T=5, seed=9)
     b = small_batch([(44, 9), (37, 8)], seed=51)

@@ -206,8 +206,8 @@ def test_diffsbdd_model_class(golden_dir):
     oa, ob = OD.sample_p_zs_given_zt(sd["pos_scheduler.gamma.gamma"], 1000, s, t, zt, pocket, bl, br, 2, pred, eps, True)
     assert torch.equal(a, oa) and torch.equal(b, ob)
     assert torch.allclose(OD.scatter_mean(a, bl, 2), torch.zeros(2, 3), atol=1e-6)   # COM-free after the draw
-    with pytest.raises(NotImplementedError):
-        model(dict())
+    with pytest.raises(NotImplementedError):      # evaluation-mode VLB is not built; training mode is (GPU tests)
+        model.eval()(dict())
 
 
 def test_diffbp_model_class(golden_dir):

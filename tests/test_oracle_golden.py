@@ -185,3 +185,25 @@ def test_diffbp_training_loss_and_gradients_match_reference(golden_dir):
         torch.testing.assert_close(sample, g["g/" + k], rtol=1e-4, atol=1e-8 + 1e-5 * ref_norm / max(flat.numel(), 1) ** 0.5)
         n += 1
     assert n == 8 + 6 + 9 * 36 + 4 + (6 + 3 * 18)
+
+
+@pytest.mark.parametrize("case", ["train_loss_diffsbdd", "train_loss_diffsbdd_t0"])
+def test_diffsbdd_training_loss_and_gradients_match_reference(golden_dir, case):
+    """DiffSBDD's variational training loss (diffsbdd.py:91-195): loss_t, the t = 0 reconstruction terms and the KL
+    prior, against the unmodified reference's losses and gradients"""
+    from oracle import diffsbdd as OS
+    g = load(golden_dir, case)
+    batch = golden_batch(g)
+    sd = W.synthetic_state_dict_diffsbdd(8, 9, seed=0, num_timesteps=1000)
+    losses, grads = OS.loss_and_grads(sd, batch, g["t"], g["eps_x"], g["eps_c"], 8, 1000)
+    for k in ("pos", "atom"):
+        assert abs(float(losses[k]) - g["loss_" + k]) <= 2e-6 * abs(g["loss_" + k]) + 1e-7, (k, float(losses[k]), g["loss_" + k])
+    n = 0
+    for k, gr in grads.items():
+        ref_norm = float(g["gnorm/" + k])
+        assert abs(gr.double().norm().item() - ref_norm) <= 1e-5 * ref_norm + 1e-8, k
+        flat = gr.reshape(-1)
+        sample = flat if flat.numel() <= 2048 else flat[::61]
+        torch.testing.assert_close(sample, g["g/" + k], rtol=1e-4, atol=1e-8 + 1e-5 * ref_norm / max(flat.numel(), 1) ** 0.5)
+        n += 1
+    assert n == 8 + 6 + 9 * 36 + 4
