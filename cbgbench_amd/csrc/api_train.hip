@@ -62,6 +62,8 @@ static Tape carve_tape(void* base, int n, int L) {
 struct TrainWs {
     float *P, *Qt, *Gt, *T, *S, *gb, *sw, *qs, *dqb, *zb, *dP, *gh, *gx[2], *de_w, *E8, *tmp, *partial, *folded, *qln;
     int *act, *act_count;
+    uint8_t* mask;        // receptive field of the loss, walked backwards (see cbgx_unitransformer_backward)
+    int *rf_list[2], *rf_count;
     size_t partial_floats;
     size_t total;
 };
@@ -101,6 +103,10 @@ static TrainWs carve_train(void* base, int n) {
     w.tmp = (float*)take(N * H * 4);
     w.act = (int*)take(N * 4);
     w.act_count = (int*)take(256);
+    w.mask = (uint8_t*)take(N);
+    w.rf_list[0] = (int*)take(N * 4);
+    w.rf_list[1] = (int*)take(N * 4);
+    w.rf_count = (int*)take(256);
     w.partial_floats = partial_floats_needed();
     w.partial = (float*)take(w.partial_floats * 4);
     w.folded = (float*)take((size_t)FOLD * H * PROW * 4);
@@ -392,6 +398,18 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
     else HIP_TRY(hipMemsetAsync(w.gx[cur], 0, nx * 4, s));
     HIP_TRY(hipMemsetAsync(w.de_w, 0, (size_t)n * KNN * 4, s));
     HIP_TRY(launch_build_active(gen_flag, n, w.act, w.act_count, s));
+    // Receptive-field pruning, the mirror image of the forward's: without a caller gradient on h_out, dL/dh_L is non-zero
+    // on ligand rows only (classifier), the last h2x block adds rows of A1 = gen | lig | nbr(gen), and the x2h block of a
+    // layer spreads its input gradient one hop further (A2 = A1 | nbr(A1)).  Rows outside carry an exactly zero gradient
+    // and contribute exactly zero to everything, so the last two x2h blocks are walked on A1 / A2 only.
+    const bool prune = (grad_h_out == nullptr) && L >= 3;
+    if (prune) {
+        HIP_TRY(launch_mark_seed(gen_flag, lig_flag, n, w.mask, s));
+        HIP_TRY(launch_mark_nbr(w.act, w.act_count, n, tp.nbr, tp.deg, w.mask, s));
+        HIP_TRY(launch_build_active(w.mask, n, w.rf_list[0], w.rf_count, s));
+        HIP_TRY(launch_mark_nbr(w.rf_list[0], w.rf_count, n, tp.nbr, tp.deg, w.mask, s));
+        HIP_TRY(launch_build_active(w.mask, n, w.rf_list[1], w.rf_count + 16, s));
+    }
 
     for (int l = L - 1; l >= 0; --l) {
         const float* xl = tp.xs + (size_t)l * nx;
@@ -406,8 +424,11 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         // h_mid = h_in + X2H(x_l, h_in): w.gh holds dL/dh_mid, which is also the residual part of dL/dh_in.  The edge
         // kernel reads it (through the fold) before the final GEMM accumulates into it, so a snapshot is needed.
         HIP_TRY(hipMemcpyAsync(w.tmp, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
+        const int k = L - 1 - l;      // 0 for the last layer
+        const int* rows = (prune && k < 2) ? w.rf_list[k] : nullptr;
+        const int* n_rows = (prune && k < 2) ? w.rf_count + 16 * k : nullptr;
         RC_TRY(attention_block_backward(true, packed + x2h_off(l), xl, h_in, w.tmp, tp.nbr, tp.deg, lig_flag, tp.e_w,
-                                        nullptr, nullptr, n, w, w.gh, w.gx[nxt], w.de_w, g, s));
+                                        rows, n_rows, n, w, w.gh, w.gx[nxt], w.de_w, g, s));
         cur = nxt;
     }
     if (grad_h_in) HIP_TRY(hipMemcpyAsync(grad_h_in, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));

@@ -843,7 +843,7 @@ hipError_t launch_edge_backward(bool x2h, const float* att, const float* x, cons
                                 const int32_t* deg, const uint8_t* lig, const float* e_w, const int* rows,
                                 const int* n_rows, int n_nodes, float* T, float* S, float* sw, float* dP, float* dx,
                                 float* de_w, float* partial, int grid, hipStream_t s) {
-    profile_mark_begin(x2h ? K_EDGE_X2H_BWD : K_EDGE_H2X_BWD, s);
+    profile_mark_begin(x2h ? (rows ? K_EDGE_X2H_BWD_LISTED : K_EDGE_X2H_BWD) : K_EDGE_H2X_BWD, s);
     if (x2h)
         hipLaunchKernelGGL(edge_backward_kernel<true>, dim3(grid), dim3(256), 0, s, att, x, P, Qt, Gt, gb, gx_out, nbr,
                            deg, lig, e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial);

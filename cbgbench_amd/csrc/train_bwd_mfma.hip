@@ -619,7 +619,7 @@ hipError_t launch_edge_backward_mfma(bool x2h, const float* att, const float* x,
                                      float* de_w, float* partial, int grid, hipStream_t s) {
     if ((long)n_nodes * HEADS * H >= (1L << 32)) return hipErrorInvalidValue;   // 32-bit element offsets inside the kernel
     static const int abl = getenv("CBGX_BWD_ABL") ? atoi(getenv("CBGX_BWD_ABL")) : 0;   // timing ablations (wrong results)
-    profile_mark_begin(x2h ? K_EDGE_X2H_BWD : K_EDGE_H2X_BWD, s);
+    profile_mark_begin(x2h ? (rows ? K_EDGE_X2H_BWD_LISTED : K_EDGE_X2H_BWD) : K_EDGE_H2X_BWD, s);
     if (x2h)
         hipLaunchKernelGGL(edge_backward_mfma_kernel<true>, dim3(grid), dim3(BWD_THREADS), 0, s, att, x, P, Qt, Gt, gb,
                            gx_out, nbr, deg, lig, e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl);

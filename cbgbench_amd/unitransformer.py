@@ -107,6 +107,7 @@ class _DenoiserFunction(torch.autograd.Function):
         _native.check(rc, "cbgx_unitransformer_forward_train")
         ctx.module, ctx.tape, ctx.packed, ctx.flags, ctx.n = module, tape, packed, (lig, gen), N
         ctx.param_shapes = [tuple(p.shape) for p in params]
+        ctx.set_materialize_grads(False)     # an unused output (h' in TargetDiff / DiffSBDD) arrives as None, not zeros
         return x_out, h_out, logits
 
     @staticmethod

@@ -236,8 +236,9 @@ int cbgx_h2x_stack_backward(const float *packed, int num_layers, const void *tap
  * its own stream.  cbgx_profile_end() synchronises them and returns, per kernel class, the summed
  * device time in ms and the launch count.  Classes: 0 knn, 1 gate, 2 node GEMM, 3 node query fold,
  * 4 x2h edge kernel over all nodes, 5 h2x edge kernel (node list), 6 x2h edge kernel over a node list (pruned last
- * layers), 7 x2h edge backward, 8 h2x edge backward, 9 training GEMMs (CBGX_PROFILE_CLASSES = 10).  Not thread-safe with concurrent launches from other threads; process-wide. */
-#define CBGX_PROFILE_CLASSES 10
+ * layers), 7 x2h edge backward over all nodes, 8 h2x edge backward, 9 training GEMMs, 10 x2h edge backward over a node list
+ * (CBGX_PROFILE_CLASSES = 11).  Not thread-safe with concurrent launches from other threads; process-wide. */
+#define CBGX_PROFILE_CLASSES 11
 int cbgx_profile_begin(int max_launches);
 int cbgx_profile_end(double *ms_by_class, int *launches_by_class, int num_classes);
 
