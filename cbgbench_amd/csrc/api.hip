@@ -216,6 +216,9 @@ static int pack_attention_block(const float* const* p, int blk, float* a, hipStr
     HIP_TRY(launch_center_linear(wk0, bk0, KV_IN, a + A_WAKC, a + A_BAKC, s));
     HIP_TRY(launch_center_linear(wv0, bv0, KV_IN, a + A_WAVC, a + A_BAVC, s));
     const float *wkc = a + A_WAKC, *wvc = a + A_WAVC;
+    { int rc = flush_pack(s); if (rc) return rc; }   // the two copies below read the centred matrices just produced on this stream
+    CP(wkc, KV_IN, NT, 1, a + A_WRC, 2 * H, NT * G, H);
+    CP(wvc, KV_IN, NT, 1, a + A_WRC + H, 2 * H, NT * G, H);
     HIP_TRY(launch_pack_node_frags(wkc, wvc, wq0, wq1, wk1, a, s));
     HIP_TRY(launch_pack_bn2(a, bq0, a, s));
     // LDS image of the MFMA edge kernel

@@ -75,7 +75,10 @@ constexpr size_t A_WBKT = A_BN2 + 2 * PROW;
 constexpr size_t A_WQ1O = A_WBKT + (size_t)H * H;
 // rbf columns of the first Linears, transposed and padded for the backward's B operand: [4 types][256 c][32 g]
 constexpr size_t A_WRT = A_WQ1O + (size_t)H * H;
-constexpr size_t ATT_SIZE = A_WRT + (size_t)NT * 2 * H * 32;
+// rbf columns of the *centred* first Linears, same layout as A_WR: the backward's recomputation when the node projection
+// comes from the MFMA node kernel (whose P is centred and already contains the protein-source type column)
+constexpr size_t A_WRC = A_WRT + (size_t)NT * 2 * H * 32;
+constexpr size_t ATT_SIZE = A_WRC + (size_t)NT * G * 2 * H;
 
 constexpr size_t LAYER_SIZE = 2 * ATT_SIZE;       // x2h then h2x
 

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
     const uint8_t* __restrict__ lig, const float* __restrict__ e_w, const int* __restrict__ rows,
     const int* __restrict__ n_rows_ptr, int n_nodes, float* __restrict__ T, float* __restrict__ S,
     float* __restrict__ sw, float* __restrict__ dP, float* __restrict__ dx, float* __restrict__ de_w,
-    float* __restrict__ partial, int abl) {
+    float* __restrict__ partial, int abl, int centred) {
     __shared__ EdgeBwdMfmaLds L;
     const int t = threadIdx.x;
     // vector-ALU view: column c of the k|v pair (path p, channel m), edges [16 eh, 16 eh + 16)
@@ -196,7 +196,8 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
 #pragma unroll
             for (int cl = 0; cl < 2; ++cl) {
                 if (!has_cls[cl]) continue;
-                const float* wr = att + A_WR + (unsigned)(cl ? ty_lig : ty_prot) * G * 2 * H + cbase + li;
+                // P from the MFMA node kernel is centred (and holds the protein-source type column): use the centred rbf columns
+                const float* wr = att + (centred ? A_WRC : A_WR) + (unsigned)(cl ? ty_lig : ty_prot) * G * 2 * H + cbase + li;
                 float a0[G / 4], a1[G / 4], bq[G / 4][2];
 #pragma unroll
                 for (int s = 0; s < G / 4; ++s) {
@@ -223,8 +224,8 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
             for (int ct = 0; ct < 2; ++ct) {
                 const int cc = cbase + 16 * ct + li;
                 pd[ct] = P[(unsigned)i * PROW + cc];
-                wtv[0][ct] = att[A_WT + ty_prot * 2 * H + cc];
-                wtv[1][ct] = att[A_WT + ty_lig * 2 * H + cc];
+                wtv[0][ct] = centred ? 0.f : att[A_WT + ty_prot * 2 * H + cc];
+                wtv[1][ct] = centred ? att[A_IMG + IMG_WT + lig_i * 2 * H + cc] : att[A_WT + ty_lig * 2 * H + cc];
             }
             float ps[2][4][2];
             int clv[2][4];
@@ -616,16 +617,16 @@ hipError_t launch_edge_backward_mfma(bool x2h, const float* att, const float* x,
                                      const float* Gt, const float* gb, const float* gx_out, const int32_t* nbr,
                                      const int32_t* deg, const uint8_t* lig, const float* e_w, const int* rows,
                                      const int* n_rows, int n_nodes, float* T, float* S, float* sw, float* dP, float* dx,
-                                     float* de_w, float* partial, int grid, hipStream_t s) {
+                                     float* de_w, float* partial, int grid, hipStream_t s, int centred) {
     if ((long)n_nodes * HEADS * H >= (1L << 32)) return hipErrorInvalidValue;   // 32-bit element offsets inside the kernel
     static const int abl = getenv("CBGX_BWD_ABL") ? atoi(getenv("CBGX_BWD_ABL")) : 0;   // timing ablations (wrong results)
     profile_mark_begin(x2h ? (rows ? K_EDGE_X2H_BWD_LISTED : K_EDGE_X2H_BWD) : K_EDGE_H2X_BWD, s);
     if (x2h)
         hipLaunchKernelGGL(edge_backward_mfma_kernel<true>, dim3(grid), dim3(BWD_THREADS), 0, s, att, x, P, Qt, Gt, gb,
-                           gx_out, nbr, deg, lig, e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl);
+                           gx_out, nbr, deg, lig, e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl, centred);
     else
         hipLaunchKernelGGL(edge_backward_mfma_kernel<false>, dim3(grid), dim3(BWD_THREADS), 0, s, att, x, P, Qt, Gt, gb,
-                           gx_out, nbr, deg, lig, e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl);
+                           gx_out, nbr, deg, lig, e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl, centred);
     profile_mark_end(s);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;

@@ -463,7 +463,9 @@ def main():
     step_case(model, "step_t0", small_batch([(64, 10), (50, 12)], seed=22), 0, seed=6)
     step_case(model, "step_t999_linker", small_batch([(58, 15), (44, 12)], seed=23, ctx=[10, 8]), 999, seed=7)
     train_case(model, "train_loss_denovo", small_batch([(64, 10), (50, 12), (57, 9)], seed=61), seed=15)
-    train_case(model, "train_loss_t0_linker", small_batch([(58, 15), (44, 12)], seed=62, ctx=[10, 8]), seed=16,
+    # (batch seed 62 put one value-net ReLU of block 2 within fp32 rounding of zero: centred and uncentred evaluation of the
+    # first Linear then disagree by 2 % in that channel's gradients -- same effect as noted at train_loss_diffsbdd_t0)
+    train_case(model, "train_loss_t0_linker", small_batch([(58, 15), (44, 12)], seed=68, ctx=[10, 8]), seed=16,
                t_override=torch.tensor([0, 700]))
     priors_case("priors_atom_num")
     diffsbdd_train_case("train_loss_diffsbdd", small_batch([(64, 10), (50, 12), (57, 9)], seed=64, num_classes=8), seed=18)
