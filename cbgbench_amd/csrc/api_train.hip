@@ -196,7 +196,8 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     {
         const int tiles = (n + 15) / 16, qgrid = tiles < 4 * NODE_GRID ? tiles : 4 * NODE_GRID;   // ~43 KB LDS: 3 per CU
         HIP_TRY(hipMemsetAsync(w.qln, 0, 2 * H * sizeof(float), s));
-        HIP_TRY(launch_q_backward(att, w.P, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, w.qln, qgrid, s));
+        HIP_TRY((mfma ? launch_q_backward_mfma : launch_q_backward)(att, w.P, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP,
+                                                                    w.qln, qgrid, s));
     }
     // node-level reductions, all into one slab per workgroup (NS_* layout), folded and scattered once:
     //   second Linears: dWbk = sum_i (q_i / sqrt 8) (x) T_i ;  x2h: dWbv = sum_i G_i (x) S_i ;  dWq1 = sum_i dq_i (x) z_i

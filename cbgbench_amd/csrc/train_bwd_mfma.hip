@@ -607,6 +607,199 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Query path backward on the matrix cores.  Same contract as q_backward_kernel (train_bwd.hip, kept as the VALU
+// cross-check): for every listed node recompute z = ReLU(LN(P[:,512:640])) and q = Wq1 z + bq1, take
+// dq = (1/sqrt 8) fold(T, Wbk), and produce qs = q/sqrt(8), dq, z and dP[:,512:640]; the LayerNorm affine gradients
+// are accumulated into partial[0:256] by atomics.
+//
+// One 16-node tile per 4-wave workgroup pass; the three [16 x 128] x [128 x 128] products of a tile are MFMA
+// 16x16x4 chains whose A operand is read four k at a time (one ds_read_b128 / global float4 per four MFMAs): lane
+// (i, kq) holds k = 16 s + 4 kq + j for j = 0..3, and the B operand is loaded for the same k, so the k permutation
+// cancels.  Every load is unconditional (out-of-range rows read row 0 and are masked at the stores): predicated loads
+// compile to branch + wait per element, which is what made the VALU version latency bound (~130 us per tile).
+// ------------------------------------------------------------------------------------------------
+constexpr int QB_LD = H + 4;   // row stride of the LDS tiles (16-byte aligned rows, conflict-light b128 reads)
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void q_backward_mfma_kernel(const float* __restrict__ att, const float* __restrict__ P,
+                                                              const float* __restrict__ T, const int* __restrict__ rows,
+                                                              const int* __restrict__ n_rows_ptr, int n_nodes,
+                                                              float* __restrict__ qs, float* __restrict__ dqb,
+                                                              float* __restrict__ zb, float* __restrict__ dP,
+                                                              float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float sZ[16][QB_LD];    // z (post ReLU); later d(normalised) in place
+    __shared__ __attribute__((aligned(16))) float sNq[16][QB_LD];   // normalised pre-activation
+    __shared__ __attribute__((aligned(16))) float sDq[16][QB_LD];   // dq
+    __shared__ float sRstd[16];
+    __shared__ int sRow[16];
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const float s8 = 0.35355339059327376220f;
+    float aG[2] = {0.f, 0.f}, aB[2] = {0.f, 0.f};
+    const int count = rows ? *n_rows_ptr : n_nodes;
+    const int tiles = (count + 15) / 16;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        __syncthreads();
+        if (t < 16) { const int it = tile * 16 + t; sRow[t] = it < count ? (rows ? rows[it] : it) : -1; }
+        __syncthreads();
+        {   // LayerNorm + ReLU of the query hidden, 16 threads per row
+            const int r = t >> 4, part = t & 15, node = sRow[r];
+            const unsigned base = (unsigned)(node < 0 ? 0 : node) * PROW + 4 * H;
+            float v[8], s = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v[u] = P[base + part + 16 * u]; s += v[u]; }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+            const float mean = s * (1.f / H);
+            float q = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q += (v[u] - mean) * (v[u] - mean);
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+            const float rstd = 1.f / sqrtf(q * (1.f / H) + 1e-5f);
+            const float live = node >= 0 ? 1.f : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = part + 16 * u;
+                const float nq = (v[u] - mean) * rstd * live;
+                const float z = fmaxf(nq * att[A_LNQ_G + k] + att[A_LNQ_B + k], 0.f) * live;
+                sNq[r][k] = nq;
+                sZ[r][k] = z;
+                if (node >= 0) zb[(unsigned)node * H + k] = z;
+            }
+            if (part == 0) sRstd[r] = rstd;
+        }
+        __syncthreads();
+        // ---- dq: wave w owns heads 4w .. 4w+3; A = T rows straight from global, B = 8 columns of Wbk^T ------
+        // one head at a time (rolled: keeps the live set to one head's gathers), results go straight to LDS / HBM;
+        // lane column c = i < 8 is n = 8a + c, register r is row 4 kq + r
+        {
+            const int node = sRow[i];
+            const unsigned trow = (unsigned)(node < 0 ? 0 : node) * HEADS * H;
+#pragma unroll 1
+            for (int hh = 0; hh < 4; ++hh) {
+                const int a = 4 * w + hh;
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+                float4 ta[8];
+#pragma unroll
+                for (int sp = 0; sp < 8; ++sp) ta[sp] = *reinterpret_cast<const float4*>(T + trow + a * H + 16 * sp + 4 * kq);
+#pragma unroll
+                for (int sp = 0; sp < 8; ++sp) {
+                    const float* wb = att + A_WBKT + (unsigned)(16 * sp + 4 * kq) * H + 8 * a + (i & 7);
+                    const float b0 = wb[0], b1 = wb[H], b2 = wb[2 * H], b3 = wb[3 * H];
+                    acc = MFMA(ta[sp].x, b0, acc);
+                    acc = MFMA(ta[sp].y, b1, acc);
+                    acc = MFMA(ta[sp].z, b2, acc);
+                    acc = MFMA(ta[sp].w, b3, acc);
+                }
+                const int n = 8 * a + (i & 7);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dq = acc[r] * s8;
+                    const int nd = sRow[4 * kq + r];
+                    if (i < 8) {
+                        sDq[4 * kq + r][n] = dq;
+                        if (nd >= 0) dqb[(unsigned)nd * H + n] = dq;
+                    }
+                }
+            }
+        }
+        {   // ---- q = Wq1 z + bq1: wave w owns columns 32w .. 32w+31 ------------------------------------
+            floatx4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 2
+            for (int sp = 0; sp < 8; ++sp) {
+                const float4 za = *reinterpret_cast<const float4*>(&sZ[i][16 * sp + 4 * kq]);
+                const float* wq = att + A_WQ1T + (unsigned)(16 * sp + 4 * kq) * H + 32 * w + i;
+                float b[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { b[0][j] = wq[j * H]; b[1][j] = wq[j * H + 16]; }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    acc[tt] = MFMA(za.x, b[tt][0], acc[tt]);
+                    acc[tt] = MFMA(za.y, b[tt][1], acc[tt]);
+                    acc[tt] = MFMA(za.z, b[tt][2], acc[tt]);
+                    acc[tt] = MFMA(za.w, b[tt][3], acc[tt]);
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int n = 32 * w + 16 * tt + i;
+                const float b1 = att[A_BQ1 + n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int node = sRow[4 * kq + r];
+                    if (node >= 0) qs[(unsigned)node * H + n] = (acc[tt][r] + b1) * s8;
+                }
+            }
+        }
+        __syncthreads();
+        {   // ---- dz = dq Wq1 -> ReLU/LayerNorm-affine backward; wave w owns hidden columns 32w .. 32w+31 ----
+            floatx4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 2
+            for (int sp = 0; sp < 8; ++sp) {
+                const float4 da = *reinterpret_cast<const float4*>(&sDq[i][16 * sp + 4 * kq]);
+                const float* wq = att + A_WQ1O + (unsigned)(16 * sp + 4 * kq) * H + 32 * w + i;
+                float b[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { b[0][j] = wq[j * H]; b[1][j] = wq[j * H + 16]; }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    acc[tt] = MFMA(da.x, b[tt][0], acc[tt]);
+                    acc[tt] = MFMA(da.y, b[tt][1], acc[tt]);
+                    acc[tt] = MFMA(da.z, b[tt][2], acc[tt]);
+                    acc[tt] = MFMA(da.w, b[tt][3], acc[tt]);
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int k = 32 * w + 16 * tt + i;
+                const float gq = att[A_LNQ_G + k];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = 4 * kq + r;
+                    const float dy = sZ[rr][k] > 0.f ? acc[tt][r] : 0.f;    // z = 0 on padding rows
+                    aG[tt] = fmaf(dy, sNq[rr][k], aG[tt]);
+                    aB[tt] += dy;
+                    sZ[rr][k] = dy * gq;       // each element is read and rewritten by the same lane only
+                }
+            }
+        }
+        __syncthreads();
+        {   // LayerNorm backward, 16 threads per row
+            const int r = t >> 4, part = t & 15, node = sRow[r];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float dn = sZ[r][part + 16 * u];
+                s1 += dn;
+                s2 = fmaf(dn, sNq[r][part + 16 * u], s2);
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+            const float m1 = s1 * (1.f / H), m2 = s2 * (1.f / H), rstd = sRstd[r];
+            if (node >= 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = part + 16 * u;
+                    dP[(unsigned)node * PROW + 4 * H + k] = rstd * (sZ[r][k] - m1 - sNq[r][k] * m2);
+                }
+            }
+        }
+    }
+    // LayerNorm affine gradients [gamma | beta]: fold the four kq lanes of a column, then one atomic per column and wave
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        float g = aG[tt], b = aB[tt];
+        g += __shfl_xor(g, 16, 64); g += __shfl_xor(g, 32, 64);
+        b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+        if (kq == 0) {
+            atomicAdd(&partial[32 * w + 16 * tt + i], g);
+            atomicAdd(&partial[H + 32 * w + 16 * tt + i], b);
+        }
+    }
+}
+
 #define CBGX_LAUNCH_CHECK()                            \
     do {                                               \
         hipError_t _e = hipGetLastError();             \
@@ -628,6 +821,16 @@ hipError_t launch_edge_backward_mfma(bool x2h, const float* att, const float* x,
         hipLaunchKernelGGL(edge_backward_mfma_kernel<false>, dim3(grid), dim3(BWD_THREADS), 0, s, att, x, P, Qt, Gt, gb,
                            gx_out, nbr, deg, lig, e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl, centred);
     profile_mark_end(s);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_q_backward_mfma(const float* att, const float* P, const float* T, const int* rows, const int* n_rows,
+                                  int n_nodes, float* qs, float* dqb, float* zb, float* dP, float* partial, int grid,
+                                  hipStream_t s) {
+    if ((long)n_nodes * HEADS * H >= (1L << 32)) return hipErrorInvalidValue;   // 32-bit element offsets inside the kernel
+    hipLaunchKernelGGL(q_backward_mfma_kernel, dim3(grid), dim3(256), 0, s, att, P, T, rows, n_rows, n_nodes, qs, dqb, zb,
+                       dP, partial);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }
