@@ -202,12 +202,13 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     // node-level reductions, all into one slab per workgroup (NS_* layout), folded and scattered once:
     //   second Linears: dWbk = sum_i (q_i / sqrt 8) (x) T_i ;  x2h: dWbv = sum_i G_i (x) S_i ;  dWq1 = sum_i dq_i (x) z_i
     //   biases: second v / q Linears, and the first Linears = column sums of dP (k | v | - | - | q hidden)
-    HIP_TRY(launch_outer_accum(true, w.qs, w.T, rows, n_rows, n, w.partial + NS_WBK, NS_SIZE, ng, s));
+    const auto outer = mfma ? launch_outer_accum_mfma : launch_outer_accum;
+    HIP_TRY(outer(true, w.qs, w.T, rows, n_rows, n, w.partial + NS_WBK, NS_SIZE, ng, s));
     if (x2h) {
-        HIP_TRY(launch_outer_accum(true, g_out, w.S, rows, n_rows, n, w.partial + NS_WBV, NS_SIZE, ng, s));
+        HIP_TRY(outer(true, g_out, w.S, rows, n_rows, n, w.partial + NS_WBV, NS_SIZE, ng, s));
         HIP_TRY(launch_colsum(g_out, H, H, w.sw, rows, n_rows, n, w.partial + NS_V1B, NS_SIZE, ng, s));
     }
-    HIP_TRY(launch_outer_accum(false, w.dqb, w.zb, rows, n_rows, n, w.partial + NS_WQ1, NS_SIZE, ng, s));
+    HIP_TRY(outer(false, w.dqb, w.zb, rows, n_rows, n, w.partial + NS_WQ1, NS_SIZE, ng, s));
     HIP_TRY(launch_colsum(w.dqb, H, H, nullptr, rows, n_rows, n, w.partial + NS_Q1B, NS_SIZE, ng, s));
     HIP_TRY(launch_colsum(w.dP, PROW, PROW, nullptr, nullptr, nullptr, n, w.partial + NS_DP, NS_SIZE, ng, s));
     HIP_TRY(hipMemsetAsync(k1b, 0, H * sizeof(float), s));   // the key bias cancels in the softmax

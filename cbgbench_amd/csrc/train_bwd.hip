@@ -559,26 +559,29 @@ __global__ __launch_bounds__(256) void outer_accum_kernel(const float* __restric
 }
 
 // column sums of A[rows, cols] (optionally of A[i][c] * scale[i][c >> 3]) -> one partial row per workgroup
+template <bool LISTED, bool SCALED>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int lda, int cols,
                                                      const float* __restrict__ scale, const int* __restrict__ rows,
                                                      const int* __restrict__ n_rows_ptr, int n_rows,
                                                      float* __restrict__ partial, size_t slab_stride) {
-    const int count = rows ? *n_rows_ptr : n_rows;
+    const int count = LISTED ? *n_rows_ptr : n_rows;
     for (int c0 = threadIdx.x; c0 < cols; c0 += 256) {
         float acc = 0.f;
-        for (int it = blockIdx.x; it < count; it += 4 * gridDim.x) {
-            float v[4];
+        // eight rows per pass, loads unconditional (rows past the end read row 0 and are weighted by zero): predicated
+        // loads compile to one branch + wait per element and leave the kernel latency bound
+        for (int it = blockIdx.x; it < count; it += 8 * gridDim.x) {
+            float v[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 8; ++j) {
                 const int itj = it + j * gridDim.x;
-                v[j] = 0.f;
-                if (itj < count) {
-                    const int i = rows ? rows[itj] : itj;
-                    v[j] = A[(size_t)i * lda + c0];
-                    if (scale) v[j] *= scale[(size_t)i * HEADS + (c0 >> 3)];
-                }
+                const bool ok = itj < count;
+                const int itc = ok ? itj : 0;
+                const int i = LISTED ? rows[itc] : itc;
+                v[j] = A[(size_t)i * lda + c0];
+                if (SCALED) v[j] *= scale[(size_t)i * HEADS + (c0 >> 3)];
+                v[j] = ok ? v[j] : 0.f;
             }
-            acc += (v[0] + v[1]) + (v[2] + v[3]);
+            acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
         partial[(size_t)blockIdx.x * slab_stride + c0] = acc;
     }
@@ -884,8 +887,12 @@ hipError_t launch_outer_accum(bool headed, const float* Lm, const float* R, cons
 
 hipError_t launch_colsum(const float* A, int lda, int cols, const float* scale, const int* rows, const int* n_rows_ptr,
                          int n_rows, float* partial, size_t slab_stride, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, s, A, lda, cols, scale, rows, n_rows_ptr, n_rows, partial,
-                       slab_stride);
+#define CBGX_COLSUM(L, S)                                                                                             \
+    hipLaunchKernelGGL((colsum_kernel<L, S>), dim3(grid), dim3(256), 0, s, A, lda, cols, scale, rows, n_rows_ptr, n_rows, \
+                       partial, slab_stride)
+    if (rows) { if (scale) CBGX_COLSUM(true, true); else CBGX_COLSUM(true, false); }
+    else      { if (scale) CBGX_COLSUM(false, true); else CBGX_COLSUM(false, false); }
+#undef CBGX_COLSUM
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }

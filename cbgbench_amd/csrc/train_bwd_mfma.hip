@@ -800,6 +800,98 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Outer-product accumulation over nodes on the matrix cores (same contract as outer_accum_kernel, train_bwd.hip):
+//   dW[n][m] = sum_i L[i][n] * R[i][(HEADED ? n >> 3 : 0)][m],   one 128 x 128 partial per workgroup.
+// The node index is the MFMA k dimension: lane (i, kq) feeds node kq of a group of four, A = L[node][16 tn + i],
+// B = R[node][..][m].  Wave w owns rows n = 32w .. 32w+31 (heads 4w .. 4w+3) and all 128 columns; B comes in as two
+// float4 per (node, head) with the column labelling m = 64 tmq + 4 i + j, so one load feeds four column tiles and
+// the results leave as float4 stores.  HEADED row tiles span two heads: two MFMAs per tile with the other head's
+// rows of A zeroed.  Eight nodes per pass, every load unconditional (padding nodes read row 0 with A = 0).
+// ------------------------------------------------------------------------------------------------
+template <bool HEADED>
+__global__ __launch_bounds__(256) void outer_accum_mfma_kernel(const float* __restrict__ Lm, const float* __restrict__ R,
+                                                               const int* __restrict__ rows,
+                                                               const int* __restrict__ n_rows_ptr, int n_nodes,
+                                                               float* __restrict__ partial, size_t slab_stride) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    floatx4 acc[2][8];
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[tr][c] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int count = rows ? *n_rows_ptr : n_nodes;
+    const float lo = (i >> 3) == 0 ? 1.f : 0.f, hi = 1.f - lo;
+    for (int base = blockIdx.x * 8; base < count; base += gridDim.x * 8) {
+        float a[2][2];
+        float4 b[2][HEADED ? 4 : 1][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int it = base + 4 * g + kq;
+            const bool ok = it < count;
+            const int itc = ok ? it : 0;
+            const unsigned node = (unsigned)(rows ? rows[itc] : itc);
+            const float live = ok ? 1.f : 0.f;
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr) a[g][tr] = Lm[node * H + 32 * w + 16 * tr + i] * live;
+            if (HEADED) {
+#pragma unroll
+                for (int hh = 0; hh < 4; ++hh) {
+                    const float* r = R + (node * HEADS + 4 * w + hh) * H + 4 * i;
+                    b[g][hh][0] = *reinterpret_cast<const float4*>(r);
+                    b[g][hh][1] = *reinterpret_cast<const float4*>(r + 64);
+                }
+            } else {
+                const float* r = R + node * H + 4 * i;
+                b[g][0][0] = *reinterpret_cast<const float4*>(r);
+                b[g][0][1] = *reinterpret_cast<const float4*>(r + 64);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // all gathers of the pass in flight before the first MFMA waits on one
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr) {
+                if (HEADED) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const float am = a[g][tr] * (hf ? hi : lo);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const float4 bb = b[g][2 * tr + hf][q];
+                            acc[tr][4 * q + 0] = MFMA(am, bb.x, acc[tr][4 * q + 0]);
+                            acc[tr][4 * q + 1] = MFMA(am, bb.y, acc[tr][4 * q + 1]);
+                            acc[tr][4 * q + 2] = MFMA(am, bb.z, acc[tr][4 * q + 2]);
+                            acc[tr][4 * q + 3] = MFMA(am, bb.w, acc[tr][4 * q + 3]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float4 bb = b[g][0][q];
+                        acc[tr][4 * q + 0] = MFMA(a[g][tr], bb.x, acc[tr][4 * q + 0]);
+                        acc[tr][4 * q + 1] = MFMA(a[g][tr], bb.y, acc[tr][4 * q + 1]);
+                        acc[tr][4 * q + 2] = MFMA(a[g][tr], bb.z, acc[tr][4 * q + 2]);
+                        acc[tr][4 * q + 3] = MFMA(a[g][tr], bb.w, acc[tr][4 * q + 3]);
+                    }
+                }
+            }
+    }
+    // D register r of tile (tr, q, j): row n = 32w + 16tr + 4kq + r, column m = 64q + 4i + j
+    float* slab = partial + (size_t)blockIdx.x * slab_stride;
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 o = make_float4(acc[tr][4 * q + 0][r], acc[tr][4 * q + 1][r], acc[tr][4 * q + 2][r],
+                                             acc[tr][4 * q + 3][r]);
+                *reinterpret_cast<float4*>(slab + (size_t)(32 * w + 16 * tr + 4 * kq + r) * H + 64 * q + 4 * i) = o;
+            }
+}
+
 #define CBGX_LAUNCH_CHECK()                            \
     do {                                               \
         hipError_t _e = hipGetLastError();             \
@@ -831,6 +923,19 @@ hipError_t launch_q_backward_mfma(const float* att, const float* P, const float*
     if ((long)n_nodes * HEADS * H >= (1L << 32)) return hipErrorInvalidValue;   // 32-bit element offsets inside the kernel
     hipLaunchKernelGGL(q_backward_mfma_kernel, dim3(grid), dim3(256), 0, s, att, P, T, rows, n_rows, n_nodes, qs, dqb, zb,
                        dP, partial);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_outer_accum_mfma(bool headed, const float* Lm, const float* R, const int* rows, const int* n_rows,
+                                   int n_nodes, float* partial, size_t slab_stride, int grid, hipStream_t s) {
+    if ((long)n_nodes * HEADS * H >= (1L << 32)) return hipErrorInvalidValue;   // 32-bit element offsets inside the kernel
+    if (headed)
+        hipLaunchKernelGGL(outer_accum_mfma_kernel<true>, dim3(grid), dim3(256), 0, s, Lm, R, rows, n_rows, n_nodes,
+                           partial, slab_stride);
+    else
+        hipLaunchKernelGGL(outer_accum_mfma_kernel<false>, dim3(grid), dim3(256), 0, s, Lm, R, rows, n_rows, n_nodes,
+                           partial, slab_stride);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }
