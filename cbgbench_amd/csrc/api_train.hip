@@ -31,7 +31,7 @@ constexpr int EDGE_GRID = 256;    // persistent workgroups of the edge backward 
 constexpr int NODE_GRID = 256;    // persistent workgroups of the node-level reductions
 constexpr int FOLD = 8;           // slab reductions are two-level: n_slabs -> FOLD (slab_fold_kernel) -> 1 (reduce_store)
 constexpr int GATE_GRID = 256;
-constexpr int MAX_SPLITS = 32;
+constexpr int MAX_SPLITS = 128;   // node groups of the weight-gradient products (one [128 x 640] partial slab each)
 
 // ---- tape: what the taped forward keeps for the backward ------------------------------------------------
 struct Tape {
@@ -117,6 +117,11 @@ static TrainWs carve_train(void* base, int n) {
 
 static inline int edge_grid(int n) { return n < EDGE_GRID ? (n > 0 ? n : 1) : EDGE_GRID; }
 static inline int node_grid(int n) { return n < NODE_GRID ? (n > 0 ? n : 1) : NODE_GRID; }
+// node groups of wgrad_mfma_kernel: at least 128 nodes (8 passes) each
+static inline int wgrad_groups(int n) {
+    int g = (n + 127) / 128;
+    return g < 1 ? 1 : (g > MAX_SPLITS ? MAX_SPLITS : g);
+}
 static inline int splits_for(int n) {
     int s = (n + 511) / 512;
     return s < 1 ? 1 : (s > MAX_SPLITS ? MAX_SPLITS : s);
@@ -230,8 +235,11 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
         rb.n = 0;
     }
     // dense projection: dWn[k][n] = sum_i h_in[i][k] dP[i][n]  -> h_dst / h_src / q columns of the first Linears
-    const int sp = splits_for(n);
-    HIP_TRY(launch_sgemm(true, false, h_in, H, w.dP, PROW, w.partial, PROW, H, PROW, n, sp, (size_t)H * PROW, 0, s));
+    const int sp = mfma ? wgrad_groups(n) : (splits_for(n) > 32 ? 32 : splits_for(n));
+    if (mfma)
+        HIP_TRY(launch_wgrad_mfma(h_in, H, w.dP, PROW, n, PROW / H, w.partial, PROW, (size_t)H * PROW, sp, s));
+    else
+        HIP_TRY(launch_sgemm(true, false, h_in, H, w.dP, PROW, w.partial, PROW, H, PROW, n, sp, (size_t)H * PROW, 0, s));
     {
         FOLDED(w.partial, sp, (size_t)H * PROW, H * PROW);
         piece(fz + 0 * H, fn, fs, PROW, H, H, k0w + NT + NT * G, KV_IN, 1);
@@ -243,7 +251,10 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
         rb.n = 0;
     }
     // dL/dh_in += dP Wn^T
-    HIP_TRY(launch_sgemm(false, true, w.dP, PROW, att + A_WN, PROW, gh, H, n, H, PROW, 1, 0, 1, s));
+    if (mfma)
+        HIP_TRY(launch_dgrad_mfma(w.dP, PROW, att + A_WN, PROW, gh, H, n, PROW, 1, s));
+    else
+        HIP_TRY(launch_sgemm(false, true, w.dP, PROW, att + A_WN, PROW, gh, H, n, H, PROW, 1, 0, 1, s));
     return CBGX_OK;
 }
 
@@ -392,11 +403,20 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         HIP_TRY(launch_sgemm(false, true, grad_logits, C, c + C_W1T, C, dact, H, n, H, C, 1, 0, 0, s));
         HIP_TRY(launch_ssp_backward(pre, dact, (long)nh, w.tmp, s));
         // classifier.0: dW0[n][k] = sum_i dpre[i][n] h[i][k];  db0 = colsum(dpre);  dh += dpre W0
-        HIP_TRY(launch_sgemm(true, false, w.tmp, H, hl, H, w.partial, H, H, H, n, sp, (size_t)H * H, 0, s));
-        { FOLDED(w.partial, sp, (size_t)H * H, H * H); RS(fz, fn, fs, H, H, H, cg[0], H, 0); }
+        if (g_edge_impl == 0) {
+            const int wg = wgrad_groups(n);
+            HIP_TRY(launch_wgrad_mfma(w.tmp, H, hl, H, n, 1, w.partial, H, (size_t)H * H, wg, s));
+            FOLDED(w.partial, wg, (size_t)H * H, H * H); RS(fz, fn, fs, H, H, H, cg[0], H, 0);
+        } else {
+            HIP_TRY(launch_sgemm(true, false, w.tmp, H, hl, H, w.partial, H, H, H, n, sp, (size_t)H * H, 0, s));
+            FOLDED(w.partial, sp, (size_t)H * H, H * H); RS(fz, fn, fs, H, H, H, cg[0], H, 0);
+        }
         HIP_TRY(launch_colsum(w.tmp, H, H, nullptr, nullptr, nullptr, n, w.partial, H, ng, s));
         { FOLDED(w.partial, ng, H, H); RS(fz, fn, fs, H, 1, H, cg[1], H, 0); }
-        HIP_TRY(launch_sgemm(false, true, w.tmp, H, c + C_W0T, H, w.gh, H, n, H, H, 1, 0, 1, s));
+        if (g_edge_impl == 0)
+            HIP_TRY(launch_dgrad_mfma(w.tmp, H, c + C_W0T, H, w.gh, H, n, H, 1, s));
+        else
+            HIP_TRY(launch_sgemm(false, true, w.tmp, H, c + C_W0T, H, w.gh, H, n, H, H, 1, 0, 1, s));
     } else {
         HIP_TRY(hipMemsetAsync(cg[0], 0, (size_t)H * H * 4, s));
         HIP_TRY(hipMemsetAsync(cg[1], 0, H * 4, s));

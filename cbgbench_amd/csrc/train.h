@@ -47,6 +47,10 @@ hipError_t launch_edge_backward_mfma(bool x2h, const float* att, const float* x,
 hipError_t launch_fold_grad(const float* att, const float* Gr, int n_nodes, float* Gt, float* gb, hipStream_t s);
 hipError_t launch_outer_accum_mfma(bool headed, const float* Lm, const float* R, const int* rows, const int* n_rows,
                                    int n_nodes, float* partial, size_t slab_stride, int grid, hipStream_t s);
+hipError_t launch_wgrad_mfma(const float* Lm, int ldl, const float* R, int ldr, int n_nodes, int col_blocks, float* partial,
+                             int ldo, size_t slab_stride, int groups, hipStream_t s);
+hipError_t launch_dgrad_mfma(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K,
+                             int accumulate, hipStream_t s);
 hipError_t launch_q_backward_mfma(const float* att, const float* P, const float* T, const int* rows, const int* n_rows,
                                   int n_nodes, float* qs, float* dqb, float* zb, float* dP, float* partial, int grid,
                                   hipStream_t s);

@@ -892,6 +892,134 @@ __global__ __launch_bounds__(256) void outer_accum_mfma_kernel(const float* __re
             }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The two dense products of the backward whose long dimension is the node index, without LDS staging: both MFMA
+// operands are read from global memory in the layout the instruction wants, all loads of a pass are issued before the
+// first MFMA (sched_barrier) and none is predicated (rows past the end are clamped and not stored).
+//
+// wgrad:  C_g[128][128 cb .. +127] = sum over the nodes of group g of L[node][0:128]^T R[node][128 cb .. +127]
+//         (weight gradient of a Linear applied to every node: node = MFMA k, one partial slab per node group,
+//         folded by the caller).  Wave w owns rows 32w .. 32w+31; columns labelled m = 64 q + 4 i + j (float4 loads).
+// dgrad:  C[row][0:128] (+)= A[row][0:K] B[col][0:K]^T   (gradient w.r.t. the Linear's input: row = node)
+//         32 rows per workgroup, wave w owns columns 32w .. 32w+31; k labelled 16 s + 4 kq + j on both operands.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const float* __restrict__ Lm, int ldl, const float* __restrict__ R,
+                                                         int ldr, int n_nodes, int nodes_per_group,
+                                                         float* __restrict__ partial, int ldo, size_t slab_stride) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int cb = blockIdx.y;
+    floatx4 acc[2][8];
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[tr][c] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int n0 = blockIdx.x * nodes_per_group;
+    const int n1 = min(n_nodes, n0 + nodes_per_group);
+    for (int base = n0; base < n1; base += 16) {
+        float a[4][2];
+        float4 b[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int it = base + 4 * g + kq;
+            const bool ok = it < n1;
+            const unsigned node = (unsigned)(ok ? it : n0);
+            const float live = ok ? 1.f : 0.f;
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr) a[g][tr] = Lm[node * ldl + 32 * w + 16 * tr + i] * live;
+            const float* r = R + node * ldr + 128 * cb + 4 * i;
+            b[g][0] = *reinterpret_cast<const float4*>(r);
+            b[g][1] = *reinterpret_cast<const float4*>(r + 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float4 bb = b[g][q];
+                    acc[tr][4 * q + 0] = MFMA(a[g][tr], bb.x, acc[tr][4 * q + 0]);
+                    acc[tr][4 * q + 1] = MFMA(a[g][tr], bb.y, acc[tr][4 * q + 1]);
+                    acc[tr][4 * q + 2] = MFMA(a[g][tr], bb.z, acc[tr][4 * q + 2]);
+                    acc[tr][4 * q + 3] = MFMA(a[g][tr], bb.w, acc[tr][4 * q + 3]);
+                }
+    }
+    float* slab = partial + (size_t)blockIdx.x * slab_stride + 128 * cb;
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 o = make_float4(acc[tr][4 * q + 0][r], acc[tr][4 * q + 1][r], acc[tr][4 * q + 2][r],
+                                             acc[tr][4 * q + 3][r]);
+                *reinterpret_cast<float4*>(slab + (size_t)(32 * w + 16 * tr + 4 * kq + r) * ldo + 64 * q + 4 * i) = o;
+            }
+}
+
+__global__ __launch_bounds__(256) void dgrad_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                         int ldb, float* __restrict__ C, int ldc, int M, int K,
+                                                         int accumulate) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * 32;
+    const float* ap[2];
+    const float* bp[2];
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr) {
+        ap[tr] = A + (unsigned)min(row0 + 16 * tr + i, M - 1) * lda + 4 * kq;
+        bp[tr] = B + (unsigned)(32 * w + 16 * tr + i) * ldb + 4 * kq;
+    }
+    // old values of the accumulated output: in flight during the whole product
+    float cold[2][2][4];
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned row = (unsigned)min(row0 + 16 * tr + 4 * kq + r, M - 1);
+                cold[tr][tc][r] = accumulate ? C[row * ldc + 32 * w + 16 * tc + i] : 0.f;
+            }
+    floatx4 acc[2][2];
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc) acc[tr][tc] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 64) {       // K is a multiple of 64 (launcher)
+        float4 a[4][2], b[4][2];
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr) {
+                a[sp][tr] = *reinterpret_cast<const float4*>(ap[tr] + k0 + 16 * sp);
+                b[sp][tr] = *reinterpret_cast<const float4*>(bp[tr] + k0 + 16 * sp);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+                for (int tc = 0; tc < 2; ++tc) {
+                    acc[tr][tc] = MFMA(a[sp][tr].x, b[sp][tc].x, acc[tr][tc]);
+                    acc[tr][tc] = MFMA(a[sp][tr].y, b[sp][tc].y, acc[tr][tc]);
+                    acc[tr][tc] = MFMA(a[sp][tr].z, b[sp][tc].z, acc[tr][tc]);
+                    acc[tr][tc] = MFMA(a[sp][tr].w, b[sp][tc].w, acc[tr][tc]);
+                }
+    }
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 16 * tr + 4 * kq + r;
+                if (row < M) C[(unsigned)row * ldc + 32 * w + 16 * tc + i] = cold[tr][tc][r] + acc[tr][tc][r];
+            }
+}
+
 #define CBGX_LAUNCH_CHECK()                            \
     do {                                               \
         hipError_t _e = hipGetLastError();             \
@@ -936,6 +1064,31 @@ hipError_t launch_outer_accum_mfma(bool headed, const float* Lm, const float* R,
     else
         hipLaunchKernelGGL(outer_accum_mfma_kernel<false>, dim3(grid), dim3(256), 0, s, Lm, R, rows, n_rows, n_nodes,
                            partial, slab_stride);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// C_slabs[g][128][ldo] (column blocks of 128) = partial sums over node groups of L^T R; returns the number of slabs
+hipError_t launch_wgrad_mfma(const float* Lm, int ldl, const float* R, int ldr, int n_nodes, int col_blocks, float* partial,
+                             int ldo, size_t slab_stride, int groups, hipStream_t s) {
+    if ((long)n_nodes * (ldl > ldr ? ldl : ldr) >= (1L << 32)) return hipErrorInvalidValue;
+    const int per = ((n_nodes + groups - 1) / groups + 15) / 16 * 16;
+    profile_mark_begin(K_TRAIN_GEMM, s);
+    hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(groups, col_blocks), dim3(256), 0, s, Lm, ldl, R, ldr, n_nodes, per, partial,
+                       ldo, slab_stride);
+    profile_mark_end(s);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// C[M][128] (+)= A[M][K] B[128][K]^T, K a multiple of 64
+hipError_t launch_dgrad_mfma(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K,
+                             int accumulate, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    if (K % 64 != 0 || (long)M * (lda > ldc ? lda : ldc) >= (1L << 32)) return hipErrorInvalidValue;
+    profile_mark_begin(K_TRAIN_GEMM, s);
+    hipLaunchKernelGGL(dgrad_mfma_kernel, dim3((M + 31) / 32), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, accumulate);
+    profile_mark_end(s);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }
