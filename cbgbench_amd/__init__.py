@@ -34,12 +34,13 @@ def default_targetdiff_config(num_atomtype=13, num_layers=9, num_diffusion_times
     )
 
 
-def default_diffsbdd_config(num_atomtype=8, num_layers=9, num_diffusion_timesteps=1000):
+def default_diffsbdd_config(num_atomtype=8, num_layers=9, num_diffusion_timesteps=1000, eval_interval=10):
     """The ``model:`` block of configs/denovo/train/diffsbdd.yml:1-19 (+ num_atomtype; the shipped test config uses
     the 'basic' 8-type vocabulary, configs/denovo/test/diffsbdd.yml:17)."""
     return Config(
         type="diffsbdd",
         num_atomtype=num_atomtype,
+        eval_interval=eval_interval,     # evaluation times of the eval-mode loss (diffsbdd.py:74-76, default 10)
         encoder=dict(type="unitransformer", node_feat_dim=128, n_heads=16, num_layers=num_layers),
         generator=dict(pos_schedule=dict(type="polynomial_2"), atom_schedule=dict(type="polynomial_2"),
                        num_diffusion_timesteps=num_diffusion_timesteps, time_sampler="random"),

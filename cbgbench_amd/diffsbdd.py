@@ -120,6 +120,37 @@ class DiffsbddVariationalScheduler(nn.Module):
         info = {"eps_0": tgt, "eps_pred": pred, "mask_gen": gen_flag}
         return (loss_t + loss_0 + kl).mean(), info
 
+    def neg_log_constants(self, n, dim):
+        """-log_constants_p_x_given_z0 (:679-691): (n - 1) dim (0.5 gamma_0 + 0.5 log 2 pi) per graph"""
+        g0 = self.gamma(torch.zeros(n.shape[0], 1, device=n.device)).view(-1)
+        return ((n - 1) * dim) * (0.5 * g0 + 0.5 * math.log(2 * math.pi))
+
+    def get_score_loss_eval(self, pred, tgt, s, t, gen_flag, batch_idx, B, pred0, tgt0, x_lig_0=None, c_lig_0=None,
+                            c_lig_t0=None):
+        """evaluation-mode loss (:902-928): per graph  -T/2 (1 - SNR(gamma_s - gamma_t)) sum(err^2)  +  KL prior  +
+        -log p(. | z_0) of a second network call on the t = 0 noising (``pred0``/``tgt0``; ``c_lig_t0`` the t = 0 noised
+        types)  +  the Gaussian normalisation constant (which the reference also adds to the type term, dim = C)."""
+        bl = batch_idx
+        n = torch.bincount(bl, minlength=B)
+        err = self.sum_except_batch((tgt - pred) ** 2, bl, B)
+        g_s, g_t = self.gamma(s).view(B), self.gamma(t).view(B)
+        loss_t = -self.num_timestep * 0.5 * (1.0 - torch.exp(-(g_s - g_t))) * err
+        if x_lig_0 is not None:
+            kl = self.kl_prior(x_lig_0, bl, B, (n - 1) * 3)
+            loss_0 = 0.5 * self.sum_except_batch((tgt0 - pred0) ** 2, bl, B)
+        else:
+            kl = self.kl_prior(c_lig_0, bl, B, 1)
+            g_0 = self.gamma(torch.zeros_like(s)).view(B, 1)
+            sigma0 = self.sigma(g_0) * 4.0
+            centred = c_lig_t0 * 4.0 - 1.0
+            cdf = lambda v: 0.5 * (1.0 + torch.erf(v / math.sqrt(2.0)))
+            logp = torch.log(cdf((centred + 0.5) / sigma0[bl]) - cdf((centred - 0.5) / sigma0[bl]) + 1e-10)
+            logp = logp - torch.logsumexp(logp, dim=1, keepdim=True)
+            loss_0 = -self.sum_except_batch(logp * (c_lig_0 * 4.0), bl, B)
+        loss_0 = loss_0 + self.neg_log_constants(n, tgt0.shape[-1])
+        info = {"eps_0": tgt, "eps_pred": pred, "mask_gen": gen_flag}
+        return (loss_t + loss_0 + kl).mean(), info
+
     def sample_normal_zero_com(self, mu_lig, xh0_pocket, sigma, bl, br, B, com=False, eps=None):
         if eps is None:
             eps = torch.randn((bl.shape[0], mu_lig.size(1)), device=mu_lig.device)
@@ -164,18 +195,30 @@ class DiffSBDD(nn.Module):
         return torch.randint(0, self.num_diffusion_timesteps + 1, size=(batch_size,), device=device).float()
 
     def forward(self, batch, t=None, noise=None):
-        """``loss_dict, results = model(batch)`` in training mode: {'pos', 'atom'} (the variational loss with the
-        reference's training-time weighting).  ``t`` [B] float in {0..T} / ``noise=(eps_x [N_lig,3], eps_c [N_lig,C])``
-        replay the draws in tests.  Evaluation mode (the exact VLB with a second denoiser call at t = 0) is not built."""
-        if not (self.training or t is not None):
-            raise NotImplementedError("DiffSBDD evaluation-mode loss (diffsbdd.py:66-84, 131-153) is not built")
+        """``loss_dict, results = model(batch)`` (diffsbdd.py:48-86).  Training mode: {'pos', 'atom'} of one random time
+        per graph with the reference's training-time weighting; ``t`` [B] float in {0..T} and
+        ``noise=(eps_x [N_lig,3], eps_c [N_lig,C])`` replay the draws in tests.  Evaluation mode: the variational bound
+        (SNR-weighted loss_t + KL prior + the t = 0 reconstruction term from a second denoiser call) averaged over
+        ``cfg.eval_interval`` (10) evenly spaced times, ``results`` a list with one entry per time; ``noise`` is then a
+        list of (eps_x, eps_c, eps_x0, eps_c0) per time."""
         bl = batch["ligand_element_batch"]
         B = int(bl.max().item()) + 1
-        if t is None:
-            t = self.sample_time(B, device=batch["ligand_pos"].device)
-        return self.get_loss(batch, t, noise)
+        dev = batch["ligand_pos"].device
+        if self.training or t is not None:
+            if t is None:
+                t = self.sample_time(B, device=dev)
+            return self.get_loss(batch, t, noise)
+        times = np.linspace(1, self.num_diffusion_timesteps, self.cfg.get("eval_interval", 10))
+        tot, results = {"pos": 0.0, "atom": 0.0}, []
+        for k, tv in enumerate(times):
+            t_long = torch.full((B,), int(tv), dtype=torch.long, device=dev)
+            ld, res = self.get_loss(batch, t_long, noise[k] if noise is not None else None, evaluate=True)
+            for key in tot:
+                tot[key] = tot[key] + ld[key]
+            results.append(res)
+        return {k: v / len(times) for k, v in tot.items()}, results
 
-    def get_loss(self, batch, t_int, noise=None):
+    def get_loss(self, batch, t_int, noise=None, evaluate=False):
         T, C = self.num_diffusion_timesteps, self.num_classes
         x0 = batch["ligand_pos"].float()
         bl, br = batch["ligand_element_batch"], batch["protein_element_batch"]
@@ -185,24 +228,37 @@ class DiffSBDD(nn.Module):
         B = int(t_int.shape[0])
         c0 = F.one_hot(batch["ligand_atom_type"], C).float() / 4.0
         v_rec = batch["protein_atom_feature"].float() / 4.0
-        t_is_zero = (t_int == 0).float()
         t = t_int / T
-        eps_x, eps_c = noise if noise is not None else (None, None)
         x0c, xr0 = self.pos_scheduler.remove_mean_batch(x0, batch["protein_pos"].float(), bl, br, B)
-        x_t, pos_noise, xr_t = self.pos_scheduler.forward_pos_center_noise(x0c, xr0, t, bl, br, B, gen_l, noise=eps_x)
-        c_t, type_noise = self.type_scheduler.forward_type_add_noise(c0, t, bl, B, gen_l, noise=eps_c)
         aa = F.one_hot(batch["protein_aa_type"], NUM_AA).float()
-        h_lig = self.context_embedder.embed_ligand(c_t)
         h_rec = self.context_embedder.embed_protein(v_rec, aa)
         sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = TargetDiff.compose_plan(bl, br, B)
-        x = torch.cat([xr_t, x_t], 0)[sort_idx]
-        h = torch.cat([h_rec, h_lig], 0)[sort_idx]
         gen_flag = torch.cat([gen_r, gen_l], 0)[sort_idx]
-        xo, _, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
-                                      graph_ptr=graph_ptr)
-        loss_pos, pos_info = self.pos_scheduler.get_score_loss(xo[lig_rows], pos_noise, t, gen_l, bl, B, t_is_zero, x_lig_0=x0c)
-        loss_atom, atom_info = self.type_scheduler.get_score_loss(logits[lig_rows], type_noise, t, gen_l, bl, B, t_is_zero,
-                                                                  c_lig_0=c0, c_lig_t=c_t)
+
+        def noise_and_denoise(tt, eps_x, eps_c):
+            x_t, pos_noise, xr_t = self.pos_scheduler.forward_pos_center_noise(x0c, xr0, tt, bl, br, B, gen_l, noise=eps_x)
+            c_t, type_noise = self.type_scheduler.forward_type_add_noise(c0, tt, bl, B, gen_l, noise=eps_c)
+            h_lig = self.context_embedder.embed_ligand(c_t)
+            x = torch.cat([xr_t, x_t], 0)[sort_idx]
+            h = torch.cat([h_rec, h_lig], 0)[sort_idx]
+            xo, _, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
+                                          graph_ptr=graph_ptr)
+            return xo[lig_rows], logits[lig_rows], pos_noise, type_noise, c_t
+
+        noise = noise if noise is not None else (None,) * (4 if evaluate else 2)
+        x_pred, c_pred, pos_noise, type_noise, c_t = noise_and_denoise(t, noise[0], noise[1])
+        if not evaluate:
+            t_is_zero = (t_int == 0).float()
+            loss_pos, pos_info = self.pos_scheduler.get_score_loss(x_pred, pos_noise, t, gen_l, bl, B, t_is_zero, x_lig_0=x0c)
+            loss_atom, atom_info = self.type_scheduler.get_score_loss(c_pred, type_noise, t, gen_l, bl, B, t_is_zero,
+                                                                      c_lig_0=c0, c_lig_t=c_t)
+        else:
+            s = (t_int - 1) / T
+            x_pred0, c_pred0, pos_noise0, type_noise0, c_t0 = noise_and_denoise(torch.zeros_like(s), noise[2], noise[3])
+            loss_pos, pos_info = self.pos_scheduler.get_score_loss_eval(x_pred, pos_noise, s, t, gen_l, bl, B, x_pred0,
+                                                                        pos_noise0, x_lig_0=x0c)
+            loss_atom, atom_info = self.type_scheduler.get_score_loss_eval(c_pred, type_noise, s, t, gen_l, bl, B, c_pred0,
+                                                                           type_noise0, c_lig_0=c0, c_lig_t0=c_t0)
         results = {k + "_pos": v for k, v in pos_info.items()}
         results.update({k + "_atom": v for k, v in atom_info.items()})
         return {"pos": loss_pos, "atom": loss_atom}, results

@@ -200,3 +200,83 @@ def loss_and_grads(sd, batch, t_int, eps_x, eps_c, num_classes, Tn, weights=None
     sum(w[k] * v for k, v in losses.items()).backward()
     grads = {k: (sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])) for k in keys}
     return {k: v.detach() for k, v in losses.items()}, grads
+
+
+# ---- evaluation-mode objective (diffsbdd.py:72-86,138-153; diffusion_scheduler.py:679-691,864-928) ----------------
+def neg_log_constants(gamma_tab, Tn, n, dim):
+    """-log_constants_p_x_given_z0 (:679-691): (n-1) dim (0.5 gamma_0 + 0.5 log 2 pi) per graph"""
+    g0 = gamma_at(gamma_tab, torch.zeros(n.shape[0], 1), Tn).view(-1)
+    return ((n - 1) * dim) * (0.5 * g0 + 0.5 * np.log(2 * np.pi))
+
+
+def score_loss_eval(gamma_tab, Tn, pred, tgt, s, t, bl, B, pred0, tgt0, x0=None, c0=None, c_t0=None):
+    """get_score_loss outside training (:902-928): per graph  -T/2 (1 - SNR(gamma_s - gamma_t)) sum(err^2)  +  KL prior
+    +  -log p(. | z_0) from a second network call on the t = 0 noising (pred0, tgt0; c_t0 = the t = 0 noised types)
+    + the Gaussian normalisation constant (added to the type term too, with dim = C, as the reference does)."""
+    n = torch.bincount(bl, minlength=B)
+    err = _sum_per_graph((tgt - pred) ** 2, bl, B)
+    g_s, g_t = gamma_at(gamma_tab, s, Tn).view(B), gamma_at(gamma_tab, t, Tn).view(B)
+    loss_t = -Tn * 0.5 * (1.0 - torch.exp(-(g_s - g_t))) * err
+    g_0 = gamma_at(gamma_tab, torch.zeros_like(s), Tn).view(B, 1)
+    if x0 is not None:
+        kl = kl_prior(gamma_tab, Tn, x0, bl, B, (n - 1) * 3)
+        loss_0 = 0.5 * _sum_per_graph((tgt0 - pred0) ** 2, bl, B)
+    else:
+        kl = kl_prior(gamma_tab, Tn, c0, bl, B, 1)
+        sigma0 = torch.sqrt(torch.sigmoid(g_0)) * 4.0
+        centred = c_t0 * 4.0 - 1.0
+        logp = torch.log(_cdf((centred + 0.5) / sigma0[bl]) - _cdf((centred - 0.5) / sigma0[bl]) + 1e-10)
+        logp = logp - torch.logsumexp(logp, dim=1, keepdim=True)
+        loss_0 = -_sum_per_graph(logp * (c0 * 4.0), bl, B)
+    loss_0 = loss_0 + neg_log_constants(gamma_tab, Tn, n, tgt0.shape[-1])
+    return (loss_t + loss_0 + kl).mean()
+
+
+def _noised(sd, batch, t, eps_x, eps_c, x0c, xr0, c0, gen_l, bl, br, B, Tn):
+    gp, gt_ = sd["pos_scheduler.gamma.gamma"], sd["type_scheduler.gamma.gamma"]
+    g = gamma_at(gp, t, Tn).view(B, 1)
+    x_noisy = torch.sqrt(torch.sigmoid(-g))[bl] * x0c + torch.sqrt(torch.sigmoid(g))[bl] * eps_x
+    x_noisy, xr_t = remove_mean_batch(x_noisy, xr0.detach().clone(), bl, br, B)
+    x_t = torch.where(gen_l.unsqueeze(-1), x_noisy, x0c)
+    g2 = gamma_at(gt_, t, Tn).view(B, 1)
+    c_t = torch.where(gen_l.unsqueeze(-1), torch.sqrt(torch.sigmoid(-g2))[bl] * c0 + torch.sqrt(torch.sigmoid(g2))[bl] * eps_c, c0)
+    return x_t, c_t, xr_t
+
+
+def get_loss_eval(sd, batch, t_long, draws, num_classes, Tn):
+    """DiffSBDD.get_loss with the model in eval mode (diffsbdd.py:95-191): ``t_long`` [B] integer times;
+    ``draws`` = (eps_x, eps_c, eps_x0, eps_c0) in the reference's draw order."""
+    x0 = batch["ligand_pos"]
+    bl, br = batch["ligand_element_batch"], batch["protein_element_batch"]
+    gen_l = batch.get("ligand_gen_flag", torch.ones(x0.shape[0], dtype=torch.bool))
+    B = int(bl.max()) + 1
+    c0 = F.one_hot(batch["ligand_atom_type"], num_classes) / 4.0
+    v_rec = batch["protein_atom_feature"] / 4.0
+    s = (t_long - 1) / Tn
+    t = t_long / Tn
+    gp, gt_ = sd["pos_scheduler.gamma.gamma"], sd["type_scheduler.gamma.gamma"]
+    x0c, xr0 = remove_mean_batch(x0, batch["protein_pos"], bl, br, B)
+    eps_x, eps_c, eps_x0, eps_c0 = draws
+    x_t, c_t, xr_t = _noised(sd, batch, t, eps_x, eps_c, x0c, xr0, c0, gen_l, bl, br, B, Tn)
+    x_pred, c_pred = denoise(sd, batch, x_t, c_t, xr_t, v_rec)
+    x_z, c_z, xr_z = _noised(sd, batch, torch.zeros_like(s), eps_x0, eps_c0, x0c, xr0, c0, gen_l, bl, br, B, Tn)
+    x_pred0, c_pred0 = denoise(sd, batch, x_z, c_z, xr_z, v_rec)
+    return {"pos": score_loss_eval(gp, Tn, x_pred, eps_x, s, t, bl, B, x_pred0, eps_x0, x0=x0c),
+            "atom": score_loss_eval(gt_, Tn, c_pred, eps_c, s, t, bl, B, c_pred0, eps_c0, c0=c0, c_t0=c_z)}
+
+
+def eval_times(Tn, eval_interval=10):
+    """diffsbdd.py:74-78: np.linspace(1, T, eval_interval), truncated to integers"""
+    return [int(v) for v in np.linspace(1, Tn, eval_interval)]
+
+
+def forward_eval(sd, batch, draws_per_time, num_classes, Tn, eval_interval=10):
+    """DiffSBDD.forward in eval mode (diffsbdd.py:72-86): the mean of get_loss over the evaluation times."""
+    B = int(batch["ligand_element_batch"].max()) + 1
+    tot = {"pos": 0.0, "atom": 0.0}
+    times = eval_times(Tn, eval_interval)
+    for tv, draws in zip(times, draws_per_time):
+        ld = get_loss_eval(sd, batch, torch.full((B,), tv, dtype=torch.long), draws, num_classes, Tn)
+        for k in tot:
+            tot[k] = tot[k] + ld[k]
+    return {k: v / len(times) for k, v in tot.items()}

@@ -393,6 +393,39 @@ def diffsbdd_train_case(name, batch, seed, t_override=None):
     print(name, {k: float(v) for k, v in loss_dict.items()}, "t", t.tolist())
 
 
+def diffsbdd_eval_case(name, batch, seed, eval_interval=3):
+    """DiffSBDD.forward of the unmodified reference in eval mode (diffsbdd.py:72-86): variational bound averaged over
+    ``eval_interval`` evenly spaced times, two denoiser calls per time."""
+    if not _selected(name):
+        return
+    M = ref_shim.load_reference()
+    T = 1000
+    cfg = ref_shim.AttrDict(
+        type="diffsbdd", num_atomtype=8, eval_interval=eval_interval,
+        encoder=dict(type="unitransformer", node_feat_dim=128, n_heads=16, num_layers=9),
+        generator=dict(pos_schedule=dict(type="polynomial_2"), atom_schedule=dict(type="polynomial_2"),
+                       num_diffusion_timesteps=T, time_sampler="random"),
+        embedder=dict(emb_dim=128, atom=dict(type="linear"), residue=dict(type="linear")))
+    model = M.get_model(cfg)
+    model.load_state_dict(W.synthetic_state_dict_diffsbdd(8, 9, seed=0, num_timesteps=T), strict=True)
+    model.eval()
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        loss_dict, results = model(batch)
+    assert len(results) == eval_interval
+    torch.manual_seed(seed)
+    n = batch["ligand_pos"].shape[0]
+    out = {"seed": seed, "eval_interval": eval_interval}
+    for k in range(eval_interval):     # draw order per time: pos noise, type noise, then the t = 0 pair
+        for tag, shape in (("eps_x", (n, 3)), ("eps_c", (n, 8)), ("eps_x0", (n, 3)), ("eps_c0", (n, 8))):
+            out[f"{tag}_{k}"] = _np(torch.randn(*shape))
+    for k, v in loss_dict.items():
+        out["loss_" + k] = _np(v)
+    out.update({"batch_" + k: _np(v) for k, v in batch.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, {k: float(v) for k, v in loss_dict.items()})
+
+
 def priors_case(name):
     """Ligand-size prior of the reference (repo/datasets/transforms/init_lig.py:28-52,232-258): pocket size function and
     bin lookup on seeded pockets, the bin edges, and per-bin mean / support of the histogram table (the table itself is
@@ -473,6 +506,7 @@ def main():
     # a unit makes two fp32 evaluation orders differ by 0.5 % in one tensor -- seen with seed 65)
     diffsbdd_train_case("train_loss_diffsbdd_t0", small_batch([(58, 11), (44, 8)], seed=67, num_classes=8), seed=19,
                         t_override=torch.tensor([0.0, 640.0]))
+    diffsbdd_eval_case("eval_loss_diffsbdd", small_batch([(64, 10), (50, 12)], seed=69, num_classes=8), seed=20)
     diffbp_train_case("train_loss_diffbp", small_batch([(64, 10), (50, 12), (57, 9)], seed=63), seed=17)
     sample_case("sample_T5", small_batch([(40, 8), (36, 6)], seed=31), T=5, seed=9)
     b = small_batch([(44, 9), (37, 8)], seed=51)

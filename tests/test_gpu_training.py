@@ -267,3 +267,21 @@ def test_diffsbdd_training_step_matches_reference_gradients(golden_dir, case):
         assert bool((err <= tol).all()), f"{k}: max err {err.max():.3e} vs norm {ref_norm:.3e}"
         n += 1
     assert n == 8 + 6 + 9 * 36 + 4
+
+
+def test_diffsbdd_eval_loss_matches_reference(golden_dir):
+    """DiffSBDD.forward in eval mode (diffsbdd.py:72-86): the variational bound averaged over the evaluation times, two
+    denoiser calls per time, against the value recorded from the unmodified reference"""
+    from oracle import weights as W
+    g = load(golden_dir, "eval_loss_diffsbdd")
+    K = int(g["eval_interval"])
+    m = C.get_model(C.default_diffsbdd_config(8, eval_interval=K))
+    m.load_state_dict(W.synthetic_state_dict_diffsbdd(8, 9, seed=0, num_timesteps=1000), strict=True)
+    m = m.to(DEV).eval()
+    batch = golden_batch(g, DEV)
+    draws = [tuple(g[f"{tag}_{k}"].to(DEV) for tag in ("eps_x", "eps_c", "eps_x0", "eps_c0")) for k in range(K)]
+    with torch.no_grad():
+        ld, results = m(batch, noise=draws)
+    assert len(results) == K
+    for k in ("pos", "atom"):
+        assert abs(float(ld[k]) - g["loss_" + k]) <= 2e-4 * abs(g["loss_" + k]) + 1e-6, (k, float(ld[k]), g["loss_" + k])

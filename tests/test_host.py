@@ -206,8 +206,20 @@ def test_diffsbdd_model_class(golden_dir):
     oa, ob = OD.sample_p_zs_given_zt(sd["pos_scheduler.gamma.gamma"], 1000, s, t, zt, pocket, bl, br, 2, pred, eps, True)
     assert torch.equal(a, oa) and torch.equal(b, ob)
     assert torch.allclose(OD.scatter_mean(a, bl, 2), torch.zeros(2, 3), atol=1e-6)   # COM-free after the draw
-    with pytest.raises(NotImplementedError):      # evaluation-mode VLB is not built; training mode is (GPU tests)
-        model.eval()(dict())
+    # evaluation-mode loss terms of the scheduler (diffusion_scheduler.py:902-928) against the oracle on random inputs
+    gam = sd["type_scheduler.gamma.gamma"]
+    c0 = torch.nn.functional.one_hot(torch.tensor([1, 3, 0, 7, 2]), 8).float() / 4.0
+    p1, e1, p0, e0 = (torch.randn(5, 8, generator=g) for _ in range(4))
+    c_t0 = c0 + 0.01 * torch.randn(5, 8, generator=g)
+    s2, t2 = torch.tensor([499, 0]) / 1000, torch.tensor([500, 1]) / 1000
+    with torch.no_grad():
+        got, _ = model.type_scheduler.get_score_loss_eval(p1, e1, s2, t2, None, bl, 2, p0, e0, c_lig_0=c0, c_lig_t0=c_t0)
+        ref = OD.score_loss_eval(gam, 1000, p1, e1, s2, t2, bl, 2, p0, e0, c0=c0, c_t0=c_t0)
+        assert torch.allclose(got, ref, rtol=1e-6, atol=0), (got, ref)
+        x0c = zt - OD.scatter_mean(zt, bl, 2)[bl]
+        got, _ = sch.get_score_loss_eval(pred, eps, s2, t2, None, bl, 2, p0[:, :3], e0[:, :3], x_lig_0=x0c)
+        ref = OD.score_loss_eval(sd["pos_scheduler.gamma.gamma"], 1000, pred, eps, s2, t2, bl, 2, p0[:, :3], e0[:, :3], x0=x0c)
+        assert torch.allclose(got, ref, rtol=1e-6, atol=0), (got, ref)
 
 
 def test_diffbp_model_class(golden_dir):

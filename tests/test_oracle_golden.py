@@ -207,3 +207,19 @@ def test_diffsbdd_training_loss_and_gradients_match_reference(golden_dir, case):
         torch.testing.assert_close(sample, g["g/" + k], rtol=1e-4, atol=1e-8 + 1e-5 * ref_norm / max(flat.numel(), 1) ** 0.5)
         n += 1
     assert n == 8 + 6 + 9 * 36 + 4
+
+
+def test_diffsbdd_eval_loss_matches_reference(golden_dir):
+    """DiffSBDD.forward in eval mode (diffsbdd.py:72-86): the variational bound with the SNR-weighted loss_t, the KL prior
+    and the t = 0 reconstruction term from a second denoiser call, averaged over the evaluation times"""
+    from oracle import diffsbdd as OS
+    g = load(golden_dir, "eval_loss_diffsbdd")
+    batch = golden_batch(g)
+    sd = W.synthetic_state_dict_diffsbdd(8, 9, seed=0, num_timesteps=1000)
+    K = int(g["eval_interval"])
+    draws = [tuple(g[f"{tag}_{k}"] for tag in ("eps_x", "eps_c", "eps_x0", "eps_c0")) for k in range(K)]
+    assert OS.eval_times(1000, K) == [1, 500, 1000]
+    with torch.no_grad():
+        losses = OS.forward_eval(sd, batch, draws, 8, 1000, eval_interval=K)
+    for k in ("pos", "atom"):
+        assert abs(float(losses[k]) - g["loss_" + k]) <= 5e-6 * abs(g["loss_" + k]) + 1e-6, (k, float(losses[k]), g["loss_" + k])
