@@ -26,3 +26,5 @@ find $OUT/prof_$TAG -name "*kernel_stats*" | head -3
 f=$(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -20 "$f" && cp "$f" $OUT/kernel_stats_$TAG.csv
 # keep the merged-back payload small
 find $OUT/prof_$TAG -name "*kernel_trace.csv" -size +20M -delete
+echo "== training bench (configs[4] shape) =="
+timeout 300 python bench.py --workload train --steps 10 --warmup 3 2>&1 | tail -1 | tee $OUT/bench_train_$TAG.json
