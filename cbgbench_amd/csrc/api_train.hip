@@ -154,10 +154,8 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     const int eg = edge_grid(n), ng = node_grid(n);
     // recompute the node stage of the forward: the MFMA node kernels (centred projection; own columns and query fold only
     // for the listed rows) with the MFMA edge backward, the first-generation ones with the VALU cross-check kernel
-    static const bool v1node = getenv("CBGX_BWD_V1NODE") != nullptr;
     const bool mfma = g_edge_impl == 0;
-    const bool cnode = mfma && !v1node;
-    if (cnode) {
+    if (mfma) {
         HIP_TRY(launch_node_mfma(att, h_in, lig, n, w.P, w.qs, w.Qt, rows, n_rows, nullptr, nullptr, s));
     } else {
         HIP_TRY(launch_node_gemm(h_in, H, att + A_WN, att + A_BN, w.P, PROW, n, PROW, 0, s));
@@ -168,7 +166,7 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     // cbgx_debug_set_edge_kernel(1) selects the first-generation (VALU) backward kernel as an on-device cross-check
     if (mfma)
         HIP_TRY(launch_edge_backward_mfma(x2h, att, x, w.P, w.Qt, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n,
-                                          w.T, w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s, cnode ? 1 : 0));
+                                          w.T, w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s, 1));
     else
         HIP_TRY(launch_edge_backward(x2h, att, x, w.P, w.Qt, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n, w.T,
                                      w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s));

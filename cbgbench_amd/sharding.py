@@ -30,7 +30,10 @@ def init_process_group(backend=None):
 
 def barrier():
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":      # name the device: the communicator is created lazily at the first collective
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def reduce_max_sum(elapsed_s, units, device="cpu"):
