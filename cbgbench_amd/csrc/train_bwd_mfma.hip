@@ -12,6 +12,11 @@
 // scatter stay on the vector ALU: they are O(32 x 256) per node.  Operands of every MFMA block are loaded into
 // registers first (explicit scheduling fences): the compiler otherwise serialises load -> wait -> 2 MFMAs.
 // MFMA 16x16x4 fp32 operand layout (lane l: i = l & 15, kq = l >> 4): A[i][kq], B[kq][i], D regs r: D[4 kq + r][i].
+//
+// The file also holds the node-level kernels of the backward (further down, each with its own header): the query-MLP
+// backward (q_backward_mfma_kernel), the weight-gradient outer products over nodes (outer_accum_mfma_kernel,
+// wgrad_mfma_kernel) and the input-gradient product (dgrad_mfma_kernel).  They read both MFMA operands straight from global
+// memory (no LDS staging), issue all gathers of a pass before its first MFMA and never predicate a load.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
