@@ -40,6 +40,11 @@ struct Tape {
     float* e_w;
     float* xs;   // [(L+1)][N][3]   xs[l] = coordinates entering layer l
     float* hs;   // [(L+1)][N][128] hs[l] = features entering layer l (hs[l+1] = x2h output = h2x input)
+    // node stage of every attention block as the forward computed it (block 2l = x2h of layer l, 2l+1 = h2x): the
+    // projection P [N][640] and the folded query Qt [N][16][128].  177 KB per node and layer -- 3.2 GB for a 32-graph
+    // batch, a cheap trade on a 288 GB part for not running three node kernels per block again in the backward.
+    float* P;    // [2L][N][640]
+    float* Qt;   // [2L][N][16][128]
     size_t total;
 };
 
@@ -54,6 +59,8 @@ static Tape carve_tape(void* base, int n, int L) {
     t.e_w = (float*)take(N * KNN * 4);
     t.xs = (float*)take((size_t)(L + 1) * N * 3 * 4);
     t.hs = (float*)take((size_t)(L + 1) * N * H * 4);
+    t.P = (float*)take((size_t)2 * L * N * PROW * 4);
+    t.Qt = (float*)take((size_t)2 * L * N * HEADS * H * 4);
     t.total = off;
     return t;
 }
@@ -150,12 +157,17 @@ static int fold_slabs(const float* src, int n_slabs, size_t stride, int size, Tr
 static int attention_block_backward(bool x2h, const float* att, const float* x, const float* h_in, const float* g_out,
                                     const int32_t* nbr, const int32_t* deg, const uint8_t* lig, const float* e_w,
                                     const int* rows, const int* n_rows, int n, TrainWs& w, float* gh, float* dx,
-                                    float* de_w, float* const* grads, hipStream_t s) {
+                                    float* de_w, float* const* grads, hipStream_t s, const float* P_saved = nullptr,
+                                    const float* Qt_saved = nullptr) {
     const int eg = edge_grid(n), ng = node_grid(n);
     // recompute the node stage of the forward: the MFMA node kernels (centred projection; own columns and query fold only
     // for the listed rows) with the MFMA edge backward, the first-generation ones with the VALU cross-check kernel
+    // (skipped when the taped forward left its own P / Qt: P_saved, Qt_saved)
     const bool mfma = g_edge_impl == 0;
-    if (mfma) {
+    const float* Pn = P_saved ? P_saved : w.P;
+    const float* Qn = Qt_saved ? Qt_saved : w.Qt;
+    if (P_saved && Qt_saved) {
+    } else if (mfma) {
         HIP_TRY(launch_node_mfma(att, h_in, lig, n, w.P, w.qs, w.Qt, rows, n_rows, nullptr, nullptr, s));
     } else {
         HIP_TRY(launch_node_gemm(h_in, H, att + A_WN, att + A_BN, w.P, PROW, n, PROW, 0, s));
@@ -165,10 +177,10 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     HIP_TRY(hipMemsetAsync(w.dP, 0, (size_t)n * PROW * sizeof(float), s));
     // cbgx_debug_set_edge_kernel(1) selects the first-generation (VALU) backward kernel as an on-device cross-check
     if (mfma)
-        HIP_TRY(launch_edge_backward_mfma(x2h, att, x, w.P, w.Qt, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n,
+        HIP_TRY(launch_edge_backward_mfma(x2h, att, x, Pn, Qn, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n,
                                           w.T, w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s, 1));
     else
-        HIP_TRY(launch_edge_backward(x2h, att, x, w.P, w.Qt, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n, w.T,
+        HIP_TRY(launch_edge_backward(x2h, att, x, Pn, Qn, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n, w.T,
                                      w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s));
     float *k0w = grads[0], *k0b = grads[1], *kg = grads[2], *kb = grads[3], *k1w = grads[4], *k1b = grads[5];
     float *v0w = grads[6], *v0b = grads[7], *vg = grads[8], *vb = grads[9], *v1w = grads[10], *v1b = grads[11];
@@ -199,7 +211,7 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     {
         const int tiles = (n + 15) / 16, qgrid = tiles < 4 * NODE_GRID ? tiles : 4 * NODE_GRID;   // ~43 KB LDS: 3 per CU
         HIP_TRY(hipMemsetAsync(w.qln, 0, 2 * H * sizeof(float), s));
-        HIP_TRY((mfma ? launch_q_backward_mfma : launch_q_backward)(att, w.P, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP,
+        HIP_TRY((mfma ? launch_q_backward_mfma : launch_q_backward)(att, Pn, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP,
                                                                     w.qln, qgrid, s));
     }
     // node-level reductions, all into one slab per workgroup (NS_* layout), folded and scattered once:
@@ -301,10 +313,13 @@ int cbgx_unitransformer_forward_train(const float* packed, int num_layers, int n
         const float* hc = tp.hs + (size_t)l * nh;
         float* xn = tp.xs + (size_t)(l + 1) * nx;
         float* hn = tp.hs + (size_t)(l + 1) * nh;
+        float* Px = tp.P + (size_t)(2 * l) * n_nodes * PROW;
+        float* Qx = tp.Qt + (size_t)(2 * l) * n_nodes * HEADS * H;
         HIP_TRY(launch_attention(true, packed + x2h_off(l), xc, hc, tp.nbr, tp.deg, lig_flag, gen_flag, tp.e_w, n_nodes,
-                                 w.P, w.Qt, w.qs, hn, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+                                 Px, Qx, w.qs, hn, nullptr, nullptr, nullptr, nullptr, nullptr, s));
         HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, tp.nbr, tp.deg, lig_flag, gen_flag, tp.e_w, n_nodes,
-                                 w.P, w.Qt, w.qs, xn, nullptr, w.act, w.act_count, nullptr, nullptr, s));
+                                 Px + (size_t)n_nodes * PROW, Qx + (size_t)n_nodes * HEADS * H, w.qs, xn, nullptr, w.act,
+                                 w.act_count, nullptr, nullptr, s));
     }
     const float* hl = tp.hs + (size_t)num_layers * nh;
     HIP_TRY(hipMemcpyAsync(x_out, tp.xs + (size_t)num_layers * nx, nx * 4, hipMemcpyDeviceToDevice, s));
@@ -447,8 +462,11 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         // x_{l+1} = x_l + gen * H2X(x_l, h_mid): identity path first, then the block's own contributions
         const int nxt = cur ^ 1;
         HIP_TRY(hipMemcpyAsync(w.gx[nxt], w.gx[cur], nx * 4, hipMemcpyDeviceToDevice, s));
+        const float* Px = tp.P + (size_t)(2 * l) * n * PROW;
+        const float* Qx = tp.Qt + (size_t)(2 * l) * n * HEADS * H;
         RC_TRY(attention_block_backward(false, packed + h2x_off(l), xl, h_mid, w.gx[cur], tp.nbr, tp.deg, lig_flag, tp.e_w,
-                                        w.act, w.act_count, n, w, w.gh, w.gx[nxt], w.de_w, g + 18, s));
+                                        w.act, w.act_count, n, w, w.gh, w.gx[nxt], w.de_w, g + 18, s,
+                                        Px + (size_t)n * PROW, Qx + (size_t)n * HEADS * H));
         // h_mid = h_in + X2H(x_l, h_in): w.gh holds dL/dh_mid, which is also the residual part of dL/dh_in.  The edge
         // kernel reads it (through the fold) before the final GEMM accumulates into it, so a snapshot is needed.
         HIP_TRY(hipMemcpyAsync(w.tmp, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
@@ -456,7 +474,7 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         const int* rows = (prune && k < 2) ? w.rf_list[k] : nullptr;
         const int* n_rows = (prune && k < 2) ? w.rf_count + 16 * k : nullptr;
         RC_TRY(attention_block_backward(true, packed + x2h_off(l), xl, h_in, w.tmp, tp.nbr, tp.deg, lig_flag, tp.e_w,
-                                        rows, n_rows, n, w, w.gh, w.gx[nxt], w.de_w, g, s));
+                                        rows, n_rows, n, w, w.gh, w.gx[nxt], w.de_w, g, s, Px, Qx));
         cur = nxt;
     }
     if (grad_h_in) HIP_TRY(hipMemcpyAsync(grad_h_in, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
