@@ -182,7 +182,8 @@ int cbgx_targetdiff_epilogue_traj(const float *x_den, const float *logits, const
  * (unitransformer.py:102-123) backwards through every X2HAttention / H2XAttention (x2h_attention.py:43-97,
  * h2x_attention.py:34-73), the gate and the classifier.  libcbgx replaces that pair with
  *   cbgx_unitransformer_forward_train : same outputs as cbgx_unitransformer_forward (no pruning) and a *tape*
- *       (caller-owned, cbgx_train_tape_bytes) holding the kNN lists, the gate and the per-layer x / h inputs;
+ *       (caller-owned, cbgx_train_tape_bytes) holding the kNN lists, the gate, the per-layer x / h inputs and the node
+ *       stage of every block (projection [N,640] + folded query [N,16,128]: 177 KB per node and layer);
  *   cbgx_unitransformer_backward      : given dL/dx_out [N,3], dL/dh_out [N,128], dL/dlogits [N,C] (each may be
  *       NULL = zero) it recomputes the per-edge intermediates block by block (nothing per-edge is ever stored) and
  *       writes dL/dh_in [N,128] (may be NULL) and the gradient of every parameter tensor: `grads` is a HOST array
