@@ -30,7 +30,7 @@ static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 constexpr int EDGE_GRID = 256;    // persistent workgroups of the edge backward (one per CU: ~97 KB LDS each)
 constexpr int NODE_GRID = 256;    // persistent workgroups of the node-level reductions
 constexpr int FOLD = 8;           // slab reductions are two-level: n_slabs -> FOLD (slab_fold_kernel) -> 1 (reduce_store)
-constexpr int GATE_GRID = 256;
+constexpr int GATE_GRID = 1024;  // gate weight-gradient kernel: 160-thread workgroups, four per CU keep every SIMD busy
 constexpr int MAX_SPLITS = 128;   // node groups of the weight-gradient products (one [128 x 640] partial slab each)
 
 // ---- tape: what the taped forward keeps for the backward ------------------------------------------------
