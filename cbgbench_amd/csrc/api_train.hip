@@ -164,14 +164,16 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     // for the listed rows) with the MFMA edge backward, the first-generation ones with the VALU cross-check kernel
     // (skipped when the taped forward left its own P / Qt: P_saved, Qt_saved)
     const bool mfma = g_edge_impl == 0;
-    const float* Pn = P_saved ? P_saved : w.P;
-    const float* Qn = Qt_saved ? Qt_saved : w.Qt;
-    if (P_saved && Qt_saved) {
-    } else if (mfma) {
-        HIP_TRY(launch_node_mfma(att, h_in, lig, n, w.P, w.qs, w.Qt, rows, n_rows, nullptr, nullptr, s));
-    } else {
-        HIP_TRY(launch_node_gemm(h_in, H, att + A_WN, att + A_BN, w.P, PROW, n, PROW, 0, s));
-        HIP_TRY(launch_node_query_v1(att, w.P, w.Qt, n, s));
+    const bool saved = P_saved && Qt_saved;
+    const float* Pn = saved ? P_saved : w.P;
+    const float* Qn = saved ? Qt_saved : w.Qt;
+    if (!saved) {
+        if (mfma) {
+            HIP_TRY(launch_node_mfma(att, h_in, lig, n, w.P, w.qs, w.Qt, rows, n_rows, nullptr, nullptr, s));
+        } else {
+            HIP_TRY(launch_node_gemm(h_in, H, att + A_WN, att + A_BN, w.P, PROW, n, PROW, 0, s));
+            HIP_TRY(launch_node_query_v1(att, w.P, w.Qt, n, s));
+        }
     }
     if (x2h) HIP_TRY(launch_fold_grad(att, g_out, n, w.Gt, w.gb, s));
     HIP_TRY(hipMemsetAsync(w.dP, 0, (size_t)n * PROW * sizeof(float), s));
