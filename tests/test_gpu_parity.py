@@ -232,6 +232,38 @@ def test_properties_at_full_batch(model):
         assert torch.equal(xo[~gen], x[~gen])
 
 
+def test_full_config2_job_in_one_batch(model, synthetic_sd):
+    """BASELINE configs[1] at full size in ONE batch: 100 pockets x 10 samples = 1000 graphs, ~5.3e5 nodes -- the folded
+    query alone is 4.3 GB, so every 32-bit byte offset would wrap.  The last graph (highest addresses) and one past the
+    2 GB mark must equal the same graph run alone bit for bit (batch independence) and match the oracle."""
+    rng = np.random.default_rng(11)
+    pk = [synthetic.make_pocket(rng, int(rng.integers(350, 651))) for _ in range(100)]
+    plist = [p for p in pk for _ in range(10)]
+    nlig = [int(rng.integers(10, 46)) for _ in plist]
+    batch = synthetic.make_batch(plist, nlig, rng, 13)
+    x, h, batch_idx, lig_flag, gen, gp = _composed(model, batch)
+    assert x.shape[0] > 450_000
+    den = model.denoiser
+    with torch.no_grad():
+        xo, ho, lo = den(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
+        assert torch.isfinite(xo).all() and torch.isfinite(ho).all() and torch.isfinite(lo).all()
+        assert torch.equal(xo[~gen], x[~gen]) and bool((xo[gen] != x[gen]).any())
+        for gidx in (999, 620, 0):
+            s, e = int(gp[gidx]), int(gp[gidx + 1])
+            gp1 = torch.tensor([0, e - s], dtype=torch.int32, device=DEV)
+            x1, h1, l1 = den(x=x[s:e].contiguous(), h=h[s:e].contiguous(),
+                             batch_idx=torch.zeros(e - s, dtype=torch.long, device=DEV),
+                             lig_flag=lig_flag[s:e].contiguous(), gen_flag=gen[s:e].contiguous(), graph_ptr=gp1)
+            assert torch.equal(x1, xo[s:e]) and torch.equal(h1, ho[s:e]) and torch.equal(l1, lo[s:e]), gidx
+    s, e = int(gp[999]), int(gp[1000])
+    rx, rh, rl = OU.unitransformer_forward(synthetic_sd, x[s:e].cpu(), h[s:e].cpu(), torch.zeros(e - s, dtype=torch.long),
+                                           lig_flag[s:e].cpu(), gen[s:e].cpu())
+    close(xo[s:e], rx, "x_out (graph 999 of 1000)")
+    close(ho[s:e], rh, "h_out (graph 999 of 1000)", scale=10.0)
+    lig = lig_flag[s:e].cpu()
+    assert torch.equal(lo[s:e].cpu()[lig].argmax(-1), rl[lig].argmax(-1))
+
+
 def test_linker_256_graphs_runs_and_freezes_context(model):
     """config 3 shape: 256 ragged linker graphs in one batch (N ~ 1.3e5, E ~ 4e6)."""
     batch = synthetic.linker_batch(256, seed=7)
