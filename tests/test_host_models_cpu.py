@@ -159,3 +159,45 @@ def test_diffbp_training_plumbing_matches_reference(golden_dir):
     k0 = "com_head.h2xattentions.2.xk_func.net.0.weight"
     gd = m.com_head.params[m.com_head.keys.index(k0)].grad
     assert abs(float(gd.double().norm()) - float(g["gnorm/" + k0])) <= 2e-5 * float(g["gnorm/" + k0])
+
+
+def test_diffsbdd_sampler_plumbing_matches_reference(golden_dir):
+    """DiffSBDD.sample (diffsbdd.py:240-319) of a 5-step model: the gamma-schedule ancestral sampler, COM projection and the
+    final p(x, h | z_0) draw, bit for bit against the reference's trajectory with its Gaussian draws replayed"""
+    g = load(golden_dir, "diffsbdd_sample_T5")
+    T, Cn = int(g["T"]), 8
+    sd = W.synthetic_state_dict_diffsbdd(Cn, 9, seed=0, num_timesteps=T)
+    m = with_oracle_denoiser(C.get_model(C.default_diffsbdd_config(Cn, num_diffusion_timesteps=T)), sd).eval()
+    batch = golden_batch(g)
+    n_lig = batch["ligand_element_batch"].shape[0]
+    torch.manual_seed(int(g["seed"]))
+    draws = []
+    for _ in range(T + 2):
+        draws += [torch.randn(n_lig, 3), torch.randn(n_lig, Cn)]
+    traj = m.sample(batch, noise_draws=draws)
+    assert sorted(traj.keys()) == list(range(-1, T))
+    for t in range(-1, T):
+        torch.testing.assert_close(traj[t][0], g[f"traj_x_{t}"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(traj[t][1], g[f"traj_c_{t}"], rtol=1e-5, atol=1e-5)
+
+
+def test_diffbp_sampler_plumbing_matches_reference(golden_dir):
+    """DiffBP.sample (diffbp.py:240-299) of a 5-step model: score-type position update with the COM shift, absorbing-state
+    type sampler, the reference's noise tape replayed"""
+    g = load(golden_dir, "diffbp_sample_T5")
+    T, Cn = int(g["T"]), 13
+    sd = W.synthetic_state_dict_diffbp(Cn, 9, seed=0, num_timesteps=T)
+    m = C.get_model(C.default_diffbp_config(Cn, num_diffusion_timesteps=T))
+    m.load_state_dict(sd, strict=True)
+    m.denoiser, m.com_head = OracleDenoiser(sd), OracleComHead(sd)
+    m.eval()
+    batch = golden_batch(g)
+    n_lig = batch["ligand_pos"].shape[0]
+    torch.manual_seed(int(g["seed"]))
+    tape = {t: (torch.randn(n_lig, 3), torch.rand(n_lig)) for t in reversed(range(T))}
+    with torch.no_grad():
+        traj = m.sample(batch, noise_tape=tape)
+    assert sorted(traj.keys()) == list(range(-1, T))
+    for t in range(-1, T):
+        torch.testing.assert_close(traj[t][0], g[f"traj_x_{t}"], rtol=1e-5, atol=1e-5)
+        assert torch.equal(traj[t][1], g[f"traj_c_{t}"]), t
