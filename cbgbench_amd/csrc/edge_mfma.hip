@@ -67,6 +67,18 @@ __device__ __forceinline__ float xrow_max(float v) {
 }
 __device__ __forceinline__ float wave_sum(float v) { return xrow_sum(row16_sum(v)); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// packed fp32: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 do two lanes' worth of work per issue slot, so the elementwise
+// parts of the kernel (sum of squares, LayerNorm affine) are written on register pairs
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2v lo2(floatx4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ float2v hi2(floatx4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+__device__ __forceinline__ float2v splat2(float a) { float2v r = {a, a}; return r; }
+// 1-ulp hardware approximations (v_rsq_f32, v_rcp_f32, v_sqrt_f32, v_exp_f32): the IEEE-exact library forms cost ~10
+// instructions each and the parity tolerance (1e-4 rel) is three orders of magnitude away
+__device__ __forceinline__ float fast_rsqrt(float a) { return __builtin_amdgcn_rsqf(a); }
+__device__ __forceinline__ float fast_rcp(float a) { return __builtin_amdgcn_rcpf(a); }
+__device__ __forceinline__ float fast_sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
+__device__ __forceinline__ float fast_exp(float a) { return __builtin_amdgcn_exp2f(a * 1.44269504088896340736f); }
 __device__ __forceinline__ floatx4 f4(float4 a) { floatx4 r = {a.x, a.y, a.z, a.w}; return r; }
 
 // edge type, unitransformer.py:92-97: (src lig, dst lig)->0, (lig, prot)->1, (prot, lig)->2, (prot, prot)->3
@@ -108,12 +120,15 @@ __device__ __forceinline__ floatx4 edge_major_half(const float4 (&pd)[8], const 
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the tail's operand loads (g, b, B row) below the MFMA block
     // LayerNorm: the first Linear is centred, so mean(pre) == 0 and var = mean(pre^2)
-    float v = 0.f;
+    float2v v2 = {0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-        v += (acc[t].x * acc[t].x + acc[t].y * acc[t].y) + (acc[t].z * acc[t].z + acc[t].w * acc[t].w);
-    v = xrow_sum(v);
-    const float rstd = 1.f / sqrtf(v * (1.f / H) + 1e-5f);
+    for (int t = 0; t < 8; ++t) {
+        v2 = lo2(acc[t]) * lo2(acc[t]) + v2;
+        v2 = hi2(acc[t]) * hi2(acc[t]) + v2;
+    }
+    const float v = xrow_sum(v2.x + v2.y);
+    const float rstd = fast_rsqrt(v * (1.f / H) + 1e-5f);
+    const float2v r2 = splat2(rstd);
     const float* lg_ = lds_ln + (2 * kv) * H + 4 * q;
     const float* lb_ = lds_ln + (2 * kv + 1) * H + 4 * q;
     // two interleaved accumulators: a dependent 16x16x4 MFMA needs 40 cycles, an independent one 32
@@ -121,12 +136,13 @@ __device__ __forceinline__ floatx4 edge_major_half(const float4 (&pd)[8], const 
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const floatx4 g = f4(ld4(lg_ + 16 * t)), b = f4(ld4(lb_ + 16 * t));
-        const floatx4 y = (acc[t] * rstd) * g + b;
+        const float2v ya = (lo2(acc[t]) * r2) * lo2(g) + lo2(b);
+        const float2v yb = (hi2(acc[t]) * r2) * hi2(g) + hi2(b);
         const float4 bb = PRE ? pre[t] : ld4(Brow + 16 * t);
-        out0 = MFMA(fmaxf(y.x, 0.f), bb.x, out0);
-        out1 = MFMA(fmaxf(y.y, 0.f), bb.y, out1);
-        out0 = MFMA(fmaxf(y.z, 0.f), bb.z, out0);
-        out1 = MFMA(fmaxf(y.w, 0.f), bb.w, out1);
+        out0 = MFMA(fmaxf(ya.x, 0.f), bb.x, out0);
+        out1 = MFMA(fmaxf(ya.y, 0.f), bb.y, out1);
+        out0 = MFMA(fmaxf(yb.x, 0.f), bb.z, out0);
+        out1 = MFMA(fmaxf(yb.y, 0.f), bb.w, out1);
     }
     return out0 + out1;
 }
@@ -218,7 +234,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             j0[hf] = j;
             lg0[hf] = valid && lig[j];
             const float rx = xi - x[3 * j], ry = yi - x[3 * j + 1], rz = zi - x[3 * j + 2];
-            dist0[hf] = sqrtf(rx * rx + ry * ry + rz * rz);
+            dist0[hf] = fast_sqrt(rx * rx + ry * ry + rz * rz);
         }
     }
 
@@ -249,7 +265,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
             for (int s = 0; s < 5; ++s) {
                 const float u = dist0[hf] - mu[s];
-                R[hf][s] = valid ? expf(-0.5f * (u * u)) : 0.f;
+                R[hf][s] = valid ? fast_exp(-0.5f * (u * u)) : 0.f;
             }
         }
         const unsigned long long b0 = __ballot(lg0[0]), b1 = __ballot(lg0[1]);
@@ -294,11 +310,11 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool valid = 4 * q + r + 16 * hf < d;
-                al[hf][r] = valid ? expf(al[hf][r] - mx) : 0.f;
+                al[hf][r] = valid ? fast_exp(al[hf][r] - mx) : 0.f;
                 den += al[hf][r];
             }
         den = xrow_sum(den);
-        const float inv_den = den > 0.f ? 1.f / den : 0.f;
+        const float inv_den = den > 0.f ? fast_rcp(den) : 0.f;
         const float4 ew0 = ld4(e_w + (size_t)i * KNN + 4 * q), ew1 = ld4(e_w + (size_t)i * KNN + 16 + 4 * q);
         const float ew[2][4] = {{ew0.x, ew0.y, ew0.z, ew0.w}, {ew1.x, ew1.y, ew1.z, ew1.w}};
         // neighbours in the E1 mapping
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                 nj[hf] = j;
                 nlg[hf] = valid && lig[j];
                 const float rx = nx - x[3 * j], ry = ny - x[3 * j + 1], rz = nz - x[3 * j + 2];
-                ndist[hf] = sqrtf(rx * rx + ry * ry + rz * rz);
+                ndist[hf] = fast_sqrt(rx * rx + ry * ry + rz * rz);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -390,15 +406,25 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                         for (int t = 0; t < 8; ++t) hv[t] = MFMA(Rm[s], fb[(t * 5 + s) * 64], hv[t]);
                 }
                 // LayerNorm per edge r (zero mean by construction): in-lane over t, across the 16 lanes of the row
+                {   // edges r and r + 1 share the packed instructions
+                    float2v va = {0.f, 0.f}, vb = {0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = 0.f;
+                    for (int t = 0; t < 8; ++t) {
+                        va = lo2(hv[t]) * lo2(hv[t]) + va;
+                        vb = hi2(hv[t]) * hi2(hv[t]) + vb;
+                    }
+                    float2v ra, rb;
+                    ra.x = fast_rsqrt(row16_sum(va.x) * (1.f / H) + 1e-5f);
+                    ra.y = fast_rsqrt(row16_sum(va.y) * (1.f / H) + 1e-5f);
+                    rb.x = fast_rsqrt(row16_sum(vb.x) * (1.f / H) + 1e-5f);
+                    rb.y = fast_rsqrt(row16_sum(vb.y) * (1.f / H) + 1e-5f);
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) v = fmaf(hv[t][r], hv[t][r], v);
-                    v = row16_sum(v);
-                    const float rstd = 1.f / sqrtf(v * (1.f / H) + 1e-5f);
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) hv[t][r] = fmaxf((hv[t][r] * rstd) * gv[t] + bv[t], 0.f);
+                    for (int t = 0; t < 8; ++t) {
+                        const float2v g2 = splat2(gv[t]), b2 = splat2(bv[t]);
+                        const float2v ya = (lo2(hv[t]) * ra) * g2 + b2;
+                        const float2v yb = (hi2(hv[t]) * rb) * g2 + b2;
+                        hv[t] = floatx4{fmaxf(ya.x, 0.f), fmaxf(ya.y, 0.f), fmaxf(yb.x, 0.f), fmaxf(yb.y, 0.f)};
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
