@@ -378,9 +378,17 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                 floatx4 hv[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    // a gathered float4 is four channels of one edge, a tile register quad is four edges of one channel:
+                    // plain v_add_f32 writes each sum where the MFMA wants it.  The empty asm keeps the vectoriser from
+                    // pairing the adds (it would build every pair with two v_mov first: 3 instructions per 2 sums).
                     const float4 sa = sva[hf][r], sb = svb[hf][r];
-                    hv[0][r] = pdv[0] + sa.x; hv[1][r] = pdv[1] + sa.y; hv[2][r] = pdv[2] + sa.z; hv[3][r] = pdv[3] + sa.w;
-                    hv[4][r] = pdv[4] + sb.x; hv[5][r] = pdv[5] + sb.y; hv[6][r] = pdv[6] + sb.z; hv[7][r] = pdv[7] + sb.w;
+                    const float in[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        float sum = pdv[t] + in[t];
+                        asm("" : "+v"(sum));
+                        hv[t][r] = sum;
+                    }
                 }
                 if (has_lig) {
                     const float* dw = lds_dwt + lig_i * 2 * H + H + 4 * c;
@@ -437,20 +445,27 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             // so the 16 lanes of a row (16 different Wbv rows, same columns) hit 16 different bank groups.
             float o8[8];
             const float* lds_wbv = lds + IMG_WBV;
+            // tiles 2tp, 2tp+1 paired once per node, so that the 8 x 32 products below are packed FMAs against adjacent
+            // weight pairs (same two partial sums, same order as the scalar form)
+            float2v sp[4][4];
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+                for (int rp = 0; rp < 4; ++rp) sp[tp][rp] = float2v{s2[2 * tp][rp], s2[2 * tp + 1][rp]};
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc) {
                 const float* wrow = lds_wbv + (size_t)(8 * c + cc) * H;
-                float a0 = 0.f, a1 = 0.f;
+                float2v a2 = {0.f, 0.f};
 #pragma unroll
                 for (int rp = 0; rp < 4; ++rp) {
-                    const float4 wa = ld4(wrow + (((4 * q + rp) ^ c) << 2));        // channels 16q + 4rp .. +3
-                    const float4 wb = ld4(wrow + (((16 + 4 * q + rp) ^ c) << 2));   // channels 64 + 16q + 4rp .. +3
-                    a0 = fmaf(wa.x, s2[0][rp], a0); a1 = fmaf(wa.y, s2[1][rp], a1);
-                    a0 = fmaf(wa.z, s2[2][rp], a0); a1 = fmaf(wa.w, s2[3][rp], a1);
-                    a0 = fmaf(wb.x, s2[4][rp], a0); a1 = fmaf(wb.y, s2[5][rp], a1);
-                    a0 = fmaf(wb.z, s2[6][rp], a0); a1 = fmaf(wb.w, s2[7][rp], a1);
+                    const floatx4 wa = f4(ld4(wrow + (((4 * q + rp) ^ c) << 2)));        // channels 16q + 4rp .. +3
+                    const floatx4 wb = f4(ld4(wrow + (((16 + 4 * q + rp) ^ c) << 2)));   // channels 64 + 16q + 4rp .. +3
+                    a2 = lo2(wa) * sp[0][rp] + a2;
+                    a2 = hi2(wa) * sp[1][rp] + a2;
+                    a2 = lo2(wb) * sp[2][rp] + a2;
+                    a2 = hi2(wb) * sp[3][rp] + a2;
                 }
-                o8[cc] = xrow_sum(a0 + a1);
+                o8[cc] = xrow_sum(a2.x + a2.y);
             }
             // lane (c, q) writes outputs n = 8c + 2q, 8c + 2q + 1
             const float oa = q == 0 ? o8[0] : (q == 1 ? o8[2] : (q == 2 ? o8[4] : o8[6]));
