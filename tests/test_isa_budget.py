@@ -1,0 +1,83 @@
+"""Register / scratch budgets of the hot kernels, read from the gfx950 ISA that hipcc emits (no GPU needed).
+A kernel that starts spilling or loses its occupancy target after an edit shows up here, at build time, instead of as a
+silent slowdown on the GPU box (0 B of scratch is what made the backward kernels fast)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "cbgbench_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def kernel_resources(source, tmp_path):
+    out = os.path.join(str(tmp_path), os.path.basename(source) + ".s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-S", "--cuda-device-only",
+           "-o", out, os.path.join(CSRC, source)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    res, name = {}, None
+    for line in open(out):
+        m = re.match(r"\s*\.amdhsa_kernel\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+            res[name] = {"body": 0}
+        elif name and ".amdhsa_private_segment_fixed_size" in line:
+            res[name]["scratch"] = int(line.split()[-1])
+        elif name and ".amdhsa_next_free_vgpr" in line:
+            res[name]["vgpr"] = int(line.split()[-1])
+        elif name and ".amdhsa_group_segment_fixed_size" in line:
+            res[name]["lds"] = int(line.split()[-1])
+        elif ".end_amdhsa_kernel" in line:
+            name = None
+    text = open(out).read()
+    return res, text
+
+
+def find(res, *needles):
+    hits = [k for k in res if all(n in k for n in needles)]
+    assert len(hits) == 1, (needles, hits)
+    return res[hits[0]]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_forward_edge_kernels_fit_their_budget(tmp_path):
+    res, text = kernel_resources("edge_mfma.hip", tmp_path)
+    # edge_mfma_kernel<X2H, WAVES = 8, ABL = 0, LISTED>: the three variants the product launches
+    x2h = find(res, "edge_mfma_kernelILb1ELi8ELi0ELb0E")
+    x2h_listed = find(res, "edge_mfma_kernelILb1ELi8ELi0ELb1E")
+    h2x_listed = find(res, "edge_mfma_kernelILb0ELi8ELi0ELb1E")
+    for k in (x2h, x2h_listed):
+        assert k["scratch"] == 0 and k["vgpr"] <= 256          # 8 waves per CU = 2 per SIMD need <= 256 registers
+        assert k["lds"] <= 160 * 1024
+    assert h2x_listed["scratch"] <= 32 and h2x_listed["vgpr"] <= 256
+    # the elementwise parts run packed (two fp32 per issue slot) and on the 1-ulp hardware approximations
+    assert text.count("v_pk_fma_f32") > 300 and "v_rsq_f32" in text and "v_exp_f32" in text
+    assert "v_div_fmas_f32" not in text.split("edge_mfma_kernelILb1ELi8ELi0ELb0E")[1].split(".end_amdhsa_kernel")[0]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_backward_kernels_fit_their_budget(tmp_path):
+    res, _ = kernel_resources("train_bwd_mfma.hip", tmp_path)
+    for x2h in ("Lb1E", "Lb0E"):
+        k = find(res, "edge_backward_mfma_kernelI" + x2h)
+        assert k["scratch"] == 0 and k["vgpr"] <= 256 and k["lds"] <= 160 * 1024   # 512 threads: 2 waves per SIMD
+    q = find(res, "q_backward_mfma_kernel")
+    assert q["scratch"] == 0 and q["vgpr"] <= 128 and q["lds"] <= 40 * 1024        # 4 workgroups per CU
+    for name in ("outer_accum_mfma_kernelILb1E", "outer_accum_mfma_kernelILb0E", "wgrad_mfma_kernel", "dgrad_mfma_kernel"):
+        k = find(res, name)
+        assert k["scratch"] == 0 and k["lds"] == 0 and k["vgpr"] <= 256            # operands straight from global memory
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_node_and_graph_kernels_do_not_spill(tmp_path):
+    res, _ = kernel_resources("node_mfma.hip", tmp_path)
+    for name in ("node_proj_kernel", "node_qmlp_kernel", "node_qfold_kernel"):
+        k = find(res, name)
+        assert k["scratch"] == 0 and k["lds"] <= 64 * 1024 and k["vgpr"] <= 256, (name, k)   # 64 KB: two workgroups per CU
+    res, _ = kernel_resources("graph_mfma.hip", tmp_path)
+    for name in ("knn_graph_reg_kernel", "edge_gate_mfma_kernel"):
+        k = find(res, name)
+        assert k["scratch"] == 0, (name, k)
