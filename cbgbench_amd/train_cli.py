@@ -114,9 +114,9 @@ class ShardedLoader:
             perm = torch.randperm(self.n, generator=g)
         else:
             perm = torch.arange(self.n)
-        pad = self.per_rank * self.world - self.n
-        if pad:
-            perm = torch.cat([perm, perm[:pad]])
+        total = self.per_rank * self.world
+        if total > self.n:                                   # wrap around (more than once when n_items < world / 2)
+            perm = perm.repeat((total + self.n - 1) // self.n)[:total]
         mine = perm[self.rank::self.world]
         return [mine[i:i + self.bs].tolist() for i in range(0, mine.numel(), self.bs)]
 

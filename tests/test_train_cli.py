@@ -26,6 +26,8 @@ def test_sharded_loader_partitions_every_epoch():
     it = iter(train_cli.ShardedLoader(3, 2, 0, 1, seed=0))
     seen = [next(it) for _ in range(4)]                                  # infinite: two epochs of two batches
     assert sorted(seen[0] + seen[1]) == [0, 1, 2] and sorted(seen[2] + seen[3]) == [0, 1, 2]
+    tiny = [train_cli.ShardedLoader(1, 2, r, 3, shuffle=False).epoch(0) for r in range(3)]
+    assert tiny == [[[0]], [[0]], [[0]]]                                  # fewer items than ranks: everyone still steps
     with pytest.raises(ValueError):
         train_cli.ShardedLoader(0, 2)
 
