@@ -28,16 +28,12 @@ import numpy as np
 import torch
 
 from . import get_model, load_config, set_num_atom_type, sharding, synthetic
-from .train import (FlatGradients, broadcast_parameters, get_optimizer, get_scheduler, sum_weighted_losses, train_step,
-                    validate)
+from .train import FlatGradients, broadcast_parameters, get_optimizer, get_scheduler, train_step, validate
 
 
 # ---- data ------------------------------------------------------------------------------------------------------
 class ComplexSet:
     """Protein-ligand complexes packed once (CSR on the host); ``collate(ids)`` builds a batch dict with index arithmetic."""
-
-    KEYS_REC = ("protein_pos", "protein_atom_feature", "protein_aa_type")
-    KEYS_LIG = ("ligand_pos", "ligand_atom_type")
 
     def __init__(self, complexes, center=True):
         t = lambda a, dt: torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).to(dt)
