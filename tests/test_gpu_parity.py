@@ -232,6 +232,31 @@ def test_properties_at_full_batch(model):
         assert torch.equal(xo[~gen], x[~gen])
 
 
+def test_permutation_of_atoms_within_a_graph(model):
+    """relabelling the atoms of a graph (protein atoms among themselves, ligand atoms among themselves, which
+    keeps the composed order of common.py:200) permutes the outputs the same way"""
+    batch = synthetic.denovo_batch(4, seed=9)
+    x, h, batch_idx, lig_flag, gen, gp = _composed(model, batch)
+    g = torch.Generator().manual_seed(3)
+    perm = []
+    for b in range(4):
+        s, e = int(gp[b]), int(gp[b + 1])
+        n_rec = int((~lig_flag[s:e]).sum())
+        assert not bool(lig_flag[s:s + n_rec].any())            # protein rows first
+        perm.append(s + torch.randperm(n_rec, generator=g))
+        perm.append(s + n_rec + torch.randperm(e - s - n_rec, generator=g))
+    perm = torch.cat(perm).to(DEV)
+    den = model.denoiser
+    with torch.no_grad():
+        xo, ho, lo = den(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
+        xp, hp, lp = den(x=x[perm].contiguous(), h=h[perm].contiguous(), batch_idx=batch_idx, lig_flag=lig_flag[perm].contiguous(),
+                         gen_flag=gen[perm].contiguous(), graph_ptr=gp)
+    close(xp, xo[perm], "x_out under an atom permutation")
+    close(hp, ho[perm], "h_out under an atom permutation", scale=10.0)
+    lig = lig_flag[perm]
+    assert torch.equal(lp[lig].argmax(-1), lo[perm][lig].argmax(-1))
+
+
 def test_full_config2_job_in_one_batch(model, synthetic_sd):
     """BASELINE configs[1] at full size in ONE batch: 100 pockets x 10 samples = 1000 graphs, ~5.3e5 nodes -- the folded
     query alone is 4.3 GB, so every 32-bit byte offset would wrap.  The last graph (highest addresses) and one past the
