@@ -75,6 +75,29 @@ def load_config(config_path):
 # atom-type vocabulary sizes: len(map_atom_type_only_to_index) = 8 (repo/utils/molecule/constants.py:54-63),
 # len(map_atom_type_aromatic_to_index) = 13 (:65-79).
 NUM_ATOM_TYPES = {"basic": 8, "add_aromatic": 13}
+# what an atom-type index stands for (the inverse of those two maps): atomic number, and for 'add_aromatic' the aromatic flag
+# -- the ``atom`` / ``aromatic`` fields sample.py:29-30 hands to the reconstruction step
+_ATOMIC_NUMBER = {"basic": (1, 6, 7, 8, 9, 15, 16, 17),
+                  "add_aromatic": (1, 6, 6, 7, 7, 8, 8, 9, 15, 15, 16, 16, 17)}
+_AROMATIC = {"add_aromatic": (False, False, True, False, True, False, True, False, False, True, False, True, False)}
+
+
+def get_atomic_number_from_index(index, mode):
+    """repo/utils/molecule/constants.py:85-94 for the two vocabularies the diffusion configs use"""
+    if mode not in _ATOMIC_NUMBER:
+        raise ValueError(mode)
+    return [_ATOMIC_NUMBER[mode][int(i)] for i in index]
+
+
+def is_aromatic_from_index(index, mode):
+    """constants.py:97-106: per-atom flags for 'add_aromatic', None for 'basic'"""
+    if mode == "basic":
+        return None
+    if mode not in _AROMATIC:
+        raise ValueError(mode)
+    return [_AROMATIC[mode][int(i)] for i in index]
+
+
 # transforms that carry a ``mode`` (repo/datasets/transforms: featurize_ligand*, assign_atomtype, ...)
 _MODE_KEYS = ("mode",)
 

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import get_model, load_config, priors, set_num_atom_type, sharding, synthetic
+from .config import get_atomic_number_from_index, is_aromatic_from_index
 
 
 def build_pocket_batch(pockets, num_samples, rng, num_classes, prior_types="uniform", device="cpu", num_dist=None,
@@ -30,12 +31,17 @@ def build_pocket_batch(pockets, num_samples, rng, num_classes, prior_types="unif
                                        type_prior=prior_types)
 
 
-def split_samples(x, c, batch_idx, n_graphs):
-    """per-graph (pos, atom type index) like ``split_batch_into_samples`` (sample.py:203-206)."""
+def split_samples(x, c, batch_idx, n_graphs, mode="add_aromatic"):
+    """per-graph records like ``split_batch_into_samples`` (sample.py:16-32): ``pos``, ``type`` (index), ``atom`` (atomic
+    numbers) and ``aromatic`` (flags, None in 'basic' mode) -- the arguments of ``reconstruct_mol`` (sample.py:211-214) -- plus
+    the raw ``type_vector``."""
     out = []
     for g in range(n_graphs):
         m = batch_idx == g
-        out.append({"pos": x[m].clone(), "atom_type": c[m].argmax(-1).clone(), "type_vector": c[m].clone()})
+        typ = c[m].argmax(-1) if c.dim() == 2 else c[m]
+        out.append({"pos": x[m].clone(), "type": typ.clone(), "atom_type": typ.clone(),
+                    "atom": get_atomic_number_from_index(typ.tolist(), mode),
+                    "aromatic": is_aromatic_from_index(typ.tolist(), mode), "type_vector": c[m].clone()})
     return out
 
 
@@ -52,6 +58,8 @@ def main(argv=None):
     ap.add_argument("--num_samples", type=int, default=None)
     ap.add_argument("--pockets_per_batch", type=int, default=10)
     ap.add_argument("--save_traj", action="store_true")
+    ap.add_argument("--final_state", action="store_true",
+                    help="write traj[-1] (the state after the last step) instead of traj[0], which sample.py:198 uses")
     ap.add_argument("--atom_num_dist", default=None,
                     help="the reference's size-conditioned ligand-size histogram (repo/datasets/transforms/_atom_num_dist.npy); "
                          "without it ligand sizes are U{10..45}")
@@ -102,8 +110,10 @@ def main(argv=None):
         batch = build_pocket_batch([pockets[i] for i in ids], num_samples, rng, config.model.num_atomtype, prior,
                                    device=dev, num_dist=num_dist)
         traj = model.sample(batch)
-        x, c, bidx = traj[-1] if config.model.type != "diffsbdd" else traj[0]
-        samples = split_samples(x.cpu(), c.cpu(), bidx.cpu(), len(ids) * num_samples)
+        # sample.py:198-201 hands traj[0] to the reconstruction -- for targetdiff / diffbp that is the state entering the
+        # last step, not traj[-1]; kept as the default for drop-in outputs, --final_state selects traj[-1]
+        x, c, bidx = traj[-1] if (args.final_state and config.model.type != "diffsbdd") else traj[0]
+        samples = split_samples(x.cpu(), c.cpu(), bidx.cpu(), len(ids) * num_samples, config.get("mode", "add_aromatic"))
         for k, pid in enumerate(ids):
             rec = {"pocket_index": pid, "samples": samples[k * num_samples:(k + 1) * num_samples]}
             if args.save_traj:

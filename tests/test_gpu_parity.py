@@ -420,6 +420,7 @@ def test_sampling_driver_end_to_end(tmp_path):
     for s in rec["samples"]:
         assert s["pos"].shape[1] == 3 and torch.isfinite(s["pos"]).all()
         assert s["atom_type"].min() >= 0 and s["atom_type"].max() < 13
+        assert len(s["atom"]) == s["pos"].shape[0] == len(s["aromatic"]) and set(s["atom"]) <= {1, 6, 7, 8, 9, 15, 16, 17}
 
 
 def test_static_context_cache_is_exact(model):

@@ -105,3 +105,25 @@ def test_priors_and_context_atoms():
     d = priors.build_sampling_batch(ps, 50, 13)
     c = torch.bincount(d["ligand_element_batch"])
     assert int(c.min()) >= 10 and int(c.max()) <= 45
+
+
+def test_sample_records_follow_the_reference_schema():
+    """split_batch_into_samples (sample.py:16-32): pos / type / atom / aromatic per graph; decode tables of
+    repo/utils/molecule/constants.py:54-106"""
+    import torch
+    from cbgbench_amd import sample_cli
+    from cbgbench_amd.config import get_atomic_number_from_index, is_aromatic_from_index
+    assert get_atomic_number_from_index(range(13), "add_aromatic") == [1, 6, 6, 7, 7, 8, 8, 9, 15, 15, 16, 16, 17]
+    assert is_aromatic_from_index([2, 4, 6, 9, 11, 0, 12], "add_aromatic") == [True] * 5 + [False] * 2
+    assert get_atomic_number_from_index(range(8), "basic") == [1, 6, 7, 8, 9, 15, 16, 17]
+    assert is_aromatic_from_index([0, 1], "basic") is None
+    try:
+        get_atomic_number_from_index([0], "full")
+        raise AssertionError("unsupported vocabulary must raise")
+    except ValueError:
+        pass
+    x = torch.arange(15.0).reshape(5, 3)
+    c = torch.nn.functional.one_hot(torch.tensor([2, 0, 12, 5, 5]), 13).float()
+    recs = sample_cli.split_samples(x, c, torch.tensor([0, 0, 1, 1, 1]), 2)
+    assert [r["atom"] for r in recs] == [[6, 1], [17, 8, 8]] and recs[0]["aromatic"] == [True, False]
+    assert recs[1]["type"].tolist() == [12, 5, 5] and torch.equal(recs[1]["pos"], x[2:])
