@@ -55,7 +55,13 @@ def test_forward_edge_kernels_fit_their_budget(tmp_path):
     assert h2x_listed["scratch"] <= 32 and h2x_listed["vgpr"] <= 256
     # the elementwise parts run packed (two fp32 per issue slot) and on the 1-ulp hardware approximations
     assert text.count("v_pk_fma_f32") > 300 and "v_rsq_f32" in text and "v_exp_f32" in text
-    assert "v_div_fmas_f32" not in text.split("edge_mfma_kernelILb1ELi8ELi0ELb0E")[1].split(".end_amdhsa_kernel")[0]
+    start = re.search(r"^_ZN4cbgx16edge_mfma_kernelILb1ELi8ELi0ELb0E\S*:", text, flags=re.M).start()
+    body = text[start:text.index(".end_amdhsa_kernel", start)]          # label .. descriptor of the main x2h kernel
+    assert len(body.splitlines()) > 2000
+    assert "v_div_fmas_f32" not in body
+    valu = len(re.findall(r"^\s+v_(?!mfma)", body, flags=re.M))
+    mfma = len(re.findall(r"^\s+v_mfma_f32_16x16x4", body, flags=re.M))
+    assert mfma == 448 and valu <= 1500, (mfma, valu)       # 2 179 VALU instructions before the packed-fp32 pass
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
