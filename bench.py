@@ -4,17 +4,22 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pockets P] [--samples S]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one full reverse-diffusion step (ligand embedding + pocket/ligand composition + the 9-layer
-equivariant denoiser in libcbgx + position/type posterior sampling + trajectory store) over one batch of
-pocket+ligand graphs.  Workload = BASELINE.json configs[1] ("configs/denovo, 100 pockets x 10 samples each,
-1000 steps, fp32, 1 MI355X"): each batch holds P pockets x S=10 samples of that pocket (sample.py:177
-replicates one pocket num_samples times; independent pockets are additionally batched together because
-one pocket's 10 graphs cannot fill 256 CUs).  Synthetic pockets (cbgbench_amd/synthetic.py), deterministic
-synthetic weights (cbgbench_amd/synthetic_weights.py).  Default batch: 20 pockets x 10 samples = 200 graphs, ~100 k
-nodes per step (--pockets 10 for the 100-graph batches of the earlier profile rows).
+Workload = the whole BASELINE.json configs[1] job ("configs/denovo, 100 pockets x 10 samples each, 1000 steps, fp32,
+1 MI355X"): 100 distinct pockets x 10 samples of each (sample.py:177 replicates one pocket num_samples times) = 1000
+pocket+ligand graphs (~5.3e5 nodes, 1.7e7 edges) resident in HBM as --graphs-per-batch sized batches (default 200
+graphs = 20 pockets x 10 samples: independent pockets are batched together because one pocket's 10 graphs cannot fill
+256 CUs).  A reverse-diffusion step of a batch = ligand embedding + pocket/ligand composition + the 9-layer equivariant
+denoiser in libcbgx + position/type posterior sampling + trajectory store.  One bench "step" advances the WHOLE job
+(all batches) by one reverse-diffusion step at each of the five time blocks t = 999-i, 749-i, 499-i, 249-i, 24-(i mod 25)
+(the network has no time input in the shipped configs; t selects the posterior coefficients and the noise scale, down
+to the noise-free t = 0 step), i.e. 5 denoising steps x 1000 graphs = 5000 graph-steps per bench step; `value` =
+graph-steps / wall time.  Synthetic pockets (cbgbench_amd/synthetic.py), deterministic synthetic weights
+(cbgbench_amd/synthetic_weights.py).
 
-With N > 1 every rank owns its own pockets (weak scaling, no data-path collective); the
-timed region is bracketed by barrier + synchronize and the MAX over ranks is reported.
+`--gpus N` with N > 1 and no torchrun environment re-executes itself under `python -m torch.distributed.run` with N
+ranks on 127.0.0.1; under torchrun it checks WORLD_SIZE == N.  Every rank owns its own 1000-graph job (weak scaling,
+no data-path collective; SURVEY.md 8e = BASELINE configs[3]: 1000 pockets per GPU); the timed region is bracketed by
+barrier + synchronize, the MAX over ranks is reported and `ranks_seen` comes from an RCCL all-reduce.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` (dominant kernel =
 the fused x2h edge kernel, timed live with HIP events on its own stream via cbgx_profile_*) and
@@ -135,8 +140,11 @@ def cpu_baseline(sd, seed, max_seconds=20.0):
                 break
     return {"value": round(10 * steps / el, 4), "unit": "graph-steps/s", "cores": threads,
             "kind": "port", "sample": f"{steps} full denoising steps of one 10-graph batch (1 pocket x 10 samples, "
-            f"N={batch['protein_pos'].shape[0] + n_lig} nodes), oracle/targetdiff.py on PyTorch-CPU fp32 with "
-            f"{threads} threads (best of 4..64 on this {os.cpu_count()}-core host), {el:.1f} s"}
+            f"N={batch['protein_pos'].shape[0] + n_lig} nodes: the batch sample.py:177-183 builds), oracle/targetdiff.py "
+            f"= the PyTorch-CPU port of the reference step in the reference's own formulation, bit-identical to the "
+            f"unmodified reference on tests/golden (tests/test_oracle_golden.py; /root/reference does not exist on this box; "
+            f"the reference itself timed on the build container: BASELINE.md section 2), fp32, {threads} threads "
+            f"(best of 4..64 on this {os.cpu_count()}-core host), {el:.1f} s"}
 
 
 # backward of the message-passing stage at the reference's tensor boundary (autograd of x2h_attention.py:80-97):
@@ -192,6 +200,9 @@ def bench_train(args, rank, world, dev):
     torch.cuda.synchronize(); sharding.barrier()
     elapsed = time.perf_counter() - t0
     el_max, units = sharding.reduce_max_sum(elapsed, n_graphs * args.steps, device=dev)
+    seen = ranks_seen(dev)
+    if seen != world:
+        raise SystemExit(f"bench.py: all-reduce saw {seen} ranks, expected {world}")
     out = {
         "metric": "training graph-steps/s (pocket+ligand graphs x optimiser steps per second: forward + backward + "
                   "gradient all-reduce + clip + Adam)",
@@ -202,7 +213,7 @@ def bench_train(args, rank, world, dev):
                                f"per step, N_rec~U[350,650], N_lig~U[10,45], symmetric time sampler, loss weights pos 1 / "
                                f"atom 100, Adam lr 5e-4, clip 8.0, one flat-buffer gradient all-reduce "
                                f"({fg.flat.numel()} fp32) per step",
-                   "graphs_per_batch_per_gpu": n_graphs, "nodes_per_batch": N, "sharding": f"data-parallel x{world} ranks",
+                   "graphs_per_batch_per_gpu": n_graphs, "nodes_per_batch": N, "sharding": f"data-parallel x{world} ranks", "ranks_seen": seen,
                    "allreduce_ms_per_step": round(1e3 * t_ar / max(args.steps, 1), 4)},
     }
     if rank == 0 and not args.no_roofline:
@@ -238,56 +249,109 @@ def bench_train(args, rank, world, dev):
         torch.distributed.destroy_process_group()
 
 
+T_BLOCKS = (999, 749, 499, 249, 24)     # first t of each time block; bench step i runs t = block - i (last block: i mod 25)
+
+
+def block_times(i, T=1000):
+    """the reverse-diffusion times bench step i visits, one per time block (scaled for models with T != 1000)"""
+    out = []
+    for b in T_BLOCKS:
+        b = min(b * T // 1000, T - 1)
+        out.append(max(b - (i % 25 if b < 25 else i % 225), 0))
+    return out
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: re-execute under torch.distributed.run with N ranks on this node."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def ranks_seen(dev):
+    """number of ranks that took part, from a real all-reduce on the job's backend (RCCL when one GPU per rank)"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    one = torch.ones(1, dtype=torch.float32, device="cpu" if dist.get_backend() == "gloo" else dev)
+    dist.all_reduce(one)
+    return int(one.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pockets", type=int, default=None,
-                    help="distinct pockets per batch (default 20 -> 200 graphs, ~100 k nodes per step; train: 32 graphs)")
+                    help="distinct pockets of the job per GPU (default 100 -> 1000 graphs; linker: 256 graphs; train: 32 graphs)")
     ap.add_argument("--samples", type=int, default=10, help="samples (graphs) per pocket")
+    ap.add_argument("--graphs-per-batch", type=int, default=200,
+                    help="graphs per resident batch (whole pockets; default 200 = 20 pockets x 10 samples, ~100 k nodes)")
     ap.add_argument("--workload", choices=["denovo", "linker", "train"], default="denovo",
                     help="denovo = BASELINE configs[1] (default); linker = configs[2]: --pockets distinct pockets, one "
                          "graph each, fixed context atoms + a few generated linker atoms (partial gen_flag); train = "
                          "configs[4] shape: forward + backward + all-reduce + Adam on --pockets graphs per GPU")
     ap.add_argument("--graph", choices=["on", "off"], default="off",
-                    help="replay one captured hipGraph per denoising step instead of stream launches (no gain measured: "
-                         "small batches are bound by the dependent-kernel chain on the device)")
+                    help="replay one captured hipGraph per denoising step instead of stream launches (single batch only; no "
+                         "gain measured: small batches are bound by the dependent-kernel chain on the device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    if sharding.env_rank_world()[1] != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {sharding.env_rank_world()[1]} rank(s) "
+                         f"(WORLD_SIZE); refusing to report a mislabelled n_gpus")
     rank, world, local = sharding.init_process_group()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
-    # one process per GPU; LOCAL_RANK -> device (modulo the visible devices so the multi-rank path can also be
-    # exercised on a 1-GPU box with CBGX_DIST_BACKEND=gloo)
+    # one process per GPU; LOCAL_RANK -> device.  Only with CBGX_DIST_BACKEND=gloo may ranks share a device (the
+    # multi-rank path exercised on a 1-GPU box); RCCL needs one GPU per rank.
+    if local >= torch.cuda.device_count() and os.environ.get("CBGX_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local}, {torch.cuda.device_count()} visible)")
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.pockets is None:
-        args.pockets = 32 if args.workload == "train" else 20
+        args.pockets = {"train": 32, "linker": 256}.get(args.workload, 100)
     if args.workload == "train":
         return bench_train(args, rank, world, dev)
     model = make_model(dev)
     T = model.num_diffusion_timesteps
 
+    # the job of this rank, resident in HBM as whole-pocket batches
     if args.workload == "linker":
         args.samples = 1
-        batch = synthetic.batch_to(synthetic.linker_batch(args.pockets, seed=1000 + rank), dev)
-    else:
-        batch = synthetic.batch_to(build_batch(args.pockets, args.samples, seed=1000 + rank), dev)
+    ppb = max(1, args.graphs_per_batch // args.samples)          # pockets per batch
+    chunks = [min(ppb, args.pockets - s) for s in range(0, args.pockets, ppb)]
+    states = []
+    for b, npk in enumerate(chunks):
+        seed = 1000 + 97 * rank + 7919 * b
+        batch = synthetic.linker_batch(npk, seed=seed) if args.workload == "linker" else build_batch(npk, args.samples, seed=seed)
+        states.append(model.begin_sampling(synthetic.batch_to(batch, dev), keep_trajectory=True))
     n_graphs = args.pockets * args.samples
-    st = model.begin_sampling(batch, keep_trajectory=True)
-    N, E = st["N"], None
+    N = sum(st["N"] for st in states)
     torch.manual_seed(2024 + rank)   # sample.py:106 seed (+rank: independent streams per shard)
+    n_blocks = len(T_BLOCKS)
 
-    t_idx = T - 1
-    use_graph = args.graph == "on"
-    if use_graph and args.warmup + args.steps + 2 >= T:
-        use_graph = False
+    def bench_step(i):
+        for t in block_times(i, T):
+            for st in states:
+                model.denoise_step(st, t)
+
+    use_graph = args.graph == "on" and len(states) == 1 and args.warmup + args.steps + 2 < T
     if use_graph:
-        replay, done = model.make_step_graph(st, warmup=2)
+        n_blocks = 1
+        replay, done = model.make_step_graph(states[0], warmup=2)
         for _ in range(args.warmup):
             replay()
         sharding.barrier(); torch.cuda.synchronize()
@@ -297,66 +361,80 @@ def main():
         torch.cuda.synchronize(); sharding.barrier()
         elapsed = time.perf_counter() - t0
         t_idx = T - 1 - done - args.warmup - args.steps
+        st = states[0]
         st["x_lig"], st["c_lig"] = st["traj_x"][t_idx + 1].clone(), st["traj_c"][t_idx + 1].clone()
     else:
-        for _ in range(args.warmup):
-            model.denoise_step(st, t_idx); t_idx = (t_idx - 1) % T
+        for i in range(args.warmup):
+            bench_step(i)
         sharding.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            model.denoise_step(st, t_idx); t_idx = (t_idx - 1) % T
+        for i in range(args.warmup, args.warmup + args.steps):
+            bench_step(i)
         torch.cuda.synchronize(); sharding.barrier()
         elapsed = time.perf_counter() - t0
-    el_max, graph_steps = sharding.reduce_max_sum(elapsed, n_graphs * args.steps, device=dev)
+    el_max, graph_steps = sharding.reduce_max_sum(elapsed, n_graphs * n_blocks * args.steps, device=dev)
+    seen = ranks_seen(dev)
+    if seen != world:
+        raise SystemExit(f"bench.py: all-reduce saw {seen} ranks, expected {world}")
 
+    shape = (f"{args.pockets} pockets x {args.samples} samples = {n_graphs} graphs per GPU as {len(states)} resident "
+             f"batch(es) of <= {ppb * args.samples} graphs")
     out = {
         "metric": "denoising graph-steps/s (pocket+ligand graphs x reverse-diffusion steps per second)",
         "value": round(graph_steps / el_max, 2), "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * el_max / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": (f"configs/denovo targetdiff sampling (BASELINE configs[1]): {args.pockets} pockets x "
-                                f"{args.samples} samples per batch per GPU, N_rec~U[350,650], N_lig~U[10,45], "
-                                f"k=32, 9 layers, fp32, random-init synthetic weights") if args.workload == "denovo" else
-                               (f"configs/linker targetdiff sampling (BASELINE configs[2]): {args.pockets} fragment-pair "
-                                f"pockets per batch per GPU, N_rec~U[350,650], 10-35 fixed context atoms + 3-14 generated "
-                                f"atoms per graph (partial gen_flag), k=32, 9 layers, fp32, synthetic weights"),
-                   "graphs_per_batch_per_gpu": n_graphs, "nodes_per_batch": N, "sharding": f"pockets x{world} ranks",
+        "config": {"workload": (f"configs/denovo targetdiff sampling, the whole BASELINE configs[1] job: {shape}, "
+                                f"N_rec~U[350,650], N_lig~U[10,45], k=32, 9 layers, fp32, random-init synthetic weights; one "
+                                f"bench step = one reverse-diffusion step of the whole job at each of {n_blocks} time "
+                                f"blocks (t = 999-i, 749-i, 499-i, 249-i, 24-(i mod 25))") if args.workload == "denovo" else
+                               (f"configs/linker targetdiff sampling (BASELINE configs[2]): {shape} (fragment-pair pockets), "
+                                f"N_rec~U[350,650], 10-35 fixed context atoms + 3-14 generated atoms per graph (partial "
+                                f"gen_flag), k=32, 9 layers, fp32, synthetic weights; one bench step = one reverse-diffusion "
+                                f"step of the job at each of {n_blocks} time blocks"),
+                   "graphs_per_gpu": n_graphs, "nodes_per_gpu": N, "denoising_steps_per_bench_step": n_blocks,
+                   "graph_steps_per_bench_step_per_gpu": n_graphs * n_blocks,
+                   "ms_per_denoising_step_of_the_job": round(1e3 * el_max / args.steps / n_blocks, 4),
+                   "sharding": f"independent pockets x{world} ranks, no data-path collective", "ranks_seen": seen,
                    "launch": "one hipGraph replay per step" if use_graph else "stream launches"},
     }
 
     if rank == 0 and not args.no_roofline:
         # live per-kernel timing with HIP events on the launch stream (same inputs, separate pass so the
-        # event records do not perturb `value`)
+        # event records do not perturb `value`); the dominant kernel's launches all cover one whole batch
         lib = _native.lib()
-        prof_steps = min(args.steps, 10)
+        st = states[0]
+        Nb = st["N"]
+        prof_steps = 2
         names = _native.PROFILE_CLASSES
 
-        _native.check(lib.cbgx_profile_begin(80 * prof_steps + 64), "cbgx_profile_begin")
-        for _ in range(prof_steps):
-            model.denoise_step(st, t_idx); t_idx = (t_idx - 1) % T
+        _native.check(lib.cbgx_profile_begin(80 * 5 * prof_steps + 64), "cbgx_profile_begin")
+        for i in range(prof_steps):
+            for t in block_times(args.warmup + args.steps + i, T):
+                model.denoise_step(st, t)
         NCLS = len(names)
         ms = (ctypes.c_double * NCLS)(); cnt = (ctypes.c_int * NCLS)()
         _native.check(lib.cbgx_profile_end(ms, cnt, NCLS), "cbgx_profile_end")
-        # class "edge_x2h" = the launches that process all N nodes (7 of 9 layers; the samplers let the library prune
-        # the last two, reported separately as "edge_x2h_listed")
+        # class "edge_x2h" = the launches that process all N nodes of the batch (the samplers let the library prune
+        # the last two layers and cache the first two, reported separately as "edge_x2h_listed")
         per = {n: {"ms_total": round(ms[i], 4), "launches": cnt[i],
                    "us_avg": round(1e3 * ms[i] / max(cnt[i], 1), 3)} for i, n in enumerate(names)}
-        deg_edges = 32 * N  # every node of a >=33-node graph has exactly 32 incoming edges
-        x2h_bytes = X2H_BYTES_PER_EDGE * deg_edges + X2H_BYTES_PER_NODE * N
+        deg_edges = 32 * Nb  # every node of a >=33-node graph has exactly 32 incoming edges
+        x2h_bytes = X2H_BYTES_PER_EDGE * deg_edges + X2H_BYTES_PER_NODE * Nb
         x2h_s = 1e-3 * ms[4] / max(cnt[4], 1)
         achieved = x2h_bytes / x2h_s / 1e9 if x2h_s > 0 else 0.0
-        layer_flops = FLOPS_PER_EDGE_LAYER * deg_edges + FLOPS_PER_NODE_LAYER * N
+        layer_flops = FLOPS_PER_EDGE_LAYER * deg_edges + FLOPS_PER_NODE_LAYER * Nb
         dev_s_layer = 1e-3 * (ms[2] + ms[3] + ms[4] + ms[5] + ms[6]) / max(cnt[4] + cnt[6], 1)
         out["roofline"] = {
             "bound": "hbm", "kernel": "cbgx::edge_mfma_kernel<x2h> (fused x2h edge kernel)", "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": measured_traffic(N),
-            "algorithmic_bytes_per_launch": x2h_bytes, "avg_launch_us": round(1e6 * x2h_s, 3),
+            "traffic": measured_traffic(Nb),
+            "nodes_per_launch": Nb, "algorithmic_bytes_per_launch": x2h_bytes, "avg_launch_us": round(1e6 * x2h_s, 3),
             "note": "algorithmic bytes = SURVEY.md 8d message-passing stage at the reference tensor boundary "
                     "(1032 B/edge + 1536 B/node) x edges/nodes per launch; the kernel is fused (edge MLP + "
-                    "attention), so real HBM traffic is far lower",
+                    "attention), so real HBM traffic is far lower; timed on the first resident batch",
             "mfma_view": {
-                "x2h_kernel_executed_tflops": round((X2H_EXEC_FLOPS_PER_EDGE * deg_edges + X2H_EXEC_FLOPS_PER_NODE * N)
+                "x2h_kernel_executed_tflops": round((X2H_EXEC_FLOPS_PER_EDGE * deg_edges + X2H_EXEC_FLOPS_PER_NODE * Nb)
                                                     / x2h_s / 1e12, 3) if x2h_s > 0 else 0,
                 "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
                 "reference_factored_equiv_tflops": round(layer_flops / dev_s_layer / 1e12, 3) if dev_s_layer else 0,
@@ -366,6 +444,7 @@ def main():
                         "second Linears off the edges (query fold, post-aggregation value Linear), caches the "
                         "ligand-free protein rows and prunes the last layers"},
             "per_kernel": per,
+            "launches_per_denoising_step": round(sum(cnt) / (5.0 * prof_steps), 1),
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(oracle_state_dict(), seed=1000)

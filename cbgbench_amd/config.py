@@ -44,6 +44,52 @@ class Config(dict):
         del self[k]
 
 
+def to_plain(v):
+    """nested plain dict / list copy of a Config (what goes into checkpoints: unpicklable without this package otherwise)"""
+    if isinstance(v, dict):
+        return {k: to_plain(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return type(v)(to_plain(x) for x in v)
+    return v
+
+
+def checkpoint_config(config):
+    """the `config` entry of a checkpoint in a form the reference's scripts can unpickle: an easydict.EasyDict when
+    easydict is importable (what the reference's train.py:266-273 stores), else plain nested dicts"""
+    plain = to_plain(config)
+    try:
+        from easydict import EasyDict
+    except ImportError:
+        return plain
+    return EasyDict(plain)
+
+
+def load_checkpoint_file(path, map_location="cpu"):
+    """torch.load of a checkpoint written by this package OR by the reference (whose `config` is a pickled
+    easydict.EasyDict: when easydict is not installed a stand-in module mapping EasyDict -> Config is registered for the
+    duration of the load).  `config`, when present, comes back as a Config."""
+    import sys
+    import types
+
+    import torch
+    shim = None
+    if "easydict" not in sys.modules:
+        try:
+            import easydict  # noqa: F401
+        except ImportError:
+            shim = types.ModuleType("easydict")
+            shim.EasyDict = Config
+            sys.modules["easydict"] = shim
+    try:
+        ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    finally:
+        if shim is not None and sys.modules.get("easydict") is shim:
+            del sys.modules["easydict"]
+    if isinstance(ckpt, dict) and isinstance(ckpt.get("config"), dict):
+        ckpt["config"] = Config(to_plain(ckpt["config"]))
+    return ckpt
+
+
 class _Loader(yaml.SafeLoader):
     def __init__(self, stream):
         self._root = os.path.split(getattr(stream, "name", os.path.curdir + os.sep))[0]

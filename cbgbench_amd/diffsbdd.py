@@ -242,7 +242,7 @@ class DiffSBDD(nn.Module):
             x = torch.cat([xr_t, x_t], 0)[sort_idx]
             h = torch.cat([h_rec, h_lig], 0)[sort_idx]
             xo, _, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
-                                          graph_ptr=graph_ptr)
+                                          graph_ptr=graph_ptr, ligand_outputs_only=True)
             return xo[lig_rows], logits[lig_rows], pos_noise, type_noise, c_t
 
         noise = noise if noise is not None else (None,) * (4 if evaluate else 2)

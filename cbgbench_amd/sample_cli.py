@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import get_model, load_config, priors, set_num_atom_type, sharding, synthetic
-from .config import get_atomic_number_from_index, is_aromatic_from_index
+from .config import get_atomic_number_from_index, is_aromatic_from_index, load_checkpoint_file
 
 
 def build_pocket_batch(pockets, num_samples, rng, num_classes, prior_types="uniform", device="cpu", num_dist=None,
@@ -57,6 +57,8 @@ def main(argv=None):
     ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic pockets when --pockets is not given")
     ap.add_argument("--num_samples", type=int, default=None)
     ap.add_argument("--pockets_per_batch", type=int, default=10)
+    ap.add_argument("--random_init", action="store_true",
+                    help="sample from randomly initialised weights when no checkpoint is given / found (smoke runs only)")
     ap.add_argument("--save_traj", action="store_true")
     ap.add_argument("--final_state", action="store_true",
                     help="write traj[-1] (the state after the last step) instead of traj[0], which sample.py:198 uses")
@@ -79,13 +81,21 @@ def main(argv=None):
 
     ckpt_path = args.checkpoint or config.model.get("checkpoint", None)
     if ckpt_path and os.path.exists(ckpt_path):
-        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        ckpt = load_checkpoint_file(ckpt_path, map_location="cpu")
         model_cfg = ckpt["config"].model if "config" in ckpt else config.model
         model_cfg.num_atomtype = config.model.num_atomtype
         model = get_model(model_cfg)
         model.load_state_dict(ckpt["model"])            # strict, like sample.py:156
+    elif args.random_init:
+        # no checkpoints ship with the reference: explicit opt-in, and said loudly
+        print(f"[sample_cli] WARNING: --random_init: sampling from a RANDOMLY INITIALISED {config.model.type} model"
+              + (f" (checkpoint {ckpt_path!r} not found)" if ckpt_path else ""), flush=True)
+        model = get_model(config.model)
     else:
-        model = get_model(config.model)                 # random init (no checkpoints ship with the reference)
+        raise SystemExit(f"sample_cli: checkpoint {ckpt_path!r} does not exist (the reference fails here too, sample.py:150-156); "
+                         f"pass --random_init to sample from random weights on purpose" if ckpt_path else
+                         "sample_cli: no checkpoint given (--checkpoint or model.checkpoint in the config); pass --random_init "
+                         "to sample from random weights on purpose")
     model = model.to(dev).eval()
 
     if args.pockets:

@@ -352,7 +352,7 @@ class TargetDiff(nn.Module):
         h = torch.cat([h_rec, h_lig], 0)[sort_idx]
         gen_flag = torch.cat([gen_r, gen_l], 0)[sort_idx]
         xo, _, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
-                                      graph_ptr=graph_ptr)
+                                      graph_ptr=graph_ptr, ligand_outputs_only=True)
         x_pred, c_pred = xo[lig_rows], logits[lig_rows]
         results = {}
         if self.denoise_structure:

@@ -13,31 +13,41 @@ import torch.distributed as dist
 from torch.nn.utils import clip_grad_norm_
 
 
+# config `type` -> constructor; the keys each one reads are the ones the reference's YAMLs carry
+# (configs/*/train/*.yml `train.optimizer` / `train.scheduler`; repo/utils/train.py:8-44)
+_OPTIMIZERS = {
+    "adam": lambda c, params: torch.optim.Adam(params, lr=c.lr, weight_decay=c.weight_decay, betas=(c.beta1, c.beta2)),
+}
+_SCHEDULERS = {
+    "plateau": lambda c, opt: torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=c.factor, patience=c.patience,
+                                                                         min_lr=c.min_lr),
+    "multistep": lambda c, opt: torch.optim.lr_scheduler.MultiStepLR(opt, milestones=c.milestones, gamma=c.gamma),
+    "exp": lambda c, opt: torch.optim.lr_scheduler.ExponentialLR(opt, gamma=c.gamma),
+}
+
+
+def _dispatch(table, what, cfg, arg):
+    try:
+        make = table[cfg.type]
+    except KeyError:
+        raise NotImplementedError(f"{what} not supported: {cfg.type}") from None
+    return make(cfg, arg)
+
+
 def get_optimizer(cfg, model):
-    if cfg.type == "adam":
-        return torch.optim.Adam(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay,
-                                betas=(cfg.beta1, cfg.beta2))
-    raise NotImplementedError("Optimizer not supported: %s" % cfg.type)
+    return _dispatch(_OPTIMIZERS, "Optimizer", cfg, model.parameters())
 
 
 def get_scheduler(cfg, optimizer):
+    """None when the config has no scheduler block / type (the reference returns None there too)"""
     if cfg is None or cfg.get("type", None) is None:
         return None
-    if cfg.type == "plateau":
-        return torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=cfg.factor, patience=cfg.patience,
-                                                          min_lr=cfg.min_lr)
-    if cfg.type == "multistep":
-        return torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=cfg.milestones, gamma=cfg.gamma)
-    if cfg.type == "exp":
-        return torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=cfg.gamma)
-    raise NotImplementedError("Scheduler not supported: %s" % cfg.type)
+    return _dispatch(_SCHEDULERS, "Scheduler", cfg, optimizer)
 
 
 def sum_weighted_losses(losses, weights):
-    loss = 0
-    for k in losses.keys():
-        loss = loss + (losses[k] if weights is None else weights[k] * losses[k])
-    return loss
+    """weighted sum of a loss dict; ``weights=None`` means all ones (repo/utils/train.py:121-133)"""
+    return sum(v if weights is None else weights[k] * v for k, v in losses.items())
 
 
 class FlatGradients:
@@ -53,12 +63,14 @@ class FlatGradients:
             p.grad = v.view_as(p)
         # libcbgx-backed encoders write their gradients straight into these views (one backward per step, zeroed by
         # zero() before it) instead of returning tensors for autograd to accumulate
-        for mod in model.modules():
-            if hasattr(mod, "_direct_grads"):
-                mod._direct_grads = True
+        self._direct_modules = [mod for mod in model.modules() if hasattr(mod, "_direct_grads")]
+        for mod in self._direct_modules:
+            mod._direct_grads, mod._direct_written = True, False
 
     def zero(self):
         self.flat.zero_()
+        for mod in self._direct_modules:
+            mod._direct_written = False     # the next backward through it may overwrite (the buffer is zero)
         for p, v in zip(self.params, self.flat.split([p.numel() for p in self.params])):
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():   # optimizer.zero_grad(set_to_none=True) undoes the views
                 p.grad = v.view_as(p)
@@ -111,13 +123,17 @@ def train_step(model, batch, optimizer, flat_grads, loss_weights=None, max_grad_
 @torch.no_grad()
 def validate(model, batches, loss_weights=None):
     """train.py:207-246 without the RDKit/auroc evaluator: mean weighted loss over the batches at the model's
-    evenly spaced evaluation times, all-reduced so every rank sees the same value (ReduceLROnPlateau input)."""
+    evenly spaced evaluation times (each batch weighted by its graph count), all-reduced so every rank sees the same value
+    (ReduceLROnPlateau input)."""
     model.eval()
     tot, n = 0.0, 0
     for batch in batches:
         loss_dict, _ = model(batch)
-        tot += float(sum_weighted_losses(loss_dict, loss_weights))
-        n += 1
+        # weighted by the number of graphs, like the reference's ScalarMetricAccumulator (train.py:222-232)
+        bl = batch.get("ligand_element_batch", None) if isinstance(batch, dict) else None
+        B = int(bl.max().item()) + 1 if bl is not None and bl.numel() else 1
+        tot += float(sum_weighted_losses(loss_dict, loss_weights)) * B
+        n += B
     val = torch.tensor([tot, float(n)], dtype=torch.float64)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         if dist.get_backend() != "gloo":

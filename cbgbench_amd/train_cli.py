@@ -28,6 +28,7 @@ import numpy as np
 import torch
 
 from . import get_model, load_config, set_num_atom_type, sharding, synthetic
+from .config import checkpoint_config, load_checkpoint_file
 from .train import FlatGradients, broadcast_parameters, get_optimizer, get_scheduler, train_step, validate
 
 
@@ -128,8 +129,9 @@ class ShardedLoader:
 def save_checkpoint(path, config, model, optimizer, scheduler, iteration, avg_val_loss):
     os.makedirs(os.path.dirname(path), exist_ok=True)
     tmp = path + ".tmp"
-    torch.save({"config": config, "model": model.state_dict(), "optimizer": optimizer.state_dict(),
-                "scheduler": scheduler.state_dict() if scheduler is not None else None,
+    # same keys as train.py:266-273; `config` in a form the reference's scripts can unpickle without this package
+    torch.save({"config": checkpoint_config(config), "model": model.state_dict(), "optimizer": optimizer.state_dict(),
+                "scheduler": scheduler.state_dict() if scheduler is not None else {},
                 "iteration": iteration, "avg_val_loss": avg_val_loss}, tmp)
     os.replace(tmp, path)         # never leave a truncated checkpoint behind
 
@@ -137,13 +139,13 @@ def save_checkpoint(path, config, model, optimizer, scheduler, iteration, avg_va
 def load_checkpoint(path, model, optimizer=None, scheduler=None, finetune=False, device="cpu"):
     """``train.py:160-175``: weights with strict=False; optimizer / scheduler / iteration unless fine-tuning.
     Returns (first iteration, missing keys, unexpected keys)."""
-    ckpt = torch.load(path, map_location=device, weights_only=False)
+    ckpt = load_checkpoint_file(path, map_location=device)
     res = model.load_state_dict(ckpt["model"], strict=False)
     it_first = 1
     if not finetune:
         if optimizer is not None:
             optimizer.load_state_dict(ckpt["optimizer"])
-        if scheduler is not None and ckpt.get("scheduler") is not None:
+        if scheduler is not None and ckpt.get("scheduler"):
             scheduler.load_state_dict(ckpt["scheduler"])
         it_first = int(ckpt["iteration"])          # the reference resumes AT the saved iteration (no + 1)
     return it_first, list(res.missing_keys), list(res.unexpected_keys)

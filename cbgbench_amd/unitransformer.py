@@ -90,7 +90,7 @@ class _DenoiserFunction(torch.autograd.Function):
     coordinates (they are data in every training loss of the reference, targetdiff.py:87-101)."""
 
     @staticmethod
-    def forward(ctx, module, x, h, graph_ptr, lig, gen, *params):
+    def forward(ctx, module, ligand_outputs_only, x, h, graph_ptr, lig, gen, *params):
         device = x.device
         N, B = x.shape[0], graph_ptr.numel() - 1
         L, C = module.num_layers, module.out_classes
@@ -106,6 +106,7 @@ class _DenoiserFunction(torch.autograd.Function):
             tape.numel(), _native.ptr(ws), ws.numel(), _native.current_stream(device))
         _native.check(rc, "cbgx_unitransformer_forward_train")
         ctx.module, ctx.tape, ctx.packed, ctx.flags, ctx.n = module, tape, packed, (lig, gen), N
+        ctx.ligand_outputs_only = bool(ligand_outputs_only)
         ctx.param_shapes = [tuple(p.shape) for p in params]
         ctx.set_materialize_grads(False)     # an unused output (h' in TargetDiff / DiffSBDD) arrives as None, not zeros
         return x_out, h_out, logits
@@ -117,11 +118,13 @@ class _DenoiserFunction(torch.autograd.Function):
         device = ctx.tape.device
         L, C = module.num_layers, module.out_classes
         sizes = [int(torch.Size(s).numel()) for s in ctx.param_shapes]
-        direct = module._direct_grads
+        # The library OVERWRITES its gradient outputs.  Direct mode (write straight into the parameters' .grad storage, which
+        # cbgbench_amd.train.FlatGradients owns and zeroes every step; saves one accumulate kernel per parameter tensor) is
+        # therefore used for the FIRST backward through this module after FlatGradients.zero() only; any further backward
+        # before the next zero() (eval-mode losses with several denoiser calls, gradient accumulation, two loss.backward()
+        # calls) takes the temporary-buffer path, whose results autograd ADDS to .grad.
+        direct = module._direct_grads and not module._direct_written
         if direct:
-            # write straight into the parameters' .grad storage (cbgbench_amd.train.FlatGradients owns it and zeroes it
-            # every step): saves one accumulate kernel per parameter tensor.  The library overwrites, so this mode is only
-            # for one backward per optimiser step.
             params = module._ordered_params()
             views = [p.grad for p in params]
             if any(v is None or not v.is_contiguous() or v.dtype != torch.float32 or v.device != device for v in views):
@@ -130,20 +133,27 @@ class _DenoiserFunction(torch.autograd.Function):
             flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
             views = list(flat.split(sizes))
         arr = (ctypes.c_void_p * len(views))(*[v.data_ptr() for v in views])
-        need_h = ctx.needs_input_grad[2]
+        need_h = ctx.needs_input_grad[3]
         gh_in = torch.empty(N, module.hidden_dim, dtype=torch.float32, device=device) if need_h else None
         ws = module.train_workspace(N, device)
         cont = lambda g: None if g is None else g.contiguous().float()
         gx, gh, gl = cont(gx), cont(gh), cont(gl)
+        if gh is None and not ctx.ligand_outputs_only:
+            # a NULL dL/dh_out makes the library prune the backward of the last blocks to the receptive field of the
+            # ligand / movable rows (include/cbgx.h); only callers that promise their loss reads x' on gen_flag rows and
+            # logits on lig_flag rows may have that, everyone else gets the unpruned backward
+            gh = torch.zeros(N, module.hidden_dim, dtype=torch.float32, device=device)
+        if direct:
+            module._direct_written = True
         rc = _native.lib().cbgx_unitransformer_backward(
             _native.ptr(ctx.packed), L, C, _native.ptr(ctx.tape), ctx.tape.numel(), _native.ptr(lig),
             _native.ptr(gen), N, _native.ptr(gx), _native.ptr(gh), _native.ptr(gl), arr, len(views),
             _native.ptr(gh_in), _native.ptr(ws), ws.numel(), _native.current_stream(device))
         _native.check(rc, "cbgx_unitransformer_backward")
         if direct:
-            return (None, None, gh_in, None, None, None) + (None,) * len(views)
+            return (None, None, None, gh_in, None, None, None) + (None,) * len(views)
         grads = [v.view(s) for v, s in zip(views, ctx.param_shapes)]
-        return (None, None, gh_in, None, None, None, *grads)
+        return (None, None, None, gh_in, None, None, None, *grads)
 
 
 class UniTransformer(nn.Module):
@@ -195,6 +205,7 @@ class UniTransformer(nn.Module):
         self._workspace = None
         self._train_workspace = None
         self._direct_grads = False     # set by cbgbench_amd.train.FlatGradients
+        self._direct_written = False   # a direct (overwriting) backward has run since FlatGradients.zero()
 
     def __repr__(self):
         return (f"UniTransformer[libcbgx/gfx950](num_layers={self.num_layers}, n_heads={self.n_heads}, "
@@ -299,14 +310,18 @@ class UniTransformer(nn.Module):
         r32sq[rec_rows] = r32
         return (out[0], out[1], nbr.contiguous(), deg, ew, r32sq)
 
-    def forward(self, x, h, batch_idx, lig_flag, gen_flag, graph_ptr=None, need_h=True, static_h=None):
+    def forward(self, x, h, batch_idx, lig_flag, gen_flag, graph_ptr=None, need_h=True, static_h=None,
+                ligand_outputs_only=False):
         """Same contract as the reference (unitransformer.py:102-123): returns (x', h', logits).
         ``batch_idx`` must be sorted (compose_context guarantees it).  ``graph_ptr`` (int32 CSR
         offsets) may be passed to avoid recomputing it from ``batch_idx`` every call.  ``need_h=False`` (samplers that
         only read ``x'`` and the logits of ligand rows): ``h'`` is returned as None, logits are defined on
         ``lig_flag`` rows only, and the library prunes the last layers to the nodes that can still reach them.
         ``static_h`` (from ``static_context``): lets the library skip, in the first two layers, the protein rows that
-        cannot yet have seen a ligand atom (bit-identical results)."""
+        cannot yet have seen a ligand atom (bit-identical results).
+        ``ligand_outputs_only`` (training): the caller promises that its loss reads ``x'`` on ``gen_flag`` rows and the logits
+        on ``lig_flag`` rows only and ignores ``h'`` (TargetDiff / DiffSBDD losses); the backward may then be pruned to
+        the receptive field of those rows.  Without the promise the full backward runs."""
         if not x.is_cuda:
             raise RuntimeError("UniTransformer.forward runs on an MI355X through libcbgx; got a CPU tensor "
                                "(no CPU fallback exists; use oracle/ for CPU reference results)")
@@ -319,7 +334,7 @@ class UniTransformer(nn.Module):
         gen = gen_flag.to(torch.uint8).contiguous()
         if torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.parameters())):
             # training: taped forward + hand-written backward behind torch.autograd
-            return _DenoiserFunction.apply(self, x.detach().to(torch.float32).contiguous(),
+            return _DenoiserFunction.apply(self, ligand_outputs_only, x.detach().to(torch.float32).contiguous(),
                                            h.to(torch.float32).contiguous(), graph_ptr, lig, gen,
                                            *self._ordered_params())
         x = x.detach().to(torch.float32).contiguous()

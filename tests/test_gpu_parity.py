@@ -411,7 +411,8 @@ def test_sampling_driver_end_to_end(tmp_path):
     import os as _os
     from cbgbench_amd import sample_cli
     cfg = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "fixtures", "targetdiff_T20.yml")
-    rc = sample_cli.main(["--config", cfg, "--out_root", str(tmp_path), "--synthetic", "3", "--pockets_per_batch", "2"])
+    rc = sample_cli.main(["--config", cfg, "--out_root", str(tmp_path), "--synthetic", "3", "--pockets_per_batch", "2",
+                          "--random_init"])
     assert rc == 0
     files = sorted(_os.listdir(tmp_path / "targetdiff_T20"))
     assert files == ["pocket_00000.pt", "pocket_00001.pt", "pocket_00002.pt"]

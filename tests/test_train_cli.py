@@ -171,3 +171,62 @@ eval: {val_freq: 2}
     assert saved["iteration"] == 2 and np.isfinite(saved["avg_val_loss"])
     assert train_cli.main(["--config", str(cfg), "--logdir", logdir, "--tag", "resumed", "--synthetic", "12",
                            "--resume", ck, "--max_iters", "3"]) == 0
+
+
+def test_checkpoint_config_is_interchangeable_with_the_reference(tmp_path):
+    """(1) a checkpoint written here carries its config as plain nested dicts (or an EasyDict when easydict is installed): the
+    pickle names no cbgbench_amd class, so the reference's scripts can load it; (2) a checkpoint written the reference's
+    way -- config pickled as easydict.EasyDict (train.py:266-273) -- loads here without easydict installed."""
+    import pickle
+    import pickletools
+    import sys
+    import types
+    from cbgbench_amd.config import load_checkpoint_file
+    cfg = Config({"model": {"type": "targetdiff", "encoder": {"num_layers": 9}}, "train": {"seed": 2022, "list": [1, {"a": 2}]}})
+    model = torch.nn.Linear(2, 2)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    path = str(tmp_path / "ck" / "10.pt")
+    train_cli.save_checkpoint(path, cfg, model, opt, None, 10, 0.5)
+    import zipfile
+    with zipfile.ZipFile(path) as z:
+        pkl = [n for n in z.namelist() if n.endswith("data.pkl")][0]
+        ops = [(op.name, arg) for op, arg, _ in pickletools.genops(z.read(pkl))]
+    named = " ".join(str(a) for n, a in ops if n in ("GLOBAL", "STACK_GLOBAL", "SHORT_BINUNICODE", "BINUNICODE") and a)
+    assert "cbgbench_amd" not in named
+    ck = load_checkpoint_file(path)
+    assert isinstance(ck["config"], Config) and ck["config"].model.encoder.num_layers == 9 and ck["config"].train.list[1].a == 2
+    assert ck["scheduler"] == {} and ck["iteration"] == 10
+
+    # the reference's way: a dict subclass `easydict.EasyDict` with attribute access, pickled by reference
+    had = sys.modules.pop("easydict", None)
+    fake = types.ModuleType("easydict")
+
+    class EasyDict(dict):
+        def __init__(self, d=None):
+            super().__init__()
+            for k, v in (d or {}).items():
+                setattr(self, k, EasyDict(v) if isinstance(v, dict) else v)
+
+        def __setattr__(self, k, v):
+            super().__setattr__(k, v)
+            super().__setitem__(k, v)
+    EasyDict.__module__, EasyDict.__qualname__ = "easydict", "EasyDict"
+    fake.EasyDict = EasyDict
+    sys.modules["easydict"] = fake
+    try:
+        ref_path = str(tmp_path / "ref.pt")
+        torch.save({"config": EasyDict({"model": {"type": "targetdiff", "generator": {"num_diffusion_timesteps": 1000}}}),
+                    "model": model.state_dict(), "optimizer": opt.state_dict(), "scheduler": {}, "iteration": 3,
+                    "avg_val_loss": 1.0}, ref_path)
+    finally:
+        del sys.modules["easydict"]
+        if had is not None:
+            sys.modules["easydict"] = had
+    try:
+        import easydict  # noqa: F401
+        pytest.skip("easydict is installed here: the stand-in path is not exercised")
+    except ImportError:
+        pass
+    ck = load_checkpoint_file(ref_path)
+    assert isinstance(ck["config"], Config) and ck["config"].model.generator.num_diffusion_timesteps == 1000
+    assert "easydict" not in sys.modules
