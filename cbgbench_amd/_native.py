@@ -1,13 +1,15 @@
 """ctypes binding of libcbgx.so (include/cbgx.h).  There is no fallback: if the library is missing
 or a call fails, this raises."""
+import contextlib
 import ctypes
 import os
 
 import torch  # noqa: F401  (loads the HIP runtime libcbgx links against, by SONAME)
 
-from .build import LIBPATH
+from .build import LIBPATH, XCHECK_LIBPATH
 
 _LIB = None
+_XLIB = None
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 
@@ -47,7 +49,6 @@ EXPORTS = {
     "cbgx_h2x_stack_forward_train": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
     "cbgx_h2x_stack_backward": (_i, [_vp, _i, _vp, _sz, _vp, _vp, _vp, _i, _vp, ctypes.POINTER(_vp), _i, _vp, _vp, _sz,
                                      _vp]),
-    "cbgx_debug_set_edge_kernel": (_i, [_i]),
     "cbgx_profile_begin": (_i, [_i]),
     "cbgx_profile_end": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i), _i]),
 }
@@ -60,23 +61,51 @@ class NativeError(RuntimeError):
     pass
 
 
+def _load(path, extra=None):
+    dll = ctypes.CDLL(path)
+    exports = dict(EXPORTS)
+    exports.update(extra or {})
+    for name, (res, args) in exports.items():
+        fn = getattr(dll, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if dll.cbgx_abi_version() != 1:
+        raise NativeError(f"{path}: ABI version {dll.cbgx_abi_version()} != 1")
+    return dll
+
+
 def lib():
     """Load libcbgx.so (once). Raises NativeError if it has not been built."""
     global _LIB
     if _LIB is None:
-        if not os.path.exists(LIBPATH):
+        # CBGX_LIBRARY: another build of the same library (scripts/abl_bwd.sh points it at libcbgx_ablate.so)
+        path = os.environ.get("CBGX_LIBRARY", LIBPATH)
+        if not os.path.exists(path):
             raise NativeError(
-                f"{LIBPATH} not found: build it with `python -m cbgbench_amd.build` "
+                f"{path} not found: build it with `python -m cbgbench_amd.build` "
                 "(there is no CPU / PyTorch fallback for the message-passing path)")
-        dll = ctypes.CDLL(LIBPATH)
-        for name, (res, args) in EXPORTS.items():
-            fn = getattr(dll, name)  # AttributeError if the symbol is missing
-            fn.restype = res
-            fn.argtypes = args
-        if dll.cbgx_abi_version() != 1:
-            raise NativeError(f"libcbgx ABI version {dll.cbgx_abi_version()} != 1")
-        _LIB = dll
+        _LIB = _load(path)
     return _LIB
+
+
+@contextlib.contextmanager
+def first_generation_kernels():
+    """TEST-ONLY: inside the block every binding call goes to libcbgx_xcheck.so (include/cbgx_xcheck.h) with the
+    first-generation VALU kernels selected -- an independent on-device implementation of the same stages.  The product
+    library has neither those kernels nor the switch."""
+    global _LIB, _XLIB
+    if _XLIB is None:
+        if not os.path.exists(XCHECK_LIBPATH):
+            raise NativeError(f"{XCHECK_LIBPATH} not found: build it with `python -m cbgbench_amd.build`")
+        _XLIB = _load(XCHECK_LIBPATH, {"cbgx_debug_set_edge_kernel": (_i, [_i])})
+    product = lib()
+    old = _XLIB.cbgx_debug_set_edge_kernel(1)
+    _LIB = _XLIB
+    try:
+        yield _XLIB
+    finally:
+        _XLIB.cbgx_debug_set_edge_kernel(old)
+        _LIB = product
 
 
 def check(rc, what):

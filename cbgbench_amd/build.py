@@ -1,4 +1,5 @@
-"""Build libcbgx.so (hipcc, gfx950) in-tree: cbgbench_amd/lib/libcbgx.so.
+"""Build libcbgx.so (hipcc, gfx950) in-tree: cbgbench_amd/lib/libcbgx.so, and the test-only cross-check build
+cbgbench_amd/lib/libcbgx_xcheck.so (same sources + the first-generation VALU kernels, -DCBGX_XCHECK; include/cbgx_xcheck.h).
 
 The library is a plain C-ABI shared object (include/cbgx.h); it links against the HIP runtime by
 SONAME (libamdhip64.so.7), which is the one PyTorch-ROCm has already loaded when the Python host
@@ -13,19 +14,28 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libcbgx.so")
+XCHECK_LIBPATH = os.path.join(LIBDIR, "libcbgx_xcheck.so")
 ARCH = "gfx950"
+# first-generation kernels: compiled into libcbgx_xcheck.so only
+XCHECK_ONLY = ("kernels_v1.hip", "train_bwd_v1.hip")
 
 
-def sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+def sources(xcheck=False):
+    src = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    return src if xcheck else [p for p in src if os.path.basename(p) not in XCHECK_ONLY]
 
 
-def _stale():
-    if not os.path.exists(LIBPATH):
+def _headers():
+    inc = os.path.join(HERE, "..", "include")
+    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(inc, "cbgx.h"), os.path.join(inc, "cbgx_xcheck.h")]
+
+
+def _stale(xcheck=False):
+    lib = XCHECK_LIBPATH if xcheck else LIBPATH
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIBPATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "cbgx.h")]
-    return any(os.path.getmtime(p) > t for p in deps)
+    t = os.path.getmtime(lib)
+    return any(os.path.getmtime(p) > t for p in sources(xcheck) + _headers())
 
 
 def hipcc():
@@ -35,20 +45,23 @@ def hipcc():
     return exe
 
 
-def build_native(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link libcbgx.so. Returns the library path."""
-    if not force and not _stale():
-        return LIBPATH
+def build_native(force=False, verbose=False, xcheck=False, ablate=False):
+    """Compile the HIP sources for gfx950 and link libcbgx.so (xcheck=True: libcbgx_xcheck.so; ablate=True:
+    libcbgx_ablate.so with the timing-ablation switches of scripts/abl_bwd.sh, wrong results by design).
+    Returns the library path."""
+    lib = os.path.join(LIBDIR, "libcbgx_ablate.so") if ablate else (XCHECK_LIBPATH if xcheck else LIBPATH)
+    if not force and not ablate and not _stale(xcheck):
+        return lib
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build", "ablate" if ablate else ("xcheck" if xcheck else "product"))
     os.makedirs(objdir, exist_ok=True)
     objs = []
     # -munsafe-fp-atomics: fp32 atomicAdd of the backward kernels compiles to the hardware global_atomic_add_f32
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-             "-munsafe-fp-atomics"]
-    headers = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "cbgx.h")]
-    newest_header = max(os.path.getmtime(p) for p in headers)
-    for src in sources():
+             "-munsafe-fp-atomics"] + (["-DCBGX_XCHECK"] if xcheck else []) + (["-DCBGX_ABLATE"] if ablate else [])
+    newest_header = max(os.path.getmtime(p) for p in _headers())
+    jobs = []
+    for src in sources(xcheck):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
@@ -56,14 +69,18 @@ def build_native(force=False, verbose=False):
         cmd = [hipcc()] + flags + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", LIBPATH + ".tmp"]
+        jobs.append(subprocess.Popen(cmd))
+    for j in jobs:
+        if j.wait() != 0:
+            raise subprocess.CalledProcessError(j.returncode, j.args)
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", lib + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    os.replace(LIBPATH + ".tmp", LIBPATH)
-    return LIBPATH
+    os.replace(lib + ".tmp", lib)
+    return lib
 
 
 if __name__ == "__main__":
     print(build_native(force=True, verbose=True))
+    print(build_native(force=True, verbose=True, xcheck=True))

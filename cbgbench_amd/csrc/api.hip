@@ -8,6 +8,9 @@
 #include <cstdlib>
 
 #include "../../include/cbgx.h"
+#ifdef CBGX_XCHECK
+#include "../../include/cbgx_xcheck.h"
+#endif
 #include "kernels.h"
 #include "layout.h"
 
@@ -132,12 +135,15 @@ extern "C" {
 int cbgx_abi_version(void) { return CBGX_ABI_VERSION; }
 const char* cbgx_last_error(void) { return g_err; }
 
+#ifdef CBGX_XCHECK
+// test-only library (include/cbgx_xcheck.h): route the stages through the first-generation VALU kernels
 int cbgx_debug_set_edge_kernel(int impl) {
     if (impl != 0 && impl != 1) return fail(CBGX_E_INVALID, "debug_set_edge_kernel: impl must be 0 (mfma) or 1 (valu)");
     int old = g_edge_impl;
     g_edge_impl = impl;
     return old;
 }
+#endif
 
 size_t cbgx_packed_weights_floats(int num_layers, int num_classes) {
     if (num_layers < 0 || num_classes < 1) return 0;

@@ -168,22 +168,26 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     const float* Pn = saved ? P_saved : w.P;
     const float* Qn = saved ? Qt_saved : w.Qt;
     if (!saved) {
-        if (mfma) {
-            HIP_TRY(launch_node_mfma(att, h_in, lig, n, w.P, w.qs, w.Qt, rows, n_rows, nullptr, nullptr, s));
-        } else {
-            HIP_TRY(launch_node_gemm(h_in, H, att + A_WN, att + A_BN, w.P, PROW, n, PROW, 0, s));
+#ifdef CBGX_XCHECK
+        if (!mfma) {
+            HIP_TRY(launch_node_gemm_v1(h_in, H, att + A_WN, att + A_BN, w.P, PROW, n, PROW, 0, s, nullptr, nullptr));
             HIP_TRY(launch_node_query_v1(att, w.P, w.Qt, n, s));
-        }
+        } else
+#endif
+            HIP_TRY(launch_node_mfma(att, h_in, lig, n, w.P, w.qs, w.Qt, rows, n_rows, nullptr, nullptr, s));
     }
     if (x2h) HIP_TRY(launch_fold_grad(att, g_out, n, w.Gt, w.gb, s));
     HIP_TRY(hipMemsetAsync(w.dP, 0, (size_t)n * PROW * sizeof(float), s));
-    // cbgx_debug_set_edge_kernel(1) selects the first-generation (VALU) backward kernel as an on-device cross-check
-    if (mfma)
-        HIP_TRY(launch_edge_backward_mfma(x2h, att, x, Pn, Qn, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n,
-                                          w.T, w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s, 1));
-    else
+    // libcbgx_xcheck.so only: cbgx_debug_set_edge_kernel(1) selects the first-generation (VALU) backward kernels as an
+    // on-device cross-check
+#ifdef CBGX_XCHECK
+    if (!mfma)
         HIP_TRY(launch_edge_backward(x2h, att, x, Pn, Qn, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n, w.T,
                                      w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s));
+    else
+#endif
+        HIP_TRY(launch_edge_backward_mfma(x2h, att, x, Pn, Qn, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n,
+                                          w.T, w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s, 1));
     float *k0w = grads[0], *k0b = grads[1], *kg = grads[2], *kb = grads[3], *k1w = grads[4], *k1b = grads[5];
     float *v0w = grads[6], *v0b = grads[7], *vg = grads[8], *vb = grads[9], *v1w = grads[10], *v1b = grads[11];
     float *q0w = grads[12], *q0b = grads[13], *qg = grads[14], *qb = grads[15], *q1w = grads[16], *q1b = grads[17];
@@ -213,13 +217,20 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     {
         const int tiles = (n + 15) / 16, qgrid = tiles < 4 * NODE_GRID ? tiles : 4 * NODE_GRID;   // ~43 KB LDS: 3 per CU
         HIP_TRY(hipMemsetAsync(w.qln, 0, 2 * H * sizeof(float), s));
-        HIP_TRY((mfma ? launch_q_backward_mfma : launch_q_backward)(att, Pn, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP,
-                                                                    w.qln, qgrid, s));
+#ifdef CBGX_XCHECK
+        if (!mfma) HIP_TRY(launch_q_backward(att, Pn, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, w.qln, qgrid, s));
+        else
+#endif
+            HIP_TRY(launch_q_backward_mfma(att, Pn, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, w.qln, qgrid, s));
     }
     // node-level reductions, all into one slab per workgroup (NS_* layout), folded and scattered once:
     //   second Linears: dWbk = sum_i (q_i / sqrt 8) (x) T_i ;  x2h: dWbv = sum_i G_i (x) S_i ;  dWq1 = sum_i dq_i (x) z_i
     //   biases: second v / q Linears, and the first Linears = column sums of dP (k | v | - | - | q hidden)
+#ifdef CBGX_XCHECK
     const auto outer = mfma ? launch_outer_accum_mfma : launch_outer_accum;
+#else
+    const auto outer = launch_outer_accum_mfma;
+#endif
     HIP_TRY(outer(true, w.qs, w.T, rows, n_rows, n, w.partial + NS_WBK, NS_SIZE, ng, s));
     if (x2h) {
         HIP_TRY(outer(true, g_out, w.S, rows, n_rows, n, w.partial + NS_WBV, NS_SIZE, ng, s));

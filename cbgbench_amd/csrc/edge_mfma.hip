@@ -1,6 +1,6 @@
 // libcbgx -- fused x2h / h2x edge kernels on the gfx950 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).
 //
-// One wavefront owns one destination node i and its <= 32 incoming edges; a persistent 16-wave workgroup
+// One wavefront owns one destination node i and its <= 32 incoming edges; a persistent 8-wave workgroup
 // keeps the layer's rbf weight fragments (and, for x2h, the second v Linear) in LDS and loops over nodes.
 //
 //   pre[e][m] = PD[i][m] + PS[j_e][m] + dWt[e][m] + sum_g Wr[type_e][g][m] rbf_g(|x_i - x_j|)     (k and v)
@@ -25,7 +25,6 @@
 // wave instruction instead of 64): the texture addresser, not the ALUs, was the first bottleneck.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "kernels.h"
 #include "layout.h"
@@ -67,6 +66,55 @@ __device__ __forceinline__ float xrow_max(float v) {
 }
 __device__ __forceinline__ float wave_sum(float v) { return xrow_sum(row16_sum(v)); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// Wave-uniform row base (pinned in scalar registers) + 32-bit per-lane BYTE offset: selects the
+// `global_load v, v_off, s[base:base+1]` form -- one address VGPR and no 64-bit vector arithmetic per gathered row.  The
+// empty asm makes the base opaque: without it LICM re-associates `base + lane part` into hoisted 64-bit per-lane pointers
+// (two VGPRs per address, all live across the whole node loop).  Every offset used this way is < 2^32 (checked by the launcher).
+typedef const __attribute__((address_space(1))) char* gptr;
+typedef __attribute__((address_space(1))) char* gwptr;
+__device__ __forceinline__ gptr sbase(const void* p) {
+    uint64_t v = reinterpret_cast<uint64_t>(p);
+    asm volatile("" : "+s"(v));
+    return (gptr)v;
+}
+__device__ __forceinline__ gwptr sbase_w(void* p) {
+    uint64_t v = reinterpret_cast<uint64_t>(p);
+    asm volatile("" : "+s"(v));
+    return (gwptr)v;
+}
+// loop-invariant lane offsets are laundered once per use site: the zero-extension then sits in the block of the load
+// (instruction selection is per block) instead of being hoisted out of the node loop as a 64-bit register pair
+__device__ __forceinline__ unsigned vop(unsigned off) {
+    asm volatile("" : "+v"(off));
+    return off;
+}
+typedef float nfloat2 __attribute__((ext_vector_type(2)));
+typedef int nint4 __attribute__((ext_vector_type(4)));
+#define CBGX_GLOBAL_AS(T) const __attribute__((address_space(1))) T*
+__device__ __forceinline__ float4 ldo4(gptr base, unsigned byte_off) {
+    const floatx4 v = *reinterpret_cast<CBGX_GLOBAL_AS(floatx4)>(base + byte_off);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float ldo1(gptr base, unsigned byte_off) {
+    return *reinterpret_cast<CBGX_GLOBAL_AS(float)>(base + byte_off);
+}
+__device__ __forceinline__ float2 ldo2(gptr base, unsigned byte_off) {
+    const nfloat2 v = *reinterpret_cast<CBGX_GLOBAL_AS(nfloat2)>(base + byte_off);
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ int ldoi(gptr base, unsigned byte_off) {
+    return *reinterpret_cast<CBGX_GLOBAL_AS(int32_t)>(base + byte_off);
+}
+__device__ __forceinline__ int4 ldoi4(gptr base, unsigned byte_off) {
+    const nint4 v = *reinterpret_cast<CBGX_GLOBAL_AS(nint4)>(base + byte_off);
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int ldob(gptr base, unsigned byte_off) {
+    return *reinterpret_cast<CBGX_GLOBAL_AS(uint8_t)>(base + byte_off);
+}
+__device__ __forceinline__ void sto2(gwptr base, unsigned byte_off, float2 v) {
+    *reinterpret_cast<__attribute__((address_space(1))) nfloat2*>(base + byte_off) = nfloat2{v.x, v.y};
+}
 // packed fp32: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 do two lanes' worth of work per issue slot, so the elementwise
 // parts of the kernel (sum of squares, LayerNorm affine) are written on register pairs
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -81,30 +129,31 @@ __device__ __forceinline__ float fast_sqrt(float a) { return __builtin_amdgcn_sq
 __device__ __forceinline__ float fast_exp(float a) { return __builtin_amdgcn_exp2f(a * 1.44269504088896340736f); }
 __device__ __forceinline__ floatx4 f4(float4 a) { floatx4 r = {a.x, a.y, a.z, a.w}; return r; }
 
+// |x_i - x_j| with one fixed evaluation order (explicit FMAs, no re-association): the prologue and the pipelined loop body
+// must give the same bits for the same edge, or a node's result would depend on its position in the work list
+__device__ __forceinline__ float edge_len(float xi, float yi, float zi, float xj, float yj, float zj) {
+    const float rx = xi - xj, ry = yi - yj, rz = zi - zj;
+    return fast_sqrt(__builtin_fmaf(rx, rx, __builtin_fmaf(ry, ry, rz * rz)));
+}
 // edge type, unitransformer.py:92-97: (src lig, dst lig)->0, (lig, prot)->1, (prot, lig)->2, (prot, prot)->3
 __device__ __forceinline__ int etype(bool src_lig, int lig_i) { return src_lig ? (lig_i ? 0 : 1) : (lig_i ? 2 : 3); }
 
 // ---- edge-major path for one half (16 edges): pre-activation -> LayerNorm -> ReLU -> contraction with a
 // per-lane row of B (Qt[i][a] for scores, Wbv[a] for the h2x values).  Returns the 16x16 result tile:
 // lane (c = a, q), reg r <-> edge 4q + r + 16hf.  `kv` selects the k (0) or v (1) quarter everywhere.
-// `pd` / `ps`: this node's and the neighbour's projection rows (8 float4 = channels 16t + 4q .. +3), loaded by the
-// caller so that the gathers of the second half are in flight while the first half computes.
+// `acc` enters as PD[i] + PS[j] (this node's and the neighbour's projection rows, channels 16t + 4q .. +3), summed by
+// the caller as soon as the gathered rows arrive, so that the registers of the gather can be reused for the next one.
 template <bool PRE>
-__device__ __forceinline__ floatx4 edge_major_half(const float4 (&pd)[8], const float4 (&ps)[8], bool lg, int kv,
+__device__ __forceinline__ floatx4 edge_major_half(floatx4 (&acc)[8], bool lg, int kv,
                                                    const float* lds_frag, const float* lds_dwt, const float* lds_ln,
                                                    const float (&R)[5], bool has_prot, bool has_lig, int lig_i,
-                                                   int lane, int q, const float* __restrict__ Brow,
+                                                   int lane, int q, gptr Brow, unsigned brow_off,
                                                    const float4 (&pre)[8]) {
-    floatx4 acc[8];
-    {
+    if (has_lig) {  // wave-uniform: only nodes with a ligand neighbour pay for the type correction
+        const float* dw = lds_dwt + lig_i * 2 * H + kv * H + 4 * q;
+        const float m = lg ? 1.f : 0.f;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = f4(pd[t]) + f4(ps[t]);
-        if (has_lig) {  // wave-uniform: only nodes with a ligand neighbour pay for the type correction
-            const float* dw = lds_dwt + lig_i * 2 * H + kv * H + 4 * q;
-            const float m = lg ? 1.f : 0.f;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) acc[t] += f4(ld4(dw + 16 * t)) * m;
-        }
+        for (int t = 0; t < 8; ++t) acc[t] += f4(ld4(dw + 16 * t)) * m;
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -138,7 +187,7 @@ __device__ __forceinline__ floatx4 edge_major_half(const float4 (&pd)[8], const 
         const floatx4 g = f4(ld4(lg_ + 16 * t)), b = f4(ld4(lb_ + 16 * t));
         const float2v ya = (lo2(acc[t]) * r2) * lo2(g) + lo2(b);
         const float2v yb = (hi2(acc[t]) * r2) * hi2(g) + hi2(b);
-        const float4 bb = PRE ? pre[t] : ld4(Brow + 16 * t);
+        const float4 bb = PRE ? pre[t] : ldo4(Brow, brow_off + 64 * t);
         out0 = MFMA(fmaxf(ya.x, 0.f), bb.x, out0);
         out1 = MFMA(fmaxf(ya.y, 0.f), bb.y, out1);
         out0 = MFMA(fmaxf(yb.x, 0.f), bb.z, out0);
@@ -147,11 +196,29 @@ __device__ __forceinline__ floatx4 edge_major_half(const float4 (&pd)[8], const 
     return out0 + out1;
 }
 
-// ABL (timing ablations only, results are wrong when != 0): 1 no Qt streaming (row 0 for every node),
-// 2 no neighbour gathers (every neighbour row = own row), 3 no rbf pre-activation MFMAs, 4 = 1+2, 5 = 1+2+3
+// Geometry of one work item in the two lane mappings the kernel uses:
+//   E0: lane (c, q) <-> edges c and c + 16 (distances, rbf, edge-major tiles);  E1: lane (c, q) <-> edges 4q + r (+16)
+// Invalid slots (e >= deg) point at the node itself, so every gather below is unconditional: a predicated load compiles
+// to branch + load + wait per element, which is what used to serialise the memory latencies of a node.
+struct ItemGeom {
+    int node, d, lig_i;
+    float xi, yi, zi;
+    int j0[2];          // E0 neighbour ids
+    int jv[2][4];       // E1 neighbour ids
+};
+
 // LISTED: the launch iterates over a device-side node list (h2x always; x2h in the pruned last layers) -- a separate
 // instantiation so that profilers report full-graph and listed launches under different kernel names.
-template <bool X2H, int WAVES, int ABL, bool LISTED>
+//
+// Memory pipeline of one iteration (every gather has at least one MFMA block between its issue and its first use):
+//   previous iteration   ids / flags / coordinates of this node and its neighbours; PD[i], PS_k[j] rows (issued before
+//                        that node's epilogue)
+//   top                  both halves' PD + PS_k summed (frees the 24 gather registers); then Qt[i] rows, PS_v gathers of
+//                        half 0 (x2h), ids of the next node (a)
+//   after k half 0       PS_v gathers of half 1 (x2h), e_w; coordinates / flags of the next node's neighbours (b)
+//   after k half 1       distances / flags of the next node's edges
+//   before the epilogue  PD / PS_k rows of the next node (c)
+template <bool X2H, int WAVES, bool LISTED>
 __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     const float* __restrict__ att, const float* __restrict__ x, const float* __restrict__ h,
     const float* __restrict__ P, const float* __restrict__ Qt, const int32_t* __restrict__ nbr,
@@ -161,6 +228,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     const int* __restrict__ act = LISTED ? act_arg : nullptr;
     constexpr int IMG = X2H ? (int)IMG_SIZE_X2H : (int)IMG_SIZE_H2X;
     __shared__ __attribute__((aligned(16))) float lds[IMG];
+    __shared__ float lds_mu[G];
     if (!X2H && act) {
         // work list mode: x_out = x for every node that cannot move (done by all workgroups, before any early exit)
         for (int n = blockIdx.x * (WAVES * 64) + threadIdx.x; n < n_nodes; n += gridDim.x * WAVES * 64)
@@ -185,6 +253,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         const float4* src = reinterpret_cast<const float4*>(att + A_IMG);
         float4* dst = reinterpret_cast<float4*>(lds);
         for (int t = threadIdx.x; t < IMG / 4; t += WAVES * 64) dst[t] = src[t];
+        if (threadIdx.x < G) lds_mu[threadIdx.x] = c_mu[threadIdx.x];
     }
     __syncthreads();
     const float* lds_fk = lds + IMG_FRAG_K;
@@ -192,11 +261,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     const float* lds_dwt = lds + IMG_WT;
     const float* lds_ln = lds + IMG_LN;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index -- and with it every node index of the persistent loop -- lives in scalar registers: node-level values
+    // (degree, flag, position, row bases) are then scalar loads and SGPR operands instead of 64 identical lanes
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, q = lane >> 4;
-    float mu[5];
-#pragma unroll
-    for (int s = 0; s < 5; ++s) mu[s] = c_mu[4 * s + q];
 
     // XCD-aware persistent schedule: workgroup b runs on XCD b % 8 (observed dispatch order), so give every
     // XCD one contiguous eighth of the item range: a graph's PS / Qt rows are then pulled into one L2 only.
@@ -212,85 +280,148 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         i_end = n_items;
         i_step = gridDim.x * WAVES;
     }
+    if (i_begin >= i_end) return;
 
-    // ---- stage 0 is software-pipelined one node ahead: (a) deg / lig / x_i / neighbour ids, (b) neighbour
-    // coordinates and flags.  E0 mapping: lane (c, q) <-> edges c and c + 16.
-    int d = 0, lig_i = 0;
-    float xi = 0.f, yi = 0.f, zi = 0.f;
-    int j0[2] = {0, 0};
-    bool lg0[2] = {false, false};
-    float dist0[2] = {0.f, 0.f};
-    int node = 0;   // node id of the current item
-    if (i_begin < i_end) {
-        const int i = act ? act[i_begin] : i_begin;
-        node = i;
-        d = deg[i]; lig_i = lig[i];
-        xi = x[3 * i]; yi = x[3 * i + 1]; zi = x[3 * i + 2];
+    // ---- first item: geometry and the k-path rows, everything unconditional -------------------------------------
+    ItemGeom g;
+    bool lg0[2];
+    float dist0[2];
+    float4 pd[8], ps0[8], ps1[8];
+    {
+        const int i = __builtin_amdgcn_readfirstlane(act ? act[i_begin] : i_begin);
+        g.node = i;
+        g.d = deg[i]; g.lig_i = lig[i];
+        g.xi = x[3 * i]; g.yi = x[3 * i + 1]; g.zi = x[3 * i + 2];
+        const gptr nrow = sbase(nbr + (size_t)i * KNN);
+        const unsigned oc = vop(4 * c), oq = vop(16 * q);
+        const int r0 = ldoi(nrow, oc), r1 = ldoi(nrow, oc + 64);
+        const int4 nb0 = ldoi4(nrow, oq), nb1 = ldoi4(nrow, oq + 64);
+        g.j0[0] = c < g.d ? r0 : i;
+        g.j0[1] = c + 16 < g.d ? r1 : i;
+        const int nbv[2][4] = {{nb0.x, nb0.y, nb0.z, nb0.w}, {nb1.x, nb1.y, nb1.z, nb1.w}};
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g.jv[hf][r] = 4 * q + r + 16 * hf < g.d ? nbv[hf][r] : i;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            const int e = c + 16 * hf;
-            const bool valid = e < d;
-            const int j = (valid && ABL != 2 && ABL < 4) ? nbr[(size_t)i * KNN + e] : i;
-            j0[hf] = j;
-            lg0[hf] = valid && lig[j];
-            const float rx = xi - x[3 * j], ry = yi - x[3 * j + 1], rz = zi - x[3 * j + 2];
-            dist0[hf] = fast_sqrt(rx * rx + ry * ry + rz * rz);
+            const int j = g.j0[hf];
+            const int lj = ldob(sbase(lig), (unsigned)j);
+            lg0[hf] = (c + 16 * hf < g.d) && lj;
+            dist0[hf] = edge_len(g.xi, g.yi, g.zi, ldo1(sbase(x), 12u * j), ldo1(sbase(x), 12u * j + 4), ldo1(sbase(x), 12u * j + 8));
         }
+        const gptr pdp = sbase(P + (size_t)i * PROW);
+        const unsigned o0 = (unsigned)g.j0[0] * (PROW * 4) + (2 * H + 4 * q) * 4, o1 = (unsigned)g.j0[1] * (PROW * 4) + (2 * H + 4 * q) * 4;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { pd[t] = ldo4(pdp, oq + 64 * t); ps0[t] = ldo4(sbase(P), o0 + 64 * t); }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) ps1[t] = ldo4(sbase(P), o1 + 64 * t);
     }
 
     for (int k = i_begin; k < i_end; k += i_step) {
-        const int i = node;
+        const int i = __builtin_amdgcn_readfirstlane(g.node), d = g.d, lig_i = g.lig_i;
         const bool more = k + i_step < i_end;   // wave-uniform
-        const int inext = more ? (act ? act[k + i_step] : k + i_step) : 0;
-        // this node's folded query row (B operand of the score MFMAs): issue now, consume after the pre-activation
+        // both halves' PD[i] + PS_k[j] as soon as the rows (requested one epilogue ago) are here: the 24 gather registers
+        // are then free for this iteration's other gathers
+        floatx4 acc0[8], acc1[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { acc0[t] = f4(pd[t]) + f4(ps0[t]); acc1[t] = f4(pd[t]) + f4(ps1[t]); }
+        __builtin_amdgcn_sched_barrier(0);
+        // this node's folded query row (B operand of the score MFMAs): consumed after the first pre-activation block
         float4 qrow[8];
         {
-            const float* qp = Qt + ((size_t)((ABL == 1 || ABL >= 4) ? 0 : i) * HEADS + c) * H + 4 * q;
+            const gptr qp = sbase(Qt + (size_t)i * HEADS * H);
+            const unsigned oqr = vop((c * H + 4 * q) * 4);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) qrow[t] = ld4(qp + 16 * t);
+            for (int t = 0; t < 8; ++t) qrow[t] = ldo4(qp, oqr + 64 * t);
         }
-        // next node, stage (a)
-        int nd = 0, nlig = 0, njr[2] = {0, 0};
-        float nx = 0.f, ny = 0.f, nz = 0.f;
-        if (more) {
-            nd = deg[inext]; nlig = lig[inext];
-            nx = x[3 * inext]; ny = x[3 * inext + 1]; nz = x[3 * inext + 2];
-            njr[0] = nbr[(size_t)inext * KNN + c];
-            njr[1] = nbr[(size_t)inext * KNN + 16 + c];
+        // x2h: PS_v rows (channel-major gather, E1 mapping) of half 0, needed two MFMA blocks from here
+        float4 sva[2][4], svb[2][4];
+        if (X2H) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned o = (unsigned)g.jv[0][r] * (PROW * 4) + (3 * H + 4 * c) * 4;
+                sva[0][r] = ldo4(sbase(P), o);
+                svb[0][r] = ldo4(sbase(P), o + 256);
+            }
         }
+        // (a) next item: id, degree, flag, position, neighbour ids in both mappings.  The last iteration re-requests its own
+        // node (every prefetch below is unconditional: no divergent joins for the register allocator, no predicated loads)
+        ItemGeom ng;
+        const int inext = __builtin_amdgcn_readfirstlane(more ? (act ? act[k + i_step] : k + i_step) : i);
+        ng.node = inext;
+        ng.d = deg[inext]; ng.lig_i = lig[inext];
+        ng.xi = x[3 * inext]; ng.yi = x[3 * inext + 1]; ng.zi = x[3 * inext + 2];
+        const gptr nrow = sbase(nbr + (size_t)inext * KNN);
+        const unsigned oc = vop(4 * c), oq = vop(16 * q);
+        const int nr0 = ldoi(nrow, oc), nr1 = ldoi(nrow, oc + 64);
+        const int4 nnb0 = ldoi4(nrow, oq), nnb1 = ldoi4(nrow, oq + 64);
+        __builtin_amdgcn_sched_barrier(0);
         float R[2][5];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            const bool valid = c + 16 * hf < d;
+            // exp() of every slot, then a 0 / 1 factor: `valid ? exp(..) : 0` compiles to a divergent branch per value
+            const float vm = c + 16 * hf < d ? 1.f : 0.f;
 #pragma unroll
             for (int s = 0; s < 5; ++s) {
-                const float u = dist0[hf] - mu[s];
-                R[hf][s] = valid ? fast_exp(-0.5f * (u * u)) : 0.f;
+                const float u = dist0[hf] - lds_mu[4 * s + q];   // re-read per node: five registers less across the loop
+                R[hf][s] = fast_exp(-0.5f * (u * u)) * vm;
             }
         }
         const unsigned long long b0 = __ballot(lg0[0]), b1 = __ballot(lg0[1]);
         const unsigned mask_lig = (unsigned)(b0 & 0xffffull) | ((unsigned)(b1 & 0xffffull) << 16);
         const unsigned mask_valid = d >= 32 ? 0xffffffffu : ((1u << d) - 1u);
-        const bool has_lig = (mask_lig & mask_valid) != 0 && ABL != 3 && ABL != 5;
-        const bool has_prot = (((~mask_lig) & mask_valid) != 0 || d == 0) && ABL != 3 && ABL != 5;
+        const bool has_lig = (mask_lig & mask_valid) != 0;
+        const bool has_prot = ((~mask_lig) & mask_valid) != 0 || d == 0;
 
         // ---- k path: hidden (edge-major) -> scores -> softmax ------------------------------------------
         floatx4 sc[2];
+        sc[0] = edge_major_half<true>(acc0, lg0[0], 0, lds_fk, lds_dwt, lds_ln, R[0], has_prot, has_lig, lig_i, lane, q,
+                                      (gptr)0, 0u, qrow);
+        __builtin_amdgcn_sched_barrier(0);
+        // second half of the PS_v gather and the gate values; (b) next item: resolve its neighbour ids (they arrived during
+        // the first half), request their flags and coordinates
+        float4 ew0 = {0.f, 0.f, 0.f, 0.f}, ew1 = {0.f, 0.f, 0.f, 0.f};
+        if (X2H) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned o = (unsigned)g.jv[1][r] * (PROW * 4) + (3 * H + 4 * c) * 4;
+                sva[1][r] = ldo4(sbase(P), o);
+                svb[1][r] = ldo4(sbase(P), o + 256);
+            }
+        }
+        const gptr ewp = sbase(e_w + (size_t)i * KNN);
+        const unsigned oqe = vop(16 * q);
+        ew0 = ldo4(ewp, oqe);
+        ew1 = ldo4(ewp, oqe + 64);
+        int nlj[2];
+        float nxj[2][3];
         {
-            float4 pd[8], ps0[8], ps1[8];
-            const float* pdp = P + (size_t)i * PROW + 4 * q;
-            const float* p0 = P + (size_t)j0[0] * PROW + 2 * H + 4 * q;
-            const float* p1 = P + (size_t)j0[1] * PROW + 2 * H + 4 * q;
+            ng.j0[0] = c < ng.d ? nr0 : inext;
+            ng.j0[1] = c + 16 < ng.d ? nr1 : inext;
+            const int nbv[2][4] = {{nnb0.x, nnb0.y, nnb0.z, nnb0.w}, {nnb1.x, nnb1.y, nnb1.z, nnb1.w}};
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { pd[t] = ld4(pdp + 16 * t); ps0[t] = ld4(p0 + 16 * t); }
+            for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) ps1[t] = ld4(p1 + 16 * t);   // second half's gather flies during the first half
-            sc[0] = edge_major_half<true>(pd, ps0, lg0[0], 0, lds_fk, lds_dwt, lds_ln, R[0], has_prot, has_lig, lig_i, lane,
-                                          q, nullptr, qrow);
-            __builtin_amdgcn_sched_barrier(0);
-            sc[1] = edge_major_half<true>(pd, ps1, lg0[1], 0, lds_fk, lds_dwt, lds_ln, R[1], has_prot, has_lig, lig_i, lane,
-                                          q, nullptr, qrow);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int r = 0; r < 4; ++r) ng.jv[hf][r] = 4 * q + r + 16 * hf < ng.d ? nbv[hf][r] : inext;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int j = ng.j0[hf];
+                nlj[hf] = ldob(sbase(lig), (unsigned)j);
+                nxj[hf][0] = ldo1(sbase(x), 12u * j); nxj[hf][1] = ldo1(sbase(x), 12u * j + 4); nxj[hf][2] = ldo1(sbase(x), 12u * j + 8);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sc[1] = edge_major_half<true>(acc1, lg0[1], 0, lds_fk, lds_dwt, lds_ln, R[1], has_prot, has_lig, lig_i, lane, q,
+                                      (gptr)0, 0u, qrow);
+        __builtin_amdgcn_sched_barrier(0);
+        // next item: distances and ligand flags of its edges from the (b) loads
+        bool nlg[2];
+        float ndist[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            nlg[hf] = (c + 16 * hf < ng.d) && nlj[hf];
+            ndist[hf] = edge_len(ng.xi, ng.yi, ng.zi, nxj[hf][0], nxj[hf][1], nxj[hf][2]);
         }
         // E1 mapping: lane (c = head a, q), reg (hf, r) <-> edge e = 4q + r + 16hf
         float al[2][4];
@@ -315,27 +446,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             }
         den = xrow_sum(den);
         const float inv_den = den > 0.f ? fast_rcp(den) : 0.f;
-        const float4 ew0 = ld4(e_w + (size_t)i * KNN + 4 * q), ew1 = ld4(e_w + (size_t)i * KNN + 16 + 4 * q);
         const float ew[2][4] = {{ew0.x, ew0.y, ew0.z, ew0.w}, {ew1.x, ew1.y, ew1.z, ew1.w}};
-        // neighbours in the E1 mapping
-        const int4 nb0 = *reinterpret_cast<const int4*>(nbr + (size_t)i * KNN + 4 * q);
-        const int4 nb1 = *reinterpret_cast<const int4*>(nbr + (size_t)i * KNN + 16 + 4 * q);
-        const int nb[2][4] = {{nb0.x, nb0.y, nb0.z, nb0.w}, {nb1.x, nb1.y, nb1.z, nb1.w}};
-        // next node, stage (b): neighbour coordinates / flags (their ids arrived during the k path)
-        int nj[2] = {0, 0};
-        bool nlg[2] = {false, false};
-        float ndist[2] = {0.f, 0.f};
-        if (more) {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const bool valid = c + 16 * hf < nd;
-                const int j = (valid && ABL != 2 && ABL < 4) ? njr[hf] : inext;
-                nj[hf] = j;
-                nlg[hf] = valid && lig[j];
-                const float rx = nx - x[3 * j], ry = ny - x[3 * j + 1], rz = nz - x[3 * j + 2];
-                ndist[hf] = fast_sqrt(rx * rx + ry * ry + rz * rz);
-            }
-        }
         __builtin_amdgcn_sched_barrier(0);
 
         if (X2H) {
@@ -355,24 +466,14 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             floatx4 s2[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) s2[t] = floatx4{0.f, 0.f, 0.f, 0.f};
-            const float4 pa = ld4(P + (size_t)i * PROW + H + 4 * c), pb = ld4(P + (size_t)i * PROW + H + 64 + 4 * c);
+            const gptr pvp = sbase(P + (size_t)i * PROW);
+            const unsigned ocv = vop((H + 4 * c) * 4);
+            const float4 pa = ldo4(pvp, ocv), pb = ldo4(pvp, ocv + 256);
             const float pdv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
             const float4 ga = ld4(lds_ln + 2 * H + 4 * c), gb = ld4(lds_ln + 2 * H + 64 + 4 * c);
             const float4 ba = ld4(lds_ln + 3 * H + 4 * c), bb = ld4(lds_ln + 3 * H + 64 + 4 * c);
             const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
             const float bv[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
-            // PS_v rows of both halves are requested up front: the second half's gather flies during the first half
-            float4 sva[2][4], svb[2][4];
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int e = 4 * q + r + 16 * hf;
-                    const int j = (e < d && ABL != 2 && ABL < 4) ? nb[hf][r] : i;
-                    const float* ps = P + (size_t)j * PROW + 3 * H + 4 * c;
-                    sva[hf][r] = ld4(ps);
-                    svb[hf][r] = ld4(ps + 64);
-                }
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 floatx4 hv[8];
@@ -394,9 +495,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                     const float* dw = lds_dwt + lig_i * 2 * H + H + 4 * c;
                     const float4 da = ld4(dw), db = ld4(dw + 64);
                     const float dv[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+                    const unsigned msh = mask_lig >> (4 * q);   // bit r (+16) <-> edge 4q + r (+16): immediate bit-field extracts
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float m = ((mask_lig >> (4 * q + r + 16 * hf)) & 1u) ? 1.f : 0.f;
+                        const float m = ((msh >> (r + 16 * hf)) & 1u) ? 1.f : 0.f;
 #pragma unroll
                         for (int t = 0; t < 8; ++t) hv[t][r] = fmaf(m, dv[t], hv[t][r]);
                     }
@@ -440,6 +542,23 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                     for (int t = 0; t < 8; ++t) s2[t] = MFMA(hv[t][r], w[hf][r], s2[t]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // (c) next item: its PD / PS_k rows fly during the epilogue (the v path's gather registers are free again)
+            {
+                const gptr pdp = sbase(P + (size_t)inext * PROW);
+                const unsigned o0 = (unsigned)ng.j0[0] * (PROW * 4) + (2 * H + 4 * q) * 4;
+                const unsigned o1 = (unsigned)ng.j0[1] * (PROW * 4) + (2 * H + 4 * q) * 4;
+                const unsigned oq = vop(16 * q);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { pd[t] = ldo4(pdp, oq + 64 * t); ps0[t] = ldo4(sbase(P), o0 + 64 * t); }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) ps1[t] = ldo4(sbase(P), o1 + 64 * t);
+            }
+            // residual row and bias of this lane's two outputs: requested here, used after the Wbv products
+            const int n0 = 8 * c + 2 * q;
+            const unsigned on0 = vop(n0 * 4);
+            const float2 hres = ldo2(sbase(h + (size_t)i * H), on0);
+            const float2 bias2 = ldo2(sbase(att + A_BBV), on0);
+            __builtin_amdgcn_sched_barrier(0);
             // epilogue: out[8a + cc] = sum_m Wbv[8a + cc][m] S[a][m] + bbv[8a + cc] sum_e alpha e_w ; this lane holds
             // S[a = c][16q .. 16q+15] and [64 + 16q .. 64 + 16q + 15]; Wbv rows live in LDS with their 16-byte chunks XOR-swizzled by the head index
             // so the 16 lanes of a row (16 different Wbv rows, same columns) hit 16 different bank groups.
@@ -470,60 +589,73 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             // lane (c, q) writes outputs n = 8c + 2q, 8c + 2q + 1
             const float oa = q == 0 ? o8[0] : (q == 1 ? o8[2] : (q == 2 ? o8[4] : o8[6]));
             const float ob = q == 0 ? o8[1] : (q == 1 ? o8[3] : (q == 2 ? o8[5] : o8[7]));
-            const int n0 = 8 * c + 2 * q;
-            const float2 hres = *reinterpret_cast<const float2*>(h + (size_t)i * H + n0);
-            const float2 bias2 = *reinterpret_cast<const float2*>(att + A_BBV + n0);
             float2 o;
             o.x = hres.x + (oa + bias2.x * sw);
             o.y = hres.y + (ob + bias2.y * sw);
-            *reinterpret_cast<float2*>(out + (size_t)i * H + n0) = o;
+            sto2(sbase_w(out + (size_t)i * H), vop(n0 * 4), o);
         } else {
             // ---- h2x: v hidden edge-major, wv[e][a] = Wbv[a] . hid_v[e] + bbv[a] -------------------------------
             floatx4 wv[2];
             {
-                float4 pd[8], ps0[8], ps1[8];
-                const float* pdp = P + (size_t)i * PROW + H + 4 * q;
-                const float* p0 = P + (size_t)j0[0] * PROW + 3 * H + 4 * q;
-                const float* p1 = P + (size_t)j0[1] * PROW + 3 * H + 4 * q;
+                float4 vd[8], vs0[8], vs1[8];
+                const gptr pdp = sbase(P + (size_t)i * PROW);
+                const unsigned o0 = (unsigned)g.j0[0] * (PROW * 4) + (3 * H + 4 * q) * 4, o1 = (unsigned)g.j0[1] * (PROW * 4) + (3 * H + 4 * q) * 4;
+                const unsigned ovd = vop((H + 4 * q) * 4);
 #pragma unroll
-                for (int t = 0; t < 8; ++t) { pd[t] = ld4(pdp + 16 * t); ps0[t] = ld4(p0 + 16 * t); }
+                for (int t = 0; t < 8; ++t) { vd[t] = ldo4(pdp, ovd + 64 * t); vs0[t] = ldo4(sbase(P), o0 + 64 * t); }
 #pragma unroll
-                for (int t = 0; t < 8; ++t) ps1[t] = ld4(p1 + 16 * t);
-                const float* wrow = att + A_WBV + (size_t)c * H + 4 * q;
-                wv[0] = edge_major_half<false>(pd, ps0, lg0[0], 1, lds_fv, lds_dwt, lds_ln, R[0], has_prot, has_lig, lig_i,
-                                               lane, q, wrow, qrow);
+                for (int t = 0; t < 8; ++t) vs1[t] = ldo4(sbase(P), o1 + 64 * t);
+                const gptr wrow = sbase(att + A_WBV);
+                const unsigned wrow_off = vop((c * H + 4 * q) * 4);
+                floatx4 acc[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] = f4(vd[t]) + f4(vs0[t]);
+                wv[0] = edge_major_half<false>(acc, lg0[0], 1, lds_fv, lds_dwt, lds_ln, R[0], has_prot, has_lig, lig_i, lane, q,
+                                               wrow, wrow_off, qrow);
                 __builtin_amdgcn_sched_barrier(0);
-                wv[1] = edge_major_half<false>(pd, ps1, lg0[1], 1, lds_fv, lds_dwt, lds_ln, R[1], has_prot, has_lig, lig_i,
-                                               lane, q, wrow, qrow);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] = f4(vd[t]) + f4(vs1[t]);
+                wv[1] = edge_major_half<false>(acc, lg0[1], 1, lds_fv, lds_dwt, lds_ln, R[1], has_prot, has_lig, lig_i, lane, q,
+                                               wrow, wrow_off, qrow);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const float bbv = att[A_BBV + c];
+            // (c) next item: its PD / PS_k rows
+            {
+                const gptr pdp = sbase(P + (size_t)inext * PROW);
+                const unsigned o0 = (unsigned)ng.j0[0] * (PROW * 4) + (2 * H + 4 * q) * 4;
+                const unsigned o1 = (unsigned)ng.j0[1] * (PROW * 4) + (2 * H + 4 * q) * 4;
+                const unsigned oq = vop(16 * q);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { pd[t] = ldo4(pdp, oq + 64 * t); ps0[t] = ldo4(sbase(P), o0 + 64 * t); }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) ps1[t] = ldo4(sbase(P), o1 + 64 * t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float bbv = ldo1(sbase(att + A_BBV), vop(4 * c));
             float dx = 0.f, dy = 0.f, dz = 0.f;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int e = 4 * q + r + 16 * hf;
-                    if (e < d) {
-                        const int j = nb[hf][r];
-                        const float coef = (al[hf][r] * inv_den) * ((wv[hf][r] + bbv) * ew[hf][r]);
-                        dx = fmaf(coef, xi - x[3 * j], dx);
-                        dy = fmaf(coef, yi - x[3 * j + 1], dy);
-                        dz = fmaf(coef, zi - x[3 * j + 2], dz);
-                    }
+                    // invalid slots point at the node itself: rel = 0 and alpha = 0, so they add exactly nothing
+                    const int j = g.jv[hf][r];
+                    const float coef = (al[hf][r] * inv_den) * ((wv[hf][r] + bbv) * ew[hf][r]);
+                    const float cf = 4 * q + r + 16 * hf < d ? coef : 0.f;
+                    dx = fmaf(cf, g.xi - ldo1(sbase(x), 12u * j), dx);
+                    dy = fmaf(cf, g.yi - ldo1(sbase(x), 12u * j + 4), dy);
+                    dz = fmaf(cf, g.zi - ldo1(sbase(x), 12u * j + 8), dz);
                 }
             dx = wave_sum(dx); dy = wave_sum(dy); dz = wave_sum(dz);
             if (lane < 3) {
                 const float v = (lane == 0 ? dx : (lane == 1 ? dy : dz)) * (1.f / HEADS);
-                const float xin = lane == 0 ? xi : (lane == 1 ? yi : zi);
+                const float xin = lane == 0 ? g.xi : (lane == 1 ? g.yi : g.zi);
                 if (dx_out) dx_out[3 * i + lane] = v;
                 out[3 * i + lane] = xin + (gen[i] ? v : 0.f);
             }
         }
         // rotate the pipelined geometry
-        node = inext;
-        d = nd; lig_i = nlig; xi = nx; yi = ny; zi = nz;
-        j0[0] = nj[0]; j0[1] = nj[1]; lg0[0] = nlg[0]; lg0[1] = nlg[1]; dist0[0] = ndist[0]; dist0[1] = ndist[1];
+        lg0[0] = nlg[0]; lg0[1] = nlg[1]; dist0[0] = ndist[0]; dist0[1] = ndist[1];
+        g = ng;
     }
 }
 
@@ -599,37 +731,20 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
                             const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,
                             const int* act, const int* act_count, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
-    // waves per (persistent, one-per-CU) workgroup: 8 -> 256 VGPRs, 12 -> 168 per lane.
-    static const int waves = [] {
-        const char* e = getenv("CBGX_EDGE_WAVES");
-        const int w = e ? atoi(e) : 8;
-        return (w == 8 || w == 12) ? w : 8;
-    }();
-    static const int abl = [] {
-        const char* e = getenv("CBGX_EDGE_ABL");
-        const int a = e ? atoi(e) : 0;
-        return (a >= 0 && a <= 5) ? a : 0;
-    }();
-    int grid = (n_nodes + waves - 1) / waves;
+    if ((size_t)n_nodes * PROW * sizeof(float) >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit byte offsets into P
+    constexpr int W = 8;                        // waves per persistent workgroup: 2 per SIMD at <= 256 VGPRs per lane
+    int grid = (n_nodes + W - 1) / W;
     if (grid > 256) grid = 256;                 // persistent: one workgroup per CU (LDS-limited)
     if (grid >= 64) grid &= ~7;                 // multiple of 8 -> XCD-aware node partition
     profile_mark_begin(x2h ? (act ? K_EDGE_X2H_LISTED : K_EDGE_X2H) : K_EDGE_H2X, s);
-#define CBGX_LAUNCH_EDGE(X2H_, W_, A_, L_)                                                                            \
-    hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W_, A_, L_>), dim3(grid), dim3(W_ * 64), 0, s, att, x, h, P, Qt, nbr, deg, \
+#define CBGX_LAUNCH_EDGE(X2H_, L_)                                                                              \
+    hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W, L_>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qt, nbr, deg, \
                        lig, gen, e_w, n_nodes, out, dx_out, act, act_count)
-#define CBGX_LAUNCH_ABL(X2H_, A_) case A_: CBGX_LAUNCH_EDGE(X2H_, 8, A_, false); break;
-    if (act) {
-        if (x2h) CBGX_LAUNCH_EDGE(true, 8, 0, true); else CBGX_LAUNCH_EDGE(false, 8, 0, true);
-    } else if (waves == 12) {
-        if (x2h) CBGX_LAUNCH_EDGE(true, 12, 0, false); else CBGX_LAUNCH_EDGE(false, 12, 0, false);
-    } else if (x2h) {
-        switch (abl) { CBGX_LAUNCH_ABL(true, 1) CBGX_LAUNCH_ABL(true, 2) CBGX_LAUNCH_ABL(true, 3) CBGX_LAUNCH_ABL(true, 4)
-                       CBGX_LAUNCH_ABL(true, 5) default: CBGX_LAUNCH_EDGE(true, 8, 0, false); }
+    if (x2h) {
+        if (act) CBGX_LAUNCH_EDGE(true, true); else CBGX_LAUNCH_EDGE(true, false);
     } else {
-        switch (abl) { CBGX_LAUNCH_ABL(false, 1) CBGX_LAUNCH_ABL(false, 2) CBGX_LAUNCH_ABL(false, 3) CBGX_LAUNCH_ABL(false, 4)
-                       CBGX_LAUNCH_ABL(false, 5) default: CBGX_LAUNCH_EDGE(false, 8, 0, false); }
+        if (act) CBGX_LAUNCH_EDGE(false, true); else CBGX_LAUNCH_EDGE(false, false);
     }
-#undef CBGX_LAUNCH_ABL
 #undef CBGX_LAUNCH_EDGE
     profile_mark_end(s);
     return hipGetLastError();

@@ -24,7 +24,23 @@ hipError_t launch_attention(bool x2h, const float* att, const float* x, const fl
                             const int32_t* deg, const uint8_t* lig, const uint8_t* gen, const float* e_w, int n_nodes,
                             float* P, float* Qt, float* qbuf, float* out, float* dx_out, const int* act, const int* act_count,
                             const int* src, const int* src_count, hipStream_t s);
+// which generation of kernels the stage dispatchers (dispatch.hip) use: always the MFMA one in libcbgx.so; the test-only
+// library libcbgx_xcheck.so (-DCBGX_XCHECK) can switch to the first-generation VALU kernels at run time
+#ifdef CBGX_XCHECK
 extern int g_edge_impl;
+hipError_t launch_knn_v1(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, int32_t* nbr, int32_t* deg,
+                         hipStream_t s);
+hipError_t launch_gate_v1(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
+                          float* e_w, hipStream_t s);
+hipError_t launch_node_gemm_v1(const float* A, int lda, const float* Wt, const float* bias, float* C, int ldc, int M,
+                               int nout, int act, hipStream_t s, const int* rows, const int* n_rows);
+hipError_t launch_node_query_v1(const float* att, const float* P, float* Qt, int n_nodes, hipStream_t s);
+hipError_t launch_attention_v1(bool x2h, const float* att, const float* x, const float* h, const int32_t* nbr,
+                               const int32_t* deg, const uint8_t* lig, const uint8_t* gen, const float* e_w, int n_nodes,
+                               float* P, float* Qt, float* out, float* dx_out, hipStream_t s);
+#else
+constexpr int g_edge_impl = 0;
+#endif
 // fragment-ordered rbf weight table: mode 0 edge-major (A operand), 1 channel-major (B operand)
 hipError_t launch_pack_frag(const float* w_a, int mode, float* dst, hipStream_t s);
 hipError_t launch_center_linear(const float* w, const float* b, int cols, float* wc, float* bc, hipStream_t s);

@@ -417,30 +417,16 @@ __global__ __launch_bounds__(128) void edge_attention_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight packing
+// launchers of the first-generation kernels (test-only library libcbgx_xcheck.so, see dispatch.hip)
 // ------------------------------------------------------------------------------------------------
-__global__ void pack_copy_kernel(const float* __restrict__ src, int src_ld, int src_off, int transpose,
-                                 float* __restrict__ dst, int dst_ld, int rows, int cols) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * cols) return;
-    int i = idx / cols, j = idx % cols;
-    dst[(size_t)i * dst_ld + j] = transpose ? src[(size_t)j * src_ld + i + src_off] : src[(size_t)i * src_ld + j + src_off];
-}
-
-// ------------------------------------------------------------------------------------------------
-// launchers
-// ------------------------------------------------------------------------------------------------
-int g_edge_impl = 0;  // 0: MFMA edge kernels (edge_mfma.hip); 1: first-generation VALU kernels (cross-check)
 #define CBGX_LAUNCH_CHECK()                            \
     do {                                               \
         hipError_t _e = hipGetLastError();             \
         if (_e != hipSuccess) return _e;               \
     } while (0)
 
-hipError_t launch_knn(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, int32_t* nbr,
-                      int32_t* deg, hipStream_t s) {
-    if (n_nodes == 0) return hipSuccess;
-    if (g_edge_impl == 0) return launch_knn_reg(x, graph_ptr, n_graphs, n_nodes, nbr, deg, s);
+hipError_t launch_knn_v1(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, int32_t* nbr,
+                         int32_t* deg, hipStream_t s) {
     profile_mark_begin(K_KNN, s);
     hipLaunchKernelGGL(knn_graph_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, x, graph_ptr, n_graphs, n_nodes,
                        nbr, deg);
@@ -449,10 +435,8 @@ hipError_t launch_knn(const float* x, const int32_t* graph_ptr, int n_graphs, in
     return hipSuccess;
 }
 
-hipError_t launch_gate(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
-                       float* e_w, hipStream_t s) {
-    if (n_nodes == 0) return hipSuccess;
-    if (g_edge_impl == 0) return launch_gate_mfma(packed, x, nbr, deg, n_nodes, e_w, s);
+hipError_t launch_gate_v1(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
+                          float* e_w, hipStream_t s) {
     long total = (long)n_nodes * KNN;
     profile_mark_begin(K_GATE, s);
     hipLaunchKernelGGL(edge_gate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, packed, x, nbr, deg,
@@ -462,8 +446,8 @@ hipError_t launch_gate(const float* packed, const float* x, const int32_t* nbr, 
     return hipSuccess;
 }
 
-hipError_t launch_node_gemm(const float* A, int lda, const float* Wt, const float* bias, float* C, int ldc, int M,
-                            int nout, int act, hipStream_t s, const int* rows, const int* n_rows) {
+hipError_t launch_node_gemm_v1(const float* A, int lda, const float* Wt, const float* bias, float* C, int ldc, int M,
+                               int nout, int act, hipStream_t s, const int* rows, const int* n_rows) {
     if (M == 0) return hipSuccess;
     dim3 grid((M + 15) / 16), block(256);
     profile_mark_begin(K_NODE_GEMM, s);
@@ -471,34 +455,6 @@ hipError_t launch_node_gemm(const float* A, int lda, const float* Wt, const floa
         hipLaunchKernelGGL(node_gemm_kernel<0>, grid, block, 0, s, A, lda, Wt, bias, C, ldc, M, nout, rows, n_rows);
     else
         hipLaunchKernelGGL(node_gemm_kernel<1>, grid, block, 0, s, A, lda, Wt, bias, C, ldc, M, nout, rows, n_rows);
-    profile_mark_end(s);
-    CBGX_LAUNCH_CHECK();
-    return hipSuccess;
-}
-
-hipError_t launch_attention(bool x2h, const float* att, const float* x, const float* h, const int32_t* nbr,
-                            const int32_t* deg, const uint8_t* lig, const uint8_t* gen, const float* e_w, int n_nodes,
-                            float* P, float* Qt, float* qbuf, float* out, float* dx_out, const int* act, const int* act_count,
-                            const int* src, const int* src_count, hipStream_t s) {
-    if (n_nodes == 0) return hipSuccess;
-    if (g_edge_impl == 0) {
-        hipError_t e0 = launch_node_mfma(att, h, lig, n_nodes, P, qbuf, Qt, act, act_count, src, src_count, s);
-        if (e0 != hipSuccess) return e0;
-        return launch_edge_mfma(x2h, att, x, h, P, Qt, nbr, deg, lig, gen, e_w, n_nodes, out, dx_out, act, act_count, s);
-    }
-    hipError_t e = launch_node_gemm(h, H, att + A_WN, att + A_BN, P, PROW, n_nodes, PROW, 0, s);
-    if (e != hipSuccess) return e;
-    profile_mark_begin(K_NODE_QUERY, s);
-    hipLaunchKernelGGL(node_query_kernel, dim3((n_nodes + 15) / 16), dim3(256), 0, s, att, P, Qt, n_nodes);
-    profile_mark_end(s);
-    CBGX_LAUNCH_CHECK();
-    profile_mark_begin(x2h ? K_EDGE_X2H : K_EDGE_H2X, s);
-    if (x2h)
-        hipLaunchKernelGGL(edge_attention_kernel<true>, dim3(n_nodes), dim3(128), 0, s, att, x, h, P, Qt, nbr, deg,
-                           lig, gen, e_w, n_nodes, out, dx_out);
-    else
-        hipLaunchKernelGGL(edge_attention_kernel<false>, dim3(n_nodes), dim3(128), 0, s, att, x, h, P, Qt, nbr, deg,
-                           lig, gen, e_w, n_nodes, out, dx_out);
     profile_mark_end(s);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
@@ -513,33 +469,21 @@ hipError_t launch_node_query_v1(const float* att, const float* P, float* Qt, int
     return hipSuccess;
 }
 
-// many strided / transposed copies in one launch (blockIdx.y = piece): weight packing is ~40 small copies per block
-__global__ void pack_copy_multi_kernel(PackBatch b) {
-    const PackPiece& pc = b.p[blockIdx.y];
-    const int total = pc.rows * pc.cols;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int i = idx / pc.cols, j = idx % pc.cols;
-        pc.dst[(size_t)i * pc.dst_ld + j] =
-            pc.transpose ? pc.src[(size_t)j * pc.src_ld + i + pc.src_off] : pc.src[(size_t)i * pc.src_ld + j + pc.src_off];
-    }
-}
-
-hipError_t launch_pack_copy_multi(const PackBatch& b, hipStream_t s) {
-    if (b.n == 0) return hipSuccess;
-    int mx = 0;
-    for (int k = 0; k < b.n; ++k) mx = b.p[k].rows * b.p[k].cols > mx ? b.p[k].rows * b.p[k].cols : mx;
-    int gx = (mx + 255) / 256;
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(pack_copy_multi_kernel, dim3(gx, b.n), dim3(256), 0, s, b);
-    CBGX_LAUNCH_CHECK();
-    return hipSuccess;
-}
-
-hipError_t launch_pack_copy(const float* src, int src_ld, int src_off, int transpose, float* dst, int dst_ld,
-                            int rows, int cols, hipStream_t s) {
-    int total = rows * cols;
-    hipLaunchKernelGGL(pack_copy_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, src_ld, src_off, transpose,
-                       dst, dst_ld, rows, cols);
+hipError_t launch_attention_v1(bool x2h, const float* att, const float* x, const float* h, const int32_t* nbr,
+                               const int32_t* deg, const uint8_t* lig, const uint8_t* gen, const float* e_w, int n_nodes,
+                               float* P, float* Qt, float* out, float* dx_out, hipStream_t s) {
+    hipError_t e = launch_node_gemm_v1(h, H, att + A_WN, att + A_BN, P, PROW, n_nodes, PROW, 0, s, nullptr, nullptr);
+    if (e != hipSuccess) return e;
+    e = launch_node_query_v1(att, P, Qt, n_nodes, s);
+    if (e != hipSuccess) return e;
+    profile_mark_begin(x2h ? K_EDGE_X2H : K_EDGE_H2X, s);
+    if (x2h)
+        hipLaunchKernelGGL(edge_attention_kernel<true>, dim3(n_nodes), dim3(128), 0, s, att, x, h, P, Qt, nbr, deg,
+                           lig, gen, e_w, n_nodes, out, dx_out);
+    else
+        hipLaunchKernelGGL(edge_attention_kernel<false>, dim3(n_nodes), dim3(128), 0, s, att, x, h, P, Qt, nbr, deg,
+                           lig, gen, e_w, n_nodes, out, dx_out);
+    profile_mark_end(s);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }

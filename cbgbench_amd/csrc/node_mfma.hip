@@ -272,6 +272,85 @@ __global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// node_linear: C[M, nout] = act(A[M,128] @ Wt[128, nout] + bias), nout <= 128 (the classifier's two Linears,
+// unitransformer.py:119-122).  Persistent 4-wave workgroups, Wt staged once in LDS ([128][nout padded to 16]), one
+// wavefront per 16 rows, A in MFMA layout straight from global memory (k = 16u + 4q + j), scalar stores of 64-byte runs.
+// ACT: 0 none, 1 softplus(x) - ln 2 (ShiftedSoftplus, repo/modules/common.py:174-180).
+// ------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(256) void node_linear_kernel(const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                          float* __restrict__ C, int ldc, int M_all, int nout,
+                                                          const int* __restrict__ rows, const int* __restrict__ n_rows_ptr) {
+    __shared__ __attribute__((aligned(16))) float lds[H * H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
+    const int M = rows ? *n_rows_ptr : M_all;
+    const int n_tiles = (M + 63) / 64;
+    if ((int)blockIdx.x >= n_tiles) return;
+    const int npad = (nout + 15) & ~15;
+    for (int t = tid; t < H * npad; t += 256) {
+        const int k = t / npad, col = t - k * npad;
+        lds[t] = col < nout ? Wt[(size_t)k * nout + col] : 0.f;
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row0 = tile * 64 + wave * 16;
+        const int ak = min(row0 + c, M - 1);
+        const int arow = rows ? rows[ak] : ak;
+        int orow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = row0 + 4 * q + r;
+            orow[r] = k < M ? (rows ? rows[k] : k) : -1;
+        }
+        float a[32];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 v = nld4(A + (size_t)arow * lda + 16 * u + 4 * q);
+            a[4 * u] = v.x; a[4 * u + 1] = v.y; a[4 * u + 2] = v.z; a[4 * u + 3] = v.w;
+        }
+        for (int ct = 0; ct < npad / 16; ++ct) {
+            const int col = 16 * ct + c;
+            const float b = (bias && col < nout) ? bias[col] : 0.f;
+            floatx4 acc0 = {b, b, b, b}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float* wp = lds + (16 * u + 4 * q) * npad + col;
+                acc0 = MFMA(a[4 * u + 0], wp[0], acc0);
+                acc1 = MFMA(a[4 * u + 1], wp[npad], acc1);
+                acc0 = MFMA(a[4 * u + 2], wp[2 * npad], acc0);
+                acc1 = MFMA(a[4 * u + 3], wp[3 * npad], acc1);
+            }
+            if (col < nout) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (orow[r] >= 0) {
+                        float v = acc0[r] + acc1[r];
+                        if (ACT == 1) v = (v > 20.f ? v : log1pf(expf(v))) - 0.69314718055994530942f;
+                        C[(size_t)orow[r] * ldc + col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_node_gemm(const float* A, int lda, const float* Wt, const float* bias, float* C, int ldc, int M,
+                            int nout, int act, hipStream_t s, const int* rows, const int* n_rows) {
+    if (M == 0) return hipSuccess;
+    if (nout < 1 || nout > H) return hipErrorInvalidValue;
+    const int tiles = (M + 63) / 64;
+    const dim3 grid(tiles < 512 ? tiles : 512), block(256);
+    profile_mark_begin(K_NODE_GEMM, s);
+    if (act == 0)
+        hipLaunchKernelGGL(node_linear_kernel<0>, grid, block, 0, s, A, lda, Wt, bias, C, ldc, M, nout, rows, n_rows);
+    else
+        hipLaunchKernelGGL(node_linear_kernel<1>, grid, block, 0, s, A, lda, Wt, bias, C, ldc, M, nout, rows, n_rows);
+    profile_mark_end(s);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // fragment packing (from reference-layout tensors)
 // ------------------------------------------------------------------------------------------------
 // node projection: dst[ch][ct][s4][lane][j] = Wcat[col = 64ch + 4c + ct][k = 32q + 4 s4 + j]; Wcat rows are assembled

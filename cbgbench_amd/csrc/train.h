@@ -34,11 +34,13 @@ constexpr int GB_W2 = GB_LNB + GH;
 constexpr int GB_B2 = GB_W2 + GH;
 constexpr int GB_SIZE = GB_B2 + 4;
 
+#ifdef CBGX_XCHECK
 hipError_t launch_edge_backward(bool x2h, const float* att, const float* x, const float* P, const float* Qt,
                                 const float* Gt, const float* gb, const float* gx_out, const int32_t* nbr,
                                 const int32_t* deg, const uint8_t* lig, const float* e_w, const int* rows,
                                 const int* n_rows, int n_nodes, float* T, float* S, float* sw, float* dP, float* dx,
                                 float* de_w, float* partial, int grid, hipStream_t s);
+#endif
 hipError_t launch_edge_backward_mfma(bool x2h, const float* att, const float* x, const float* P, const float* Qt,
                                      const float* Gt, const float* gb, const float* gx_out, const int32_t* nbr,
                                      const int32_t* deg, const uint8_t* lig, const float* e_w, const int* rows,
@@ -54,11 +56,15 @@ hipError_t launch_dgrad_mfma(const float* A, int lda, const float* B, int ldb, f
 hipError_t launch_q_backward_mfma(const float* att, const float* P, const float* T, const int* rows, const int* n_rows,
                                   int n_nodes, float* qs, float* dqb, float* zb, float* dP, float* partial, int grid,
                                   hipStream_t s);
+#ifdef CBGX_XCHECK
 hipError_t launch_q_backward(const float* att, const float* P, const float* T, const int* rows, const int* n_rows,
                              int n_nodes, float* qs, float* dqb, float* zb, float* dP, float* partial, int grid,
                              hipStream_t s);
+#endif
+#ifdef CBGX_XCHECK
 hipError_t launch_outer_accum(bool headed, const float* Lm, const float* R, const int* rows, const int* n_rows,
                               int n_nodes, float* partial, size_t slab_stride, int grid, hipStream_t s);
+#endif
 hipError_t launch_colsum(const float* A, int lda, int cols, const float* scale, const int* rows, const int* n_rows_ptr,
                          int n_rows, float* partial, size_t slab_stride, int grid, hipStream_t s);
 // up to RS_MAX reduce_store pieces in one launch
@@ -82,7 +88,5 @@ hipError_t launch_gate_backward(const float* packed, const float* x, const int32
                                 const float* de_w, float* E8, float* partial, int grid, hipStream_t s);
 hipError_t launch_ssp_backward(const float* pre, const float* dact, long n, float* dpre, hipStream_t s);
 hipError_t launch_add_inplace(float* dst, const float* src, long n, hipStream_t s);
-// first-generation forward node kernels, used by the backward's recomputation (kernels_v1.hip)
-hipError_t launch_node_query_v1(const float* att, const float* P, float* Qt, int n_nodes, hipStream_t s);
 
 }  // namespace cbgx

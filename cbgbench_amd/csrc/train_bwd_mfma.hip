@@ -1037,7 +1037,12 @@ hipError_t launch_edge_backward_mfma(bool x2h, const float* att, const float* x,
                                      const int* n_rows, int n_nodes, float* T, float* S, float* sw, float* dP, float* dx,
                                      float* de_w, float* partial, int grid, hipStream_t s, int centred) {
     if ((long)n_nodes * HEADS * H >= (1L << 32)) return hipErrorInvalidValue;   // 32-bit element offsets inside the kernel
-    static const int abl = getenv("CBGX_BWD_ABL") ? atoi(getenv("CBGX_BWD_ABL")) : 0;   // timing ablations (wrong results)
+#ifdef CBGX_ABLATE
+    // timing ablations (WRONG results): only in libcbgx_ablate.so, built by scripts/abl_bwd.sh with -DCBGX_ABLATE
+    static const int abl = getenv("CBGX_BWD_ABL") ? atoi(getenv("CBGX_BWD_ABL")) : 0;
+#else
+    constexpr int abl = 0;
+#endif
     profile_mark_begin(x2h ? (rows ? K_EDGE_X2H_BWD_LISTED : K_EDGE_X2H_BWD) : K_EDGE_H2X_BWD, s);
     if (x2h)
         hipLaunchKernelGGL(edge_backward_mfma_kernel<true>, dim3(grid), dim3(BWD_THREADS), 0, s, att, x, P, Qt, Gt, gb,

@@ -1,0 +1,430 @@
+// libcbgx -- node-level helpers of the denoiser's backward (training): the fold of the
+// output gradient through the second v Linear, column sums, two-level slab reductions into the reference's tensor layouts,
+// a small SGEMM, the gate MLP's backward, ShiftedSoftplus' backward.  The fused edge backward and the MFMA node kernels live
+// in train_bwd_mfma.hip; the first-generation VALU kernels (test-only cross-check) in train_bwd_v1.hip.
+// Math follows the reference modules (autograd of x2h_attention.py:43-97, h2x_attention.py:34-73,
+// common.py:151-171); oracle/training.py + torch.autograd is the checker (tests/test_gpu_training.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "layout.h"
+#include "train.h"
+
+namespace cbgx {
+
+__constant__ float c_mu_b[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.75f, 3.f,
+                                3.5f, 4.f, 4.5f, 5.f, 5.5f, 6.f, 7.f, 8.f, 9.f, 10.f};
+
+
+
+// ------------------------------------------------------------------------------------------------
+// x2h: fold the output gradient through the second v Linear (the mirror image of the query fold):
+//   Gt[i][a][m] = sum_c G[i][8a+c] Wbv[8a+c][m],   gb[i][a] = sum_c G[i][8a+c] bbv[8a+c]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void fold_grad_kernel(const float* __restrict__ att, const float* __restrict__ Gr,
+                                                        int n_nodes, float* __restrict__ Gt, float* __restrict__ gb) {
+    __shared__ float sG[16][H];
+    const int row0 = blockIdx.x * 16, m = threadIdx.x;
+    for (int u = m; u < 16 * H; u += 128) {
+        const int r = u >> 7;
+        sG[r][u & 127] = row0 + r < n_nodes ? Gr[(size_t)(row0 + r) * H + (u & 127)] : 0.f;
+    }
+    __syncthreads();
+    for (int a = 0; a < HEADS; ++a) {
+        float w[DH];
+#pragma unroll
+        for (int cc = 0; cc < DH; ++cc) w[cc] = att[A_WBV + (size_t)m * H + a * DH + cc];   // x2h layout [m][n]
+        for (int r = 0; r < 16 && row0 + r < n_nodes; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < DH; ++cc) s = fmaf(sG[r][a * DH + cc], w[cc], s);
+            Gt[((size_t)(row0 + r) * HEADS + a) * H + m] = s;
+        }
+    }
+    if (m < HEADS) {
+        for (int r = 0; r < 16 && row0 + r < n_nodes; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < DH; ++cc) s = fmaf(sG[r][m * DH + cc], att[A_BBV + m * DH + cc], s);
+            gb[(size_t)(row0 + r) * HEADS + m] = s;
+        }
+    }
+}
+
+
+
+// column sums of A[rows, cols] (optionally of A[i][c] * scale[i][c >> 3]) -> one partial row per workgroup
+template <bool LISTED, bool SCALED>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int lda, int cols,
+                                                     const float* __restrict__ scale, const int* __restrict__ rows,
+                                                     const int* __restrict__ n_rows_ptr, int n_rows,
+                                                     float* __restrict__ partial, size_t slab_stride) {
+    const int count = LISTED ? *n_rows_ptr : n_rows;
+    for (int c0 = threadIdx.x; c0 < cols; c0 += 256) {
+        float acc = 0.f;
+        // eight rows per pass, loads unconditional (rows past the end read row 0 and are weighted by zero): predicated
+        // loads compile to one branch + wait per element and leave the kernel latency bound
+        for (int it = blockIdx.x; it < count; it += 8 * gridDim.x) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int itj = it + j * gridDim.x;
+                const bool ok = itj < count;
+                const int itc = ok ? itj : 0;
+                const int i = LISTED ? rows[itc] : itc;
+                v[j] = A[(size_t)i * lda + c0];
+                if (SCALED) v[j] *= scale[(size_t)i * HEADS + (c0 >> 3)];
+                v[j] = ok ? v[j] : 0.f;
+            }
+            acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        partial[(size_t)blockIdx.x * slab_stride + c0] = acc;
+    }
+}
+
+// first level of a two-level slab reduction: dst[g][c] = sum over slabs s = g (mod groups) of src[s][c]
+__global__ __launch_bounds__(256) void slab_fold_kernel(const float* __restrict__ src, int n_slabs, size_t slab_stride,
+                                                        int size, int groups, float* __restrict__ dst) {
+    const int c = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (c >= size) return;
+    float acc = 0.f;
+    for (int s = g; s < n_slabs; s += groups) acc += src[(size_t)s * slab_stride + c];
+    dst[(size_t)g * size + c] = acc;
+}
+
+// dst[r][c] (or dst[c][r] if transpose) = sum_s src[s * slab_stride + r * src_ld + c]
+__global__ void reduce_store_kernel(const float* __restrict__ src, int n_slabs, size_t slab_stride, int src_ld,
+                                    int rows, int cols, float* __restrict__ dst, int dst_ld, int transpose) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int r = idx / cols, c = idx % cols;
+    float acc = 0.f;
+    for (int s = 0; s < n_slabs; ++s) acc += src[(size_t)s * slab_stride + (size_t)r * src_ld + c];
+    if (transpose) dst[(size_t)c * dst_ld + r] = acc; else dst[(size_t)r * dst_ld + c] = acc;
+}
+
+// several reduce_store pieces in one launch (blockIdx.y = piece)
+__global__ void reduce_store_multi_kernel(RsBatch b) {
+    const RsPiece& pc = b.p[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= pc.rows * pc.cols) return;
+    const int r = idx / pc.cols, c = idx % pc.cols;
+    float acc = 0.f;
+    for (int s = 0; s < pc.n_slabs; ++s) acc += pc.src[(size_t)s * pc.stride + (size_t)r * pc.src_ld + c];
+    if (pc.transpose) pc.dst[(size_t)c * pc.dst_ld + r] = acc; else pc.dst[(size_t)r * pc.dst_ld + c] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic fp32 GEMM for the node-level products of the backward (sizes are small: N_nodes x 640 x 128):
+//   C[z] (+)= op(A) op(B) over the K range of split z.  64x64 tile, 256 threads, 4x4 per thread.
+// ------------------------------------------------------------------------------------------------
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                    int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
+                                                    int k_chunk, size_t c_split_stride, int accumulate) {
+    // 64 x 64 output tile per workgroup, K staged 16 at a time through LDS; wave (wr, wc) of the 2 x 2 wave grid owns a
+    // 32 x 32 sub-tile = 2 x 2 MFMA tiles (v_mfma_f32_16x16x4_f32: lane (li, kq) feeds A[row li][k kq], B[k kq][col li]).
+    __shared__ float sA[16][68];
+    __shared__ float sB[16][68];
+    const int bm = blockIdx.y * 64, bn = blockIdx.x * 64, z = blockIdx.z;
+    const int k0 = z * k_chunk, k1 = min(K, k0 + k_chunk);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    floatx4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (floatx4_t){0.f, 0.f, 0.f, 0.f};
+    for (int kb = k0; kb < k1; kb += 16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = threadIdx.x + 256 * r;
+            {
+                int row, kk;
+                if (!TA) { row = idx >> 4; kk = idx & 15; } else { kk = idx >> 6; row = idx & 63; }
+                const bool ok = bm + row < M && kb + kk < k1;
+                float v = 0.f;
+                if (ok) v = TA ? A[(size_t)(kb + kk) * lda + bm + row] : A[(size_t)(bm + row) * lda + kb + kk];
+                sA[kk][row] = v;
+            }
+            {
+                int col, kk;
+                if (!TB) { kk = idx >> 6; col = idx & 63; } else { col = idx >> 4; kk = idx & 15; }
+                const bool ok = bn + col < N && kb + kk < k1;
+                float v = 0.f;
+                if (ok) v = TB ? B[(size_t)(bn + col) * ldb + kb + kk] : B[(size_t)(kb + kk) * ldb + bn + col];
+                sB[kk][col] = v;
+            }
+        }
+        __syncthreads();
+        float a[4][2], b[4][2];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[kk][i] = sA[4 * kk + kq][32 * wr + 16 * i + li];
+                b[kk][i] = sB[4 * kk + kq][32 * wc + 16 * i + li];
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+    float* Cz = C + (size_t)z * c_split_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = bm + 32 * wr + 16 * i + 4 * kq + r, col = bn + 32 * wc + 16 * j + li;
+                if (row < M && col < N) {
+                    float* o = Cz + (size_t)row * ldc + col;
+                    *o = accumulate ? *o + acc[i][j][r] : acc[i][j][r];
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// distance gate backward (unitransformer.py:109-112): pass 1 per edge (scalars of the LayerNorm
+// backward), pass 2 per hidden unit (weight gradients).  The gate reads the *input* coordinates, which
+// are data, so no coordinate gradient is produced.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_bwd_edge_kernel(const float* __restrict__ wts, const float* __restrict__ x,
+                                                            const int32_t* __restrict__ nbr,
+                                                            const int32_t* __restrict__ deg, int n_nodes,
+                                                            const float* __restrict__ de_w, float* __restrict__ E8) {
+    __shared__ float sW1[GH * G];
+    __shared__ float sB1[GH], sG[GH], sBe[GH], sW2[GH];
+    for (int t = threadIdx.x; t < GH * G; t += blockDim.x) sW1[t] = wts[GATE_W1 + t];
+    for (int t = threadIdx.x; t < GH; t += blockDim.x) {
+        sB1[t] = wts[GATE_B1 + t]; sG[t] = wts[GATE_LNG + t]; sBe[t] = wts[GATE_LNB + t]; sW2[t] = wts[GATE_W2 + t];
+    }
+    __syncthreads();
+    const float b2 = wts[GATE_B2];
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)n_nodes * KNN) return;
+    const int i = (int)(e >> 5), s = (int)(e & 31);
+    float* o = E8 + (size_t)e * 8;
+    if (s >= deg[i]) { o[5] = 0.f; o[0] = 0.f; o[1] = 0.f; o[2] = 1.f; o[3] = 0.f; o[4] = 0.f; return; }
+    const int j = nbr[e];
+    const float dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+    const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+    float r[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { const float t = dist - c_mu_b[g]; r[g] = expf(-0.5f * (t * t)); }
+    float sum = 0.f;
+    for (int u = 0; u < GH; ++u) {
+        float y = sB1[u];
+#pragma unroll
+        for (int g = 0; g < G; ++g) y = fmaf(sW1[u * G + g], r[g], y);
+        sum += y;
+    }
+    const float mean = sum * (1.f / GH);
+    float var = 0.f;
+    for (int u = 0; u < GH; ++u) {
+        float y = sB1[u];
+#pragma unroll
+        for (int g = 0; g < G; ++g) y = fmaf(sW1[u * G + g], r[g], y);
+        var += (y - mean) * (y - mean);
+    }
+    const float rstd = 1.f / sqrtf(var * (1.f / GH) + 1e-5f);
+    float acc = b2;
+    for (int u = 0; u < GH; ++u) {
+        float y = sB1[u];
+#pragma unroll
+        for (int g = 0; g < G; ++g) y = fmaf(sW1[u * G + g], r[g], y);
+        acc = fmaf(sW2[u], fmaxf((y - mean) * rstd * sG[u] + sBe[u], 0.f), acc);
+    }
+    const float ew = 1.f / (1.f + expf(-acc));
+    const float dacc = de_w[e] * ew * (1.f - ew);
+    float s1 = 0.f, s2 = 0.f;
+    for (int u = 0; u < GH; ++u) {
+        float y = sB1[u];
+#pragma unroll
+        for (int g = 0; g < G; ++g) y = fmaf(sW1[u * G + g], r[g], y);
+        const float n = (y - mean) * rstd;
+        const float dn = (n * sG[u] + sBe[u] > 0.f) ? dacc * sW2[u] * sG[u] : 0.f;
+        s1 += dn;
+        s2 = fmaf(dn, n, s2);
+    }
+    o[0] = dist; o[1] = mean; o[2] = rstd; o[3] = s1 * (1.f / GH); o[4] = s2 * (1.f / GH); o[5] = dacc;
+}
+
+constexpr int GATE_TILE = 64;
+
+__global__ __launch_bounds__(GH) void gate_bwd_weight_kernel(const float* __restrict__ wts, const float* __restrict__ E8,
+                                                             long n_edges, float* __restrict__ partial) {
+    __shared__ float sR[GATE_TILE][G];
+    __shared__ float sE[GATE_TILE][8];
+    const int u = threadIdx.x;
+    float w1[G], aW1[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { w1[g] = wts[GATE_W1 + u * G + g]; aW1[g] = 0.f; }
+    const float b1 = wts[GATE_B1 + u], gam = wts[GATE_LNG + u], bet = wts[GATE_LNB + u], w2 = wts[GATE_W2 + u];
+    float aB1 = 0.f, aG = 0.f, aBe = 0.f, aW2 = 0.f, aB2 = 0.f;
+    const long tiles = (n_edges + GATE_TILE - 1) / GATE_TILE;
+    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const long e0 = tile * GATE_TILE;
+        __syncthreads();
+        for (int k = u; k < GATE_TILE * 8; k += GH) {
+            const long e = e0 + (k >> 3);
+            sE[k >> 3][k & 7] = e < n_edges ? E8[(size_t)e * 8 + (k & 7)] : 0.f;
+        }
+        __syncthreads();
+        for (int k = u; k < GATE_TILE * G; k += GH) {
+            const int ee = k / G, g = k % G;
+            const float t = sE[ee][0] - c_mu_b[g];
+            sR[ee][g] = expf(-0.5f * (t * t));
+        }
+        __syncthreads();
+        for (int ee = 0; ee < GATE_TILE; ++ee) {
+            const float dacc = sE[ee][5];
+            if (dacc == 0.f) continue;   // padded slot or zero upstream gradient (uniform across the workgroup)
+            float y = b1;
+#pragma unroll
+            for (int g = 0; g < G; ++g) y = fmaf(w1[g], sR[ee][g], y);
+            const float n = (y - sE[ee][1]) * sE[ee][2];
+            const float ya = n * gam + bet;
+            aW2 = fmaf(dacc, fmaxf(ya, 0.f), aW2);
+            aB2 += dacc;
+            const float dy = ya > 0.f ? dacc * w2 : 0.f;
+            aG = fmaf(dy, n, aG);
+            aBe += dy;
+            const float dn = dy * gam;
+            const float dp = sE[ee][2] * (dn - sE[ee][3] - n * sE[ee][4]);
+            aB1 += dp;
+#pragma unroll
+            for (int g = 0; g < G; ++g) aW1[g] = fmaf(dp, sR[ee][g], aW1[g]);
+        }
+    }
+    float* slab = partial + (size_t)blockIdx.x * GB_SIZE;
+#pragma unroll
+    for (int g = 0; g < G; ++g) slab[GB_W1 + u * G + g] = aW1[g];
+    slab[GB_B1 + u] = aB1;
+    slab[GB_LNG + u] = aG;
+    slab[GB_LNB + u] = aBe;
+    slab[GB_W2 + u] = aW2;
+    if (u == 0) slab[GB_B2] = aB2;
+}
+
+// classifier: d(pre) = d(act) * sigmoid(pre)   (derivative of softplus(x) - ln 2)
+__global__ void ssp_backward_kernel(const float* __restrict__ pre, const float* __restrict__ dact, long n,
+                                    float* __restrict__ dpre) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) dpre[idx] = dact[idx] / (1.f + expf(-pre[idx]));
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) dst[idx] += src[idx];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+#define CBGX_LAUNCH_CHECK()                            \
+    do {                                               \
+        hipError_t _e = hipGetLastError();             \
+        if (_e != hipSuccess) return _e;               \
+    } while (0)
+
+
+hipError_t launch_fold_grad(const float* att, const float* Gr, int n_nodes, float* Gt, float* gb, hipStream_t s) {
+    hipLaunchKernelGGL(fold_grad_kernel, dim3((n_nodes + 15) / 16), dim3(128), 0, s, att, Gr, n_nodes, Gt, gb);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+
+
+hipError_t launch_colsum(const float* A, int lda, int cols, const float* scale, const int* rows, const int* n_rows_ptr,
+                         int n_rows, float* partial, size_t slab_stride, int grid, hipStream_t s) {
+#define CBGX_COLSUM(L, S)                                                                                             \
+    hipLaunchKernelGGL((colsum_kernel<L, S>), dim3(grid), dim3(256), 0, s, A, lda, cols, scale, rows, n_rows_ptr, n_rows, \
+                       partial, slab_stride)
+    if (rows) { if (scale) CBGX_COLSUM(true, true); else CBGX_COLSUM(true, false); }
+    else      { if (scale) CBGX_COLSUM(false, true); else CBGX_COLSUM(false, false); }
+#undef CBGX_COLSUM
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_slab_fold(const float* src, int n_slabs, size_t slab_stride, int size, int groups, float* dst,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(slab_fold_kernel, dim3((size + 255) / 256, groups), dim3(256), 0, s, src, n_slabs, slab_stride, size,
+                       groups, dst);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_reduce_store(const float* src, int n_slabs, size_t slab_stride, int src_ld, int rows, int cols,
+                               float* dst, int dst_ld, int transpose, hipStream_t s) {
+    const int total = rows * cols;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(reduce_store_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, n_slabs, slab_stride, src_ld,
+                       rows, cols, dst, dst_ld, transpose);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_reduce_store_multi(const RsBatch& b, hipStream_t s) {
+    if (b.n == 0) return hipSuccess;
+    int mx = 0;
+    for (int k = 0; k < b.n; ++k) mx = b.p[k].rows * b.p[k].cols > mx ? b.p[k].rows * b.p[k].cols : mx;
+    hipLaunchKernelGGL(reduce_store_multi_kernel, dim3((mx + 255) / 256, b.n), dim3(256), 0, s, b);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_sgemm(bool ta, bool tb, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
+                        int N, int K, int splits, size_t c_split_stride, int accumulate, hipStream_t s) {
+    if (M == 0 || N == 0) return hipSuccess;
+    if (splits < 1) splits = 1;
+    int k_chunk = (K + splits - 1) / splits;
+    k_chunk = (k_chunk + 15) / 16 * 16;
+    dim3 grid((N + 63) / 64, (M + 63) / 64, splits), block(256);
+    profile_mark_begin(K_TRAIN_GEMM, s);
+    if (!ta && !tb) hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, k_chunk, c_split_stride, accumulate);
+    else if (!ta && tb) hipLaunchKernelGGL((sgemm_kernel<false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, k_chunk, c_split_stride, accumulate);
+    else if (ta && !tb) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, k_chunk, c_split_stride, accumulate);
+    else hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, k_chunk, c_split_stride, accumulate);
+    profile_mark_end(s);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_gate_backward(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
+                                const float* de_w, float* E8, float* partial, int grid, hipStream_t s) {
+    const long total = (long)n_nodes * KNN;
+    hipLaunchKernelGGL(gate_bwd_edge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, packed, x, nbr, deg,
+                       n_nodes, de_w, E8);
+    CBGX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gate_bwd_weight_kernel, dim3(grid), dim3(GH), 0, s, packed, E8, total, partial);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_ssp_backward(const float* pre, const float* dact, long n, float* dpre, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(ssp_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, dact, n, dpre);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_add_inplace(float* dst, const float* src, long n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, src, n);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+}  // namespace cbgx

@@ -11,6 +11,14 @@
  * re-entrant, keeps no pointer after it returns and never frees or allocates
  * device memory: the caller owns inputs, outputs and the workspace.
  *
+ * The only state the library owns, besides the optional profiling hook at the end of this file:
+ * one auxiliary non-blocking HIP stream and two events per HOST THREAD (created on the first multi-layer
+ * forward of that thread, never destroyed).  cbgx_unitransformer_forward{,_cached} fork the node stage of
+ * layer l+1 onto it next to the h2x block of layer l and join it back before returning work to `stream`, so
+ * from the caller's point of view everything is still ordered on `stream` (hipGraph capture of `stream`
+ * records the fork/join).  One device per host thread (the one-process-per-GPU model): a thread that switches
+ * devices falls back to the serial schedule.  CBGX_OVERLAP=0 in the environment disables the auxiliary stream.
+ *
  * Return value: 0 on success, negative CBGX_E_* on failure (never abort());
  * cbgx_last_error() gives a thread-local message.
  *
@@ -246,12 +254,6 @@ int cbgx_h2x_stack_backward(const float *packed, int num_layers, const void *tap
 #define CBGX_PROFILE_CLASSES 11
 int cbgx_profile_begin(int max_launches);
 int cbgx_profile_end(double *ms_by_class, int *launches_by_class, int num_classes);
-
-/* ---- cross-check hook (tests only) ---------------------------------------------------------------
- * The library carries two generations of the fused edge kernels: 0 = MFMA (default, edge_mfma.hip) and
- * 1 = the first-generation VALU kernels kept as an on-device cross-check for sizes the CPU oracle cannot
- * reach.  Returns the previous setting (>= 0) or CBGX_E_INVALID.  Process-wide. */
-int cbgx_debug_set_edge_kernel(int impl);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,9 @@
 #!/bin/bash
 # timing ablations of the MFMA edge backward kernel (CBGX_BWD_ABL bits: 1 no neighbour atomics, 2 no neighbour
-# gathers, 4 no rbf-column / rbf gradient MFMAs, 8 no softmax, 16 no T/S stores).  Results are WRONG by design.
+# gathers, 4 no rbf-column / rbf gradient MFMAs, 8 no softmax, 16 no T/S stores).  Results are WRONG by design, so the
+# switch exists only in a separate build: libcbgx_ablate.so (-DCBGX_ABLATE), selected through CBGX_LIBRARY.
+python -c "from cbgbench_amd.build import build_native; print(build_native(ablate=True))" || exit 1
+export CBGX_LIBRARY=$(pwd)/cbgbench_amd/lib/libcbgx_ablate.so
 for a in 0 1 2 4 8 16 31; do
   CBGX_BWD_ABL=$a python bench.py --workload train --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import json,sys

@@ -27,8 +27,8 @@ sd = W.synthetic_state_dict(13, 9, seed=0)
 
 
 def gpu_grads(impl):
-    old = _native.lib().cbgx_debug_set_edge_kernel(impl)
-    try:
+    import contextlib
+    with (_native.first_generation_kernels() if impl else contextlib.nullcontext()):
         m = C.get_model(C.default_targetdiff_config(13))
         m.load_state_dict(sd, strict=True)
         m = m.to(dev).train()
@@ -36,8 +36,6 @@ def gpu_grads(impl):
         (1.0 * ld["pos"] + 100.0 * ld["atom"]).backward()
         torch.cuda.synchronize()
         return {k: p.grad.detach().cpu().double() for k, p in m.named_parameters() if p.requires_grad}
-    finally:
-        _native.lib().cbgx_debug_set_edge_kernel(old)
 
 
 ref = None

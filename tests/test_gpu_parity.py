@@ -74,9 +74,11 @@ def test_knn_large_graphs_bitexact(sizes):
 def edge_impl(request):
     """Both generations of the fused edge kernels are checked against the reference."""
     from cbgbench_amd import _native
-    old = _native.lib().cbgx_debug_set_edge_kernel(request.param)
-    yield request.param
-    _native.lib().cbgx_debug_set_edge_kernel(old)
+    if request.param == 0:
+        yield 0                                         # libcbgx.so: the product path
+    else:
+        with _native.first_generation_kernels():        # libcbgx_xcheck.so (test-only): first-generation VALU kernels
+            yield 1
 
 
 @pytest.mark.parametrize("case", DENOISER_CASES)
@@ -300,12 +302,8 @@ def test_linker_256_graphs_runs_and_freezes_context(model):
     assert bool((xo[gen] != x[gen]).any())
     # the whole batch against the first-generation VALU kernels on the device (independent implementation)
     from cbgbench_amd import _native
-    old = _native.lib().cbgx_debug_set_edge_kernel(1)
-    try:
-        with torch.no_grad():
-            xv, hv, lv = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
-    finally:
-        _native.lib().cbgx_debug_set_edge_kernel(old)
+    with _native.first_generation_kernels(), torch.no_grad():
+        xv, hv, lv = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
     close(xo, xv, "x_out mfma vs valu kernels (256 graphs)")
     close(ho, hv, "h_out mfma vs valu kernels (256 graphs)", scale=10.0)
     assert torch.equal(lo[lig_flag].argmax(-1), lv[lig_flag].argmax(-1))

@@ -133,12 +133,22 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name)
     assert lib.cbgx_abi_version() == 1
+    # the product library carries no debug switch and none of the first-generation kernels; the test-only build has both
+    import subprocess
+    assert not hasattr(lib, "cbgx_debug_set_edge_kernel")
+    from cbgbench_amd.build import LIBPATH, XCHECK_LIBPATH
+    sym = subprocess.run(["nm", "-D", "--defined-only", LIBPATH], capture_output=True, text=True).stdout
+    assert "cbgx_debug" not in sym and "_v1" not in sym and "edge_attention_kernel" not in sym
+    xhdr = open(os.path.join(ROOT, "include", "cbgx_xcheck.h")).read()
+    assert set(re.findall(r"\b(cbgx_[a-z0-9_]+)\s*\(", xhdr)) == {"cbgx_debug_set_edge_kernel"}
+    xsym = subprocess.run(["nm", "-D", "--defined-only", XCHECK_LIBPATH], capture_output=True, text=True).stdout
+    for name in declared | {"cbgx_debug_set_edge_kernel"}:
+        assert f" {name}\n" in xsym, name
 
 
 def test_abi_argument_errors_without_gpu():
     lib = _native.lib()
     assert lib.cbgx_packed_weights_floats(9, 13) >= 2666014   # at least every denoiser parameter
-    assert lib.cbgx_debug_set_edge_kernel(7) == -1
     assert lib.cbgx_workspace_bytes(425, 1) > 425 * (640 + 16 * 128) * 4
     one = ctypes.c_void_p(16)  # never dereferenced: argument checks come first
     assert lib.cbgx_knn_graph(one, one, 1, 10, 16, one, one, None) == -1

@@ -45,17 +45,19 @@ def find(res, *needles):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
 def test_forward_edge_kernels_fit_their_budget(tmp_path):
     res, text = kernel_resources("edge_mfma.hip", tmp_path)
-    # edge_mfma_kernel<X2H, WAVES = 8, ABL = 0, LISTED>: the three variants the product launches
-    x2h = find(res, "edge_mfma_kernelILb1ELi8ELi0ELb0E")
-    x2h_listed = find(res, "edge_mfma_kernelILb1ELi8ELi0ELb1E")
-    h2x_listed = find(res, "edge_mfma_kernelILb0ELi8ELi0ELb1E")
+    # edge_mfma_kernel<X2H, WAVES = 8, LISTED>: the three variants the product launches
+    x2h = find(res, "edge_mfma_kernelILb1ELi8ELb0E")
+    x2h_listed = find(res, "edge_mfma_kernelILb1ELi8ELb1E")
+    h2x_listed = find(res, "edge_mfma_kernelILb0ELi8ELb1E")
     for k in (x2h, x2h_listed):
         assert k["scratch"] == 0 and k["vgpr"] <= 256          # 8 waves per CU = 2 per SIMD need <= 256 registers
         assert k["lds"] <= 160 * 1024
-    assert h2x_listed["scratch"] <= 32 and h2x_listed["vgpr"] <= 256
+    # no spill anywhere: a scratch reload is a VMEM operation, and the `s_waitcnt vmcnt(0)` in front of its first use would
+    # drain every gather the kernel has just put in flight (that is how 24 spilled registers cost 7 % in round 2)
+    assert h2x_listed["scratch"] == 0 and h2x_listed["vgpr"] <= 256
     # the elementwise parts run packed (two fp32 per issue slot) and on the 1-ulp hardware approximations
     assert text.count("v_pk_fma_f32") > 300 and "v_rsq_f32" in text and "v_exp_f32" in text
-    start = re.search(r"^_ZN4cbgx16edge_mfma_kernelILb1ELi8ELi0ELb0E\S*:", text, flags=re.M).start()
+    start = re.search(r"^_ZN4cbgx16edge_mfma_kernelILb1ELi8ELb0E\S*:", text, flags=re.M).start()
     body = text[start:text.index(".end_amdhsa_kernel", start)]          # label .. descriptor of the main x2h kernel
     assert len(body.splitlines()) > 2000
     assert "v_div_fmas_f32" not in body
