@@ -327,6 +327,23 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
         for (int t = 0; t < 8; ++t) { acc0[t] = f4(pd[t]) + f4(ps0[t]); acc1[t] = f4(pd[t]) + f4(ps1[t]); }
         __builtin_amdgcn_sched_barrier(0);
+        // (a) next item: id, degree, flag, position, neighbour ids in both mappings.  The last iteration re-requests its own
+        // node (every prefetch below is unconditional: no divergent joins for the register allocator, no predicated loads).
+        // Issued BEFORE this node's gathers: vmcnt retires in order, so waiting for these few words later (b) leaves the
+        // gathers in flight, while the other order would drain them.  The values stay in vector registers until (b).
+        ItemGeom ng;
+        const int inext = __builtin_amdgcn_readfirstlane(more ? (act ? act[k + i_step] : k + i_step) : i);
+        ng.node = inext;
+        const int nd_raw = deg[inext];
+        const int nlig_raw = ldob(sbase(lig), vop((unsigned)inext));
+        const gptr xrow = sbase(x + 3 * (size_t)inext);
+        const unsigned ozero = vop(0u);
+        const float nx_raw = ldo1(xrow, ozero), ny_raw = ldo1(xrow, ozero + 4), nz_raw = ldo1(xrow, ozero + 8);
+        const gptr nrow = sbase(nbr + (size_t)inext * KNN);
+        const unsigned oc = vop(4 * c), oq = vop(16 * q);
+        const int nr0 = ldoi(nrow, oc), nr1 = ldoi(nrow, oc + 64);
+        const int4 nnb0 = ldoi4(nrow, oq), nnb1 = ldoi4(nrow, oq + 64);
+        __builtin_amdgcn_sched_barrier(0);
         // this node's folded query row (B operand of the score MFMAs): consumed after the first pre-activation block
         float4 qrow[8];
         {
@@ -335,8 +352,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
             for (int t = 0; t < 8; ++t) qrow[t] = ldo4(qp, oqr + 64 * t);
         }
-        // x2h: PS_v rows (channel-major gather, E1 mapping) of half 0, needed two MFMA blocks from here
+        // x2h: PS_v rows (channel-major gather, E1 mapping) of half 0 and this node's own PD_v, needed two MFMA blocks from here
         float4 sva[2][4], svb[2][4];
+        float4 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
         if (X2H) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -344,18 +362,11 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                 sva[0][r] = ldo4(sbase(P), o);
                 svb[0][r] = ldo4(sbase(P), o + 256);
             }
+            const gptr pvp = sbase(P + (size_t)i * PROW);
+            const unsigned ocv = vop((H + 4 * c) * 4);
+            pa = ldo4(pvp, ocv);
+            pb = ldo4(pvp, ocv + 256);
         }
-        // (a) next item: id, degree, flag, position, neighbour ids in both mappings.  The last iteration re-requests its own
-        // node (every prefetch below is unconditional: no divergent joins for the register allocator, no predicated loads)
-        ItemGeom ng;
-        const int inext = __builtin_amdgcn_readfirstlane(more ? (act ? act[k + i_step] : k + i_step) : i);
-        ng.node = inext;
-        ng.d = deg[inext]; ng.lig_i = lig[inext];
-        ng.xi = x[3 * inext]; ng.yi = x[3 * inext + 1]; ng.zi = x[3 * inext + 2];
-        const gptr nrow = sbase(nbr + (size_t)inext * KNN);
-        const unsigned oc = vop(4 * c), oq = vop(16 * q);
-        const int nr0 = ldoi(nrow, oc), nr1 = ldoi(nrow, oc + 64);
-        const int4 nnb0 = ldoi4(nrow, oq), nnb1 = ldoi4(nrow, oq + 64);
         __builtin_amdgcn_sched_barrier(0);
         float R[2][5];
 #pragma unroll
@@ -379,24 +390,16 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         sc[0] = edge_major_half<true>(acc0, lg0[0], 0, lds_fk, lds_dwt, lds_ln, R[0], has_prot, has_lig, lig_i, lane, q,
                                       (gptr)0, 0u, qrow);
         __builtin_amdgcn_sched_barrier(0);
-        // second half of the PS_v gather and the gate values; (b) next item: resolve its neighbour ids (they arrived during
-        // the first half), request their flags and coordinates
-        float4 ew0 = {0.f, 0.f, 0.f, 0.f}, ew1 = {0.f, 0.f, 0.f, 0.f};
-        if (X2H) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned o = (unsigned)g.jv[1][r] * (PROW * 4) + (3 * H + 4 * c) * 4;
-                sva[1][r] = ldo4(sbase(P), o);
-                svb[1][r] = ldo4(sbase(P), o + 256);
-            }
-        }
-        const gptr ewp = sbase(e_w + (size_t)i * KNN);
-        const unsigned oqe = vop(16 * q);
-        ew0 = ldo4(ewp, oqe);
-        ew1 = ldo4(ewp, oqe + 64);
+        // (b) next item: resolve its neighbour ids (they arrived during the first half), request their flags and
+        // coordinates; then the second half of the PS_v gather and the gate values
         int nlj[2];
         float nxj[2][3];
         {
+            ng.d = __builtin_amdgcn_readfirstlane(nd_raw);
+            ng.lig_i = __builtin_amdgcn_readfirstlane(nlig_raw);
+            ng.xi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(nx_raw)));
+            ng.yi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ny_raw)));
+            ng.zi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(nz_raw)));
             ng.j0[0] = c < ng.d ? nr0 : inext;
             ng.j0[1] = c + 16 < ng.d ? nr1 : inext;
             const int nbv[2][4] = {{nnb0.x, nnb0.y, nnb0.z, nnb0.w}, {nnb1.x, nnb1.y, nnb1.z, nnb1.w}};
@@ -411,6 +414,19 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                 nxj[hf][0] = ldo1(sbase(x), 12u * j); nxj[hf][1] = ldo1(sbase(x), 12u * j + 4); nxj[hf][2] = ldo1(sbase(x), 12u * j + 8);
             }
         }
+        float4 ew0 = {0.f, 0.f, 0.f, 0.f}, ew1 = {0.f, 0.f, 0.f, 0.f};
+        if (X2H) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned o = (unsigned)g.jv[1][r] * (PROW * 4) + (3 * H + 4 * c) * 4;
+                sva[1][r] = ldo4(sbase(P), o);
+                svb[1][r] = ldo4(sbase(P), o + 256);
+            }
+        }
+        const gptr ewp = sbase(e_w + (size_t)i * KNN);
+        const unsigned oqe = vop(16 * q);
+        ew0 = ldo4(ewp, oqe);
+        ew1 = ldo4(ewp, oqe + 64);
         __builtin_amdgcn_sched_barrier(0);
         sc[1] = edge_major_half<true>(acc1, lg0[1], 0, lds_fk, lds_dwt, lds_ln, R[1], has_prot, has_lig, lig_i, lane, q,
                                       (gptr)0, 0u, qrow);
@@ -466,9 +482,6 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             floatx4 s2[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) s2[t] = floatx4{0.f, 0.f, 0.f, 0.f};
-            const gptr pvp = sbase(P + (size_t)i * PROW);
-            const unsigned ocv = vop((H + 4 * c) * 4);
-            const float4 pa = ldo4(pvp, ocv), pb = ldo4(pvp, ocv + 256);
             const float pdv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
             const float4 ga = ld4(lds_ln + 2 * H + 4 * c), gb = ld4(lds_ln + 2 * H + 64 + 4 * c);
             const float4 ba = ld4(lds_ln + 3 * H + 4 * c), bb = ld4(lds_ln + 3 * H + 64 + 4 * c);
