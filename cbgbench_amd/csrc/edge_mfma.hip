@@ -4,6 +4,9 @@
 // keeps the layer's rbf weight fragments (and, for x2h, the second v Linear) in LDS and loops over nodes.
 //
 //   pre[e][m] = PD[i][m] + PS[j_e][m] + dWt[e][m] + sum_g Wr[type_e][g][m] rbf_g(|x_i - x_j|)     (k and v)
+//               the rbf sum was 160 of the node's 288 fp32 MFMAs; it runs on the f16 matrix pipe in split-f16 arithmetic
+//               (weights and rbf values as hi + lo f16 pairs, three products per term, fp32 accumulate: 2^-22 relative, see
+//               rbf_tuples) -- 128 v_mfma_f32_16x16x16_f16 of half the issue time each, with the same LDS footprint
 //   hid       = ReLU(LayerNorm(pre))
 //   score[e][a] = Qt[i][a] . hid_k[e]          (the key's 2nd Linear and 1/sqrt(8) are folded into Qt)
 //   alpha     = softmax over the node's incoming edges, per head
@@ -37,6 +40,9 @@ __constant__ float c_mu[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.
                               3.5f, 4.f, 4.5f, 5.f, 5.5f, 6.f, 7.f, 8.f, 9.f, 10.f};
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// split-f16 rbf pre-activation (protein destinations): v_mfma_f32_16x16x16_f16, four f16 per lane and operand
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+#define MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16((a), (b), (c), 0, 0, 0)
 
 // ---- cross-lane reductions without LDS traffic -----------------------------------------------------
 // within a 16-lane row: DPP quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror (every lane gets the sum)
@@ -135,6 +141,36 @@ __device__ __forceinline__ float edge_len(float xi, float yi, float zi, float xj
     const float rx = xi - xj, ry = yi - yj, rz = zi - zj;
     return fast_sqrt(__builtin_fmaf(rx, rx, __builtin_fmaf(ry, ry, rz * rz)));
 }
+// The five rbf values of a lane (g = 4s + q, already masked to this pass's source class) as the four f16 tuples that pair
+// with the weight tuples T1, T1, T2, T3 (load_wtuples below):  [rh0..3]  [rl0..3]  [rh4 rh0 rh1 rh2]  [rh3 rh4 rl4 0]
+// (rh = f16(r) round to nearest, rl = f16(r - rh); the dropped rl * wl term is 2^-22 relative)
+__device__ __forceinline__ void rbf_tuples(const float (&R)[5], half4 (&B)[4]) {
+    _Float16 h[5], l[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        h[s] = (_Float16)R[s];
+        l[s] = (_Float16)(R[s] - (float)h[s]);
+    }
+    B[0] = half4{h[0], h[1], h[2], h[3]};
+    B[1] = half4{l[0], l[1], l[2], l[3]};
+    B[2] = half4{h[4], h[0], h[1], h[2]};
+    B[3] = half4{h[3], h[4], l[4], (_Float16)0.f};
+}
+// The weight pieces of (type, tile) for this lane: T1 = (d0, d1) = [h0 h1 h2 h3], T2 = (d2, d3) = [h4 l0 l1 l2],
+// T3 = (d4, d2) = [l3 l4 h4 l0] -- d2 is read twice, so the table needs no duplicate and is exactly as large as the five
+// fp32 fragments it replaces.  blk = lds_frag + (type * 8 + t) * FRAG_BLK.
+struct WTuples { half4 t1, t2, t3; };
+__device__ __forceinline__ WTuples load_wtuples(const float* blk, int lane) {
+    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+    WTuples w;
+    w.t1 = *reinterpret_cast<const half4*>(blk + 2 * lane);
+    w.t2 = *reinterpret_cast<const half4*>(blk + 128 + 2 * lane);
+    const unsigned d4 = *reinterpret_cast<const unsigned*>(blk + 256 + lane);
+    const unsigned d2 = *reinterpret_cast<const unsigned*>(blk + 128 + 2 * lane);
+    const uint2v p = {d4, d2};
+    w.t3 = __builtin_bit_cast(half4, p);
+    return w;
+}
 // edge type, unitransformer.py:92-97: (src lig, dst lig)->0, (lig, prot)->1, (prot, lig)->2, (prot, prot)->3
 __device__ __forceinline__ int etype(bool src_lig, int lig_i) { return src_lig ? (lig_i ? 0 : 1) : (lig_i ? 2 : 3); }
 
@@ -158,14 +194,21 @@ __device__ __forceinline__ floatx4 edge_major_half(floatx4 (&acc)[8], bool lg, i
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         if (p == 0 ? !has_prot : !has_lig) continue;  // wave-uniform
-        const float* fa = lds_frag + (size_t)etype(p == 1, lig_i) * (8 * 5 * 64) + lane;
         float Rm[5];
 #pragma unroll
         for (int s = 0; s < 5; ++s) Rm[s] = (lg == (p == 1)) ? R[s] : 0.f;
+        // split-f16 on the f16 matrix pipe, weight tuples as the A operand; two tiles at a time
+        half4 B[4];
+        rbf_tuples(Rm, B);
+        const float* fa = lds_frag + (size_t)etype(p == 1, lig_i) * (8 * FRAG_BLK);
 #pragma unroll
-        for (int s = 0; s < 5; ++s)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) acc[t] = MFMA(fa[(t * 5 + s) * 64], Rm[s], acc[t]);
+        for (int tg = 0; tg < 8; tg += 2) {
+            const WTuples w0 = load_wtuples(fa + (tg + 0) * FRAG_BLK, lane), w1 = load_wtuples(fa + (tg + 1) * FRAG_BLK, lane);
+            acc[tg] = MFMAH(w0.t1, B[0], acc[tg]);         acc[tg + 1] = MFMAH(w1.t1, B[0], acc[tg + 1]);
+            acc[tg] = MFMAH(w0.t1, B[1], acc[tg]);         acc[tg + 1] = MFMAH(w1.t1, B[1], acc[tg + 1]);
+            acc[tg] = MFMAH(w0.t2, B[2], acc[tg]);         acc[tg + 1] = MFMAH(w1.t2, B[2], acc[tg + 1]);
+            acc[tg] = MFMAH(w0.t3, B[3], acc[tg]);         acc[tg + 1] = MFMAH(w1.t3, B[3], acc[tg + 1]);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the tail's operand loads (g, b, B row) below the MFMA block
     // LayerNorm: the first Linear is centred, so mean(pre) == 0 and var = mean(pre^2)
@@ -204,8 +247,9 @@ struct ItemGeom {
     int node, d, lig_i;
     float xi, yi, zi;
     int j0[2];          // E0 neighbour ids
-    int jv[2][4];       // E1 neighbour ids
 };
+// E1 neighbour id of slot r of a half: the raw row entry (-1 padded) or the node itself
+__device__ __forceinline__ int e1_id(int raw, int e, int d, int self) { return e < d ? raw : self; }
 
 // LISTED: the launch iterates over a device-side node list (h2x always; x2h in the pruned last layers) -- a separate
 // instantiation so that profilers report full-graph and listed launches under different kernel names.
@@ -287,6 +331,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     bool lg0[2];
     float dist0[2];
     float4 pd[8], ps0[8], ps1[8];
+    int4 nb0, nb1;      // this node's neighbour row in the E1 mapping (raw, -1 padded): requested with the rows above
     {
         const int i = __builtin_amdgcn_readfirstlane(act ? act[i_begin] : i_begin);
         g.node = i;
@@ -295,14 +340,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         const gptr nrow = sbase(nbr + (size_t)i * KNN);
         const unsigned oc = vop(4 * c), oq = vop(16 * q);
         const int r0 = ldoi(nrow, oc), r1 = ldoi(nrow, oc + 64);
-        const int4 nb0 = ldoi4(nrow, oq), nb1 = ldoi4(nrow, oq + 64);
+        nb0 = ldoi4(nrow, oq); nb1 = ldoi4(nrow, oq + 64);
         g.j0[0] = c < g.d ? r0 : i;
         g.j0[1] = c + 16 < g.d ? r1 : i;
-        const int nbv[2][4] = {{nb0.x, nb0.y, nb0.z, nb0.w}, {nb1.x, nb1.y, nb1.z, nb1.w}};
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) g.jv[hf][r] = 4 * q + r + 16 * hf < g.d ? nbv[hf][r] : i;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int j = g.j0[hf];
@@ -340,9 +380,8 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         const unsigned ozero = vop(0u);
         const float nx_raw = ldo1(xrow, ozero), ny_raw = ldo1(xrow, ozero + 4), nz_raw = ldo1(xrow, ozero + 8);
         const gptr nrow = sbase(nbr + (size_t)inext * KNN);
-        const unsigned oc = vop(4 * c), oq = vop(16 * q);
+        const unsigned oc = vop(4 * c);
         const int nr0 = ldoi(nrow, oc), nr1 = ldoi(nrow, oc + 64);
-        const int4 nnb0 = ldoi4(nrow, oq), nnb1 = ldoi4(nrow, oq + 64);
         __builtin_amdgcn_sched_barrier(0);
         // this node's folded query row (B operand of the score MFMAs): consumed after the first pre-activation block
         float4 qrow[8];
@@ -356,9 +395,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         float4 sva[2][4], svb[2][4];
         float4 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
         if (X2H) {
+            const int nbv[4] = {nb0.x, nb0.y, nb0.z, nb0.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const unsigned o = (unsigned)g.jv[0][r] * (PROW * 4) + (3 * H + 4 * c) * 4;
+                const unsigned o = (unsigned)e1_id(nbv[r], 4 * q + r, d, i) * (PROW * 4) + (3 * H + 4 * c) * 4;
                 sva[0][r] = ldo4(sbase(P), o);
                 svb[0][r] = ldo4(sbase(P), o + 256);
             }
@@ -402,11 +442,6 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             ng.zi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(nz_raw)));
             ng.j0[0] = c < ng.d ? nr0 : inext;
             ng.j0[1] = c + 16 < ng.d ? nr1 : inext;
-            const int nbv[2][4] = {{nnb0.x, nnb0.y, nnb0.z, nnb0.w}, {nnb1.x, nnb1.y, nnb1.z, nnb1.w}};
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ng.jv[hf][r] = 4 * q + r + 16 * hf < ng.d ? nbv[hf][r] : inext;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int j = ng.j0[hf];
@@ -416,9 +451,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         }
         float4 ew0 = {0.f, 0.f, 0.f, 0.f}, ew1 = {0.f, 0.f, 0.f, 0.f};
         if (X2H) {
+            const int nbv[4] = {nb1.x, nb1.y, nb1.z, nb1.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const unsigned o = (unsigned)g.jv[1][r] * (PROW * 4) + (3 * H + 4 * c) * 4;
+                const unsigned o = (unsigned)e1_id(nbv[r], 4 * q + r + 16, d, i) * (PROW * 4) + (3 * H + 4 * c) * 4;
                 sva[1][r] = ldo4(sbase(P), o);
                 svb[1][r] = ldo4(sbase(P), o + 256);
             }
@@ -465,6 +501,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         const float ew[2][4] = {{ew0.x, ew0.y, ew0.z, ew0.w}, {ew1.x, ew1.y, ew1.z, ew1.w}};
         __builtin_amdgcn_sched_barrier(0);
 
+        int4 nnb0, nnb1;   // next node's neighbour row in the E1 mapping, requested before the epilogue
         if (X2H) {
             float w[2][4];
             float sw = 0.f;
@@ -519,14 +556,21 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     if (p == 0 ? !has_prot : !has_lig) continue;
-                    const float* fb = lds_fv + (size_t)etype(p == 1, lig_i) * (8 * 5 * 64) + lane;
                     float Rm[5];
 #pragma unroll
                     for (int s = 0; s < 5; ++s) Rm[s] = (lg0[hf] == (p == 1)) ? R[hf][s] : 0.f;
+                    // split-f16, rbf tuples as the A operand, weight tuples as B
+                    half4 A[4];
+                    rbf_tuples(Rm, A);
+                    const float* fb = lds_fv + (size_t)etype(p == 1, lig_i) * (8 * FRAG_BLK);
 #pragma unroll
-                    for (int s = 0; s < 5; ++s)
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) hv[t] = MFMA(Rm[s], fb[(t * 5 + s) * 64], hv[t]);
+                    for (int tg = 0; tg < 8; tg += 2) {
+                        const WTuples w0 = load_wtuples(fb + (tg + 0) * FRAG_BLK, lane), w1 = load_wtuples(fb + (tg + 1) * FRAG_BLK, lane);
+                        hv[tg] = MFMAH(A[0], w0.t1, hv[tg]);         hv[tg + 1] = MFMAH(A[0], w1.t1, hv[tg + 1]);
+                        hv[tg] = MFMAH(A[1], w0.t1, hv[tg]);         hv[tg + 1] = MFMAH(A[1], w1.t1, hv[tg + 1]);
+                        hv[tg] = MFMAH(A[2], w0.t2, hv[tg]);         hv[tg + 1] = MFMAH(A[2], w1.t2, hv[tg + 1]);
+                        hv[tg] = MFMAH(A[3], w0.t3, hv[tg]);         hv[tg + 1] = MFMAH(A[3], w1.t3, hv[tg + 1]);
+                    }
                 }
                 // LayerNorm per edge r (zero mean by construction): in-lane over t, across the 16 lanes of the row
                 {   // edges r and r + 1 share the packed instructions
@@ -566,11 +610,17 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
                 for (int t = 0; t < 8; ++t) ps1[t] = ldo4(sbase(P), o1 + 64 * t);
             }
-            // residual row and bias of this lane's two outputs: requested here, used after the Wbv products
+            // residual row and bias of this lane's two outputs: requested here, used after the Wbv products; then the next
+            // node's neighbour row in the E1 mapping (last in the queue: it is only needed at the top of the next iteration)
             const int n0 = 8 * c + 2 * q;
             const unsigned on0 = vop(n0 * 4);
             const float2 hres = ldo2(sbase(h + (size_t)i * H), on0);
             const float2 bias2 = ldo2(sbase(att + A_BBV), on0);
+            {
+                const gptr nrow2 = sbase(nbr + (size_t)inext * KNN);
+                const unsigned oq2 = vop(16 * q);
+                nnb0 = ldoi4(nrow2, oq2); nnb1 = ldoi4(nrow2, oq2 + 64);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // epilogue: out[8a + cc] = sum_m Wbv[8a + cc][m] S[a][m] + bbv[8a + cc] sum_e alpha e_w ; this lane holds
             // S[a = c][16q .. 16q+15] and [64 + 16q .. 64 + 16q + 15]; Wbv rows live in LDS with their 16-byte chunks XOR-swizzled by the head index
@@ -645,13 +695,19 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);
             const float bbv = ldo1(sbase(att + A_BBV), vop(4 * c));
+            {
+                const gptr nrow2 = sbase(nbr + (size_t)inext * KNN);
+                const unsigned oq2 = vop(16 * q);
+                nnb0 = ldoi4(nrow2, oq2); nnb1 = ldoi4(nrow2, oq2 + 64);
+            }
+            const int nbv[2][4] = {{nb0.x, nb0.y, nb0.z, nb0.w}, {nb1.x, nb1.y, nb1.z, nb1.w}};
             float dx = 0.f, dy = 0.f, dz = 0.f;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // invalid slots point at the node itself: rel = 0 and alpha = 0, so they add exactly nothing
-                    const int j = g.jv[hf][r];
+                    const int j = e1_id(nbv[hf][r], 4 * q + r + 16 * hf, d, i);
                     const float coef = (al[hf][r] * inv_den) * ((wv[hf][r] + bbv) * ew[hf][r]);
                     const float cf = 4 * q + r + 16 * hf < d ? coef : 0.f;
                     dx = fmaf(cf, g.xi - ldo1(sbase(x), 12u * j), dx);
@@ -667,6 +723,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             }
         }
         // rotate the pipelined geometry
+        nb0 = nnb0; nb1 = nnb1;
         lg0[0] = nlg[0]; lg0[1] = nlg[1]; dist0[0] = ndist[0]; dist0[1] = ndist[1];
         g = ng;
     }
@@ -675,14 +732,28 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 // ------------------------------------------------------------------------------------------------
 // packing helpers for the LDS image
 // ------------------------------------------------------------------------------------------------
-// fragment order [type][t][s][lane] of the rbf columns of a (centred) first Linear W_a [128][340]
+// split-f16 pieces of the rbf columns of a (centred) first Linear W_a [128][340], block order [type][t] (layout.h): a weight
+// w is carried as h = f16(w) (round to nearest) and l = f16(w - h)
 __global__ void pack_frag_kernel(const float* __restrict__ w_a, int mode, float* __restrict__ dst) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // ((type*8 + t)*5 + s)*64 + lane
-    if (idx >= (int)FRAG) return;
-    const int lane = idx & 63, s = (idx >> 6) % 5, t = (idx / 320) & 7, type = idx / 2560;
-    const int c = lane & 15, kk = lane >> 4;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (type*8 + t)*64 + lane
+    if (idx >= NT * 8 * 64) return;
+    const int lane = idx & 63, t = (idx >> 6) & 7, type = idx >> 9;
+    const int c = lane & 15, q = lane >> 4;
     const int m = mode == 0 ? 16 * t + c : 64 * (t >> 2) + 4 * c + (t & 3);
-    dst[idx] = w_a[(size_t)m * KV_IN + NT + G * type + 4 * s + kk];
+    _Float16 h[5], l[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const float w = w_a[(size_t)m * KV_IN + NT + G * type + 4 * s + q];
+        h[s] = (_Float16)w;
+        l[s] = (_Float16)(w - (float)h[s]);
+    }
+    _Float16* blk = reinterpret_cast<_Float16*>(dst + (size_t)(type * 8 + t) * FRAG_BLK);
+    _Float16* a0 = blk + 4 * lane;            // (d0, d1) = [h0 h1 h2 h3]
+    _Float16* a1 = blk + 256 + 4 * lane;      // (d2, d3) = [h4 l0 l1 l2]
+    _Float16* a2 = blk + 512 + 2 * lane;      //  d4      = [l3 l4]
+    a0[0] = h[0]; a0[1] = h[1]; a0[2] = h[2]; a0[3] = h[3];
+    a1[0] = h[4]; a1[1] = l[0]; a1[2] = l[1]; a1[3] = l[2];
+    a2[0] = l[3]; a2[1] = l[4];
 }
 
 // dWt[dst class lig_i][k|v][m] = Wt[type(src lig, lig_i)][m] - Wt[type(src prot, lig_i)][m]
@@ -735,7 +806,7 @@ hipError_t launch_pack_dwt(const float* wk, const float* wv, float* dst, hipStre
 }
 
 hipError_t launch_pack_frag(const float* w_a, int mode, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(pack_frag_kernel, dim3((FRAG + 255) / 256), dim3(256), 0, s, w_a, mode, dst);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(NT * 8 * 64 / 256), dim3(256), 0, s, w_a, mode, dst);
     return hipGetLastError();
 }
 

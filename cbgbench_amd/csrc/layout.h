@@ -44,12 +44,19 @@ constexpr size_t A_WBK = A_BQ1 + H;               // [128][128] (out n, in m) se
 constexpr size_t A_WBV = A_WBK + (size_t)H * H;   // x2h: [128 m][128 n] K-major; h2x: [16][128] (head, m)
 constexpr size_t A_BBV = A_WBV + (size_t)H * H;   // [128] (h2x: first 16)
 // LDS image of the MFMA edge kernel: one contiguous region copied verbatim into LDS.
-//   frag_k [4 types][8 t][5 s][64 lanes]  A-operand fragments of the rbf columns of W_a (k), edge-major
-//   frag_v [4][8][5][64]                  x2h: B-operand fragments (channel-major); h2x: A-operand (edge-major)
+//   frag_k [4 types][8 t][320]            split-f16 pieces of the rbf columns of W_a (k), A operand, edge-major.  A weight w
+//                                         is carried as h = f16(w), l = f16(w - h); per (type, t) block, with h_s / l_s the
+//                                         pieces of W[m(t, c)][g = 4s + q] of lane (c, q):
+//                                           floats [  0,128): lane's (d0, d1) = [h0 h1 | h2 h3]
+//                                           floats [128,256): lane's (d2, d3) = [h4 l0 | l1 l2]
+//                                           floats [256,320): lane's  d4      = [l3 l4]
+//                                         = 20 bytes per lane, the footprint of the five fp32 fragments it replaces
+//   frag_v [4][8][320]                    same for v.  x2h: B operand, channel-major; h2x: A operand, edge-major
 //   dwt    [2][256] (+512 unused)         dWt[lig_i][k|v] = Wt[type(src lig, i)] - Wt[type(src prot, i)]
 //   ln     [4][128]                       gamma_k, beta_k, gamma_v, beta_v
 //   wbv_rm [128][128]                     x2h only: second v Linear, row-major (out n, in m)
-constexpr size_t FRAG = (size_t)NT * 8 * 5 * 64;   // 10240
+constexpr size_t FRAG_BLK = 320;                       // floats per (type, tile)
+constexpr size_t FRAG = (size_t)NT * 8 * FRAG_BLK;     // 10240
 constexpr size_t A_IMG = A_BBV + H;
 constexpr size_t IMG_FRAG_K = 0;
 constexpr size_t IMG_FRAG_V = IMG_FRAG_K + FRAG;

@@ -7,6 +7,15 @@ be compared with the oracle; the HIP kernel mirrors it line by line.  ``tests/te
 
 MFMA 16x16x4 f32 operand maps (cdna_hip_programming.md section 3): lane l, c = l & 15, q = l >> 4
     A[i = c][k = q]      B[k = q][j = c]      C/D reg r: [row = 4q + r][col = c]
+v_mfma_f32_16x16x16_f16 (the rbf pre-activation of protein destinations, "split-f16" arithmetic): four f16 per lane,
+    A[i = c][k = 4q + j]   B[k = 4q + j][j = c]   same C/D map (scripts/ubench/mfma_f16_check.hip probes the K = 32 sibling)
+
+Split-f16: an fp32 value v is carried as hi = f16(v) (round to nearest) and lo = f16(v - hi); a product of two such values is
+hi*hi + hi*lo + lo*hi accumulated in fp32 (the lo*lo term, 2^-22 relative, is dropped).  The rbf weights are split at pack
+time, the 5 rbf values of a lane per node.  Per (type, tile t) a lane owns five dwords of weight pieces in LDS
+    d0 = [h0 h1]  d1 = [h2 h3]  d2 = [h4 l0]  d3 = [l1 l2]  d4 = [l3 l4]          (index = s of g = 4s + q)
+-- 20 bytes, exactly the fp32 footprint -- read as the tuples T1 = (d0, d1), T2 = (d2, d3), T3 = (d4, d2), which four MFMAs
+contract with the rbf tuples  [rh0..3], [rl0..3], [rh4 rh0 rh1 rh2], [rh3 rh4 rl4 0]  (T1 is used twice, d2 is read twice).
 """
 import numpy as np
 
@@ -24,6 +33,45 @@ def mfma(a, b, c):
     B[Q_, C_] = b
     D = (A.astype(np.float64) @ B.astype(np.float64)).astype(np.float32)
     return np.stack([c[r] + D[4 * Q_ + r, C_] for r in range(4)])
+
+
+def mfma_f16(a4, b4, c):
+    """v_mfma_f32_16x16x16_f16: a4[4 slots][64], b4[4][64] (float16), c[4][64] -> d[4][64]; products exact, fp32 accumulate."""
+    A = np.zeros((16, 16), np.float64)
+    B = np.zeros((16, 16), np.float64)
+    for j in range(4):
+        A[C_, 4 * Q_ + j] = a4[j].astype(np.float64)
+        B[4 * Q_ + j, C_] = b4[j].astype(np.float64)
+    D = (A @ B).astype(np.float32)
+    return np.stack([c[r] + D[4 * Q_ + r, C_] for r in range(4)])
+
+
+def split_f16(v):
+    hi = v.astype(np.float16)
+    lo = (v.astype(np.float32) - hi.astype(np.float32)).astype(np.float16)
+    return hi, lo
+
+
+def rbf_tuples(R5):
+    """R5[5][64] fp32 (index s, g = 4s + q) -> the four B tuples [4][4 slots][64] float16."""
+    h, l = zip(*[split_f16(r) for r in R5])
+    z = np.zeros(64, np.float16)
+    return [np.stack([h[0], h[1], h[2], h[3]]), np.stack([l[0], l[1], l[2], l[3]]),
+            np.stack([h[4], h[0], h[1], h[2]]), np.stack([h[3], h[4], l[4], z])]
+
+
+def frag16(Wr, labeling):
+    """Wr[4 types][20 g][128 m] -> [type][t][tuple 3][slot 4][lane] float16: the weight tuples of the split-f16 rbf MFMAs
+    (lane (c, q): channel labeling(t, c), g = 4s + q), i.e. (d0, d1), (d2, d3), (d4, d2) of the LDS record."""
+    out = np.zeros((4, 8, 3, 4, 64), np.float16)
+    for t in range(8):
+        m = labeling(t, C_)
+        h, l = zip(*[split_f16(Wr[:, 4 * s + Q_, m]) for s in range(5)])     # each [4 types][64]
+        z = np.zeros_like(h[0])
+        out[:, t, 0] = np.stack([h[0], h[1], h[2], h[3]], 1)
+        out[:, t, 1] = np.stack([h[4], l[0], l[1], l[2]], 1)
+        out[:, t, 2] = np.stack([l[3], l[4], h[4], l[0]], 1)
+    return out
 
 
 # ---- hidden-channel labelings ---------------------------------------------------------------------
@@ -89,6 +137,10 @@ class Weights:
         self.fragA_k = frag_wr_edge(self.Wr_k)
         self.fragA_v = frag_wr_edge(self.Wr_v)
         self.fragB_v = frag_wr_chan(self.Wr_v)
+        # split-f16 tuples (protein destinations): A operand edge-major (k; h2x v), B operand channel-major (x2h v)
+        self.frag16A_k = frag16(self.Wr_k, m_edge)
+        self.frag16A_v = frag16(self.Wr_v, m_edge)
+        self.frag16B_v = frag16(self.Wr_v, m_chan)
 
     def node_tables(self, h, lig):
         """What the node kernels produce: P = [PDk | PDv | PSk | PSv] and the folded query Qt.
@@ -133,8 +185,11 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
     def etype(src_lig):
         return (0 if lig_i else 1) if src_lig else (2 if lig_i else 3)
 
-    def pre_edge_major(PD, PS, Wt, frag):
-        """C[t][hf][r][lane]: lane (c = e16, q), m = 32q + 4t + r (edge-major)."""
+    def rbf_masked(hf, src_lig):
+        return [np.where(lg0[hf] == src_lig, R[hf][s], 0).astype(np.float32) for s in range(5)]
+
+    def pre_edge_major(PD, PS, Wt, frag, frag16_):
+        """C[t][hf][r][lane]: lane (c = e16, q), m = 32q + 4t + r (edge-major); the rbf term in split-f16 MFMAs."""
         Cacc = np.zeros((8, 2, 4, 64), np.float32)
         for t in range(8):
             for hf in range(2):
@@ -143,9 +198,9 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
                     m = m_edge(t, 4 * Q_ + r)
                     Cacc[t, hf, r] = PD[i, m] + PS[j0[hf], m] + np.where(lg0[hf], dWt[m], 0)
                 for src_lig in passes:
-                    for s in range(5):
-                        Rm = np.where(lg0[hf] == src_lig, R[hf][s], 0).astype(np.float32)
-                        Cacc[t, hf] = mfma(frag[etype(src_lig), t, s], Rm, Cacc[t, hf])
+                    T, Bt = frag16_[etype(src_lig), t], rbf_tuples(rbf_masked(hf, src_lig))
+                    for tu, b in ((0, 0), (0, 1), (1, 2), (2, 3)):
+                        Cacc[t, hf] = mfma_f16(T[tu], Bt[b], Cacc[t, hf])
         return Cacc
 
     def ln_edge_major(Cacc, gamma, beta):
@@ -171,7 +226,7 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
         return out
 
     # ---- k path (edge-major) -----------------------------------------------------------------------
-    Hk = ln_edge_major(pre_edge_major(PDk, PSk, W.Wt_k, W.fragA_k), W.g_k, W.be_k)
+    Hk = ln_edge_major(pre_edge_major(PDk, PSk, W.Wt_k, W.fragA_k, W.frag16A_k), W.g_k, W.be_k)
     S = contract_channels(Hk, Qt[i])                           # scores: lane (a, q) reg r <-> e = 4q + r + 16hf
     e1 = np.stack([[4 * Q_ + r + 16 * hf for r in range(4)] for hf in range(2)])   # [2][4][64]
     valid1 = e1 < d
@@ -196,9 +251,10 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
                 for r in range(4):
                     Cv[t, hf, r] = PDv[i, m] + PSv[j1[hf, r], m] + np.where(lg1[hf, r], dWt[m], 0)
                 for src_lig in passes:
-                    for s in range(5):
-                        Rm = np.where(lg0[hf] == src_lig, R[hf][s], 0).astype(np.float32)
-                        Cv[t, hf] = mfma(Rm, W.fragB_v[etype(src_lig), t, s], Cv[t, hf])
+                    # rbf tuples as the A operand, weight tuples as B
+                    T, Bt = W.frag16B_v[etype(src_lig), t], rbf_tuples(rbf_masked(hf, src_lig))
+                    for tu, b in ((0, 0), (0, 1), (1, 2), (2, 3)):
+                        Cv[t, hf] = mfma_f16(Bt[b], T[tu], Cv[t, hf])
         # LN over m = (t, c): in-lane over t, across the 16 lanes of a row (xor 1,2,4,8)
         Hv = np.zeros_like(Cv)
         for hf in range(2):
@@ -234,7 +290,7 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
         out = out + W.bb_v * np.repeat(sw_head, 8)
         return h[i] + out
     # ---- h2x: v path edge-major as well; wv[e, a] = Wbv[a] . hid_v[e] + bbv[a] --------------------------
-    Hv = ln_edge_major(pre_edge_major(PDv, PSv, W.Wt_v, W.fragA_v), W.g_v, W.be_v)
+    Hv = ln_edge_major(pre_edge_major(PDv, PSv, W.Wt_v, W.fragA_v, W.frag16A_v), W.g_v, W.be_v)
     WV = contract_channels(Hv, W.Wb_v) + W.bb_v[C_]
     j1 = np.where(valid1, nbr[i, np.minimum(e1, 31)], i)
     rel = x[i] - x[j1]                                           # [2][4][64][3]

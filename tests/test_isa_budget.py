@@ -62,8 +62,11 @@ def test_forward_edge_kernels_fit_their_budget(tmp_path):
     assert len(body.splitlines()) > 2000
     assert "v_div_fmas_f32" not in body
     valu = len(re.findall(r"^\s+v_(?!mfma)", body, flags=re.M))
-    mfma = len(re.findall(r"^\s+v_mfma_f32_16x16x4", body, flags=re.M))
-    assert mfma == 448 and valu <= 1500, (mfma, valu)       # 2 179 VALU instructions before the packed-fp32 pass
+    mfma32 = len(re.findall(r"^\s+v_mfma_f32_16x16x4", body, flags=re.M))
+    mfma16 = len(re.findall(r"^\s+v_mfma_f32_16x16x16_f16", body, flags=re.M))
+    # static counts: 128 exact-fp32 MFMAs (scores + aggregation); the rbf pre-activation as split-f16 MFMAs, 4 blocks (k / v x two
+    # halves) x 2 source-class passes x 8 tiles x 4; 2 179 VALU instructions before the packed-fp32 pass, 1 344 before split-f16
+    assert mfma32 == 128 and mfma16 == 256 and valu <= 1800, (mfma32, mfma16, valu)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
