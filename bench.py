@@ -50,10 +50,14 @@ X2H_BYTES_PER_EDGE, X2H_BYTES_PER_NODE = 1032, 1536
 H2X_BYTES_PER_EDGE, H2X_BYTES_PER_NODE = 596, 536
 # Factored algorithmic FLOPs: 122 880 per edge-layer + 8*32 768 + 131 072 per node-layer
 FLOPS_PER_EDGE_LAYER, FLOPS_PER_NODE_LAYER = 122880, 8 * 32768 + 131072
-# what the fused x2h edge kernel actually issues on the matrix cores: per edge the rbf columns of both first
-# Linears (2*20*256), the scores against the folded query (2*128*16) and the value aggregation (2*16*128); per node the
-# value's second Linear applied after aggregation (2*128*128).  Both second Linears have left the edge.
+# what the fused x2h edge kernel actually issues on the matrix cores: per edge the scores against the folded
+# query (2*128*16) and the value aggregation (2*16*128) as exact-fp32 MFMAs; the rbf columns of both first Linears
+# (2*20*256 useful flop per edge) as split-f16 MFMAs: 128 v_mfma_f32_16x16x16_f16 of 8192 flop per 32-edge node; per node the
+# value's second Linear applied after aggregation (2*128*128, packed fp32 VALU).  Both second Linears have left the edge.
+X2H_FP32_MFMA_FLOPS_PER_EDGE = 2 * 128 * 16 + 2 * 16 * 128
+X2H_F16_MFMA_FLOPS_PER_NODE = 128 * 2 * 16 * 16 * 16
 X2H_EXEC_FLOPS_PER_EDGE, X2H_EXEC_FLOPS_PER_NODE = 2 * 20 * 256 + 2 * 128 * 16 + 2 * 16 * 128, 2 * 128 * 128
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 matrix peak
 
 
 def measured_traffic(n_nodes):
@@ -79,9 +83,13 @@ def build_batch(pockets, samples, seed, num_classes=13):
     return synthetic.make_batch(plist, nlig, rng, num_classes)
 
 
-def make_model(device, T=1000):
+def make_model(device, T=1000, name="targetdiff"):
+    """the three diffusion model classes of the reference share the denoiser (repo/models/diffusion/{targetdiff,diffbp,diffsbdd}.py)"""
     from cbgbench_amd import synthetic_weights
-    model = C.get_model(C.default_targetdiff_config(13, 9, T)).eval()
+    cfg = {"targetdiff": lambda: C.default_targetdiff_config(13, 9, T),
+           "diffbp": lambda: C.default_diffbp_config(13, num_diffusion_timesteps=T),
+           "diffsbdd": lambda: C.default_diffsbdd_config(8, num_diffusion_timesteps=T)}[name]()
+    model = C.get_model(cfg).eval()
     synthetic_weights.fill_(model, seed=0)      # deterministic random-init weights (no checkpoints ship with the reference)
     return model.to(device)
 
@@ -116,31 +124,53 @@ def _pick_cpu_threads(sd, seed):
     return best_t
 
 
-def cpu_baseline(sd, seed, max_seconds=20.0):
-    """The CPU oracle (oracle/targetdiff.py: a port of the reference's PyTorch-CPU step, reference formulation
-    with materialised [E,340] edge inputs) on this host's cores, on a bounded sample of the same workload:
+def cpu_baseline(sd, seed, max_seconds=20.0, model="targetdiff"):
+    """The CPU oracle (oracle/{targetdiff,diffbp,diffsbdd}.py: ports of the reference's PyTorch-CPU step, reference
+    formulation with materialised [E,340] edge inputs) on this host's cores, on a bounded sample of the same workload:
     whole steps of one 10-graph batch (1 pocket x 10 samples) until ~max_seconds."""
     from oracle import targetdiff as OT
-    threads = _pick_cpu_threads(sd, seed)
+    threads = _pick_cpu_threads(sd if model == "targetdiff" else oracle_state_dict(), seed)
     torch.set_num_threads(threads)
-    batch = build_batch(1, 10, seed)
+    C_ = 8 if model == "diffsbdd" else 13
+    batch = build_batch(1, 10, seed, num_classes=C_)
     x = batch["ligand_pos"]
-    c = torch.nn.functional.one_hot(batch["ligand_atom_type"], 13).float()
+    c = torch.nn.functional.one_hot(batch["ligand_atom_type"], C_).float()
     g = torch.Generator().manual_seed(seed)
     n_lig = x.shape[0]
+    if model == "diffbp":
+        from oracle import diffbp as OB
+        step = lambda x, c, k: OB.denoise_step(sd, batch, x, c, 999 - k, torch.randn(n_lig, 3, generator=g),
+                                               torch.rand(n_lig, generator=g), 13, 1000)
+    elif model == "diffsbdd":
+        from oracle import diffsbdd as OS
+        gamma_tab = sd["pos_scheduler.gamma.gamma"]
+        bl, br = batch["ligand_element_batch"], batch["protein_element_batch"]
+        B = int(bl.max()) + 1
+        v_rec = batch["protein_atom_feature"] / 4.0
+        pocket = {"x_rec": batch["protein_pos"]}
+
+        def step(x, c, k):     # one iteration of the loop at diffsbdd.py:296-304 (oracle/diffsbdd.py::sample)
+            s_, t_ = torch.full((B,), 999 - k) / 1000, (torch.full((B,), 999 - k) + 1) / 1000
+            x_pred, c_out = OS.denoise(sd, batch, x, c, pocket["x_rec"], v_rec)
+            x, pocket["x_rec"] = OS.sample_p_zs_given_zt(gamma_tab, 1000, s_, t_, x, pocket["x_rec"], bl, br, B, x_pred,
+                                                         torch.randn(n_lig, 3, generator=g), True)
+            c, _ = OS.sample_p_zs_given_zt(gamma_tab, 1000, s_, t_, c, v_rec, bl, br, B, c_out,
+                                           torch.randn(n_lig, C_, generator=g), False)
+            return x, c
+    else:
+        step = lambda x, c, k: OT.denoise_step(sd, batch, x, c, 999 - k, torch.randn(n_lig, 3, generator=g),
+                                               torch.rand(n_lig, 13, generator=g), 13)
     steps, t0 = 0, time.perf_counter()
     with torch.no_grad():
         while True:
-            eps = torch.randn(n_lig, 3, generator=g)
-            u = torch.rand(n_lig, 13, generator=g)
-            x, c = OT.denoise_step(sd, batch, x, c, 999 - steps, eps, u, 13)
+            x, c = step(x, c, steps)
             steps += 1
             el = time.perf_counter() - t0
             if el > max_seconds or steps >= 8:
                 break
     return {"value": round(10 * steps / el, 4), "unit": "graph-steps/s", "cores": threads,
             "kind": "port", "sample": f"{steps} full denoising steps of one 10-graph batch (1 pocket x 10 samples, "
-            f"N={batch['protein_pos'].shape[0] + n_lig} nodes: the batch sample.py:177-183 builds), oracle/targetdiff.py "
+            f"N={batch['protein_pos'].shape[0] + n_lig} nodes: the batch sample.py:177-183 builds), oracle/{model}.py "
             f"= the PyTorch-CPU port of the reference step in the reference's own formulation, bit-identical to the "
             f"unmodified reference on tests/golden (tests/test_oracle_golden.py; /root/reference does not exist on this box; "
             f"the reference itself timed on the build container: BASELINE.md section 2), fp32, {threads} threads "
@@ -299,6 +329,10 @@ def main():
                     help="denovo = BASELINE configs[1] (default); linker = configs[2]: --pockets distinct pockets, one "
                          "graph each, fixed context atoms + a few generated linker atoms (partial gen_flag); train = "
                          "configs[4] shape: forward + backward + all-reduce + Adam on --pockets graphs per GPU")
+    ap.add_argument("--model", choices=["targetdiff", "diffbp", "diffsbdd"], default="targetdiff",
+                    help="sampler timed on the denovo / linker workloads (default: targetdiff, the driver line). diffbp adds the "
+                         "CoMPredictor H2X stack + score / mask-type step per step, diffsbdd the zero-COM variational step "
+                         "(its pocket moves every step: no static-context cache)")
     ap.add_argument("--graph", choices=["on", "off"], default="off",
                     help="replay one captured hipGraph per denoising step instead of stream launches (single batch only; no "
                          "gain measured: small batches are bound by the dependent-kernel chain on the device)")
@@ -325,8 +359,9 @@ def main():
         args.pockets = {"train": 32, "linker": 256}.get(args.workload, 100)
     if args.workload == "train":
         return bench_train(args, rank, world, dev)
-    model = make_model(dev)
+    model = make_model(dev, name=args.model)
     T = model.num_diffusion_timesteps
+    num_classes = model.num_classes
 
     # the job of this rank, resident in HBM as whole-pocket batches
     if args.workload == "linker":
@@ -336,7 +371,8 @@ def main():
     states = []
     for b, npk in enumerate(chunks):
         seed = 1000 + 97 * rank + 7919 * b
-        batch = synthetic.linker_batch(npk, seed=seed) if args.workload == "linker" else build_batch(npk, args.samples, seed=seed)
+        batch = (synthetic.linker_batch(npk, seed=seed) if args.workload == "linker"
+                 else build_batch(npk, args.samples, seed=seed, num_classes=num_classes))
         states.append(model.begin_sampling(synthetic.batch_to(batch, dev), keep_trajectory=True))
     n_graphs = args.pockets * args.samples
     N = sum(st["N"] for st in states)
@@ -348,7 +384,7 @@ def main():
             for st in states:
                 model.denoise_step(st, t)
 
-    use_graph = args.graph == "on" and len(states) == 1 and args.warmup + args.steps + 2 < T
+    use_graph = args.graph == "on" and len(states) == 1 and args.warmup + args.steps + 2 < T and args.model == "targetdiff"
     if use_graph:
         n_blocks = 1
         replay, done = model.make_step_graph(states[0], warmup=2)
@@ -384,11 +420,11 @@ def main():
         "value": round(graph_steps / el_max, 2), "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * el_max / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": (f"configs/denovo targetdiff sampling, the whole BASELINE configs[1] job: {shape}, "
+        "config": {"workload": (f"configs/denovo {args.model} sampling, the whole BASELINE configs[1] job: {shape}, "
                                 f"N_rec~U[350,650], N_lig~U[10,45], k=32, 9 layers, fp32, random-init synthetic weights; one "
                                 f"bench step = one reverse-diffusion step of the whole job at each of {n_blocks} time "
                                 f"blocks (t = 999-i, 749-i, 499-i, 249-i, 24-(i mod 25))") if args.workload == "denovo" else
-                               (f"configs/linker targetdiff sampling (BASELINE configs[2]): {shape} (fragment-pair pockets), "
+                               (f"configs/linker {args.model} sampling (BASELINE configs[2]): {shape} (fragment-pair pockets), "
                                 f"N_rec~U[350,650], 10-35 fixed context atoms + 3-14 generated atoms per graph (partial "
                                 f"gen_flag), k=32, 9 layers, fp32, synthetic weights; one bench step = one reverse-diffusion "
                                 f"step of the job at each of {n_blocks} time blocks"),
@@ -434,20 +470,29 @@ def main():
                     "(1032 B/edge + 1536 B/node) x edges/nodes per launch; the kernel is fused (edge MLP + "
                     "attention), so real HBM traffic is far lower; timed on the first resident batch",
             "mfma_view": {
-                "x2h_kernel_executed_tflops": round((X2H_EXEC_FLOPS_PER_EDGE * deg_edges + X2H_EXEC_FLOPS_PER_NODE * Nb)
-                                                    / x2h_s / 1e12, 3) if x2h_s > 0 else 0,
-                "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                "fp32_mfma_tflops": round(X2H_FP32_MFMA_FLOPS_PER_EDGE * deg_edges / x2h_s / 1e12, 3) if x2h_s > 0 else 0,
+                "fp32_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                "f16_mfma_tflops_issued": round(X2H_F16_MFMA_FLOPS_PER_NODE * Nb / x2h_s / 1e12, 3) if x2h_s > 0 else 0,
+                "f16_peak_tflops": F16_MFMA_PEAK_TFLOPS,
+                "x2h_kernel_useful_tflops": round((X2H_EXEC_FLOPS_PER_EDGE * deg_edges + X2H_EXEC_FLOPS_PER_NODE * Nb)
+                                                  / x2h_s / 1e12, 3) if x2h_s > 0 else 0,
                 "reference_factored_equiv_tflops": round(layer_flops / dev_s_layer / 1e12, 3) if dev_s_layer else 0,
-                "note": "executed = exact-fp32 MFMA work the x2h kernel issues (18432 flop/edge + 32768/node) / its launch "
-                        "time, to be read against peak_tflops; reference_factored_equiv = SURVEY.md 8d factored flops of "
-                        "a whole layer / device time per layer: it may exceed the peak because the library moves both "
-                        "second Linears off the edges (query fold, post-aggregation value Linear), caches the "
-                        "ligand-free protein rows and prunes the last layers"},
+                "note": "fp32_mfma = the exact-fp32 MFMAs the x2h kernel issues (scores + aggregation, 8192 flop/edge) / its "
+                        "launch time; f16_mfma_issued = the split-f16 MFMAs of the rbf pre-activation (three f16 products per "
+                        "fp32 product, 128 x 8192 flop per node); useful = fp32-equivalent work of the kernel (18432 flop/edge "
+                        "+ 32768/node).  The kernel is bound by the sum of fp32-MFMA and VALU issue time on a SIMD, not by "
+                        "either peak (DESIGN.md 9).  reference_factored_equiv = SURVEY.md 8d factored flops of a whole layer / "
+                        "device time per layer: it may exceed the fp32 peak because the library moves both second Linears off "
+                        "the edges (query fold, post-aggregation value Linear), caches the ligand-free protein rows and prunes "
+                        "the last layers"},
             "per_kernel": per,
             "launches_per_denoising_step": round(sum(cnt) / (5.0 * prof_steps), 1),
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(oracle_state_dict(), seed=1000)
+        from oracle import weights as OW
+        osd = {"targetdiff": oracle_state_dict, "diffbp": lambda: OW.synthetic_state_dict_diffbp(13, 9, seed=0, num_timesteps=T),
+               "diffsbdd": lambda: OW.synthetic_state_dict_diffsbdd(8, 9, seed=0, num_timesteps=T)}[args.model]()
+        out["cpu_baseline"] = cpu_baseline(osd, seed=1000, model=args.model)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

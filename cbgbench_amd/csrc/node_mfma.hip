@@ -1,4 +1,4 @@
-// libcbgx -- node-level GEMMs of one attention block on the gfx950 matrix cores (exact fp32 MFMA).
+// libcbgx -- node-level GEMMs of one attention block on the gfx950 matrix cores (split-f16 projection, exact-fp32 MFMA else).
 //
 //   node_proj :  P[N,640]   = h[N,128] @ Wn + bn          (PDk | PDv | PSk | PSv | q-hidden), LDS-staged Wn chunks
 //   node_qmlp :  q[N,128]   = ReLU(LN(P[:,512:640])) @ Wq1^T + bq1
@@ -20,6 +20,10 @@ namespace cbgx {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// split-f16 (edge_mfma.hip): an fp32 value v = hi + lo with hi = f16(v) (round to nearest), lo = f16(v - hi);
+// a product is hi*hi + hi*lo + lo*hi on the f16 matrix pipe with fp32 accumulation (2^-22 relative)
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#define MFMAH32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ float4 nld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -31,11 +35,16 @@ __device__ __forceinline__ float nxrow_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// node_proj: 4 waves x 16 rows per workgroup; 10 column chunks of 64; chunk fragments double-buffered in LDS.
-// fragment order of a chunk: [ct 4][s4 8][lane 64][4]  = Wn[k = 16 s4 + 4q + j][col = 64 ch + 4c + ct]
+// node_proj: 4 waves x 16 rows per workgroup; 10 column chunks of 64; chunk tables double-buffered in LDS.
+// The product runs in split-f16 on v_mfma_f32_16x16x32_f16 (K = 32 per instruction, 8 f16 per lane and operand): the 128
+// features of a row are split once per row tile (hi / lo, 4 + 4 operands per lane), the weights at pack time; 3 x 4 MFMAs per
+// 16 x 16 output tile instead of 32 exact-fp32 ones -- the kernel goes from matrix-bound to bound by its 2.5 KB/row of stores.
+// K slot j of instruction u in lane group q <-> k = 16 (2u + (j >> 2)) + 4q + (j & 3), so the four q-lanes of a row still read
+// one contiguous 64-byte run of h per load.  Chunk table order: [part hi|lo][ct 4][u 4][lane 64][8 f16]
+//   = split(Wn[k(u, q, j)][col = 64 ch + 4c + ct])
 // ------------------------------------------------------------------------------------------------
-constexpr int NP_CHUNK = 4 * 8 * 64 * 4;  // 8192 floats = 32 KB
-constexpr int NP_CHUNKS = PROW / 64;      // 10
+constexpr int NP_CHUNK = 2 * 4 * 4 * 64 * 4;  // 8192 floats = 32 KB (two f16 per float slot)
+constexpr int NP_CHUNKS = PROW / 64;          // 10
 
 // `rows` / `n_rows_ptr` (optional): compute only the listed rows (device-side count, no host sync); results are
 // written to their natural positions P[rows[k]].  `chunk_mask`: which of the 10 column chunks to produce.
@@ -69,11 +78,17 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
             orow[r] = k < n_rows ? (rows ? rows[kk] : kk) : -1;
             lgr[r] = lig[rows ? rows[kk] : kk] != 0;
         }
-        float a[32];
+        half8 ah[4], al[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float4 v = nld4(h + (size_t)arow * H + 16 * u + 4 * q);
-            a[4 * u] = v.x; a[4 * u + 1] = v.y; a[4 * u + 2] = v.z; a[4 * u + 3] = v.w;
+        for (int u = 0; u < 4; ++u) {
+            const float4 v0 = nld4(h + (size_t)arow * H + 32 * u + 4 * q), v1 = nld4(h + (size_t)arow * H + 32 * u + 16 + 4 * q);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 hi = (_Float16)v[j];
+                ah[u][j] = hi;
+                al[u][j] = (_Float16)(v[j] - (float)hi);
+            }
         }
         __syncthreads();  // previous tile's readers of lds[0] are done
         {
@@ -96,7 +111,8 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
 #pragma unroll
                 for (int u = 0; u < NP_CHUNK / 4 / 256; ++u) stage[u] = src[tid + 256 * u];
             }
-            const float* B = lds[is & 1];
+            const half8* Bh = reinterpret_cast<const half8*>(lds[is & 1]) + lane;   // [ct][u][lane]
+            const half8* Bl = Bh + 4 * 4 * 64;
             const float4 bP = nld4(bias + 64 * ch + 4 * c), bL = nld4(bias + PROW + 64 * ch + 4 * c);
             floatx4 acc[4];
 #pragma unroll
@@ -105,18 +121,16 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
                 acc[2][r] = lgr[r] ? bL.z : bP.z; acc[3][r] = lgr[r] ? bL.w : bP.w;
             }
 #pragma unroll
-            for (int s4 = 0; s4 < 8; ++s4) {
-                float4 bf[4];
+            for (int u = 0; u < 4; ++u) {
+                half8 bh[4], bl[4];
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) bf[ct] = nld4(B + ((ct * 8 + s4) * 64 + lane) * 4);
+                for (int ct = 0; ct < 4; ++ct) { bh[ct] = Bh[(ct * 4 + u) * 64]; bl[ct] = Bl[(ct * 4 + u) * 64]; }
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA(a[4 * s4 + 0], bf[ct].x, acc[ct]);
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(ah[u], bl[ct], acc[ct]);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA(a[4 * s4 + 1], bf[ct].y, acc[ct]);
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(al[u], bh[ct], acc[ct]);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA(a[4 * s4 + 2], bf[ct].z, acc[ct]);
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA(a[4 * s4 + 3], bf[ct].w, acc[ct]);
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(ah[u], bh[ct], acc[ct]);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -137,7 +151,8 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------------
 // node_qmlp: LayerNorm + ReLU on the q-hidden quarter of P (A layout: LN is in-lane + across q), then
-// q = z @ Wq1^T + bq1.  Wq1 fragments [nt 8][s4 8][lane][4] = Wq1[n = 64(nt>>2) + 4c + (nt&3)][k = 16 s4 + 4q + j].
+// q = z @ Wq1^T + bq1 in split-f16 (K = 32 per MFMA, same slot map as node_proj).
+// Wq1 tables [part hi|lo][nt 8][u 4][lane][8 f16] = split(Wq1[n = 64(nt>>2) + 4c + (nt&3)][k = 16 (2u + (j>>2)) + 4q + (j&3)]).
 // ------------------------------------------------------------------------------------------------
 constexpr int NQ_FRAG = 8 * 8 * 64 * 4;  // 16384 floats = 64 KB
 
@@ -151,7 +166,10 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
     {
         const float4* src = reinterpret_cast<const float4*>(att + A_WQ1_FRAG);
         float4* dst = reinterpret_cast<float4*>(lds);
-        for (int t = grp_begin * (NQ_FRAG / 8) + tid; t < grp_end * (NQ_FRAG / 8); t += 256) dst[t] = src[t];
+        // group g owns the tiles nt = 4g .. 4g + 3 of both parts (hi | lo): two float4 ranges of NQ_FRAG / 16 each
+        for (int part = 0; part < 2; ++part)
+            for (int t = part * (NQ_FRAG / 8) + grp_begin * (NQ_FRAG / 16) + tid; t < part * (NQ_FRAG / 8) + grp_end * (NQ_FRAG / 16); t += 256)
+                dst[t] = src[t];
     }
     __syncthreads();
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
@@ -187,23 +205,32 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
             z[4 * u + 2] = fmaxf(z[4 * u + 2] * rstd * g.z + b.z, 0.f);
             z[4 * u + 3] = fmaxf(z[4 * u + 3] * rstd * g.w + b.w, 0.f);
         }
+        half8 zh[4], zl[4];   // z[8u + j] <-> k = 16 (2u + (j >> 2)) + 4q + (j & 3): exactly the order z was loaded in
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 hi = (_Float16)z[8 * u + j];
+                zh[u][j] = hi;
+                zl[u][j] = (_Float16)(z[8 * u + j] - (float)hi);
+            }
+        const half8* Bh = reinterpret_cast<const half8*>(lds) + lane;   // [nt][u][lane]
+        const half8* Bl = Bh + 8 * 4 * 64;
         for (int grp = grp_begin; grp < grp_end; ++grp) {
             const float4 b4 = nld4(att + A_BQ1 + 64 * grp + 4 * c);
             floatx4 acc[4] = {{b4.x, b4.x, b4.x, b4.x}, {b4.y, b4.y, b4.y, b4.y}, {b4.z, b4.z, b4.z, b4.z},
                               {b4.w, b4.w, b4.w, b4.w}};
 #pragma unroll
-            for (int s4 = 0; s4 < 8; ++s4) {
-                float4 bf[4];
+            for (int u = 0; u < 4; ++u) {
+                half8 bh[4], bl[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bf[j] = nld4(lds + (((grp * 4 + j) * 8 + s4) * 64 + lane) * 4);
+                for (int j = 0; j < 4; ++j) { bh[j] = Bh[((grp * 4 + j) * 4 + u) * 64]; bl[j] = Bl[((grp * 4 + j) * 4 + u) * 64]; }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = MFMA(z[4 * s4 + 0], bf[j].x, acc[j]);
+                for (int j = 0; j < 4; ++j) acc[j] = MFMAH32(zh[u], bl[j], acc[j]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = MFMA(z[4 * s4 + 1], bf[j].y, acc[j]);
+                for (int j = 0; j < 4; ++j) acc[j] = MFMAH32(zl[u], bh[j], acc[j]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = MFMA(z[4 * s4 + 2], bf[j].z, acc[j]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = MFMA(z[4 * s4 + 3], bf[j].w, acc[j]);
+                for (int j = 0; j < 4; ++j) acc[j] = MFMAH32(zh[u], bh[j], acc[j]);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -353,15 +380,16 @@ hipError_t launch_node_gemm(const float* A, int lda, const float* Wt, const floa
 // ------------------------------------------------------------------------------------------------
 // fragment packing (from reference-layout tensors)
 // ------------------------------------------------------------------------------------------------
-// node projection: dst[ch][ct][s4][lane][j] = Wcat[col = 64ch + 4c + ct][k = 32q + 4 s4 + j]; Wcat rows are assembled
-// from W_a_k / W_a_v (dst and src thirds) and W_q0, exactly like the K-major A_WN table.
+// node projection: split-f16 chunk tables, dst[ch][part][ct][u][lane][j] (f16) = hi / lo of
+// Wcat[col = 64ch + 4c + ct][k = 16 (2u + (j >> 2)) + 4q + (j & 3)]; Wcat rows are assembled from W_a_k / W_a_v (dst and src
+// thirds) and W_q0, exactly like the K-major A_WN table.
 __global__ void pack_nproj_kernel(const float* __restrict__ wk0, const float* __restrict__ wv0,
-                                  const float* __restrict__ wq0, float* __restrict__ dst) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= NP_CHUNKS * NP_CHUNK) return;
-    const int j = idx & 3, lane = (idx >> 2) & 63, s4 = (idx >> 8) & 7, ct = (idx >> 11) & 3, ch = idx >> 13;
+                                  const float* __restrict__ wq0, _Float16* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per weight: ((ch*4 + ct)*4 + u)*64*8 + lane*8 + j
+    if (idx >= NP_CHUNKS * 4 * 4 * 64 * 8) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63, u = (idx >> 9) & 3, ct = (idx >> 11) & 3, ch = idx >> 13;
     const int c = lane & 15, q = lane >> 4;
-    const int col = 64 * ch + 4 * c + ct, k = 16 * s4 + 4 * q + j;
+    const int col = 64 * ch + 4 * c + ct, k = 16 * (2 * u + (j >> 2)) + 4 * q + (j & 3);
     const int blk = col >> 7, n = col & 127;
     float v;
     if (blk == 0) v = wk0[(size_t)n * KV_IN + NT + NT * G + k];            // PDk
@@ -369,15 +397,22 @@ __global__ void pack_nproj_kernel(const float* __restrict__ wk0, const float* __
     else if (blk == 2) v = wk0[(size_t)n * KV_IN + NT + NT * G + H + k];   // PSk
     else if (blk == 3) v = wv0[(size_t)n * KV_IN + NT + NT * G + H + k];   // PSv
     else v = wq0[(size_t)n * H + k];                                       // q hidden
-    dst[idx] = v;
+    const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+    _Float16* chunk = dst + (size_t)ch * (NP_CHUNK * 2);                   // f16 elements per chunk
+    const size_t off = ((size_t)(ct * 4 + u) * 64 + lane) * 8 + j;
+    chunk[off] = hi;
+    chunk[(size_t)4 * 4 * 64 * 8 + off] = lo;
 }
 
-__global__ void pack_wq1_kernel(const float* __restrict__ wq1, float* __restrict__ dst) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // [nt][s4][lane][j]
-    if (idx >= NQ_FRAG) return;
-    const int j = idx & 3, lane = (idx >> 2) & 63, s4 = (idx >> 8) & 7, nt = idx >> 11;
+__global__ void pack_wq1_kernel(const float* __restrict__ wq1, _Float16* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per weight: [nt 8][u 4][lane 64][j 8]
+    if (idx >= H * H) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63, u = (idx >> 9) & 3, nt = idx >> 11;
     const int c = lane & 15, q = lane >> 4;
-    dst[idx] = wq1[(size_t)(64 * (nt >> 2) + 4 * c + (nt & 3)) * H + 16 * s4 + 4 * q + j];
+    const float v = wq1[(size_t)(64 * (nt >> 2) + 4 * c + (nt & 3)) * H + 16 * (2 * u + (j >> 2)) + 4 * q + (j & 3)];
+    const _Float16 hi = (_Float16)v;
+    dst[idx] = hi;
+    dst[(size_t)H * H + idx] = (_Float16)(v - (float)hi);
 }
 
 __global__ void pack_wbk_kernel(const float* __restrict__ wbk, float* __restrict__ dst) {
@@ -408,9 +443,9 @@ hipError_t launch_pack_bn2(const float* att_in, const float* bq0, float* att, hi
 
 hipError_t launch_pack_node_frags(const float* wk0, const float* wv0, const float* wq0, const float* wq1,
                                   const float* wbk, float* att, hipStream_t s) {
-    hipLaunchKernelGGL(pack_nproj_kernel, dim3(NP_CHUNKS * NP_CHUNK / 256), dim3(256), 0, s, wk0, wv0, wq0,
-                       att + A_NPROJ_FRAG);
-    hipLaunchKernelGGL(pack_wq1_kernel, dim3(NQ_FRAG / 256), dim3(256), 0, s, wq1, att + A_WQ1_FRAG);
+    hipLaunchKernelGGL(pack_nproj_kernel, dim3(NP_CHUNKS * 4 * 4 * 64 * 8 / 256), dim3(256), 0, s, wk0, wv0, wq0,
+                       reinterpret_cast<_Float16*>(att + A_NPROJ_FRAG));
+    hipLaunchKernelGGL(pack_wq1_kernel, dim3(H * H / 256), dim3(256), 0, s, wq1, reinterpret_cast<_Float16*>(att + A_WQ1_FRAG));
     hipLaunchKernelGGL(pack_wbk_kernel, dim3(NF_FRAG / 256), dim3(256), 0, s, wbk, att + A_WBK_FRAG);
     return hipGetLastError();
 }

@@ -315,8 +315,8 @@ class DiffBP(nn.Module):
         return {"pos": loss_pos, "atom": loss_atom, "com": loss_com, "inter": loss_inter}, results
 
     @torch.no_grad()
-    def sample(self, batch, noise_tape=None, return_device=None):
-        """diffbp.py:240-299. ``noise_tape``: dict t -> (eps [N_lig,3], u [N_lig]) replacing randn_like / rand_like."""
+    def begin_sampling(self, batch, keep_trajectory=True):
+        """Step-invariant part of ``sample`` (diffbp.py:240-262): composition plan, protein rows of x / h, flags."""
         x_lig = batch["ligand_pos"].float()
         dev = x_lig.device
         x_rec = batch["protein_pos"].float()
@@ -337,24 +337,46 @@ class DiffBP(nn.Module):
         h = torch.empty(n_rec + n_lig, self.context_embedder.emb_dim, dtype=torch.float32, device=dev)
         x[rec_rows] = x_rec
         h[rec_rows] = self.context_embedder.embed_protein(v_rec, aa)
-        traj_x = torch.empty(T + 1, n_lig, 3, dtype=torch.float32, device=dev)
-        traj_c = torch.empty(T + 1, n_lig, C, dtype=torch.float32, device=dev)
-        traj_x[T], traj_c[T] = x_lig, c_lig
+        st = {"B": B, "N": n_rec + n_lig, "n_lig": n_lig, "x": x, "h": h, "x_lig": x_lig, "c_lig": c_lig, "bl": bl,
+              "gen_l": gen_l, "batch_idx": batch_idx, "lig_flag": lig_flag, "gen_flag": gen_flag, "lig_rows": lig_rows,
+              "graph_ptr": graph_ptr, "traj_x": None, "traj_c": None}
+        if keep_trajectory:
+            st["traj_x"] = torch.empty(T + 1, n_lig, 3, dtype=torch.float32, device=dev)
+            st["traj_c"] = torch.empty(T + 1, n_lig, C, dtype=torch.float32, device=dev)
+            st["traj_x"][T], st["traj_c"][T] = x_lig, c_lig
+        return st
+
+    @torch.no_grad()
+    def denoise_step(self, st, t_idx, noise=None):
+        """One reverse step (diffbp.py:263-296): denoiser, CoMPredictor, score step on the positions, mask-type step.
+        ``noise``: (eps [N_lig,3], u [N_lig]) replacing randn_like / rand_like."""
+        dev = st["x"].device
+        t = torch.full((st["B"],), t_idx, dtype=torch.long, device=dev)
+        x, h, lig_rows, bl, gen_l = st["x"], st["h"], st["lig_rows"], st["bl"], st["gen_l"]
+        x[lig_rows] = st["x_lig"]
+        h[lig_rows] = self.context_embedder.embed_ligand(st["c_lig"])
+        xo, ho, logits = self.denoiser(x=x, h=h, batch_idx=st["batch_idx"], lig_flag=st["lig_flag"], gen_flag=st["gen_flag"],
+                                       graph_ptr=st["graph_ptr"])
+        eps_t, eps_com = self.com_head(xo[lig_rows], bl, x, ho, st["gen_flag"], st["lig_flag"], st["batch_idx"],
+                                       graph_ptr=st["graph_ptr"])
+        eps, u = noise if noise is not None else (None, None)
+        if self.denoise_structure:
+            st["x_lig"] = self.pos_scheduler.backward_remove_noise(eps_t + eps_com, st["x_lig"], t, bl, gen_l, type="score",
+                                                                   noise=eps)
+        if self.denoise_atom:
+            st["c_lig"], _ = self.type_scheduler.backward_remove_noise(logits[lig_rows], st["c_lig"], t, bl, gen_l,
+                                                                       pred_logit=True, uniform=u)
+        if st["traj_x"] is not None:
+            st["traj_x"][t_idx], st["traj_c"][t_idx] = st["x_lig"], st["c_lig"]
+        return st
+
+    @torch.no_grad()
+    def sample(self, batch, noise_tape=None, return_device=None):
+        """diffbp.py:240-299. ``noise_tape``: dict t -> (eps [N_lig,3], u [N_lig]) replacing randn_like / rand_like."""
+        T = self.num_diffusion_timesteps
+        st = self.begin_sampling(batch, keep_trajectory=True)
         for t_idx in reversed(range(T)):
-            t = torch.full((B,), t_idx, dtype=torch.long, device=dev)
-            x[lig_rows] = x_lig
-            h[lig_rows] = self.context_embedder.embed_ligand(c_lig)
-            xo, ho, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
-                                           graph_ptr=graph_ptr)
-            eps_t, eps_com = self.com_head(xo[lig_rows], bl, x, ho, gen_flag, lig_flag, batch_idx, graph_ptr=graph_ptr)
-            eps, u = noise_tape[t_idx] if noise_tape is not None else (None, None)
-            if self.denoise_structure:
-                x_lig = self.pos_scheduler.backward_remove_noise(eps_t + eps_com, x_lig, t, bl, gen_l, type="score",
-                                                                 noise=eps)
-            if self.denoise_atom:
-                c_lig, _ = self.type_scheduler.backward_remove_noise(logits[lig_rows], c_lig, t, bl, gen_l,
-                                                                     pred_logit=True, uniform=u)
-            traj_x[t_idx], traj_c[t_idx] = x_lig, c_lig
+            self.denoise_step(st, t_idx, noise_tape[t_idx] if noise_tape is not None else None)
         out_dev = torch.device("cpu") if return_device is None else torch.device(return_device)
-        traj_x, traj_c, bl_out = traj_x.to(out_dev), traj_c.to(out_dev), bl.to(out_dev)
+        traj_x, traj_c, bl_out = st["traj_x"].to(out_dev), st["traj_c"].to(out_dev), st["bl"].to(out_dev)
         return {t - 1: (traj_x[t], traj_c[t], bl_out) for t in range(T + 1)}

@@ -264,8 +264,9 @@ class DiffSBDD(nn.Module):
         return {"pos": loss_pos, "atom": loss_atom}, results
 
     @torch.no_grad()
-    def sample(self, batch, noise_draws=None, return_device=None):
-        """diffsbdd.py:240-319. ``noise_draws`` (tests): list of the randn tensors in the reference's draw order."""
+    def begin_sampling(self, batch, keep_trajectory=True, noise_draws=None):
+        """Everything of ``sample`` (diffsbdd.py:240-319) before the loop: composition plan, protein features, the initial
+        zero-COM draws.  ``noise_draws`` (tests): the randn tensors in the reference's draw order, consumed across the steps."""
         sch = self.pos_scheduler
         x_rec = batch["protein_pos"].float()
         dev = x_rec.device
@@ -279,7 +280,6 @@ class DiffSBDD(nn.Module):
         n_lig, n_rec = bl.shape[0], x_rec.shape[0]
         draws = iter(noise_draws) if noise_draws is not None else None
         nxt = (lambda: next(draws).to(dev)) if draws is not None else (lambda: None)
-
         aa = F.one_hot(batch["protein_aa_type"], NUM_AA).float()
         sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = TargetDiff.compose_plan(bl, br, B)
         gen_flag = torch.cat([gen_r, gen_l], 0)[sort_idx]
@@ -287,45 +287,75 @@ class DiffSBDD(nn.Module):
         x = torch.empty(n_rec + n_lig, 3, dtype=torch.float32, device=dev)
         h = torch.empty(n_rec + n_lig, self.context_embedder.emb_dim, dtype=torch.float32, device=dev)
         h[rec_rows] = self.context_embedder.embed_protein(v_rec, aa)          # step-invariant
-
-        def denoise(x_lig, c_lig, x_rec_now):
-            x[rec_rows] = x_rec_now                                          # the pocket is translated every draw
-            x[lig_rows] = x_lig
-            h[lig_rows] = self.context_embedder.embed_ligand(c_lig)
-            xo, _, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
-                                          graph_ptr=graph_ptr, need_h=False)
-            return xo[lig_rows], logits[lig_rows]
-
         mu_x = sch.scatter_mean(x_rec, br, B)[bl]
         mu_h = torch.zeros(B, C, device=dev)[bl]
         sigma1 = torch.ones(B, 1, device=dev)
         x_lig, x_rec = sch.sample_normal_zero_com(mu_x, x_rec, sigma1, bl, br, B, com=True, eps=nxt())
         c_lig = sch.sample_normal_zero_com(mu_h, v_rec, sigma1, bl, br, B, com=False, eps=nxt())
+        st = {"B": B, "N": n_rec + n_lig, "n_lig": n_lig, "x": x, "h": h, "x_lig": x_lig, "c_lig": c_lig, "x_rec": x_rec,
+              "v_rec": v_rec, "bl": bl, "br": br, "batch_idx": batch_idx, "lig_flag": lig_flag, "gen_flag": gen_flag,
+              "lig_rows": lig_rows, "rec_rows": rec_rows, "graph_ptr": graph_ptr, "nxt": nxt, "drawn": draws is not None,
+              "traj_x": None, "traj_c": None}
+        if keep_trajectory:
+            st["traj_x"] = torch.empty(T + 1, n_lig, 3, dtype=torch.float32, device=dev)
+            st["traj_c"] = torch.empty(T + 1, n_lig, C, dtype=torch.float32, device=dev)
+            st["traj_x"][T], st["traj_c"][T] = x_lig, c_lig
+        return st
 
-        traj_x = torch.empty(T + 1, n_lig, 3, dtype=torch.float32, device=dev)
-        traj_c = torch.empty(T + 1, n_lig, C, dtype=torch.float32, device=dev)
-        traj_x[T], traj_c[T] = x_lig, c_lig
-        for t_idx in reversed(range(T)):
-            s = torch.full((B,), t_idx, device=dev) / T
-            t = (torch.full((B,), t_idx, device=dev) + 1) / T
-            x_pred, c_out = denoise(x_lig, c_lig, x_rec)
-            if self.denoise_structure:
-                x_lig, x_rec = sch.sample_p_zs_given_zt(s, t, x_lig, x_rec, bl, br, B, x_pred, com=True, eps=nxt())
-            if self.denoise_atom:
-                c_lig, _ = sch.sample_p_zs_given_zt(s, t, c_lig, v_rec, bl, br, B, c_out, com=False, eps=nxt())
-            traj_x[t_idx], traj_c[t_idx] = x_lig, c_lig
+    def _denoise(self, st):
+        x, h = st["x"], st["h"]
+        x[st["rec_rows"]] = st["x_rec"]                                       # the pocket is translated every draw
+        x[st["lig_rows"]] = st["x_lig"]
+        h[st["lig_rows"]] = self.context_embedder.embed_ligand(st["c_lig"])
+        xo, _, logits = self.denoiser(x=x, h=h, batch_idx=st["batch_idx"], lig_flag=st["lig_flag"], gen_flag=st["gen_flag"],
+                                      graph_ptr=st["graph_ptr"], need_h=False)
+        return xo[st["lig_rows"]], logits[st["lig_rows"]]
 
-        # sample_p_xh_given_z0 (diffsbdd.py:321-352)
+    @torch.no_grad()
+    def denoise_step(self, st, t_idx, noise=None):
+        """One reverse step s = t_idx / T <- t = (t_idx + 1) / T (diffsbdd.py:296-304): denoiser call and the two
+        sample_p_zs_given_zt draws.  ``noise`` is ignored when the state was built with ``noise_draws``."""
+        sch, T, B = self.pos_scheduler, self.num_diffusion_timesteps, st["B"]
+        dev = st["x"].device
+        bl, br, nxt = st["bl"], st["br"], st["nxt"]
+        s = torch.full((B,), t_idx, device=dev) / T
+        t = (torch.full((B,), t_idx, device=dev) + 1) / T
+        x_pred, c_out = self._denoise(st)
+        if self.denoise_structure:
+            st["x_lig"], st["x_rec"] = sch.sample_p_zs_given_zt(s, t, st["x_lig"], st["x_rec"], bl, br, B, x_pred, com=True,
+                                                                eps=nxt())
+        if self.denoise_atom:
+            st["c_lig"], _ = sch.sample_p_zs_given_zt(s, t, st["c_lig"], st["v_rec"], bl, br, B, c_out, com=False, eps=nxt())
+        if st["traj_x"] is not None:
+            st["traj_x"][t_idx], st["traj_c"][t_idx] = st["x_lig"], st["c_lig"]
+        return st
+
+    @torch.no_grad()
+    def finish_sampling(self, st):
+        """sample_p_xh_given_z0 (diffsbdd.py:321-352): the final denoiser call and the x draw; returns (x_final, c_final)."""
+        sch, B, C = self.pos_scheduler, st["B"], self.num_classes
+        dev = st["x"].device
+        bl, br, nxt = st["bl"], st["br"], st["nxt"]
         g0 = sch.gamma(torch.zeros(B, device=dev))
         sigma0 = torch.exp(0.5 * g0).unsqueeze(1)
-        x_pred, c_out = denoise(x_lig, c_lig, x_rec)
+        x_pred, c_out = self._denoise(st)
         sig_t = torch.sqrt(torch.sigmoid(g0)).view(-1, 1)
         alp_t = torch.sqrt(torch.sigmoid(-g0)).view(-1, 1)
-        mu_x = 1.0 / alp_t[bl] * (x_lig - sig_t[bl] * x_pred)
-        x_fin, _ = sch.sample_normal_zero_com(mu_x, x_rec, sigma0, bl, br, B, com=True, eps=nxt())
-        nxt() if draws is not None else torch.randn(n_lig, C, device=dev)   # the reference draws and discards it
+        mu_x = 1.0 / alp_t[bl] * (st["x_lig"] - sig_t[bl] * x_pred)
+        x_fin, _ = sch.sample_normal_zero_com(mu_x, st["x_rec"], sigma0, bl, br, B, com=True, eps=nxt())
+        nxt() if st["drawn"] else torch.randn(st["n_lig"], C, device=dev)   # the reference draws and discards it
+        return x_fin, st["c_lig"] * 4.0
+
+    @torch.no_grad()
+    def sample(self, batch, noise_draws=None, return_device=None):
+        """diffsbdd.py:240-319. ``noise_draws`` (tests): list of the randn tensors in the reference's draw order."""
+        T = self.num_diffusion_timesteps
+        st = self.begin_sampling(batch, keep_trajectory=True, noise_draws=noise_draws)
+        for t_idx in reversed(range(T)):
+            self.denoise_step(st, t_idx)
+        x_fin, c_fin = self.finish_sampling(st)
         out_dev = torch.device("cpu") if return_device is None else torch.device(return_device)
-        traj_x, traj_c, bl_out = traj_x.to(out_dev), traj_c.to(out_dev), bl.to(out_dev)
+        traj_x, traj_c, bl_out = st["traj_x"].to(out_dev), st["traj_c"].to(out_dev), st["bl"].to(out_dev)
         traj = {t - 1: (traj_x[t], traj_c[t], bl_out) for t in range(T + 1)}
-        traj[0] = (x_fin.to(out_dev), (c_lig * 4.0).to(out_dev), bl_out)
+        traj[0] = (x_fin.to(out_dev), c_fin.to(out_dev), bl_out)
         return traj
