@@ -35,6 +35,10 @@ EXPORTS = {
                                       _vp, _vp]),
     "cbgx_targetdiff_prologue_traj": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cbgx_targetdiff_epilogue_traj": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp]),
+    "cbgx_diffbp_epilogue": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp,
+                                  _vp, _vp]),
+    "cbgx_diffsbdd_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_float, ctypes.c_float,
+                                ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cbgx_train_tape_bytes": (_sz, [_i, _i]),
     "cbgx_train_workspace_bytes": (_sz, [_i]),
     "cbgx_unitransformer_forward_train": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz,

@@ -579,6 +579,43 @@ int cbgx_targetdiff_epilogue(const float* x_den, const float* logits, const int3
     return CBGX_OK;
 }
 
+int cbgx_diffbp_epilogue(const float* x_den, const float* x_com, const float* x_in, const float* logits,
+                         const int32_t* lig_rows, const int32_t* lig_ptr, const float* x_lig, const float* c_lig,
+                         const uint8_t* gen_lig, int n_lig, int n_graphs, int num_classes, int t, int num_timesteps,
+                         const float* alphas_cumprod, const float* betas, int absorbing_state, const float* eps,
+                         const float* u, float* x_next, float* c_next, void* stream) {
+    if (n_lig == 0 || n_graphs == 0) return CBGX_OK;
+    if (n_lig < 0 || n_graphs < 0 || num_classes < 1 || num_classes > 32 || t < 0 || t >= num_timesteps ||
+        absorbing_state < 0 || absorbing_state >= num_classes)
+        return fail(CBGX_E_INVALID, "diffbp_epilogue: bad sizes (n_lig=%d B=%d C=%d t=%d T=%d)", n_lig, n_graphs, num_classes, t,
+                    num_timesteps);
+    if (!x_den || !x_com || !x_in || !logits || !lig_rows || !lig_ptr || !x_lig || !c_lig || !gen_lig || !alphas_cumprod ||
+        !betas || !eps || !u || !x_next || !c_next)
+        return fail(CBGX_E_INVALID, "diffbp_epilogue: NULL pointer");
+    HIP_TRY(launch_diffbp_epilogue(x_den, x_com, x_in, logits, lig_rows, lig_ptr, x_lig, c_lig, gen_lig, n_graphs, num_classes, t,
+                                   num_timesteps, alphas_cumprod, betas, absorbing_state, eps, u, x_next, c_next,
+                                   (hipStream_t)stream));
+    return CBGX_OK;
+}
+
+int cbgx_diffsbdd_step(const float* x_den, const float* logits, const int32_t* graph_ptr, const int32_t* lig_rows,
+                       const int32_t* lig_ptr, const uint8_t* lig_flag, const float* x_lig, const float* c_lig, int n_lig,
+                       int n_graphs, int num_classes, float inv_alpha, float coef, float sigma, int update_positions,
+                       int update_types, const float* eps_x, const float* eps_c, const float* lig_emb_w,
+                       const float* lig_emb_b, const float* ind_w, const float* ind_b, float* x_next, float* c_next,
+                       float* x, float* h, float* shift, void* stream) {
+    if (n_lig == 0 || n_graphs == 0) return CBGX_OK;
+    if (n_lig < 0 || n_graphs < 0 || num_classes < 1 || num_classes > 32)
+        return fail(CBGX_E_INVALID, "diffsbdd_step: bad sizes (n_lig=%d B=%d C=%d)", n_lig, n_graphs, num_classes);
+    if (!x_den || !logits || !graph_ptr || !lig_rows || !lig_ptr || !lig_flag || !x_lig || !c_lig || !lig_emb_w || !lig_emb_b ||
+        !ind_w || !ind_b || !x_next || !c_next || !x || !h || (update_positions && !eps_x) || (update_types && !eps_c))
+        return fail(CBGX_E_INVALID, "diffsbdd_step: NULL pointer");
+    HIP_TRY(launch_diffsbdd_step(x_den, logits, graph_ptr, lig_rows, lig_ptr, lig_flag, x_lig, c_lig, n_graphs, num_classes,
+                                 inv_alpha, coef, sigma, update_positions, update_types, eps_x, eps_c, lig_emb_w, lig_emb_b, ind_w,
+                                 ind_b, x_next, c_next, x, h, shift, (hipStream_t)stream));
+    return CBGX_OK;
+}
+
 // ---- trajectory-resident variants (one captured hipGraph can then be replayed for every step) ---------------------
 int cbgx_targetdiff_prologue_traj(const float* traj_x, const float* traj_c, const int32_t* t_dev, const int32_t* lig_rows,
                                   int n_lig, int num_classes, const float* lig_emb_w, const float* lig_emb_b,

@@ -82,6 +82,17 @@ hipError_t launch_step_epilogue(const float* x_den, const float* logits, const i
                                 const float* c_lig, const uint8_t* gen_lig, int n_lig, int C, int t,
                                 const float* const* tabs, float log_c, const float* eps, const float* u, float* x_next,
                                 float* c_next, int32_t* v_next, hipStream_t s, int32_t* t_ptr = nullptr);
+hipError_t launch_diffbp_epilogue(const float* x_den, const float* x_com, const float* x_in, const float* logits,
+                                  const int32_t* lig_rows, const int32_t* lig_ptr, const float* x_lig, const float* c_lig,
+                                  const uint8_t* gen_lig, int n_graphs, int C, int t, int T, const float* acp_tab,
+                                  const float* beta_tab, int absorbing, const float* eps, const float* u, float* x_next,
+                                  float* c_next, hipStream_t s);
+hipError_t launch_diffsbdd_step(const float* x_den, const float* logits, const int32_t* graph_ptr, const int32_t* lig_rows,
+                                const int32_t* lig_ptr, const uint8_t* lig_flag, const float* x_lig, const float* c_lig,
+                                int n_graphs, int C, float inv_alpha, float coef, float sigma, int do_x, int do_c,
+                                const float* eps_x, const float* eps_c, const float* emb_w, const float* emb_b,
+                                const float* ind_w, const float* ind_b, float* x_next, float* c_next, float* x, float* h,
+                                float* shift_out, hipStream_t s);
 constexpr int PACK_MAX = 64;
 struct PackPiece {
     const float* src; float* dst; int src_ld, src_off, transpose, dst_ld, rows, cols;

@@ -175,6 +175,23 @@ class CoMPredictor(nn.Module):
             self._packed, self._packed_key = packed, key
         return self._packed
 
+    @torch.no_grad()
+    def stack_forward(self, x_in, h_in, graph_ptr, lig8, gen8):
+        """the raw output coordinates [N,3] of the H2X stack on its own kNN graph (one cbgx_h2x_stack_forward call)"""
+        dev = x_in.device
+        N, B = x_in.shape[0], graph_ptr.numel() - 1
+        lib = _native.lib()
+        need = lib.cbgx_workspace_bytes(N, B)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        x_out = torch.empty_like(x_in)
+        rc = lib.cbgx_h2x_stack_forward(
+            _native.ptr(self.packed_weights(dev)), self.num_layers, _native.ptr(x_in), _native.ptr(h_in),
+            _native.ptr(graph_ptr), _native.ptr(lig8), _native.ptr(gen8), N, B, _native.ptr(x_out),
+            _native.ptr(self._workspace), self._workspace.numel(), _native.current_stream(dev))
+        _native.check(rc, "cbgx_h2x_stack_forward")
+        return x_out
+
     def forward(self, x_lig_pred, batch_idx_lig, x_composed, h_composed, gen_flag_composed, lig_flag_composed,
                 batch_idx_composed, graph_ptr=None, n_graphs=None):
         """-> (zero-COM noise prediction [N_lig,3], per-graph mean shift of the ligand [N_lig,3]) (diffbp.py:79-101)."""
@@ -200,14 +217,8 @@ class CoMPredictor(nn.Module):
                                             gen_flag_composed.to(torch.uint8).contiguous(), *self._ordered_params())
             delta = (x_out - x_in)[lig_flag_composed]
             return noise, _S.scatter_mean(delta, batch_idx_lig, B)[batch_idx_lig]
-        h_in = h_composed.detach().float().contiguous()
-        x_out = torch.empty_like(x_in)
-        rc = lib.cbgx_h2x_stack_forward(
-            _native.ptr(self.packed_weights(dev)), self.num_layers, _native.ptr(x_in), _native.ptr(h_in),
-            _native.ptr(graph_ptr), _native.ptr(lig_flag_composed.to(torch.uint8).contiguous()),
-            _native.ptr(gen_flag_composed.to(torch.uint8).contiguous()), N, B, _native.ptr(x_out),
-            _native.ptr(self._workspace), self._workspace.numel(), _native.current_stream(dev))
-        _native.check(rc, "cbgx_h2x_stack_forward")
+        x_out = self.stack_forward(x_in, h_composed.detach().float().contiguous(), graph_ptr,
+                                   lig_flag_composed.to(torch.uint8).contiguous(), gen_flag_composed.to(torch.uint8).contiguous())
         delta = (x_out - x_in)[lig_flag_composed]
         shift = _S.scatter_mean(delta, batch_idx_lig, B)[batch_idx_lig]
         return noise, shift
@@ -315,8 +326,10 @@ class DiffBP(nn.Module):
         return {"pos": loss_pos, "atom": loss_atom, "com": loss_com, "inter": loss_inter}, results
 
     @torch.no_grad()
-    def begin_sampling(self, batch, keep_trajectory=True):
-        """Step-invariant part of ``sample`` (diffbp.py:240-262): composition plan, protein rows of x / h, flags."""
+    def begin_sampling(self, batch, keep_trajectory=True, static_cache=True):
+        """Step-invariant part of ``sample`` (diffbp.py:240-262): composition plan, protein rows of x / h, flags -- and, as in
+        TargetDiff.begin_sampling, the static-context cache of the denoiser (the pocket never moves in DiffBP either: what the
+        ligand-free pocket produces in layers 0 / 1, its neighbour lists and gate values are computed once per run)."""
         x_lig = batch["ligand_pos"].float()
         dev = x_lig.device
         x_rec = batch["protein_pos"].float()
@@ -339,7 +352,19 @@ class DiffBP(nn.Module):
         h[rec_rows] = self.context_embedder.embed_protein(v_rec, aa)
         st = {"B": B, "N": n_rec + n_lig, "n_lig": n_lig, "x": x, "h": h, "x_lig": x_lig, "c_lig": c_lig, "bl": bl,
               "gen_l": gen_l, "batch_idx": batch_idx, "lig_flag": lig_flag, "gen_flag": gen_flag, "lig_rows": lig_rows,
-              "graph_ptr": graph_ptr, "traj_x": None, "traj_c": None}
+              "graph_ptr": graph_ptr, "traj_x": None, "traj_c": None, "static_h": None}
+        if dev.type == "cuda" and static_cache and not bool(gen_r.any()):
+            st["static_h"] = self.denoiser.static_context(x_rec, h[rec_rows], br, rec_rows, n_rec + n_lig)
+        # operands of the native step kernels (include/cbgx.h: cbgx_targetdiff_prologue, cbgx_diffbp_epilogue); they need the
+        # ligand arrays sorted by graph, which is how every collate of the reference lays them out
+        st["native"] = dev.type == "cuda" and self.denoise_structure and self.denoise_atom and bool((bl[1:] >= bl[:-1]).all())
+        if st["native"]:
+            st["lig_rows32"] = lig_rows.to(torch.int32).contiguous()
+            st["gen_l8"] = gen_l.to(torch.uint8).contiguous()
+            st["lig8"], st["gen8"] = lig_flag.to(torch.uint8).contiguous(), gen_flag.to(torch.uint8).contiguous()
+            st["lig_ptr"] = torch.cat([torch.zeros(1, dtype=torch.long, device=dev),
+                                       torch.bincount(bl, minlength=B).cumsum(0)]).to(torch.int32).contiguous()
+            st["x_lig"], st["c_lig"] = x_lig.contiguous(), c_lig.contiguous()
         if keep_trajectory:
             st["traj_x"] = torch.empty(T + 1, n_lig, 3, dtype=torch.float32, device=dev)
             st["traj_c"] = torch.empty(T + 1, n_lig, C, dtype=torch.float32, device=dev)
@@ -351,12 +376,14 @@ class DiffBP(nn.Module):
         """One reverse step (diffbp.py:263-296): denoiser, CoMPredictor, score step on the positions, mask-type step.
         ``noise``: (eps [N_lig,3], u [N_lig]) replacing randn_like / rand_like."""
         dev = st["x"].device
+        if st.get("native"):
+            return self._denoise_step_native(st, t_idx, noise)
         t = torch.full((st["B"],), t_idx, dtype=torch.long, device=dev)
         x, h, lig_rows, bl, gen_l = st["x"], st["h"], st["lig_rows"], st["bl"], st["gen_l"]
         x[lig_rows] = st["x_lig"]
         h[lig_rows] = self.context_embedder.embed_ligand(st["c_lig"])
         xo, ho, logits = self.denoiser(x=x, h=h, batch_idx=st["batch_idx"], lig_flag=st["lig_flag"], gen_flag=st["gen_flag"],
-                                       graph_ptr=st["graph_ptr"])
+                                       graph_ptr=st["graph_ptr"], static_h=st["static_h"])
         eps_t, eps_com = self.com_head(xo[lig_rows], bl, x, ho, st["gen_flag"], st["lig_flag"], st["batch_idx"],
                                        graph_ptr=st["graph_ptr"])
         eps, u = noise if noise is not None else (None, None)
@@ -368,6 +395,40 @@ class DiffBP(nn.Module):
                                                                        pred_logit=True, uniform=u)
         if st["traj_x"] is not None:
             st["traj_x"][t_idx], st["traj_c"][t_idx] = st["x_lig"], st["c_lig"]
+        return st
+
+    def _denoise_step_native(self, st, t_idx, noise):
+        """the same step with the arithmetic around the two network calls in two kernels (csrc/step.hip)"""
+        lib = _native.lib()
+        dev = st["x"].device
+        stream = _native.current_stream(dev)
+        n_lig, C, B = st["n_lig"], self.num_classes, st["B"]
+        x_lig, c_lig, x, h = st["x_lig"], st["c_lig"], st["x"], st["h"]
+        emb, ps = self.context_embedder, self.pos_scheduler
+        _native.check(lib.cbgx_targetdiff_prologue(
+            _native.ptr(x_lig), _native.ptr(c_lig), _native.ptr(st["lig_rows32"]), n_lig, C,
+            _native.ptr(emb.ligand_atom_emb.weight), _native.ptr(emb.ligand_atom_emb.bias),
+            _native.ptr(emb.ligand_indicator.weight), _native.ptr(emb.ligand_indicator.bias),
+            _native.ptr(x), _native.ptr(h), stream), "cbgx_targetdiff_prologue")
+        xo, ho, logits = self.denoiser(x=x, h=h, batch_idx=st["batch_idx"], lig_flag=st["lig_flag"], gen_flag=st["gen_flag"],
+                                       graph_ptr=st["graph_ptr"], static_h=st["static_h"])
+        x_com = self.com_head.stack_forward(x, ho, st["graph_ptr"], st["lig8"], st["gen8"])
+        if noise is not None:
+            eps, u = noise[0].float().contiguous(), noise[1].float().contiguous()
+        else:   # the reference's draw order: randn_like(x_lig), then rand_like(v_t)
+            eps = torch.randn(n_lig, 3, dtype=torch.float32, device=dev)
+            u = torch.rand(n_lig, dtype=torch.float32, device=dev)
+        if st["traj_x"] is not None:
+            x_next, c_next = st["traj_x"][t_idx], st["traj_c"][t_idx]
+        else:
+            x_next, c_next = torch.empty_like(x_lig), torch.empty_like(c_lig)
+        _native.check(lib.cbgx_diffbp_epilogue(
+            _native.ptr(xo), _native.ptr(x_com), _native.ptr(x), _native.ptr(logits), _native.ptr(st["lig_rows32"]),
+            _native.ptr(st["lig_ptr"]), _native.ptr(x_lig), _native.ptr(c_lig), _native.ptr(st["gen_l8"]), n_lig, B, C,
+            int(t_idx), self.num_diffusion_timesteps, _native.ptr(ps.alphas_cumprod), _native.ptr(ps.betas),
+            self.type_scheduler.absorbing_state, _native.ptr(eps), _native.ptr(u), _native.ptr(x_next), _native.ptr(c_next),
+            stream), "cbgx_diffbp_epilogue")
+        st["x_lig"], st["c_lig"] = x_next, c_next
         return st
 
     @torch.no_grad()

@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _native
 from .registry import get_e3_gnn, register_model
 from .targetdiff import NUM_AA, PLContextEmbedder, TargetDiff
 
@@ -300,10 +301,40 @@ class DiffSBDD(nn.Module):
             st["traj_x"] = torch.empty(T + 1, n_lig, 3, dtype=torch.float32, device=dev)
             st["traj_c"] = torch.empty(T + 1, n_lig, C, dtype=torch.float32, device=dev)
             st["traj_x"][T], st["traj_c"][T] = x_lig, c_lig
+        # native step (include/cbgx.h: cbgx_diffsbdd_step): the composed x / h are then kept up to date on the device by the
+        # step kernel itself (pocket translated in place, ligand rows rewritten), st["x_rec"] is only refreshed on demand
+        st["native"] = dev.type == "cuda" and bool((bl[1:] >= bl[:-1]).all())
+        if st["native"]:
+            st["lig_rows32"] = lig_rows.to(torch.int32).contiguous()
+            st["lig8"] = lig_flag.to(torch.uint8).contiguous()
+            st["lig_ptr"] = torch.cat([torch.zeros(1, dtype=torch.long, device=dev),
+                                       torch.bincount(bl, minlength=B).cumsum(0)]).to(torch.int32).contiguous()
+            st["coef"] = self.step_tables()
+            st["x_lig"], st["c_lig"] = x_lig.contiguous(), c_lig.contiguous()
+            x[rec_rows], x[lig_rows] = x_rec, x_lig
+            h[lig_rows] = self.context_embedder.embed_ligand(c_lig)
         return st
+
+    def step_tables(self):
+        """(1 / alpha_ts, sigma2_ts / alpha_ts / sigma_t, sigma_ts sigma_s / sigma_t) of every step s = k / T <- t = (k + 1) / T
+        as Python floats, from the scheduler's own expressions (sample_p_zs_given_zt above; diffusion_scheduler.py:982-1040),
+        evaluated once on the host in fp32"""
+        sch, T = self.pos_scheduler, self.num_diffusion_timesteps
+        g = sch.gamma.gamma.detach().float().cpu()
+        k = torch.arange(T)
+        gs, gt = g[torch.round(k / T * T).long()], g[torch.round((k + 1) / T * T).long()]
+        sigma2_ts = -torch.expm1(F.softplus(gs) - F.softplus(gt))
+        alpha_ts = torch.exp(0.5 * (F.logsigmoid(-gt) - F.logsigmoid(-gs)))
+        sigma_s, sigma_t = torch.sqrt(torch.sigmoid(gs)), torch.sqrt(torch.sigmoid(gt))
+        return ((1.0 / alpha_ts).tolist(), (sigma2_ts / alpha_ts / sigma_t).tolist(),
+                (torch.sqrt(sigma2_ts) * sigma_s / sigma_t).tolist())
 
     def _denoise(self, st):
         x, h = st["x"], st["h"]
+        if st.get("native"):   # x / h already hold the current state
+            xo, _, logits = self.denoiser(x=x, h=h, batch_idx=st["batch_idx"], lig_flag=st["lig_flag"],
+                                          gen_flag=st["gen_flag"], graph_ptr=st["graph_ptr"], need_h=False)
+            return xo[st["lig_rows"]], logits[st["lig_rows"]]
         x[st["rec_rows"]] = st["x_rec"]                                       # the pocket is translated every draw
         x[st["lig_rows"]] = st["x_lig"]
         h[st["lig_rows"]] = self.context_embedder.embed_ligand(st["c_lig"])
@@ -318,6 +349,8 @@ class DiffSBDD(nn.Module):
         sch, T, B = self.pos_scheduler, self.num_diffusion_timesteps, st["B"]
         dev = st["x"].device
         bl, br, nxt = st["bl"], st["br"], st["nxt"]
+        if st.get("native"):
+            return self._denoise_step_native(st, t_idx)
         s = torch.full((B,), t_idx, device=dev) / T
         t = (torch.full((B,), t_idx, device=dev) + 1) / T
         x_pred, c_out = self._denoise(st)
@@ -330,6 +363,37 @@ class DiffSBDD(nn.Module):
             st["traj_x"][t_idx], st["traj_c"][t_idx] = st["x_lig"], st["c_lig"]
         return st
 
+    def _denoise_step_native(self, st, t_idx):
+        lib = _native.lib()
+        dev = st["x"].device
+        n_lig, C, B = st["n_lig"], self.num_classes, st["B"]
+        x, h, x_lig, c_lig, nxt = st["x"], st["h"], st["x_lig"], st["c_lig"], st["nxt"]
+        xo, _, logits = self.denoiser(x=x, h=h, batch_idx=st["batch_idx"], lig_flag=st["lig_flag"], gen_flag=st["gen_flag"],
+                                      graph_ptr=st["graph_ptr"], need_h=False)
+        eps_x = eps_c = None
+        if self.denoise_structure:      # the reference's draw order: positions, then types
+            eps_x = nxt()
+            eps_x = torch.randn(n_lig, 3, dtype=torch.float32, device=dev) if eps_x is None else eps_x.float().contiguous()
+        if self.denoise_atom:
+            eps_c = nxt()
+            eps_c = torch.randn(n_lig, C, dtype=torch.float32, device=dev) if eps_c is None else eps_c.float().contiguous()
+        if st["traj_x"] is not None:
+            x_next, c_next = st["traj_x"][t_idx], st["traj_c"][t_idx]
+        else:
+            x_next, c_next = torch.empty_like(x_lig), torch.empty_like(c_lig)
+        emb = self.context_embedder
+        inv_alpha, coef, sigma = (tab[t_idx] for tab in st["coef"])
+        _native.check(lib.cbgx_diffsbdd_step(
+            _native.ptr(xo), _native.ptr(logits), _native.ptr(st["graph_ptr"]), _native.ptr(st["lig_rows32"]),
+            _native.ptr(st["lig_ptr"]), _native.ptr(st["lig8"]), _native.ptr(x_lig), _native.ptr(c_lig), n_lig, B, C,
+            inv_alpha, coef, sigma, int(self.denoise_structure), int(self.denoise_atom), _native.ptr(eps_x), _native.ptr(eps_c),
+            _native.ptr(emb.ligand_atom_emb.weight), _native.ptr(emb.ligand_atom_emb.bias),
+            _native.ptr(emb.ligand_indicator.weight), _native.ptr(emb.ligand_indicator.bias), _native.ptr(x_next),
+            _native.ptr(c_next), _native.ptr(x), _native.ptr(h), None, _native.current_stream(dev)), "cbgx_diffsbdd_step")
+        st["x_lig"], st["c_lig"] = x_next, c_next
+        st["x_rec"] = None      # lives in x[rec_rows] now
+        return st
+
     @torch.no_grad()
     def finish_sampling(self, st):
         """sample_p_xh_given_z0 (diffsbdd.py:321-352): the final denoiser call and the x draw; returns (x_final, c_final)."""
@@ -339,6 +403,8 @@ class DiffSBDD(nn.Module):
         g0 = sch.gamma(torch.zeros(B, device=dev))
         sigma0 = torch.exp(0.5 * g0).unsqueeze(1)
         x_pred, c_out = self._denoise(st)
+        if st["x_rec"] is None:
+            st["x_rec"] = st["x"][st["rec_rows"]]
         sig_t = torch.sqrt(torch.sigmoid(g0)).view(-1, 1)
         alp_t = torch.sqrt(torch.sigmoid(-g0)).view(-1, 1)
         mu_x = 1.0 / alp_t[bl] * (st["x_lig"] - sig_t[bl] * x_pred)

@@ -185,6 +185,30 @@ int cbgx_targetdiff_epilogue_traj(const float *x_den, const float *logits, const
                                   float *traj_c, const uint8_t *gen_lig, int n_lig, int num_classes, int32_t *t_dev,
                                   const float *const *tables, const float *eps, const float *u, void *stream);
 
+/* ---- DiffBP / DiffSBDD: the per-step arithmetic around the network calls, one launch per step -------------------
+ * cbgx_diffbp_epilogue: diffbp.py:262-297 after the denoiser and the CoMPredictor stack -- zero-COM noise estimate,
+ *   mean shift of the H2X stack (CoMPredictor.forward, diffbp.py:79-101), score step on the positions
+ *   (CTNVPScheduler.backward_remove_noise(type='score'), diffusion_scheduler.py:154-158) and the absorbing-state type
+ *   step (MaskTypeSchedule.backward_remove_noise, :475-496).  x_den / x_com / x_in: [N,3] denoiser output, H2X-stack
+ *   output and their common input; lig_ptr [B+1]: ligand atoms of graph g are [lig_ptr[g], lig_ptr[g+1]) (ligand arrays are
+ *   sorted by graph); tables: alphas_cumprod [T], betas [T] of the position scheduler; eps [n_lig,3], u [n_lig].
+ * cbgx_diffsbdd_step: one iteration of diffsbdd.py:296-304 after the denoiser (sample_p_zs_given_zt for positions with
+ *   the ligand's centre of mass removed and the pocket translated with it, and for types; diffusion_scheduler.py:1012-1040).
+ *   inv_alpha, coef, sigma: 1 / alpha_ts, sigma2_ts / alpha_ts / sigma_t and sigma_ts sigma_s / sigma_t of the step.  Updates
+ *   the composed x IN PLACE (pocket rows of every graph, ligand rows) and writes h on ligand rows from the new types, so
+ *   that the next denoiser call needs no prologue; shift [B,3] (may be NULL) receives the removed mean per graph. */
+int cbgx_diffbp_epilogue(const float *x_den, const float *x_com, const float *x_in, const float *logits,
+                         const int32_t *lig_rows, const int32_t *lig_ptr, const float *x_lig, const float *c_lig,
+                         const uint8_t *gen_lig, int n_lig, int n_graphs, int num_classes, int t, int num_timesteps,
+                         const float *alphas_cumprod, const float *betas, int absorbing_state, const float *eps,
+                         const float *u, float *x_next, float *c_next, void *stream);
+int cbgx_diffsbdd_step(const float *x_den, const float *logits, const int32_t *graph_ptr, const int32_t *lig_rows,
+                       const int32_t *lig_ptr, const uint8_t *lig_flag, const float *x_lig, const float *c_lig, int n_lig,
+                       int n_graphs, int num_classes, float inv_alpha, float coef, float sigma, int update_positions,
+                       int update_types, const float *eps_x, const float *eps_c, const float *lig_emb_w,
+                       const float *lig_emb_b, const float *ind_w, const float *ind_b, float *x_next, float *c_next,
+                       float *x, float *h, float *shift, void *stream);
+
 /* ---- training: taped forward and backward -----------------------------------------------------------
  * train.py:185-189 runs `loss_dict, _ = model(batch); loss.backward()`; autograd walks UniTransformer.forward
  * (unitransformer.py:102-123) backwards through every X2HAttention / H2XAttention (x2h_attention.py:43-97,

@@ -127,6 +127,70 @@ def _bp_model(T):
     return m.to(DEV), sd
 
 
+def test_diffbp_static_context_cache_is_exact():
+    """DiffBP.begin_sampling keeps the denoiser's static-context cache (the pocket never moves, diffbp.py:262-297): three
+    steps on real-size pockets with and without it, identical bits although DiffBP also consumes the denoiser's h'"""
+    m, _ = _bp_model(1000)
+    batch = synthetic.batch_to(synthetic.denovo_batch(3, seed=31), DEV)
+    n_lig = batch["ligand_pos"].shape[0]
+    g = torch.Generator(device=DEV).manual_seed(5)
+    noise = [(torch.randn(n_lig, 3, device=DEV, generator=g), torch.rand(n_lig, device=DEV, generator=g)) for _ in range(3)]
+    outs = []
+    for cache in (True, False):
+        st = m.begin_sampling(batch, keep_trajectory=False, static_cache=cache)
+        assert (st["static_h"] is not None) == cache
+        for k, t in enumerate((999, 998, 300)):
+            m.denoise_step(st, t, noise=noise[k])
+        outs.append((st["x_lig"].clone(), st["c_lig"].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("name", ["diffbp", "diffsbdd"])
+def test_native_step_kernels_match_the_torch_step(name):
+    """cbgx_diffbp_epilogue / cbgx_diffsbdd_step (one launch around the network calls) against the same step written with
+    torch ops on the device (the restatement of diffbp.py:262-297 / diffsbdd.py:296-304 that the oracle tests pin): three
+    steps on real-size pockets with shared noise; positions within 2e-6 absolute (per-graph means are summed in a different
+    order), DiffBP's discrete types identical, DiffSBDD's continuous types within 2e-6."""
+    if name == "diffbp":
+        m, _ = _bp_model(1000)
+    else:
+        m = C.get_model(C.default_diffsbdd_config(8)).eval()
+        m.load_state_dict(W.synthetic_state_dict_diffsbdd(8, 9, seed=0, num_timesteps=1000), strict=True)
+        m = m.to(DEV)
+    Cn = m.num_classes
+    batch = synthetic.batch_to(synthetic.denovo_batch(4, seed=52, num_classes=Cn), DEV)
+    n_lig = batch["ligand_pos"].shape[0]
+    g = torch.Generator(device=DEV).manual_seed(9)
+    if name == "diffbp":
+        noise = [(torch.randn(n_lig, 3, device=DEV, generator=g), torch.rand(n_lig, device=DEV, generator=g)) for _ in range(3)]
+        draws = None
+    else:
+        draws = [torch.randn(n_lig, 3, device=DEV, generator=g), torch.randn(n_lig, Cn, device=DEV, generator=g)]
+        for _ in range(3):
+            draws += [torch.randn(n_lig, 3, device=DEV, generator=g), torch.randn(n_lig, Cn, device=DEV, generator=g)]
+    outs = []
+    for native in (True, False):
+        st = (m.begin_sampling(batch, keep_trajectory=False) if name == "diffbp"
+              else m.begin_sampling(batch, keep_trajectory=False, noise_draws=[d.clone() for d in draws]))
+        assert st["native"]
+        if not native:
+            st["native"] = False
+            if name == "diffsbdd":      # the torch path keeps the pocket in st["x_rec"]
+                st["x_rec"] = st["x"][st["rec_rows"]].clone()
+        for k, t in enumerate((999, 998, 420)):
+            m.denoise_step(st, t, noise[k]) if name == "diffbp" else m.denoise_step(st, t)
+        # the pocket: never moves in DiffBP (protein rows of the composed x); translated every step in DiffSBDD
+        x_rec = st["x"][~st["lig_flag"]] if (native or name == "diffbp") else st["x_rec"]
+        outs.append((st["x_lig"].clone(), st["c_lig"].clone(), x_rec.clone()))
+    (xa, ca, ra), (xb, cb, rb) = outs
+    assert float((xa - xb).abs().max()) <= 2e-6 * max(1.0, float(xb.abs().max())), float((xa - xb).abs().max())
+    assert float((ra - rb).abs().max()) <= 2e-6 * max(1.0, float(rb.abs().max()))
+    if name == "diffbp":
+        assert torch.equal(ca, cb)
+    else:
+        assert float((ca - cb).abs().max()) <= 2e-6 * max(1.0, float(cb.abs().max()))
+
+
 def test_diffbp_sampler_on_real_size_pockets():
     """DiffBP.sample, T = 2, three real-size pockets: denoiser + CoMPredictor + score step + mask-type step.
     x within 1e-4 relative + 2e-5 absolute per step (two denoiser calls deep at the second), types identical."""
