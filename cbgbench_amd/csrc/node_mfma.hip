@@ -299,6 +299,169 @@ __global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// node_stage: the whole node stage of one attention block in ONE launch -- projection, query MLP, query fold -- built for
+// LATENCY: small batches (1 - 10 graphs) are bound by ~60 dependent launches of ~10 us per step, and three of every four
+// or five launches of a block were the node kernels above.  Here a 16-wave workgroup owns ONE 16-row tile and spreads the
+// columns over its waves, so that each of the three dependent phases costs one round of operand loads:
+//   phase 1  20 units of 32 projection columns over the 16 waves (split-f16, 24 MFMAs per unit), B operands straight from
+//            the packed tables in global memory (L2-resident; no LDS staging, nothing to wait for but the wave's own loads);
+//            the two q-hidden chunks go first and also land in a [16][128] LDS tile
+//   phase 2  waves 0..7: LayerNorm + ReLU of the tile (each wave for itself), one 16-column tile of the query MLP's second
+//            Linear each (split-f16, 12 MFMAs) -> q into a second LDS tile
+//   phase 3  wave a: the fold of head a (exact fp32, 16 MFMAs) -> Qt[:, a]
+// Every workgroup re-reads the block's 448 KB of tables (28 KB per row), which is why this kernel is only used up to
+// CBGX_NODE_STAGE_MAX_ROWS rows; beyond that the three throughput kernels above take over.
+// ------------------------------------------------------------------------------------------------
+constexpr int NS_TPITCH = H + 4;   // LDS tile row pitch (floats)
+
+__global__ __launch_bounds__(1024) void node_stage_kernel(const float* __restrict__ att, const float* __restrict__ h,
+                                                          const uint8_t* __restrict__ lig, float* __restrict__ P,
+                                                          float* __restrict__ qout, float* __restrict__ Qt, int n_nodes,
+                                                          const int* __restrict__ rows, const int* __restrict__ n_rows_ptr,
+                                                          unsigned chunk_mask) {
+    __shared__ __attribute__((aligned(16))) float qh[16][NS_TPITCH];
+    __shared__ __attribute__((aligned(16))) float qt[16][NS_TPITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, q = lane >> 4;
+    const int n_rows = rows ? *n_rows_ptr : n_nodes;
+    const int n_tiles = (n_rows + 15) / 16;
+    for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        const int row0 = tl * 16;
+        const int ak = min(row0 + c, n_rows - 1);
+        const int arow = rows ? rows[ak] : ak;
+        int orow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = row0 + 4 * q + r;
+            orow[r] = k < n_rows ? (rows ? rows[min(k, n_rows - 1)] : k) : -1;
+        }
+        // ---- phase 1: projection, 20 units of 32 columns (half a chunk); the q-hidden chunks first: wave w takes unit w, waves
+        // 0..3 a second one.  One unit's 16 operand loads are all in flight at once (64 VGPRs of the 128 a 16-wave group gets).
+        half8 ah[4], al[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 v0 = nld4(h + (size_t)arow * H + 32 * u + 4 * q), v1 = nld4(h + (size_t)arow * H + 32 * u + 16 + 4 * q);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 hi = (_Float16)v[j];
+                ah[u][j] = hi;
+                al[u][j] = (_Float16)(v[j] - (float)hi);
+            }
+        }
+        bool lgr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lgr[r] = lig[orow[r] >= 0 ? orow[r] : arow] != 0;
+        for (int unit = wave; unit < 2 * NP_CHUNKS; unit += 16) {
+            const int ch = unit < 4 ? 8 + (unit >> 1) : (unit - 4) >> 1, half = unit & 1;   // units 0..3: chunks 8, 9
+            if (!(((chunk_mask | 0x300u) >> ch) & 1u)) continue;
+            const half8* Bh = reinterpret_cast<const half8*>(att + A_NPROJ_FRAG + (size_t)ch * NP_CHUNK) + (2 * half) * 4 * 64 + lane;
+            const half8* Bl = Bh + 4 * 4 * 64;
+            half8 bh[4][2], bl[4][2];     // [u][ct]
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) { bh[u][ct] = Bh[(ct * 4 + u) * 64]; bl[u][ct] = Bl[(ct * 4 + u) * 64]; }
+            const float* bias = att + A_BN2 + 64 * ch + 4 * c + 2 * half;   // [dst class][640]: bias + type column of a protein source
+            const float2 bP = *reinterpret_cast<const float2*>(bias), bL = *reinterpret_cast<const float2*>(bias + PROW);
+            floatx4 acc[2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc[0][r] = lgr[r] ? bL.x : bP.x; acc[1][r] = lgr[r] ? bL.y : bP.y; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[ct] = MFMAH32(ah[u], bl[u][ct], acc[ct]);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[ct] = MFMAH32(al[u], bh[u][ct], acc[ct]);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[ct] = MFMAH32(ah[u], bh[u][ct], acc[ct]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float2 o = {acc[0][r], acc[1][r]};
+                if (orow[r] >= 0) *reinterpret_cast<float2*>(P + (size_t)orow[r] * PROW + 64 * ch + 4 * c + 2 * half) = o;
+                if (ch >= 8) *reinterpret_cast<float2*>(&qh[4 * q + r][64 * (ch - 8) + 4 * c + 2 * half]) = o;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: query MLP, output tile nt = wave (16 columns 64 (nt >> 2) + 4c + (nt & 3)) ---------------------------
+        if (wave < 8) {
+            const int nt = wave;
+            const half8* Bh = reinterpret_cast<const half8*>(att + A_WQ1_FRAG) + (size_t)nt * 4 * 64 + lane;   // [nt][u][lane]
+            const half8* Bl = Bh + 8 * 4 * 64;
+            half8 bh[4], bl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { bh[u] = Bh[u * 64]; bl[u] = Bl[u * 64]; }
+            float z[32];
+            float sm = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 v = nld4(&qh[c][16 * u + 4 * q]);
+                z[4 * u] = v.x; z[4 * u + 1] = v.y; z[4 * u + 2] = v.z; z[4 * u + 3] = v.w;
+                sm += (v.x + v.y) + (v.z + v.w);
+            }
+            const float mean = nxrow_sum(sm) * (1.f / H);
+            float var = 0.f;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) { z[u] -= mean; var += z[u] * z[u]; }
+            const float rstd = 1.f / sqrtf(nxrow_sum(var) * (1.f / H) + 1e-5f);
+            half8 zh[4], zl[4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 g = nld4(att + A_LNQ_G + 16 * u + 4 * q), b = nld4(att + A_LNQ_B + 16 * u + 4 * q);
+                const float y[4] = {fmaxf(z[4 * u + 0] * rstd * g.x + b.x, 0.f), fmaxf(z[4 * u + 1] * rstd * g.y + b.y, 0.f),
+                                    fmaxf(z[4 * u + 2] * rstd * g.z + b.z, 0.f), fmaxf(z[4 * u + 3] * rstd * g.w + b.w, 0.f)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const _Float16 hi = (_Float16)y[j];
+                    zh[u >> 1][4 * (u & 1) + j] = hi;
+                    zl[u >> 1][4 * (u & 1) + j] = (_Float16)(y[j] - (float)hi);
+                }
+            }
+            const int col = 64 * (nt >> 2) + 4 * c + (nt & 3);
+            const float b1 = att[A_BQ1 + col];
+            floatx4 acc = {b1, b1, b1, b1};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = MFMAH32(zh[u], bl[u], acc);
+                acc = MFMAH32(zl[u], bh[u], acc);
+                acc = MFMAH32(zh[u], bh[u], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                qt[4 * q + r][col] = acc[r];
+                if (orow[r] >= 0) qout[(size_t)orow[r] * H + col] = acc[r];
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: the fold of head a = wave: Qt[row][a][m] = sum_cc q[row][8a+cc] Wbk[8a+cc][m] / sqrt 8 (exact fp32) ---
+        {
+            const int a = wave;
+            const float* fb = att + A_WBK_FRAG + ((size_t)a * 2 * 64 + lane) * 8;
+            const float4 b00 = nld4(fb), b01 = nld4(fb + 4), b10 = nld4(fb + 64 * 8), b11 = nld4(fb + 64 * 8 + 4);
+            const float2 qv = *reinterpret_cast<const float2*>(&qt[c][8 * a + 2 * q]);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float4 b0 = g ? b10 : b00, b1 = g ? b11 : b01;
+                floatx4 acc[4];
+                const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+                acc[0] = MFMA(qv.x, b0.x, zero); acc[1] = MFMA(qv.x, b0.z, zero);
+                acc[2] = MFMA(qv.x, b1.x, zero); acc[3] = MFMA(qv.x, b1.z, zero);
+                acc[0] = MFMA(qv.y, b0.y, acc[0]); acc[1] = MFMA(qv.y, b0.w, acc[1]);
+                acc[2] = MFMA(qv.y, b1.y, acc[2]); acc[3] = MFMA(qv.y, b1.w, acc[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (orow[r] >= 0) {
+                        const float4 o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                        *reinterpret_cast<float4*>(Qt + ((size_t)orow[r] * HEADS + a) * H + 64 * g + 4 * c) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();   // the tiles are rewritten by the next row tile
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // node_linear: C[M, nout] = act(A[M,128] @ Wt[128, nout] + bias), nout <= 128 (the classifier's two Linears,
 // unitransformer.py:119-122).  Persistent 4-wave workgroups, Wt staged once in LDS ([128][nout padded to 16]), one
 // wavefront per 16 rows, A in MFMA layout straight from global memory (k = 16u + 4q + j), scalar stores of 64-byte runs.
@@ -532,6 +695,8 @@ constexpr unsigned CHUNKS_OWN = 0x30fu;   // PDk | PDv | qh: what the destinatio
 // `act` / `act_count` (optional): only the listed destination nodes will be processed by the edge kernel (h2x: nodes
 // that can move; x2h in the last layers: nodes whose features can still reach an output).  `src` / `src_count`
 // (optional): the nodes that can be *sources* of those destinations; without it PS is produced for every node.
+constexpr int NODE_STAGE_MAX_ROWS = 8192;   // up to here the latency-built fused kernel replaces the three-kernel chain
+
 hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,
                             float* Qt, const int* act, const int* act_count, const int* src, const int* src_count,
                             hipStream_t s) {
@@ -541,23 +706,33 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
     // few row tiles (small batches, or a work list): spread the column chunks / heads over workgroups too
     const bool small = tiles <= 128 || act != nullptr;
     auto py = [&](unsigned mask) { return small ? (unsigned)__builtin_popcount(mask) : 1u; };
+    // Small inputs (n_nodes bounds a work list's length too): ONE launch does projection (own columns, or all of them when
+    // every node is a destination), query MLP and query fold -- such launches are bound by kernel boundaries, not throughput.
+    const bool fused = n_nodes <= NODE_STAGE_MAX_ROWS;
     profile_mark_begin(K_NODE_GEMM, s);
     if (!act) {
-        hipLaunchKernelGGL(node_proj_kernel, dim3(grid, py(CHUNKS_ALL)), dim3(256), 0, s, att, h, lig, P, n_nodes,
-                           (const int*)nullptr, (const int*)nullptr, CHUNKS_ALL);
+        if (!fused)
+            hipLaunchKernelGGL(node_proj_kernel, dim3(grid, py(CHUNKS_ALL)), dim3(256), 0, s, att, h, lig, P, n_nodes,
+                               (const int*)nullptr, (const int*)nullptr, CHUNKS_ALL);
     } else {
         hipLaunchKernelGGL(node_proj_kernel, dim3(grid, (tiles <= 128 || src) ? py(CHUNKS_PS) : 1u), dim3(256), 0, s, att, h,
                            lig, P, n_nodes, src, src_count, CHUNKS_PS);
-        hipLaunchKernelGGL(node_proj_kernel, dim3(grid, py(CHUNKS_OWN)), dim3(256), 0, s, att, h, lig, P, n_nodes, act,
-                           act_count, CHUNKS_OWN);
+        if (!fused)
+            hipLaunchKernelGGL(node_proj_kernel, dim3(grid, py(CHUNKS_OWN)), dim3(256), 0, s, att, h, lig, P, n_nodes, act,
+                               act_count, CHUNKS_OWN);
     }
     profile_mark_end(s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     profile_mark_begin(K_NODE_QUERY, s);
-    hipLaunchKernelGGL(node_qmlp_kernel, dim3(grid, small ? 2 : 1), dim3(256), 0, s, att, P, qbuf, n_nodes, act, act_count);
-    hipLaunchKernelGGL(node_qfold_kernel, dim3(grid, small ? 4 : 1), dim3(256), 0, s, att, qbuf, Qt, n_nodes, act,
-                       act_count);
+    if (fused) {
+        hipLaunchKernelGGL(node_stage_kernel, dim3(min((n_nodes + 15) / 16, 512)), dim3(1024), 0, s, att, h, lig, P, qbuf, Qt,
+                           n_nodes, act, act_count, act ? CHUNKS_OWN : CHUNKS_ALL);
+    } else {
+        hipLaunchKernelGGL(node_qmlp_kernel, dim3(grid, small ? 2 : 1), dim3(256), 0, s, att, P, qbuf, n_nodes, act, act_count);
+        hipLaunchKernelGGL(node_qfold_kernel, dim3(grid, small ? 4 : 1), dim3(256), 0, s, att, qbuf, Qt, n_nodes, act,
+                           act_count);
+    }
     profile_mark_end(s);
     return hipGetLastError();
 }
