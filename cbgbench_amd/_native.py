@@ -93,9 +93,9 @@ def lib():
 
 
 @contextlib.contextmanager
-def first_generation_kernels():
+def first_generation_kernels(impl=1):
     """TEST-ONLY: inside the block every binding call goes to libcbgx_xcheck.so (include/cbgx_xcheck.h) with the
-    first-generation VALU kernels selected -- an independent on-device implementation of the same stages.  The product
+    first-generation VALU kernels selected (impl=2: the current kernels except the x2h backward, which is the second-generation one) -- an independent on-device implementation of the same stages.  The product
     library has neither those kernels nor the switch."""
     global _LIB, _XLIB
     if _XLIB is None:
@@ -103,7 +103,7 @@ def first_generation_kernels():
             raise NativeError(f"{XCHECK_LIBPATH} not found: build it with `python -m cbgbench_amd.build`")
         _XLIB = _load(XCHECK_LIBPATH, {"cbgx_debug_set_edge_kernel": (_i, [_i])})
     product = lib()
-    old = _XLIB.cbgx_debug_set_edge_kernel(1)
+    old = _XLIB.cbgx_debug_set_edge_kernel(impl)
     _LIB = _XLIB
     try:
         yield _XLIB

@@ -138,7 +138,7 @@ const char* cbgx_last_error(void) { return g_err; }
 #ifdef CBGX_XCHECK
 // test-only library (include/cbgx_xcheck.h): route the stages through the first-generation VALU kernels
 int cbgx_debug_set_edge_kernel(int impl) {
-    if (impl != 0 && impl != 1) return fail(CBGX_E_INVALID, "debug_set_edge_kernel: impl must be 0 (mfma) or 1 (valu)");
+    if (impl < 0 || impl > 2) return fail(CBGX_E_INVALID, "debug_set_edge_kernel: impl must be 0 (current), 1 (valu) or 2 (mfma, second-generation x2h backward)");
     int old = g_edge_impl;
     g_edge_impl = impl;
     return old;
@@ -231,6 +231,7 @@ static int pack_attention_block(const float* const* p, int blk, float* a, hipStr
     float* img = a + A_IMG;
     HIP_TRY(launch_pack_frag(wkc, 0, img + IMG_FRAG_K, s));
     HIP_TRY(launch_pack_frag(wvc, blk == 0 ? 1 : 0, img + IMG_FRAG_V, s));
+    if (blk == 0) HIP_TRY(launch_pack_frag(wvc, 0, a + A_FRAGV_EM, s));   // edge-major v table for the x2h backward
     HIP_TRY(launch_pack_dwt(wkc, wvc, img + IMG_WT, s));
     CP(gk, H, 0, 0, img + IMG_LN + 0 * H, H, 1, H);
     CP(bek, H, 0, 0, img + IMG_LN + 1 * H, H, 1, H);
@@ -407,7 +408,7 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
     const bool cached = static_h1 && static_h2 && num_layers >= 4;
     // with the graph part of the cache, only the nodes that have a ligand atom within reach get a fresh neighbour list
     // and gate: everything else about the pocket's own graph was computed once (same order, same bits)
-    const bool graph_cached = cached && static_nbr && static_deg && static_ew && static_r32sq && g_edge_impl == 0;
+    const bool graph_cached = cached && static_nbr && static_deg && static_ew && static_r32sq && g_edge_impl != 1;
     if (graph_cached) {
         HIP_TRY(launch_lig_proximity(x, graph_ptr, n_graphs, lig_flag, static_r32sq, n_nodes, w.fmask[0], s));   // D1
         HIP_TRY(launch_build_active(w.fmask[0], n_nodes, w.fw_list[0], w.fw_count, s));
@@ -461,7 +462,7 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
     // still to come -- so it runs on an auxiliary stream next to that h2x block.  Three node-stage buffer sets: x2h
     // alternates between two, h2x has its own.
     static const bool overlap_env = [] { const char* e = getenv("CBGX_OVERLAP"); return !e || atoi(e) != 0; }();
-    const bool overlap = overlap_env && g_edge_impl == 0 && !profile_is_on() && num_layers > 1 && aux_ready();
+    const bool overlap = overlap_env && g_edge_impl != 1 && !profile_is_on() && num_layers > 1 && aux_ready();
     auto layer_lists = [&](int l, const int*& dst, const int*& dst_n, const int*& src, const int*& src_n) {
         dst = dst_n = src = src_n = nullptr;
         if (cached && l < 2) {

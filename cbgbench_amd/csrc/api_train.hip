@@ -159,11 +159,14 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
                                     const int* rows, const int* n_rows, int n, TrainWs& w, float* gh, float* dx,
                                     float* de_w, float* const* grads, hipStream_t s, const float* P_saved = nullptr,
                                     const float* Qt_saved = nullptr) {
-    const int eg = edge_grid(n), ng = node_grid(n);
+    // x2h blocks run the one-wave-per-node backward (8 nodes in flight per workgroup); h2x blocks and, in libcbgx_xcheck.so,
+    // cbgx_debug_set_edge_kernel(2) the second-generation workgroup-per-node kernel
+    const bool gen3 = x2h && g_edge_impl == 0;
+    const int eg = gen3 ? edge_grid((n + 7) / 8) : edge_grid(n), ng = node_grid(n);
     // recompute the node stage of the forward: the MFMA node kernels (centred projection; own columns and query fold only
     // for the listed rows) with the MFMA edge backward, the first-generation ones with the VALU cross-check kernel
     // (skipped when the taped forward left its own P / Qt: P_saved, Qt_saved)
-    const bool mfma = g_edge_impl == 0;
+    const bool mfma = g_edge_impl != 1;
     const bool saved = P_saved && Qt_saved;
     const float* Pn = saved ? P_saved : w.P;
     const float* Qn = saved ? Qt_saved : w.Qt;
@@ -186,6 +189,10 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
                                      w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s));
     else
 #endif
+    if (gen3)
+        HIP_TRY(launch_edge_backward_x2h(att, x, Pn, Qn, w.Gt, w.gb, nbr, deg, lig, e_w, rows, n_rows, n, w.T, w.S, w.sw,
+                                         w.dP, dx, de_w, w.partial, eg, s));
+    else
         HIP_TRY(launch_edge_backward_mfma(x2h, att, x, Pn, Qn, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n,
                                           w.T, w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s, 1));
     float *k0w = grads[0], *k0b = grads[1], *kg = grads[2], *kb = grads[3], *k1w = grads[4], *k1b = grads[5];
@@ -429,7 +436,7 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         HIP_TRY(launch_sgemm(false, true, grad_logits, C, c + C_W1T, C, dact, H, n, H, C, 1, 0, 0, s));
         HIP_TRY(launch_ssp_backward(pre, dact, (long)nh, w.tmp, s));
         // classifier.0: dW0[n][k] = sum_i dpre[i][n] h[i][k];  db0 = colsum(dpre);  dh += dpre W0
-        if (g_edge_impl == 0) {
+        if (g_edge_impl != 1) {
             const int wg = wgrad_groups(n);
             HIP_TRY(launch_wgrad_mfma(w.tmp, H, hl, H, n, 1, w.partial, H, (size_t)H * H, wg, s));
             FOLDED(w.partial, wg, (size_t)H * H, H * H); RS(fz, fn, fs, H, H, H, cg[0], H, 0);
@@ -439,7 +446,7 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         }
         HIP_TRY(launch_colsum(w.tmp, H, H, nullptr, nullptr, nullptr, n, w.partial, H, ng, s));
         { FOLDED(w.partial, ng, H, H); RS(fz, fn, fs, H, 1, H, cg[1], H, 0); }
-        if (g_edge_impl == 0)
+        if (g_edge_impl != 1)
             HIP_TRY(launch_dgrad_mfma(w.tmp, H, c + C_W0T, H, w.gh, H, n, H, 1, s));
         else
             HIP_TRY(launch_sgemm(false, true, w.tmp, H, c + C_W0T, H, w.gh, H, n, H, H, 1, 0, 1, s));

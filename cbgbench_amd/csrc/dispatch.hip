@@ -13,7 +13,7 @@
 namespace cbgx {
 
 #ifdef CBGX_XCHECK
-int g_edge_impl = 0;  // 0: MFMA kernels (what libcbgx.so runs); 1: first-generation VALU kernels
+int g_edge_impl = 0;  // 0: what libcbgx.so runs; 1: first-generation VALU kernels; 2: as 0 with the second-generation x2h backward
 #endif
 
 #define CBGX_LAUNCH_CHECK()                            \
@@ -26,7 +26,7 @@ hipError_t launch_knn(const float* x, const int32_t* graph_ptr, int n_graphs, in
                       int32_t* deg, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
 #ifdef CBGX_XCHECK
-    if (g_edge_impl != 0) return launch_knn_v1(x, graph_ptr, n_graphs, n_nodes, nbr, deg, s);
+    if (g_edge_impl == 1) return launch_knn_v1(x, graph_ptr, n_graphs, n_nodes, nbr, deg, s);
 #endif
     return launch_knn_reg(x, graph_ptr, n_graphs, n_nodes, nbr, deg, s);
 }
@@ -35,7 +35,7 @@ hipError_t launch_gate(const float* packed, const float* x, const int32_t* nbr, 
                        float* e_w, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
 #ifdef CBGX_XCHECK
-    if (g_edge_impl != 0) return launch_gate_v1(packed, x, nbr, deg, n_nodes, e_w, s);
+    if (g_edge_impl == 1) return launch_gate_v1(packed, x, nbr, deg, n_nodes, e_w, s);
 #endif
     return launch_gate_mfma(packed, x, nbr, deg, n_nodes, e_w, s);
 }
@@ -47,7 +47,7 @@ hipError_t launch_attention(bool x2h, const float* att, const float* x, const fl
                             const int* src, const int* src_count, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
 #ifdef CBGX_XCHECK
-    if (g_edge_impl != 0) return launch_attention_v1(x2h, att, x, h, nbr, deg, lig, gen, e_w, n_nodes, P, Qt, out, dx_out, s);
+    if (g_edge_impl == 1) return launch_attention_v1(x2h, att, x, h, nbr, deg, lig, gen, e_w, n_nodes, P, Qt, out, dx_out, s);
 #endif
     hipError_t e0 = launch_node_mfma(att, h, lig, n_nodes, P, qbuf, Qt, act, act_count, src, src_count, s);
     if (e0 != hipSuccess) return e0;

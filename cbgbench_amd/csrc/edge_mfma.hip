@@ -29,150 +29,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "edge_common.h"
 #include "kernels.h"
 #include "layout.h"
 
 namespace cbgx {
 
-typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 __constant__ float c_mu[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.75f, 3.f,
                               3.5f, 4.f, 4.5f, 5.f, 5.5f, 6.f, 7.f, 8.f, 9.f, 10.f};
-
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-// split-f16 rbf pre-activation (protein destinations): v_mfma_f32_16x16x16_f16, four f16 per lane and operand
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-#define MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16((a), (b), (c), 0, 0, 0)
-
-// ---- cross-lane reductions without LDS traffic -----------------------------------------------------
-// within a 16-lane row: DPP quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror (every lane gets the sum)
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_mov<0xB1>(v);
-    v += dpp_mov<0x4E>(v);
-    v += dpp_mov<0x141>(v);
-    v += dpp_mov<0x140>(v);
-    return v;
-}
-// across the 4 rows (q): v_permlane16_swap / v_permlane32_swap (gfx950); every lane gets the result
-__device__ __forceinline__ float xrow_sum(float v) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float xrow_max(float v) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float wave_sum(float v) { return xrow_sum(row16_sum(v)); }
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-// Wave-uniform row base (pinned in scalar registers) + 32-bit per-lane BYTE offset: selects the
-// `global_load v, v_off, s[base:base+1]` form -- one address VGPR and no 64-bit vector arithmetic per gathered row.  The
-// empty asm makes the base opaque: without it LICM re-associates `base + lane part` into hoisted 64-bit per-lane pointers
-// (two VGPRs per address, all live across the whole node loop).  Every offset used this way is < 2^32 (checked by the launcher).
-typedef const __attribute__((address_space(1))) char* gptr;
-typedef __attribute__((address_space(1))) char* gwptr;
-__device__ __forceinline__ gptr sbase(const void* p) {
-    uint64_t v = reinterpret_cast<uint64_t>(p);
-    asm volatile("" : "+s"(v));
-    return (gptr)v;
-}
-__device__ __forceinline__ gwptr sbase_w(void* p) {
-    uint64_t v = reinterpret_cast<uint64_t>(p);
-    asm volatile("" : "+s"(v));
-    return (gwptr)v;
-}
-// loop-invariant lane offsets are laundered once per use site: the zero-extension then sits in the block of the load
-// (instruction selection is per block) instead of being hoisted out of the node loop as a 64-bit register pair
-__device__ __forceinline__ unsigned vop(unsigned off) {
-    asm volatile("" : "+v"(off));
-    return off;
-}
-typedef float nfloat2 __attribute__((ext_vector_type(2)));
-typedef int nint4 __attribute__((ext_vector_type(4)));
-#define CBGX_GLOBAL_AS(T) const __attribute__((address_space(1))) T*
-__device__ __forceinline__ float4 ldo4(gptr base, unsigned byte_off) {
-    const floatx4 v = *reinterpret_cast<CBGX_GLOBAL_AS(floatx4)>(base + byte_off);
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ float ldo1(gptr base, unsigned byte_off) {
-    return *reinterpret_cast<CBGX_GLOBAL_AS(float)>(base + byte_off);
-}
-__device__ __forceinline__ float2 ldo2(gptr base, unsigned byte_off) {
-    const nfloat2 v = *reinterpret_cast<CBGX_GLOBAL_AS(nfloat2)>(base + byte_off);
-    return make_float2(v.x, v.y);
-}
-__device__ __forceinline__ int ldoi(gptr base, unsigned byte_off) {
-    return *reinterpret_cast<CBGX_GLOBAL_AS(int32_t)>(base + byte_off);
-}
-__device__ __forceinline__ int4 ldoi4(gptr base, unsigned byte_off) {
-    const nint4 v = *reinterpret_cast<CBGX_GLOBAL_AS(nint4)>(base + byte_off);
-    return make_int4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ int ldob(gptr base, unsigned byte_off) {
-    return *reinterpret_cast<CBGX_GLOBAL_AS(uint8_t)>(base + byte_off);
-}
-__device__ __forceinline__ void sto2(gwptr base, unsigned byte_off, float2 v) {
-    *reinterpret_cast<__attribute__((address_space(1))) nfloat2*>(base + byte_off) = nfloat2{v.x, v.y};
-}
-// packed fp32: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 do two lanes' worth of work per issue slot, so the elementwise
-// parts of the kernel (sum of squares, LayerNorm affine) are written on register pairs
-typedef float float2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float2v lo2(floatx4 v) { return __builtin_shufflevector(v, v, 0, 1); }
-__device__ __forceinline__ float2v hi2(floatx4 v) { return __builtin_shufflevector(v, v, 2, 3); }
-__device__ __forceinline__ float2v splat2(float a) { float2v r = {a, a}; return r; }
-// 1-ulp hardware approximations (v_rsq_f32, v_rcp_f32, v_sqrt_f32, v_exp_f32): the IEEE-exact library forms cost ~10
-// instructions each and the parity tolerance (1e-4 rel) is three orders of magnitude away
-__device__ __forceinline__ float fast_rsqrt(float a) { return __builtin_amdgcn_rsqf(a); }
-__device__ __forceinline__ float fast_rcp(float a) { return __builtin_amdgcn_rcpf(a); }
-__device__ __forceinline__ float fast_sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
-__device__ __forceinline__ float fast_exp(float a) { return __builtin_amdgcn_exp2f(a * 1.44269504088896340736f); }
-__device__ __forceinline__ floatx4 f4(float4 a) { floatx4 r = {a.x, a.y, a.z, a.w}; return r; }
-
-// |x_i - x_j| with one fixed evaluation order (explicit FMAs, no re-association): the prologue and the pipelined loop body
-// must give the same bits for the same edge, or a node's result would depend on its position in the work list
-__device__ __forceinline__ float edge_len(float xi, float yi, float zi, float xj, float yj, float zj) {
-    const float rx = xi - xj, ry = yi - yj, rz = zi - zj;
-    return fast_sqrt(__builtin_fmaf(rx, rx, __builtin_fmaf(ry, ry, rz * rz)));
-}
-// The five rbf values of a lane (g = 4s + q, already masked to this pass's source class) as the four f16 tuples that pair
-// with the weight tuples T1, T1, T2, T3 (load_wtuples below):  [rh0..3]  [rl0..3]  [rh4 rh0 rh1 rh2]  [rh3 rh4 rl4 0]
-// (rh = f16(r) round to nearest, rl = f16(r - rh); the dropped rl * wl term is 2^-22 relative)
-__device__ __forceinline__ void rbf_tuples(const float (&R)[5], half4 (&B)[4]) {
-    _Float16 h[5], l[5];
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        h[s] = (_Float16)R[s];
-        l[s] = (_Float16)(R[s] - (float)h[s]);
-    }
-    B[0] = half4{h[0], h[1], h[2], h[3]};
-    B[1] = half4{l[0], l[1], l[2], l[3]};
-    B[2] = half4{h[4], h[0], h[1], h[2]};
-    B[3] = half4{h[3], h[4], l[4], (_Float16)0.f};
-}
-// The weight pieces of (type, tile) for this lane: T1 = (d0, d1) = [h0 h1 h2 h3], T2 = (d2, d3) = [h4 l0 l1 l2],
-// T3 = (d4, d2) = [l3 l4 h4 l0] -- d2 is read twice, so the table needs no duplicate and is exactly as large as the five
-// fp32 fragments it replaces.  blk = lds_frag + (type * 8 + t) * FRAG_BLK.
-struct WTuples { half4 t1, t2, t3; };
-__device__ __forceinline__ WTuples load_wtuples(const float* blk, int lane) {
-    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-    WTuples w;
-    w.t1 = *reinterpret_cast<const half4*>(blk + 2 * lane);
-    w.t2 = *reinterpret_cast<const half4*>(blk + 128 + 2 * lane);
-    const unsigned d4 = *reinterpret_cast<const unsigned*>(blk + 256 + lane);
-    const unsigned d2 = *reinterpret_cast<const unsigned*>(blk + 128 + 2 * lane);
-    const uint2v p = {d4, d2};
-    w.t3 = __builtin_bit_cast(half4, p);
-    return w;
-}
-// edge type, unitransformer.py:92-97: (src lig, dst lig)->0, (lig, prot)->1, (prot, lig)->2, (prot, prot)->3
-__device__ __forceinline__ int etype(bool src_lig, int lig_i) { return src_lig ? (lig_i ? 0 : 1) : (lig_i ? 2 : 3); }
 
 // ---- edge-major path for one half (16 edges): pre-activation -> LayerNorm -> ReLU -> contraction with a
 // per-lane row of B (Qt[i][a] for scores, Wbv[a] for the h2x values).  Returns the 16x16 result tile:

@@ -85,7 +85,10 @@ constexpr size_t A_WRT = A_WQ1O + (size_t)H * H;
 // rbf columns of the *centred* first Linears, same layout as A_WR: the backward's recomputation when the node projection
 // comes from the MFMA node kernel (whose P is centred and already contains the protein-source type column)
 constexpr size_t A_WRC = A_WRT + (size_t)NT * 2 * H * 32;
-constexpr size_t ATT_SIZE = A_WRC + (size_t)NT * G * 2 * H;
+// training only (x2h blocks): the split-f16 rbf table of the v path in the EDGE-major labeling (A operand), as IMG_FRAG_K
+// is for k -- the x2h forward image keeps v channel-major.  Read from L2 by train_bwd_x2h.hip.
+constexpr size_t A_FRAGV_EM = A_WRC + (size_t)NT * G * 2 * H;
+constexpr size_t ATT_SIZE = A_FRAGV_EM + FRAG;
 
 constexpr size_t LAYER_SIZE = 2 * ATT_SIZE;       // x2h then h2x
 

@@ -46,6 +46,12 @@ hipError_t launch_edge_backward_mfma(bool x2h, const float* att, const float* x,
                                      const int32_t* deg, const uint8_t* lig, const float* e_w, const int* rows,
                                      const int* n_rows, int n_nodes, float* T, float* S, float* sw, float* dP, float* dx,
                                      float* de_w, float* partial, int grid, hipStream_t s, int centred = 0);
+// third-generation x2h backward (train_bwd_x2h.hip): one wavefront per node, 8 nodes in flight per workgroup; P must be the
+// centred projection of the MFMA node kernel.  grid = edge_grid_x2h(n) workgroups, one PB_SIZE slab each.
+hipError_t launch_edge_backward_x2h(const float* att, const float* x, const float* P, const float* Qt, const float* Gt,
+                                    const float* gb, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
+                                    const float* e_w, const int* rows, const int* n_rows, int n_nodes, float* T, float* S,
+                                    float* sw, float* dP, float* dx, float* de_w, float* partial, int grid, hipStream_t s);
 hipError_t launch_fold_grad(const float* att, const float* Gr, int n_nodes, float* Gt, float* gb, hipStream_t s);
 hipError_t launch_outer_accum_mfma(bool headed, const float* Lm, const float* R, const int* rows, const int* n_rows,
                                    int n_nodes, float* partial, size_t slab_stride, int grid, hipStream_t s);

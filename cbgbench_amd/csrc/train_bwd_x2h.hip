@@ -1,0 +1,662 @@
+// libcbgx -- third-generation backward of the X2H attention block: ONE WAVEFRONT PER DESTINATION NODE, tiles in registers.
+//
+// Same contract as edge_backward_mfma_kernel<true> (train_bwd_mfma.hip; autograd of x2h_attention.py:43-97 for one node
+// and its <= 32 incoming edges, nothing per-edge ever stored by the forward), different structure.  The second-generation
+// kernel spread a node over an 8-wave workgroup with ten barrier-separated phases and 135 KB of LDS tiles (one node in
+// flight per CU, 13.4 k vector instructions per node, waves waiting half of their cycles).  Here a wave does what the
+// forward kernel (edge_mfma.hip) does -- the [32 x 128] tiles of a path live in MFMA accumulator layout, LayerNorm and
+// softmax are DPP / permlane reductions -- and LDS serves one purpose: turning a tile from the edge-major labeling
+//   E: lane (c = edge c + 16 hf, q), register (t, r) <-> channel 16 t + 4 q + r        (contractions over channels)
+// into the channel-major one
+//   C: lane (c, q), (t, hf, r)                       <-> channel 16 t + c, edge 4 q + r + 16 hf   (contractions over edges)
+// through a wave-private [32][132] buffer.  Per path (k, then v; k's forward is recomputed for its backward):
+//   pre-activation (split-f16, as the forward)  64 MFMAs   E      normalised n kept in 64 registers
+//   scores / gv = hid . Qt|Gt                    64         E  ->  alpha (k), d alpha / d e_w / w = alpha e_w (v)
+//   fold  T|S[a][m] = sum_e ds|w[e][a] hid[e][m] 64         C  (n through the tile, hid = ReLU(n g + b) on the fly)
+//   d hid = ds|w . Qt|Gt                         64         E  ->  LayerNorm backward in registers -> d pre
+//   d rbf = d pre . Wr^T                         128        E  ->  d dist -> d x (atomics)
+//   d PS[j_e] += d pre[e]   (atomics, 16-byte runs of a neighbour's row);  d pre through the tile:
+//   d Wr[type] += rbf^T . d pre                  128        C  ->  LDS slab (type 3) / workgroup slab in memory
+//   d PD[i], type columns, per-class sums        VALU       C
+// LayerNorm affine gradients are reduced over the 16 edge lanes with DPP row sums (512 per node) into an LDS slab.
+// 8 waves per workgroup (2 per SIMD, 256 VGPRs), persistent, one workgroup per CU; LDS = 8 x 16.9 KB transpose tiles +
+// 20 KB type-3 d Wr + 6 KB of small slabs.  Outputs, slab layout (train.h PB_*) and launch contract are those of
+// launch_edge_backward_mfma, so api_train.hip swaps one call.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "edge_common.h"
+#include "kernels.h"
+#include "layout.h"
+#include "train.h"
+
+namespace cbgx {
+
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+__constant__ float c_mu_x[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.75f, 3.f,
+                                3.5f, 4.f, 4.5f, 5.f, 5.5f, 6.f, 7.f, 8.f, 9.f, 10.f};
+
+constexpr int BX_WAVES = 8;
+constexpr int BX_PITCH = H + 4;                 // transpose tile row pitch (floats): 16-byte aligned rows
+constexpr int BX_TILE = KNN * BX_PITCH;         // 4224 floats per wave
+
+struct BwdX2hLds {
+    float tile[BX_WAVES][BX_TILE];              // per-wave E <-> C transposes (and the 32 x 16 E1 transposes)
+    float dwr3[G][2 * H];                       // d Wr of the dominant edge type 3, accumulated with ds_add_f32
+    float wt[NT][2 * H];                        // type-column gradients
+    float lng[2 * H], lnb[2 * H];               // LayerNorm affine gradients (k | v)
+};
+
+// accesses of the wave's tile by different lanes are ordered by the LDS queue (one wave, in issue order); the fence keeps the
+// compiler from moving a lane's reads above another lane's writes it cannot see
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+
+__global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
+    const float* __restrict__ att, const float* __restrict__ x, const float* __restrict__ P,
+    const float* __restrict__ Qt, const float* __restrict__ Gt, const float* __restrict__ gb,
+    const int32_t* __restrict__ nbr, const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig,
+    const float* __restrict__ e_w, const int* __restrict__ rows, const int* __restrict__ n_rows_ptr, int n_nodes,
+    float* __restrict__ T, float* __restrict__ S, float* __restrict__ sw, float* __restrict__ dP, float* __restrict__ dx,
+    float* __restrict__ de_w, float* __restrict__ partial
+#ifdef CBGX_ABLATE
+    , int abl
+#endif
+    ) {
+#ifndef CBGX_ABLATE
+    constexpr int abl = 0;      // timing ablations (WRONG results) exist only in libcbgx_ablate.so
+#endif
+    __shared__ BwdX2hLds L;
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = lane0 & 15, q0 = lane0 >> 4;
+    float* slab = partial + (size_t)blockIdx.x * PB_SIZE;
+    // the workgroup's slab is (re)written in full: the LDS-accumulated parts at the end, types 0..2 of d Wr by atomics
+    for (int u = tid; u < 3 * G * 2 * H; u += BX_WAVES * 64) slab[PB_WR + u] = 0.f;
+    for (int u = tid; u < G * 2 * H; u += BX_WAVES * 64) (&L.dwr3[0][0])[u] = 0.f;
+    for (int u = tid; u < NT * 2 * H; u += BX_WAVES * 64) (&L.wt[0][0])[u] = 0.f;
+    for (int u = tid; u < 2 * H; u += BX_WAVES * 64) { L.lng[u] = 0.f; L.lnb[u] = 0.f; }
+    __threadfence();
+    __syncthreads();
+    float* tw = L.tile[wave];
+    const int count = rows ? *n_rows_ptr : n_nodes;
+    const float mu0 = c_mu_x[c0], mu1 = c_mu_x[16 + (c0 & 3)];
+    float muq[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) muq[s] = c_mu_x[4 * s + q0];
+
+    // A node's header (index, degree, class, neighbour list) is fetched one node ahead: its three dependent round trips
+    // (rows -> deg / nbr -> coordinates) would otherwise open every node
+    const int stride = gridDim.x * BX_WAVES;
+    int it = blockIdx.x * BX_WAVES + wave;
+    int i_n = 0, d_n = 0, lig_n = 0, jr_n[2] = {0, 0};
+    auto load_header = [&](int itx) {
+        i_n = __builtin_amdgcn_readfirstlane(rows ? rows[itx] : itx);
+        d_n = deg[i_n];
+        lig_n = lig[i_n];
+        jr_n[0] = nbr[(size_t)i_n * KNN + c0];
+        jr_n[1] = nbr[(size_t)i_n * KNN + 16 + c0];
+    };
+    if (it < count) load_header(it);
+    for (; it < count; it += stride) {
+        const int i = i_n;
+        const int d = __builtin_amdgcn_readfirstlane(d_n), lig_i = __builtin_amdgcn_readfirstlane(lig_n);
+        const int jr[2] = {jr_n[0], jr_n[1]};
+        load_header(it + stride < count ? it + stride : it);
+        // the lane coordinates are re-materialised every node: otherwise every per-lane address below is loop-invariant, gets
+        // hoisted out of the node loop as a 64-bit pointer pair and spilled
+        int lane = lane0, c = c0, q = q0;
+        asm volatile("" : "+v"(lane), "+v"(c), "+v"(q));
+        const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
+        // ---- geometry.  E0: lane (c, q) <-> edges c, c + 16;  E1: lane (c, q), [hf][r] <-> edge 4q + r + 16 hf ---------------------
+        int j0[2];
+        bool lg0[2];
+        float dist0[2];
+        {
+            float xj[2][3];
+            int lj[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {   // unconditional gathers (padded slots read the node itself), all issued together
+                j0[hf] = c + 16 * hf < d ? jr[hf] : i;
+                lj[hf] = lig[j0[hf]];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) xj[hf][k] = x[3 * j0[hf] + k];
+            }
+            SCHED_FENCE();
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                lg0[hf] = (c + 16 * hf < d) & (lj[hf] != 0);
+                dist0[hf] = edge_len(xi, yi, zi, xj[hf][0], xj[hf][1], xj[hf][2]);
+            }
+        }
+        const unsigned long long b0 = __ballot(lg0[0]), b1 = __ballot(lg0[1]);
+        const unsigned mask_lig = (unsigned)(b0 & 0xffffull) | ((unsigned)(b1 & 0xffffull) << 16);
+        const unsigned mask_valid = d >= 32 ? 0xffffffffu : ((1u << d) - 1u);
+        const bool has_lig = (mask_lig & mask_valid) != 0;
+        const bool has_prot = ((~mask_lig) & mask_valid) != 0 || d == 0;
+        const bool mixed = has_lig && has_prot;
+        const unsigned msh = mask_lig >> (4 * q);       // bit r + 16 hf <-> E1 slot (hf, r)
+        const unsigned vsh = mask_valid >> (4 * q);
+        const bool val0[2] = {c < d, c + 16 < d};
+        // E1 copy of the edge length: lane (c', q') needs edge 4q' + r (+16 hf) = the E0 value of lane 4q' + r
+        float dist1[2][4];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dist1[hf][r] = __shfl(dist0[hf], 4 * q + r, 64);
+        // rbf of the E1 edges at g = c (tile 0) and g = 16 + c (tile 1, lanes c < 4): A operand of d Wr, factor of d dist.  Recomputed
+        // where needed (16 v_exp) instead of living in 16 registers across the phases
+        auto rbf_e1 = [&](float (&r0)[2][4], float (&r1)[2][4]) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float vm = ((vsh >> (r + 16 * hf)) & 1u) ? 1.f : 0.f;
+                    const float u0 = dist1[hf][r] - mu0, u1 = dist1[hf][r] - mu1;
+                    r0[hf][r] = fast_exp(-0.5f * (u0 * u0)) * vm;
+                    r1[hf][r] = fast_exp(-0.5f * (u1 * u1)) * (c < 4 ? vm : 0.f);
+                }
+        };
+        const int ty_prot = lig_i ? 2 : 3, ty_lig = lig_i ? 0 : 1;
+        float ddist[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // d L / d dist, E1 mapping (all 16 lanes of a row), k + v
+        float alpha[2][4];       // softmax weights; after phase 1: d L / d score
+
+        // three phases through one body: 0 = key forward (scores -> alpha), 1 = value forward + backward, 2 = key forward
+        // again + backward
+#pragma unroll 1
+        for (int ph = 0; ph < 3; ++ph) {
+            if ((abl & 32) && ph == 2) break;
+            const int kv = ph == 1;
+            // everything derived from these is phase-invariant and would be hoisted out of the phase loop into ~60 live registers
+            asm volatile("" : "+v"(lane), "+v"(c), "+v"(q), "+v"(dist0[0]), "+v"(dist0[1]), "+v"(j0[0]), "+v"(j0[1]));
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(dist1[hf][r]));
+            const float* Brow = (kv ? Gt : Qt) + (size_t)i * HEADS * H;
+            const float* lng = att + (kv ? A_LNV_G : A_LNK_G);
+            const float* lnb = att + (kv ? A_LNV_B : A_LNK_B);
+            // ---- forward of the path, E labeling: n[hf][t][r] <-> edge c + 16 hf, channel 16 t + 4 q + r -------------------------------
+            floatx4 n[2][8];
+            float rstd[2];
+            {
+                // every gather of the stage is issued before its first use (the scheduler otherwise serialises load -> wait -> add
+                // to save registers: one memory round trip per row chunk)
+                const float* pdp = P + (size_t)i * PROW + kv * H + 4 * q;
+                const float* psa = P + (size_t)j0[0] * PROW + (2 + kv) * H + 4 * q;
+                const float* psb = P + (size_t)j0[1] * PROW + (2 + kv) * H + 4 * q;
+                float4 pd[8], pa[8], pb[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) pd[t] = (abl & 128) ? make_float4(1.f, 2.f, 3.f, 4.f) : ld4(pdp + 16 * t);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) pa[t] = (abl & 128) ? make_float4(1.f, 2.f, 3.f, 4.f) : ld4(psa + 16 * t);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) pb[t] = (abl & 128) ? make_float4(1.f, 2.f, 3.f, 4.f) : ld4(psb + 16 * t);
+                SCHED_FENCE();
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { n[0][t] = f4(pd[t]) + f4(pa[t]); n[1][t] = f4(pd[t]) + f4(pb[t]); }
+                if (has_lig) {      // type column of ligand sources (P already holds the protein-source one)
+                    const float* dw = att + A_IMG + IMG_WT + lig_i * 2 * H + kv * H + 4 * q;
+                    const float m0 = lg0[0] ? 1.f : 0.f, m1 = lg0[1] ? 1.f : 0.f;
+                    float4 w4[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) w4[t] = ld4(dw + 16 * t);
+                    SCHED_FENCE();
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        n[0][t] += f4(w4[t]) * m0;
+                        n[1][t] += f4(w4[t]) * m1;
+                    }
+                }
+                // rbf columns, split-f16 exactly as the forward kernel (edge_mfma.hip edge_major_half); weight tuples from the
+                // packed table in memory, shared by the two halves
+#pragma unroll 1
+                for (int p = 0; p < 2; ++p) {
+                    if (p == 0 ? !has_prot : !has_lig) continue;  // wave-uniform
+                    if (abl & 16) continue;
+                    half4 B[2][4];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        float Rm[5];
+#pragma unroll
+                        for (int s = 0; s < 5; ++s) {
+                            const float u = dist0[hf] - muq[s];
+                            Rm[s] = (val0[hf] && lg0[hf] == (p == 1)) ? fast_exp(-0.5f * (u * u)) : 0.f;
+                        }
+                        rbf_tuples(Rm, B[hf]);
+                    }
+                    const float* fa = att + (kv ? A_FRAGV_EM : A_IMG + IMG_FRAG_K) + (size_t)etype(p == 1, lig_i) * (8 * FRAG_BLK);
+                    WTuples wt[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) wt[t] = load_wtuples(fa + t * FRAG_BLK, lane);
+                    SCHED_FENCE();
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        n[0][t] = MFMAH(wt[t].t1, B[0][0], n[0][t]);       n[1][t] = MFMAH(wt[t].t1, B[1][0], n[1][t]);
+                        n[0][t] = MFMAH(wt[t].t1, B[0][1], n[0][t]);       n[1][t] = MFMAH(wt[t].t1, B[1][1], n[1][t]);
+                        n[0][t] = MFMAH(wt[t].t2, B[0][2], n[0][t]);       n[1][t] = MFMAH(wt[t].t2, B[1][2], n[1][t]);
+                        n[0][t] = MFMAH(wt[t].t3, B[0][3], n[0][t]);       n[1][t] = MFMAH(wt[t].t3, B[1][3], n[1][t]);
+                    }
+                }
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {    // LayerNorm: the first Linear is centred, mean(pre) == 0
+                    float v = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v = fmaf(n[hf][t][r], n[hf][t][r], v);
+                    v = xrow_sum(v);
+                    rstd[hf] = fast_rsqrt(v * (1.f / H) + 1e-5f);
+                    const float sc = val0[hf] ? rstd[hf] : 0.f;     // padded slots: exact zeros downstream
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) n[hf][t] = n[hf][t] * sc;
+                }
+            }
+            // ---- scores (k) / G . v_raw (v):  out[hf] lane (c = head, q) reg r <-> edge 4q + r + 16 hf -----------------------------------
+            float w[2][4];      // coefficient of hidden[e] per head in the backward (k: d score, v: alpha e_w)
+            if ((abl & 64) && ph < 2) {
+                if (ph == 0) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) alpha[hf][r] = n[hf][r][0];
+                    continue;
+                }
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w[hf][r] = n[hf][r][1];
+            } else if (ph < 2) {
+                floatx4 o[2][2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) { o[hf][0] = floatx4{0.f, 0.f, 0.f, 0.f}; o[hf][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int tc = 0; tc < 8; tc += 4) {
+                    float4 g4[4], b4[4], br[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        g4[t] = ld4(lng + 16 * (tc + t) + 4 * q);
+                        b4[t] = ld4(lnb + 16 * (tc + t) + 4 * q);
+                        br[t] = ld4(Brow + (size_t)c * H + 16 * (tc + t) + 4 * q);
+                    }
+                    SCHED_FENCE();
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {    // padded slots produce ReLU(beta) . B: masked by `valid` / e_w = 0 below
+                            const floatx4 nn = n[hf][tc + t];
+                            o[hf][0] = MFMA(fmaxf(fmaf(nn[0], g4[t].x, b4[t].x), 0.f), br[t].x, o[hf][0]);
+                            o[hf][1] = MFMA(fmaxf(fmaf(nn[1], g4[t].y, b4[t].y), 0.f), br[t].y, o[hf][1]);
+                            o[hf][0] = MFMA(fmaxf(fmaf(nn[2], g4[t].z, b4[t].z), 0.f), br[t].z, o[hf][0]);
+                            o[hf][1] = MFMA(fmaxf(fmaf(nn[3], g4[t].w, b4[t].w), 0.f), br[t].w, o[hf][1]);
+                        }
+                }
+                if (ph == 0) {      // softmax over the incoming edges
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool valid = (vsh >> (r + 16 * hf)) & 1u;
+                            alpha[hf][r] = valid ? o[hf][0][r] + o[hf][1][r] : -INFINITY;
+                            mx = fmaxf(mx, alpha[hf][r]);
+                        }
+                    mx = xrow_max(mx);
+                    float den = 0.f;
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool valid = (vsh >> (r + 16 * hf)) & 1u;
+                            alpha[hf][r] = valid ? expf(alpha[hf][r] - mx) : 0.f;
+                            den += alpha[hf][r];
+                        }
+                    den = xrow_sum(den);
+                    const float inv = den > 0.f ? 1.f / den : 0.f;
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) alpha[hf][r] *= inv;
+                    continue;
+                }
+                const float gbc = gb[(size_t)i * HEADS + c];
+                float ewv[2][4];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ewv[hf][r] = e_w[(size_t)i * KNN + 4 * q + r + 16 * hf];
+                SCHED_FENCE();
+                float swl = 0.f, dot = 0.f;
+                float da[2][4];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool valid = (vsh >> (r + 16 * hf)) & 1u;
+                        const float ew = valid ? ewv[hf][r] : 0.f;
+                        const float g = o[hf][0][r] + o[hf][1][r] + gbc;
+                        da[hf][r] = ew * g;                       // d L / d alpha
+                        dot = fmaf(alpha[hf][r], da[hf][r], dot);
+                        w[hf][r] = alpha[hf][r] * ew;
+                        swl += w[hf][r];
+                        // d e_w[e] = sum over the heads (the 16 lanes of a row) of alpha (G . v_raw + gb)
+                        const float de = row16_sum(alpha[hf][r] * g);
+                        if (c == 0 && valid) de_w[(size_t)i * KNN + 4 * q + r + 16 * hf] += de;
+                    }
+                swl = xrow_sum(swl);
+                dot = xrow_sum(dot);
+                if (q == 0) sw[(size_t)i * HEADS + c] = swl;
+                // softmax backward: from here on `alpha` holds d L / d score, the key path's coefficient in phase 2
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) alpha[hf][r] *= da[hf][r] - dot;
+            } else {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w[hf][r] = alpha[hf][r];
+            }
+            // ================================= backward of the path =======================================================================
+            if (abl & 8) continue;
+            float* fold_dst = (kv ? S : T) + (size_t)i * HEADS * H;
+            // w (E1: lane (c = head, q), edge 4q + r + 16 hf) -> wT[hf][s] in lane (c, q) = w[edge c + 16 hf][head 4 s + q]
+            float wT[2][4];
+            wave_sync();
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tw[(4 * q + r + 16 * hf) * 20 + c] = w[hf][r];
+            wave_sync();
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) wT[hf][s] = tw[(c + 16 * hf) * 20 + 4 * s + q];
+            wave_sync();
+            // n -> tile [edge][channel]
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    *reinterpret_cast<float4*>(tw + (c + 16 * hf) * BX_PITCH + 16 * t + 4 * q) =
+                        make_float4(n[hf][t][0], n[hf][t][1], n[hf][t][2], n[hf][t][3]);
+            wave_sync();
+            float rs1[2][4];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rs1[hf][r] = __shfl(rstd[hf], 4 * q + r, 64);
+            // ---- pass 1, C labeling: lane (c, q), step (u, j), [hf][r] <-> channel 32 u + 2 c + j, edge 4q + r + 16 hf ------------
+            // folds T / S, LayerNorm affine gradients, the two per-edge sums of the LayerNorm backward.  Padded slots need no mask:
+            // their w and wT are zero, so they add nothing to the fold and their d hidden is zero.
+            // LayerNorm affine and the A-side rows of d hidden for the four steps: loaded once, used by pass 1 and pass 2
+            float2 g2a[4], b2a[4], qaa[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ch = 32 * u + 2 * c;
+                g2a[u] = ld2(lng + ch);
+                b2a[u] = ld2(lnb + ch);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) qaa[u][s] = ld2(Brow + (size_t)(4 * s + q) * H + ch);
+            }
+            SCHED_FENCE();
+            float s1[2][4], s2[2][4];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1[hf][r] = 0.f; s2[hf][r] = 0.f; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ch = 32 * u + 2 * c;
+                const float2 g2 = g2a[u], b2 = b2a[u];
+                const float2 (&qa)[4] = qaa[u];
+                float2 nv[2][4];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nv[hf][r] = *reinterpret_cast<const float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + ch);
+                floatx4 fold[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float gmc = j ? g2.y : g2.x, btc = j ? b2.y : b2.x;
+                    fold[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    float pre[2][4];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            pre[hf][r] = fmaf(j ? nv[hf][r].y : nv[hf][r].x, gmc, btc);
+                            fold[j] = MFMA(fmaxf(pre[hf][r], 0.f), w[hf][r], fold[j]);
+                        }
+                    float gsum = 0.f, bsum = 0.f;
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        floatx4 de = {0.f, 0.f, 0.f, 0.f};      // d hidden[e][m] = sum_a w[e][a] Brow[a][m]
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) de = MFMA(wT[hf][s], j ? qa[s].y : qa[s].x, de);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float nn = j ? nv[hf][r].y : nv[hf][r].x;
+                            const float dy = pre[hf][r] > 0.f ? de[r] : 0.f;
+                            gsum = fmaf(dy, nn, gsum);
+                            bsum += dy;
+                            const float v = dy * gmc;
+                            s1[hf][r] += v;
+                            s2[hf][r] = fmaf(v, nn, s2[hf][r]);
+                        }
+                    }
+                    gsum = xrow_sum(gsum);
+                    bsum = xrow_sum(bsum);
+                    if (q == 0) {
+                        atomicAdd(&L.lng[kv * H + ch + j], gsum);
+                        atomicAdd(&L.lnb[kv * H + ch + j], bsum);
+                    }
+                }
+                // fold D: lane (c = head, q) reg r <-> channel 32 u + 2 (4 q + r) + j
+                float* fd = fold_dst + (size_t)c * H + 32 * u + 8 * q;
+                *reinterpret_cast<float4*>(fd) = make_float4(fold[0][0], fold[1][0], fold[0][1], fold[1][1]);
+                *reinterpret_cast<float4*>(fd + 4) = make_float4(fold[0][2], fold[1][2], fold[0][3], fold[1][3]);
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s1[hf][r] = row16_sum(s1[hf][r]) * (1.f / H);
+                    s2[hf][r] = row16_sum(s2[hf][r]) * (1.f / H);
+                }
+            // ---- pass 2 (C): d hidden again (cheaper than 64 live registers of it) -> d pre, in place in the tile ------------------------
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ch = 32 * u + 2 * c;
+                const float2 g2 = g2a[u], b2 = b2a[u];
+                const float2 (&qa)[4] = qaa[u];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    floatx4 de0 = {0.f, 0.f, 0.f, 0.f}, de1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) { de0 = MFMA(wT[hf][s], qa[s].x, de0); de1 = MFMA(wT[hf][s], qa[s].y, de1); }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float2* cell = reinterpret_cast<float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + ch);
+                        const float2 nn = *cell;
+                        const float dn0 = fmaf(nn.x, g2.x, b2.x) > 0.f ? de0[r] * g2.x : 0.f;
+                        const float dn1 = fmaf(nn.y, g2.y, b2.y) > 0.f ? de1[r] * g2.y : 0.f;
+                        // padded slots: d hidden = 0, n = 0, s1 = s2 = 0 -> exact zeros
+                        *cell = make_float2(rs1[hf][r] * (dn0 - s1[hf][r] - nn.x * s2[hf][r]),
+                                            rs1[hf][r] * (dn1 - s1[hf][r] - nn.y * s2[hf][r]));
+                    }
+                }
+            }
+            wave_sync();
+            // ---- pass 3 (E): d rbf[e][g] = sum_m d pre[e][m] Wr[type_e][g][m]  ->  d dist ----------------------------------------------
+            float rT0[2][4], rT1[2][4];
+            rbf_e1(rT0, rT1);
+#pragma unroll 1
+            for (int p = 0; p < 2; ++p) {
+                if (p == 0 ? !has_prot : !has_lig) continue;
+                if (abl & 2) continue;
+                // centred rbf columns [type][g][k | v]: rows g = c and 16 + c (clamped; those results are discarded through rT1 = 0)
+                const float* w0p = att + A_WRC + ((size_t)etype(p == 1, lig_i) * G + c) * 2 * H + kv * H + 4 * q;
+                const float* w1p = att + A_WRC + ((size_t)etype(p == 1, lig_i) * G + (c < 4 ? 16 + c : 19)) * 2 * H + kv * H + 4 * q;
+                const float m0 = (!mixed || lg0[0] == (p == 1)) ? 1.f : 0.f, m1 = (!mixed || lg0[1] == (p == 1)) ? 1.f : 0.f;
+                floatx4 d0[2], d1[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) { d0[hf] = floatx4{0.f, 0.f, 0.f, 0.f}; d1[hf] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+                float4 w0a[8], w1a[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { w0a[t] = ld4(w0p + 16 * t); w1a[t] = ld4(w1p + 16 * t); }
+                SCHED_FENCE();
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const float4 w0 = w0a[t], w1 = w1a[t];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const floatx4 dE = f4(*reinterpret_cast<const float4*>(tw + (c + 16 * hf) * BX_PITCH + 16 * t + 4 * q)) * (hf ? m1 : m0);
+                        d0[hf] = MFMA(dE[0], w0.x, d0[hf]);  d1[hf] = MFMA(dE[0], w1.x, d1[hf]);
+                        d0[hf] = MFMA(dE[1], w0.y, d0[hf]);  d1[hf] = MFMA(dE[1], w1.y, d1[hf]);
+                        d0[hf] = MFMA(dE[2], w0.z, d0[hf]);  d1[hf] = MFMA(dE[2], w1.z, d1[hf]);
+                        d0[hf] = MFMA(dE[3], w0.w, d0[hf]);  d1[hf] = MFMA(dE[3], w1.w, d1[hf]);
+                    }
+                }
+                // D: lane (c = g | 16 + g, q) reg r <-> edge 4 q + r + 16 hf (rows of the other class are zero)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float u0 = dist1[hf][r] - mu0, u1 = dist1[hf][r] - mu1;
+                        const float v = d0[hf][r] * (-u0 * rT0[hf][r]) + d1[hf][r] * (-u1 * rT1[hf][r]);
+                        ddist[hf][r] += row16_sum(v);
+                    }
+            }
+            // ---- pass 4 (C): every atomic of the path in one burst, no global load in between (any vmcnt wait after an atomic is a
+            // full drain on gfx9): neighbour rows, own row, type columns, rbf columns of the first Linear -------------------------------------
+            // (labeling of this pass: step t, lane (c, q), [hf][r] <-> channel 16 t + c -- a row's 16 lanes add to one 64-byte run)
+            gwptr dPb = sbase_w(dP);
+            unsigned joff[2][4];    // byte offset of the neighbour's PS columns of this path
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    joff[hf][r] = ((unsigned)__shfl(j0[hf], 4 * q + r, 64) * (unsigned)PROW + (unsigned)((2 + kv) * H + c)) * 4u;
+            const unsigned ioff = ((unsigned)i * (unsigned)PROW + (unsigned)(kv * H + c)) * 4u;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                float dp[2][4];
+                float all = 0.f, ligs = 0.f;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dp[hf][r] = tw[(4 * q + r + 16 * hf) * BX_PITCH + 16 * t + c];
+                        all += dp[hf][r];
+                        const float lm = ((msh >> (r + 16 * hf)) & 1u) ? 1.f : 0.f;
+                        ligs = fmaf(lm, dp[hf][r], ligs);
+                        if (!(abl & 1)) atomo(dPb, joff[hf][r] + 64 * t, dp[hf][r]);   // padded slots add 0 to the node's own row
+                    }
+                all = xrow_sum(all);
+                ligs = xrow_sum(ligs);
+                if (q == 0) {
+                    atomo(dPb, ioff + 64 * t, all);
+                    atomicAdd(&L.wt[ty_lig][kv * H + 16 * t + c], ligs);
+                    atomicAdd(&L.wt[ty_prot][kv * H + 16 * t + c], all - ligs);
+                }
+#pragma unroll 1
+                for (int p = 0; p < 2; ++p) {
+                    if (p == 0 ? !has_prot : !has_lig) continue;
+                    if (abl & 4) continue;
+                    const int tyc = p ? ty_lig : ty_prot;
+                    const unsigned sel = !mixed ? 0xffffffffu : (p ? msh : ~msh);   // edges of source class p (padded: rT = 0)
+                    floatx4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // A[g][edge] = rbf_g(d_e) over the edges of the class, B[edge][channel] = d pre
+                            const float m = ((sel >> (r + 16 * hf)) & 1u) ? 1.f : 0.f;
+                            a0 = MFMA(rT0[hf][r] * m, dp[hf][r], a0);
+                            a1 = MFMA(rT1[hf][r] * m, dp[hf][r], a1);
+                        }
+                    // D: lane (c = channel, q) reg r <-> g = 4 q + r (tile 0), 16 + r (tile 1, q == 0)
+                    const int col = kv * H + 16 * t + c;
+                    if (tyc == 3) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) atomicAdd(&L.dwr3[4 * q + r][col], a0[r]);
+                        if (q == 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) atomicAdd(&L.dwr3[16 + r][col], a1[r]);
+                        }
+                    } else {
+                        float* sl = slab + PB_WR + (size_t)tyc * G * 2 * H + col;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) atomicAdd(sl + (4 * q + r) * 2 * H, a0[r]);
+                        if (q == 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) atomicAdd(sl + (16 + r) * 2 * H, a1[r]);
+                        }
+                    }
+                }
+            }
+            wave_sync();
+        }
+        // =================================== coordinates ============================================================================
+        // d dist (E1 mapping, replicated over the 16 lanes of a row) -> one lane per edge through the tile: lane (c, q < 2) <-> edge
+        // c + 16 q; the node's own gradient is reduced over the wave first (one atomic per coordinate instead of 32)
+        wave_sync();
+        if (c == 0) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tw[4 * q + r + 16 * hf] = ddist[hf][r];
+        }
+        wave_sync();
+        {
+            const int sel = q & 1;
+            const int j = sel ? j0[1] : j0[0];
+            const float xj = x[3 * j], yj = x[3 * j + 1], zj = x[3 * j + 2];
+            const float dd = tw[c + 16 * sel];
+            const float dist = sel ? dist0[1] : dist0[0];
+            const bool on = q < 2 && c + 16 * sel < d;
+            const float cf = (on && dist > 0.f) ? dd / dist : 0.f;
+            const float g3[3] = {cf * (xi - xj), cf * (yi - yj), cf * (zi - zj)};
+            if (on) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) atomicAdd(&dx[3 * j + k], -g3[k]);
+            }
+            const float sx = wave_sum(g3[0]), sy = wave_sum(g3[1]), sz = wave_sum(g3[2]);
+            if (lane == 0) {
+                atomicAdd(&dx[3 * i], sx);
+                atomicAdd(&dx[3 * i + 1], sy);
+                atomicAdd(&dx[3 * i + 2], sz);
+            }
+        }
+        wave_sync();
+    }
+    // per-workgroup partial sums of the edge-indexed weight gradients
+    __syncthreads();
+    for (int u = tid; u < G * 2 * H; u += BX_WAVES * 64) slab[PB_WR + 3 * G * 2 * H + u] = (&L.dwr3[0][0])[u];
+    for (int u = tid; u < NT * 2 * H; u += BX_WAVES * 64) slab[PB_WT + u] = (&L.wt[0][0])[u];
+    for (int u = tid; u < 2 * H; u += BX_WAVES * 64) { slab[PB_LNG + u] = L.lng[u]; slab[PB_LNB + u] = L.lnb[u]; }
+}
+
+hipError_t launch_edge_backward_x2h(const float* att, const float* x, const float* P, const float* Qt, const float* Gt,
+                                    const float* gb, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
+                                    const float* e_w, const int* rows, const int* n_rows, int n_nodes, float* T, float* S,
+                                    float* sw, float* dP, float* dx, float* de_w, float* partial, int grid, hipStream_t s) {
+    profile_mark_begin(rows ? K_EDGE_X2H_BWD_LISTED : K_EDGE_X2H_BWD, s);
+#ifdef CBGX_ABLATE
+    static const int abl = getenv("CBGX_BWD_ABL") ? atoi(getenv("CBGX_BWD_ABL")) : 0;
+    hipLaunchKernelGGL(edge_backward_x2h_kernel, dim3(grid), dim3(BX_WAVES * 64), 0, s, att, x, P, Qt, Gt, gb, nbr, deg, lig,
+                       e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl);
+#else
+    hipLaunchKernelGGL(edge_backward_x2h_kernel, dim3(grid), dim3(BX_WAVES * 64), 0, s, att, x, P, Qt, Gt, gb, nbr, deg, lig,
+                       e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial);
+#endif
+    profile_mark_end(s);
+    return hipGetLastError();
+}
+
+}  // namespace cbgx

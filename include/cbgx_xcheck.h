@@ -12,7 +12,8 @@
 extern "C" {
 #endif
 
-/* 0 = MFMA generation (what libcbgx.so always runs), 1 = first-generation VALU kernels.
+/* 0 = the kernels libcbgx.so always runs, 1 = first-generation VALU kernels, 2 = as 0 but the x2h backward of the
+ * second generation (one workgroup per node, train_bwd_mfma.hip) instead of train_bwd_x2h.hip.
  * Returns the previous setting (>= 0) or CBGX_E_INVALID.  Process-wide. */
 int cbgx_debug_set_edge_kernel(int impl);
 
