@@ -404,11 +404,18 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 for (int s = 0; s < 4; ++s) qaa[u][s] = ld2(Brow + (size_t)(4 * s + q) * H + ch);
             }
             SCHED_FENCE();
+            // (LLVM keeps every memory access on its side of an atomic, even a relaxed one to another address space: the tile reads of
+            // the next step are therefore issued by hand before a step's atomics, or each would wait out a full LDS round trip)
             float s1[2][4], s2[2][4];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { s1[hf][r] = 0.f; s2[hf][r] = 0.f; }
+            float2 nvn[2][4];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nvn[hf][r] = *reinterpret_cast<const float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + 2 * c);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int ch = 32 * u + 2 * c;
@@ -418,48 +425,61 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) nv[hf][r] = *reinterpret_cast<const float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + ch);
+                    for (int r = 0; r < 4; ++r) nv[hf][r] = nvn[hf][r];
+                if (u < 3) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            nvn[hf][r] = *reinterpret_cast<const float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + ch + 32);
+                }
                 floatx4 fold[2];
+                float gsum[2], bsum[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const float gmc = j ? g2.y : g2.x, btc = j ? b2.y : b2.x;
-                    fold[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    floatx4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = {0.f, 0.f, 0.f, 0.f};
                     float pre[2][4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pre[0][r] = fmaf(j ? nv[0][r].y : nv[0][r].x, gmc, btc);
+                        pre[1][r] = fmaf(j ? nv[1][r].y : nv[1][r].x, gmc, btc);
+                        f0 = MFMA(fmaxf(pre[0][r], 0.f), w[0][r], f0);
+                        f1 = MFMA(fmaxf(pre[1][r], 0.f), w[1][r], f1);
+                    }
+                    fold[j] = f0 + f1;
+                    floatx4 de[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // d hidden[e][m] = sum_a w[e][a] Brow[a][m]
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        de[0] = MFMA(wT[0][s], j ? qa[s].y : qa[s].x, de[0]);
+                        de[1] = MFMA(wT[1][s], j ? qa[s].y : qa[s].x, de[1]);
+                    }
+                    float gs = 0.f, bs = 0.f;
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            pre[hf][r] = fmaf(j ? nv[hf][r].y : nv[hf][r].x, gmc, btc);
-                            fold[j] = MFMA(fmaxf(pre[hf][r], 0.f), w[hf][r], fold[j]);
-                        }
-                    float gsum = 0.f, bsum = 0.f;
-#pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
-                        floatx4 de = {0.f, 0.f, 0.f, 0.f};      // d hidden[e][m] = sum_a w[e][a] Brow[a][m]
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) de = MFMA(wT[hf][s], j ? qa[s].y : qa[s].x, de);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
                             const float nn = j ? nv[hf][r].y : nv[hf][r].x;
-                            const float dy = pre[hf][r] > 0.f ? de[r] : 0.f;
-                            gsum = fmaf(dy, nn, gsum);
-                            bsum += dy;
+                            const float dy = pre[hf][r] > 0.f ? de[hf][r] : 0.f;
+                            gs = fmaf(dy, nn, gs);
+                            bs += dy;
                             const float v = dy * gmc;
                             s1[hf][r] += v;
                             s2[hf][r] = fmaf(v, nn, s2[hf][r]);
                         }
-                    }
-                    gsum = xrow_sum(gsum);
-                    bsum = xrow_sum(bsum);
-                    if (q == 0) {
-                        atomicAdd(&L.lng[kv * H + ch + j], gsum);
-                        atomicAdd(&L.lnb[kv * H + ch + j], bsum);
-                    }
+                    gsum[j] = xrow_sum(gs);
+                    bsum[j] = xrow_sum(bs);
                 }
                 // fold D: lane (c = head, q) reg r <-> channel 32 u + 2 (4 q + r) + j
                 float* fd = fold_dst + (size_t)c * H + 32 * u + 8 * q;
                 *reinterpret_cast<float4*>(fd) = make_float4(fold[0][0], fold[1][0], fold[0][1], fold[1][1]);
                 *reinterpret_cast<float4*>(fd + 4) = make_float4(fold[0][2], fold[1][2], fold[0][3], fold[1][3]);
+                if (q == 0) {
+                    atomicAdd(&L.lng[kv * H + ch], gsum[0]);
+                    atomicAdd(&L.lng[kv * H + ch + 1], gsum[1]);
+                    atomicAdd(&L.lnb[kv * H + ch], bsum[0]);
+                    atomicAdd(&L.lnb[kv * H + ch + 1], bsum[1]);
+                }
             }
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
@@ -468,12 +488,19 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     s1[hf][r] = row16_sum(s1[hf][r]) * (1.f / H);
                     s2[hf][r] = row16_sum(s2[hf][r]) * (1.f / H);
                 }
-            // ---- pass 2 (C): d hidden again (cheaper than 64 live registers of it) -> d pre, in place in the tile ------------------------
+            // ---- pass 2 (C): d hidden again (cheaper than 64 live registers of it) -> d pre, in place in the tile.  All cells of a step
+            // are read before the first is written back (the compiler cannot tell the cells apart and would serialise read -> write) ----
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int ch = 32 * u + 2 * c;
                 const float2 g2 = g2a[u], b2 = b2a[u];
                 const float2 (&qa)[4] = qaa[u];
+                float2 nn[2][4];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nn[hf][r] = *reinterpret_cast<const float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + ch);
+                float2 out[2][4];
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     floatx4 de0 = {0.f, 0.f, 0.f, 0.f}, de1 = {0.f, 0.f, 0.f, 0.f};
@@ -481,15 +508,17 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     for (int s = 0; s < 4; ++s) { de0 = MFMA(wT[hf][s], qa[s].x, de0); de1 = MFMA(wT[hf][s], qa[s].y, de1); }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float2* cell = reinterpret_cast<float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + ch);
-                        const float2 nn = *cell;
-                        const float dn0 = fmaf(nn.x, g2.x, b2.x) > 0.f ? de0[r] * g2.x : 0.f;
-                        const float dn1 = fmaf(nn.y, g2.y, b2.y) > 0.f ? de1[r] * g2.y : 0.f;
+                        const float dn0 = fmaf(nn[hf][r].x, g2.x, b2.x) > 0.f ? de0[r] * g2.x : 0.f;
+                        const float dn1 = fmaf(nn[hf][r].y, g2.y, b2.y) > 0.f ? de1[r] * g2.y : 0.f;
                         // padded slots: d hidden = 0, n = 0, s1 = s2 = 0 -> exact zeros
-                        *cell = make_float2(rs1[hf][r] * (dn0 - s1[hf][r] - nn.x * s2[hf][r]),
-                                            rs1[hf][r] * (dn1 - s1[hf][r] - nn.y * s2[hf][r]));
+                        out[hf][r] = make_float2(rs1[hf][r] * (dn0 - s1[hf][r] - nn[hf][r].x * s2[hf][r]),
+                                                 rs1[hf][r] * (dn1 - s1[hf][r] - nn[hf][r].y * s2[hf][r]));
                     }
                 }
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) *reinterpret_cast<float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + ch) = out[hf][r];
             }
             wave_sync();
             // ---- pass 3 (E): d rbf[e][g] = sum_m d pre[e][m] Wr[type_e][g][m]  ->  d dist ----------------------------------------------
@@ -543,6 +572,11 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 for (int r = 0; r < 4; ++r)
                     joff[hf][r] = ((unsigned)__shfl(j0[hf], 4 * q + r, 64) * (unsigned)PROW + (unsigned)((2 + kv) * H + c)) * 4u;
             const unsigned ioff = ((unsigned)i * (unsigned)PROW + (unsigned)(kv * H + c)) * 4u;
+            float dpn[2][4];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dpn[hf][r] = tw[(4 * q + r + 16 * hf) * BX_PITCH + c];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 float dp[2][4];
@@ -550,8 +584,17 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
+                    for (int r = 0; r < 4; ++r) dp[hf][r] = dpn[hf][r];
+                if (t < 7) {    // the next step's cells, ahead of this step's atomics
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dpn[hf][r] = tw[(4 * q + r + 16 * hf) * BX_PITCH + 16 * (t + 1) + c];
+                }
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        dp[hf][r] = tw[(4 * q + r + 16 * hf) * BX_PITCH + 16 * t + c];
                         all += dp[hf][r];
                         const float lm = ((msh >> (r + 16 * hf)) & 1u) ? 1.f : 0.f;
                         ligs = fmaf(lm, dp[hf][r], ligs);
