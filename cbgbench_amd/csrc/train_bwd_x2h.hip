@@ -41,12 +41,16 @@ __constant__ float c_mu_x[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 
 constexpr int BX_WAVES = 8;
 constexpr int BX_PITCH = H + 4;                 // transpose tile row pitch (floats): 16-byte aligned rows
 constexpr int BX_TILE = KNN * BX_PITCH;         // 4224 floats per wave
+// the four pad columns of a tile row hold per-edge scalars of the node (row = edge) instead of living in registers across the
+// phases: edge length, neighbour index, d L / d dist; column 131 of rows 0..19 holds the rbf centres
+constexpr int BX_DIST = H, BX_NBR = H + 1, BX_DDIST = H + 2, BX_MU = H + 3;
 
 struct BwdX2hLds {
     float tile[BX_WAVES][BX_TILE];              // per-wave E <-> C transposes (and the 32 x 16 E1 transposes)
     float dwr3[G][2 * H];                       // d Wr of the dominant edge type 3, accumulated with ds_add_f32
     float wt[NT][2 * H];                        // type-column gradients
     float lng[2 * H], lnb[2 * H];               // LayerNorm affine gradients (k | v)
+    float ln[4][H];                             // LayerNorm affine itself: k gamma, k beta, v gamma, v beta
 };
 
 // accesses of the wave's tile by different lanes are ordered by the LDS queue (one wave, in issue order); the fence keeps the
@@ -80,15 +84,12 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
     for (int u = tid; u < G * 2 * H; u += BX_WAVES * 64) (&L.dwr3[0][0])[u] = 0.f;
     for (int u = tid; u < NT * 2 * H; u += BX_WAVES * 64) (&L.wt[0][0])[u] = 0.f;
     for (int u = tid; u < 2 * H; u += BX_WAVES * 64) { L.lng[u] = 0.f; L.lnb[u] = 0.f; }
+    for (int u = tid; u < 4 * H; u += BX_WAVES * 64) (&L.ln[0][0])[u] = att[A_LNK_G + u];
     __threadfence();
     __syncthreads();
     float* tw = L.tile[wave];
     const int count = rows ? *n_rows_ptr : n_nodes;
-    const float mu0 = c_mu_x[c0], mu1 = c_mu_x[16 + (c0 & 3)];
-    float muq[5];
-#pragma unroll
-    for (int s = 0; s < 5; ++s) muq[s] = c_mu_x[4 * s + q0];
-
+    if (lane0 < G) tw[lane0 * BX_PITCH + BX_MU] = c_mu_x[lane0];
     // A node's header (index, degree, class, neighbour list) is fetched one node ahead: its three dependent round trips
     // (rows -> deg / nbr -> coordinates) would otherwise open every node
     const int stride = gridDim.x * BX_WAVES;
@@ -139,32 +140,39 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
         const bool has_lig = (mask_lig & mask_valid) != 0;
         const bool has_prot = ((~mask_lig) & mask_valid) != 0 || d == 0;
         const bool mixed = has_lig && has_prot;
-        const unsigned msh = mask_lig >> (4 * q);       // bit r + 16 hf <-> E1 slot (hf, r)
-        const unsigned vsh = mask_valid >> (4 * q);
+        const unsigned msh_n = mask_lig >> (4 * q);       // bit r + 16 hf <-> E1 slot (hf, r)
+        const unsigned vsh_n = mask_valid >> (4 * q);
         const bool val0[2] = {c < d, c + 16 < d};
-        // E1 copy of the edge length: lane (c', q') needs edge 4q' + r (+16 hf) = the E0 value of lane 4q' + r
-        float dist1[2][4];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dist1[hf][r] = __shfl(dist0[hf], 4 * q + r, 64);
-        // rbf of the E1 edges at g = c (tile 0) and g = 16 + c (tile 1, lanes c < 4): A operand of d Wr, factor of d dist.  Recomputed
-        // where needed (16 v_exp) instead of living in 16 registers across the phases
-        auto rbf_e1 = [&](float (&r0)[2][4], float (&r1)[2][4]) {
+        // per-edge scalars into the tile's pad columns (rows = edges); the E1 mapping reads them back where it needs them
+        wave_sync();
+        if (q < 2) {
+            const int e = c + 16 * q;
+            tw[e * BX_PITCH + BX_DIST] = q ? dist0[1] : dist0[0];
+            reinterpret_cast<int*>(tw)[e * BX_PITCH + BX_NBR] = q ? j0[1] : j0[0];
+            tw[e * BX_PITCH + BX_DDIST] = 0.f;
+        }
+        wave_sync();
+        // rbf of the E1 edges (lane (c, q), [hf][r] <-> edge 4q + r + 16 hf) at g = c (tile 0) and g = 16 + c (tile 1, lanes c < 4):
+        // A operand of d Wr, factor of d dist.  Recomputed where needed (16 v_exp) instead of living in registers across the phases;
+        // u0 / u1 = dist - mu come back as well
+        auto rbf_e1 = [&](unsigned vsh, float (&r0)[2][4], float (&r1)[2][4], float (&u0)[2][4], float (&u1)[2][4]) {
+            const float mu0 = tw[c * BX_PITCH + BX_MU], mu1 = tw[(16 + (c & 3)) * BX_PITCH + BX_MU];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float vm = ((vsh >> (r + 16 * hf)) & 1u) ? 1.f : 0.f;
-                    const float u0 = dist1[hf][r] - mu0, u1 = dist1[hf][r] - mu1;
-                    r0[hf][r] = fast_exp(-0.5f * (u0 * u0)) * vm;
-                    r1[hf][r] = fast_exp(-0.5f * (u1 * u1)) * (c < 4 ? vm : 0.f);
+                    const float dist = tw[(4 * q + r + 16 * hf) * BX_PITCH + BX_DIST];
+                    u0[hf][r] = dist - mu0;
+                    u1[hf][r] = dist - mu1;
+                    r0[hf][r] = fast_exp(-0.5f * (u0[hf][r] * u0[hf][r])) * vm;
+                    r1[hf][r] = fast_exp(-0.5f * (u1[hf][r] * u1[hf][r])) * (c < 4 ? vm : 0.f);
                 }
         };
         const int ty_prot = lig_i ? 2 : 3, ty_lig = lig_i ? 0 : 1;
-        float ddist[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // d L / d dist, E1 mapping (all 16 lanes of a row), k + v
         float alpha[2][4];       // softmax weights; after phase 1: d L / d score
 
+        const int p1 = has_prot ? 0 : 1;       // first (usually only) source class present
         // three phases through one body: 0 = key forward (scores -> alpha), 1 = value forward + backward, 2 = key forward
         // again + backward
 #pragma unroll 1
@@ -172,17 +180,17 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
             if ((abl & 32) && ph == 2) break;
             const int kv = ph == 1;
             // everything derived from these is phase-invariant and would be hoisted out of the phase loop into ~60 live registers
-            asm volatile("" : "+v"(lane), "+v"(c), "+v"(q), "+v"(dist0[0]), "+v"(dist0[1]), "+v"(j0[0]), "+v"(j0[1]));
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(dist1[hf][r]));
+            unsigned msh = msh_n, vsh = vsh_n;
+            asm volatile("" : "+v"(lane), "+v"(c), "+v"(q), "+v"(dist0[0]), "+v"(dist0[1]), "+v"(j0[0]), "+v"(j0[1]), "+v"(msh), "+v"(vsh));
             const float* Brow = (kv ? Gt : Qt) + (size_t)i * HEADS * H;
-            const float* lng = att + (kv ? A_LNV_G : A_LNK_G);
-            const float* lnb = att + (kv ? A_LNV_B : A_LNK_B);
+            const float* lng = L.ln[2 * kv];
+            const float* lnb = L.ln[2 * kv + 1];
             // ---- forward of the path, E labeling: n[hf][t][r] <-> edge c + 16 hf, channel 16 t + 4 q + r -------------------------------
             floatx4 n[2][8];
             float rstd[2];
+            WTuples wt[8];
+            float4 br[8];
+            const float* frag = att + (kv ? A_FRAGV_EM : A_IMG + IMG_FRAG_K);
             {
                 // every gather of the stage is issued before its first use (the scheduler otherwise serialises load -> wait -> add
                 // to save registers: one memory round trip per row chunk)
@@ -196,9 +204,20 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 for (int t = 0; t < 8; ++t) pa[t] = (abl & 128) ? make_float4(1.f, 2.f, 3.f, 4.f) : ld4(psa + 16 * t);
 #pragma unroll
                 for (int t = 0; t < 8; ++t) pb[t] = (abl & 128) ? make_float4(1.f, 2.f, 3.f, 4.f) : ld4(psb + 16 * t);
+                // the same round trip brings the rbf weight tuples of the first source class
+                {
+                    const float* fa = frag + (size_t)etype(p1 == 1, lig_i) * (8 * FRAG_BLK);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) wt[t] = load_wtuples(fa + t * FRAG_BLK, lane);
+                }
                 SCHED_FENCE();
 #pragma unroll
                 for (int t = 0; t < 8; ++t) { n[0][t] = f4(pd[t]) + f4(pa[t]); n[1][t] = f4(pd[t]) + f4(pb[t]); }
+                // the contraction's B rows: in flight behind the rbf MFMAs and the LayerNorm (phase 2 has no contraction; loading
+                // them anyway keeps the array from being carried around the phase loop)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) br[t] = ld4(Brow + (size_t)c * H + 16 * t + 4 * q);
+                SCHED_FENCE();
                 if (has_lig) {      // type column of ligand sources (P already holds the protein-source one)
                     const float* dw = att + A_IMG + IMG_WT + lig_i * 2 * H + kv * H + 4 * q;
                     const float m0 = lg0[0] ? 1.f : 0.f, m1 = lg0[1] ? 1.f : 0.f;
@@ -214,11 +233,11 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 }
                 // rbf columns, split-f16 exactly as the forward kernel (edge_mfma.hip edge_major_half); weight tuples from the
                 // packed table in memory, shared by the two halves
-#pragma unroll 1
-                for (int p = 0; p < 2; ++p) {
-                    if (p == 0 ? !has_prot : !has_lig) continue;  // wave-uniform
-                    if (abl & 16) continue;
+                for (int p = p1;;) {
                     half4 B[2][4];
+                    float muq[5];
+#pragma unroll
+                    for (int s = 0; s < 5; ++s) muq[s] = tw[(4 * s + q) * BX_PITCH + BX_MU];
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
                         float Rm[5];
@@ -229,18 +248,21 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                         }
                         rbf_tuples(Rm, B[hf]);
                     }
-                    const float* fa = att + (kv ? A_FRAGV_EM : A_IMG + IMG_FRAG_K) + (size_t)etype(p == 1, lig_i) * (8 * FRAG_BLK);
-                    WTuples wt[8];
+                    if (!(abl & 16)) {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            n[0][t] = MFMAH(wt[t].t1, B[0][0], n[0][t]);       n[1][t] = MFMAH(wt[t].t1, B[1][0], n[1][t]);
+                            n[0][t] = MFMAH(wt[t].t1, B[0][1], n[0][t]);       n[1][t] = MFMAH(wt[t].t1, B[1][1], n[1][t]);
+                            n[0][t] = MFMAH(wt[t].t2, B[0][2], n[0][t]);       n[1][t] = MFMAH(wt[t].t2, B[1][2], n[1][t]);
+                            n[0][t] = MFMAH(wt[t].t3, B[0][3], n[0][t]);       n[1][t] = MFMAH(wt[t].t3, B[1][3], n[1][t]);
+                        }
+                    }
+                    if (p == 1 || !has_lig) break;      // mixed neighbourhood: the ligand-source class as well
+                    p = 1;
+                    const float* fa = frag + (size_t)etype(true, lig_i) * (8 * FRAG_BLK);
 #pragma unroll
                     for (int t = 0; t < 8; ++t) wt[t] = load_wtuples(fa + t * FRAG_BLK, lane);
                     SCHED_FENCE();
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        n[0][t] = MFMAH(wt[t].t1, B[0][0], n[0][t]);       n[1][t] = MFMAH(wt[t].t1, B[1][0], n[1][t]);
-                        n[0][t] = MFMAH(wt[t].t1, B[0][1], n[0][t]);       n[1][t] = MFMAH(wt[t].t1, B[1][1], n[1][t]);
-                        n[0][t] = MFMAH(wt[t].t2, B[0][2], n[0][t]);       n[1][t] = MFMAH(wt[t].t2, B[1][2], n[1][t]);
-                        n[0][t] = MFMAH(wt[t].t3, B[0][3], n[0][t]);       n[1][t] = MFMAH(wt[t].t3, B[1][3], n[1][t]);
-                    }
                 }
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {    // LayerNorm: the first Linear is centred, mean(pre) == 0
@@ -275,25 +297,16 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) { o[hf][0] = floatx4{0.f, 0.f, 0.f, 0.f}; o[hf][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-                for (int tc = 0; tc < 8; tc += 4) {
-                    float4 g4[4], b4[4], br[4];
+                for (int t = 0; t < 8; ++t) {
+                    const float4 g4 = ld4(lng + 16 * t + 4 * q), b4 = ld4(lnb + 16 * t + 4 * q);     // LDS
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        g4[t] = ld4(lng + 16 * (tc + t) + 4 * q);
-                        b4[t] = ld4(lnb + 16 * (tc + t) + 4 * q);
-                        br[t] = ld4(Brow + (size_t)c * H + 16 * (tc + t) + 4 * q);
+                    for (int hf = 0; hf < 2; ++hf) {    // padded slots produce ReLU(beta) . B: masked by `valid` / e_w = 0 below
+                        const floatx4 nn = n[hf][t];
+                        o[hf][0] = MFMA(fmaxf(fmaf(nn[0], g4.x, b4.x), 0.f), br[t].x, o[hf][0]);
+                        o[hf][1] = MFMA(fmaxf(fmaf(nn[1], g4.y, b4.y), 0.f), br[t].y, o[hf][1]);
+                        o[hf][0] = MFMA(fmaxf(fmaf(nn[2], g4.z, b4.z), 0.f), br[t].z, o[hf][0]);
+                        o[hf][1] = MFMA(fmaxf(fmaf(nn[3], g4.w, b4.w), 0.f), br[t].w, o[hf][1]);
                     }
-                    SCHED_FENCE();
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int hf = 0; hf < 2; ++hf) {    // padded slots produce ReLU(beta) . B: masked by `valid` / e_w = 0 below
-                            const floatx4 nn = n[hf][tc + t];
-                            o[hf][0] = MFMA(fmaxf(fmaf(nn[0], g4[t].x, b4[t].x), 0.f), br[t].x, o[hf][0]);
-                            o[hf][1] = MFMA(fmaxf(fmaf(nn[1], g4[t].y, b4[t].y), 0.f), br[t].y, o[hf][1]);
-                            o[hf][0] = MFMA(fmaxf(fmaf(nn[2], g4[t].z, b4[t].z), 0.f), br[t].z, o[hf][0]);
-                            o[hf][1] = MFMA(fmaxf(fmaf(nn[3], g4[t].w, b4[t].w), 0.f), br[t].w, o[hf][1]);
-                        }
                 }
                 if (ph == 0) {      // softmax over the incoming edges
                     float mx = -INFINITY;
@@ -370,12 +383,12 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tw[(4 * q + r + 16 * hf) * 20 + c] = w[hf][r];
+                for (int r = 0; r < 4; ++r) tw[(4 * q + r + 16 * hf) * BX_PITCH + c] = w[hf][r];
             wave_sync();
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) wT[hf][s] = tw[(c + 16 * hf) * 20 + 4 * s + q];
+                for (int s = 0; s < 4; ++s) wT[hf][s] = tw[(c + 16 * hf) * BX_PITCH + 4 * s + q];
             wave_sync();
             // n -> tile [edge][channel]
 #pragma unroll
@@ -522,8 +535,9 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
             }
             wave_sync();
             // ---- pass 3 (E): d rbf[e][g] = sum_m d pre[e][m] Wr[type_e][g][m]  ->  d dist ----------------------------------------------
-            float rT0[2][4], rT1[2][4];
-            rbf_e1(rT0, rT1);
+            float rT0[2][4], rT1[2][4], u0[2][4], u1[2][4];
+            rbf_e1(vsh, rT0, rT1, u0, u1);
+            float dd[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 1
             for (int p = 0; p < 2; ++p) {
                 if (p == 0 ? !has_prot : !has_lig) continue;
@@ -556,10 +570,15 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float u0 = dist1[hf][r] - mu0, u1 = dist1[hf][r] - mu1;
-                        const float v = d0[hf][r] * (-u0 * rT0[hf][r]) + d1[hf][r] * (-u1 * rT1[hf][r]);
-                        ddist[hf][r] += row16_sum(v);
+                        const float v = d0[hf][r] * (-u0[hf][r] * rT0[hf][r]) + d1[hf][r] * (-u1[hf][r] * rT1[hf][r]);
+                        dd[hf][r] += row16_sum(v);
                     }
+            }
+            if (c == 0) {       // d L / d dist of the row's eight edges, accumulated over the two paths in the pad column
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tw[(4 * q + r + 16 * hf) * BX_PITCH + BX_DDIST] += dd[hf][r];
             }
             // ---- pass 4 (C): every atomic of the path in one burst, no global load in between (any vmcnt wait after an atomic is a
             // full drain on gfx9): neighbour rows, own row, type columns, rbf columns of the first Linear -------------------------------------
@@ -570,7 +589,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    joff[hf][r] = ((unsigned)__shfl(j0[hf], 4 * q + r, 64) * (unsigned)PROW + (unsigned)((2 + kv) * H + c)) * 4u;
+                    joff[hf][r] = ((unsigned)reinterpret_cast<const int*>(tw)[(4 * q + r + 16 * hf) * BX_PITCH + BX_NBR] * (unsigned)PROW + (unsigned)((2 + kv) * H + c)) * 4u;
             const unsigned ioff = ((unsigned)i * (unsigned)PROW + (unsigned)(kv * H + c)) * 4u;
             float dpn[2][4];
 #pragma unroll
@@ -646,21 +665,14 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
             wave_sync();
         }
         // =================================== coordinates ============================================================================
-        // d dist (E1 mapping, replicated over the 16 lanes of a row) -> one lane per edge through the tile: lane (c, q < 2) <-> edge
-        // c + 16 q; the node's own gradient is reduced over the wave first (one atomic per coordinate instead of 32)
-        wave_sync();
-        if (c == 0) {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) tw[4 * q + r + 16 * hf] = ddist[hf][r];
-        }
+        // one lane per edge: lane (c, q < 2) <-> edge c + 16 q, its d L / d dist from the pad column; the node's own gradient is
+        // reduced over the wave first (one atomic per coordinate instead of 32)
         wave_sync();
         {
             const int sel = q & 1;
             const int j = sel ? j0[1] : j0[0];
             const float xj = x[3 * j], yj = x[3 * j + 1], zj = x[3 * j + 2];
-            const float dd = tw[c + 16 * sel];
+            const float dd = tw[(c + 16 * sel) * BX_PITCH + BX_DDIST];
             const float dist = sel ? dist0[1] : dist0[0];
             const bool on = q < 2 && c + 16 * sel < d;
             const float cf = (on && dist > 0.f) ? dd / dist : 0.f;
