@@ -24,6 +24,7 @@
 // launch_edge_backward_mfma, so api_train.hip swaps one call.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "edge_common.h"
@@ -34,6 +35,22 @@
 namespace cbgx {
 
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// libcbgx_ablate.so only: cycle counters per section of the kernel (s_memtime at the section boundaries, summed over all waves),
+// printed by the launcher when CBGX_BX_PROF is set
+#ifdef CBGX_ABLATE
+__device__ unsigned long long g_bx_prof[16];
+#define BX_T(k)                                                          \
+    do {                                                                 \
+        SCHED_FENCE();                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();    \
+        if (lane0 == 0) atomicAdd(&g_bx_prof[k], now_ - tprev_);         \
+        tprev_ = now_;                                                   \
+        SCHED_FENCE();                                                   \
+    } while (0)
+#else
+#define BX_T(k) do { } while (0)
+#endif
 
 __constant__ float c_mu_x[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.75f, 3.f,
                                 3.5f, 4.f, 4.5f, 5.f, 5.5f, 6.f, 7.f, 8.f, 9.f, 10.f};
@@ -88,6 +105,9 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
     __threadfence();
     __syncthreads();
     float* tw = L.tile[wave];
+#ifdef CBGX_ABLATE
+    unsigned long long tprev_ = __builtin_readcyclecounter();
+#endif
     const int count = rows ? *n_rows_ptr : n_nodes;
     if (lane0 < G) tw[lane0 * BX_PITCH + BX_MU] = c_mu_x[lane0];
     // A node's header (index, degree, class, neighbour list) is fetched one node ahead: its three dependent round trips
@@ -169,6 +189,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     r1[hf][r] = fast_exp(-0.5f * (u1[hf][r] * u1[hf][r])) * (c < 4 ? vm : 0.f);
                 }
         };
+        BX_T(0);
         const int ty_prot = lig_i ? 2 : 3, ty_lig = lig_i ? 0 : 1;
         float alpha[2][4];       // softmax weights; after phase 1: d L / d score
 
@@ -204,12 +225,14 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 for (int t = 0; t < 8; ++t) pa[t] = (abl & 128) ? make_float4(1.f, 2.f, 3.f, 4.f) : ld4(psa + 16 * t);
 #pragma unroll
                 for (int t = 0; t < 8; ++t) pb[t] = (abl & 128) ? make_float4(1.f, 2.f, 3.f, 4.f) : ld4(psb + 16 * t);
+                BX_T(11);
                 // the same round trip brings the rbf weight tuples of the first source class
                 {
                     const float* fa = frag + (size_t)etype(p1 == 1, lig_i) * (8 * FRAG_BLK);
 #pragma unroll
                     for (int t = 0; t < 8; ++t) wt[t] = load_wtuples(fa + t * FRAG_BLK, lane);
                 }
+                BX_T(10);
                 SCHED_FENCE();
 #pragma unroll
                 for (int t = 0; t < 8; ++t) { n[0][t] = f4(pd[t]) + f4(pa[t]); n[1][t] = f4(pd[t]) + f4(pb[t]); }
@@ -233,6 +256,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 }
                 // rbf columns, split-f16 exactly as the forward kernel (edge_mfma.hip edge_major_half); weight tuples from the
                 // packed table in memory, shared by the two halves
+                BX_T(1);
                 for (int p = p1;;) {
                     half4 B[2][4];
                     float muq[5];
@@ -278,6 +302,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     for (int t = 0; t < 8; ++t) n[hf][t] = n[hf][t] * sc;
                 }
             }
+            BX_T(2);
             // ---- scores (k) / G . v_raw (v):  out[hf] lane (c = head, q) reg r <-> edge 4q + r + 16 hf -----------------------------------
             float w[2][4];      // coefficient of hidden[e] per head in the backward (k: d score, v: alpha e_w)
             if ((abl & 64) && ph < 2) {
@@ -334,6 +359,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) alpha[hf][r] *= inv;
+                    BX_T(3);
                     continue;
                 }
                 const float gbc = gb[(size_t)i * HEADS + c];
@@ -374,6 +400,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) w[hf][r] = alpha[hf][r];
             }
+            BX_T(3);
             // ================================= backward of the path =======================================================================
             if (abl & 8) continue;
             float* fold_dst = (kv ? S : T) + (size_t)i * HEADS * H;
@@ -403,6 +430,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rs1[hf][r] = __shfl(rstd[hf], 4 * q + r, 64);
+            BX_T(4);
             // ---- pass 1, C labeling: lane (c, q), step (u, j), [hf][r] <-> channel 32 u + 2 c + j, edge 4q + r + 16 hf ------------
             // folds T / S, LayerNorm affine gradients, the two per-edge sums of the LayerNorm backward.  Padded slots need no mask:
             // their w and wT are zero, so they add nothing to the fold and their d hidden is zero.
@@ -501,6 +529,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     s1[hf][r] = row16_sum(s1[hf][r]) * (1.f / H);
                     s2[hf][r] = row16_sum(s2[hf][r]) * (1.f / H);
                 }
+            BX_T(5);
             // ---- pass 2 (C): d hidden again (cheaper than 64 live registers of it) -> d pre, in place in the tile.  All cells of a step
             // are read before the first is written back (the compiler cannot tell the cells apart and would serialise read -> write) ----
 #pragma unroll
@@ -534,6 +563,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     for (int r = 0; r < 4; ++r) *reinterpret_cast<float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + ch) = out[hf][r];
             }
             wave_sync();
+            BX_T(6);
             // ---- pass 3 (E): d rbf[e][g] = sum_m d pre[e][m] Wr[type_e][g][m]  ->  d dist ----------------------------------------------
             float rT0[2][4], rT1[2][4], u0[2][4], u1[2][4];
             rbf_e1(vsh, rT0, rT1, u0, u1);
@@ -580,6 +610,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) tw[(4 * q + r + 16 * hf) * BX_PITCH + BX_DDIST] += dd[hf][r];
             }
+            BX_T(7);
             // ---- pass 4 (C): every atomic of the path in one burst, no global load in between (any vmcnt wait after an atomic is a
             // full drain on gfx9): neighbour rows, own row, type columns, rbf columns of the first Linear -------------------------------------
             // (labeling of this pass: step t, lane (c, q), [hf][r] <-> channel 16 t + c -- a row's 16 lanes add to one 64-byte run)
@@ -663,6 +694,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 }
             }
             wave_sync();
+            BX_T(8);
         }
         // =================================== coordinates ============================================================================
         // one lane per edge: lane (c, q < 2) <-> edge c + 16 q, its d L / d dist from the pad column; the node's own gradient is
@@ -689,6 +721,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
             }
         }
         wave_sync();
+        BX_T(9);
     }
     // per-workgroup partial sums of the edge-indexed weight gradients
     __syncthreads();
@@ -704,8 +737,28 @@ hipError_t launch_edge_backward_x2h(const float* att, const float* x, const floa
     profile_mark_begin(rows ? K_EDGE_X2H_BWD_LISTED : K_EDGE_X2H_BWD, s);
 #ifdef CBGX_ABLATE
     static const int abl = getenv("CBGX_BWD_ABL") ? atoi(getenv("CBGX_BWD_ABL")) : 0;
+    static const bool prof = getenv("CBGX_BX_PROF") != nullptr;
+    if (prof && !rows) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bx_prof), z, sizeof(z));
+    }
     hipLaunchKernelGGL(edge_backward_x2h_kernel, dim3(grid), dim3(BX_WAVES * 64), 0, s, att, x, P, Qt, Gt, gb, nbr, deg, lig,
                        e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl);
+    if (prof && !rows) {
+        unsigned long long z[16];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_bx_prof), sizeof(z));
+        static int shown = 0;
+        if (shown++ % 7 == 3) {
+            const char* nm[12] = {"prologue", "gather wait + adds", "rbf+LN", "contraction/softmax", "transposes", "pass1", "pass2", "pass3",
+                                  "pass4", "coordinates", "tuple issue", "gather issue"};
+            unsigned long long tot = 0;
+            for (int k = 0; k < 12; ++k) tot += z[k];
+            fprintf(stderr, "[bx prof] n=%d grid=%d total wave-cycles %llu:", n_nodes, grid, tot);
+            for (int k = 0; k < 12; ++k) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)z[k] / (double)tot);
+            fprintf(stderr, "\n");
+        }
+    }
 #else
     hipLaunchKernelGGL(edge_backward_x2h_kernel, dim3(grid), dim3(BX_WAVES * 64), 0, s, att, x, P, Qt, Gt, gb, nbr, deg, lig,
                        e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial);
