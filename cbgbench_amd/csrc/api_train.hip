@@ -67,7 +67,7 @@ static Tape carve_tape(void* base, int n, int L) {
 
 // ---- backward workspace -----------------------------------------------------------------------------------
 struct TrainWs {
-    float *P, *Qt, *Gt, *T, *S, *gb, *sw, *qs, *dqb, *zb, *dP, *gh, *gx[2], *de_w, *E8, *tmp, *partial, *folded, *qln;
+    float *P, *Qt, *Gt, *T, *S, *gb, *sw, *qs, *dqb, *zb, *dP, *gh, *gx[2], *de_w, *E8, *tmp, *partial, *folded, *qln, *nk;
     int *act, *act_count;
     uint8_t* mask;        // receptive field of the loss, walked backwards (see cbgx_unitransformer_backward)
     int *rf_list[2], *rf_count;
@@ -118,6 +118,7 @@ static TrainWs carve_train(void* base, int n) {
     w.partial = (float*)take(w.partial_floats * 4);
     w.folded = (float*)take((size_t)FOLD * H * PROW * 4);
     w.qln = (float*)take(2 * H * 4);
+    w.nk = (float*)take(BX_NK_FLOATS * 4);     // x2h edge backward: the key path of every wave in flight, parked between two phases
     w.total = off;
     return w;
 }
@@ -162,7 +163,10 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     // x2h blocks run the one-wave-per-node backward (8 nodes in flight per workgroup); h2x blocks and, in libcbgx_xcheck.so,
     // cbgx_debug_set_edge_kernel(2) the second-generation workgroup-per-node kernel
     const bool gen3 = x2h && g_edge_impl == 0;
-    const int eg = gen3 ? edge_grid((n + 7) / 8) : edge_grid(n), ng = node_grid(n);
+    // (gen3: 8 nodes in flight per workgroup; a grid that is a multiple of 8 switches on its XCD-aware node partition)
+    int eg = gen3 ? edge_grid((n + 7) / 8) : edge_grid(n);
+    if (gen3 && eg >= 64) eg &= ~7;
+    const int ng = node_grid(n);
     // recompute the node stage of the forward: the MFMA node kernels (centred projection; own columns and query fold only
     // for the listed rows) with the MFMA edge backward, the first-generation ones with the VALU cross-check kernel
     // (skipped when the taped forward left its own P / Qt: P_saved, Qt_saved)
@@ -191,7 +195,7 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
 #endif
     if (gen3)
         HIP_TRY(launch_edge_backward_x2h(att, x, Pn, Qn, w.Gt, w.gb, nbr, deg, lig, e_w, rows, n_rows, n, w.T, w.S, w.sw,
-                                         w.dP, dx, de_w, w.partial, eg, s));
+                                         w.dP, dx, de_w, w.partial, w.nk, eg, s));
     else
         HIP_TRY(launch_edge_backward_mfma(x2h, att, x, Pn, Qn, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n,
                                           w.T, w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s, 1));

@@ -61,6 +61,8 @@ constexpr int BX_TILE = KNN * BX_PITCH;         // 4224 floats per wave
 // the four pad columns of a tile row hold per-edge scalars of the node (row = edge) instead of living in registers across the
 // phases: edge length, neighbour index, d L / d dist; column 131 of rows 0..19 holds the rbf centres
 constexpr int BX_DIST = H, BX_NBR = H + 1, BX_DDIST = H + 2, BX_MU = H + 3;
+// per-wave slot of the scratch buffer that parks the key path between phase 0 and phase 2: n [2][8][64 lanes][4] + rstd [64][2]
+constexpr int BX_NK_SLOT = KNN * H + 128;
 
 struct BwdX2hLds {
     float tile[BX_WAVES][BX_TILE];              // per-wave E <-> C transposes (and the 32 x 16 E1 transposes)
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig,
     const float* __restrict__ e_w, const int* __restrict__ rows, const int* __restrict__ n_rows_ptr, int n_nodes,
     float* __restrict__ T, float* __restrict__ S, float* __restrict__ sw, float* __restrict__ dP, float* __restrict__ dx,
-    float* __restrict__ de_w, float* __restrict__ partial
+    float* __restrict__ de_w, float* __restrict__ partial, float* __restrict__ nk_scratch
 #ifdef CBGX_ABLATE
     , int abl
 #endif
@@ -112,8 +114,20 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
     if (lane0 < G) tw[lane0 * BX_PITCH + BX_MU] = c_mu_x[lane0];
     // A node's header (index, degree, class, neighbour list) is fetched one node ahead: its three dependent round trips
     // (rows -> deg / nbr -> coordinates) would otherwise open every node
-    const int stride = gridDim.x * BX_WAVES;
-    int it = blockIdx.x * BX_WAVES + wave;
+    // XCD-aware persistent schedule (as the forward kernel): workgroup b runs on XCD b % 8, so every XCD gets one contiguous
+    // eighth of the work list -- a graph's projection rows and their gradient rows then live in one L2
+    int it, it_end, stride;
+    if ((gridDim.x & 7) == 0) {
+        const int per_xcd = (((count + 7) >> 3) + BX_WAVES - 1) / BX_WAVES * BX_WAVES;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        it = xcd * per_xcd + slot * BX_WAVES + wave;
+        it_end = min(count, (xcd + 1) * per_xcd);
+        stride = (gridDim.x >> 3) * BX_WAVES;
+    } else {
+        it = blockIdx.x * BX_WAVES + wave;
+        it_end = count;
+        stride = gridDim.x * BX_WAVES;
+    }
     int i_n = 0, d_n = 0, lig_n = 0, jr_n[2] = {0, 0};
     auto load_header = [&](int itx) {
         i_n = __builtin_amdgcn_readfirstlane(rows ? rows[itx] : itx);
@@ -122,12 +136,12 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
         jr_n[0] = nbr[(size_t)i_n * KNN + c0];
         jr_n[1] = nbr[(size_t)i_n * KNN + 16 + c0];
     };
-    if (it < count) load_header(it);
-    for (; it < count; it += stride) {
+    if (it < it_end) load_header(it);
+    for (; it < it_end; it += stride) {
         const int i = i_n;
         const int d = __builtin_amdgcn_readfirstlane(d_n), lig_i = __builtin_amdgcn_readfirstlane(lig_n);
         const int jr[2] = {jr_n[0], jr_n[1]};
-        load_header(it + stride < count ? it + stride : it);
+        load_header(it + stride < it_end ? it + stride : it);
         // the lane coordinates are re-materialised every node: otherwise every per-lane address below is loop-invariant, gets
         // hoisted out of the node loop as a 64-bit pointer pair and spilled
         int lane = lane0, c = c0, q = q0;
@@ -209,10 +223,23 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
             // ---- forward of the path, E labeling: n[hf][t][r] <-> edge c + 16 hf, channel 16 t + 4 q + r -------------------------------
             floatx4 n[2][8];
             float rstd[2];
-            WTuples wt[8];
             float4 br[8];
             const float* frag = att + (kv ? A_FRAGV_EM : A_IMG + IMG_FRAG_K);
-            {
+            // the key path's normalised pre-activation is parked in the wave's slot of a scratch buffer in phase 0 and read back in
+            // phase 2 (16 coalesced KB each way) instead of being gathered, multiplied and normalised a second time
+            float* nk = nk_scratch + ((size_t)blockIdx.x * BX_WAVES + wave) * BX_NK_SLOT + 4 * lane;
+            if (ph == 2) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) n[hf][t] = f4(ld4(nk + (hf * 8 + t) * 256));
+                const float2 rs = ld2(nk + 16 * 256 - 2 * lane);
+                rstd[0] = rs.x; rstd[1] = rs.y;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) br[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                SCHED_FENCE();
+            } else {
+                WTuples wt[8];
                 // every gather of the stage is issued before its first use (the scheduler otherwise serialises load -> wait -> add
                 // to save registers: one memory round trip per row chunk)
                 const float* pdp = P + (size_t)i * PROW + kv * H + 4 * q;
@@ -300,6 +327,14 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     const float sc = val0[hf] ? rstd[hf] : 0.f;     // padded slots: exact zeros downstream
 #pragma unroll
                     for (int t = 0; t < 8; ++t) n[hf][t] = n[hf][t] * sc;
+                }
+                if (ph == 0) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            *reinterpret_cast<float4*>(nk + (hf * 8 + t) * 256) = make_float4(n[hf][t][0], n[hf][t][1], n[hf][t][2], n[hf][t][3]);
+                    *reinterpret_cast<float2*>(nk + 16 * 256 - 2 * lane) = make_float2(rstd[0], rstd[1]);
                 }
             }
             BX_T(2);
@@ -677,7 +712,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     const int col = kv * H + 16 * t + c;
                     if (tyc == 3) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) atomicAdd(&L.dwr3[4 * q + r][col], a0[r]);
+                        for (int r = 0; r < 4; ++r) atomicAdd(&L.dwr3[4 * q + r][col ^ (16 * (q & 1))], a0[r]);   // swizzle: 2-way banks, not 4
                         if (q == 0) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) atomicAdd(&L.dwr3[16 + r][col], a1[r]);
@@ -725,7 +760,8 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
     }
     // per-workgroup partial sums of the edge-indexed weight gradients
     __syncthreads();
-    for (int u = tid; u < G * 2 * H; u += BX_WAVES * 64) slab[PB_WR + 3 * G * 2 * H + u] = (&L.dwr3[0][0])[u];
+    for (int u = tid; u < G * 2 * H; u += BX_WAVES * 64)       // rows 4q + r of q odd are stored with column bit 4 flipped
+        slab[PB_WR + 3 * G * 2 * H + u] = (&L.dwr3[0][0])[u ^ (16 * ((u >> 10) & 1) * ((u >> 8) < 16 ? 1 : 0))];
     for (int u = tid; u < NT * 2 * H; u += BX_WAVES * 64) slab[PB_WT + u] = (&L.wt[0][0])[u];
     for (int u = tid; u < 2 * H; u += BX_WAVES * 64) { slab[PB_LNG + u] = L.lng[u]; slab[PB_LNB + u] = L.lnb[u]; }
 }
@@ -733,7 +769,8 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
 hipError_t launch_edge_backward_x2h(const float* att, const float* x, const float* P, const float* Qt, const float* Gt,
                                     const float* gb, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                                     const float* e_w, const int* rows, const int* n_rows, int n_nodes, float* T, float* S,
-                                    float* sw, float* dP, float* dx, float* de_w, float* partial, int grid, hipStream_t s) {
+                                    float* sw, float* dP, float* dx, float* de_w, float* partial, float* nk_scratch, int grid,
+                                    hipStream_t s) {
     profile_mark_begin(rows ? K_EDGE_X2H_BWD_LISTED : K_EDGE_X2H_BWD, s);
 #ifdef CBGX_ABLATE
     static const int abl = getenv("CBGX_BWD_ABL") ? atoi(getenv("CBGX_BWD_ABL")) : 0;
@@ -743,7 +780,7 @@ hipError_t launch_edge_backward_x2h(const float* att, const float* x, const floa
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bx_prof), z, sizeof(z));
     }
     hipLaunchKernelGGL(edge_backward_x2h_kernel, dim3(grid), dim3(BX_WAVES * 64), 0, s, att, x, P, Qt, Gt, gb, nbr, deg, lig,
-                       e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl);
+                       e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, nk_scratch, abl);
     if (prof && !rows) {
         unsigned long long z[16];
         (void)hipStreamSynchronize(s);
@@ -761,7 +798,7 @@ hipError_t launch_edge_backward_x2h(const float* att, const float* x, const floa
     }
 #else
     hipLaunchKernelGGL(edge_backward_x2h_kernel, dim3(grid), dim3(BX_WAVES * 64), 0, s, att, x, P, Qt, Gt, gb, nbr, deg, lig,
-                       e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial);
+                       e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, nk_scratch);
 #endif
     profile_mark_end(s);
     return hipGetLastError();
