@@ -37,16 +37,18 @@ namespace cbgx {
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // libcbgx_ablate.so only: cycle counters per section of the kernel (s_memtime at the section boundaries, summed over all waves),
-// printed by the launcher when CBGX_BX_PROF is set
+// printed by the launcher; switched on by bit 512 of CBGX_BWD_ABL
 #ifdef CBGX_ABLATE
 __device__ unsigned long long g_bx_prof[16];
-#define BX_T(k)                                                          \
-    do {                                                                 \
-        SCHED_FENCE();                                                   \
-        const unsigned long long now_ = __builtin_readcyclecounter();    \
-        if (lane0 == 0) atomicAdd(&g_bx_prof[k], now_ - tprev_);         \
-        tprev_ = now_;                                                   \
-        SCHED_FENCE();                                                   \
+#define BX_T(k)                                                              \
+    do {                                                                     \
+        if (abl & 512) {                                                     \
+            SCHED_FENCE();                                                   \
+            const unsigned long long now_ = __builtin_readcyclecounter();    \
+            if (lane0 == 0) atomicAdd(&g_bx_prof[k], now_ - tprev_);         \
+            tprev_ = now_;                                                   \
+            SCHED_FENCE();                                                   \
+        }                                                                    \
     } while (0)
 #else
 #define BX_T(k) do { } while (0)
@@ -657,6 +659,39 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 for (int r = 0; r < 4; ++r)
                     joff[hf][r] = ((unsigned)reinterpret_cast<const int*>(tw)[(4 * q + r + 16 * hf) * BX_PITCH + BX_NBR] * (unsigned)PROW + (unsigned)((2 + kv) * H + c)) * 4u;
             const unsigned ioff = ((unsigned)i * (unsigned)PROW + (unsigned)(kv * H + c)) * 4u;
+            const int ty1 = p1 ? ty_lig : ty_prot;
+            float a0m[2][4], a1m[2][4];     // rbf of the edges of the first source class (padded slots: rT = 0)
+            {
+                const unsigned sel = !mixed ? 0xffffffffu : (p1 ? msh : ~msh);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m = ((sel >> (r + 16 * hf)) & 1u) ? 1.f : 0.f;
+                        a0m[hf][r] = rT0[hf][r] * m;
+                        a1m[hf][r] = rT1[hf][r] * m;
+                    }
+            }
+            // D of the rbf-column products: lane (c = channel, q) reg r <-> g = 4 q + r (tile 0), 16 + r (tile 1, q == 0)
+            auto flush_rbf_columns = [&](int tyc, int col, floatx4 a0, floatx4 a1) {
+                if (tyc == 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicAdd(&L.dwr3[4 * q + r][col ^ (16 * (q & 1))], a0[r]);   // swizzle: 2-way banks, not 4
+                    if (q == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) atomicAdd(&L.dwr3[16 + r][col], a1[r]);
+                    }
+                } else {
+                    float* sl = slab + PB_WR + (size_t)tyc * G * 2 * H + col;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicAdd(sl + (4 * q + r) * 2 * H, a0[r]);
+                    if (q == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) atomicAdd(sl + (16 + r) * 2 * H, a1[r]);
+                    }
+                }
+            };
+            floatx4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0, y0 = x0, y1 = x0;
             float dpn[2][4];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
@@ -692,40 +727,37 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     atomicAdd(&L.wt[ty_lig][kv * H + 16 * t + c], ligs);
                     atomicAdd(&L.wt[ty_prot][kv * H + 16 * t + c], all - ligs);
                 }
+                // rbf columns of the first source class: A[g][edge] = rbf_g(d_e) over the edges of the class, B[edge][channel] = d pre.
+                // The products of step t are added to the slab during step t + 1, when the matrix pipe has long delivered them.
+                if (!(abl & 4)) {
+                    if (t > 0) flush_rbf_columns(ty1, kv * H + 16 * (t - 1) + c, x0 + x1, y0 + y1);
+                    x0 = x1 = y0 = y1 = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {       // four independent accumulator chains
+                        x0 = MFMA(a0m[0][r], dp[0][r], x0); y0 = MFMA(a1m[0][r], dp[0][r], y0);
+                        x1 = MFMA(a0m[1][r], dp[1][r], x1); y1 = MFMA(a1m[1][r], dp[1][r], y1);
+                    }
+                }
+            }
+            if (!(abl & 4)) flush_rbf_columns(ty1, kv * H + 16 * 7 + c, x0 + x1, y0 + y1);
+            if (mixed && !(abl & 4)) {      // rbf columns of the ligand-source class (its type is never 3): a second, rare sweep
+                float lm[2][4];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lm[hf][r] = ((msh >> (r + 16 * hf)) & 1u) ? 1.f : 0.f;
 #pragma unroll 1
-                for (int p = 0; p < 2; ++p) {
-                    if (p == 0 ? !has_prot : !has_lig) continue;
-                    if (abl & 4) continue;
-                    const int tyc = p ? ty_lig : ty_prot;
-                    const unsigned sel = !mixed ? 0xffffffffu : (p ? msh : ~msh);   // edges of source class p (padded: rT = 0)
+                for (int t = 0; t < 8; ++t) {
                     floatx4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            // A[g][edge] = rbf_g(d_e) over the edges of the class, B[edge][channel] = d pre
-                            const float m = ((sel >> (r + 16 * hf)) & 1u) ? 1.f : 0.f;
-                            a0 = MFMA(rT0[hf][r] * m, dp[hf][r], a0);
-                            a1 = MFMA(rT1[hf][r] * m, dp[hf][r], a1);
+                            const float b = tw[(4 * q + r + 16 * hf) * BX_PITCH + 16 * t + c];
+                            a0 = MFMA(rT0[hf][r] * lm[hf][r], b, a0);
+                            a1 = MFMA(rT1[hf][r] * lm[hf][r], b, a1);
                         }
-                    // D: lane (c = channel, q) reg r <-> g = 4 q + r (tile 0), 16 + r (tile 1, q == 0)
-                    const int col = kv * H + 16 * t + c;
-                    if (tyc == 3) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) atomicAdd(&L.dwr3[4 * q + r][col ^ (16 * (q & 1))], a0[r]);   // swizzle: 2-way banks, not 4
-                        if (q == 0) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) atomicAdd(&L.dwr3[16 + r][col], a1[r]);
-                        }
-                    } else {
-                        float* sl = slab + PB_WR + (size_t)tyc * G * 2 * H + col;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) atomicAdd(sl + (4 * q + r) * 2 * H, a0[r]);
-                        if (q == 0) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) atomicAdd(sl + (16 + r) * 2 * H, a1[r]);
-                        }
-                    }
+                    flush_rbf_columns(ty_lig, kv * H + 16 * t + c, a0, a1);
                 }
             }
             wave_sync();
@@ -774,7 +806,7 @@ hipError_t launch_edge_backward_x2h(const float* att, const float* x, const floa
     profile_mark_begin(rows ? K_EDGE_X2H_BWD_LISTED : K_EDGE_X2H_BWD, s);
 #ifdef CBGX_ABLATE
     static const int abl = getenv("CBGX_BWD_ABL") ? atoi(getenv("CBGX_BWD_ABL")) : 0;
-    static const bool prof = getenv("CBGX_BX_PROF") != nullptr;
+    static const bool prof = (abl & 512) != 0;      // section timers: CBGX_BWD_ABL bit 512
     if (prof && !rows) {
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bx_prof), z, sizeof(z));
