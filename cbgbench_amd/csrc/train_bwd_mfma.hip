@@ -1044,10 +1044,17 @@ hipError_t launch_edge_backward_mfma(bool x2h, const float* att, const float* x,
     constexpr int abl = 0;
 #endif
     profile_mark_begin(x2h ? (rows ? K_EDGE_X2H_BWD_LISTED : K_EDGE_X2H_BWD) : K_EDGE_H2X_BWD, s);
-    if (x2h)
+    if (x2h) {
+        // the product runs x2h blocks through train_bwd_x2h.hip; this instantiation exists in libcbgx_xcheck.so only
+        // (cbgx_debug_set_edge_kernel(2)) as an independent on-device implementation of the same contract
+#ifdef CBGX_XCHECK
         hipLaunchKernelGGL(edge_backward_mfma_kernel<true>, dim3(grid), dim3(BWD_THREADS), 0, s, att, x, P, Qt, Gt, gb,
                            gx_out, nbr, deg, lig, e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl, centred);
-    else
+#else
+        profile_mark_end(s);
+        return hipErrorNotSupported;
+#endif
+    } else
         hipLaunchKernelGGL(edge_backward_mfma_kernel<false>, dim3(grid), dim3(BWD_THREADS), 0, s, att, x, P, Qt, Gt, gb,
                            gx_out, nbr, deg, lig, e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, abl, centred);
     profile_mark_end(s);

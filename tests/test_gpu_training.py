@@ -56,15 +56,17 @@ def model(synthetic_sd):
     return m.to(DEV)
 
 
-@pytest.fixture(params=[0, 1], ids=["mfma", "valu"])
+@pytest.fixture(params=[0, 1, 2], ids=["product", "valu", "mfma_gen2"])
 def edge_impl(request):
-    """both generations of the edge backward kernel (libcbgx.so / the test-only libcbgx_xcheck.so) are checked against autograd"""
+    """the three generations of the edge backward (libcbgx.so / the test-only libcbgx_xcheck.so) are checked against autograd"""
     from cbgbench_amd import _native
     if request.param == 0:
         yield 0                                         # libcbgx.so: the product path
     else:
-        with _native.first_generation_kernels():        # libcbgx_xcheck.so (test-only): first-generation VALU kernels
-            yield 1
+        # libcbgx_xcheck.so (test-only): 1 = first-generation VALU kernels, 2 = the product kernels except the x2h backward, which
+        # is the second-generation workgroup-per-node kernel
+        with _native.first_generation_kernels(request.param):
+            yield request.param
 
 
 def _oracle_block(sd, g, layer, kind, seed):
