@@ -159,9 +159,24 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         }
     }
     {
-        const float4* src = reinterpret_cast<const float4*>(att + A_IMG);
-        float4* dst = reinterpret_cast<float4*>(lds);
-        for (int t = threadIdx.x; t < IMG / 4; t += WAVES * 64) dst[t] = src[t];
+        // LDS fill: every load of the thread is requested before the first is written (19 float4 per thread for the x2h image).
+        // Left as a plain loop the compiler emits load -> wait -> ds_write per iteration: 19 dependent L2 round trips, ~25 us at
+        // the head of EVERY launch -- the whole duration of a small one (a 1-graph step is 18 such launches).
+        const floatx4* src = reinterpret_cast<const floatx4*>(att + A_IMG);
+        floatx4* dst = reinterpret_cast<floatx4*>(lds);
+        constexpr int NV = (IMG / 4 + WAVES * 64 - 1) / (WAVES * 64);
+        floatx4 v[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int t = threadIdx.x + u * (WAVES * 64);
+            v[u] = src[t < IMG / 4 ? t : IMG / 4 - 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int t = threadIdx.x + u * (WAVES * 64);
+            if (t < IMG / 4) dst[t] = v[u];
+        }
         if (threadIdx.x < G) lds_mu[threadIdx.x] = c_mu[threadIdx.x];
     }
     __syncthreads();

@@ -148,8 +148,22 @@ __global__ __launch_bounds__(256) void edge_gate_mfma_kernel(const float* __rest
                                                              float* __restrict__ e_w, const int* __restrict__ rows,
                                                              const int* __restrict__ n_rows_ptr) {
     __shared__ __attribute__((aligned(16))) float lds[GATE_IMG_SIZE];
-    for (int t = threadIdx.x; t < (int)GATE_IMG_SIZE / 4; t += 256)
-        reinterpret_cast<float4*>(lds)[t] = reinterpret_cast<const float4*>(wts + GATE_IMG)[t];
+    {   // LDS fill, all loads of the thread in flight together (a plain loop compiles to one dependent round trip per iteration)
+        typedef float fx4 __attribute__((ext_vector_type(4)));
+        constexpr int NV = ((int)GATE_IMG_SIZE / 4 + 255) / 256;
+        fx4 v[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int t = threadIdx.x + 256 * u;
+            v[u] = reinterpret_cast<const fx4*>(wts + GATE_IMG)[t < (int)GATE_IMG_SIZE / 4 ? t : (int)GATE_IMG_SIZE / 4 - 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int t = threadIdx.x + 256 * u;
+            if (t < (int)GATE_IMG_SIZE / 4) reinterpret_cast<fx4*>(lds)[t] = v[u];
+        }
+    }
     __syncthreads();
     const float* l_frag = lds;                       // [10][5][64]
     const float* l_b1 = lds + GT * 5 * 64;           // centred bias [160]

@@ -104,10 +104,24 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
 
     for (int u = t; u < 2 * KNN * EPM; u += BWD_THREADS) { (&L.N[0][0][0])[u] = 0.f; (&L.U[0][0][0])[u] = 0.f; }
     for (int u = t; u < 2 * KNN * HP2; u += BWD_THREADS) (&L.cf[0][0][0])[u] = 0.f;
+    // (LDS fills: every load of the thread goes out before the first value is stored -- as plain loops they compile to one
+    // dependent L2 round trip per iteration, 14 of them at the head of every launch)
     if (!X2H) {
-        for (int u = t; u < HEADS * H; u += BWD_THREADS) L.QG[1][u >> 7][u & 127] = att[A_WBV + u];
+        float v[HEADS * H / BWD_THREADS];
+#pragma unroll
+        for (int k = 0; k < HEADS * H / BWD_THREADS; ++k) v[k] = att[A_WBV + t + BWD_THREADS * k];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < HEADS * H / BWD_THREADS; ++k) { const int u = t + BWD_THREADS * k; L.QG[1][u >> 7][u & 127] = v[k]; }
     }
-    for (int u = t; u < G * 2 * H; u += BWD_THREADS) L.wrt3[u & 255][u >> 8] = att[A_WR + (size_t)3 * G * 2 * H + u];
+    {
+        float v[G * 2 * H / BWD_THREADS];
+#pragma unroll
+        for (int k = 0; k < G * 2 * H / BWD_THREADS; ++k) v[k] = att[A_WR + (size_t)3 * G * 2 * H + t + BWD_THREADS * k];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < G * 2 * H / BWD_THREADS; ++k) { const int u = t + BWD_THREADS * k; L.wrt3[u & 255][u >> 8] = v[k]; }
+    }
     for (int u = t; u < 2 * KNN * 33; u += BWD_THREADS) (&L.rbfc[0][0][0])[u] = 0.f;
     const int count = rows ? *n_rows_ptr : n_nodes;
     // geometry of a node is built by all 512 threads: thread = (edge ge, rbf group gg); the (neighbour, coordinates, flags)
