@@ -263,7 +263,7 @@ def bench_train(args, rank, world, dev):
         bwd_s = 1e-3 * ms[k] / max(cnt[k], 1)
         achieved = bwd_bytes / bwd_s / 1e9 if bwd_s > 0 else 0.0
         out["roofline"] = {
-            "bound": "hbm", "kernel": "cbgx::edge_backward_mfma_kernel<x2h> (backward of the x2h block: per-node recompute in LDS, MFMA contractions)",
+            "bound": "hbm", "kernel": "cbgx::edge_backward_x2h_kernel (backward of the x2h block: one wavefront per node, per-node recompute in registers, MFMA contractions)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": None, "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_us": round(1e6 * bwd_s, 3),
             "note": "algorithmic bytes = backward of the message-passing stage at the reference tensor boundary "

@@ -1,4 +1,5 @@
-"""Lane-level model of the planned two-wave x2h edge backward (docs/x2h_backward_two_wave_plan.md).
+"""Lane-level model of the tile layouts of the x2h edge backward (docs/x2h_backward.md), written for the round-1 two-wave plan:
+the kernel that was built (train_bwd_x2h.hip) runs both paths in ONE wave, with the same operand layouts per product.
 
 Same idea as tests/lanesim.py for the forward kernel: a numpy re-enactment of what each of the 64 lanes of the key-path
 wave and of the value-path wave would hold and feed to ``v_mfma_f32_16x16x4_f32``, so that the operand layouts of every

@@ -1,5 +1,5 @@
-"""The lane-level model of the planned two-wave x2h edge backward (tests/lanesim_bwd.py) against torch.autograd of the
-same node function (CPU only): pins, before any HIP exists, the operand layouts of every product of the backward -- both
+"""The lane-level model of the x2h edge backward's tile layouts (tests/lanesim_bwd.py) against torch.autograd of the
+same node function (CPU only): pins the operand layouts of every product of the backward -- both
 tile labelings, the transposed softmax-gradient tile, the transposed rbf operand, the transposed d(rbf) tile."""
 import os
 
