@@ -214,7 +214,9 @@ def bench_train(args, rank, world, dev):
     model.train()
     TRN.broadcast_parameters(model)
     fg = TRN.FlatGradients(model)
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.95, 0.999))   # configs/denovo/train/targetdiff.yml:42-47
+    # configs/denovo/train/targetdiff.yml:42-47 through the product's own factory (train.get_optimizer: FlatAdam on device parameters)
+    import types
+    opt = TRN.get_optimizer(types.SimpleNamespace(type="adam", lr=5e-4, weight_decay=0.0, beta1=0.95, beta2=0.999), model)
     weights = {"pos": 1.0, "atom": 100.0}
     n_graphs = args.pockets
     batch = synthetic.batch_to(build_batch(n_graphs, 1, seed=3000 + rank), dev)

@@ -16,7 +16,8 @@ from torch.nn.utils import clip_grad_norm_
 # config `type` -> constructor; the keys each one reads are the ones the reference's YAMLs carry
 # (configs/*/train/*.yml `train.optimizer` / `train.scheduler`; repo/utils/train.py:8-44)
 _OPTIMIZERS = {
-    "adam": lambda c, params: torch.optim.Adam(params, lr=c.lr, weight_decay=c.weight_decay, betas=(c.beta1, c.beta2)),
+    # fused=True on device parameters: one multi-tensor kernel chain instead of a Python loop over 342 tensors (same update rule)
+    "adam": lambda c, params: _adam(params, lr=c.lr, weight_decay=c.weight_decay, betas=(c.beta1, c.beta2)),
 }
 _SCHEDULERS = {
     "plateau": lambda c, opt: torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=c.factor, patience=c.patience,
@@ -24,6 +25,85 @@ _SCHEDULERS = {
     "multistep": lambda c, opt: torch.optim.lr_scheduler.MultiStepLR(opt, milestones=c.milestones, gamma=c.gamma),
     "exp": lambda c, opt: torch.optim.lr_scheduler.ExponentialLR(opt, gamma=c.gamma),
 }
+
+
+class FlatAdam(torch.optim.Adam):
+    """torch.optim.Adam (default flags: no amsgrad, no maximize) whose parameters, first and second moments are views of three flat
+    fp32 buffers, so that ``step()`` is a handful of kernels over 2.7 M elements instead of a Python loop over 342 tensors (1.5 ms of
+    host time per step, the device idle meanwhile).  Same update rule, same op order as torch's single-tensor path; ``param_groups``,
+    ``state`` and ``state_dict()`` have the stock layout (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``), so checkpoints
+    are interchangeable with ``torch.optim.Adam`` in both directions -- ``load_state_dict`` copies into the flat buffers."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(list(params), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        assert len(self.param_groups) == 1, "one parameter group (what the reference's configs build)"
+        self._ps = [p for p in self.param_groups[0]["params"] if p.requires_grad]
+        sizes = [p.numel() for p in self._ps]
+        dev = self._ps[0].device
+        self._sizes = sizes
+        self._w = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        self._m = torch.zeros_like(self._w)
+        self._v = torch.zeros_like(self._w)
+        self._step = torch.zeros((), dtype=torch.float32)       # one counter, referenced by every parameter's state
+        with torch.no_grad():
+            for p, w in zip(self._ps, self._w.split(sizes)):
+                w.copy_(p.detach().reshape(-1))
+                p.data = w.view_as(p)                            # the module's tensors now alias the flat buffer
+        self._bind_state()
+
+    def _bind_state(self):
+        for p, m, v in zip(self._ps, self._m.split(self._sizes), self._v.split(self._sizes)):
+            self.state[p] = {"step": self._step, "exp_avg": m.view_as(p), "exp_avg_sq": v.view_as(p)}
+
+    def state_dict(self):
+        """stock layout with independent tensors: the shared step counter and the views of the flat moment buffers are cloned, so
+        that a consumer (torch.optim.Adam.load_state_dict, torch.save) sees what torch.optim.Adam itself would have produced"""
+        sd = super().state_dict()
+        sd["state"] = {k: {n: (t.clone() if torch.is_tensor(t) else t) for n, t in st.items()} for k, st in sd["state"].items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)                      # fills self.state[p] with fresh tensors (stock behaviour)
+        with torch.no_grad():
+            for p, m, v in zip(self._ps, self._m.split(self._sizes), self._v.split(self._sizes)):
+                st = self.state.get(p, None)
+                if st:
+                    m.copy_(st["exp_avg"].reshape(-1))
+                    v.copy_(st["exp_avg_sq"].reshape(-1))
+                    self._step = torch.as_tensor(float(st["step"]), dtype=torch.float32)
+        self._bind_state()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None if closure is None else closure()
+        g0 = self._ps[0].grad
+        # the gradients are views of one flat buffer in parameter order (FlatGradients); recover it, or gather
+        base = g0._base if g0 is not None and g0._base is not None else None
+        if base is not None and base.numel() == self._w.numel() and all(
+                p.grad is not None and p.grad._base is base for p in self._ps):
+            g = base
+        else:
+            g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self._ps])
+        grp = self.param_groups[0]
+        beta1, beta2 = grp["betas"]
+        self._step += 1
+        step = float(self._step)
+        if grp["weight_decay"] != 0:
+            g = g.add(self._w, alpha=grp["weight_decay"])
+        self._m.lerp_(g, 1 - beta1)
+        self._v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+        denom = (self._v.sqrt() / (bc2 ** 0.5)).add_(grp["eps"])
+        self._w.addcdiv_(self._m, denom, value=-grp["lr"] / bc1)
+        return loss
+
+
+def _adam(params, **kw):
+    """device parameters: FlatAdam (same update, same checkpoint format, one flat update); host parameters: the stock class"""
+    params = list(params)
+    if params and all(p.is_cuda for p in params):
+        return FlatAdam(params, **kw)
+    return torch.optim.Adam(params, **kw)
 
 
 def _dispatch(table, what, cfg, arg):
@@ -59,8 +139,9 @@ class FlatGradients:
         sizes = [p.numel() for p in self.params]
         dev = self.params[0].device
         self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-        for p, v in zip(self.params, self.flat.split(sizes)):
-            p.grad = v.view_as(p)
+        self.views = [v.view_as(p) for p, v in zip(self.params, self.flat.split(sizes))]
+        for p, v in zip(self.params, self.views):
+            p.grad = v
         # libcbgx-backed encoders write their gradients straight into these views (one backward per step, zeroed by
         # zero() before it) instead of returning tensors for autograd to accumulate
         self._direct_modules = [mod for mod in model.modules() if hasattr(mod, "_direct_grads")]
@@ -71,9 +152,16 @@ class FlatGradients:
         self.flat.zero_()
         for mod in self._direct_modules:
             mod._direct_written = False     # the next backward through it may overwrite (the buffer is zero)
-        for p, v in zip(self.params, self.flat.split([p.numel() for p in self.params])):
-            if p.grad is None or p.grad.data_ptr() != v.data_ptr():   # optimizer.zero_grad(set_to_none=True) undoes the views
-                p.grad = v.view_as(p)
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:     # optimizer.zero_grad(set_to_none=True) undoes the views (identity check: no per-tensor device call)
+                p.grad = v
+
+    def clip_norm_(self, max_norm, eps=1e-6):
+        """torch.nn.utils.clip_grad_norm_(params, max_norm) on the flat buffer: the 2-norm of the per-tensor 2-norms is the 2-norm
+        of the concatenation, so one reduction and one scaling replace 342 of each.  Returns the total norm (before clipping)."""
+        total = torch.linalg.vector_norm(self.flat, 2)
+        self.flat.mul_(torch.clamp(max_norm / (total + eps), max=1.0))
+        return total
 
     def all_reduce_mean(self):
         """sum over ranks / world size; returns the wall time of the collective in seconds (0 when not distributed)."""
@@ -109,13 +197,18 @@ def broadcast_parameters(model, src=0):
 
 def train_step(model, batch, optimizer, flat_grads, loss_weights=None, max_grad_norm=8.0, **forward_kwargs):
     """One iteration of train.py:173-190.  Returns (loss, loss_dict, grad_norm, allreduce_seconds)."""
-    model.train()
+    if not model.training:
+        model.train()       # (walks the module tree: 0.7 ms when repeated every step)
     flat_grads.zero()
     loss_dict, _ = model(batch, **forward_kwargs)
     loss = sum_weighted_losses(loss_dict, loss_weights)
     loss.backward()
     t_ar = flat_grads.all_reduce_mean()
-    grad_norm = clip_grad_norm_(flat_grads.params, max_grad_norm)
+    # (every p.grad is a view of the flat buffer unless something replaced it: then fall back to the per-tensor form)
+    if all(p.grad is v for p, v in zip(flat_grads.params, flat_grads.views)):
+        grad_norm = flat_grads.clip_norm_(max_grad_norm)
+    else:
+        grad_norm = clip_grad_norm_(flat_grads.params, max_grad_norm)
     optimizer.step()
     return loss.detach(), {k: v.detach() for k, v in loss_dict.items()}, grad_norm, t_ar
 

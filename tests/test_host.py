@@ -374,3 +374,65 @@ def test_product_side_synthetic_weights_equal_the_oracle_generator():
     assert set(msd) == set(sd)
     for k, v in sd.items():
         assert torch.equal(msd[k], v), k
+
+
+def test_flat_buffer_clip_equals_clip_grad_norm():
+    """FlatGradients.clip_norm_ (one reduction over the flat buffer) is torch.nn.utils.clip_grad_norm_ over the per-tensor views"""
+    from cbgbench_amd import train as TRN
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    fg = TRN.FlatGradients(net)
+    for max_norm in (0.5, 1e3):          # clipping / not clipping
+        fg.flat.copy_(torch.randn_like(fg.flat) * 3.0)
+        ps = [torch.nn.Parameter(torch.zeros_like(p)) for p in fg.params]
+        for q, p in zip(ps, fg.params):
+            q.grad = p.grad.clone()
+        ref_norm = torch.nn.utils.clip_grad_norm_(ps, max_norm)
+        got_norm = fg.clip_norm_(max_norm)
+        assert torch.allclose(got_norm, ref_norm, rtol=1e-6)
+        for q, p in zip(ps, fg.params):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-8)
+    # zero() restores the views after optimizer-style set_to_none and leaves the buffer zero
+    net.zero_grad(set_to_none=True)
+    fg.zero()
+    assert all(p.grad is v for p, v in zip(fg.params, fg.views)) and float(fg.flat.abs().sum()) == 0.0
+
+
+def test_flat_adam_is_adam_with_interchangeable_checkpoints():
+    """train.FlatAdam (parameters and moments as views of flat buffers, one update) = torch.optim.Adam step for step, and their
+    state dicts load into each other mid-run"""
+    from cbgbench_amd import train as TRN
+    torch.manual_seed(1)
+
+    def make():
+        torch.manual_seed(7)
+        return torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.Tanh(), torch.nn.Linear(9, 4))
+
+    def grads(net, k):
+        g = torch.Generator().manual_seed(100 + k)
+        for p in net.parameters():
+            p.grad = torch.randn(p.shape, generator=g) if p.grad is None else p.grad.copy_(torch.randn(p.shape, generator=g))
+
+    a, b = make(), make()
+    kw = dict(lr=3e-3, betas=(0.95, 0.999), eps=1e-8, weight_decay=0.0)
+    oa, ob = torch.optim.Adam(a.parameters(), **kw), TRN.FlatAdam(b.parameters(), **kw)
+    fg = TRN.FlatGradients(b)                      # gradients of b as views of one buffer: FlatAdam's fast path
+    for k in range(4):
+        grads(a, k); grads(b, k)
+        oa.step(); ob.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(p, q, rtol=0, atol=1e-7)
+    # checkpoints both ways, then two more steps
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa.keys() == sb.keys() and sa["state"].keys() == sb["state"].keys()
+    assert set(sb["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sb["state"][0]["step"]) == 4.0
+    a2, b2 = make(), make()
+    a2.load_state_dict(b.state_dict()); b2.load_state_dict(a.state_dict())
+    oa2, ob2 = torch.optim.Adam(a2.parameters(), **kw), TRN.FlatAdam(b2.parameters(), **kw)
+    oa2.load_state_dict(sb); ob2.load_state_dict(sa)
+    for k in range(4, 6):
+        for net, o in ((a, oa), (b, ob), (a2, oa2), (b2, ob2)):
+            grads(net, k); o.step()
+    for p, q, r, t in zip(a.parameters(), b.parameters(), a2.parameters(), b2.parameters()):
+        assert torch.allclose(p, q, atol=1e-7) and torch.allclose(p, r, atol=1e-7) and torch.allclose(p, t, atol=1e-7)
+    assert fg.flat.numel() == sum(p.numel() for p in b.parameters())
