@@ -220,6 +220,7 @@ def bench_train(args, rank, world, dev):
     weights = {"pos": 1.0, "atom": 100.0}
     n_graphs = args.pockets
     batch = synthetic.batch_to(build_batch(n_graphs, 1, seed=3000 + rank), dev)
+    batch["num_graphs"] = n_graphs      # what train_cli's collate records: the model then needs no device round trip for it
     N = batch["protein_pos"].shape[0] + batch["ligand_pos"].shape[0]
     torch.manual_seed(2022 + rank)
     t_ar = 0.0

@@ -89,6 +89,17 @@ def scatter_mean(src, index, dim_size=None):
     return out / cnt.clamp(min=1).view((n,) + (1,) * (src.dim() - 1))
 
 
+def masked_graph_mean(values, index, mask, n_graphs):
+    """``scatter_mean(values[mask], index[mask]).mean()`` -- the per-graph mean over the masked rows, averaged over the graphs -- without
+    the two host synchronisations of that expression (boolean indexing and the output size of the scatter): rows outside the mask
+    enter with weight 0, and the outer mean divides by the largest masked graph id + 1, which is how torch_scatter sizes its output."""
+    w = mask.to(values.dtype)
+    s = torch.zeros(n_graphs, dtype=values.dtype, device=values.device).index_add(0, index, torch.where(mask, values, torch.zeros_like(values)))
+    c = torch.zeros(n_graphs, dtype=values.dtype, device=values.device).index_add(0, index, w)
+    n_eff = torch.where(mask, index, torch.zeros_like(index)).max() + 1
+    return (s / c.clamp(min=1)).sum() / n_eff.to(values.dtype)
+
+
 class CTNVPScheduler(VPSchedule):
     """Continuous (position) schedule; the posterior step is ``backward_remove_noise``."""
 
@@ -110,11 +121,11 @@ class CTNVPScheduler(VPSchedule):
         sigma = (1 - a).sqrt()
         noise = tgt / sigma if score_in else tgt
         mse = ((pred - noise) ** 2).sum(-1)
-        loss = scatter_mean(mse[gen_flag], batch_idx[gen_flag])
+        loss = masked_graph_mean(mse, batch_idx, gen_flag, int(t.shape[0]))
         info = {"eps_0": noise, "eps_pred": pred, "score_0": noise * sigma, "score_pred": pred * sigma, "mask_gen": gen_flag}
         if info_tag is not None:
             info = {k + "_{}".format(info_tag): v for k, v in info.items()}
-        return loss.mean(), info
+        return loss, info
 
     def xs_mean(self, x_pred, x_noisy, t, batch_idx, gen_flag, type="score"):
         """mean of the reverse step (diffusion_scheduler.py:166-183)"""
@@ -135,8 +146,7 @@ class CTNVPScheduler(VPSchedule):
         else:
             tgt = x0
         mse = ((x_pred - tgt) ** 2).sum(-1)
-        loss = scatter_mean(mse[gen_flag], batch_idx[gen_flag])
-        return loss.mean(), {"x0": x0, "xt": xt, "x_pred": x_pred, "mask_gen": gen_flag}
+        return masked_graph_mean(mse, batch_idx, gen_flag, int(t.shape[0])), {"x0": x0, "xt": xt, "x_pred": x_pred, "mask_gen": gen_flag}
 
     def backward_remove_noise(self, x_pred, x_noisy, t, batch_idx, gen_flag, type="score", noise=None):
         """x_{t-1} from x_t (diffusion_scheduler.py:144-165).  type='denoise': x_pred is x0, sample the Gaussian
@@ -212,7 +222,7 @@ class TypeVPScheduler(VPSchedule):
         kl = (log_c_true_prob.exp() * (log_c_true_prob - log_c_pred_prob)).sum(1)
         nll = -(log_v0.exp() * log_c_pred_prob).sum(1)
         mask = (t == 0).float()[batch]
-        return scatter_mean((mask * nll + (1.0 - mask) * kl)[mask_generate], batch[mask_generate]).mean()
+        return masked_graph_mean(mask * nll + (1.0 - mask) * kl, batch, mask_generate, int(t.shape[0]))
 
     def get_loss(self, c_pred, v0, vt, t, gen_flag, batch_idx, pred_logit=True):
         log_c0 = _index_to_log_onehot(v0, self.num_classes)
@@ -315,7 +325,9 @@ class TargetDiff(nn.Module):
         eval mode: the average over ``eval_interval`` evenly spaced times (targetdiff.py:62-78).  ``t`` /
         ``noise=(eps, u)`` replay the random draws in tests."""
         bl = batch["ligand_element_batch"]
-        B = int(bl.max().item()) + 1
+        # the graph count: from the batch if the collate recorded it (no host synchronisation in the training step), else as the
+        # reference computes it
+        B = int(batch["num_graphs"]) if "num_graphs" in batch else (int(t.shape[0]) if t is not None else int(bl.max().item()) + 1)
         dev = batch["ligand_pos"].device
         if self.training or t is not None:
             if t is None:
@@ -377,7 +389,10 @@ class TargetDiff(nn.Module):
         batch_idx = batch_ctx[sort_idx]
         n_rec = batch_idx_rec.shape[0]
         lig_flag = sort_idx >= n_rec
-        lig_rows = torch.nonzero(lig_flag).flatten()   # composed rows of ligand atoms, in ligand order
+        # composed rows of ligand atoms, in ligand order = the inverse permutation's tail (no nonzero(): that synchronises)
+        inv = torch.empty_like(sort_idx)
+        inv[sort_idx] = torch.arange(sort_idx.numel(), device=sort_idx.device)
+        lig_rows = inv[n_rec:]
         return sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr_from_batch(batch_idx, n_graphs)
 
     @torch.no_grad()

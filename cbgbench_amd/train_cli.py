@@ -78,7 +78,9 @@ class ComplexSet:
         }
         if self.has_gen:
             b["ligand_gen_flag"] = self.ligand_gen_flag[lr]
-        return {k: v.to(device) for k, v in b.items()}
+        b = {k: v.to(device) for k, v in b.items()}
+        b["num_graphs"] = int(ids.numel())       # known on the host: spares the model a device round trip per step
+        return b
 
 
 def synthetic_complexes(n, seed, num_classes, n_rec_range=(350, 650), n_lig_range=(10, 45)):

@@ -77,7 +77,8 @@ def graph_ptr_from_batch(batch_idx, n_graphs=None):
     """int32 CSR offsets from a sorted graph-id vector (one host sync if n_graphs is not given)."""
     if n_graphs is None:
         n_graphs = int(batch_idx[-1].item()) + 1 if batch_idx.numel() else 0
-    counts = torch.bincount(batch_idx, minlength=n_graphs)
+    # (not torch.bincount: it synchronises to size its output)
+    counts = torch.zeros(n_graphs, dtype=torch.int64, device=batch_idx.device).index_add_(0, batch_idx, torch.ones_like(batch_idx))
     ptr = torch.zeros(n_graphs + 1, dtype=torch.int32, device=batch_idx.device)
     ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
     return ptr

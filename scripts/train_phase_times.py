@@ -10,7 +10,7 @@ from torch.nn.utils import clip_grad_norm_
 
 dev = "cuda:0"
 model = bench.make_model(dev)
-batch = synthetic.batch_to(synthetic.denovo_batch(32, seed=3000), dev)
+batch = synthetic.batch_to(synthetic.denovo_batch(32, seed=3000), dev); batch["num_graphs"] = 32
 import types
 opt = TRN.get_optimizer(types.SimpleNamespace(type="adam", lr=1e-4, weight_decay=0.0, beta1=0.95, beta2=0.999), model)
 fg = TRN.FlatGradients(model)
