@@ -242,8 +242,10 @@ class UniTransformer(nn.Module):
             _native.check(lib.cbgx_pack_weights(arr, len(srcs), self.num_layers, self.out_classes,
                                                 _native.ptr(packed), _native.current_stream(device)),
                           "cbgx_pack_weights")
-            torch.cuda.current_stream(device).synchronize()  # srcs may be temporaries
-            self._packed, self._packed_key = packed, key
+            # No host synchronisation: the pack kernels run on torch's current stream, so the caching allocator cannot hand a
+            # temporary of `srcs` to anyone who writes before they have read it; the references are kept until the next repack
+            # anyway.  (A synchronize() here used to stall the host once per training step -- the weights change every step.)
+            self._packed, self._packed_key, self._packed_srcs = packed, key, srcs
         return self._packed
 
     def workspace(self, n_nodes, n_graphs, device):
