@@ -21,6 +21,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "layout.h"
 #include "train.h"
@@ -977,66 +979,114 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const float* __restrict
             }
 }
 
+// C[M x 128] (+)= A[M x K] . B^T, B = [128 x K] row-major: the input-gradient product (dh += dP . Wn^T).  LDS-tiled: a workgroup
+// (4 waves) owns 64 rows x 128 columns, wave w the columns [32 w, 32 w + 32); k in chunks of 32, double-buffered through registers.
+// The first version read both MFMA operands straight from global memory in fragment order -- 16 rows x 64 bytes per load
+// instruction, the most expensive shape for the CU's texture addresser (scripts/ubench/vmem.hip: ~64 cycles per instruction), four
+// waves each fetching the same A rows: the addresser, not the matrix pipe, set its 69 us.  Here every global load covers 128
+// contiguous bytes per row and every operand byte is fetched once per workgroup.
+constexpr int DG_KC = 32, DG_PITCH = DG_KC + 4;
+template <int TR>      // 16 TR rows per workgroup
 __global__ __launch_bounds__(256) void dgrad_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                          int ldb, float* __restrict__ C, int ldc, int M, int K,
                                                          int accumulate) {
+    constexpr int DG_ROWS = 16 * TR;
+    __shared__ __attribute__((aligned(16))) float sA[2][DG_ROWS][DG_PITCH];
+    __shared__ __attribute__((aligned(16))) float sB[2][H][DG_PITCH];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int row0 = blockIdx.x * 32;
-    const float* ap[2];
-    const float* bp[2];
+    const int row0 = blockIdx.x * DG_ROWS;
+    // loader view: thread = (row t >> 3 [+32 ...], four k at 4 (t & 7)): 8 lanes cover one row's 128 contiguous bytes
+    const int lr = t >> 3, lk = 4 * (t & 7);
+    constexpr int NA = TR / 2;      // float4 of A per thread and chunk
+    unsigned ao[NA], bo[4];
 #pragma unroll
-    for (int tr = 0; tr < 2; ++tr) {
-        ap[tr] = A + (unsigned)min(row0 + 16 * tr + i, M - 1) * lda + 4 * kq;
-        bp[tr] = B + (unsigned)(32 * w + 16 * tr + i) * ldb + 4 * kq;
+    for (int u = 0; u < NA; ++u) ao[u] = (unsigned)min(row0 + lr + 32 * u, M - 1) * lda + lk;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bo[u] = (unsigned)(lr + 32 * u) * ldb + lk;
+    // Two register sets: chunk c travels in set c & 1 and is requested TWO chunks before it is staged into LDS (one chunk of
+    // MFMAs, ~0.85 us, does not cover a memory round trip when every CU streams at once).
+    floatx4 ga[2][NA], gb[2][4];
+    auto fetch = [&](auto S, int k0) {
+        constexpr int st = decltype(S)::value;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) ga[st][u] = *reinterpret_cast<const floatx4*>(A + ao[u] + k0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gb[st][u] = *reinterpret_cast<const floatx4*>(B + bo[u] + k0);
+    };
+    auto stage = [&](auto S) {      // chunk in register set S -> LDS buffer S
+        constexpr int st = decltype(S)::value;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) *reinterpret_cast<floatx4*>(&sA[st][lr + 32 * u][lk]) = ga[st][u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<floatx4*>(&sB[st][lr + 32 * u][lk]) = gb[st][u];
+    };
+    floatx4 acc[TR][2];
+#pragma unroll
+    for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc) acc[tr][tc] = floatx4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](auto S) {
+        constexpr int buf = decltype(S)::value;
+#pragma unroll
+        for (int sp = 0; sp < DG_KC / 16; ++sp) {
+            float4 a[TR], b[2];
+#pragma unroll
+            for (int tr = 0; tr < TR; ++tr) a[tr] = *reinterpret_cast<const float4*>(&sA[buf][16 * tr + i][16 * sp + 4 * kq]);
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc) b[tc] = *reinterpret_cast<const float4*>(&sB[buf][32 * w + 16 * tc + i][16 * sp + 4 * kq]);
+            // eight independent accumulators between two MFMAs of the same one (a dependent 16x16x4 issues every 40+ cycles, not 32)
+#pragma unroll
+            for (int comp = 0; comp < 4; ++comp)
+#pragma unroll
+                for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+                    for (int tc = 0; tc < 2; ++tc)
+                        acc[tr][tc] = MFMA(reinterpret_cast<const float*>(&a[tr])[comp], reinterpret_cast<const float*>(&b[tc])[comp],
+                                           acc[tr][tc]);
+        }
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    const int nch = K / DG_KC;       // even: K is a multiple of 64 (launcher)
+    fetch(S0{}, 0);
+    stage(S0{});
+    fetch(S1{}, DG_KC);
+    __syncthreads();
+    // step(S): chunk ch (parity S) is in LDS buffer S, chunk ch + 1 in flight in register set 1 - S
+    auto step = [&](auto S, auto Sn, int ch) {
+        if (ch + 2 < nch) fetch(S, (ch + 2) * DG_KC);       // set S is free: its chunk was staged one step ago
+        SCHED_FENCE();      // (without the fences the scheduler waits for loads and stages them BEFORE the MFMAs: an exposed memory
+                            // round trip per chunk -- what every earlier version of this kernel spent two thirds of its time on)
+        compute(S);
+        SCHED_FENCE();
+        if (ch + 1 < nch) {
+            stage(Sn);      // LDS buffer 1 - S: last read one step ago, behind that step's barrier
+            __syncthreads();
+        }
+    };
+    for (int ch = 0; ch < nch; ch += 2) {
+        step(S0{}, S1{}, ch);
+        step(S1{}, S0{}, ch + 1);
     }
-    // old values of the accumulated output: in flight during the whole product
-    float cold[2][2][4];
 #pragma unroll
-    for (int tr = 0; tr < 2; ++tr)
+    for (int tr = 0; tr < TR; ++tr) {
+        float cold[2][4];
 #pragma unroll
         for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const unsigned row = (unsigned)min(row0 + 16 * tr + 4 * kq + r, M - 1);
-                cold[tr][tc][r] = accumulate ? C[row * ldc + 32 * w + 16 * tc + i] : 0.f;
+                cold[tc][r] = accumulate ? C[row * ldc + 32 * w + 16 * tc + i] : 0.f;
             }
-    floatx4 acc[2][2];
-#pragma unroll
-    for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-        for (int tc = 0; tc < 2; ++tc) acc[tr][tc] = floatx4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 64) {       // K is a multiple of 64 (launcher)
-        float4 a[4][2], b[4][2];
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp)
-#pragma unroll
-            for (int tr = 0; tr < 2; ++tr) {
-                a[sp][tr] = *reinterpret_cast<const float4*>(ap[tr] + k0 + 16 * sp);
-                b[sp][tr] = *reinterpret_cast<const float4*>(bp[tr] + k0 + 16 * sp);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp)
-#pragma unroll
-            for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-                for (int tc = 0; tc < 2; ++tc) {
-                    acc[tr][tc] = MFMA(a[sp][tr].x, b[sp][tc].x, acc[tr][tc]);
-                    acc[tr][tc] = MFMA(a[sp][tr].y, b[sp][tc].y, acc[tr][tc]);
-                    acc[tr][tc] = MFMA(a[sp][tr].z, b[sp][tc].z, acc[tr][tc]);
-                    acc[tr][tc] = MFMA(a[sp][tr].w, b[sp][tc].w, acc[tr][tc]);
-                }
-    }
-#pragma unroll
-    for (int tr = 0; tr < 2; ++tr)
 #pragma unroll
         for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = row0 + 16 * tr + 4 * kq + r;
-                if (row < M) C[(unsigned)row * ldc + 32 * w + 16 * tc + i] = cold[tr][tc][r] + acc[tr][tc][r];
+                if (row < M) C[(unsigned)row * ldc + 32 * w + 16 * tc + i] = cold[tc][r] + acc[tr][tc][r];
             }
+    }
 }
 
 #define CBGX_LAUNCH_CHECK()                            \
@@ -1118,7 +1168,15 @@ hipError_t launch_dgrad_mfma(const float* A, int lda, const float* B, int ldb, f
     if (M <= 0) return hipSuccess;
     if (K % 64 != 0 || (long)M * (lda > ldc ? lda : ldc) >= (1L << 32)) return hipErrorInvalidValue;
     profile_mark_begin(K_TRAIN_GEMM, s);
-    hipLaunchKernelGGL(dgrad_mfma_kernel, dim3((M + 31) / 32), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, accumulate);
+#ifdef CBGX_ABLATE
+    {   // timing ablations (wrong results): 1024 = every row of A is row 0 (A from cache), 2048 = no accumulate (C not read)
+        static const int abl = getenv("CBGX_BWD_ABL") ? atoi(getenv("CBGX_BWD_ABL")) : 0;
+        if (abl & 1024) lda = 0;
+        if (abl & 2048) accumulate = 0;
+    }
+#endif
+    // two workgroups of 32 rows per CU overlap each other's barriers and loads better than one of 64 (measured: 51.7 vs ... us)
+    hipLaunchKernelGGL(dgrad_mfma_kernel<2>, dim3((M + 31) / 32), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, accumulate);
     profile_mark_end(s);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
