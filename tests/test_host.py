@@ -436,3 +436,10 @@ def test_flat_adam_is_adam_with_interchangeable_checkpoints():
     for p, q, r, t in zip(a.parameters(), b.parameters(), a2.parameters(), b2.parameters()):
         assert torch.allclose(p, q, atol=1e-7) and torch.allclose(p, r, atol=1e-7) and torch.allclose(p, t, atol=1e-7)
     assert fg.flat.numel() == sum(p.numel() for p in b.parameters())
+    # without FlatGradients (gradients are ordinary per-parameter tensors): same update through the gather path
+    c, d = make(), make()
+    oc, od = torch.optim.Adam(c.parameters(), **kw), TRN.FlatAdam(d.parameters(), **kw)
+    for k in range(3):
+        grads(c, k); grads(d, k); oc.step(); od.step()
+    for p, q in zip(c.parameters(), d.parameters()):
+        assert torch.allclose(p, q, rtol=0, atol=1e-7)
