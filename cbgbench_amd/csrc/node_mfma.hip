@@ -154,6 +154,28 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
 // q = z @ Wq1^T + bq1 in split-f16 (K = 32 per MFMA, same slot map as node_proj).
 // Wq1 tables [part hi|lo][nt 8][u 4][lane][8 f16] = split(Wq1[n = 64(nt>>2) + 4c + (nt&3)][k = 16 (2u + (j>>2)) + 4q + (j&3)]).
 // ------------------------------------------------------------------------------------------------
+// LDS fill of the float4 range [begin, end) by 256 threads with every load of a thread requested before its first store (at most
+// MAXV per thread).  Written as a plain loop the compiler emits load -> wait -> ds_write per iteration: up to 16 dependent L2 round
+// trips (~11 us) at the head of every launch of the query kernels.
+typedef float lds_fx4 __attribute__((ext_vector_type(4)));
+template <int MAXV>
+__device__ __forceinline__ void lds_fill_f4(float* lds, const float* src_base, int begin, int end, int tid) {
+    const lds_fx4* src = reinterpret_cast<const lds_fx4*>(src_base);
+    lds_fx4* dst = reinterpret_cast<lds_fx4*>(lds);
+    lds_fx4 v[MAXV];
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+        const int t = begin + tid + 256 * u;
+        v[u] = src[t < end ? t : end - 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+        const int t = begin + tid + 256 * u;
+        if (t < end) dst[t] = v[u];
+    }
+}
+
 constexpr int NQ_FRAG = 8 * 8 * 64 * 4;  // 16384 floats = 64 KB
 
 __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict__ att, const float* __restrict__ P,
@@ -163,14 +185,11 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
     if ((int)blockIdx.x >= ((rows ? *n_rows_ptr : n_nodes) + 63) / 64) return;   // no tile for this workgroup
     const int grp_begin = gridDim.y > 1 ? blockIdx.y : 0, grp_end = gridDim.y > 1 ? blockIdx.y + 1 : 2;
-    {
-        const float4* src = reinterpret_cast<const float4*>(att + A_WQ1_FRAG);
-        float4* dst = reinterpret_cast<float4*>(lds);
-        // group g owns the tiles nt = 4g .. 4g + 3 of both parts (hi | lo): two float4 ranges of NQ_FRAG / 16 each
-        for (int part = 0; part < 2; ++part)
-            for (int t = part * (NQ_FRAG / 8) + grp_begin * (NQ_FRAG / 16) + tid; t < part * (NQ_FRAG / 8) + grp_end * (NQ_FRAG / 16); t += 256)
-                dst[t] = src[t];
-    }
+    // group g owns the tiles nt = 4g .. 4g + 3 of both parts (hi | lo): two float4 ranges of at most NQ_FRAG / 8 float4 (8 per thread)
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+        lds_fill_f4<8>(lds, att + A_WQ1_FRAG, part * (NQ_FRAG / 8) + grp_begin * (NQ_FRAG / 16),
+                       part * (NQ_FRAG / 8) + grp_end * (NQ_FRAG / 16), tid);
     __syncthreads();
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
     const int n_tiles = (n_rows + 63) / 64;
@@ -256,11 +275,7 @@ __global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
     if ((int)blockIdx.x >= ((rows ? *n_rows_ptr : n_nodes) + 63) / 64) return;   // no tile for this workgroup
     const int heads_per = HEADS / gridDim.y, a_begin = blockIdx.y * heads_per, a_end = a_begin + heads_per;
-    {
-        const float4* src = reinterpret_cast<const float4*>(att + A_WBK_FRAG);
-        float4* dst = reinterpret_cast<float4*>(lds);
-        for (int t = a_begin * (NF_FRAG / 64) + tid; t < a_end * (NF_FRAG / 64); t += 256) dst[t] = src[t];
-    }
+    lds_fill_f4<16>(lds, att + A_WBK_FRAG, a_begin * (NF_FRAG / 64), a_end * (NF_FRAG / 64), tid);   // <= 16 float4 per thread
     __syncthreads();
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
     const int n_tiles = (n_rows + 63) / 64;
