@@ -630,16 +630,27 @@ hipError_t launch_pack_node_frags(const float* wk0, const float* wv0, const floa
 
 // compact the indices of flagged nodes (gen_flag) -> list[0 .. *count); order is irrelevant (each node is computed
 // independently, so results are identical for any order).  *count must be zero on entry.
-__global__ void build_active_kernel(const uint8_t* __restrict__ flag, int n, int* __restrict__ list,
-                                    int* __restrict__ count) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// One returning atomic per 1024-thread workgroup, not per wave: a single counter word serves ~88 returning atomics per microsecond
+// (MI355X_MICROARCH.md, dequeue row), so 1 556 wave-level atomics for a 99.5 k-node batch were the kernel's whole 18 us.
+constexpr int BA_THREADS = 1024;
+__global__ __launch_bounds__(BA_THREADS) void build_active_kernel(const uint8_t* __restrict__ flag, int n, int* __restrict__ list,
+                                                                  int* __restrict__ count) {
+    __shared__ int s_cnt[BA_THREADS / 64];
+    __shared__ int s_base;
+    const int idx = blockIdx.x * BA_THREADS + threadIdx.x;
     const bool a = idx < n && flag[idx] != 0;
     const unsigned long long m = __ballot(a);
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
-    base = __shfl(base, 0, 64);
-    if (a) list[base + __popcll(m & ((1ull << lane) - 1ull))] = idx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < BA_THREADS / 64; ++w) { const int c = s_cnt[w]; s_cnt[w] = tot; tot += c; }   // exclusive prefix
+        s_base = tot ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
+    if (a) list[s_base + s_cnt[wave] + __popcll(m & ((1ull << lane) - 1ull))] = idx;
 }
 
 // ---- receptive-field pruning helpers ---------------------------------------------------------------
@@ -698,7 +709,7 @@ hipError_t launch_build_active(const uint8_t* flag, int n, int* list, int* count
     hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(build_active_kernel, dim3((n + 255) / 256), dim3(256), 0, s, flag, n, list, count);
+    hipLaunchKernelGGL(build_active_kernel, dim3((n + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, s, flag, n, list, count);
     return hipGetLastError();
 }
 

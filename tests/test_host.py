@@ -443,3 +443,33 @@ def test_flat_adam_is_adam_with_interchangeable_checkpoints():
         grads(c, k); grads(d, k); oc.step(); od.step()
     for p, q in zip(c.parameters(), d.parameters()):
         assert torch.allclose(p, q, rtol=0, atol=1e-7)
+
+
+def test_sync_free_host_forms_equal_the_reference_forms():
+    """The training step's host code avoids device->host synchronisations; each replacement is the reference
+    expression's value: masked_graph_mean == scatter_mean(v[mask], idx[mask]).mean(), ligand rows from the inverse permutation ==
+    nonzero(), CSR offsets without bincount."""
+    from cbgbench_amd import targetdiff as TD
+    from cbgbench_amd.unitransformer import graph_ptr_from_batch
+    g = torch.Generator().manual_seed(5)
+    for trailing_empty in (False, True):
+        B = 7
+        idx = torch.sort(torch.randint(0, B - (2 if trailing_empty else 0), (60,), generator=g)).values
+        v = torch.randn(60, generator=g, dtype=torch.float64)
+        mask = torch.rand(60, generator=g) < 0.6
+        mask[0] = True
+        ref = TD.scatter_mean(v[mask], idx[mask]).mean()
+        got = TD.masked_graph_mean(v, idx, mask, B)
+        assert torch.allclose(got, ref, rtol=1e-12, atol=0)
+        # a NaN outside the mask must not leak in
+        v2 = v.clone(); v2[~mask] = float("nan")
+        assert torch.allclose(TD.masked_graph_mean(v2, idx, mask, B), ref, rtol=1e-12, atol=0)
+    # composition plan: ligand rows in ligand order
+    br = torch.sort(torch.randint(0, 4, (30,), generator=g)).values
+    bl = torch.sort(torch.randint(0, 4, (9,), generator=g)).values
+    sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = TD.TargetDiff.compose_plan(bl, br, 4)
+    assert torch.equal(lig_rows, torch.nonzero(lig_flag).flatten()[torch.argsort(sort_idx[lig_flag])])
+    assert torch.equal(sort_idx[lig_rows], torch.arange(30, 39))
+    counts = torch.bincount(batch_idx, minlength=4)
+    assert torch.equal(graph_ptr, torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)]).to(torch.int32))
+    assert torch.equal(graph_ptr_from_batch(batch_idx, 4), graph_ptr) and torch.equal(graph_ptr_from_batch(batch_idx), graph_ptr)
