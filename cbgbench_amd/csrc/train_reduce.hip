@@ -88,8 +88,18 @@ __global__ __launch_bounds__(256) void slab_fold_kernel(const float* __restrict_
                                                         int size, int groups, float* __restrict__ dst) {
     const int c = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
     if (c >= size) return;
+    // eight loads in flight per thread, added in slab order (the same sum, bit for bit, as the one-load-at-a-time loop the
+    // compiler otherwise emits: load -> wait -> add, 32 dependent round trips per launch)
     float acc = 0.f;
-    for (int s = g; s < n_slabs; s += groups) acc += src[(size_t)s * slab_stride + c];
+    int s = g;
+    for (; s + 7 * groups < n_slabs; s += 8 * groups) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + u * groups) * slab_stride + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; s < n_slabs; s += groups) acc += src[(size_t)s * slab_stride + c];
     dst[(size_t)g * size + c] = acc;
 }
 
@@ -100,7 +110,15 @@ __global__ void reduce_store_kernel(const float* __restrict__ src, int n_slabs, 
     if (idx >= rows * cols) return;
     const int r = idx / cols, c = idx % cols;
     float acc = 0.f;
-    for (int s = 0; s < n_slabs; ++s) acc += src[(size_t)s * slab_stride + (size_t)r * src_ld + c];
+    int s = 0;
+    for (; s + 7 < n_slabs; s += 8) {       // eight loads in flight, added in slab order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + u) * slab_stride + (size_t)r * src_ld + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; s < n_slabs; ++s) acc += src[(size_t)s * slab_stride + (size_t)r * src_ld + c];
     if (transpose) dst[(size_t)c * dst_ld + r] = acc; else dst[(size_t)r * dst_ld + c] = acc;
 }
 
@@ -110,8 +128,17 @@ __global__ void reduce_store_multi_kernel(RsBatch b) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= pc.rows * pc.cols) return;
     const int r = idx / pc.cols, c = idx % pc.cols;
+    const float* src = pc.src + (size_t)r * pc.src_ld + c;
     float acc = 0.f;
-    for (int s = 0; s < pc.n_slabs; ++s) acc += pc.src[(size_t)s * pc.stride + (size_t)r * pc.src_ld + c];
+    int s = 0;
+    for (; s + 7 < pc.n_slabs; s += 8) {    // eight loads in flight, added in slab order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + u) * pc.stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; s < pc.n_slabs; ++s) acc += src[(size_t)s * pc.stride];
     if (pc.transpose) pc.dst[(size_t)c * pc.dst_ld + r] = acc; else pc.dst[(size_t)r * pc.dst_ld + c] = acc;
 }
 
