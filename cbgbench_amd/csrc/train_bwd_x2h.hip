@@ -9,19 +9,24 @@
 //   E: lane (c = edge c + 16 hf, q), register (t, r) <-> channel 16 t + 4 q + r        (contractions over channels)
 // into the channel-major one
 //   C: lane (c, q), (t, hf, r)                       <-> channel 16 t + c, edge 4 q + r + 16 hf   (contractions over edges)
-// through a wave-private [32][132] buffer.  Per path (k, then v; k's forward is recomputed for its backward):
-//   pre-activation (split-f16, as the forward)  64 MFMAs   E      normalised n kept in 64 registers
-//   scores / gv = hid . Qt|Gt                    64         E  ->  alpha (k), d alpha / d e_w / w = alpha e_w (v)
-//   fold  T|S[a][m] = sum_e ds|w[e][a] hid[e][m] 64         C  (n through the tile, hid = ReLU(n g + b) on the fly)
-//   d hid = ds|w . Qt|Gt                         64         E  ->  LayerNorm backward in registers -> d pre
-//   d rbf = d pre . Wr^T                         128        E  ->  d dist -> d x (atomics)
-//   d PS[j_e] += d pre[e]   (atomics, 16-byte runs of a neighbour's row);  d pre through the tile:
-//   d Wr[type] += rbf^T . d pre                  128        C  ->  LDS slab (type 3) / workgroup slab in memory
-//   d PD[i], type columns, per-class sums        VALU       C
-// LayerNorm affine gradients are reduced over the 16 edge lanes with DPP row sums (512 per node) into an LDS slab.
-// 8 waves per workgroup (2 per SIMD, 256 VGPRs), persistent, one workgroup per CU; LDS = 8 x 16.9 KB transpose tiles +
-// 20 KB type-3 d Wr + 6 KB of small slabs.  Outputs, slab layout (train.h PB_*) and launch contract are those of
-// launch_edge_backward_mfma, so api_train.hip swaps one call.
+// through a wave-private [32][132] buffer.  A node runs three phases through ONE loop body (docs/x2h_backward.md):
+//   0  key path forward -> scores -> alpha; the normalised pre-activation n_k is parked in the wave's 16 KB scratch slot
+//   1  value path forward -> G . v_raw -> d alpha, d e_w, w = alpha e_w; backward of the value path
+//   2  n_k read back; backward of the key path with d score = alpha (d alpha - sum alpha d alpha)
+// and the backward of a path is four passes over the tile:
+//   forward (phases 0, 1): pre-activation, split-f16 as the forward kernel   64 MFMAs  E    n in 64 registers
+//                          scores / G . v_raw = hid . Qt | Gt                 64        E
+//   pass 1  fold T | S[a][m] = sum_e w[e][a] hid[e][m], d hid = w . Qt | Gt   64 + 64   C    LayerNorm affine gradients, the two
+//           (labeling: channel 32 u + 2 c + j -- 8-byte tile reads, float2 operand loads)    per-edge sums of LayerNorm's backward
+//   pass 2  d hid again (cheaper than 64 live registers of it) -> d pre, in place in the tile        64        C
+//   pass 3  d rbf = d pre . Wr^T -> d dist (accumulated per edge in a pad column of the tile)        128       E
+//   pass 4  every atomic of the path in one burst (labeling: channel 16 t + c, so a row's 16 lanes hit one 64-byte run):
+//           d PS[j_e] += d pre[e], d PD[i], type columns; d Wr[type] += rbf^T . d pre                 128       C
+//           -> LDS slab (type 3) / the workgroup's slab in memory, flushed one step late
+// Per-edge scalars (edge length, neighbour index, d dist, the rbf centres) live in the four pad columns of the tile rows, the LayerNorm
+// affine in LDS.  8 waves per workgroup (2 per SIMD, 256 VGPRs), persistent, one workgroup per CU, XCD-aware node partition; LDS =
+// 8 x 16.9 KB tiles + 20 KB type-3 d Wr + 8 KB of small slabs = 160 KB.  Outputs, slab layout (train.h PB_*) and launch contract are
+// those of launch_edge_backward_mfma, so api_train.hip swaps one call.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
