@@ -12,6 +12,7 @@ _LIB = None
 _XLIB = None
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+ABI_VERSION = 2      # include/cbgx.h CBGX_ABI_VERSION: bumped whenever the packed-weight layout or an entry point changes
 
 EXPORTS = {
     "cbgx_abi_version": (_i, []),
@@ -73,8 +74,8 @@ def _load(path, extra=None):
         fn = getattr(dll, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if dll.cbgx_abi_version() != 1:
-        raise NativeError(f"{path}: ABI version {dll.cbgx_abi_version()} != 1")
+    if dll.cbgx_abi_version() != ABI_VERSION:
+        raise NativeError(f"{path}: ABI version {dll.cbgx_abi_version()} != {ABI_VERSION} (stale build? run `python -m cbgbench_amd.build`)")
     return dll
 
 

@@ -229,9 +229,10 @@ static int pack_attention_block(const float* const* p, int blk, float* a, hipStr
     HIP_TRY(launch_pack_bn2(a, bq0, a, s));
     // LDS image of the MFMA edge kernel
     float* img = a + A_IMG;
-    HIP_TRY(launch_pack_frag(wkc, 0, img + IMG_FRAG_K, s));
-    HIP_TRY(launch_pack_frag(wvc, blk == 0 ? 1 : 0, img + IMG_FRAG_V, s));
-    if (blk == 0) HIP_TRY(launch_pack_frag(wvc, 0, a + A_FRAGV_EM, s));   // edge-major v table for the x2h backward
+    HIP_TRY(launch_pack_rbf_scale(wkc, wvc, a + A_RBF_SC, s));   // power-of-two scales of the split-f16 rbf tables
+    HIP_TRY(launch_pack_frag(wkc, 0, a + A_RBF_SC, img + IMG_FRAG_K, s));
+    HIP_TRY(launch_pack_frag(wvc, blk == 0 ? 1 : 0, a + A_RBF_SC + 4, img + IMG_FRAG_V, s));
+    if (blk == 0) HIP_TRY(launch_pack_frag(wvc, 0, a + A_RBF_SC + 4, a + A_FRAGV_EM, s));   // edge-major v table for the x2h backward
     HIP_TRY(launch_pack_dwt(wkc, wvc, img + IMG_WT, s));
     CP(gk, H, 0, 0, img + IMG_LN + 0 * H, H, 1, H);
     CP(bek, H, 0, 0, img + IMG_LN + 1 * H, H, 1, H);

@@ -149,6 +149,19 @@ __device__ __forceinline__ WTuples load_wtuples(const float* blk, int lane) {
     w.t3 = __builtin_bit_cast(half4, p);
     return w;
 }
+// Range-safe split-f16 of the rbf pre-activation (layout.h A_RBF_SC): the weight tuples hold Wr 2^kw, the kernels produce the rbf
+// values times 2^RBF_EXP (the 0 / 1 validity factor becomes 0 / 2^RBF_EXP) and carry the whole pre-activation tile scaled by
+// S = 2^(kw + RBF_EXP): PD + PS and the type column are multiplied by S when they enter the accumulator, and LayerNorm divides
+// it out again -- rstd = rsqrt(sum(acc^2) c1 + eps) with c1 = 1 / (H S^2), normalised value = acc (rstd c2) with c2 = 1 / S.
+// Exact powers of two: no rounding is added anywhere, only the f16 exponent range is used where it has full precision.
+struct RbfScale { float S, c1, c2; };
+__device__ __forceinline__ RbfScale load_rbf_scale(const float* att, int kv) {
+    RbfScale r;
+    r.S = att[A_RBF_SC + 4 * kv]; r.c1 = att[A_RBF_SC + 4 * kv + 1]; r.c2 = att[A_RBF_SC + 4 * kv + 2];
+    return r;
+}
+constexpr float RBF_UP = (float)(1 << RBF_EXP);
+
 // edge type, unitransformer.py:92-97: (src lig, dst lig)->0, (lig, prot)->1, (prot, lig)->2, (prot, prot)->3
 __device__ __forceinline__ int etype(bool src_lig, int lig_i) { return src_lig ? (lig_i ? 0 : 1) : (lig_i ? 2 : 3); }
 

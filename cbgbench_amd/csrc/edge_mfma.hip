@@ -49,10 +49,10 @@ __device__ __forceinline__ floatx4 edge_major_half(floatx4 (&acc)[8], bool lg, i
                                                    const float* lds_frag, const float* lds_dwt, const float* lds_ln,
                                                    const float (&R)[5], bool has_prot, bool has_lig, int lig_i,
                                                    int lane, int q, gptr Brow, unsigned brow_off,
-                                                   const float4 (&pre)[8]) {
+                                                   const float4 (&pre)[8], const RbfScale sc) {
     if (has_lig) {  // wave-uniform: only nodes with a ligand neighbour pay for the type correction
         const float* dw = lds_dwt + lig_i * 2 * H + kv * H + 4 * q;
-        const float m = lg ? 1.f : 0.f;
+        const float m = lg ? sc.S : 0.f;     // the tile is carried scaled by S (edge_common.h RbfScale)
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] += f4(ld4(dw + 16 * t)) * m;
     }
@@ -84,7 +84,7 @@ __device__ __forceinline__ floatx4 edge_major_half(floatx4 (&acc)[8], bool lg, i
         v2 = hi2(acc[t]) * hi2(acc[t]) + v2;
     }
     const float v = xrow_sum(v2.x + v2.y);
-    const float rstd = fast_rsqrt(v * (1.f / H) + 1e-5f);
+    const float rstd = fast_rsqrt(__builtin_fmaf(v, sc.c1, 1e-5f)) * sc.c2;
     const float2v r2 = splat2(rstd);
     const float* lg_ = lds_ln + (2 * kv) * H + 4 * q;
     const float* lb_ = lds_ln + (2 * kv + 1) * H + 4 * q;
@@ -205,6 +205,8 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         i_step = gridDim.x * WAVES;
     }
     if (i_begin >= i_end) return;
+    // power-of-two scales of the split-f16 rbf tables (wave-uniform: scalar registers)
+    const RbfScale sck = load_rbf_scale(att, 0), scv = load_rbf_scale(att, 1);
 
     // ---- first item: geometry and the k-path rows, everything unconditional -------------------------------------
     ItemGeom g;
@@ -245,7 +247,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         // are then free for this iteration's other gathers
         floatx4 acc0[8], acc1[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { acc0[t] = f4(pd[t]) + f4(ps0[t]); acc1[t] = f4(pd[t]) + f4(ps1[t]); }
+        for (int t = 0; t < 8; ++t) {   // (PD + PS) S: the tile is carried scaled by S (edge_common.h RbfScale)
+            const floatx4 pds = f4(pd[t]) * sck.S;
+            acc0[t] = f4(ps0[t]) * sck.S + pds; acc1[t] = f4(ps1[t]) * sck.S + pds;
+        }
         __builtin_amdgcn_sched_barrier(0);
         // (a) next item: id, degree, flag, position, neighbour ids in both mappings.  The last iteration re-requests its own
         // node (every prefetch below is unconditional: no divergent joins for the register allocator, no predicated loads).
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             // exp() of every slot, then a 0 / 1 factor: `valid ? exp(..) : 0` compiles to a divergent branch per value
-            const float vm = c + 16 * hf < d ? 1.f : 0.f;
+            const float vm = c + 16 * hf < d ? RBF_UP : 0.f;   // 0 / 2^RBF_EXP: the rbf values enter the f16 pipe scaled
 #pragma unroll
             for (int s = 0; s < 5; ++s) {
                 const float u = dist0[hf] - lds_mu[4 * s + q];   // re-read per node: five registers less across the loop
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         // ---- k path: hidden (edge-major) -> scores -> softmax ------------------------------------------
         floatx4 sc[2];
         sc[0] = edge_major_half<true>(acc0, lg0[0], 0, lds_fk, lds_dwt, lds_ln, R[0], has_prot, has_lig, lig_i, lane, q,
-                                      (gptr)0, 0u, qrow);
+                                      (gptr)0, 0u, qrow, sck);
         __builtin_amdgcn_sched_barrier(0);
         // (b) next item: resolve its neighbour ids (they arrived during the first half), request their flags and
         // coordinates; then the second half of the PS_v gather and the gate values
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         ew1 = ldo4(ewp, oqe + 64);
         __builtin_amdgcn_sched_barrier(0);
         sc[1] = edge_major_half<true>(acc1, lg0[1], 0, lds_fk, lds_dwt, lds_ln, R[1], has_prot, has_lig, lig_i, lane, q,
-                                      (gptr)0, 0u, qrow);
+                                      (gptr)0, 0u, qrow, sck);
         __builtin_amdgcn_sched_barrier(0);
         // next item: distances and ligand flags of its edges from the (b) loads
         bool nlg[2];
@@ -399,7 +404,8 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             floatx4 s2[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) s2[t] = floatx4{0.f, 0.f, 0.f, 0.f};
-            const float pdv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+            const float pdv[8] = {pa.x * scv.S, pa.y * scv.S, pa.z * scv.S, pa.w * scv.S,
+                                  pb.x * scv.S, pb.y * scv.S, pb.z * scv.S, pb.w * scv.S};
             const float4 ga = ld4(lds_ln + 2 * H + 4 * c), gb = ld4(lds_ln + 2 * H + 64 + 4 * c);
             const float4 ba = ld4(lds_ln + 3 * H + 4 * c), bb = ld4(lds_ln + 3 * H + 64 + 4 * c);
             const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                     const float in[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
-                        float sum = pdv[t] + in[t];
+                        float sum = __builtin_fmaf(in[t], scv.S, pdv[t]);    // (PD_v + PS_v) S
                         asm("" : "+v"(sum));
                         hv[t][r] = sum;
                     }
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                     const unsigned msh = mask_lig >> (4 * q);   // bit r (+16) <-> edge 4q + r (+16): immediate bit-field extracts
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float m = ((msh >> (r + 16 * hf)) & 1u) ? 1.f : 0.f;
+                        const float m = ((msh >> (r + 16 * hf)) & 1u) ? scv.S : 0.f;
 #pragma unroll
                         for (int t = 0; t < 8; ++t) hv[t][r] = fmaf(m, dv[t], hv[t][r]);
                     }
@@ -461,10 +467,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                         vb = hi2(hv[t]) * hi2(hv[t]) + vb;
                     }
                     float2v ra, rb;
-                    ra.x = fast_rsqrt(row16_sum(va.x) * (1.f / H) + 1e-5f);
-                    ra.y = fast_rsqrt(row16_sum(va.y) * (1.f / H) + 1e-5f);
-                    rb.x = fast_rsqrt(row16_sum(vb.x) * (1.f / H) + 1e-5f);
-                    rb.y = fast_rsqrt(row16_sum(vb.y) * (1.f / H) + 1e-5f);
+                    ra.x = fast_rsqrt(__builtin_fmaf(row16_sum(va.x), scv.c1, 1e-5f)) * scv.c2;
+                    ra.y = fast_rsqrt(__builtin_fmaf(row16_sum(va.y), scv.c1, 1e-5f)) * scv.c2;
+                    rb.x = fast_rsqrt(__builtin_fmaf(row16_sum(vb.x), scv.c1, 1e-5f)) * scv.c2;
+                    rb.y = fast_rsqrt(__builtin_fmaf(row16_sum(vb.y), scv.c1, 1e-5f)) * scv.c2;
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
                         const float2v g2 = splat2(gv[t]), b2 = splat2(bv[t]);
@@ -552,14 +558,14 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                 const unsigned wrow_off = vop((c * H + 4 * q) * 4);
                 floatx4 acc[8];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) acc[t] = f4(vd[t]) + f4(vs0[t]);
+                for (int t = 0; t < 8; ++t) { vd[t] = make_float4(vd[t].x * scv.S, vd[t].y * scv.S, vd[t].z * scv.S, vd[t].w * scv.S); acc[t] = f4(vs0[t]) * scv.S + f4(vd[t]); }
                 wv[0] = edge_major_half<false>(acc, lg0[0], 1, lds_fv, lds_dwt, lds_ln, R[0], has_prot, has_lig, lig_i, lane, q,
-                                               wrow, wrow_off, qrow);
+                                               wrow, wrow_off, qrow, scv);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < 8; ++t) acc[t] = f4(vd[t]) + f4(vs1[t]);
+                for (int t = 0; t < 8; ++t) acc[t] = f4(vs1[t]) * scv.S + f4(vd[t]);
                 wv[1] = edge_major_half<false>(acc, lg0[1], 1, lds_fv, lds_dwt, lds_ln, R[1], has_prot, has_lig, lig_i, lane, q,
-                                               wrow, wrow_off, qrow);
+                                               wrow, wrow_off, qrow, scv);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // (c) next item: its PD / PS_k rows
@@ -614,16 +620,50 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 // ------------------------------------------------------------------------------------------------
 // split-f16 pieces of the rbf columns of a (centred) first Linear W_a [128][340], block order [type][t] (layout.h): a weight
 // w is carried as h = f16(w) (round to nearest) and l = f16(w - h)
-__global__ void pack_frag_kernel(const float* __restrict__ w_a, int mode, float* __restrict__ dst) {
+// rbf table scales of one attention block (layout.h A_RBF_SC): per path the exponent kw that puts the largest |Wr| of all four
+// edge types into [2^14, 2^15), clamped to RBF_KW_MAX; one workgroup of 256 threads
+__global__ void pack_rbf_scale_kernel(const float* __restrict__ wk, const float* __restrict__ wv, float* __restrict__ sc) {
+    __shared__ float red[256];
+    for (int kv = 0; kv < 2; ++kv) {
+        const float* w = kv ? wv : wk;
+        float mx = 0.f;
+        for (int u = threadIdx.x; u < H * NT * G; u += 256) mx = fmaxf(mx, fabsf(w[(size_t)(u / (NT * G)) * KV_IN + NT + u % (NT * G)]));
+        red[threadIdx.x] = mx;
+        __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const int E = (int)((__float_as_uint(red[0]) >> 23) & 0xffu);      // max in [2^(E-127), 2^(E-126))
+            const int kw = max(-80, min(RBF_KW_MAX, 141 - E));
+            const float S = ldexpf(1.f, kw + RBF_EXP);
+            sc[4 * kv + 0] = S;
+            sc[4 * kv + 1] = 1.f / ((float)H * S * S);
+            sc[4 * kv + 2] = 1.f / S;
+            sc[4 * kv + 3] = (float)kw;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_pack_rbf_scale(const float* wk, const float* wv, float* sc, hipStream_t s) {
+    hipLaunchKernelGGL(pack_rbf_scale_kernel, dim3(1), dim3(256), 0, s, wk, wv, sc);
+    return hipGetLastError();
+}
+
+// `sc` = the path's A_RBF_SC record (its kw entry, written by pack_rbf_scale_kernel earlier on the same stream)
+__global__ void pack_frag_kernel(const float* __restrict__ w_a, int mode, const float* __restrict__ sc, float* __restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (type*8 + t)*64 + lane
     if (idx >= NT * 8 * 64) return;
     const int lane = idx & 63, t = (idx >> 6) & 7, type = idx >> 9;
     const int c = lane & 15, q = lane >> 4;
     const int m = mode == 0 ? 16 * t + c : 64 * (t >> 2) + 4 * c + (t & 3);
+    const int kw = (int)sc[3];
     _Float16 h[5], l[5];
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
-        const float w = w_a[(size_t)m * KV_IN + NT + G * type + 4 * s + q];
+        const float w = ldexpf(w_a[(size_t)m * KV_IN + NT + G * type + 4 * s + q], kw);
         h[s] = (_Float16)w;
         l[s] = (_Float16)(w - (float)h[s]);
     }
@@ -685,8 +725,8 @@ hipError_t launch_pack_dwt(const float* wk, const float* wv, float* dst, hipStre
     return hipGetLastError();
 }
 
-hipError_t launch_pack_frag(const float* w_a, int mode, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(pack_frag_kernel, dim3(NT * 8 * 64 / 256), dim3(256), 0, s, w_a, mode, dst);
+hipError_t launch_pack_frag(const float* w_a, int mode, const float* sc, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(NT * 8 * 64 / 256), dim3(256), 0, s, w_a, mode, sc, dst);
     return hipGetLastError();
 }
 

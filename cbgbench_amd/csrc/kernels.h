@@ -42,7 +42,9 @@ hipError_t launch_attention_v1(bool x2h, const float* att, const float* x, const
 constexpr int g_edge_impl = 0;
 #endif
 // split-f16 rbf weight table of one centred first Linear (layout.h): mode 0 edge-major (A operand), 1 channel-major (B operand)
-hipError_t launch_pack_frag(const float* w_a, int mode, float* dst, hipStream_t s);
+hipError_t launch_pack_frag(const float* w_a, int mode, const float* sc, float* dst, hipStream_t s);
+// A_RBF_SC record of one attention block from its centred first Linears (k, v)
+hipError_t launch_pack_rbf_scale(const float* wkc, const float* wvc, float* sc, hipStream_t s);
 hipError_t launch_center_linear(const float* w, const float* b, int cols, float* wc, float* bc, hipStream_t s);
 hipError_t launch_pack_dwt(const float* wk, const float* wv, float* dst, hipStream_t s);
 hipError_t launch_pack_bn2(const float* att_wakc, const float* bq0, float* att, hipStream_t s);

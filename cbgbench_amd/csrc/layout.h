@@ -88,7 +88,21 @@ constexpr size_t A_WRC = A_WRT + (size_t)NT * 2 * H * 32;
 // training only (x2h blocks): the split-f16 rbf table of the v path in the EDGE-major labeling (A operand), as IMG_FRAG_K
 // is for k -- the x2h forward image keeps v channel-major.  Read from L2 by train_bwd_x2h.hip.
 constexpr size_t A_FRAGV_EM = A_WRC + (size_t)NT * G * 2 * H;
-constexpr size_t ATT_SIZE = A_FRAGV_EM + FRAG;
+// ---- range-safe split-f16: every f16 table is scaled by exact powers of two at pack time so that its
+// largest entry sits in [2^14, 2^15) -- hi = f16(w 2^k), lo = f16(w 2^k - hi) then keep 2^-21 relative accuracy over 18 binades
+// below the table's maximum instead of losing `lo` to f16 subnormals below |w| = 2^-3 -- and the scale is undone in fp32.
+//   A_RBF_SC   [2 paths k|v][4]  {S = 2^(kw + RBF_EXP), 1 / (H S^2), 1 / S, kw}: the rbf tables of a path share one exponent
+//                                kw (both source classes accumulate into one tile); the kernels scale the rbf values by
+//                                2^RBF_EXP and PD + PS by S, LayerNorm divides it out again
+//   A_NPROJ_CINV [640]           2^-kc per output column of the node projection tables (A_NPROJ_FRAG holds Wn[:, col] 2^kc)
+//   A_WQ1_CINV   [128]           same for the query MLP's second Linear (A_WQ1_FRAG)
+// The activations (rows of h, LayerNorm outputs) are scaled per row inside the node kernels.
+constexpr int RBF_EXP = 12;          // rbf values in [0, 1] -> [0, 2^12]
+constexpr int RBF_KW_MAX = 20;       // S <= 2^32: sum of squares of 128 scaled pre-activations stays finite up to |pre| = 2^28
+constexpr size_t A_RBF_SC = A_FRAGV_EM + FRAG;
+constexpr size_t A_NPROJ_CINV = A_RBF_SC + 8;
+constexpr size_t A_WQ1_CINV = A_NPROJ_CINV + PROW;
+constexpr size_t ATT_SIZE = A_WQ1_CINV + H;
 
 constexpr size_t LAYER_SIZE = 2 * ATT_SIZE;       // x2h then h2x
 

@@ -34,6 +34,41 @@ __device__ __forceinline__ float nxrow_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+__device__ __forceinline__ float nxrow_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// Range-safe split-f16 (layout.h): a row of activations is multiplied by the power of two that puts its largest
+// magnitude `mx` into [2^14, 2^15) before it is split into hi = f16(v), lo = f16(v - hi) -- every |v| >= mx 2^-17 then has a
+// normal `lo` (2^-21 relative), smaller ones an absolute error of mx 2^-39 -- and the fp32 accumulator is multiplied by the inverse.
+// Any finite input works (|h| > 65504 included); the exponent is clamped so that both factors stay normal fp32 numbers.
+// Returns the up-scale, `inv` gets its reciprocal.  All lanes of a row must pass the same mx.
+__device__ __forceinline__ float row_pow2(float mx, float& inv) {
+    const int E = (int)((__float_as_uint(mx) >> 23) & 0xffu);      // mx in [2^(E-127), 2^(E-126))
+    const int ka = max(-100, min(100, 141 - E));
+    inv = __uint_as_float((unsigned)(127 - ka) << 23);
+    return __uint_as_float((unsigned)(127 + ka) << 23);
+}
+// the inverse row scales in the MFMA C layout (register r <-> row 4q + r) from the A layout (lane c <-> row c)
+__device__ __forceinline__ void rows_to_c_layout(float inv, int q, float (&rinv)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        rinv[r] = __uint_as_float(__builtin_amdgcn_ds_bpermute(4 * (4 * q + r), __float_as_uint(inv)));
+}
+// split 8 consecutive operand slots of a row (already loaded) after scaling by `up`
+__device__ __forceinline__ void split8(const float (&v)[8], float up, half8& hi8, half8& lo8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float sv = v[j] * up;
+        const _Float16 hi = (_Float16)sv;
+        hi8[j] = hi;
+        lo8[j] = (_Float16)(sv - (float)hi);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // node_proj: 4 waves x 16 rows per workgroup; 10 column chunks of 64; chunk tables double-buffered in LDS.
 // The product runs in split-f16 on v_mfma_f32_16x16x32_f16 (K = 32 per instruction, 8 f16 per lane and operand): the 128
@@ -79,16 +114,22 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
             lgr[r] = lig[rows ? rows[kk] : kk] != 0;
         }
         half8 ah[4], al[4];
+        float rinv[4];
+        {
+            float hv[4][8];
+            float mx = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float4 v0 = nld4(h + (size_t)arow * H + 32 * u + 4 * q), v1 = nld4(h + (size_t)arow * H + 32 * u + 16 + 4 * q);
-            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            for (int u = 0; u < 4; ++u) {
+                const float4 v0 = nld4(h + (size_t)arow * H + 32 * u + 4 * q), v1 = nld4(h + (size_t)arow * H + 32 * u + 16 + 4 * q);
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 hi = (_Float16)v[j];
-                ah[u][j] = hi;
-                al[u][j] = (_Float16)(v[j] - (float)hi);
+                for (int j = 0; j < 8; ++j) { hv[u][j] = v[j]; mx = fmaxf(mx, fabsf(v[j])); }
             }
+            float inv;
+            const float up = row_pow2(nxrow_max(mx), inv);
+            rows_to_c_layout(inv, q, rinv);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) split8(hv[u], up, ah[u], al[u]);
         }
         __syncthreads();  // previous tile's readers of lds[0] are done
         {
@@ -114,12 +155,10 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
             const half8* Bh = reinterpret_cast<const half8*>(lds[is & 1]) + lane;   // [ct][u][lane]
             const half8* Bl = Bh + 4 * 4 * 64;
             const float4 bP = nld4(bias + 64 * ch + 4 * c), bL = nld4(bias + PROW + 64 * ch + 4 * c);
+            const float4 ci = nld4(att + A_NPROJ_CINV + 64 * ch + 4 * c);     // 2^-kc of this lane's four columns
             floatx4 acc[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[0][r] = lgr[r] ? bL.x : bP.x; acc[1][r] = lgr[r] ? bL.y : bP.y;
-                acc[2][r] = lgr[r] ? bL.z : bP.z; acc[3][r] = lgr[r] ? bL.w : bP.w;
-            }
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 half8 bh[4], bl[4];
@@ -135,7 +174,9 @@ __global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (orow[r] >= 0) {
-                    float4 o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                    const float4 b = lgr[r] ? bL : bP;
+                    float4 o = {fmaf(acc[0][r] * rinv[r], ci.x, b.x), fmaf(acc[1][r] * rinv[r], ci.y, b.y),
+                                fmaf(acc[2][r] * rinv[r], ci.z, b.z), fmaf(acc[3][r] * rinv[r], ci.w, b.w)};
                     *reinterpret_cast<float4*>(P + (size_t)orow[r] * PROW + 64 * ch + 4 * c) = o;
                 }
             }
@@ -225,20 +266,28 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
             z[4 * u + 3] = fmaxf(z[4 * u + 3] * rstd * g.w + b.w, 0.f);
         }
         half8 zh[4], zl[4];   // z[8u + j] <-> k = 16 (2u + (j >> 2)) + 4q + (j & 3): exactly the order z was loaded in
+        float rinv[4];
+        {
+            float mx = 0.f;   // z >= 0 after the ReLU
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 32; ++u) mx = fmaxf(mx, z[u]);
+            float inv;
+            const float up = row_pow2(nxrow_max(mx), inv);
+            rows_to_c_layout(inv, q, rinv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 hi = (_Float16)z[8 * u + j];
-                zh[u][j] = hi;
-                zl[u][j] = (_Float16)(z[8 * u + j] - (float)hi);
+            for (int u = 0; u < 4; ++u) {
+                const float v[8] = {z[8 * u], z[8 * u + 1], z[8 * u + 2], z[8 * u + 3], z[8 * u + 4], z[8 * u + 5], z[8 * u + 6], z[8 * u + 7]};
+                split8(v, up, zh[u], zl[u]);
             }
+        }
         const half8* Bh = reinterpret_cast<const half8*>(lds) + lane;   // [nt][u][lane]
         const half8* Bl = Bh + 8 * 4 * 64;
         for (int grp = grp_begin; grp < grp_end; ++grp) {
             const float4 b4 = nld4(att + A_BQ1 + 64 * grp + 4 * c);
-            floatx4 acc[4] = {{b4.x, b4.x, b4.x, b4.x}, {b4.y, b4.y, b4.y, b4.y}, {b4.z, b4.z, b4.z, b4.z},
-                              {b4.w, b4.w, b4.w, b4.w}};
+            const float4 ci = nld4(att + A_WQ1_CINV + 64 * grp + 4 * c);
+            floatx4 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 half8 bh[4], bl[4];
@@ -254,7 +303,8 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (orow[r] >= 0) {
-                    float4 o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                    float4 o = {fmaf(acc[0][r] * rinv[r], ci.x, b4.x), fmaf(acc[1][r] * rinv[r], ci.y, b4.y),
+                                fmaf(acc[2][r] * rinv[r], ci.z, b4.z), fmaf(acc[3][r] * rinv[r], ci.w, b4.w)};
                     *reinterpret_cast<float4*>(qout + (size_t)orow[r] * H + 64 * grp + 4 * c) = o;
                 }
             }
@@ -352,16 +402,22 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(const float* __restric
         // ---- phase 1: projection, 20 units of 32 columns (half a chunk); the q-hidden chunks first: wave w takes unit w, waves
         // 0..3 a second one.  One unit's 16 operand loads are all in flight at once (64 VGPRs of the 128 a 16-wave group gets).
         half8 ah[4], al[4];
+        float rinv[4];
+        {
+            float hv[4][8];
+            float mx = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float4 v0 = nld4(h + (size_t)arow * H + 32 * u + 4 * q), v1 = nld4(h + (size_t)arow * H + 32 * u + 16 + 4 * q);
-            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            for (int u = 0; u < 4; ++u) {
+                const float4 v0 = nld4(h + (size_t)arow * H + 32 * u + 4 * q), v1 = nld4(h + (size_t)arow * H + 32 * u + 16 + 4 * q);
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 hi = (_Float16)v[j];
-                ah[u][j] = hi;
-                al[u][j] = (_Float16)(v[j] - (float)hi);
+                for (int j = 0; j < 8; ++j) { hv[u][j] = v[j]; mx = fmaxf(mx, fabsf(v[j])); }
             }
+            float inv;
+            const float up = row_pow2(nxrow_max(mx), inv);
+            rows_to_c_layout(inv, q, rinv);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) split8(hv[u], up, ah[u], al[u]);
         }
         bool lgr[4];
 #pragma unroll
@@ -378,9 +434,8 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(const float* __restric
                 for (int ct = 0; ct < 2; ++ct) { bh[u][ct] = Bh[(ct * 4 + u) * 64]; bl[u][ct] = Bl[(ct * 4 + u) * 64]; }
             const float* bias = att + A_BN2 + 64 * ch + 4 * c + 2 * half;   // [dst class][640]: bias + type column of a protein source
             const float2 bP = *reinterpret_cast<const float2*>(bias), bL = *reinterpret_cast<const float2*>(bias + PROW);
-            floatx4 acc[2];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { acc[0][r] = lgr[r] ? bL.x : bP.x; acc[1][r] = lgr[r] ? bL.y : bP.y; }
+            const float2 ci = *reinterpret_cast<const float2*>(att + A_NPROJ_CINV + 64 * ch + 4 * c + 2 * half);
+            floatx4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -392,7 +447,8 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(const float* __restric
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float2 o = {acc[0][r], acc[1][r]};
+                const float2 o = {fmaf(acc[0][r] * rinv[r], ci.x, lgr[r] ? bL.x : bP.x),
+                                  fmaf(acc[1][r] * rinv[r], ci.y, lgr[r] ? bL.y : bP.y)};
                 if (orow[r] >= 0) *reinterpret_cast<float2*>(P + (size_t)orow[r] * PROW + 64 * ch + 4 * c + 2 * half) = o;
                 if (ch >= 8) *reinterpret_cast<float2*>(&qh[4 * q + r][64 * (ch - 8) + 4 * c + 2 * half]) = o;
             }
@@ -420,21 +476,25 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(const float* __restric
             for (int u = 0; u < 32; ++u) { z[u] -= mean; var += z[u] * z[u]; }
             const float rstd = 1.f / sqrtf(nxrow_sum(var) * (1.f / H) + 1e-5f);
             half8 zh[4], zl[4];
+            float zmx = 0.f;   // z >= 0 after the ReLU
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float4 g = nld4(att + A_LNQ_G + 16 * u + 4 * q), b = nld4(att + A_LNQ_B + 16 * u + 4 * q);
-                const float y[4] = {fmaxf(z[4 * u + 0] * rstd * g.x + b.x, 0.f), fmaxf(z[4 * u + 1] * rstd * g.y + b.y, 0.f),
-                                    fmaxf(z[4 * u + 2] * rstd * g.z + b.z, 0.f), fmaxf(z[4 * u + 3] * rstd * g.w + b.w, 0.f)};
+                z[4 * u + 0] = fmaxf(z[4 * u + 0] * rstd * g.x + b.x, 0.f); z[4 * u + 1] = fmaxf(z[4 * u + 1] * rstd * g.y + b.y, 0.f);
+                z[4 * u + 2] = fmaxf(z[4 * u + 2] * rstd * g.z + b.z, 0.f); z[4 * u + 3] = fmaxf(z[4 * u + 3] * rstd * g.w + b.w, 0.f);
+                zmx = fmaxf(fmaxf(zmx, fmaxf(z[4 * u], z[4 * u + 1])), fmaxf(z[4 * u + 2], z[4 * u + 3]));
+            }
+            float zinv, zrinv[4];
+            const float zup = row_pow2(nxrow_max(zmx), zinv);
+            rows_to_c_layout(zinv, q, zrinv);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const _Float16 hi = (_Float16)y[j];
-                    zh[u >> 1][4 * (u & 1) + j] = hi;
-                    zl[u >> 1][4 * (u & 1) + j] = (_Float16)(y[j] - (float)hi);
-                }
+            for (int u = 0; u < 4; ++u) {
+                const float v[8] = {z[8 * u], z[8 * u + 1], z[8 * u + 2], z[8 * u + 3], z[8 * u + 4], z[8 * u + 5], z[8 * u + 6], z[8 * u + 7]};
+                split8(v, zup, zh[u], zl[u]);
             }
             const int col = 64 * (nt >> 2) + 4 * c + (nt & 3);
-            const float b1 = att[A_BQ1 + col];
-            floatx4 acc = {b1, b1, b1, b1};
+            const float b1 = att[A_BQ1 + col], ci = att[A_WQ1_CINV + col];
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 acc = MFMAH32(zh[u], bl[u], acc);
@@ -443,8 +503,9 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(const float* __restric
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                qt[4 * q + r][col] = acc[r];
-                if (orow[r] >= 0) qout[(size_t)orow[r] * H + col] = acc[r];
+                const float o = fmaf(acc[r] * zrinv[r], ci, b1);
+                qt[4 * q + r][col] = o;
+                if (orow[r] >= 0) qout[(size_t)orow[r] * H + col] = o;
             }
         }
         __syncthreads();
@@ -561,20 +622,40 @@ hipError_t launch_node_gemm(const float* A, int lda, const float* Wt, const floa
 // node projection: split-f16 chunk tables, dst[ch][part][ct][u][lane][j] (f16) = hi / lo of
 // Wcat[col = 64ch + 4c + ct][k = 16 (2u + (j >> 2)) + 4q + (j & 3)]; Wcat rows are assembled from W_a_k / W_a_v (dst and src
 // thirds) and W_q0, exactly like the K-major A_WN table.
+// weight of the assembled node projection Wcat[col][k] (col = PDk | PDv | PSk | PSv | q hidden)
+__device__ __forceinline__ float nproj_weight(const float* wk0, const float* wv0, const float* wq0, int col, int k) {
+    const int blk = col >> 7, n = col & 127;
+    if (blk == 0) return wk0[(size_t)n * KV_IN + NT + NT * G + k];            // PDk
+    if (blk == 1) return wv0[(size_t)n * KV_IN + NT + NT * G + k];            // PDv
+    if (blk == 2) return wk0[(size_t)n * KV_IN + NT + NT * G + H + k];        // PSk
+    if (blk == 3) return wv0[(size_t)n * KV_IN + NT + NT * G + H + k];        // PSv
+    return wq0[(size_t)n * H + k];                                            // q hidden
+}
+// 2^-kc for a column whose largest |w| is mx: w 2^kc lands in [2^14, 2^15) (kc clamped so that both factors are normal)
+__device__ __forceinline__ float col_pow2_inv(float mx) {
+    const int E = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+    const int kc = max(-100, min(60, 141 - E));
+    return __uint_as_float((unsigned)(127 - kc) << 23);
+}
+// per-column inverse scales of the two split-f16 node tables: cinv[0..640) node projection, cinv[640..768) query MLP second Linear
+__global__ void pack_colscale_kernel(const float* __restrict__ wk0, const float* __restrict__ wv0, const float* __restrict__ wq0,
+                                     const float* __restrict__ wq1, float* __restrict__ cinv_proj, float* __restrict__ cinv_q1) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= PROW + H) return;
+    float mx = 0.f;
+    for (int k = 0; k < H; ++k)
+        mx = fmaxf(mx, fabsf(col < PROW ? nproj_weight(wk0, wv0, wq0, col, k) : wq1[(size_t)(col - PROW) * H + k]));
+    if (col < PROW) cinv_proj[col] = col_pow2_inv(mx); else cinv_q1[col - PROW] = col_pow2_inv(mx);
+}
+
 __global__ void pack_nproj_kernel(const float* __restrict__ wk0, const float* __restrict__ wv0,
-                                  const float* __restrict__ wq0, _Float16* __restrict__ dst) {
+                                  const float* __restrict__ wq0, const float* __restrict__ cinv, _Float16* __restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per weight: ((ch*4 + ct)*4 + u)*64*8 + lane*8 + j
     if (idx >= NP_CHUNKS * 4 * 4 * 64 * 8) return;
     const int j = idx & 7, lane = (idx >> 3) & 63, u = (idx >> 9) & 3, ct = (idx >> 11) & 3, ch = idx >> 13;
     const int c = lane & 15, q = lane >> 4;
     const int col = 64 * ch + 4 * c + ct, k = 16 * (2 * u + (j >> 2)) + 4 * q + (j & 3);
-    const int blk = col >> 7, n = col & 127;
-    float v;
-    if (blk == 0) v = wk0[(size_t)n * KV_IN + NT + NT * G + k];            // PDk
-    else if (blk == 1) v = wv0[(size_t)n * KV_IN + NT + NT * G + k];       // PDv
-    else if (blk == 2) v = wk0[(size_t)n * KV_IN + NT + NT * G + H + k];   // PSk
-    else if (blk == 3) v = wv0[(size_t)n * KV_IN + NT + NT * G + H + k];   // PSv
-    else v = wq0[(size_t)n * H + k];                                       // q hidden
+    const float v = nproj_weight(wk0, wv0, wq0, col, k) * (1.f / cinv[col]);   // exact: a power of two
     const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
     _Float16* chunk = dst + (size_t)ch * (NP_CHUNK * 2);                   // f16 elements per chunk
     const size_t off = ((size_t)(ct * 4 + u) * 64 + lane) * 8 + j;
@@ -582,12 +663,13 @@ __global__ void pack_nproj_kernel(const float* __restrict__ wk0, const float* __
     chunk[(size_t)4 * 4 * 64 * 8 + off] = lo;
 }
 
-__global__ void pack_wq1_kernel(const float* __restrict__ wq1, _Float16* __restrict__ dst) {
+__global__ void pack_wq1_kernel(const float* __restrict__ wq1, const float* __restrict__ cinv, _Float16* __restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per weight: [nt 8][u 4][lane 64][j 8]
     if (idx >= H * H) return;
     const int j = idx & 7, lane = (idx >> 3) & 63, u = (idx >> 9) & 3, nt = idx >> 11;
     const int c = lane & 15, q = lane >> 4;
-    const float v = wq1[(size_t)(64 * (nt >> 2) + 4 * c + (nt & 3)) * H + 16 * (2 * u + (j >> 2)) + 4 * q + (j & 3)];
+    const int n = 64 * (nt >> 2) + 4 * c + (nt & 3);
+    const float v = wq1[(size_t)n * H + 16 * (2 * u + (j >> 2)) + 4 * q + (j & 3)] * (1.f / cinv[n]);
     const _Float16 hi = (_Float16)v;
     dst[idx] = hi;
     dst[(size_t)H * H + idx] = (_Float16)(v - (float)hi);
@@ -621,9 +703,12 @@ hipError_t launch_pack_bn2(const float* att_in, const float* bq0, float* att, hi
 
 hipError_t launch_pack_node_frags(const float* wk0, const float* wv0, const float* wq0, const float* wq1,
                                   const float* wbk, float* att, hipStream_t s) {
-    hipLaunchKernelGGL(pack_nproj_kernel, dim3(NP_CHUNKS * 4 * 4 * 64 * 8 / 256), dim3(256), 0, s, wk0, wv0, wq0,
+    hipLaunchKernelGGL(pack_colscale_kernel, dim3((PROW + H + 255) / 256), dim3(256), 0, s, wk0, wv0, wq0, wq1, att + A_NPROJ_CINV,
+                       att + A_WQ1_CINV);
+    hipLaunchKernelGGL(pack_nproj_kernel, dim3(NP_CHUNKS * 4 * 4 * 64 * 8 / 256), dim3(256), 0, s, wk0, wv0, wq0, att + A_NPROJ_CINV,
                        reinterpret_cast<_Float16*>(att + A_NPROJ_FRAG));
-    hipLaunchKernelGGL(pack_wq1_kernel, dim3(H * H / 256), dim3(256), 0, s, wq1, reinterpret_cast<_Float16*>(att + A_WQ1_FRAG));
+    hipLaunchKernelGGL(pack_wq1_kernel, dim3(H * H / 256), dim3(256), 0, s, wq1, att + A_WQ1_CINV,
+                       reinterpret_cast<_Float16*>(att + A_WQ1_FRAG));
     hipLaunchKernelGGL(pack_wbk_kernel, dim3(NF_FRAG / 256), dim3(256), 0, s, wbk, att + A_WBK_FRAG);
     return hipGetLastError();
 }

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
             float rstd[2];
             float4 br[8];
             const float* frag = att + (kv ? A_FRAGV_EM : A_IMG + IMG_FRAG_K);
+            const RbfScale rsc = load_rbf_scale(att, kv);      // the tile is carried scaled by S until LayerNorm (edge_common.h)
             // the key path's normalised pre-activation is parked in the wave's slot of a scratch buffer in phase 0 and read back in
             // phase 2 (16 coalesced KB each way) instead of being gathered, multiplied and normalised a second time
             float* nk = nk_scratch + ((size_t)blockIdx.x * BX_WAVES + wave) * BX_NK_SLOT + 4 * lane;
@@ -269,7 +270,10 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 BX_T(10);
                 SCHED_FENCE();
 #pragma unroll
-                for (int t = 0; t < 8; ++t) { n[0][t] = f4(pd[t]) + f4(pa[t]); n[1][t] = f4(pd[t]) + f4(pb[t]); }
+                for (int t = 0; t < 8; ++t) {
+                    const floatx4 pds = f4(pd[t]) * rsc.S;
+                    n[0][t] = f4(pa[t]) * rsc.S + pds; n[1][t] = f4(pb[t]) * rsc.S + pds;
+                }
                 // the contraction's B rows: in flight behind the rbf MFMAs and the LayerNorm (phase 2 has no contraction; loading
                 // them anyway keeps the array from being carried around the phase loop)
 #pragma unroll
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 SCHED_FENCE();
                 if (has_lig) {      // type column of ligand sources (P already holds the protein-source one)
                     const float* dw = att + A_IMG + IMG_WT + lig_i * 2 * H + kv * H + 4 * q;
-                    const float m0 = lg0[0] ? 1.f : 0.f, m1 = lg0[1] ? 1.f : 0.f;
+                    const float m0 = lg0[0] ? rsc.S : 0.f, m1 = lg0[1] ? rsc.S : 0.f;
                     float4 w4[8];
 #pragma unroll
                     for (int t = 0; t < 8; ++t) w4[t] = ld4(dw + 16 * t);
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
 #pragma unroll
                         for (int s = 0; s < 5; ++s) {
                             const float u = dist0[hf] - muq[s];
-                            Rm[s] = (val0[hf] && lg0[hf] == (p == 1)) ? fast_exp(-0.5f * (u * u)) : 0.f;
+                            Rm[s] = fast_exp(-0.5f * (u * u)) * ((val0[hf] && lg0[hf] == (p == 1)) ? RBF_UP : 0.f);
                         }
                         rbf_tuples(Rm, B[hf]);
                     }
@@ -330,8 +334,8 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v = fmaf(n[hf][t][r], n[hf][t][r], v);
                     v = xrow_sum(v);
-                    rstd[hf] = fast_rsqrt(v * (1.f / H) + 1e-5f);
-                    const float sc = val0[hf] ? rstd[hf] : 0.f;     // padded slots: exact zeros downstream
+                    rstd[hf] = fast_rsqrt(__builtin_fmaf(v, rsc.c1, 1e-5f));       // the true 1 / sigma (v c1 = the unscaled variance)
+                    const float sc = val0[hf] ? rstd[hf] * rsc.c2 : 0.f;            // padded slots: exact zeros downstream
 #pragma unroll
                     for (int t = 0; t < 8; ++t) n[hf][t] = n[hf][t] * sc;
                 }

@@ -32,7 +32,15 @@ class FlatAdam(torch.optim.Adam):
     fp32 buffers, so that ``step()`` is a handful of kernels over 2.7 M elements instead of a Python loop over 342 tensors (1.5 ms of
     host time per step, the device idle meanwhile).  Same update rule, same op order as torch's single-tensor path; ``param_groups``,
     ``state`` and ``state_dict()`` have the stock layout (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``), so checkpoints
-    are interchangeable with ``torch.optim.Adam`` in both directions -- ``load_state_dict`` copies into the flat buffers."""
+    are interchangeable with ``torch.optim.Adam`` in both directions -- ``load_state_dict`` copies into the flat buffers.
+
+    Two things differ from the stock class and are part of the contract:
+    * ONE step counter is shared by all parameters (stock Adam keeps one per parameter; they only differ when some parameters
+      had no gradient in some steps).  A parameter whose ``.grad`` is None in a step is skipped exactly like stock Adam does
+      (weight and moments untouched); a loaded checkpoint must carry the same ``step`` for every parameter it has state for.
+    * every ``step()`` marks the parameters as modified in place (their autograd version counters are bumped): they are views
+      of the flat buffer the update writes, and without the bump neither autograd's saved-tensor checks nor
+      ``UniTransformer.packed_weights`` (which re-packs when a version changes) would see the update."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(list(params), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
@@ -64,14 +72,31 @@ class FlatAdam(torch.optim.Adam):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)                      # fills self.state[p] with fresh tensors (stock behaviour)
+        steps = set()
         with torch.no_grad():
             for p, m, v in zip(self._ps, self._m.split(self._sizes), self._v.split(self._sizes)):
                 st = self.state.get(p, None)
-                if st:
+                if st and "exp_avg" in st:
                     m.copy_(st["exp_avg"].reshape(-1))
                     v.copy_(st["exp_avg_sq"].reshape(-1))
-                    self._step = torch.as_tensor(float(st["step"]), dtype=torch.float32)
+                    steps.add(float(st["step"]))
+                else:                                            # no state for this parameter in the checkpoint: as after construction
+                    m.zero_()
+                    v.zero_()
+        if len(steps) > 1:
+            raise ValueError(f"FlatAdam keeps one step counter for all parameters; the checkpoint has {sorted(steps)}")
+        self._step = torch.as_tensor(steps.pop() if steps else 0.0, dtype=torch.float32)
         self._bind_state()
+
+    def _mark_modified(self):
+        """bump the version counter of every parameter (they alias ``self._w``, which ``step`` has just written)"""
+        inc = getattr(torch._C, "_increment_version", None)
+        try:
+            if inc is None:
+                raise TypeError
+            inc(self._ps)
+        except TypeError:                                        # older / newer torch without the list form: one fused no-op kernel
+            torch._foreach_mul_(self._ps, 1.0)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -79,11 +104,17 @@ class FlatAdam(torch.optim.Adam):
         g0 = self._ps[0].grad
         # the gradients are views of one flat buffer in parameter order (FlatGradients); recover it, or gather
         base = g0._base if g0 is not None and g0._base is not None else None
+        skipped = []     # (w, m, v) slices of parameters without a gradient, restored after the flat update: stock Adam skips them
         if base is not None and base.numel() == self._w.numel() and all(
                 p.grad is not None and p.grad._base is base for p in self._ps):
             g = base
         else:
+            if all(p.grad is None for p in self._ps):
+                return loss
             g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self._ps])
+            for p, w, m, v in zip(self._ps, self._w.split(self._sizes), self._m.split(self._sizes), self._v.split(self._sizes)):
+                if p.grad is None:
+                    skipped.append(((w, w.clone()), (m, m.clone()), (v, v.clone())))
         grp = self.param_groups[0]
         beta1, beta2 = grp["betas"]
         self._step += 1
@@ -95,6 +126,10 @@ class FlatAdam(torch.optim.Adam):
         bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
         denom = (self._v.sqrt() / (bc2 ** 0.5)).add_(grp["eps"])
         self._w.addcdiv_(self._m, denom, value=-grp["lr"] / bc1)
+        for pairs in skipped:
+            for dst, saved in pairs:
+                dst.copy_(saved)
+        self._mark_modified()
         return loss
 
 

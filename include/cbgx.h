@@ -22,6 +22,15 @@
  * Return value: 0 on success, negative CBGX_E_* on failure (never abort());
  * cbgx_last_error() gives a thread-local message.
  *
+ * Arithmetic contract: inputs, outputs and accumulators are fp32.  The node projection, the query MLP's second Linear and the
+ * radial-basis part of the edge pre-activation run on the f16 matrix pipe as "split-f16" products (every fp32 operand v is carried
+ * as hi = f16(v 2^k), lo = f16(v 2^k - hi) with 2^k an exact power of two chosen per weight column / per table at pack time and per
+ * row of activations at run time; three f16 products hi hi + hi lo + lo hi, fp32 accumulation, 2^-k applied to the fp32 result),
+ * everything else on fp32 MFMA / VALU.  The result is fp32-grade for ANY finite fp32 input and weight: error <= ~2^-21 of
+ * sum |a||b| per dot product, measured 5 - 8e-8 against 1.3 - 2.5e-7 for a plain fp32 FMA chain over weight scales 1e-4 .. 30 and
+ * activations 1e-3 .. 1e5 (tests/test_splitf16_range.py, tests/test_gpu_range.py; |h| > 65 504 is fine).  There is no input
+ * range to respect and hence no range error code; non-finite inputs propagate as in the reference.
+ *
  * Node order (as produced by compose_context, repo/modules/common.py:189-214):
  * nodes sorted by graph; graph g owns rows [graph_ptr[g], graph_ptr[g+1]).
  */
@@ -35,7 +44,9 @@
 extern "C" {
 #endif
 
-#define CBGX_ABI_VERSION 1
+/* 2: the packed-weight layout carries the power-of-two scales of the split-f16 tables (range-safe arithmetic, below); a blob
+ * packed by a version-1 library is not understood by version 2 and vice versa -- re-pack with the library that consumes it. */
+#define CBGX_ABI_VERSION 2
 
 #define CBGX_OK 0
 #define CBGX_E_INVALID (-1)   /* bad argument (shape, NULL pointer, unsupported hyper-parameter) */

@@ -29,14 +29,10 @@ def com_head(sd, x_lig_pred, bl, x, h, gen_flag, lig_flag, batch_idx, B, num_lay
     e_w = U.edge_gate(sdp, prefix, x, edge_index)
     x_out = x.clone()
     for l in range(num_layers):
-        dx = U.h2x_attention(_rename(sdp, f"{prefix}.h2xattentions.{l}"), "blk", x_out, h, edge_type, edge_index, e_w)
+        dx = U.h2x_attention(sdp, f"{prefix}.h2xattentions.{l}", x_out, h, edge_type, edge_index, e_w)
         x_out = x_out + dx * gen_flag.unsqueeze(-1).to(x.dtype)
     shift = scatter_mean((x_out - x)[lig_flag], bl, B)[bl]
     return noise, shift
-
-
-def _rename(sd, prefix):
-    return {"blk" + k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix + ".")}
 
 
 def pos_backward_score(tb, x_pred, x_noisy, t, bl, gen, eps):

@@ -230,13 +230,26 @@ def _diffbp_case(name, batch, T, seed):
     print(name, "keys", sorted(traj.keys()))
 
 
+EXAMPLES = {   # scripts/example/<dir>: (protein PDB, ligand SDF)
+    "Eg5": ("3zcw_protein.pdb", "3zcw_ligand.sdf"),
+    "adrb1": ("2VT4_protein.pdb", "2VT4_ligand.sdf"),
+    "drd2": ("6CM4_protein.pdb", "6CM4_ligand.sdf"),
+    "smarca2": ("6HAX_protein.pdb", "6HAX_ligand.sdf"),
+}
+
+
 def eg5_pocket(radius=10.0):
-    """scripts/example/Eg5 (PDB 3ZCW) heavy atoms of residues with any atom within ``radius`` A of
-    a ligand heavy atom -- the pocket criterion of datasets/parsers/protein_parser.py:167-177 --
+    return example_pocket("Eg5", radius)
+
+
+def example_pocket(example, radius=10.0):
+    """scripts/example/<example> (Eg5 = PDB 3ZCW, adrb1 = 2VT4, drd2 = 6CM4, smarca2 = 6HAX): heavy atoms of residues with any atom
+    within ``radius`` A of a ligand heavy atom -- the pocket criterion of datasets/parsers/protein_parser.py:167-177 --
     parsed from plain text (no RDKit/BioPython here)."""
-    base = os.path.join(ref_shim.REFERENCE_ROOT, "scripts", "example", "Eg5")
+    base = os.path.join(ref_shim.REFERENCE_ROOT, "scripts", "example", example)
+    pdb_name, sdf_name = EXAMPLES[example]
     lig = []
-    with open(os.path.join(base, "3zcw_ligand.sdf")) as f:
+    with open(os.path.join(base, sdf_name)) as f:
         lines = f.read().splitlines()
     na = int(lines[3][:3])
     for ln in lines[4:4 + na]:
@@ -247,7 +260,7 @@ def eg5_pocket(radius=10.0):
     aa3 = ["ALA", "CYS", "ASP", "GLU", "PHE", "GLY", "HIS", "ILE", "LYS", "LEU", "MET", "ASN", "PRO", "GLN",
            "ARG", "SER", "THR", "VAL", "TRP", "TYR"]
     elem_idx = {"H": 0, "C": 1, "N": 2, "O": 3, "S": 4, "SE": 5}
-    with open(os.path.join(base, "3zcw_protein.pdb")) as f:
+    with open(os.path.join(base, pdb_name)) as f:
         for ln in f:
             if not ln.startswith("ATOM"):
                 continue
@@ -491,6 +504,17 @@ def main():
     b = S.make_batch([(pos, feat, aa)], [lig.shape[0]], rng, 13)
     b["ligand_pos"] = torch.from_numpy(lig + rng.standard_normal(lig.shape).astype(np.float32) * 0.5)
     denoiser_case(model, "denoiser_eg5_pocket10", b)
+    # the other three example targets of the reference (real pocket geometry, 10 A pockets as sample.py cuts them); two samples
+    # of the ligand per pocket with different noise, as the samplers batch them
+    for k, ex in enumerate(("adrb1", "drd2", "smarca2")):
+        if not _selected(f"denoiser_{ex}_pocket10"):
+            continue
+        pos, feat, aa, lig = example_pocket(ex)
+        rng = np.random.default_rng(140 + k)
+        b = S.make_batch([(pos, feat, aa), (pos, feat, aa)], [lig.shape[0], lig.shape[0]], rng, 13)
+        noisy = [lig + rng.standard_normal(lig.shape).astype(np.float32) * sg for sg in (0.5, 2.0)]
+        b["ligand_pos"] = torch.from_numpy(np.concatenate(noisy, 0))
+        denoiser_case(model, f"denoiser_{ex}_pocket10", b)
 
     step_case(model, "step_t500", small_batch([(64, 10), (50, 12)], seed=21), 500, seed=5)
     step_case(model, "step_t0", small_batch([(64, 10), (50, 12)], seed=22), 0, seed=6)

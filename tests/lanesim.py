@@ -16,6 +16,11 @@ time, the 5 rbf values of a lane per node.  Per (type, tile t) a lane owns five 
     d0 = [h0 h1]  d1 = [h2 h3]  d2 = [h4 l0]  d3 = [l1 l2]  d4 = [l3 l4]          (index = s of g = 4s + q)
 -- 20 bytes, exactly the fp32 footprint -- read as the tuples T1 = (d0, d1), T2 = (d2, d3), T3 = (d4, d2), which four MFMAs
 contract with the rbf tuples  [rh0..3], [rl0..3], [rh4 rh0 rh1 rh2], [rh3 rh4 rl4 0]  (T1 is used twice, d2 is read twice).
+
+Range safety (csrc/layout.h A_RBF_SC): the weight table of a path holds Wr 2^kw with kw chosen at pack time so that the largest
+entry lies in [2^14, 2^15) (clamped to RBF_KW_MAX), the rbf values are produced times 2^RBF_EXP, and the pre-activation tile is
+carried scaled by S = 2^(kw + RBF_EXP) -- PD + PS and the type column enter it times S, LayerNorm divides S out again.  All
+factors are powers of two: the only effect is that hi / lo never fall into the f16 subnormal range.
 """
 import numpy as np
 
@@ -44,6 +49,16 @@ def mfma_f16(a4, b4, c):
         B[4 * Q_ + j, C_] = b4[j].astype(np.float64)
     D = (A @ B).astype(np.float32)
     return np.stack([c[r] + D[4 * Q_ + r, C_] for r in range(4)])
+
+
+RBF_EXP, RBF_KW_MAX = 12, 20
+
+
+def rbf_kw(Wr):
+    """pack_rbf_scale_kernel: exponent kw of a path's rbf tables (all four edge types share it)."""
+    mx = np.float32(np.abs(Wr).max())
+    E = (mx.view(np.uint32) >> 23) & 0xff
+    return int(max(-80, min(RBF_KW_MAX, 141 - int(E))))
 
 
 def split_f16(v):
@@ -138,9 +153,12 @@ class Weights:
         self.fragA_v = frag_wr_edge(self.Wr_v)
         self.fragB_v = frag_wr_chan(self.Wr_v)
         # split-f16 tuples (protein destinations): A operand edge-major (k; h2x v), B operand channel-major (x2h v)
-        self.frag16A_k = frag16(self.Wr_k, m_edge)
-        self.frag16A_v = frag16(self.Wr_v, m_edge)
-        self.frag16B_v = frag16(self.Wr_v, m_chan)
+        self.kw_k, self.kw_v = rbf_kw(self.Wr_k), rbf_kw(self.Wr_v)
+        self.S_k, self.S_v = np.float32(2.0 ** (self.kw_k + RBF_EXP)), np.float32(2.0 ** (self.kw_v + RBF_EXP))
+        up = lambda w, kw: np.ldexp(w, kw).astype(np.float32)
+        self.frag16A_k = frag16(up(self.Wr_k, self.kw_k), m_edge)
+        self.frag16A_v = frag16(up(self.Wr_v, self.kw_v), m_edge)
+        self.frag16B_v = frag16(up(self.Wr_v, self.kw_v), m_chan)
 
     def node_tables(self, h, lig):
         """What the node kernels produce: P = [PDk | PDv | PSk | PSv] and the folded query Qt.
@@ -168,8 +186,8 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
     lg0 = [lig[j].astype(bool) & v for j, v in zip(j0, valid0)]
     dist0 = [np.sqrt(((x[i] - x[j]) ** 2).sum(-1)).astype(np.float32) for j in j0]
     # R[hf][s][lane] = rbf_{4s+q}(d_e): B operand (edge-major MFMA) and A operand (channel-major MFMA)
-    R = [[np.where(valid0[hf], np.exp(-0.5 * (dist0[hf] - MU[4 * s + Q_]) ** 2), 0).astype(np.float32)
-          for s in range(5)] for hf in range(2)]
+    R = [[np.where(valid0[hf], np.exp(-0.5 * (dist0[hf] - MU[4 * s + Q_]) ** 2).astype(np.float32) * np.float32(2 ** RBF_EXP), 0)
+          .astype(np.float32) for s in range(5)] for hf in range(2)]     # times 2^RBF_EXP: the validity factor is 0 / 2^RBF_EXP
     mask_lig = 0
     for hf in range(2):
         for c in range(16):
@@ -188,28 +206,30 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
     def rbf_masked(hf, src_lig):
         return [np.where(lg0[hf] == src_lig, R[hf][s], 0).astype(np.float32) for s in range(5)]
 
-    def pre_edge_major(PD, PS, Wt, frag, frag16_):
-        """C[t][hf][r][lane]: lane (c = e16, q), m = 32q + 4t + r (edge-major); the rbf term in split-f16 MFMAs."""
+    def pre_edge_major(PD, PS, Wt, frag, frag16_, S):
+        """C[t][hf][r][lane]: lane (c = e16, q), m = 32q + 4t + r (edge-major); the rbf term in split-f16 MFMAs.
+        The tile is carried scaled by S."""
         Cacc = np.zeros((8, 2, 4, 64), np.float32)
         for t in range(8):
             for hf in range(2):
                 dWt = Wt[etype(True)] - Wt[etype(False)]
                 for r in range(4):
                     m = m_edge(t, 4 * Q_ + r)
-                    Cacc[t, hf, r] = PD[i, m] + PS[j0[hf], m] + np.where(lg0[hf], dWt[m], 0)
+                    Cacc[t, hf, r] = (PS[j0[hf], m] * S + PD[i, m] * S) + np.where(lg0[hf], dWt[m] * S, 0)
                 for src_lig in passes:
                     T, Bt = frag16_[etype(src_lig), t], rbf_tuples(rbf_masked(hf, src_lig))
                     for tu, b in ((0, 0), (0, 1), (1, 2), (2, 3)):
                         Cacc[t, hf] = mfma_f16(T[tu], Bt[b], Cacc[t, hf])
         return Cacc
 
-    def ln_edge_major(Cacc, gamma, beta):
+    def ln_edge_major(Cacc, gamma, beta, S):
+        c1, c2 = np.float32(1.0) / (np.float32(128) * S * S), np.float32(1.0) / S
         out = np.zeros_like(Cacc)
         for hf in range(2):
             dv = Cacc[:, hf]                                 # zero mean by construction (centred weights)
             v = (dv * dv).sum((0, 1))                        # in-lane over (t, r), then across q
             v = v + v[L ^ 16]; v = v + v[L ^ 32]
-            rstd = 1.0 / np.sqrt(v / 128 + 1e-5)
+            rstd = (1.0 / np.sqrt(v * c1 + 1e-5)) * c2
             for t in range(8):
                 for r in range(4):
                     m = m_edge(t, 4 * Q_ + r)
@@ -226,7 +246,7 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
         return out
 
     # ---- k path (edge-major) -----------------------------------------------------------------------
-    Hk = ln_edge_major(pre_edge_major(PDk, PSk, W.Wt_k, W.fragA_k, W.frag16A_k), W.g_k, W.be_k)
+    Hk = ln_edge_major(pre_edge_major(PDk, PSk, W.Wt_k, W.fragA_k, W.frag16A_k, W.S_k), W.g_k, W.be_k, W.S_k)
     S = contract_channels(Hk, Qt[i])                           # scores: lane (a, q) reg r <-> e = 4q + r + 16hf
     e1 = np.stack([[4 * Q_ + r + 16 * hf for r in range(4)] for hf in range(2)])   # [2][4][64]
     valid1 = e1 < d
@@ -249,7 +269,7 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
             for hf in range(2):
                 dWt = W.Wt_v[etype(True)] - W.Wt_v[etype(False)]
                 for r in range(4):
-                    Cv[t, hf, r] = PDv[i, m] + PSv[j1[hf, r], m] + np.where(lg1[hf, r], dWt[m], 0)
+                    Cv[t, hf, r] = (PSv[j1[hf, r], m] * W.S_v + PDv[i, m] * W.S_v) + np.where(lg1[hf, r], dWt[m] * W.S_v, 0)
                 for src_lig in passes:
                     # rbf tuples as the A operand, weight tuples as B
                     T, Bt = W.frag16B_v[etype(src_lig), t], rbf_tuples(rbf_masked(hf, src_lig))
@@ -262,7 +282,7 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
                 dv = Cv[:, hf, r]                             # zero mean by construction
                 v = (dv * dv).sum(0)
                 for o in (1, 2, 4, 8): v = v + v[L ^ o]
-                rstd = 1.0 / np.sqrt(v / 128 + 1e-5)
+                rstd = (1.0 / np.sqrt(v * (np.float32(1.0) / (np.float32(128) * W.S_v * W.S_v)) + 1e-5)) * (np.float32(1.0) / W.S_v)
                 for t in range(8):
                     m = m_chan(t, C_)
                     Hv[t, hf, r] = np.maximum(dv[t] * rstd * W.g_v[m] + W.be_v[m], 0)
@@ -290,7 +310,7 @@ def simulate_node(W, x2h, i, x, h, nbr, deg, lig, e_w, tables):
         out = out + W.bb_v * np.repeat(sw_head, 8)
         return h[i] + out
     # ---- h2x: v path edge-major as well; wv[e, a] = Wbv[a] . hid_v[e] + bbv[a] --------------------------
-    Hv = ln_edge_major(pre_edge_major(PDv, PSv, W.Wt_v, W.fragA_v, W.frag16A_v), W.g_v, W.be_v)
+    Hv = ln_edge_major(pre_edge_major(PDv, PSv, W.Wt_v, W.fragA_v, W.frag16A_v, W.S_v), W.g_v, W.be_v, W.S_v)
     WV = contract_channels(Hv, W.Wb_v) + W.bb_v[C_]
     j1 = np.where(valid1, nbr[i, np.minimum(e1, 31)], i)
     rel = x[i] - x[j1]                                           # [2][4][64][3]

@@ -18,7 +18,8 @@ from oracle import weights as W
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 RTOL, ATOL = 1e-4, 1e-5
-DENOISER_CASES = ["denoiser_2graphs", "denoiser_small_graphs", "denoiser_linker", "denoiser_eg5_pocket10"]
+DENOISER_CASES = ["denoiser_2graphs", "denoiser_small_graphs", "denoiser_linker", "denoiser_eg5_pocket10",
+                  "denoiser_adrb1_pocket10", "denoiser_drd2_pocket10", "denoiser_smarca2_pocket10"]
 
 
 def close(a, b, what, scale=1.0):

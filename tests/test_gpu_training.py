@@ -3,11 +3,13 @@ CPU oracle (which tests/test_oracle_golden.py pins to the reference's own loss.b
 
 Tolerances: gradients are sums of up to ~1e5 fp32 products with different association orders (and fp32 atomics for
 the neighbour rows), so each tensor is compared with rtol 2e-4 and an absolute floor of 2e-5 x its largest entry."""
+import contextlib
 import os
 
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import cbgbench_amd as C
 from cbgbench_amd import stages
@@ -20,28 +22,66 @@ DEV = "cuda:0"
 MLP_KEYS = ("net.0.weight", "net.0.bias", "net.1.weight", "net.1.bias", "net.3.weight", "net.3.bias")
 
 
-def gclose(a, b, what, rtol=2e-4, floor=2e-5):
-    """|a - b| <= floor * max|b| + rtol * |b| element-wise -- except for the footprint of ONE ReLU unit resolved to the other
-    side of zero ("pinning gradients": ~1e6 units per block on these fixtures, a GPU / CPU difference of ~1e-6 in
-    the LayerNorm output, so one unit in a few tests lands within it).  Such a flip changes the gradient that flows through
-    one (edge, unit) pair: in node-indexed tensors (grad_h, grad_x, grad_e_w) it touches at most the two nodes of that edge,
-    in a weight matrix it is a rank-one term, in a bias / LayerNorm vector it is one or two entries.  Exactly that footprint is
-    tolerated, bounded by 1 % of the largest reference entry; anything wider fails."""
+FLIP_EPS = 5e-6      # |LayerNorm output| below which a GPU / CPU rounding difference (~1e-6) can put a ReLU on the other side of 0
+FLIPS_USED = []      # (test id, mlp, row, unit) of every verified flip; test_relu_flip_exception_budget reads it
+
+
+@contextlib.contextmanager
+def relu_margins(force=None):
+    """While active, every MLP the CPU oracle evaluates records its pre-ReLU values within FLIP_EPS of zero as
+    ``{prefix: [(row, unit), ...]}``; ``force = {prefix: [(row, unit)]}`` evaluates those units on the OTHER side of zero (the value
+    moves by 2 |y| < 1e-5, the ReLU mask flips, the derivative with respect to everything upstream stays that of the formula).
+    This makes the ReLU-flip exception of the gradient checks VERIFIABLE: a deviation is accepted only if the oracle with ONE
+    identified near-zero unit flipped reproduces the GPU's gradients within the plain tolerance."""
+    near, orig, force = {}, OU.mlp, force or {}
+
+    def mlp(sd, prefix, z):
+        y = F.linear(z, sd[prefix + ".net.0.weight"], sd[prefix + ".net.0.bias"])
+        y = F.layer_norm(y, (y.shape[-1],), sd[prefix + ".net.1.weight"], sd[prefix + ".net.1.bias"], 1e-5)
+        idx = torch.nonzero(y.detach().abs() < FLIP_EPS)
+        if idx.numel():
+            near.setdefault(prefix, []).extend((int(r), int(u)) for r, u in idx.reshape(-1, y.dim())[:, [0, -1]].tolist())
+        if prefix in force:
+            delta = torch.zeros_like(y)
+            for r, u in force[prefix]:
+                delta[r, u] = -2.0 * float(y[r, u])
+            y = y + delta
+        return F.linear(F.relu(y), sd[prefix + ".net.3.weight"], sd[prefix + ".net.3.bias"])
+
+    OU.mlp = mlp
+    try:
+        yield near
+    finally:
+        OU.mlp = orig
+
+
+def gerr(a, b, what, rtol=2e-4, floor=2e-5):
+    """None if |a - b| <= floor * max|b| + rtol * |b| element-wise, else a message"""
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     err = (a - b).abs()
     tol = floor * max(float(b.abs().max()), 1e-12) + rtol * b.abs()
-    bad = err > tol
-    if not bool(bad.any()):
-        return
-    msg = f"{what}: max abs err {err.max():.3e}, |ref| max {b.abs().max():.3e}"
-    assert float(err.max()) <= 1e-2 * float(b.abs().max()), msg
-    if a.dim() == 1:
-        assert int(bad.sum()) <= 2, msg + f" ({int(bad.sum())} entries out of tolerance)"
-    elif int(bad.any(1).sum()) > 2 and int(bad.any(0).sum()) > 2:
-        u, sv, vt = torch.linalg.svd(a - b, full_matrices=False)
-        rest = ((a - b) - sv[0] * torch.outer(u[:, 0], vt[0])).abs()
-        assert bool((rest <= tol).all()), msg + " (not confined to two rows and not rank-one)"
-    print(f"ReLU-flip footprint tolerated in {what}: max abs err {err.max():.3e}, {int(bad.sum())} entries")
+    if bool((err <= tol).all()):
+        return None
+    return f"{what}: max abs err {err.max():.3e}, |ref| max {b.abs().max():.3e}, {int((err > tol).sum())} entries out of tolerance"
+
+
+def gclose(a, b, what, **kw):
+    msg = gerr(a, b, what, **kw)
+    assert msg is None, msg
+
+
+def accept_single_flip(near, failures, evaluate, restrict=None):
+    """`failures`: messages of the plain comparison.  Looks for ONE near-zero unit (from `near`, optionally only in the MLPs
+    `restrict`) whose flip makes `evaluate(force) -> list of messages` come back empty; asserts that one exists."""
+    cands = [(p, ru) for p, lst in sorted(near.items()) if restrict is None or p in restrict for ru in sorted(set(lst))]
+    assert cands, f"{failures} (and no pre-activation within {FLIP_EPS} of zero on this fixture)"
+    assert len(cands) <= 24, (len(cands), failures)
+    for prefix, ru in cands:
+        if not evaluate({prefix: [ru]}):
+            FLIPS_USED.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], prefix) + ru)
+            print(f"ReLU flip verified: {prefix} row {ru[0]} unit {ru[1]} explains {len(failures)} deviating tensor(s)")
+            return
+    raise AssertionError(f"{failures} (not explained by flipping any of the {len(cands)} near-zero units)")
 
 
 def load(golden_dir, name):
@@ -69,7 +109,7 @@ def edge_impl(request):
             yield request.param
 
 
-def _oracle_block(sd, g, layer, kind, seed):
+def _oracle_block(sd, g, layer, kind, seed, force=None):
     """autograd through one oracle attention block; returns inputs, upstream gradient and all gradients."""
     x = g["x"].clone().requires_grad_(True)
     h = (g["h"] if kind == "x2h" else g["h_layer0"]).clone().requires_grad_(True)
@@ -83,14 +123,15 @@ def _oracle_block(sd, g, layer, kind, seed):
     for k in keys:
         sd[k] = sd[k].clone().requires_grad_(True)
     gen = torch.Generator().manual_seed(seed)
-    if kind == "x2h":
-        out = OU.x2h_attention(sd, prefix, x, h, et, ei, e_w)
-        gout = torch.randn(out.shape, generator=gen)
-    else:
-        out = x + OU.h2x_attention(sd, prefix, x, h, et, ei, e_w) * g["gen_flag"].unsqueeze(-1).float()
-        gout = torch.randn(out.shape, generator=gen)
+    with relu_margins(force) as near:
+        if kind == "x2h":
+            out = OU.x2h_attention(sd, prefix, x, h, et, ei, e_w)
+            gout = torch.randn(out.shape, generator=gen)
+        else:
+            out = x + OU.h2x_attention(sd, prefix, x, h, et, ei, e_w) * g["gen_flag"].unsqueeze(-1).float()
+            gout = torch.randn(out.shape, generator=gen)
     out.backward(gout)
-    return h.detach(), gout, x.grad, h.grad, e_w.grad, [sd[k].grad for k in keys], keys, ei
+    return h.detach(), gout, x.grad, h.grad, e_w.grad, [sd[k].grad for k in keys], keys, ei, near
 
 
 @pytest.mark.parametrize("case,kind", [("denoiser_2graphs", "x2h"), ("denoiser_2graphs", "h2x"),
@@ -98,7 +139,7 @@ def _oracle_block(sd, g, layer, kind, seed):
                                        ("denoiser_small_graphs", "x2h"), ("denoiser_small_graphs", "h2x")])
 def test_attention_block_backward(golden_dir, synthetic_sd, model, case, kind, edge_impl):
     g = load(golden_dir, case)
-    h_in, gout, gx_ref, gh_ref, gew_ref, pg_ref, keys, ei = _oracle_block(synthetic_sd, g, 0, kind, seed=3)
+    h_in, gout, gx_ref, gh_ref, gew_ref, pg_ref, keys, ei, near = _oracle_block(synthetic_sd, g, 0, kind, seed=3)
     x = g["x"].to(DEV)
     gp = graph_ptr_from_batch(g["batch_idx"].to(DEV))
     lig = g["lig_flag"].to(DEV).to(torch.uint8)
@@ -114,32 +155,30 @@ def test_attention_block_backward(golden_dir, synthetic_sd, model, case, kind, e
                                                         gout.to(DEV))
     torch.cuda.synchronize()
     mask = (torch.arange(32, device=DEV)[None, :] < deg[:, None])
-    gclose(gh, gh_ref, f"{kind} grad_h")
-    gclose(gx, gx_ref, f"{kind} grad_x")
-    gclose(gew[mask], gew_ref.flatten(), f"{kind} grad_e_w")
-    for k, a, b in zip(keys, pg, pg_ref):
-        if k.endswith("k_func.net.3.bias"):
-            assert float(a.abs().max()) == 0.0    # exactly zero here, round-off noise in autograd
-            continue
-        gclose(a, b, k)
+    def compare(ref):
+        gx_r, gh_r, gew_r, pg_r = ref
+        msgs = [gerr(gh, gh_r, f"{kind} grad_h"), gerr(gx, gx_r, f"{kind} grad_x"), gerr(gew[mask], gew_r.flatten(), f"{kind} grad_e_w")]
+        for k, a, b in zip(keys, pg, pg_r):
+            if k.endswith("k_func.net.3.bias"):
+                assert float(a.abs().max()) == 0.0    # exactly zero here, round-off noise in autograd
+                continue
+            msgs.append(gerr(a, b, k))
+        return [m for m in msgs if m]
+
+    failures = compare((gx_ref, gh_ref, gew_ref, pg_ref))
+    if failures:      # accepted only if ONE identified near-zero ReLU unit, flipped in the oracle, reproduces the GPU's gradients
+        accept_single_flip(near, failures, lambda force: compare(_oracle_block(synthetic_sd, g, 0, kind, seed=3, force=force)[2:6]))
 
 
 def golden_batch(g, device):
     return {k[len("batch_"):]: v.to(device) for k, v in g.items() if k.startswith("batch_")}
 
 
-def check_golden_gradients(m, g, expected):
+def golden_failures(m, g, expected):
     """every parameter gradient of `m` against the reference's own `loss.backward()` recorded in a golden file: the norm of
     each tensor within 0.1 %, every stored entry (all of a small tensor, every 61st of a large one) within 0.1 % of its own
-    value + 0.1 % of the tensor's largest entry (fp32 cancellation).
-
-    One documented exception ("pinning gradients"): a ReLU whose pre-activation is within fp32 rounding of
-    zero is resolved to different sides by two equally valid evaluation orders; on these 3-graph cases one such (edge, unit)
-    pair moves the gradient of the MLP it sits in by up to ~3e-3 of a tensor's norm.  The tensors of AT MOST ONE MLP may
-    therefore miss the tolerance, by no more than 1 % -- and only if the deviation has the signature of a single unit: in
-    that MLP's first-Linear bias (128 entries, stored in full) at most two entries are out of tolerance.  Everything else
-    must pass as stated."""
-    n, loose = 0, {}
+    value + 0.1 % of the tensor's largest entry (fp32 cancellation).  Returns {mlp prefix or tensor name: [messages]}."""
+    n, bad = 0, {}
     for k, p in m.named_parameters():
         if not p.requires_grad:
             continue
@@ -156,19 +195,45 @@ def check_golden_gradients(m, g, expected):
         err = (sample.double() - ref).abs()
         scale = 1e-3 * ref.abs() + 1e-3 * float(ref.abs().max())
         worst = float((err / scale).max())
-        if (dn > 1e-3 or worst > 1.0) and ".net." in k:
-            loose.setdefault(k.rsplit(".net.", 1)[0], []).append((k, dn, worst, int((err > scale).sum())))
-            continue
-        assert dn <= 1e-3, (k, float(flat.double().norm()), ref_norm)
-        assert worst <= 1.0, f"{k}: max err {err.max():.3e} vs norm {ref_norm:.3e}"
+        if dn > 1e-3 or worst > 1.0:
+            bad.setdefault(k.rsplit(".net.", 1)[0] if ".net." in k else k, []).append(
+                f"{k}: norm off by {dn:.1e}, worst entry {worst:.1f} x tolerance")
     assert n == expected, n
-    assert len(loose) <= 1, f"more than one MLP out of tolerance: {loose}"
-    for mlp, rows in loose.items():
-        print(f"ReLU-flip exception used for {mlp}: " + "; ".join(f"{k.rsplit('.net.', 1)[1]} norm {dn:.1e} entries x{w:.1f} ({c} out)" for k, dn, w, c in rows))
-        for k, dn, w, c in rows:
-            assert dn <= 1e-2 and w <= 10.0, (k, dn, w)
-            if k.endswith(".net.0.bias"):
-                assert c <= 2, f"{k}: {c} entries out of tolerance -- not a single flipped unit"
+    return bad
+
+
+def oracle_failures(m, grads):
+    """all gradients of `m` against a full set of oracle gradients {key: tensor}, same tolerances as golden_failures"""
+    bad = []
+    for k, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        ref = grads[k].double().reshape(-1)
+        got = p.grad.detach().cpu().double().reshape(-1)
+        rn = float(ref.norm())
+        if rn < 1e-7:
+            continue
+        dn = abs(float(got.norm()) - rn) / rn
+        worst = float(((got - ref).abs() / (1e-3 * ref.abs() + 1e-3 * float(ref.abs().max()))).max())
+        if dn > 1e-3 or worst > 1.0:
+            bad.append(f"{k}: norm off by {dn:.1e}, worst entry {worst:.1f} x tolerance")
+    return bad
+
+
+def check_golden_gradients(m, g, expected, oracle_run):
+    """The gradients must match the reference's recorded ones (golden_failures).  One documented and VERIFIED exception
+    ("pinning gradients"): a ReLU whose pre-activation is within fp32 rounding of zero is resolved to different
+    sides by two equally valid evaluation orders, which moves the gradient of the MLP it sits in by up to ~3e-3 of a tensor's
+    norm.  If tensors of exactly ONE MLP deviate, `oracle_run(force) -> (near, grads)` (the CPU oracle's loss.backward() of the
+    same case, which tests/test_oracle_golden.py pins to the same golden file) is evaluated with ONE of that MLP's near-zero
+    units flipped, and ALL gradients must then agree with it within the plain tolerance.  Anything else fails."""
+    bad = golden_failures(m, g, expected)
+    if not bad:
+        return
+    assert len(bad) == 1 and ".net." in next(iter(bad.values()))[0], f"out of tolerance: {bad}"
+    mlp = next(iter(bad))
+    near, _ = oracle_run(None)
+    accept_single_flip(near, bad[mlp], lambda force: oracle_failures(m, oracle_run(force)[1]), restrict={mlp})
 
 
 @pytest.mark.parametrize("case", ["train_loss_denovo", "train_loss_t0_linker"])
@@ -188,7 +253,11 @@ def test_training_step_matches_reference_gradients(golden_dir, synthetic_sd, cas
     assert abs(float(loss_dict["atom"].detach()) - g["loss_atom"]) <= 2e-4 * abs(g["loss_atom"]) + 1e-7
     (1.0 * loss_dict["pos"] + 100.0 * loss_dict["atom"]).backward()
     torch.cuda.synchronize()
-    check_golden_gradients(m, g, 8 + 6 + 9 * 36 + 4)
+    def oracle_run(force):
+        with relu_margins(force) as near:
+            return near, TR.loss_and_grads(synthetic_sd, golden_batch(g, "cpu"), g["t"], g["eps"], g["u"], 13)[1]
+
+    check_golden_gradients(m, g, 8 + 6 + 9 * 36 + 4, oracle_run)
 
 
 def test_training_loss_decreases_with_adam(synthetic_sd):
@@ -259,7 +328,14 @@ def test_diffbp_training_step_matches_reference_gradients(golden_dir):
         assert abs(float(ld[k].detach()) - g["loss_" + k]) <= 2e-4 * abs(g["loss_" + k]) + 1e-6, (k, float(ld[k].detach()), g["loss_" + k])
     sum(ld.values()).backward()
     torch.cuda.synchronize()
-    check_golden_gradients(m, g, 8 + 6 + 9 * 36 + 4 + (6 + 3 * 18))
+    from oracle import diffbp as OBP
+
+    def oracle_run(force):
+        with relu_margins(force) as near:
+            return near, OBP.loss_and_grads(W.synthetic_state_dict_diffbp(13, 9, seed=0, num_timesteps=1000), golden_batch(g, "cpu"),
+                                            g["t"], g["eps"], g["u"], 13, 1000)[1]
+
+    check_golden_gradients(m, g, 8 + 6 + 9 * 36 + 4 + (6 + 3 * 18), oracle_run)
 
 
 @pytest.mark.parametrize("case", ["train_loss_diffsbdd", "train_loss_diffsbdd_t0"])
@@ -277,7 +353,14 @@ def test_diffsbdd_training_step_matches_reference_gradients(golden_dir, case):
         assert abs(float(ld[k].detach()) - g["loss_" + k]) <= 2e-4 * abs(g["loss_" + k]) + 1e-6, (k, float(ld[k].detach()), g["loss_" + k])
     sum(ld.values()).backward()
     torch.cuda.synchronize()
-    check_golden_gradients(m, g, 8 + 6 + 9 * 36 + 4)
+    from oracle import diffsbdd as OSB
+
+    def oracle_run(force):
+        with relu_margins(force) as near:
+            return near, OSB.loss_and_grads(W.synthetic_state_dict_diffsbdd(8, 9, seed=0, num_timesteps=1000), golden_batch(g, "cpu"),
+                                            g["t"], g["eps_x"], g["eps_c"], 8, 1000)[1]
+
+    check_golden_gradients(m, g, 8 + 6 + 9 * 36 + 4, oracle_run)
 
 
 def test_diffsbdd_eval_loss_matches_reference(golden_dir):
@@ -327,3 +410,50 @@ def test_second_backward_in_a_step_accumulates(synthetic_sd):
     want = single[0] + single[1]
     assert float(single[1].abs().max()) > 0
     assert torch.allclose(fg.flat, want, rtol=1e-4, atol=1e-6 * float(want.abs().max()))
+
+
+def test_flat_adam_trains_the_native_denoiser_on_fresh_weights(synthetic_sd):
+    """get_optimizer returns FlatAdam on device parameters, whose step() writes the flat buffer the parameters alias.  The packed
+    weights libcbgx consumes must follow (the pack cache was keyed on version counters that update never bumped, so
+    every step after the first ran on the weights of step 0): after each step the packed blob differs, the run equals a
+    torch.optim.Adam run of the same steps, and the loss falls."""
+    from cbgbench_amd import synthetic, train as TRN
+    from cbgbench_amd.config import Config as EasyDict
+    rng = np.random.default_rng(5)
+    pockets = [synthetic.make_pocket(rng, 80, radius=7.0) for _ in range(4)]
+    batch = synthetic.batch_to(synthetic.make_batch(pockets, [9, 11, 8, 10], rng, 13), DEV)
+    n_lig = batch["ligand_pos"].shape[0]
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    t = torch.tensor([100, 400, 700, 900], device=DEV)
+    noise = (torch.randn(n_lig, 3, device=DEV, generator=gen), torch.rand(n_lig, 13, device=DEV, generator=gen))
+    cfg = EasyDict(type="adam", lr=5e-4, weight_decay=0.0, beta1=0.95, beta2=0.999)
+    weights = {"pos": 1.0, "atom": 100.0}
+
+    def run(flat):
+        m = C.get_model(C.default_targetdiff_config(13))
+        m.load_state_dict(synthetic_sd, strict=True)
+        m = m.to(DEV).train()
+        opt = TRN.get_optimizer(cfg, m) if flat else torch.optim.Adam(m.parameters(), lr=cfg.lr, betas=(cfg.beta1, cfg.beta2))
+        assert isinstance(opt, TRN.FlatAdam) == flat
+        fg = TRN.FlatGradients(m)
+        losses, packs = [], []
+        for _ in range(4):
+            packs.append(m.denoiser.packed_weights(torch.device(DEV)).clone())
+            loss, _, _, _ = TRN.train_step(m, batch, opt, fg, loss_weights=weights, max_grad_norm=8.0, t=t, noise=noise)
+            losses.append(float(loss))
+        return losses, packs, torch.cat([p.detach().reshape(-1) for p in m.parameters() if p.requires_grad]).clone()
+
+    lf, packs, wf = run(True)
+    for a, b in zip(packs[:-1], packs[1:]):
+        assert float((a - b).abs().max()) > 0, "the packed weights did not follow the optimiser step"
+    ls, _, ws = run(False)
+    assert lf[-1] < lf[0], lf
+    assert np.allclose(lf, ls, rtol=2e-3), (lf, ls)                      # same trajectory as the stock optimiser
+    assert float((wf - ws).abs().max()) <= 2e-4 * float(ws.abs().max())
+
+
+def test_relu_flip_exception_budget():
+    """runs last in this file: the ReLU-flip exception (gclose / check_golden_gradients) is for isolated units, so over the whole
+    file it may have been used by at most two tests (three kernel generations x six block cases + five full-model cases ran)"""
+    tests_ = {f[0] for f in FLIPS_USED}
+    assert len(tests_) <= 3, FLIPS_USED

@@ -132,7 +132,7 @@ def test_library_exports_every_declared_symbol():
     lib = _native.lib()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.cbgx_abi_version() == 1
+    assert lib.cbgx_abi_version() == 2
     # the product library carries no debug switch and none of the first-generation kernels; the test-only build has both
     import subprocess
     assert not hasattr(lib, "cbgx_debug_set_edge_kernel")
@@ -443,6 +443,55 @@ def test_flat_adam_is_adam_with_interchangeable_checkpoints():
         grads(c, k); grads(d, k); oc.step(); od.step()
     for p, q in zip(c.parameters(), d.parameters()):
         assert torch.allclose(p, q, rtol=0, atol=1e-7)
+
+
+def test_flat_adam_marks_parameters_modified_and_skips_missing_gradients():
+    """(a) every FlatAdam.step() bumps the parameters' version counters -- UniTransformer.packed_weights keys its cache on them, so
+    without the bump the native denoiser would keep training on the weights of step 0; (b) a parameter whose
+    .grad is None is skipped like torch.optim.Adam skips it; (c) a checkpoint without state for some parameter zeroes its moments."""
+    from cbgbench_amd import train as TRN
+
+    def make():
+        torch.manual_seed(3)
+        return torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 2))
+
+    def grads(net, k, skip=None):
+        g = torch.Generator().manual_seed(50 + k)
+        for i, p in enumerate(net.parameters()):
+            v = torch.randn(p.shape, generator=g)
+            p.grad = None if i == skip else v
+
+    a, b = make(), make()
+    kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0)
+    oa, ob = torch.optim.Adam(a.parameters(), **kw), TRN.FlatAdam(b.parameters(), **kw)
+    before = [p._version for p in b.parameters()]
+    ptrs = [p.data_ptr() for p in b.parameters()]
+    grads(a, 0); grads(b, 0); oa.step(); ob.step()
+    assert all(p._version > v for p, v in zip(b.parameters(), before)), "step() must bump the version counters"
+    assert [p.data_ptr() for p in b.parameters()] == ptrs
+    # parameter 1 (first bias) without a gradient for two steps
+    for k in (1, 2):
+        grads(a, k, skip=1); grads(b, k, skip=1); oa.step(); ob.step()
+    grads(a, 3); grads(b, 3); oa.step(); ob.step()
+    pa, pb = list(a.parameters()), list(b.parameters())
+    for i, (p, q) in enumerate(zip(pa, pb)):
+        if i != 1:      # stock Adam's private step counter of the skipped parameter lags by two: its bias correction differs
+            assert torch.allclose(p, q, rtol=0, atol=1e-7), i
+    sa = oa.state_dict()
+    assert torch.allclose(sa["state"][1]["exp_avg"], ob.state_dict()["state"][1]["exp_avg"], atol=1e-7)   # moments were skipped too
+    # (c) a checkpoint that lacks the state of parameter 2 -> its moments start from zero
+    sb = ob.state_dict()
+    del sb["state"][2]
+    c = make()
+    oc = TRN.FlatAdam(c.parameters(), **kw)
+    oc._m.fill_(9.0)
+    oc.load_state_dict(sb)
+    m2 = oc._m.split(oc._sizes)[2]
+    assert float(m2.abs().sum()) == 0.0 and float(oc._step) == 4.0
+    # differing step counters are refused, not silently merged
+    sa_bad = oa.state_dict()
+    with pytest.raises(ValueError):
+        TRN.FlatAdam(make().parameters(), **kw).load_state_dict(sa_bad)
 
 
 def test_sync_free_host_forms_equal_the_reference_forms():

@@ -11,7 +11,8 @@ from oracle import targetdiff as T
 from oracle import unitransformer as U
 from oracle import weights as W
 
-DENOISER_CASES = ["denoiser_2graphs", "denoiser_small_graphs", "denoiser_linker", "denoiser_eg5_pocket10"]
+DENOISER_CASES = ["denoiser_2graphs", "denoiser_small_graphs", "denoiser_linker", "denoiser_eg5_pocket10",
+                  "denoiser_adrb1_pocket10", "denoiser_drd2_pocket10", "denoiser_smarca2_pocket10"]
 
 
 def load(golden_dir, name):
