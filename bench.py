@@ -23,7 +23,15 @@ barrier + synchronize, the MAX over ranks is reported and `ranks_seen` comes fro
 
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` (dominant kernel =
 the fused x2h edge kernel, timed live with HIP events on its own stream via cbgx_profile_*) and
-`cpu_baseline` (the CPU oracle = port of the reference's PyTorch-CPU path, timed on this host).
+`cpu_baseline` (the CPU oracle = port of the reference's PyTorch-CPU path, timed on this host: one process at its best thread
+count, and `cores / threads` such processes side by side).
+
+At N = 1 the default run also measures a `secondary` block in the same process, a few seconds each, so that every BASELINE
+config is under the driver's eyes and not only in builder-side files (--no-secondary skips it): the linker batch of 256
+(configs[2]), the training step at 32 graphs per GPU with its own roofline (configs[4] shape), the diffbp and diffsbdd samplers,
+the reference's own 10-graph batch (sample.py:177-183) and a single graph, and ONE END-TO-END run of
+`cbgbench_amd.sample_cli` at T = 1000 on 20 pockets x 10 samples (wall time including prior construction, the static-context
+cache, the trajectory download and the per-pocket result files), with its ratio to the step-sampled headline number.
 """
 import argparse
 import ctypes
@@ -69,6 +77,11 @@ def measured_traffic(n_nodes):
     with open(path) as f:
         t = json.load(f)
     return int(round((t["fetch_bytes_per_node"] + t["write_bytes_per_node"]) * n_nodes))
+
+
+TRAFFIC_SOURCE = ("NOT measured in this run: per-node bytes from profiles/traffic_x2h.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE "
+                  "in separate passes of this command, corrected as MI355X_MICROARCH.md prescribes; scripts/gpu_pmc_traffic.sh) x the "
+                  "nodes of this launch")
 
 
 def build_batch(pockets, samples, seed, num_classes=13):
@@ -124,12 +137,13 @@ def _pick_cpu_threads(sd, seed):
     return best_t
 
 
-def cpu_baseline(sd, seed, max_seconds=20.0, model="targetdiff"):
+def cpu_baseline(sd, seed, max_seconds=20.0, model="targetdiff", threads=None):
     """The CPU oracle (oracle/{targetdiff,diffbp,diffsbdd}.py: ports of the reference's PyTorch-CPU step, reference
     formulation with materialised [E,340] edge inputs) on this host's cores, on a bounded sample of the same workload:
     whole steps of one 10-graph batch (1 pocket x 10 samples) until ~max_seconds."""
     from oracle import targetdiff as OT
-    threads = _pick_cpu_threads(sd if model == "targetdiff" else oracle_state_dict(), seed)
+    if threads is None:
+        threads = _pick_cpu_threads(sd if model == "targetdiff" else oracle_state_dict(), seed)
     torch.set_num_threads(threads)
     C_ = 8 if model == "diffsbdd" else 13
     batch = build_batch(1, 10, seed, num_classes=C_)
@@ -177,6 +191,40 @@ def cpu_baseline(sd, seed, max_seconds=20.0, model="targetdiff"):
             f"(best of 4..64 on this {os.cpu_count()}-core host), {el:.1f} s"}
 
 
+def cpu_worker(argv):
+    """`bench.py --cpu-worker THREADS SECONDS MODEL`: one process of the concurrent CPU leg; prints its graph-steps/s."""
+    threads, seconds, model = int(argv[0]), float(argv[1]), argv[2]
+    from oracle import weights as OW
+    osd = {"targetdiff": lambda: oracle_state_dict(), "diffbp": lambda: OW.synthetic_state_dict_diffbp(13, 9, seed=0, num_timesteps=1000),
+           "diffsbdd": lambda: OW.synthetic_state_dict_diffsbdd(8, 9, seed=0, num_timesteps=1000)}[model]()
+    r = cpu_baseline(osd, seed=1000, max_seconds=seconds, model=model, threads=threads)
+    print(json.dumps({"value": r["value"]}), flush=True)
+
+
+def cpu_baseline_concurrent(threads, model="targetdiff", seconds=12.0):
+    """The same CPU step as cpu_baseline in `cores // threads` processes side by side (each on its own copy of the 10-graph
+    batch, `threads` threads): what this host's cores deliver when they are all used, the fair same-host figure next to one
+    GPU.  A single PyTorch-CPU process cannot use more than ~16 threads on this path (256 threads are > 30x slower)."""
+    import subprocess
+    ncpu = os.cpu_count() or 1
+    procs = max(1, ncpu // threads)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    t0 = time.perf_counter()
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(threads), str(seconds), model],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT) for _ in range(procs)]
+    vals = []
+    for p in ps:
+        try:
+            out, _ = p.communicate(timeout=seconds * 6 + 180)
+            vals.append(json.loads([l for l in out.splitlines() if l.startswith("{")][-1])["value"])
+        except Exception:      # a worker that failed or timed out contributes nothing (and is said so)
+            p.kill()
+    return {"value": round(float(sum(vals)), 4), "unit": "graph-steps/s", "processes": procs, "processes_reported": len(vals),
+            "threads_each": threads, "cores": procs * threads,
+            "sample": f"{procs} concurrent processes x {threads} threads, each the single-process sample above for ~{seconds:.0f} s "
+                      f"(sum of the per-process rates; {time.perf_counter() - t0:.0f} s wall incl. process start-up)"}
+
+
 # backward of the message-passing stage at the reference's tensor boundary (autograd of x2h_attention.py:80-97):
 # per edge read k, v (512 B each), e_w, index and write dk, dv (512 B each); per node read q, dL/dh_out and write dq, dL/dh
 X2H_BWD_BYTES_PER_EDGE = 4 * 512 + 4 + 4
@@ -208,19 +256,21 @@ def cpu_train_baseline(sd, seed, max_seconds=25.0):
 
 def bench_train(args, rank, world, dev):
     """BASELINE configs[4] shape on the GPUs at hand: train.py semantics (forward, backward, gradient all-reduce, clip,
-    Adam) with `--pockets` graphs per GPU per step (default 32)."""
+    Adam) with `--pockets` graphs per GPU per step (default 32).  `--model diffbp|diffsbdd` trains those classes."""
     from cbgbench_amd import train as TRN
-    model = make_model(dev)
+    model = make_model(dev, name=args.model)
     model.train()
     TRN.broadcast_parameters(model)
     fg = TRN.FlatGradients(model)
     # configs/denovo/train/targetdiff.yml:42-47 through the product's own factory (train.get_optimizer: FlatAdam on device parameters)
     import types
     opt = TRN.get_optimizer(types.SimpleNamespace(type="adam", lr=5e-4, weight_decay=0.0, beta1=0.95, beta2=0.999), model)
-    weights = {"pos": 1.0, "atom": 100.0}
+    # loss weights of configs/denovo/train/{targetdiff,diffbp,diffsbdd}.yml
+    weights = {"targetdiff": {"pos": 1.0, "atom": 100.0}, "diffbp": None, "diffsbdd": None}[args.model]
     n_graphs = args.pockets
-    batch = synthetic.batch_to(build_batch(n_graphs, 1, seed=3000 + rank), dev)
+    batch = synthetic.batch_to(build_batch(n_graphs, 1, seed=3000 + rank, num_classes=model.num_classes), dev)
     batch["num_graphs"] = n_graphs      # what train_cli's collate records: the model then needs no device round trip for it
+    batch["max_ligand_atoms"] = int(torch.bincount(batch["ligand_element_batch"]).max())     # (host-side knowledge of the collate too)
     N = batch["protein_pos"].shape[0] + batch["ligand_pos"].shape[0]
     torch.manual_seed(2022 + rank)
     t_ar = 0.0
@@ -242,9 +292,9 @@ def bench_train(args, rank, world, dev):
         "value": round(units / el_max, 2), "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * el_max / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs/denovo targetdiff training (BASELINE configs[4] shape): {n_graphs} graphs per GPU "
-                               f"per step, N_rec~U[350,650], N_lig~U[10,45], symmetric time sampler, loss weights pos 1 / "
-                               f"atom 100, Adam lr 5e-4, clip 8.0, one flat-buffer gradient all-reduce "
+        "config": {"workload": f"configs/denovo {args.model} training (BASELINE configs[4] shape): {n_graphs} graphs per GPU "
+                               f"per step, N_rec~U[350,650], N_lig~U[10,45], the config's time sampler and loss weights, "
+                               f"Adam lr 5e-4, clip 8.0, one flat-buffer gradient all-reduce "
                                f"({fg.flat.numel()} fp32) per step",
                    "graphs_per_batch_per_gpu": n_graphs, "nodes_per_batch": N, "sharding": f"data-parallel x{world} ranks", "ranks_seen": seen,
                    "allreduce_ms_per_step": round(1e3 * t_ar / max(args.steps, 1), 4)},
@@ -273,13 +323,9 @@ def bench_train(args, rank, world, dev):
                     "(2056 B/edge + 2048 B/node); the kernel recomputes the per-edge forward instead of reading it",
             "per_kernel": per,
         }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "targetdiff":
         out["cpu_baseline"] = cpu_train_baseline(oracle_state_dict(), seed=3000)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        sharding.barrier()      # rank 0 may still be in its (untimed) roofline pass: leave together
-        torch.distributed.destroy_process_group()
+    return out
 
 
 T_BLOCKS = (999, 749, 499, 249, 24)     # first t of each time block; bench step i runs t = block - i (last block: i mod 25)
@@ -318,7 +364,27 @@ def ranks_seen(dev):
     return int(one.item())
 
 
-def main():
+def device_identity(dev):
+    """something that names the physical GPU behind `dev` (uuid where torch exposes it, else the PCI address)"""
+    pr = torch.cuda.get_device_properties(dev)
+    for attr in ("uuid", "pci_bus_id"):
+        v = getattr(pr, attr, None)
+        if v is not None:
+            return f"{attr}:{v}" + (f":{getattr(pr, 'pci_device_id', '')}:{getattr(pr, 'pci_domain_id', '')}" if attr == "pci_bus_id" else "")
+    return f"index:{dev.index}"
+
+
+def distinct_devices(dev, world):
+    """number of distinct physical GPUs over all ranks (all-gather of device_identity)"""
+    import torch.distributed as dist
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        return 1
+    ids = [None] * world
+    dist.all_gather_object(ids, device_identity(dev))
+    return len(set(ids))
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -333,16 +399,23 @@ def main():
                          "graph each, fixed context atoms + a few generated linker atoms (partial gen_flag); train = "
                          "configs[4] shape: forward + backward + all-reduce + Adam on --pockets graphs per GPU")
     ap.add_argument("--model", choices=["targetdiff", "diffbp", "diffsbdd"], default="targetdiff",
-                    help="sampler timed on the denovo / linker workloads (default: targetdiff, the driver line). diffbp adds the "
-                         "CoMPredictor H2X stack + score / mask-type step per step, diffsbdd the zero-COM variational step "
-                         "(its pocket moves every step: no static-context cache)")
+                    help="model class timed (default: targetdiff, the driver line). Sampling: diffbp adds the CoMPredictor H2X "
+                         "stack + score / mask-type step per step, diffsbdd the zero-COM variational step (its pocket moves "
+                         "every step: no static-context cache); --workload train trains the class")
     ap.add_argument("--graph", choices=["on", "off"], default="off",
                     help="replay one captured hipGraph per denoising step instead of stream launches (single batch only; no "
                          "gain measured: small batches are bound by the dependent-kernel chain on the device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary block (other configs measured in the same run; N = 1, default workload only)")
+    return ap.parse_args(argv)
 
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker(sys.argv[2:])
+    args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
     if sharding.env_rank_world()[1] != args.gpus:
@@ -351,17 +424,43 @@ def main():
     rank, world, local = sharding.init_process_group()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
+    gloo_shared = os.environ.get("CBGX_DIST_BACKEND") == "gloo"
     # one process per GPU; LOCAL_RANK -> device.  Only with CBGX_DIST_BACKEND=gloo may ranks share a device (the
     # multi-rank path exercised on a 1-GPU box); RCCL needs one GPU per rank.
-    if local >= torch.cuda.device_count() and os.environ.get("CBGX_DIST_BACKEND") != "gloo":
+    if local >= torch.cuda.device_count() and not gloo_shared:
         raise SystemExit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local}, {torch.cuda.device_count()} visible)")
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:      # the host-side job construction of N ranks shares the host's cores
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+    # n_gpus must mean physical GPUs: every rank names its device, and a launch whose ranks share GPUs is refused -- unless it is
+    # the declared gloo dry run of the multi-rank path on one GPU, which then reports the devices it really used next to `ranks`
+    n_dev = distinct_devices(dev, world)
+    if n_dev != world and not gloo_shared:
+        raise SystemExit(f"bench.py: {world} ranks on {n_dev} distinct GPU(s); one GPU per rank is required "
+                         f"(CBGX_DIST_BACKEND=gloo declares a shared-GPU dry run)")
     if args.pockets is None:
         args.pockets = {"train": 32, "linker": 256}.get(args.workload, 100)
-    if args.workload == "train":
-        return bench_train(args, rank, world, dev)
+    primary_default = (args.workload == "denovo" and args.model == "targetdiff" and args.pockets == 100 and args.samples == 10
+                       and args.graphs_per_batch == 200 and args.graph == "off")
+    out = bench_train(args, rank, world, dev) if args.workload == "train" else bench_sampling(args, rank, world, dev)
+    out["n_gpus"] = n_dev
+    if n_dev != world:
+        out["ranks"] = world
+        out["config"]["note_shared_gpus"] = f"{world} ranks shared {n_dev} GPU(s) over gloo: a dry run of the multi-rank path, not a scaling point"
+    if rank == 0 and world == 1 and primary_default and not args.no_secondary:
+        out["secondary"] = secondary_block(args, dev, out)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        sharding.barrier()      # rank 0 may still be in its (untimed) roofline pass: leave together
+        torch.distributed.destroy_process_group()
+
+
+def bench_sampling(args, rank, world, dev):
+    """the sampling line: `--pockets` x `--samples` graphs per GPU resident as whole-pocket batches, one bench step = one
+    reverse-diffusion step of the whole job at each of the five time blocks.  Returns the JSON line as a dict."""
     model = make_model(dev, name=args.model)
     T = model.num_diffusion_timesteps
     num_classes = model.num_classes
@@ -467,7 +566,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "kernel": "cbgx::edge_mfma_kernel<x2h> (fused x2h edge kernel)", "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": measured_traffic(Nb),
+            "traffic": measured_traffic(Nb), "traffic_source": TRAFFIC_SOURCE,
             "nodes_per_launch": Nb, "algorithmic_bytes_per_launch": x2h_bytes, "avg_launch_us": round(1e6 * x2h_s, 3),
             "note": "algorithmic bytes = SURVEY.md 8d message-passing stage at the reference tensor boundary "
                     "(1032 B/edge + 1536 B/node) x edges/nodes per launch; the kernel is fused (edge MLP + "
@@ -496,11 +595,96 @@ def main():
         osd = {"targetdiff": oracle_state_dict, "diffbp": lambda: OW.synthetic_state_dict_diffbp(13, 9, seed=0, num_timesteps=T),
                "diffsbdd": lambda: OW.synthetic_state_dict_diffsbdd(8, 9, seed=0, num_timesteps=T)}[args.model]()
         out["cpu_baseline"] = cpu_baseline(osd, seed=1000, model=args.model)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        sharding.barrier()      # rank 0 may still be in its (untimed) roofline pass: leave together
-        torch.distributed.destroy_process_group()
+        out["cpu_baseline"]["all_cores"] = cpu_baseline_concurrent(out["cpu_baseline"]["cores"], model=args.model)
+    del states, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def _row(out, keep=()):
+    """the fields of a full line that a secondary row keeps"""
+    r = {"value": out["value"], "unit": out["unit"], "ms_per_step": out["ms_per_step"], "steps": out["steps"], "warmup": out["warmup"],
+         "workload": out["config"]["workload"]}
+    if "roofline" in out:
+        rf = out["roofline"]
+        r["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us") if k in rf}
+        r["roofline"]["per_kernel_us_avg"] = {k: v["us_avg"] for k, v in rf["per_kernel"].items() if v["launches"]}
+        if "launches_per_denoising_step" in rf:
+            r["launches_per_denoising_step"] = rf["launches_per_denoising_step"]
+    for k in keep:
+        r[k] = out["config"][k]
+    return r
+
+
+def sample_cli_end_to_end(dev, pockets=20, samples=10):
+    """ONE run of the sampling driver (cbgbench_amd/sample_cli.py = the role of the reference's sample.py:159-230) at the full
+    T = 1000: synthetic pockets -> priors -> one 200-graph batch -> model.sample (static-context cache, 1000 steps, the 1001-entry
+    trajectory kept on the device and downloaded once) -> one result file per pocket.  Wall time of everything after the model
+    is built."""
+    import shutil
+    import tempfile
+    from cbgbench_amd import sample_cli
+    cfg = os.path.join(ROOT, "tests", "fixtures", "targetdiff_test.yml")      # the reference's config schema, T = 1000
+    tmp = tempfile.mkdtemp(prefix="cbgx_bench_")
+    try:
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        stats = {}
+        rc = sample_cli.main(["--config", cfg, "--out_root", tmp, "--synthetic", str(pockets), "--num_samples", str(samples),
+                              "--pockets_per_batch", str(pockets), "--random_init"], stats=stats)
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        files = sorted(os.listdir(os.path.join(tmp, "targetdiff_test")))
+        nbytes = sum(os.path.getsize(os.path.join(tmp, "targetdiff_test", f)) for f in files)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    assert rc == 0 and len(files) == pockets, (rc, files)
+    gs = pockets * samples * 1000
+    return {"value": round(gs / wall, 2), "unit": "graph-steps/s", "wall_s": round(wall, 3), "graphs": pockets * samples,
+            "denoising_steps": 1000, "result_files": len(files), "result_bytes": nbytes,
+            "phases_s": {k: round(v, 3) for k, v in stats.items()},
+            "workload": f"python -m cbgbench_amd.sample_cli --config tests/fixtures/targetdiff_test.yml --synthetic {pockets} "
+                        f"--num_samples {samples} --pockets_per_batch {pockets} --random_init: one {pockets * samples}-graph "
+                        f"batch, all 1000 reverse-diffusion steps, wall time from config load to the last result file (model "
+                        f"construction + weight init + first-call library load included)"}
+
+
+def secondary_block(args, dev, primary):
+    """Other BASELINE configs measured in the same process as the headline (rank 0, N = 1): a few seconds each."""
+    ns = lambda **kw: argparse.Namespace(**{**vars(args), "no_cpu_baseline": True, "no_secondary": True, **kw})
+    sec = {}
+    t_all = time.perf_counter()
+
+    def guarded(name, fn):
+        t0 = time.perf_counter()
+        try:
+            sec[name] = fn()
+        except Exception as e:      # a failing secondary row must not take the headline line with it
+            sec[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        sec[name]["measured_in_s"] = round(time.perf_counter() - t0, 2)
+        torch.cuda.empty_cache()
+
+    guarded("linker_256_graphs", lambda: _row(bench_sampling(ns(workload="linker", pockets=256, samples=1, graphs_per_batch=256,
+                                                                  steps=4, warmup=2), 0, 1, dev), keep=("nodes_per_gpu",)))
+    guarded("train_32_graphs", lambda: _row(bench_train(ns(workload="train", pockets=32, steps=10, warmup=3), 0, 1, dev),
+                                            keep=("nodes_per_batch",)))
+    for m in ("diffbp", "diffsbdd"):
+        guarded(f"{m}_200_graphs", lambda m=m: _row(bench_sampling(ns(model=m, pockets=20, samples=10, graphs_per_batch=200, steps=3,
+                                                                      warmup=1), 0, 1, dev), keep=("nodes_per_gpu",)))
+        guarded(f"train_{m}_32_graphs", lambda m=m: _row(bench_train(ns(workload="train", model=m, pockets=32, steps=6, warmup=2,
+                                                                        no_roofline=True), 0, 1, dev), keep=("nodes_per_batch",)))
+    guarded("denovo_10_graphs", lambda: _row(bench_sampling(ns(pockets=1, samples=10, graphs_per_batch=10, steps=20, warmup=5), 0, 1, dev),
+                                             keep=("nodes_per_gpu",)))
+    guarded("denovo_1_graph", lambda: _row(bench_sampling(ns(pockets=1, samples=1, graphs_per_batch=1, steps=20, warmup=5), 0, 1, dev),
+                                           keep=("nodes_per_gpu",)))
+
+    def e2e():
+        r = sample_cli_end_to_end(dev)
+        r["ratio_to_step_sampled_headline"] = round(r["value"] / primary["value"], 4)
+        return r
+    guarded("sample_cli_T1000_200_graphs", e2e)
+    sec["total_s"] = round(time.perf_counter() - t_all, 2)
+    return sec
 
 
 if __name__ == "__main__":

@@ -15,7 +15,7 @@ from torch import nn
 
 from . import _native
 from .registry import get_e3_gnn, register_model
-from .targetdiff import NUM_AA, CTNVPScheduler, PLContextEmbedder, TargetDiff, scatter_mean
+from .targetdiff import NUM_AA, CTNVPScheduler, PLContextEmbedder, TargetDiff, masked_graph_mean, scatter_mean
 from .unitransformer import GaussianSmearing, H2XAttention, MLP, _MLP_KEYS
 
 ABSORBING_STATE = 0   # repo/utils/molecule/constants.py:8
@@ -48,9 +48,9 @@ class MaskTypeSchedule(nn.Module):
             c_pred = F.softmax(c_pred, dim=-1)
         loss_v = F.cross_entropy(c_pred, v0, reduction="none")
         info = {"v0": v0, "vt": vt, "c_pred": c_pred, "mask_gen": gen_flag}
-        if not bool(gen_flag.any()):
-            return torch.zeros_like(v0).float().mean(), info
-        return scatter_mean(loss_v[gen_flag], batch_idx[gen_flag]).mean(), info
+        # scatter_mean(loss_v[gen_flag], batch_idx[gen_flag]).mean(), zero when nothing is generated -- without the host
+        # synchronisations of the boolean indexing / the empty check (targetdiff.masked_graph_mean gives 0 for an empty mask)
+        return masked_graph_mean(loss_v, batch_idx, gen_flag, int(t.shape[0])), info
 
     def backward_remove_noise(self, c_pred, ct, t, batch_idx, gen_flag, pred_logit=True, fix_pred=True, uniform=None):
         """Unmask with probability (T - t) / T: masked, generated atoms take the predicted argmax (:475-496)."""
@@ -171,8 +171,9 @@ class CoMPredictor(nn.Module):
             arr = (ctypes.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
             _native.check(lib.cbgx_pack_h2x_stack(arr, len(srcs), self.num_layers, _native.ptr(packed),
                                                   _native.current_stream(device)), "cbgx_pack_h2x_stack")
-            torch.cuda.current_stream(device).synchronize()
-            self._packed, self._packed_key = packed, key
+            # no host synchronisation: the pack kernels run on torch's current stream and `srcs` stays referenced until the next
+            # repack (the weights change every training step; a synchronize() here stalled the host once per step)
+            self._packed, self._packed_key, self._packed_srcs = packed, key, srcs
         return self._packed
 
     @torch.no_grad()
@@ -193,8 +194,10 @@ class CoMPredictor(nn.Module):
         return x_out
 
     def forward(self, x_lig_pred, batch_idx_lig, x_composed, h_composed, gen_flag_composed, lig_flag_composed,
-                batch_idx_composed, graph_ptr=None, n_graphs=None):
-        """-> (zero-COM noise prediction [N_lig,3], per-graph mean shift of the ligand [N_lig,3]) (diffbp.py:79-101)."""
+                batch_idx_composed, graph_ptr=None, n_graphs=None, lig_rows=None):
+        """-> (zero-COM noise prediction [N_lig,3], per-graph mean shift of the ligand [N_lig,3]) (diffbp.py:79-101).
+        ``lig_rows`` (optional): the composed rows of the ligand atoms in ligand order (TargetDiff.compose_plan) -- the same rows
+        ``x_composed[lig_flag_composed]`` selects, without the host synchronisation of boolean indexing."""
         if not x_composed.is_cuda:
             raise RuntimeError("CoMPredictor.forward runs on an MI355X through libcbgx (no CPU fallback exists)")
         from .unitransformer import graph_ptr_from_batch
@@ -204,7 +207,8 @@ class CoMPredictor(nn.Module):
             graph_ptr = graph_ptr_from_batch(batch_idx_composed)
         B = graph_ptr.numel() - 1
         N = x_composed.shape[0]
-        noise = x_lig_pred - x_composed[lig_flag_composed]
+        pick = (lambda v: v[lig_rows]) if lig_rows is not None else (lambda v: v[lig_flag_composed])
+        noise = x_lig_pred - pick(x_composed)
         noise = noise - _S.scatter_mean(noise, batch_idx_lig, B)[batch_idx_lig]
         lib = _native.lib()
         need = lib.cbgx_workspace_bytes(N, B)
@@ -215,11 +219,11 @@ class CoMPredictor(nn.Module):
             x_out = _H2XStackFunction.apply(self, x_in, h_composed.float().contiguous(), graph_ptr,
                                             lig_flag_composed.to(torch.uint8).contiguous(),
                                             gen_flag_composed.to(torch.uint8).contiguous(), *self._ordered_params())
-            delta = (x_out - x_in)[lig_flag_composed]
+            delta = pick(x_out - x_in)
             return noise, _S.scatter_mean(delta, batch_idx_lig, B)[batch_idx_lig]
         x_out = self.stack_forward(x_in, h_composed.detach().float().contiguous(), graph_ptr,
                                    lig_flag_composed.to(torch.uint8).contiguous(), gen_flag_composed.to(torch.uint8).contiguous())
-        delta = (x_out - x_in)[lig_flag_composed]
+        delta = pick(x_out - x_in)
         shift = _S.scatter_mean(delta, batch_idx_lig, B)[batch_idx_lig]
         return noise, shift
 
@@ -257,7 +261,9 @@ class DiffBP(nn.Module):
         """``loss_dict, results = model(batch)``: {'pos', 'atom', 'com', 'inter'} (all weights 1 in
         configs/denovo/train/diffbp.yml:37-41).  ``t`` / ``noise=(eps [N_lig,3], u [N_lig])`` replay the draws in tests."""
         bl = batch["ligand_element_batch"]
-        B = int(bl.max().item()) + 1
+        # the graph count: from the batch if the collate recorded it (no host synchronisation in the training step), else as the
+        # reference computes it
+        B = int(batch["num_graphs"]) if "num_graphs" in batch else (int(t.shape[0]) if t is not None else int(bl.max().item()) + 1)
         dev = batch["ligand_pos"].device
         if self.training or t is not None:
             if t is None:
@@ -272,14 +278,17 @@ class DiffBP(nn.Module):
         return {k: torch.stack([d[k] for d in dicts]).mean() for k in dicts[0]}, results
 
     @staticmethod
-    def interior_loss(x_ligand, x_protein, batch_ligand, batch_protein, k=48, rho=2.0, gamma=5.0):
+    def interior_loss(x_ligand, x_protein, batch_ligand, batch_protein, k=48, rho=2.0, gamma=5.0, n_graphs=None,
+                      max_ligand_atoms=None):
         """diffbp.py:18-28: every protein atom looks at its k nearest ligand atoms of the same graph (all of them when the
-        ligand has at most k atoms); dense [N_rec, max ligand size] distances instead of torch_cluster.knn."""
+        ligand has at most k atoms); dense [N_rec, max ligand size] distances instead of torch_cluster.knn.
+        ``n_graphs`` / ``max_ligand_atoms`` (host integers the collate knows; any upper bound of the largest ligand works): without
+        them the two sizes are read back from the device, which stalls the host in the middle of a training step."""
         n_lig = x_ligand.shape[0]
-        B = int(max(batch_ligand.max(), batch_protein.max()).item()) + 1
-        counts = torch.bincount(batch_ligand, minlength=B)
+        B = int(n_graphs) if n_graphs is not None else int(max(batch_ligand.max(), batch_protein.max()).item()) + 1
+        counts = torch.zeros(B, dtype=torch.long, device=batch_ligand.device).index_add_(0, batch_ligand, torch.ones_like(batch_ligand))
         start = torch.cumsum(counts, 0) - counts
-        lmax = int(counts.max().item())
+        lmax = min(int(max_ligand_atoms), n_lig) if max_ligand_atoms is not None else int(counts.max().item())
         slot = torch.arange(lmax, device=x_ligand.device)[None, :]
         cnt_p = counts[batch_protein][:, None]
         valid = slot < cnt_p
@@ -314,13 +323,14 @@ class DiffBP(nn.Module):
         gen_flag = torch.cat([gen_r, gen_l], 0)[sort_idx]
         xo, ho, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
                                        graph_ptr=graph_ptr)
-        x_lig_pred, x_com_pred = self.com_head(xo[lig_rows], bl, x, ho, gen_flag, lig_flag, batch_idx, graph_ptr=graph_ptr)
+        x_lig_pred, x_com_pred = self.com_head(xo[lig_rows], bl, x, ho, gen_flag, lig_flag, batch_idx, graph_ptr=graph_ptr,
+                                               lig_rows=lig_rows)
         loss_pos, pos_info = self.pos_scheduler.get_score_loss(x_lig_pred, pos_noise, t, gen_l, bl, score_in=False)
         loss_com, com_info = self.pos_scheduler.get_score_loss(x_com_pred, com_noise, t, gen_l, bl, score_in=False,
                                                                info_tag="com")
         loss_atom, atom_info = self.type_scheduler.get_loss(logits[lig_rows], v0, c_t, t, type_flag, bl, pred_logit=True)
         xs = self.pos_scheduler.xs_mean(x_lig_pred + x_com_pred, x_t, t, bl, gen_flag=gen_l)
-        loss_inter = self.interior_loss(xs, x_rec, bl, br)
+        loss_inter = self.interior_loss(xs, x_rec, bl, br, n_graphs=int(t.shape[0]), max_ligand_atoms=batch.get("max_ligand_atoms", None))
         results = {}
         results.update(pos_info); results.update(atom_info); results.update(com_info)
         return {"pos": loss_pos, "atom": loss_atom, "com": loss_com, "inter": loss_inter}, results

@@ -88,6 +88,11 @@ class DiffsbddVariationalScheduler(nn.Module):
         return torch.where(gen_flag.unsqueeze(-1), c_noisy, c), noise
 
     @staticmethod
+    def graph_sizes(index, n):
+        """torch.bincount(index, minlength=n) for graph ids < n without its host synchronisation (bincount reads max(index))"""
+        return torch.zeros(n, dtype=torch.long, device=index.device).index_add_(0, index, torch.ones_like(index))
+
+    @staticmethod
     def sum_except_batch(x, index, n):
         return torch.zeros(n, dtype=x.dtype, device=x.device).index_add(0, index, x.sum(-1))
 
@@ -103,7 +108,7 @@ class DiffsbddVariationalScheduler(nn.Module):
         """training-mode loss (:886-900, 930-945): per graph  0.5 sum(err^2) [t != 0] / (n dim)  +  -log p(. | z_0) [t == 0]
         + KL prior;  mean over graphs.  Continuous reconstruction term for coordinates, discretised Gaussian for types."""
         bl = batch_idx
-        n = torch.bincount(bl, minlength=B)
+        n = self.graph_sizes(bl, B)
         err = self.sum_except_batch((tgt - pred) ** 2, bl, B)
         loss_t = 0.5 * err * (1.0 - t_is_zero) / (n * pred.shape[-1])
         if x_lig_0 is not None:
@@ -132,7 +137,7 @@ class DiffsbddVariationalScheduler(nn.Module):
         -log p(. | z_0) of a second network call on the t = 0 noising (``pred0``/``tgt0``; ``c_lig_t0`` the t = 0 noised
         types)  +  the Gaussian normalisation constant (which the reference also adds to the type term, dim = C)."""
         bl = batch_idx
-        n = torch.bincount(bl, minlength=B)
+        n = self.graph_sizes(bl, B)
         err = self.sum_except_batch((tgt - pred) ** 2, bl, B)
         g_s, g_t = self.gamma(s).view(B), self.gamma(t).view(B)
         loss_t = -self.num_timestep * 0.5 * (1.0 - torch.exp(-(g_s - g_t))) * err
@@ -203,7 +208,9 @@ class DiffSBDD(nn.Module):
         ``cfg.eval_interval`` (10) evenly spaced times, ``results`` a list with one entry per time; ``noise`` is then a
         list of (eps_x, eps_c, eps_x0, eps_c0) per time."""
         bl = batch["ligand_element_batch"]
-        B = int(bl.max().item()) + 1
+        # the graph count: from the batch if the collate recorded it (no host synchronisation in the training step), else as the
+        # reference computes it
+        B = int(batch["num_graphs"]) if "num_graphs" in batch else (int(t.shape[0]) if t is not None else int(bl.max().item()) + 1)
         dev = batch["ligand_pos"].device
         if self.training or t is not None:
             if t is None:

@@ -45,7 +45,20 @@ def split_samples(x, c, batch_idx, n_graphs, mode="add_aromatic"):
     return out
 
 
-def main(argv=None):
+def main(argv=None, stats=None):
+    """``stats`` (optional dict): filled with the wall seconds of the phases (setup = config + model + weights, batch = prior
+    construction, sample = model.sample incl. the trajectory download, write = per-pocket records and files)."""
+    t_phase = time.perf_counter()
+    phases = {"setup": 0.0, "batch": 0.0, "sample": 0.0, "write": 0.0}
+
+    def lap(name, dev=None):
+        nonlocal t_phase
+        if dev is not None and dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        now = time.perf_counter()
+        phases[name] += now - t_phase
+        t_phase = now
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", required=True)
     ap.add_argument("--out_root", default="./results")
@@ -114,12 +127,15 @@ def main(argv=None):
     os.makedirs(out_dir, exist_ok=True)
     torch.manual_seed(args.seed + rank)                 # independent noise streams per shard
     rng = np.random.default_rng([args.seed, rank])
+    lap("setup", dev)
     t0, graph_steps = time.perf_counter(), 0
     for b0 in range(0, len(mine), args.pockets_per_batch):
         ids = mine[b0:b0 + args.pockets_per_batch]
         batch = build_pocket_batch([pockets[i] for i in ids], num_samples, rng, config.model.num_atomtype, prior,
                                    device=dev, num_dist=num_dist)
+        lap("batch", dev)
         traj = model.sample(batch)
+        lap("sample", dev)
         # sample.py:198-201 hands traj[0] to the reconstruction -- for targetdiff / diffbp that is the state entering the
         # last step, not traj[-1]; kept as the default for drop-in outputs, --final_state selects traj[-1]
         x, c, bidx = traj[-1] if (args.final_state and config.model.type != "diffsbdd") else traj[0]
@@ -129,11 +145,14 @@ def main(argv=None):
             if args.save_traj:
                 rec["traj_keys"] = sorted(traj.keys())
             torch.save(rec, os.path.join(out_dir, f"pocket_{pid:05d}.pt"))
+        lap("write")
         graph_steps += len(ids) * num_samples * model.num_diffusion_timesteps
     if dev.type == "cuda":
         torch.cuda.synchronize()
     sharding.barrier()
     el, gs = sharding.reduce_max_sum(time.perf_counter() - t0, graph_steps, device=dev)
+    if stats is not None:
+        stats.update(phases)
     if rank == 0:
         print(f"sampled {len(pockets)} pockets x {num_samples} samples on {world} rank(s): "
               f"{gs / el:.1f} graph-steps/s, results in {out_dir}")

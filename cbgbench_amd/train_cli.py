@@ -80,6 +80,7 @@ class ComplexSet:
             b["ligand_gen_flag"] = self.ligand_gen_flag[lr]
         b = {k: v.to(device) for k, v in b.items()}
         b["num_graphs"] = int(ids.numel())       # known on the host: spares the model a device round trip per step
+        b["max_ligand_atoms"] = int((self.lig_ptr[ids + 1] - self.lig_ptr[ids]).max())     # DiffBP's interior loss sizes a tile with it
         return b
 
 

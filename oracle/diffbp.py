@@ -182,13 +182,14 @@ def get_loss(sd, batch, t, eps, u, num_classes, T_steps):
             "inter": interior_loss(xs, x_rec, bl, br)}
 
 
-def loss_and_grads(sd, batch, t, eps, u, num_classes, T_steps):
-    """sum of the four losses (configs/denovo/train/diffbp.yml:37-41, all weights 1) and its gradients"""
+def loss_and_grads(sd, batch, t, eps, u, num_classes, T_steps, weights=None):
+    """(weighted) sum of the four losses (configs/denovo/train/diffbp.yml:37-41: all weights 1, the default) and its gradients"""
     sd = {k: v.clone() for k, v in sd.items()}
     keys = [k for k in sd if "scheduler" not in k and not k.endswith(".offset")]
     for k in keys:
         sd[k].requires_grad_(True)
     losses = get_loss(sd, batch, t, eps, u, num_classes, T_steps)
-    sum(losses.values()).backward()
+    w = weights or {k: 1.0 for k in losses}
+    sum(w[k] * v for k, v in losses.items()).backward()
     grads = {k: (sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])) for k in keys}
     return {k: v.detach() for k, v in losses.items()}, grads

@@ -24,6 +24,8 @@ def _run(args, env=None, timeout=600):
 
 def test_bench_line_contract_small_job():
     out = _run(["--steps", "2", "--warmup", "1", "--pockets", "4", "--graphs-per-batch", "20", "--no-cpu-baseline"])
+    assert "secondary" not in out          # only the default (driver) workload carries the secondary block
+    assert "profiles/traffic_x2h.json" in out["roofline"]["traffic_source"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in out, k
@@ -41,12 +43,55 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     the whole-job aggregate.  gloo because both ranks share this box's single GPU."""
     out = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--pockets", "2", "--graphs-per-batch", "20",
                 "--no-cpu-baseline", "--no-roofline"], env={"CBGX_DIST_BACKEND": "gloo"})
-    assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == 2
+    # two ranks, ONE physical GPU: the line says so instead of claiming n_gpus = 2
+    assert out["n_gpus"] == 1 and out["ranks"] == 2 and out["config"]["ranks_seen"] == 2
     assert abs(out["value"] - 2 * 20 * 5 / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]
 
 
 def test_bench_train_two_ranks_on_one_gpu_gloo():
     out = _run(["--gpus", "2", "--workload", "train", "--steps", "2", "--warmup", "1", "--pockets", "4",
                 "--no-cpu-baseline", "--no-roofline"], env={"CBGX_DIST_BACKEND": "gloo"})
-    assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == 2
+    assert out["n_gpus"] == 1 and out["ranks"] == 2 and out["config"]["ranks_seen"] == 2
     assert out["config"]["allreduce_ms_per_step"] > 0
+
+
+def test_bench_refuses_shared_gpus_without_the_gloo_declaration():
+    """RCCL needs one GPU per rank: two ranks on this box's single GPU must be refused, not reported as n_gpus = 2"""
+    e = dict(os.environ)
+    e.pop("CBGX_DIST_BACKEND", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--pockets",
+                        "1", "--graphs-per-batch", "10", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True,
+                       env=e, timeout=600, cwd=ROOT)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("workload", ["denovo", "train"])
+def test_bench_eight_ranks_dry_run_gloo(workload):
+    """the driver's 8-GPU entry (`python bench.py --gpus 8 ...`) on the one GPU at hand, tiny job: eight ranks start, build their
+    own jobs, meet at the barriers, all take part in the reductions (and, training, in the gradient all-reduce)"""
+    args = ["--gpus", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
+    args += ["--pockets", "1", "--graphs-per-batch", "10"] if workload == "denovo" else ["--workload", "train", "--pockets", "2"]
+    out = _run(args, env={"CBGX_DIST_BACKEND": "gloo"}, timeout=900)
+    assert out["ranks"] == 8 and out["n_gpus"] == 1 and out["config"]["ranks_seen"] == 8
+    per_rank = 10 * 5 if workload == "denovo" else 2
+    assert abs(out["value"] - 8 * per_rank / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]
+
+
+def test_sample_cli_two_ranks_write_disjoint_pocket_files(tmp_path):
+    """sample.py:159's pocket loop sharded over two ranks (gloo, one GPU): every pocket is written exactly once, by the rank
+    that owns it (round-robin), and both ranks' files are complete"""
+    import torch
+    cfg = os.path.join(ROOT, "tests", "fixtures", "targetdiff_T20.yml")
+    e = dict(os.environ, CBGX_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), "-m", "cbgbench_amd.sample_cli", "--config", cfg, "--out_root",
+           str(tmp_path), "--synthetic", "5", "--pockets_per_batch", "2", "--random_init"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    files = sorted(os.listdir(tmp_path / "targetdiff_T20"))
+    assert files == [f"pocket_{i:05d}.pt" for i in range(5)]
+    for i, f in enumerate(files):
+        rec = torch.load(tmp_path / "targetdiff_T20" / f, weights_only=False)
+        assert rec["pocket_index"] == i and len(rec["samples"]) == 4
+    assert "on 2 rank(s)" in p.stdout

@@ -44,7 +44,7 @@ def relu_margins(force=None):
         if prefix in force:
             delta = torch.zeros_like(y)
             for r, u in force[prefix]:
-                delta[r, u] = -2.0 * float(y[r, u])
+                delta[r, u] = -2.0 * float(y[r, u].detach())
             y = y + delta
         return F.linear(F.relu(y), sd[prefix + ".net.3.weight"], sd[prefix + ".net.3.bias"])
 

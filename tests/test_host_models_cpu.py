@@ -131,8 +131,10 @@ class OracleComHead(torch.nn.Module):
         self.params = torch.nn.ParameterList([torch.nn.Parameter(sd[k].clone(), requires_grad=not k.endswith(".offset"))
                                               for k in self.keys])
 
-    def forward(self, x_lig_pred, batch_idx_lig, x, h, gen_flag, lig_flag, batch_idx, graph_ptr=None, n_graphs=None):
+    def forward(self, x_lig_pred, batch_idx_lig, x, h, gen_flag, lig_flag, batch_idx, graph_ptr=None, n_graphs=None, lig_rows=None):
         from oracle import diffbp as OD
+        if lig_rows is not None:      # the synchronisation-free row selection must pick the rows the flag picks
+            assert torch.equal(lig_rows, torch.nonzero(lig_flag).flatten())
         sd = {k: p for k, p in zip(self.keys, self.params)}
         B = int(batch_idx.max()) + 1
         return OD.com_head(sd, x_lig_pred, batch_idx_lig, x, h, gen_flag, lig_flag, batch_idx, B)
