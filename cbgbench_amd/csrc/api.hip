@@ -138,9 +138,7 @@ const char* cbgx_last_error(void) { return g_err; }
 #ifdef CBGX_XCHECK
 // test-only library (include/cbgx_xcheck.h): route the stages through the first-generation VALU kernels
 int cbgx_debug_set_edge_kernel(int impl) {
-    if (impl < 0 || impl > 3)
-        return fail(CBGX_E_INVALID, "debug_set_edge_kernel: impl must be 0 (current), 1 (valu), 2 (mfma, second-generation x2h backward) or "
-                                    "3 (current, query fold as a separate launch)");
+    if (impl < 0 || impl > 2) return fail(CBGX_E_INVALID, "debug_set_edge_kernel: impl must be 0 (current), 1 (valu) or 2 (mfma, second-generation x2h backward)");
     int old = g_edge_impl;
     g_edge_impl = impl;
     return old;
@@ -487,7 +485,7 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
         const int *dst, *dst_n, *src, *src_n;
         layer_lists(0, dst, dst_n, src, src_n);
         HIP_TRY(launch_node_mfma(packed + x2h_off(0), h, lig_flag, n_nodes, Pset[0], qset[0], Qtset[0], dst, dst_n, src,
-                                 src_n, s, fold_in_edge_kernel(true, n_nodes)));
+                                 src_n, s));
     }
     for (int l = 0; l < num_layers; ++l) {
         float* hn = (l == num_layers - 1 && h_out) ? h_out : w.hbuf[l & 1];
@@ -506,15 +504,14 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
             const int set = l & 1;
             if (l > 0) HIP_TRY(hipStreamWaitEvent(s, g_aux.join, 0));       // node stage of this layer (aux stream) done
             HIP_TRY(launch_edge_mfma(true, packed + x2h_off(l), xc, hc, Pset[set], Qtset[set], w.nbr, w.deg, lig_flag,
-                                     gen_flag, w.e_w, n_nodes, hn, nullptr, dst, dst_n, s,
-                                     fold_in_edge_kernel(true, n_nodes) ? qset[set] : nullptr));
+                                     gen_flag, w.e_w, n_nodes, hn, nullptr, dst, dst_n, s));
             if (l + 1 < num_layers) {
                 const int *d2, *d2n, *s2, *s2n;
                 layer_lists(l + 1, d2, d2n, s2, s2n);
                 HIP_TRY(hipEventRecord(g_aux.fork, s));
                 HIP_TRY(hipStreamWaitEvent(g_aux.s, g_aux.fork, 0));
                 HIP_TRY(launch_node_mfma(packed + x2h_off(l + 1), hn, lig_flag, n_nodes, Pset[set ^ 1], qset[set ^ 1],
-                                         Qtset[set ^ 1], d2, d2n, s2, s2n, g_aux.s, fold_in_edge_kernel(true, n_nodes)));
+                                         Qtset[set ^ 1], d2, d2n, s2, s2n, g_aux.s));
                 HIP_TRY(hipEventRecord(g_aux.join, g_aux.s));
             }
             HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,

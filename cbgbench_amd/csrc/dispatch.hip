@@ -49,11 +49,9 @@ hipError_t launch_attention(bool x2h, const float* att, const float* x, const fl
 #ifdef CBGX_XCHECK
     if (g_edge_impl == 1) return launch_attention_v1(x2h, att, x, h, nbr, deg, lig, gen, e_w, n_nodes, P, Qt, out, dx_out, s);
 #endif
-    const bool fold = fold_in_edge_kernel(x2h, n_nodes);      // large x2h blocks: the edge kernel folds the query of its own nodes
-    hipError_t e0 = launch_node_mfma(att, h, lig, n_nodes, P, qbuf, Qt, act, act_count, src, src_count, s, fold);
+    hipError_t e0 = launch_node_mfma(att, h, lig, n_nodes, P, qbuf, Qt, act, act_count, src, src_count, s);
     if (e0 != hipSuccess) return e0;
-    return launch_edge_mfma(x2h, att, x, h, P, Qt, nbr, deg, lig, gen, e_w, n_nodes, out, dx_out, act, act_count, s,
-                            fold ? qbuf : nullptr);
+    return launch_edge_mfma(x2h, att, x, h, P, Qt, nbr, deg, lig, gen, e_w, n_nodes, out, dx_out, act, act_count, s);
 }
 
 // ---- strided / transposed copies of cbgx_pack_weights ---------------------------------------------------------------

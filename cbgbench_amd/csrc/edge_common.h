@@ -94,9 +94,6 @@ __device__ __forceinline__ int ldob(gptr base, unsigned byte_off) {
 __device__ __forceinline__ void sto2(gwptr base, unsigned byte_off, float2 v) {
     *reinterpret_cast<__attribute__((address_space(1))) nfloat2*>(base + byte_off) = nfloat2{v.x, v.y};
 }
-__device__ __forceinline__ void sto4(gwptr base, unsigned byte_off, float4 v) {
-    *reinterpret_cast<__attribute__((address_space(1))) floatx4*>(base + byte_off) = floatx4{v.x, v.y, v.z, v.w};
-}
 // no-return fp32 atomic add in the same scalar-base + 32-bit-offset form (global_atomic_add_f32 v_off, v_data, s[base])
 __device__ __forceinline__ void atomo(gwptr base, unsigned byte_off, float v) {
     __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(1))) float*>(base + byte_off), v, __ATOMIC_RELAXED,

@@ -116,63 +116,6 @@ struct ItemGeom {
 // E1 neighbour id of slot r of a half: the raw row entry (-1 padded) or the node itself
 __device__ __forceinline__ int e1_id(int raw, int e, int d, int self) { return e < d ? raw : self; }
 
-// ---- query fold inside the x2h edge kernel (FOLD variants) -------------------------------------------------------------------
-// Qt[i][a][m] = (1/sqrt 8) sum_cc q[i][8a + cc] Wbk[8a + cc][m] is consumed by node i's own wavefront only, so nothing forces it
-// through a separate launch: node_qfold_kernel writes 8 KB per node at the HBM write rate while the matrix cores idle (150 us of a
-// 240 us node stage at 100 k nodes), and this kernel is matrix / VALU bound with three quarters of the HBM bandwidth unused.
-// A wavefront therefore produces the rows of its OWN next 16 work items in one burst every 16 rounds -- the 16 nodes are the 16
-// rows of the same exact-fp32 MFMA tiles node_qfold_kernel uses (K = 8 per head = two 16x16x4 steps, Wbk fragments straight from
-// L2: 64 KB per burst), 256 MFMAs = +3 % per node -- and stores them at their natural place Qt[node], where the iteration that
-// owns the node reads them 16 rounds later (same wave: program order, no barrier, no fence).  The stores overlap the edge work.
-// Bit-identical to node_qfold_kernel (same fragments, same two-step accumulation).
-constexpr int FOLD_AHEAD = 16;
-template <bool LISTED>
-__device__ __forceinline__ void fold_burst(const float* __restrict__ att, const float* __restrict__ qbuf, float* Qt,
-                                           const int* __restrict__ act, int k0, int i_step, int i_end, int lane, int c, int q) {
-    if (k0 >= i_end) return;                                   // wave-uniform: no item left for this wave
-    // A rows: slot c <-> item k0 + c i_step (slots past the end re-read the first one; their rows are never stored)
-    const int kc = k0 + c * i_step;
-    const int kcc = kc < i_end ? kc : k0;
-    const int node_c = LISTED ? act[kcc] : kcc;
-    int node_r[4];                                             // C rows: register r <-> slot 4q + r
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ks = k0 + (4 * q + r) * i_step;
-        node_r[r] = ks < i_end ? (LISTED ? act[ks] : ks) : -1;
-    }
-    // scalar bases + 32-bit lane offsets (edge_common.h): 64-bit per-lane pointers here are loop invariants of the node loop and get
-    // spilled around it.  Offsets stay below 2^32 (the launcher checks n_nodes * 8192 B for Qt).
-    const gptr qb = sbase(qbuf), fb = sbase(att + A_WBK_FRAG);
-    const gwptr qtw = sbase_w(Qt);
-    const unsigned oq_row = (unsigned)node_c * (H * 4) + 8 * q;
-    float2 qa[HEADS];
-#pragma unroll
-    for (int a = 0; a < HEADS; ++a) qa[a] = ldo2(qb, oq_row + 32 * a);
-    const unsigned ofrag = vop(lane * 32);                      // [a][g][lane][8]: Wbk[8a + 2q + step][64g + 4c + j] / sqrt 8 at 2j + step
-    float4 b0 = ldo4(fb, ofrag), b1 = ldo4(fb, ofrag + 16);
-    unsigned orow[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) orow[r] = (unsigned)(node_r[r] < 0 ? 0 : node_r[r]) * (HEADS * H * 4) + 16 * c;
-#pragma unroll
-    for (int ag = 0; ag < 2 * HEADS; ++ag) {
-        const int a = ag >> 1, g = ag & 1;
-        float4 n0 = b0, n1 = b1;
-        if (ag + 1 < 2 * HEADS) { n0 = ldo4(fb, ofrag + (ag + 1) * 2048); n1 = ldo4(fb, ofrag + (ag + 1) * 2048 + 16); }   // next fragments in flight
-        __builtin_amdgcn_sched_barrier(0);     // one pair of fragments ahead, not all 32 (the scheduler would hoist every load)
-        const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-        floatx4 acc[4];
-        acc[0] = MFMA(qa[a].x, b0.x, zero); acc[1] = MFMA(qa[a].x, b0.z, zero);
-        acc[2] = MFMA(qa[a].x, b1.x, zero); acc[3] = MFMA(qa[a].x, b1.z, zero);
-        acc[0] = MFMA(qa[a].y, b0.y, acc[0]); acc[1] = MFMA(qa[a].y, b0.w, acc[1]);
-        acc[2] = MFMA(qa[a].y, b1.y, acc[2]); acc[3] = MFMA(qa[a].y, b1.w, acc[3]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (node_r[r] >= 0) sto4(qtw, orow[r] + (a * H + 64 * g) * 4, make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]));
-        b0 = n0; b1 = n1;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // LISTED: the launch iterates over a device-side node list (h2x always; x2h in the pruned last layers) -- a separate
 // instantiation so that profilers report full-graph and listed launches under different kernel names.
 //
@@ -184,16 +127,13 @@ __device__ __forceinline__ void fold_burst(const float* __restrict__ att, const 
 //   after k half 0       PS_v gathers of half 1 (x2h), e_w; coordinates / flags of the next node's neighbours (b)
 //   after k half 1       distances / flags of the next node's edges
 //   before the epilogue  PD / PS_k rows of the next node (c)
-// FOLD (x2h launches above NODE_STAGE_MAX_ROWS rows): the kernel computes the folded query rows of its own nodes from `qbuf`
-// (the query MLP's output) FOLD_AHEAD rounds ahead (fold_burst above) instead of reading what node_qfold_kernel wrote; `Qt` is then
-// written and read by this kernel (hence neither const nor restrict).
-template <bool X2H, int WAVES, bool LISTED, bool FOLD>
+template <bool X2H, int WAVES, bool LISTED>
 __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     const float* __restrict__ att, const float* __restrict__ x, const float* __restrict__ h,
-    const float* __restrict__ P, float* Qt, const int32_t* __restrict__ nbr,
+    const float* __restrict__ P, const float* __restrict__ Qt, const int32_t* __restrict__ nbr,
     const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig, const uint8_t* __restrict__ gen,
     const float* __restrict__ e_w, int n_nodes, float* __restrict__ out, float* __restrict__ dx_out,
-    const int* __restrict__ act_arg, const int* __restrict__ act_count, const float* __restrict__ qbuf) {
+    const int* __restrict__ act_arg, const int* __restrict__ act_count) {
     const int* __restrict__ act = LISTED ? act_arg : nullptr;
     constexpr int IMG = X2H ? (int)IMG_SIZE_X2H : (int)IMG_SIZE_H2X;
     __shared__ __attribute__((aligned(16))) float lds[IMG];
@@ -267,11 +207,6 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     if (i_begin >= i_end) return;
     // power-of-two scales of the split-f16 rbf tables (wave-uniform: scalar registers)
     const RbfScale sck = load_rbf_scale(att, 0), scv = load_rbf_scale(att, 1);
-    // FOLD: the folded query rows of this wave's first FOLD_AHEAD items (every later batch is produced FOLD_AHEAD rounds ahead)
-    if (FOLD) {
-        fold_burst<LISTED>(att, qbuf, Qt, act, i_begin, i_step, i_end, lane, c, q);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first item reads its row right away (later rows: 16 rounds apart)
-    }
 
     // ---- first item: geometry and the k-path rows, everything unconditional -------------------------------------
     ItemGeom g;
@@ -305,8 +240,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         for (int t = 0; t < 8; ++t) ps1[t] = ldo4(sbase(P), o1 + 64 * t);
     }
 
-    int round = 0;
-    for (int k = i_begin; k < i_end; k += i_step, ++round) {
+    for (int k = i_begin; k < i_end; k += i_step) {
         const int i = __builtin_amdgcn_readfirstlane(g.node), d = g.d, lig_i = g.lig_i;
         const bool more = k + i_step < i_end;   // wave-uniform
         // both halves' PD[i] + PS_k[j] as soon as the rows (requested one epilogue ago) are here: the 24 gather registers
@@ -318,10 +252,6 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             acc0[t] = f4(ps0[t]) * sck.S + pds; acc1[t] = f4(ps1[t]) * sck.S + pds;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (FOLD && (round & (FOLD_AHEAD - 1)) == 0) {       // wave-uniform: the rows of rounds round + 16 .. round + 31
-            fold_burst<LISTED>(att, qbuf, Qt, act, k + FOLD_AHEAD * i_step, i_step, i_end, lane, c, q);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         // (a) next item: id, degree, flag, position, neighbour ids in both mappings.  The last iteration re-requests its own
         // node (every prefetch below is unconditional: no divergent joins for the register allocator, no predicated loads).
         // Issued BEFORE this node's gathers: vmcnt retires in order, so waiting for these few words later (b) leaves the
@@ -803,7 +733,7 @@ hipError_t launch_pack_frag(const float* w_a, int mode, const float* sc, float* 
 hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,
                             const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                             const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,
-                            const int* act, const int* act_count, hipStream_t s, const float* qbuf) {
+                            const int* act, const int* act_count, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
     if ((size_t)n_nodes * PROW * sizeof(float) >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit byte offsets into P
     constexpr int W = 8;                        // waves per persistent workgroup: 2 per SIMD at <= 256 VGPRs per lane
@@ -811,19 +741,13 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
     if (grid > 256) grid = 256;                 // persistent: one workgroup per CU (LDS-limited)
     if (grid >= 64) grid &= ~7;                 // multiple of 8 -> XCD-aware node partition
     profile_mark_begin(x2h ? (act ? K_EDGE_X2H_LISTED : K_EDGE_X2H) : K_EDGE_H2X, s);
-    // qbuf != NULL (x2h only; launch_node_mfma was told to skip the fold): the kernel folds the query of its own nodes
-    const bool fold = x2h && qbuf != nullptr;
-    if (fold && (size_t)n_nodes * HEADS * H * sizeof(float) >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit byte offsets into Qt
-    float* Qtw = const_cast<float*>(Qt);
-#define CBGX_LAUNCH_EDGE(X2H_, L_, F_)                                                                              \
-    hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W, L_, F_>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qtw, nbr, deg, \
-                       lig, gen, e_w, n_nodes, out, dx_out, act, act_count, qbuf)
-    if (x2h && fold) {
-        if (act) CBGX_LAUNCH_EDGE(true, true, true); else CBGX_LAUNCH_EDGE(true, false, true);
-    } else if (x2h) {
-        if (act) CBGX_LAUNCH_EDGE(true, true, false); else CBGX_LAUNCH_EDGE(true, false, false);
+#define CBGX_LAUNCH_EDGE(X2H_, L_)                                                                              \
+    hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W, L_>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qt, nbr, deg, \
+                       lig, gen, e_w, n_nodes, out, dx_out, act, act_count)
+    if (x2h) {
+        if (act) CBGX_LAUNCH_EDGE(true, true); else CBGX_LAUNCH_EDGE(true, false);
     } else {
-        if (act) CBGX_LAUNCH_EDGE(false, true, false); else CBGX_LAUNCH_EDGE(false, false, false);
+        if (act) CBGX_LAUNCH_EDGE(false, true); else CBGX_LAUNCH_EDGE(false, false);
     }
 #undef CBGX_LAUNCH_EDGE
     profile_mark_end(s);

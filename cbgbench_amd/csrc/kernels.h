@@ -41,13 +41,6 @@ hipError_t launch_attention_v1(bool x2h, const float* att, const float* x, const
 #else
 constexpr int g_edge_impl = 0;
 #endif
-constexpr int NODE_STAGE_MAX_ROWS = 8192;   // up to here the latency-built fused node kernel replaces the three-kernel chain
-// x2h blocks above that size: node_qfold_kernel is not launched, the edge kernel produces Qt for its own nodes (edge_mfma.hip)
-// (and below 2^32 / 8192 rows: the burst addresses Qt with 32-bit byte offsets)
-// (libcbgx_xcheck.so, cbgx_debug_set_edge_kernel(3): never -- the same kernels with the separate fold launch, for the bit-exactness test)
-inline bool fold_in_edge_kernel(bool x2h, int n_nodes) {
-    return x2h && n_nodes > NODE_STAGE_MAX_ROWS && n_nodes < (1 << 19) && g_edge_impl != 3;
-}
 // split-f16 rbf weight table of one centred first Linear (layout.h): mode 0 edge-major (A operand), 1 channel-major (B operand)
 hipError_t launch_pack_frag(const float* w_a, int mode, const float* sc, float* dst, hipStream_t s);
 // A_RBF_SC record of one attention block from its centred first Linears (k, v)
@@ -75,16 +68,14 @@ hipError_t launch_mark_from_nbr(const uint8_t* flag, const int32_t* nbr, const i
                                 hipStream_t s);
 hipError_t launch_mark_nbr(const int* list, const int* count, int n_upper, const int32_t* nbr, const int32_t* deg,
                            uint8_t* m, hipStream_t s);
-// `skip_fold`: the x2h edge kernel that follows folds the query itself (launch_edge_mfma with qbuf); only honoured where
-// fold_in_edge_kernel() says so, i.e. never for the small inputs that take the fused latency-built node_stage_kernel
 hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,
                             float* Qt, const int* act, const int* act_count, const int* src, const int* src_count,
-                            hipStream_t s, bool skip_fold = false);
+                            hipStream_t s);
 // MFMA edge kernel (edge_mfma.hip)
 hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,
                             const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                             const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,
-                            const int* act, const int* act_count, hipStream_t s, const float* qbuf = nullptr);
+                            const int* act, const int* act_count, hipStream_t s);
 // TargetDiff step prologue / epilogue (step.hip)
 hipError_t launch_step_prologue(const float* x_lig, const float* c_lig, const int32_t* lig_rows, int n_lig, int C,
                                 const float* emb_w, const float* emb_b, const float* ind_w, const float* ind_b, float* x,

@@ -806,9 +806,11 @@ constexpr unsigned CHUNKS_OWN = 0x30fu;   // PDk | PDv | qh: what the destinatio
 // `act` / `act_count` (optional): only the listed destination nodes will be processed by the edge kernel (h2x: nodes
 // that can move; x2h in the last layers: nodes whose features can still reach an output).  `src` / `src_count`
 // (optional): the nodes that can be *sources* of those destinations; without it PS is produced for every node.
+constexpr int NODE_STAGE_MAX_ROWS = 8192;   // up to here the latency-built fused kernel replaces the three-kernel chain
+
 hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,
                             float* Qt, const int* act, const int* act_count, const int* src, const int* src_count,
-                            hipStream_t s, bool skip_fold) {
+                            hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
     const int tiles = (n_nodes + 63) / 64;
     const int grid = min(tiles, 512);
@@ -839,9 +841,8 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
                            n_nodes, act, act_count, act ? CHUNKS_OWN : CHUNKS_ALL);
     } else {
         hipLaunchKernelGGL(node_qmlp_kernel, dim3(grid, small ? 2 : 1), dim3(256), 0, s, att, P, qbuf, n_nodes, act, act_count);
-        if (!skip_fold)
-            hipLaunchKernelGGL(node_qfold_kernel, dim3(grid, small ? 4 : 1), dim3(256), 0, s, att, qbuf, Qt, n_nodes, act,
-                               act_count);
+        hipLaunchKernelGGL(node_qfold_kernel, dim3(grid, small ? 4 : 1), dim3(256), 0, s, att, qbuf, Qt, n_nodes, act,
+                           act_count);
     }
     profile_mark_end(s);
     return hipGetLastError();

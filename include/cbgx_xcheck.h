@@ -13,9 +13,7 @@ extern "C" {
 #endif
 
 /* 0 = the kernels libcbgx.so always runs, 1 = first-generation VALU kernels, 2 = as 0 but the x2h backward of the
- * second generation (one workgroup per node, train_bwd_mfma.hip) instead of train_bwd_x2h.hip, 3 = as 0 but the query fold of
- * large x2h blocks as the separate node_qfold_kernel launch instead of inside the edge kernel (edge_mfma.hip fold_burst): the two
- * must agree bit for bit.
+ * second generation (one workgroup per node, train_bwd_mfma.hip) instead of train_bwd_x2h.hip.
  * Returns the previous setting (>= 0) or CBGX_E_INVALID.  Process-wide. */
 int cbgx_debug_set_edge_kernel(int impl);
 

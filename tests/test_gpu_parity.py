@@ -405,30 +405,6 @@ def test_receptive_field_pruning_is_exact(model, maker, n):
     assert torch.equal(lp[lig_flag], lf[lig_flag])
 
 
-@pytest.mark.parametrize("need_h", [True, False])
-def test_in_kernel_query_fold_is_bit_identical(model, need_h):
-    """x2h blocks above 8 192 rows fold the query inside the edge kernel (each wavefront produces Qt for its own next 16 nodes,
-    edge_mfma.hip fold_burst) instead of launching node_qfold_kernel; same fragments, same MFMA sequence -> the same bits.
-    libcbgx_xcheck.so with cbgx_debug_set_edge_kernel(3) runs the same kernels with the separate launch.  need_h=False also
-    covers the listed (pruned) launches."""
-    from cbgbench_amd import _native
-    x, h, batch_idx, lig_flag, gen, gp = _composed(model, synthetic.denovo_batch(24, seed=31))
-    assert x.shape[0] > 8192
-    with torch.no_grad():
-        a = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp, need_h=need_h)
-        torch.cuda.synchronize()
-        with _native.first_generation_kernels(3):
-            model.denoiser._packed = None          # packed by the library that consumes it
-            b = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp, need_h=need_h)
-            torch.cuda.synchronize()
-        model.denoiser._packed = None
-    assert torch.equal(a[0], b[0])
-    if need_h:
-        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
-    else:
-        assert torch.equal(a[2][lig_flag], b[2][lig_flag])
-
-
 def test_sampling_driver_end_to_end(tmp_path):
     """config YAML -> registry -> model.sample on sharded pockets -> one result file per pocket (the sample.py role)."""
     import os as _os
