@@ -405,6 +405,13 @@ def parse_args(argv=None):
     ap.add_argument("--graph", choices=["on", "off"], default="off",
                     help="replay one captured hipGraph per denoising step instead of stream launches (single batch only; no "
                          "gain measured: small batches are bound by the dependent-kernel chain on the device)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="resident batches in flight at once, round-robin over this many HIP streams (sampling workloads; default 3, "
+                         "capped by the number of resident batches): while one batch sits in its matrix-bound edge kernel the node "
+                         "kernels and small kernels of the others fill what it leaves (+6 % at three 200-graph batches)")
+    ap.add_argument("--edge-workgroups", type=int, default=0,
+                    help="cbgx_set_edge_workgroups: CUs the persistent x2h edge kernel may take (default 0 = all; leaving CUs free "
+                         "for the other streams measured slower at every setting, profiles/README.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -481,10 +488,22 @@ def bench_sampling(args, rank, world, dev):
     torch.manual_seed(2024 + rank)   # sample.py:106 seed (+rank: independent streams per shard)
     n_blocks = len(T_BLOCKS)
 
+    n_streams = max(1, min(args.streams, len(states)))
+    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else None
+    edge_wgs = args.edge_workgroups
+    _native.lib().cbgx_set_edge_workgroups(edge_wgs)
+    if streams:
+        for sx in streams:
+            sx.wait_stream(torch.cuda.current_stream(dev))       # the states were built on the current stream
+
     def bench_step(i):
         for t in block_times(i, T):
-            for st in states:
-                model.denoise_step(st, t)
+            for b, st in enumerate(states):
+                if streams:      # batch b lives on stream b mod S: its steps stay ordered, different batches overlap
+                    with torch.cuda.stream(streams[b % n_streams]):
+                        model.denoise_step(st, t)
+                else:
+                    model.denoise_step(st, t)
 
     use_graph = args.graph == "on" and len(states) == 1 and args.warmup + args.steps + 2 < T and args.model == "targetdiff"
     if use_graph:
@@ -534,7 +553,8 @@ def bench_sampling(args, rank, world, dev):
                    "graph_steps_per_bench_step_per_gpu": n_graphs * n_blocks,
                    "ms_per_denoising_step_of_the_job": round(1e3 * el_max / args.steps / n_blocks, 4),
                    "sharding": f"independent pockets x{world} ranks, no data-path collective", "ranks_seen": seen,
-                   "launch": "one hipGraph replay per step" if use_graph else "stream launches"},
+                   "launch": "one hipGraph replay per step" if use_graph else "stream launches",
+                   "streams": n_streams, "edge_workgroups": edge_wgs or 256},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -596,6 +616,7 @@ def bench_sampling(args, rank, world, dev):
                "diffsbdd": lambda: OW.synthetic_state_dict_diffsbdd(8, 9, seed=0, num_timesteps=T)}[args.model]()
         out["cpu_baseline"] = cpu_baseline(osd, seed=1000, model=args.model)
         out["cpu_baseline"]["all_cores"] = cpu_baseline_concurrent(out["cpu_baseline"]["cores"], model=args.model)
+    _native.lib().cbgx_set_edge_workgroups(0)
     del states, model
     torch.cuda.empty_cache()
     return out

@@ -17,6 +17,7 @@ ABI_VERSION = 2      # include/cbgx.h CBGX_ABI_VERSION: bumped whenever the pack
 EXPORTS = {
     "cbgx_abi_version": (_i, []),
     "cbgx_last_error": (ctypes.c_char_p, []),
+    "cbgx_set_edge_workgroups": (_i, [_i]),
     "cbgx_packed_weights_floats": (_sz, [_i, _i]),
     "cbgx_pack_weights": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _vp, _vp]),
     "cbgx_workspace_bytes": (_sz, [_i, _i]),

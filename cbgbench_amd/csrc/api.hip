@@ -106,28 +106,42 @@ static Workspace carve(void* base, int n) {
     return w;
 }
 
-// Auxiliary stream (one per host thread and device, created on first use) with the two events that fork it from and
-// join it back into the caller's stream.  The library stays re-entrant: nothing here is shared between host threads.
+// Auxiliary streams: one per (host thread, caller stream), created on first use, with the two events that fork it from and join it
+// back into that caller stream.  A caller that keeps two forward calls in flight on two of its streams (two resident batches: the
+// HBM-bound node kernels of one run under the matrix-bound edge kernel of the other) must not have them share an auxiliary stream --
+// the node stages of the second call would queue behind all nine of the first.  A small table keyed by the caller's stream handle;
+// when it is full the call falls back to the serial schedule.  Nothing here is shared between host threads.
 struct AuxStream {
-    int dev = -1;
+    hipStream_t owner = nullptr;
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
-static thread_local AuxStream g_aux;
-static bool aux_ready() {
+constexpr int MAX_AUX = 4;
+struct AuxTable {
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (g_aux.s && g_aux.dev == dev) return true;
-    if (g_aux.s) return false;   // one device per host thread (one process per GPU); otherwise stay serial
-    if (hipStreamCreateWithFlags(&g_aux.s, hipStreamNonBlocking) != hipSuccess) { g_aux.s = nullptr; return false; }
-    if (hipEventCreateWithFlags(&g_aux.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&g_aux.join, hipEventDisableTiming) != hipSuccess) {
-        (void)hipStreamDestroy(g_aux.s);
-        g_aux.s = nullptr;
-        return false;
+    int n = 0;
+    AuxStream e[MAX_AUX];
+};
+static thread_local AuxTable g_aux_table;
+static AuxStream* aux_for(hipStream_t caller) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    AuxTable& t = g_aux_table;
+    if (t.n && t.dev != dev) return nullptr;   // one device per host thread (one process per GPU); otherwise stay serial
+    for (int k = 0; k < t.n; ++k)
+        if (t.e[k].owner == caller) return &t.e[k];
+    if (t.n == MAX_AUX) return nullptr;
+    AuxStream a;
+    a.owner = caller;
+    if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(a.s);
+        return nullptr;
     }
-    g_aux.dev = dev;
-    return true;
+    t.dev = dev;
+    t.e[t.n] = a;
+    return &t.e[t.n++];
 }
 
 extern "C" {
@@ -144,6 +158,8 @@ int cbgx_debug_set_edge_kernel(int impl) {
     return old;
 }
 #endif
+
+int cbgx_set_edge_workgroups(int n) { return set_edge_workgroup_limit(n); }
 
 size_t cbgx_packed_weights_floats(int num_layers, int num_classes) {
     if (num_layers < 0 || num_classes < 1) return 0;
@@ -463,7 +479,8 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
     // still to come -- so it runs on an auxiliary stream next to that h2x block.  Three node-stage buffer sets: x2h
     // alternates between two, h2x has its own.
     static const bool overlap_env = [] { const char* e = getenv("CBGX_OVERLAP"); return !e || atoi(e) != 0; }();
-    const bool overlap = overlap_env && g_edge_impl != 1 && !profile_is_on() && num_layers > 1 && aux_ready();
+    AuxStream* aux = (overlap_env && g_edge_impl != 1 && !profile_is_on() && num_layers > 1) ? aux_for(s) : nullptr;
+    const bool overlap = aux != nullptr;
     auto layer_lists = [&](int l, const int*& dst, const int*& dst_n, const int*& src, const int*& src_n) {
         dst = dst_n = src = src_n = nullptr;
         if (cached && l < 2) {
@@ -502,17 +519,17 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
                                      w.P, w.Qt, w.q, xn, nullptr, w.act, w.act_count, w.rf_list[0], w.rf_count, s));
         } else {
             const int set = l & 1;
-            if (l > 0) HIP_TRY(hipStreamWaitEvent(s, g_aux.join, 0));       // node stage of this layer (aux stream) done
+            if (l > 0) HIP_TRY(hipStreamWaitEvent(s, aux->join, 0));       // node stage of this layer (aux stream) done
             HIP_TRY(launch_edge_mfma(true, packed + x2h_off(l), xc, hc, Pset[set], Qtset[set], w.nbr, w.deg, lig_flag,
                                      gen_flag, w.e_w, n_nodes, hn, nullptr, dst, dst_n, s));
             if (l + 1 < num_layers) {
                 const int *d2, *d2n, *s2, *s2n;
                 layer_lists(l + 1, d2, d2n, s2, s2n);
-                HIP_TRY(hipEventRecord(g_aux.fork, s));
-                HIP_TRY(hipStreamWaitEvent(g_aux.s, g_aux.fork, 0));
+                HIP_TRY(hipEventRecord(aux->fork, s));
+                HIP_TRY(hipStreamWaitEvent(aux->s, aux->fork, 0));
                 HIP_TRY(launch_node_mfma(packed + x2h_off(l + 1), hn, lig_flag, n_nodes, Pset[set ^ 1], qset[set ^ 1],
-                                         Qtset[set ^ 1], d2, d2n, s2, s2n, g_aux.s));
-                HIP_TRY(hipEventRecord(g_aux.join, g_aux.s));
+                                         Qtset[set ^ 1], d2, d2n, s2, s2n, aux->s));
+                HIP_TRY(hipEventRecord(aux->join, aux->s));
             }
             HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
                                      w.P3, w.Qt3, w.q3, xn, nullptr, w.act, w.act_count, w.rf_list[0], w.rf_count, s));

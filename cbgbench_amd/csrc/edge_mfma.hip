@@ -730,6 +730,14 @@ hipError_t launch_pack_frag(const float* w_a, int mode, const float* sc, float* 
     return hipGetLastError();
 }
 
+// cbgx_set_edge_workgroups (include/cbgx.h): upper bound of the persistent x2h grid, 0 = one workgroup per CU
+static int g_edge_wg_limit = 0;
+int set_edge_workgroup_limit(int n) {
+    const int old = g_edge_wg_limit;
+    g_edge_wg_limit = n < 0 ? 0 : n;
+    return old;
+}
+
 hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,
                             const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                             const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,
@@ -739,6 +747,7 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
     constexpr int W = 8;                        // waves per persistent workgroup: 2 per SIMD at <= 256 VGPRs per lane
     int grid = (n_nodes + W - 1) / W;
     if (grid > 256) grid = 256;                 // persistent: one workgroup per CU (LDS-limited)
+    if (x2h && g_edge_wg_limit >= 8 && grid > g_edge_wg_limit) grid = g_edge_wg_limit;   // the caller keeps CUs free for another stream
     if (grid >= 64) grid &= ~7;                 // multiple of 8 -> XCD-aware node partition
     profile_mark_begin(x2h ? (act ? K_EDGE_X2H_LISTED : K_EDGE_X2H) : K_EDGE_H2X, s);
 #define CBGX_LAUNCH_EDGE(X2H_, L_)                                                                              \

@@ -72,6 +72,7 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
                             float* Qt, const int* act, const int* act_count, const int* src, const int* src_count,
                             hipStream_t s);
 // MFMA edge kernel (edge_mfma.hip)
+int set_edge_workgroup_limit(int n);
 hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,
                             const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                             const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,

@@ -176,20 +176,29 @@ class CoMPredictor(nn.Module):
             self._packed, self._packed_key, self._packed_srcs = packed, key, srcs
         return self._packed
 
+    def _stream_workspace(self, need, dev):
+        """one workspace per (device, current stream): two calls in flight on two streams must not share scratch memory"""
+        if not isinstance(self._workspace, dict):
+            self._workspace = {}
+        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._workspace.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._workspace[key] = ws
+        return ws
+
     @torch.no_grad()
     def stack_forward(self, x_in, h_in, graph_ptr, lig8, gen8):
         """the raw output coordinates [N,3] of the H2X stack on its own kNN graph (one cbgx_h2x_stack_forward call)"""
         dev = x_in.device
         N, B = x_in.shape[0], graph_ptr.numel() - 1
         lib = _native.lib()
-        need = lib.cbgx_workspace_bytes(N, B)
-        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = self._stream_workspace(lib.cbgx_workspace_bytes(N, B), dev)
         x_out = torch.empty_like(x_in)
         rc = lib.cbgx_h2x_stack_forward(
             _native.ptr(self.packed_weights(dev)), self.num_layers, _native.ptr(x_in), _native.ptr(h_in),
             _native.ptr(graph_ptr), _native.ptr(lig8), _native.ptr(gen8), N, B, _native.ptr(x_out),
-            _native.ptr(self._workspace), self._workspace.numel(), _native.current_stream(dev))
+            _native.ptr(ws), ws.numel(), _native.current_stream(dev))
         _native.check(rc, "cbgx_h2x_stack_forward")
         return x_out
 
@@ -210,10 +219,6 @@ class CoMPredictor(nn.Module):
         pick = (lambda v: v[lig_rows]) if lig_rows is not None else (lambda v: v[lig_flag_composed])
         noise = x_lig_pred - pick(x_composed)
         noise = noise - _S.scatter_mean(noise, batch_idx_lig, B)[batch_idx_lig]
-        lib = _native.lib()
-        need = lib.cbgx_workspace_bytes(N, B)
-        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
         x_in = x_composed.detach().float().contiguous()
         if torch.is_grad_enabled() and (h_composed.requires_grad or any(p.requires_grad for p in self.parameters())):
             x_out = _H2XStackFunction.apply(self, x_in, h_composed.float().contiguous(), graph_ptr,

@@ -70,6 +70,8 @@ def main(argv=None, stats=None):
     ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic pockets when --pockets is not given")
     ap.add_argument("--num_samples", type=int, default=None)
     ap.add_argument("--pockets_per_batch", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=3,
+                    help="batches kept in flight together on this many HIP streams (model.sample_many; 1 = one batch after the other)")
     ap.add_argument("--random_init", action="store_true",
                     help="sample from randomly initialised weights when no checkpoint is given / found (smoke runs only)")
     ap.add_argument("--save_traj", action="store_true")
@@ -127,15 +129,7 @@ def main(argv=None, stats=None):
     os.makedirs(out_dir, exist_ok=True)
     torch.manual_seed(args.seed + rank)                 # independent noise streams per shard
     rng = np.random.default_rng([args.seed, rank])
-    lap("setup", dev)
-    t0, graph_steps = time.perf_counter(), 0
-    for b0 in range(0, len(mine), args.pockets_per_batch):
-        ids = mine[b0:b0 + args.pockets_per_batch]
-        batch = build_pocket_batch([pockets[i] for i in ids], num_samples, rng, config.model.num_atomtype, prior,
-                                   device=dev, num_dist=num_dist)
-        lap("batch", dev)
-        traj = model.sample(batch)
-        lap("sample", dev)
+    def write_results(ids, traj):
         # sample.py:198-201 hands traj[0] to the reconstruction -- for targetdiff / diffbp that is the state entering the
         # last step, not traj[-1]; kept as the default for drop-in outputs, --final_state selects traj[-1]
         x, c, bidx = traj[-1] if (args.final_state and config.model.type != "diffsbdd") else traj[0]
@@ -145,8 +139,24 @@ def main(argv=None, stats=None):
             if args.save_traj:
                 rec["traj_keys"] = sorted(traj.keys())
             torch.save(rec, os.path.join(out_dir, f"pocket_{pid:05d}.pt"))
+        return len(ids) * num_samples * model.num_diffusion_timesteps
+
+    lap("setup", dev)
+    t0, graph_steps = time.perf_counter(), 0
+    # `--streams` batches are in flight together (independent pockets: sample.py:159's loop has no order); models without
+    # sample_many take them one after the other
+    many = getattr(model, "sample_many", None) if (args.streams > 1 and dev.type == "cuda") else None
+    group = args.pockets_per_batch * (args.streams if many is not None else 1)
+    for g0 in range(0, len(mine), group):
+        chunk = [mine[b0:b0 + args.pockets_per_batch] for b0 in range(g0, min(g0 + group, len(mine)), args.pockets_per_batch)]
+        batches = [build_pocket_batch([pockets[i] for i in ids], num_samples, rng, config.model.num_atomtype, prior, device=dev,
+                                      num_dist=num_dist) for ids in chunk]
+        lap("batch", dev)
+        trajs = many(batches, streams=args.streams) if many is not None and len(batches) > 1 else [model.sample(b) for b in batches]
+        lap("sample", dev)
+        for ids, traj in zip(chunk, trajs):
+            graph_steps += write_results(ids, traj)
         lap("write")
-        graph_steps += len(ids) * num_samples * model.num_diffusion_timesteps
     if dev.type == "cuda":
         torch.cuda.synchronize()
     sharding.barrier()

@@ -574,3 +574,34 @@ class TargetDiff(nn.Module):
         out_dev = torch.device("cpu") if return_device is None else torch.device(return_device)
         traj_x, traj_c, bl_out = st["traj_x"].to(out_dev), st["traj_c"].to(out_dev), st["bl"].to(out_dev)
         return {t - 1: (traj_x[t], traj_c[t], bl_out) for t in range(T + 1)}
+
+    @torch.no_grad()
+    def sample_many(self, batches, noise_tapes=None, return_device=None, streams=3):
+        """``[self.sample(b) for b in batches]`` with the batches IN FLIGHT TOGETHER, round-robin over ``streams`` HIP streams: the
+        batches are independent (the pocket loop of sample.py:159), and while one batch sits in its matrix-bound edge kernel the
+        HBM-bound node kernels and the small kernels of the others fill what it leaves (measured +6 % with three 200-graph
+        batches).  Each batch's steps stay ordered on its own stream.  With ``noise_tapes`` (one per batch) the
+        trajectories equal ``sample``'s bit for bit; without, the torch generator is consumed step by step across the batches
+        instead of batch by batch, i.e. the same distribution under a different assignment of the draws."""
+        T = self.num_diffusion_timesteps
+        dev = batches[0]["ligand_pos"].device
+        if dev.type != "cuda" or len(batches) == 1 or streams <= 1:
+            return [self.sample(b, noise_tape=None if noise_tapes is None else noise_tapes[k], return_device=return_device)
+                    for k, b in enumerate(batches)]
+        states = [self.begin_sampling(b, keep_trajectory=True) for b in batches]
+        cur = torch.cuda.current_stream(dev)
+        side = [torch.cuda.Stream(dev) for _ in range(min(streams, len(states)))]
+        for sx in side:
+            sx.wait_stream(cur)                      # the states were built on the caller's stream
+        for t_idx in reversed(range(T)):
+            for k, st in enumerate(states):
+                with torch.cuda.stream(side[k % len(side)]):
+                    self.denoise_step(st, t_idx, noise_tapes[k][t_idx] if noise_tapes is not None else None)
+        for sx in side:
+            cur.wait_stream(sx)
+        out_dev = torch.device("cpu") if return_device is None else torch.device(return_device)
+        out = []
+        for st in states:
+            traj_x, traj_c, bl_out = st["traj_x"].to(out_dev), st["traj_c"].to(out_dev), st["bl"].to(out_dev)
+            out.append({t - 1: (traj_x[t], traj_c[t], bl_out) for t in range(T + 1)})
+        return out

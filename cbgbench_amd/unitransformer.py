@@ -249,11 +249,15 @@ class UniTransformer(nn.Module):
         return self._packed
 
     def workspace(self, n_nodes, n_graphs, device):
+        """one workspace per (device, current stream): two forward calls in flight on two streams must not share scratch memory"""
         need = _native.lib().cbgx_workspace_bytes(n_nodes, n_graphs)
-        ws = self._workspace
-        if ws is None or ws.numel() < need or ws.device != device:
+        if self._workspace is None:
+            self._workspace = {}
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        ws = self._workspace.get(key)
+        if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=device)
-            self._workspace = ws
+            self._workspace[key] = ws
         return ws
 
     def train_workspace(self, n_nodes, device):

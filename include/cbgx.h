@@ -12,8 +12,8 @@
  * device memory: the caller owns inputs, outputs and the workspace.
  *
  * The only state the library owns, besides the optional profiling hook at the end of this file:
- * one auxiliary non-blocking HIP stream and two events per HOST THREAD (created on the first multi-layer
- * forward of that thread, never destroyed).  cbgx_unitransformer_forward{,_cached} fork the node stage of
+ * one auxiliary non-blocking HIP stream and two events per HOST THREAD AND CALLER STREAM (at most four per thread, created on the
+ * first multi-layer forward on that stream, never destroyed; a fifth caller stream runs the serial schedule).  cbgx_unitransformer_forward{,_cached} fork the node stage of
  * layer l+1 onto it next to the h2x block of layer l and join it back before returning work to `stream`, so
  * from the caller's point of view everything is still ordered on `stream` (hipGraph capture of `stream`
  * records the fork/join).  One device per host thread (the one-process-per-GPU model): a thread that switches
@@ -65,6 +65,15 @@ extern "C" {
 
 int cbgx_abi_version(void);
 const char *cbgx_last_error(void);
+
+/* ---- scheduling hint (changes no result) -----------------------------------------------------------------------
+ * The fused x2h edge kernel is persistent: one 8-wave workgroup per CU, all registers and 150 KB of LDS, so nothing else runs
+ * beside it, while the node kernels of the same call are HBM-bound and leave the matrix cores idle.  A caller that keeps TWO
+ * forward calls in flight on two of its streams (two resident batches; every call gets its own auxiliary stream) can let the
+ * node kernels of one call run under the edge kernel of the other by leaving a few CUs free: n = upper bound of the edge
+ * kernel's workgroups (a multiple of 8; e.g. 224 of 256), 0 = default (one per CU).  Process-wide; returns the previous value.
+ * cbgbench_amd.TargetDiff.sample_many / bench.py --streams 2 use it. */
+int cbgx_set_edge_workgroups(int n);
 
 /* ---- weights -------------------------------------------------------------------------------
  * The library consumes one packed fp32 blob built from the reference state_dict tensors

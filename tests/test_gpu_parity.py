@@ -405,6 +405,29 @@ def test_receptive_field_pruning_is_exact(model, maker, n):
     assert torch.equal(lp[lig_flag], lf[lig_flag])
 
 
+def test_sample_many_equals_sample(synthetic_sd):
+    """three batches in flight on three streams (TargetDiff.sample_many: per-stream workspaces and auxiliary streams inside
+    libcbgx) against the same batches sampled one after the other with the same noise: identical trajectories"""
+    T = 12
+    m = C.get_model(C.default_targetdiff_config(13, num_diffusion_timesteps=T)).eval()
+    m.load_state_dict(W.synthetic_state_dict(13, 9, seed=0, num_timesteps=T), strict=True)
+    m = m.to(DEV)
+    batches = [synthetic.batch_to(synthetic.denovo_batch(n, seed=50 + n), DEV) for n in (3, 2, 4)]
+    g = torch.Generator(device=DEV).manual_seed(11)
+    tapes = []
+    for b in batches:
+        n_lig = b["ligand_pos"].shape[0]
+        tapes.append({t: (torch.randn(n_lig, 3, device=DEV, generator=g), torch.rand(n_lig, 13, device=DEV, generator=g))
+                      for t in range(T)})
+    one = [m.sample(b, noise_tape=tp) for b, tp in zip(batches, tapes)]
+    many = m.sample_many(batches, noise_tapes=tapes, streams=3)
+    torch.cuda.synchronize()
+    for a, b in zip(one, many):
+        assert sorted(a.keys()) == sorted(b.keys()) == list(range(-1, T))
+        for t in a:
+            assert torch.equal(a[t][0], b[t][0]) and torch.equal(a[t][1], b[t][1]) and torch.equal(a[t][2], b[t][2])
+
+
 def test_sampling_driver_end_to_end(tmp_path):
     """config YAML -> registry -> model.sample on sharded pockets -> one result file per pocket (the sample.py role)."""
     import os as _os
