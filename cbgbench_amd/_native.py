@@ -1,6 +1,7 @@
 """ctypes binding of libcbgx.so (include/cbgx.h).  There is no fallback: if the library is missing
 or a call fails, this raises."""
 import contextlib
+import contextvars
 import ctypes
 import os
 
@@ -80,9 +81,15 @@ def _load(path, extra=None):
     return dll
 
 
+_OVERRIDE = contextvars.ContextVar("cbgx_library_override", default=None)
+
+
 def lib():
     """Load libcbgx.so (once). Raises NativeError if it has not been built."""
     global _LIB
+    over = _OVERRIDE.get()
+    if over is not None:      # inside `first_generation_kernels()` (tests only): this context's calls go to libcbgx_xcheck.so
+        return over
     if _LIB is None:
         # CBGX_LIBRARY: another build of the same library (scripts/abl_bwd.sh points it at libcbgx_ablate.so)
         path = os.environ.get("CBGX_LIBRARY", LIBPATH)
@@ -96,22 +103,23 @@ def lib():
 
 @contextlib.contextmanager
 def first_generation_kernels(impl=1):
-    """TEST-ONLY: inside the block every binding call goes to libcbgx_xcheck.so (include/cbgx_xcheck.h) with the
-    first-generation VALU kernels selected (impl=2: the current kernels except the x2h backward, which is the second-generation one) -- an independent on-device implementation of the same stages.  The product
-    library has neither those kernels nor the switch."""
-    global _LIB, _XLIB
+    """TEST-ONLY: inside the block every binding call of THIS context (contextvars: thread / task local, no module global is
+    swapped) goes to libcbgx_xcheck.so (include/cbgx_xcheck.h) with the first-generation VALU kernels selected (impl=2: the
+    current kernels except the x2h backward, which is the second-generation one) -- an independent on-device implementation
+    of the same stages.  The product library has neither those kernels nor the switch.  The kernel selection inside
+    libcbgx_xcheck.so is process-wide, so concurrent blocks with different ``impl`` are not supported (tests run them serially)."""
+    global _XLIB
     if _XLIB is None:
         if not os.path.exists(XCHECK_LIBPATH):
             raise NativeError(f"{XCHECK_LIBPATH} not found: build it with `python -m cbgbench_amd.build`")
         _XLIB = _load(XCHECK_LIBPATH, {"cbgx_debug_set_edge_kernel": (_i, [_i])})
-    product = lib()
     old = _XLIB.cbgx_debug_set_edge_kernel(impl)
-    _LIB = _XLIB
+    token = _OVERRIDE.set(_XLIB)
     try:
         yield _XLIB
     finally:
+        _OVERRIDE.reset(token)
         _XLIB.cbgx_debug_set_edge_kernel(old)
-        _LIB = product
 
 
 def check(rc, what):

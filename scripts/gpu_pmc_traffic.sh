@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/pmc_traffic_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline"
+CMD="python $ROOT/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-secondary --no-roofline"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "edge_mfma_kernel" --output-format csv -d $OUT/p_$C -o pmc -- $CMD > $OUT/$C.log 2>&1
   tail -1 $OUT/$C.log | cut -c1-160

@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/pmc_x2h_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline"
+CMD="python $ROOT/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-secondary --no-roofline"
 i=0
 while read -r GROUP; do
   [ -z "$GROUP" ] && continue
