@@ -379,14 +379,21 @@ __global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 constexpr int NS_TPITCH = H + 4;   // LDS tile row pitch (floats)
 
+// Two jobs in one launch (gridDim.y == 2, the h2x blocks): y = 0 the full stage on the destination list `rows` with `chunk_mask`,
+// y = 1 the projection only (phase 1) on the SOURCE list `rows2` with `chunk_mask2` (the PS columns of every node that can be a
+// neighbour of a destination) -- one launch instead of node_proj_kernel + node_stage_kernel per h2x block: 9 fewer dependent
+// launches per denoising step, which is what small batches are bound by.
 __global__ __launch_bounds__(1024) void node_stage_kernel(const float* __restrict__ att, const float* __restrict__ h,
                                                           const uint8_t* __restrict__ lig, float* __restrict__ P,
                                                           float* __restrict__ qout, float* __restrict__ Qt, int n_nodes,
                                                           const int* __restrict__ rows, const int* __restrict__ n_rows_ptr,
-                                                          unsigned chunk_mask) {
+                                                          unsigned chunk_mask, const int* __restrict__ rows2,
+                                                          const int* __restrict__ n_rows2_ptr, unsigned chunk_mask2) {
     __shared__ __attribute__((aligned(16))) float qh[16][NS_TPITCH];
     __shared__ __attribute__((aligned(16))) float qt[16][NS_TPITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, q = lane >> 4;
+    const bool proj_only = blockIdx.y == 1;        // workgroup-uniform
+    if (proj_only) { rows = rows2; n_rows_ptr = n_rows2_ptr; chunk_mask = chunk_mask2; }
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
     const int n_tiles = (n_rows + 15) / 16;
     for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(const float* __restric
         for (int r = 0; r < 4; ++r) lgr[r] = lig[orow[r] >= 0 ? orow[r] : arow] != 0;
         for (int unit = wave; unit < 2 * NP_CHUNKS; unit += 16) {
             const int ch = unit < 4 ? 8 + (unit >> 1) : (unit - 4) >> 1, half = unit & 1;   // units 0..3: chunks 8, 9
-            if (!(((chunk_mask | 0x300u) >> ch) & 1u)) continue;
+            if (!(((chunk_mask | (proj_only ? 0u : 0x300u)) >> ch) & 1u)) continue;
             const half8* Bh = reinterpret_cast<const half8*>(att + A_NPROJ_FRAG + (size_t)ch * NP_CHUNK) + (2 * half) * 4 * 64 + lane;
             const half8* Bl = Bh + 4 * 4 * 64;
             half8 bh[4][2], bl[4][2];     // [u][ct]
@@ -453,6 +460,7 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(const float* __restric
                 if (ch >= 8) *reinterpret_cast<float2*>(&qh[4 * q + r][64 * (ch - 8) + 4 * c + 2 * half]) = o;
             }
         }
+        if (proj_only) continue;     // the source job ends with the projection (no barrier was entered: uniform per workgroup)
         __syncthreads();
         // ---- phase 2: query MLP, output tile nt = wave (16 columns 64 (nt >> 2) + 4c + (nt & 3)) ---------------------------
         if (wave < 8) {
@@ -821,13 +829,16 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
     // every node is a destination), query MLP and query fold -- such launches are bound by kernel boundaries, not throughput.
     const bool fused = n_nodes <= NODE_STAGE_MAX_ROWS;
     profile_mark_begin(K_NODE_GEMM, s);
+    // fused with a destination list: the source rows' PS columns are the second job of the node_stage_kernel launch below
+    const bool two_jobs = fused && act != nullptr;
     if (!act) {
         if (!fused)
             hipLaunchKernelGGL(node_proj_kernel, dim3(grid, py(CHUNKS_ALL)), dim3(256), 0, s, att, h, lig, P, n_nodes,
                                (const int*)nullptr, (const int*)nullptr, CHUNKS_ALL);
     } else {
-        hipLaunchKernelGGL(node_proj_kernel, dim3(grid, (tiles <= 128 || src) ? py(CHUNKS_PS) : 1u), dim3(256), 0, s, att, h,
-                           lig, P, n_nodes, src, src_count, CHUNKS_PS);
+        if (!two_jobs)
+            hipLaunchKernelGGL(node_proj_kernel, dim3(grid, (tiles <= 128 || src) ? py(CHUNKS_PS) : 1u), dim3(256), 0, s, att, h,
+                               lig, P, n_nodes, src, src_count, CHUNKS_PS);
         if (!fused)
             hipLaunchKernelGGL(node_proj_kernel, dim3(grid, py(CHUNKS_OWN)), dim3(256), 0, s, att, h, lig, P, n_nodes, act,
                                act_count, CHUNKS_OWN);
@@ -837,8 +848,8 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
     if (e != hipSuccess) return e;
     profile_mark_begin(K_NODE_QUERY, s);
     if (fused) {
-        hipLaunchKernelGGL(node_stage_kernel, dim3(min((n_nodes + 15) / 16, 512)), dim3(1024), 0, s, att, h, lig, P, qbuf, Qt,
-                           n_nodes, act, act_count, act ? CHUNKS_OWN : CHUNKS_ALL);
+        hipLaunchKernelGGL(node_stage_kernel, dim3(min((n_nodes + 15) / 16, 512), two_jobs ? 2 : 1), dim3(1024), 0, s, att, h, lig, P,
+                           qbuf, Qt, n_nodes, act, act_count, act ? CHUNKS_OWN : CHUNKS_ALL, src, src_count, CHUNKS_PS);
     } else {
         hipLaunchKernelGGL(node_qmlp_kernel, dim3(grid, small ? 2 : 1), dim3(256), 0, s, att, P, qbuf, n_nodes, act, act_count);
         hipLaunchKernelGGL(node_qfold_kernel, dim3(grid, small ? 4 : 1), dim3(256), 0, s, att, qbuf, Qt, n_nodes, act,
