@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <vector>
 
 #include "../../include/cbgx.h"
 #ifdef CBGX_XCHECK
@@ -200,8 +201,16 @@ static int pack_gate_section(const float* const* t, float* packed, hipStream_t s
     return flush_pack(s);
 }
 
-// one attention block (ATT layout) from k(6) v(6) q(6) MLP tensors; blk 0 = x2h, 1 = h2x
-static int pack_attention_block(const float* const* p, int blk, float* a, hipStream_t s) {
+// ---- attention blocks (ATT layout) from k(6) v(6) q(6) MLP tensors each; blk 0 = x2h, 1 = h2x.  Packed for ALL blocks of a
+// model phase by phase (the weights are re-packed every training step): copies of the reference tensors, stage 1 (centring),
+// copies of the centred matrices, stage 2 (every fragment table) -- ~20 launches instead of 12 per block.
+struct BlockRef { const float* const* p; int blk; float* a; };
+
+// copies that read the caller's tensors only
+static int queue_block_copies(const BlockRef& r, hipStream_t s) {
+    const float* const* p = r.p;
+    float* a = r.a;
+    const int blk = r.blk;
     const float *wk0 = p[0], *bk0 = p[1], *gk = p[2], *bek = p[3], *wk1 = p[4];
     const float *wv0 = p[6], *bv0 = p[7], *gv = p[8], *bev = p[9], *wv1 = p[10], *bv1 = p[11];
     const float *wq0 = p[12], *bq0 = p[13], *gq = p[14], *beq = p[15], *wq1 = p[16], *bq1 = p[17];
@@ -234,35 +243,53 @@ static int pack_attention_block(const float* const* p, int blk, float* a, hipStr
         CP(wk0, KV_IN, NT + G * ty, 0, a + A_WRT + (size_t)ty * 2 * H * 32, 32, H, G);
         CP(wv0, KV_IN, NT + G * ty, 0, a + A_WRT + ((size_t)ty * 2 * H + H) * 32, 32, H, G);
     }
-    // centred copies of the first k / v Linears: every MFMA-path table below is built from them
-    HIP_TRY(launch_center_linear(wk0, bk0, KV_IN, a + A_WAKC, a + A_BAKC, s));
-    HIP_TRY(launch_center_linear(wv0, bv0, KV_IN, a + A_WAVC, a + A_BAVC, s));
-    const float *wkc = a + A_WAKC, *wvc = a + A_WAVC;
-    { int rc = flush_pack(s); if (rc) return rc; }   // the two copies below read the centred matrices just produced on this stream
-    CP(wkc, KV_IN, NT, 1, a + A_WRC, 2 * H, NT * G, H);
-    CP(wvc, KV_IN, NT, 1, a + A_WRC + H, 2 * H, NT * G, H);
-    HIP_TRY(launch_pack_node_frags(wkc, wvc, wq0, wq1, wk1, a, s));
-    HIP_TRY(launch_pack_bn2(a, bq0, a, s));
-    // LDS image of the MFMA edge kernel
+    // LDS image of the MFMA edge kernel: LayerNorm affines; second v Linear
     float* img = a + A_IMG;
-    HIP_TRY(launch_pack_rbf_scale(wkc, wvc, a + A_RBF_SC, s));   // power-of-two scales of the split-f16 rbf tables
-    HIP_TRY(launch_pack_frag(wkc, 0, a + A_RBF_SC, img + IMG_FRAG_K, s));
-    HIP_TRY(launch_pack_frag(wvc, blk == 0 ? 1 : 0, a + A_RBF_SC + 4, img + IMG_FRAG_V, s));
-    if (blk == 0) HIP_TRY(launch_pack_frag(wvc, 0, a + A_RBF_SC + 4, a + A_FRAGV_EM, s));   // edge-major v table for the x2h backward
-    HIP_TRY(launch_pack_dwt(wkc, wvc, img + IMG_WT, s));
     CP(gk, H, 0, 0, img + IMG_LN + 0 * H, H, 1, H);
     CP(bek, H, 0, 0, img + IMG_LN + 1 * H, H, 1, H);
     CP(gv, H, 0, 0, img + IMG_LN + 2 * H, H, 1, H);
     CP(bev, H, 0, 0, img + IMG_LN + 3 * H, H, 1, H);
     if (blk == 0) {
-        HIP_TRY(launch_pack_wbv_swz(wv1, img + IMG_WBV, s));  // row-major (n, m), chunk-swizzled
         CP(wv1, H, 0, 1, a + A_WBV, H, H, H);   // [m][n]
         CP(bv1, H, 0, 0, a + A_BBV, H, 1, H);
     } else {
         CP(wv1, H, 0, 0, a + A_WBV, H, HEADS, H);  // [head][m]
         CP(bv1, HEADS, 0, 0, a + A_BBV, HEADS, 1, HEADS);
     }
-    return flush_pack(s);
+    return CBGX_OK;
+}
+
+// copies that read the centred first Linears stage 1 has just produced on this stream
+static int queue_centred_copies(const BlockRef& r, hipStream_t s) {
+    float* a = r.a;
+    CP(a + A_WAKC, KV_IN, NT, 1, a + A_WRC, 2 * H, NT * G, H);
+    CP(a + A_WAVC, KV_IN, NT, 1, a + A_WRC + H, 2 * H, NT * G, H);
+    return CBGX_OK;
+}
+
+static int pack_attention_blocks(const BlockRef* refs, int n_blocks, hipStream_t s) {
+    for (int k0 = 0; k0 < n_blocks; k0 += PACK_BLOCKS_MAX) {
+        const int nb = n_blocks - k0 < PACK_BLOCKS_MAX ? n_blocks - k0 : PACK_BLOCKS_MAX;
+        PackBlocks pb;
+        memset(&pb, 0, sizeof(pb));
+        pb.n = nb;
+        for (int k = 0; k < nb; ++k) {
+            const BlockRef& r = refs[k0 + k];
+            pb.wk0[k] = r.p[0]; pb.bk0[k] = r.p[1]; pb.wk1[k] = r.p[4];
+            pb.wv0[k] = r.p[6]; pb.bv0[k] = r.p[7]; pb.wv1[k] = r.p[10];
+            pb.wq0[k] = r.p[12]; pb.bq0[k] = r.p[13]; pb.wq1[k] = r.p[16];
+            pb.att[k] = r.a;
+            pb.x2h[k] = r.blk == 0;
+            int rc = queue_block_copies(r, s);
+            if (rc) return rc;
+        }
+        { int rc = flush_pack(s); if (rc) return rc; }
+        HIP_TRY(launch_pack_stage1(pb, s));
+        for (int k = 0; k < nb; ++k) { int rc = queue_centred_copies(refs[k0 + k], s); if (rc) return rc; }
+        { int rc = flush_pack(s); if (rc) return rc; }
+        HIP_TRY(launch_pack_stage2(pb, s));
+    }
+    return CBGX_OK;
 }
 
 int cbgx_pack_weights(const float* const* t, int num_tensors, int L, int C, float* packed, void* stream) {
@@ -275,13 +302,13 @@ int cbgx_pack_weights(const float* const* t, int num_tensors, int L, int C, floa
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(packed, 0, packed_floats(L, C) * sizeof(float), s));
     { int rc = pack_gate_section(t, packed, s); if (rc) return rc; }
-    for (int l = 0; l < L; ++l) {
-        for (int blk = 0; blk < 2; ++blk) {
-            const float* const* p = t + 6 + 36 * l + 18 * blk;  // k(6) v(6) q(6)
-            float* a = packed + (blk == 0 ? x2h_off(l) : h2x_off(l));
-            int rc = pack_attention_block(p, blk, a, s);
-            if (rc) return rc;
-        }
+    {
+        std::vector<BlockRef> refs;
+        for (int l = 0; l < L; ++l)
+            for (int blk = 0; blk < 2; ++blk)
+                refs.push_back(BlockRef{t + 6 + 36 * l + 18 * blk /* k(6) v(6) q(6) */, blk, packed + (blk == 0 ? x2h_off(l) : h2x_off(l))});
+        int rc = pack_attention_blocks(refs.data(), (int)refs.size(), s);
+        if (rc) return rc;
     }
     const float* const* c = t + 6 + 36 * L;
     float* cp = packed + cls_off(L);
@@ -307,10 +334,9 @@ int cbgx_pack_h2x_stack(const float* const* t, int num_tensors, int L, float* pa
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(packed, 0, cbgx_packed_h2x_stack_floats(L) * sizeof(float), s));
     { int rc = pack_gate_section(t, packed, s); if (rc) return rc; }
-    for (int l = 0; l < L; ++l) {
-        int rc = pack_attention_block(t + 6 + 18 * l, 1, packed + GATE_SIZE + (size_t)l * ATT_SIZE, s);
-        if (rc) return rc;
-    }
+    std::vector<BlockRef> refs;
+    for (int l = 0; l < L; ++l) refs.push_back(BlockRef{t + 6 + 18 * l, 1, packed + GATE_SIZE + (size_t)l * ATT_SIZE});
+    { int rc = pack_attention_blocks(refs.data(), (int)refs.size(), s); if (rc) return rc; }
     return flush_pack(s);
 }
 

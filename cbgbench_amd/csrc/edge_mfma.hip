@@ -620,46 +620,51 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 // ------------------------------------------------------------------------------------------------
 // split-f16 pieces of the rbf columns of a (centred) first Linear W_a [128][340], block order [type][t] (layout.h): a weight
 // w is carried as h = f16(w) (round to nearest) and l = f16(w - h)
-// rbf table scales of one attention block (layout.h A_RBF_SC): per path the exponent kw that puts the largest |Wr| of all four
-// edge types into [2^14, 2^15), clamped to RBF_KW_MAX; one workgroup of 256 threads
-__global__ void pack_rbf_scale_kernel(const float* __restrict__ wk, const float* __restrict__ wv, float* __restrict__ sc) {
-    __shared__ float red[256];
-    for (int kv = 0; kv < 2; ++kv) {
-        const float* w = kv ? wv : wk;
-        float mx = 0.f;
-        for (int u = threadIdx.x; u < H * NT * G; u += 256) mx = fmaxf(mx, fabsf(w[(size_t)(u / (NT * G)) * KV_IN + NT + u % (NT * G)]));
-        red[threadIdx.x] = mx;
-        __syncthreads();
-        for (int o = 128; o >= 1; o >>= 1) {
-            if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            const int E = (int)((__float_as_uint(red[0]) >> 23) & 0xffu);      // max in [2^(E-127), 2^(E-126))
-            const int kw = max(-80, min(RBF_KW_MAX, 141 - E));
-            const float S = ldexpf(1.f, kw + RBF_EXP);
-            sc[4 * kv + 0] = S;
-            sc[4 * kv + 1] = 1.f / ((float)H * S * S);
-            sc[4 * kv + 2] = 1.f / S;
-            sc[4 * kv + 3] = (float)kw;
-        }
-        __syncthreads();
+// ---- pack kernels, one launch for all attention blocks (blockIdx.y = block; kernels.h PackBlocks) -------------------------------
+// rbf table scales of a block (layout.h A_RBF_SC): per path the exponent kw that puts the largest |Wr| of all four edge types
+// into [2^14, 2^15), clamped to RBF_KW_MAX; one 1024-thread workgroup per (path, block), from the CENTRED first Linears
+__global__ __launch_bounds__(1024) void pack_rbf_scale_kernel(PackBlocks pb) {
+    __shared__ float red[16];
+    const int kv = blockIdx.x;
+    float* att = pb.att[blockIdx.y];
+    const float* w = att + (kv ? A_WAVC : A_WAKC);
+    float mx = 0.f;
+    // row m of the first Linear holds its 80 rbf columns contiguously at [m][NT .. NT + 80)
+    for (int u = threadIdx.x; u < H * NT * G; u += 1024) mx = fmaxf(mx, fabsf(w[(size_t)(u / (NT * G)) * KV_IN + NT + u % (NT * G)]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) mx = fmaxf(mx, red[k]);
+        const int E = (int)((__float_as_uint(mx) >> 23) & 0xffu);      // max in [2^(E-127), 2^(E-126))
+        const int kw = max(-80, min(RBF_KW_MAX, 141 - E));
+        const float S = ldexpf(1.f, kw + RBF_EXP);
+        float* sc = att + A_RBF_SC + 4 * kv;
+        sc[0] = S;
+        sc[1] = 1.f / ((float)H * S * S);
+        sc[2] = 1.f / S;
+        sc[3] = (float)kw;
     }
 }
 
-hipError_t launch_pack_rbf_scale(const float* wk, const float* wv, float* sc, hipStream_t s) {
-    hipLaunchKernelGGL(pack_rbf_scale_kernel, dim3(1), dim3(256), 0, s, wk, wv, sc);
-    return hipGetLastError();
-}
-
-// `sc` = the path's A_RBF_SC record (its kw entry, written by pack_rbf_scale_kernel earlier on the same stream)
-__global__ void pack_frag_kernel(const float* __restrict__ w_a, int mode, const float* __restrict__ sc, float* __restrict__ dst) {
+// split-f16 pieces of the rbf columns of a (centred) first Linear W_a [128][340], block order [type][t] (layout.h): a weight
+// w 2^kw is carried as h = f16(.) (round to nearest) and l = f16(. - h).  blockIdx.z: 0 = k table (edge-major), 1 = v table
+// (x2h: channel-major B operand; h2x: edge-major), 2 = the edge-major v table of x2h blocks (training backward, A_FRAGV_EM)
+__global__ void pack_frag_kernel(PackBlocks pb) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (type*8 + t)*64 + lane
     if (idx >= NT * 8 * 64) return;
+    float* att = pb.att[blockIdx.y];
+    const bool x2h = pb.x2h[blockIdx.y] != 0;
+    const int which = blockIdx.z;
+    if (which == 2 && !x2h) return;
+    const float* w_a = att + (which == 0 ? A_WAKC : A_WAVC);
+    const int mode = which == 1 && x2h ? 1 : 0;
+    float* dst = which == 0 ? att + A_IMG + IMG_FRAG_K : (which == 1 ? att + A_IMG + IMG_FRAG_V : att + A_FRAGV_EM);
     const int lane = idx & 63, t = (idx >> 6) & 7, type = idx >> 9;
     const int c = lane & 15, q = lane >> 4;
     const int m = mode == 0 ? 16 * t + c : 64 * (t >> 2) + 4 * c + (t & 3);
-    const int kw = (int)sc[3];
+    const int kw = (int)att[A_RBF_SC + (which == 0 ? 0 : 4) + 3];
     _Float16 h[5], l[5];
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
@@ -676,30 +681,36 @@ __global__ void pack_frag_kernel(const float* __restrict__ w_a, int mode, const 
     a2[0] = l[3]; a2[1] = l[4];
 }
 
-// dWt[dst class lig_i][k|v][m] = Wt[type(src lig, lig_i)][m] - Wt[type(src prot, lig_i)][m]
-__global__ void pack_dwt_kernel(const float* __restrict__ wk, const float* __restrict__ wv, float* __restrict__ dst) {
+// dWt[dst class lig_i][k|v][m] = Wt[type(src lig, lig_i)][m] - Wt[type(src prot, lig_i)][m]   (centred first Linears)
+__global__ void pack_dwt_kernel(PackBlocks pb) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // [lig_i][kv][m]
     if (idx >= 2 * 2 * H) return;
+    float* att = pb.att[blockIdx.y];
     const int m = idx & 127, kv = (idx >> 7) & 1, li = idx >> 8;
-    const float* w = kv ? wv : wk;
+    const float* w = att + (kv ? A_WAVC : A_WAKC);
     const int tl = li ? 0 : 1, tp = li ? 2 : 3;
-    dst[idx] = w[(size_t)m * KV_IN + tl] - w[(size_t)m * KV_IN + tp];
+    att[A_IMG + IMG_WT + idx] = w[(size_t)m * KV_IN + tl] - w[(size_t)m * KV_IN + tp];
 }
 
-__global__ void pack_wbv_swz_kernel(const float* __restrict__ w, float* __restrict__ dst) {
+// x2h blocks: second v Linear [128 n][128 m] with its 16-byte chunks XOR-swizzled by the head (n >> 3)
+__global__ void pack_wbv_swz_kernel(PackBlocks pb) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // n * 128 + m
-    if (idx >= H * H) return;
+    if (idx >= H * H || !pb.x2h[blockIdx.y]) return;
     const int n = idx >> 7, m = idx & 127;
-    dst[n * H + ((((m >> 2) ^ ((n >> 3) & 15)) << 2) | (m & 3))] = w[idx];
+    pb.att[blockIdx.y][A_IMG + IMG_WBV + n * H + ((((m >> 2) ^ ((n >> 3) & 15)) << 2) | (m & 3))] = pb.wv1[blockIdx.y][idx];
 }
 
-// centre a Linear over its 128 output channels: wc = w - colmean(w), bc = b - mean(b)   (w [128][cols])
-__global__ void center_linear_kernel(const float* __restrict__ w, const float* __restrict__ b, int cols,
-                                     float* __restrict__ wc, float* __restrict__ bc) {
-    const int col = blockIdx.x;  // col == cols -> the bias
+// centre the first Linears of k and v over their 128 output channels: wc = w - colmean(w), bc = b - mean(b)   (w [128][340]);
+// blockIdx.x = column (KV_IN -> the bias), blockIdx.y = 2 block + (k | v)
+__global__ void center_linear_kernel(PackBlocks pb) {
+    const int col = blockIdx.x, blk = blockIdx.y >> 1, kv = blockIdx.y & 1;
+    const float* w = kv ? pb.wv0[blk] : pb.wk0[blk];
+    const float* b = kv ? pb.bv0[blk] : pb.bk0[blk];
+    float* wc = pb.att[blk] + (kv ? A_WAVC : A_WAKC);
+    float* bc = pb.att[blk] + (kv ? A_BAVC : A_BAKC);
     __shared__ float red[128];
     const int r = threadIdx.x;
-    const float v = col < cols ? w[(size_t)r * cols + col] : b[r];
+    const float v = col < KV_IN ? w[(size_t)r * KV_IN + col] : b[r];
     red[r] = v;
     __syncthreads();
     for (int o = 64; o >= 1; o >>= 1) {
@@ -707,26 +718,23 @@ __global__ void center_linear_kernel(const float* __restrict__ w, const float* _
         __syncthreads();
     }
     const float mean = red[0] * (1.f / 128.f);
-    if (col < cols) wc[(size_t)r * cols + col] = v - mean; else bc[r] = v - mean;
+    if (col < KV_IN) wc[(size_t)r * KV_IN + col] = v - mean; else bc[r] = v - mean;
 }
 
-hipError_t launch_center_linear(const float* w, const float* b, int cols, float* wc, float* bc, hipStream_t s) {
-    hipLaunchKernelGGL(center_linear_kernel, dim3(cols + 1), dim3(128), 0, s, w, b, cols, wc, bc);
+hipError_t launch_pack_stage1(const PackBlocks& pb, hipStream_t s) {
+    if (pb.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(center_linear_kernel, dim3(KV_IN + 1, 2 * pb.n), dim3(128), 0, s, pb);
     return hipGetLastError();
 }
 
-hipError_t launch_pack_wbv_swz(const float* w, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(pack_wbv_swz_kernel, dim3(H * H / 256), dim3(256), 0, s, w, dst);
-    return hipGetLastError();
-}
-
-hipError_t launch_pack_dwt(const float* wk, const float* wv, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(pack_dwt_kernel, dim3(2), dim3(256), 0, s, wk, wv, dst);
-    return hipGetLastError();
-}
-
-hipError_t launch_pack_frag(const float* w_a, int mode, const float* sc, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(pack_frag_kernel, dim3(NT * 8 * 64 / 256), dim3(256), 0, s, w_a, mode, sc, dst);
+hipError_t launch_pack_stage2(const PackBlocks& pb, hipStream_t s) {
+    if (pb.n == 0) return hipSuccess;
+    hipError_t e = launch_pack_node_tables(pb, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pack_rbf_scale_kernel, dim3(2, pb.n), dim3(1024), 0, s, pb);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(NT * 8 * 64 / 256, pb.n, 3), dim3(256), 0, s, pb);
+    hipLaunchKernelGGL(pack_dwt_kernel, dim3(2, pb.n), dim3(256), 0, s, pb);
+    hipLaunchKernelGGL(pack_wbv_swz_kernel, dim3(H * H / 256, pb.n), dim3(256), 0, s, pb);
     return hipGetLastError();
 }
 

@@ -41,15 +41,28 @@ hipError_t launch_attention_v1(bool x2h, const float* att, const float* x, const
 #else
 constexpr int g_edge_impl = 0;
 #endif
-// split-f16 rbf weight table of one centred first Linear (layout.h): mode 0 edge-major (A operand), 1 channel-major (B operand)
-hipError_t launch_pack_frag(const float* w_a, int mode, const float* sc, float* dst, hipStream_t s);
-// A_RBF_SC record of one attention block from its centred first Linears (k, v)
-hipError_t launch_pack_rbf_scale(const float* wkc, const float* wvc, float* sc, hipStream_t s);
-hipError_t launch_center_linear(const float* w, const float* b, int cols, float* wc, float* bc, hipStream_t s);
-hipError_t launch_pack_dwt(const float* wk, const float* wv, float* dst, hipStream_t s);
-hipError_t launch_pack_bn2(const float* att_wakc, const float* bq0, float* att, hipStream_t s);
-// x2h second v Linear [128 n][128 m] with 16-byte chunks XOR-swizzled by head (n >> 3)
-hipError_t launch_pack_wbv_swz(const float* w, float* dst, hipStream_t s);
+// ---- weight packing, batched over attention blocks (the weights are re-packed every training step: 18 blocks x 12 small kernels
+// were 216 launches and 1.5 ms per step; one launch per kernel for all blocks is ~20) ----------------------------------------------
+constexpr int PACK_BLOCKS_MAX = 20;
+struct PackBlocks {                       // per attention block: the reference tensors the pack kernels read and the block's ATT region
+    const float* wk0[PACK_BLOCKS_MAX];    // k first Linear [128][340], its bias
+    const float* bk0[PACK_BLOCKS_MAX];
+    const float* wv0[PACK_BLOCKS_MAX];
+    const float* bv0[PACK_BLOCKS_MAX];
+    const float* wq0[PACK_BLOCKS_MAX];    // q first Linear [128][128], its bias
+    const float* bq0[PACK_BLOCKS_MAX];
+    const float* wq1[PACK_BLOCKS_MAX];    // q second Linear [128][128]
+    const float* wk1[PACK_BLOCKS_MAX];    // k second Linear [128][128]
+    const float* wv1[PACK_BLOCKS_MAX];    // v second Linear ([128][128] x2h, [16][128] h2x)
+    float* att[PACK_BLOCKS_MAX];
+    unsigned char x2h[PACK_BLOCKS_MAX];
+    int n;
+};
+// stage 1: centred first Linears of k and v (A_WAKC / A_BAKC / A_WAVC / A_BAVC) of every block
+hipError_t launch_pack_stage1(const PackBlocks& pb, hipStream_t s);
+// stage 2 (after stage 1 on the same stream): column scales, split-f16 node tables, Wbk fragments, bn2, rbf scales, rbf fragment
+// tables (k, v, and the edge-major v table of x2h blocks), dWt, the swizzled Wbv image of x2h blocks
+hipError_t launch_pack_stage2(const PackBlocks& pb, hipStream_t s);
 // second-generation graph kernels (graph_mfma.hip)
 hipError_t launch_pack_gate_img(const float* w1, const float* b1, const float* g, const float* be, const float* w2,
                                 float* img, hipStream_t s);
@@ -60,8 +73,7 @@ hipError_t launch_gate_mfma(const float* packed, const float* x, const int32_t* 
 hipError_t launch_lig_proximity(const float* x, const int32_t* graph_ptr, int n_graphs, const uint8_t* lig,
                                 const float* r32sq, int n_nodes, uint8_t* dirty, hipStream_t s);
 // MFMA node kernels (node_mfma.hip): P = h Wn + bn, q = MLP tail, Qt = folded query
-hipError_t launch_pack_node_frags(const float* wk0, const float* wv0, const float* wq0, const float* wq1,
-                                  const float* wbk, float* att, hipStream_t s);
+hipError_t launch_pack_node_tables(const PackBlocks& pb, hipStream_t s);     // node_mfma.hip part of stage 2
 hipError_t launch_build_active(const uint8_t* flag, int n, int* list, int* count, hipStream_t s);
 hipError_t launch_mark_seed(const uint8_t* a, const uint8_t* b, int n, uint8_t* m, hipStream_t s);
 hipError_t launch_mark_from_nbr(const uint8_t* flag, const int32_t* nbr, const int32_t* deg, int n, uint8_t* out,

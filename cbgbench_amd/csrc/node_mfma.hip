@@ -646,78 +646,84 @@ __device__ __forceinline__ float col_pow2_inv(float mx) {
     return __uint_as_float((unsigned)(127 - kc) << 23);
 }
 // per-column inverse scales of the two split-f16 node tables: cinv[0..640) node projection, cinv[640..768) query MLP second Linear
-__global__ void pack_colscale_kernel(const float* __restrict__ wk0, const float* __restrict__ wv0, const float* __restrict__ wq0,
-                                     const float* __restrict__ wq1, float* __restrict__ cinv_proj, float* __restrict__ cinv_q1) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- one launch for all attention blocks (blockIdx.y = block; kernels.h PackBlocks); wk0 / wv0 below are the CENTRED first Linears
+// one wavefront per column (the 128 weights of a column are contiguous in every source tensor: two coalesced loads per lane)
+__global__ __launch_bounds__(256) void pack_colscale_kernel(PackBlocks pb) {
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (col >= PROW + H) return;
+    float* att = pb.att[blockIdx.y];
+    const float *wk0 = att + A_WAKC, *wv0 = att + A_WAVC, *wq0 = pb.wq0[blockIdx.y], *wq1 = pb.wq1[blockIdx.y];
     float mx = 0.f;
-    for (int k = 0; k < H; ++k)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int k = lane + 64 * u;
         mx = fmaxf(mx, fabsf(col < PROW ? nproj_weight(wk0, wv0, wq0, col, k) : wq1[(size_t)(col - PROW) * H + k]));
-    if (col < PROW) cinv_proj[col] = col_pow2_inv(mx); else cinv_q1[col - PROW] = col_pow2_inv(mx);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) { if (col < PROW) att[A_NPROJ_CINV + col] = col_pow2_inv(mx); else att[A_WQ1_CINV + col - PROW] = col_pow2_inv(mx); }
 }
 
-__global__ void pack_nproj_kernel(const float* __restrict__ wk0, const float* __restrict__ wv0,
-                                  const float* __restrict__ wq0, const float* __restrict__ cinv, _Float16* __restrict__ dst) {
+// node projection: split-f16 chunk tables, dst[ch][part][ct][u][lane][j] (f16) = hi / lo of
+// Wcat[col = 64ch + 4c + ct][k = 16 (2u + (j >> 2)) + 4q + (j & 3)] 2^kc; Wcat rows are assembled from W_a_k / W_a_v (dst and src
+// thirds) and W_q0, exactly like the K-major A_WN table.
+__global__ void pack_nproj_kernel(PackBlocks pb) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per weight: ((ch*4 + ct)*4 + u)*64*8 + lane*8 + j
     if (idx >= NP_CHUNKS * 4 * 4 * 64 * 8) return;
+    float* att = pb.att[blockIdx.y];
     const int j = idx & 7, lane = (idx >> 3) & 63, u = (idx >> 9) & 3, ct = (idx >> 11) & 3, ch = idx >> 13;
     const int c = lane & 15, q = lane >> 4;
     const int col = 64 * ch + 4 * c + ct, k = 16 * (2 * u + (j >> 2)) + 4 * q + (j & 3);
-    const float v = nproj_weight(wk0, wv0, wq0, col, k) * (1.f / cinv[col]);   // exact: a power of two
+    const float v = nproj_weight(att + A_WAKC, att + A_WAVC, pb.wq0[blockIdx.y], col, k) * (1.f / att[A_NPROJ_CINV + col]);   // exact: a power of two
     const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
-    _Float16* chunk = dst + (size_t)ch * (NP_CHUNK * 2);                   // f16 elements per chunk
+    _Float16* chunk = reinterpret_cast<_Float16*>(att + A_NPROJ_FRAG) + (size_t)ch * (NP_CHUNK * 2);   // f16 elements per chunk
     const size_t off = ((size_t)(ct * 4 + u) * 64 + lane) * 8 + j;
     chunk[off] = hi;
     chunk[(size_t)4 * 4 * 64 * 8 + off] = lo;
 }
 
-__global__ void pack_wq1_kernel(const float* __restrict__ wq1, const float* __restrict__ cinv, _Float16* __restrict__ dst) {
+__global__ void pack_wq1_kernel(PackBlocks pb) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per weight: [nt 8][u 4][lane 64][j 8]
     if (idx >= H * H) return;
+    float* att = pb.att[blockIdx.y];
     const int j = idx & 7, lane = (idx >> 3) & 63, u = (idx >> 9) & 3, nt = idx >> 11;
     const int c = lane & 15, q = lane >> 4;
     const int n = 64 * (nt >> 2) + 4 * c + (nt & 3);
-    const float v = wq1[(size_t)n * H + 16 * (2 * u + (j >> 2)) + 4 * q + (j & 3)] * (1.f / cinv[n]);
+    const float v = pb.wq1[blockIdx.y][(size_t)n * H + 16 * (2 * u + (j >> 2)) + 4 * q + (j & 3)] * (1.f / att[A_WQ1_CINV + n]);
     const _Float16 hi = (_Float16)v;
+    _Float16* dst = reinterpret_cast<_Float16*>(att + A_WQ1_FRAG);
     dst[idx] = hi;
     dst[(size_t)H * H + idx] = (_Float16)(v - (float)hi);
 }
 
-__global__ void pack_wbk_kernel(const float* __restrict__ wbk, float* __restrict__ dst) {
+__global__ void pack_wbk_kernel(PackBlocks pb) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // [a][g][lane][j*2+step]
     if (idx >= NF_FRAG) return;
     const int step = idx & 1, j = (idx >> 1) & 3, lane = (idx >> 3) & 63, g = (idx >> 9) & 1, a = idx >> 10;
     const int c = lane & 15, q = lane >> 4;
-    dst[idx] = wbk[(size_t)(8 * a + 2 * q + step) * H + 64 * g + 4 * c + j] * 0.35355339059327376220f;
+    pb.att[blockIdx.y][A_WBK_FRAG + idx] = pb.wk1[blockIdx.y][(size_t)(8 * a + 2 * q + step) * H + 64 * g + 4 * c + j] * 0.35355339059327376220f;
 }
 
 // bn2[li][col]: PDk | PDv get the centred bias plus the type column of a protein source for destination class li
-__global__ void pack_bn2_kernel(const float* att_in, const float* bq0, float* att) {
+__global__ void pack_bn2_kernel(PackBlocks pb) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 2 * PROW) return;
+    float* att = pb.att[blockIdx.y];
     const int li = idx / PROW, col = idx % PROW, blk = col >> 7, n = col & 127;
     const int tp = li ? 2 : 3;  // type(src prot, dst lig) = 2, type(src prot, dst prot) = 3
     float v = 0.f;
-    if (blk == 0) v = att_in[A_BAKC + n] + att_in[A_WAKC + (size_t)n * KV_IN + tp];
-    else if (blk == 1) v = att_in[A_BAVC + n] + att_in[A_WAVC + (size_t)n * KV_IN + tp];
-    else if (blk == 4) v = bq0[n];
+    if (blk == 0) v = att[A_BAKC + n] + att[A_WAKC + (size_t)n * KV_IN + tp];
+    else if (blk == 1) v = att[A_BAVC + n] + att[A_WAVC + (size_t)n * KV_IN + tp];
+    else if (blk == 4) v = pb.bq0[blockIdx.y][n];
     att[A_BN2 + idx] = v;
 }
 
-hipError_t launch_pack_bn2(const float* att_in, const float* bq0, float* att, hipStream_t s) {
-    hipLaunchKernelGGL(pack_bn2_kernel, dim3((2 * PROW + 255) / 256), dim3(256), 0, s, att_in, bq0, att);
-    return hipGetLastError();
-}
-
-hipError_t launch_pack_node_frags(const float* wk0, const float* wv0, const float* wq0, const float* wq1,
-                                  const float* wbk, float* att, hipStream_t s) {
-    hipLaunchKernelGGL(pack_colscale_kernel, dim3((PROW + H + 255) / 256), dim3(256), 0, s, wk0, wv0, wq0, wq1, att + A_NPROJ_CINV,
-                       att + A_WQ1_CINV);
-    hipLaunchKernelGGL(pack_nproj_kernel, dim3(NP_CHUNKS * 4 * 4 * 64 * 8 / 256), dim3(256), 0, s, wk0, wv0, wq0, att + A_NPROJ_CINV,
-                       reinterpret_cast<_Float16*>(att + A_NPROJ_FRAG));
-    hipLaunchKernelGGL(pack_wq1_kernel, dim3(H * H / 256), dim3(256), 0, s, wq1, att + A_WQ1_CINV,
-                       reinterpret_cast<_Float16*>(att + A_WQ1_FRAG));
-    hipLaunchKernelGGL(pack_wbk_kernel, dim3(NF_FRAG / 256), dim3(256), 0, s, wbk, att + A_WBK_FRAG);
+hipError_t launch_pack_node_tables(const PackBlocks& pb, hipStream_t s) {
+    hipLaunchKernelGGL(pack_colscale_kernel, dim3((PROW + H + 3) / 4, pb.n), dim3(256), 0, s, pb);
+    hipLaunchKernelGGL(pack_nproj_kernel, dim3(NP_CHUNKS * 4 * 4 * 64 * 8 / 256, pb.n), dim3(256), 0, s, pb);
+    hipLaunchKernelGGL(pack_wq1_kernel, dim3(H * H / 256, pb.n), dim3(256), 0, s, pb);
+    hipLaunchKernelGGL(pack_wbk_kernel, dim3(NF_FRAG / 256, pb.n), dim3(256), 0, s, pb);
+    hipLaunchKernelGGL(pack_bn2_kernel, dim3((2 * PROW + 255) / 256, pb.n), dim3(256), 0, s, pb);
     return hipGetLastError();
 }
 
