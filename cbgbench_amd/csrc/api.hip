@@ -279,6 +279,8 @@ static int pack_attention_blocks(const BlockRef* refs, int n_blocks, hipStream_t
             pb.wv0[k] = r.p[6]; pb.bv0[k] = r.p[7]; pb.wv1[k] = r.p[10];
             pb.wq0[k] = r.p[12]; pb.bq0[k] = r.p[13]; pb.wq1[k] = r.p[16];
             pb.att[k] = r.a;
+            pb.nsrc[k][0] = r.a + A_WAKC; pb.nsrc[k][1] = r.a + A_WAVC; pb.nsrc[k][2] = r.a + A_WAKC; pb.nsrc[k][3] = r.a + A_WAVC;
+            pb.nsrc[k][4] = r.p[12];
             pb.x2h[k] = r.blk == 0;
             int rc = queue_block_copies(r, s);
             if (rc) return rc;

@@ -55,6 +55,10 @@ struct PackBlocks {                       // per attention block: the reference 
     const float* wk1[PACK_BLOCKS_MAX];    // k second Linear [128][128]
     const float* wv1[PACK_BLOCKS_MAX];    // v second Linear ([128][128] x2h, [16][128] h2x)
     float* att[PACK_BLOCKS_MAX];
+    // the five 128-column groups of the assembled node projection (PDk | PDv | PSk | PSv | q hidden): base pointer of each group's
+    // source matrix -- the CENTRED first Linears inside `att` for the first four, wq0 for the fifth.  A table indexed by the group,
+    // not an if-chain over pointers: hipcc 7.2 selected the wrong base for the fifth group in the wave-per-column scale kernel.
+    const float* nsrc[PACK_BLOCKS_MAX][5];
     unsigned char x2h[PACK_BLOCKS_MAX];
     int n;
 };

@@ -631,13 +631,11 @@ hipError_t launch_node_gemm(const float* A, int lda, const float* Wt, const floa
 // Wcat[col = 64ch + 4c + ct][k = 16 (2u + (j >> 2)) + 4q + (j & 3)]; Wcat rows are assembled from W_a_k / W_a_v (dst and src
 // thirds) and W_q0, exactly like the K-major A_WN table.
 // weight of the assembled node projection Wcat[col][k] (col = PDk | PDv | PSk | PSv | q hidden)
-__device__ __forceinline__ float nproj_weight(const float* wk0, const float* wv0, const float* wq0, int col, int k) {
-    const int blk = col >> 7, n = col & 127;
-    if (blk == 0) return wk0[(size_t)n * KV_IN + NT + NT * G + k];            // PDk
-    if (blk == 1) return wv0[(size_t)n * KV_IN + NT + NT * G + k];            // PDv
-    if (blk == 2) return wk0[(size_t)n * KV_IN + NT + NT * G + H + k];        // PSk
-    if (blk == 3) return wv0[(size_t)n * KV_IN + NT + NT * G + H + k];        // PSv
-    return wq0[(size_t)n * H + k];                                            // q hidden
+__device__ __forceinline__ float nproj_weight(const PackBlocks& pb, int block, int col, int k) {
+    const int grp = col >> 7, n = col & 127;      // PDk, PDv: destination third of W_a; PSk, PSv: source third; q hidden: wq0
+    const int ld = grp < 4 ? KV_IN : H;
+    const int off = grp < 2 ? NT + NT * G : (grp < 4 ? NT + NT * G + H : 0);
+    return pb.nsrc[block][grp][(size_t)n * ld + off + k];
 }
 // 2^-kc for a column whose largest |w| is mx: w 2^kc lands in [2^14, 2^15) (kc clamped so that both factors are normal)
 __device__ __forceinline__ float col_pow2_inv(float mx) {
@@ -652,12 +650,12 @@ __global__ __launch_bounds__(256) void pack_colscale_kernel(PackBlocks pb) {
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (col >= PROW + H) return;
     float* att = pb.att[blockIdx.y];
-    const float *wk0 = att + A_WAKC, *wv0 = att + A_WAVC, *wq0 = pb.wq0[blockIdx.y], *wq1 = pb.wq1[blockIdx.y];
+    const float* wq1 = pb.wq1[blockIdx.y];
     float mx = 0.f;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int k = lane + 64 * u;
-        mx = fmaxf(mx, fabsf(col < PROW ? nproj_weight(wk0, wv0, wq0, col, k) : wq1[(size_t)(col - PROW) * H + k]));
+        mx = fmaxf(mx, fabsf(col < PROW ? nproj_weight(pb, blockIdx.y, col, k) : wq1[(size_t)(col - PROW) * H + k]));
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -674,7 +672,7 @@ __global__ void pack_nproj_kernel(PackBlocks pb) {
     const int j = idx & 7, lane = (idx >> 3) & 63, u = (idx >> 9) & 3, ct = (idx >> 11) & 3, ch = idx >> 13;
     const int c = lane & 15, q = lane >> 4;
     const int col = 64 * ch + 4 * c + ct, k = 16 * (2 * u + (j >> 2)) + 4 * q + (j & 3);
-    const float v = nproj_weight(att + A_WAKC, att + A_WAVC, pb.wq0[blockIdx.y], col, k) * (1.f / att[A_NPROJ_CINV + col]);   // exact: a power of two
+    const float v = nproj_weight(pb, blockIdx.y, col, k) * (1.f / att[A_NPROJ_CINV + col]);   // exact: a power of two
     const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
     _Float16* chunk = reinterpret_cast<_Float16*>(att + A_NPROJ_FRAG) + (size_t)ch * (NP_CHUNK * 2);   // f16 elements per chunk
     const size_t off = ((size_t)(ct * 4 + u) * 64 + lane) * 8 + j;
