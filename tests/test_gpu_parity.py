@@ -428,6 +428,54 @@ def test_sample_many_equals_sample(synthetic_sd):
             assert torch.equal(a[t][0], b[t][0]) and torch.equal(a[t][1], b[t][1]) and torch.equal(a[t][2], b[t][2])
 
 
+def test_scheduling_hints_do_not_change_results(model):
+    """cbgx_set_edge_workgroups (CUs the persistent x2h edge kernel may take) and the number of caller streams are scheduling
+    only: a denoiser call gives the same bits with 64 workgroups as with all, and on a fifth caller stream (the library keeps an
+    auxiliary stream for four; the fifth runs the serial schedule)"""
+    from cbgbench_amd import _native
+    x, h, batch_idx, lig_flag, gen, gp = _composed(model, synthetic.denovo_batch(4, seed=77))
+    lib = _native.lib()
+    with torch.no_grad():
+        ref = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
+        assert lib.cbgx_set_edge_workgroups(64) == 0
+        try:
+            lim = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
+        finally:
+            assert lib.cbgx_set_edge_workgroups(0) == 64
+        outs = []
+        cur = torch.cuda.current_stream()
+        for _ in range(5):
+            sx = torch.cuda.Stream()
+            sx.wait_stream(cur)
+            with torch.cuda.stream(sx):
+                outs.append(model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp))
+        torch.cuda.synchronize()
+    for o in [lim] + outs:
+        assert all(torch.equal(a, b) for a, b in zip(ref, o))
+
+
+def test_repacking_is_deterministic_and_follows_the_weights(synthetic_sd):
+    """cbgx_pack_weights (batched over the attention blocks): packing the same parameters twice gives the same blob, changing one
+    tensor changes it, and restoring the tensor restores it bit for bit"""
+    m = C.get_model(C.default_targetdiff_config(13)).eval()
+    m.load_state_dict(synthetic_sd, strict=True)
+    m = m.to(DEV)
+    dev = torch.device(DEV)
+    a = m.denoiser.packed_weights(dev).clone()
+    m.denoiser._packed = None
+    b = m.denoiser.packed_weights(dev).clone()
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    p = m.denoiser.blocks[3].x2h_layers[0].hq_func.net[0].weight
+    with torch.no_grad():
+        saved = p.clone()
+        p.mul_(1.5)
+    c = m.denoiser.packed_weights(dev).clone()          # the in-place edit bumped the version: re-packed
+    assert not torch.equal(a, c)
+    with torch.no_grad():
+        p.copy_(saved)
+    assert torch.equal(m.denoiser.packed_weights(dev), a)
+
+
 def test_sampling_driver_end_to_end(tmp_path):
     """config YAML -> registry -> model.sample on sharded pockets -> one result file per pocket (the sample.py role)."""
     import os as _os
