@@ -608,7 +608,7 @@ def bench_sampling(args, rank, world, dev):
                         "the edges (query fold, post-aggregation value Linear), caches the ligand-free protein rows and prunes "
                         "the last layers"},
             "per_kernel": per,
-            "launches_per_denoising_step": round(sum(cnt) / (5.0 * prof_steps), 1),
+            "profiled_sections_per_denoising_step": round(sum(cnt) / (5.0 * prof_steps), 1),
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import weights as OW
@@ -630,8 +630,6 @@ def _row(out, keep=()):
         rf = out["roofline"]
         r["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us") if k in rf}
         r["roofline"]["per_kernel_us_avg"] = {k: v["us_avg"] for k, v in rf["per_kernel"].items() if v["launches"]}
-        if "launches_per_denoising_step" in rf:
-            r["launches_per_denoising_step"] = rf["launches_per_denoising_step"]
     for k in keep:
         r[k] = out["config"][k]
     return r
