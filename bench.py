@@ -365,13 +365,18 @@ def ranks_seen(dev):
 
 
 def device_identity(dev):
-    """something that names the physical GPU behind `dev` (uuid where torch exposes it, else the PCI address)"""
+    """A string that is equal for two ranks exactly when they drive the same physical GPU of this job: host name + the device
+    visibility environment + the device index under it (one node, torchrun: indices are node-global; per-rank *_VISIBLE_DEVICES
+    settings differ in the environment part).  The hardware uuid / PCI address is appended for the record when torch exposes it, but
+    is not what decides -- on some ROCm builds those fields are empty or identical."""
+    import socket
+    vis = "|".join(os.environ.get(k, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    return f"{socket.gethostname()}|{vis}|{dev.index}"
+
+
+def device_hardware_id(dev):
     pr = torch.cuda.get_device_properties(dev)
-    for attr in ("uuid", "pci_bus_id"):
-        v = getattr(pr, attr, None)
-        if v is not None:
-            return f"{attr}:{v}" + (f":{getattr(pr, 'pci_device_id', '')}:{getattr(pr, 'pci_domain_id', '')}" if attr == "pci_bus_id" else "")
-    return f"index:{dev.index}"
+    return {a: str(getattr(pr, a)) for a in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id") if hasattr(pr, a)}
 
 
 def distinct_devices(dev, world):
