@@ -575,6 +575,15 @@ class TargetDiff(nn.Module):
         traj_x, traj_c, bl_out = st["traj_x"].to(out_dev), st["traj_c"].to(out_dev), st["bl"].to(out_dev)
         return {t - 1: (traj_x[t], traj_c[t], bl_out) for t in range(T + 1)}
 
+    def _side_streams(self, dev, n):
+        """the model's own side streams, created once per device: the denoiser keeps one workspace per stream (gigabytes at 100 k
+        nodes) and libcbgx one auxiliary stream per caller stream, so the handles must not change from call to call"""
+        pool = self.__dict__.setdefault("_stream_pool", {})
+        have = pool.setdefault(str(dev), [])
+        while len(have) < n:
+            have.append(torch.cuda.Stream(dev))
+        return have[:n]
+
     @torch.no_grad()
     def sample_many(self, batches, noise_tapes=None, return_device=None, streams=3):
         """``[self.sample(b) for b in batches]`` with the batches IN FLIGHT TOGETHER, round-robin over ``streams`` HIP streams: the
@@ -590,7 +599,7 @@ class TargetDiff(nn.Module):
                     for k, b in enumerate(batches)]
         states = [self.begin_sampling(b, keep_trajectory=True) for b in batches]
         cur = torch.cuda.current_stream(dev)
-        side = [torch.cuda.Stream(dev) for _ in range(min(streams, len(states)))]
+        side = self._side_streams(dev, min(streams, len(states)))
         for sx in side:
             sx.wait_stream(cur)                      # the states were built on the caller's stream
         for t_idx in reversed(range(T)):

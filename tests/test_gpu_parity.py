@@ -430,8 +430,8 @@ def test_sample_many_equals_sample(synthetic_sd):
 
 def test_scheduling_hints_do_not_change_results(model):
     """cbgx_set_edge_workgroups (CUs the persistent x2h edge kernel may take) and the number of caller streams are scheduling
-    only: a denoiser call gives the same bits with 64 workgroups as with all, and on a fifth caller stream (the library keeps an
-    auxiliary stream for four; the fifth runs the serial schedule)"""
+    only: a denoiser call gives the same bits with 64 workgroups as with all, and on five different caller streams (the library
+    keeps an auxiliary stream for four of them and replaces the oldest entry for the fifth)"""
     from cbgbench_amd import _native
     x, h, batch_idx, lig_flag, gen, gp = _composed(model, synthetic.denovo_batch(4, seed=77))
     lib = _native.lib()
