@@ -15,7 +15,7 @@ from torch import nn
 
 from . import _native
 from .registry import get_e3_gnn, register_model
-from .targetdiff import NUM_AA, CTNVPScheduler, PLContextEmbedder, TargetDiff, masked_graph_mean, scatter_mean
+from .targetdiff import NUM_AA, BatchesInFlight, CTNVPScheduler, PLContextEmbedder, TargetDiff, masked_graph_mean, scatter_mean
 from .unitransformer import GaussianSmearing, H2XAttention, MLP, _MLP_KEYS
 
 ABSORBING_STATE = 0   # repo/utils/molecule/constants.py:8
@@ -234,7 +234,7 @@ class CoMPredictor(nn.Module):
 
 
 @register_model("diffbp")
-class DiffBP(nn.Module):
+class DiffBP(BatchesInFlight, nn.Module):
     def __init__(self, cfg):
         super().__init__()
         self.cfg = cfg
@@ -445,6 +445,18 @@ class DiffBP(nn.Module):
             stream), "cbgx_diffbp_epilogue")
         st["x_lig"], st["c_lig"] = x_next, c_next
         return st
+
+    # hooks of BatchesInFlight.sample_many
+    def _many_begin(self, batch, tape):
+        return self.begin_sampling(batch, keep_trajectory=True)
+
+    def _many_step(self, st, t_idx, tape):
+        self.denoise_step(st, t_idx, tape[t_idx] if tape is not None else None)
+
+    def _many_finish(self, st, out_dev):
+        T = self.num_diffusion_timesteps
+        traj_x, traj_c, bl_out = st["traj_x"].to(out_dev), st["traj_c"].to(out_dev), st["bl"].to(out_dev)
+        return {t - 1: (traj_x[t], traj_c[t], bl_out) for t in range(T + 1)}
 
     @torch.no_grad()
     def sample(self, batch, noise_tape=None, return_device=None):

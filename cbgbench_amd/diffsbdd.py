@@ -16,7 +16,7 @@ from torch import nn
 
 from . import _native
 from .registry import get_e3_gnn, register_model
-from .targetdiff import NUM_AA, PLContextEmbedder, TargetDiff
+from .targetdiff import NUM_AA, BatchesInFlight, PLContextEmbedder, TargetDiff
 
 
 class PredefinedNoiseSchedule(nn.Module):
@@ -179,7 +179,7 @@ class DiffsbddVariationalScheduler(nn.Module):
 
 
 @register_model("diffsbdd")
-class DiffSBDD(nn.Module):
+class DiffSBDD(BatchesInFlight, nn.Module):
     def __init__(self, cfg):
         super().__init__()
         self.cfg = cfg
@@ -420,6 +420,21 @@ class DiffSBDD(nn.Module):
         return x_fin, st["c_lig"] * 4.0
 
     @torch.no_grad()
+    # hooks of BatchesInFlight.sample_many (the tape of a batch = its list of randn draws in the reference's order)
+    def _many_begin(self, batch, tape):
+        return self.begin_sampling(batch, keep_trajectory=True, noise_draws=tape)
+
+    def _many_step(self, st, t_idx, tape):
+        self.denoise_step(st, t_idx)
+
+    def _many_finish(self, st, out_dev):
+        T = self.num_diffusion_timesteps
+        x_fin, c_fin = self.finish_sampling(st)
+        traj_x, traj_c, bl_out = st["traj_x"].to(out_dev), st["traj_c"].to(out_dev), st["bl"].to(out_dev)
+        traj = {t - 1: (traj_x[t], traj_c[t], bl_out) for t in range(T + 1)}
+        traj[0] = (x_fin.to(out_dev), c_fin.to(out_dev), bl_out)
+        return traj
+
     def sample(self, batch, noise_draws=None, return_device=None):
         """diffsbdd.py:240-319. ``noise_draws`` (tests): list of the randn tensors in the reference's draw order."""
         T = self.num_diffusion_timesteps

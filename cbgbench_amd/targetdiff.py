@@ -284,8 +284,54 @@ class PLContextEmbedder(nn.Module):
         return self.ligand_atom_emb(c_lig) + ind1
 
 
+class BatchesInFlight:
+    """``sample_many`` for the sampler classes (TargetDiff, DiffBP, DiffSBDD): ``[self.sample(b) for b in batches]`` with the batches
+    IN FLIGHT TOGETHER, round-robin over ``streams`` HIP streams.  The batches are independent (the pocket loop of sample.py:159),
+    and while one batch sits in its matrix-bound edge kernel the HBM-bound node kernels and the small kernels of the others fill what
+    it leaves (measured +5.5 % with three 200-graph batches).  Each batch's steps stay ordered on its own stream.  With
+    ``noise_tapes`` (one per batch, in the form the class's ``sample`` takes) the trajectories equal ``sample``'s bit for bit; without,
+    the torch generator is consumed step by step across the batches instead of batch by batch, i.e. the same distribution under a
+    different assignment of the draws.  A class provides ``_many_begin(batch, tape) -> state``, ``_many_step(state, t, tape)`` and
+    ``_many_finish(state, device) -> trajectory``."""
+
+    def _side_streams(self, dev, n):
+        """the model's own side streams, created once per device: the denoiser keeps one workspace per stream (gigabytes at 100 k
+        nodes) and libcbgx one auxiliary stream per caller stream, so the handles must not change from call to call"""
+        pool = self.__dict__.setdefault("_stream_pool", {})
+        have = pool.setdefault(str(dev), [])
+        while len(have) < n:
+            have.append(torch.cuda.Stream(dev))
+        return have[:n]
+
+    @torch.no_grad()
+    def sample_many(self, batches, noise_tapes=None, return_device=None, streams=3):
+        dev = batches[0]["ligand_pos"].device
+        out_dev = torch.device("cpu") if return_device is None else torch.device(return_device)
+        tape = lambda k: None if noise_tapes is None else noise_tapes[k]
+        if dev.type != "cuda" or len(batches) == 1 or streams <= 1:
+            out = []
+            for k, b in enumerate(batches):
+                st = self._many_begin(b, tape(k))
+                for t_idx in reversed(range(self.num_diffusion_timesteps)):
+                    self._many_step(st, t_idx, tape(k))
+                out.append(self._many_finish(st, out_dev))
+            return out
+        states = [self._many_begin(b, tape(k)) for k, b in enumerate(batches)]
+        cur = torch.cuda.current_stream(dev)
+        side = self._side_streams(dev, min(streams, len(states)))
+        for sx in side:
+            sx.wait_stream(cur)                      # the states were built on the caller's stream
+        for t_idx in reversed(range(self.num_diffusion_timesteps)):
+            for k, st in enumerate(states):
+                with torch.cuda.stream(side[k % len(side)]):
+                    self._many_step(st, t_idx, tape(k))
+        for sx in side:
+            cur.wait_stream(sx)
+        return [self._many_finish(st, out_dev) for st in states]
+
+
 @register_model("targetdiff")
-class TargetDiff(nn.Module):
+class TargetDiff(BatchesInFlight, nn.Module):
     def __init__(self, cfg):
         super().__init__()
         self.cfg = cfg
@@ -575,42 +621,14 @@ class TargetDiff(nn.Module):
         traj_x, traj_c, bl_out = st["traj_x"].to(out_dev), st["traj_c"].to(out_dev), st["bl"].to(out_dev)
         return {t - 1: (traj_x[t], traj_c[t], bl_out) for t in range(T + 1)}
 
-    def _side_streams(self, dev, n):
-        """the model's own side streams, created once per device: the denoiser keeps one workspace per stream (gigabytes at 100 k
-        nodes) and libcbgx one auxiliary stream per caller stream, so the handles must not change from call to call"""
-        pool = self.__dict__.setdefault("_stream_pool", {})
-        have = pool.setdefault(str(dev), [])
-        while len(have) < n:
-            have.append(torch.cuda.Stream(dev))
-        return have[:n]
+    # hooks of BatchesInFlight.sample_many
+    def _many_begin(self, batch, tape):
+        return self.begin_sampling(batch, keep_trajectory=True)
 
-    @torch.no_grad()
-    def sample_many(self, batches, noise_tapes=None, return_device=None, streams=3):
-        """``[self.sample(b) for b in batches]`` with the batches IN FLIGHT TOGETHER, round-robin over ``streams`` HIP streams: the
-        batches are independent (the pocket loop of sample.py:159), and while one batch sits in its matrix-bound edge kernel the
-        HBM-bound node kernels and the small kernels of the others fill what it leaves (measured +6 % with three 200-graph
-        batches).  Each batch's steps stay ordered on its own stream.  With ``noise_tapes`` (one per batch) the
-        trajectories equal ``sample``'s bit for bit; without, the torch generator is consumed step by step across the batches
-        instead of batch by batch, i.e. the same distribution under a different assignment of the draws."""
+    def _many_step(self, st, t_idx, tape):
+        self.denoise_step(st, t_idx, tape[t_idx] if tape is not None else None)
+
+    def _many_finish(self, st, out_dev):
         T = self.num_diffusion_timesteps
-        dev = batches[0]["ligand_pos"].device
-        if dev.type != "cuda" or len(batches) == 1 or streams <= 1:
-            return [self.sample(b, noise_tape=None if noise_tapes is None else noise_tapes[k], return_device=return_device)
-                    for k, b in enumerate(batches)]
-        states = [self.begin_sampling(b, keep_trajectory=True) for b in batches]
-        cur = torch.cuda.current_stream(dev)
-        side = self._side_streams(dev, min(streams, len(states)))
-        for sx in side:
-            sx.wait_stream(cur)                      # the states were built on the caller's stream
-        for t_idx in reversed(range(T)):
-            for k, st in enumerate(states):
-                with torch.cuda.stream(side[k % len(side)]):
-                    self.denoise_step(st, t_idx, noise_tapes[k][t_idx] if noise_tapes is not None else None)
-        for sx in side:
-            cur.wait_stream(sx)
-        out_dev = torch.device("cpu") if return_device is None else torch.device(return_device)
-        out = []
-        for st in states:
-            traj_x, traj_c, bl_out = st["traj_x"].to(out_dev), st["traj_c"].to(out_dev), st["bl"].to(out_dev)
-            out.append({t - 1: (traj_x[t], traj_c[t], bl_out) for t in range(T + 1)})
-        return out
+        traj_x, traj_c, bl_out = st["traj_x"].to(out_dev), st["traj_c"].to(out_dev), st["bl"].to(out_dev)
+        return {t - 1: (traj_x[t], traj_c[t], bl_out) for t in range(T + 1)}

@@ -428,6 +428,41 @@ def test_sample_many_equals_sample(synthetic_sd):
             assert torch.equal(a[t][0], b[t][0]) and torch.equal(a[t][1], b[t][1]) and torch.equal(a[t][2], b[t][2])
 
 
+@pytest.mark.parametrize("name", ["diffbp", "diffsbdd"])
+def test_sample_many_equals_sample_other_model_classes(name):
+    """DiffBP (CoMPredictor with its own per-stream workspace) and DiffSBDD (pocket translated every step) through
+    BatchesInFlight.sample_many on three streams against one batch after the other, same noise: identical trajectories"""
+    T = 8
+    if name == "diffbp":
+        Cn = 13
+        m = C.get_model(C.default_diffbp_config(Cn, num_diffusion_timesteps=T)).eval()
+        m.load_state_dict(W.synthetic_state_dict_diffbp(Cn, 9, seed=0, num_timesteps=T), strict=True)
+    else:
+        Cn = 8
+        m = C.get_model(C.default_diffsbdd_config(Cn, num_diffusion_timesteps=T)).eval()
+        m.load_state_dict(W.synthetic_state_dict_diffsbdd(Cn, 9, seed=0, num_timesteps=T), strict=True)
+    m = m.to(DEV)
+    batches = [synthetic.batch_to(synthetic.denovo_batch(n, seed=60 + n, num_classes=Cn), DEV) for n in (2, 3, 2)]
+    g = torch.Generator(device=DEV).manual_seed(12)
+    tapes = []
+    for b in batches:
+        n_lig = b["ligand_pos"].shape[0]
+        if name == "diffbp":
+            tapes.append({t: (torch.randn(n_lig, 3, device=DEV, generator=g), torch.rand(n_lig, device=DEV, generator=g)) for t in range(T)})
+        else:      # the reference's draw order: initial x, initial c, then (x, c) per step -- more than enough tensors of each shape
+            tapes.append([torch.randn(n_lig, 3 if k % 2 == 0 else Cn, device=DEV, generator=g) for k in range(2 * T + 4)])
+    if name == "diffbp":
+        one = [m.sample(b, noise_tape=tp) for b, tp in zip(batches, tapes)]
+    else:
+        one = [m.sample(b, noise_draws=list(tp)) for b, tp in zip(batches, tapes)]
+    many = m.sample_many(batches, noise_tapes=[list(tp) if name == "diffsbdd" else tp for tp in tapes], streams=3)
+    torch.cuda.synchronize()
+    for a, b in zip(one, many):
+        assert sorted(a.keys()) == sorted(b.keys())
+        for t in a:
+            assert torch.equal(a[t][0], b[t][0]) and torch.equal(a[t][1], b[t][1])
+
+
 def test_scheduling_hints_do_not_change_results(model):
     """cbgx_set_edge_workgroups (CUs the persistent x2h edge kernel may take) and the number of caller streams are scheduling
     only: a denoiser call gives the same bits with 64 workgroups as with all, and on five different caller streams (the library
