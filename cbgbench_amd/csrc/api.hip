@@ -111,7 +111,7 @@ static Workspace carve(void* base, int n) {
 // back into that caller stream.  A caller that keeps two forward calls in flight on two of its streams (two resident batches: the
 // HBM-bound node kernels of one run under the matrix-bound edge kernel of the other) must not have them share an auxiliary stream --
 // the node stages of the second call would queue behind all nine of the first.  A small table keyed by the caller's stream handle;
-// when it is full the oldest entries are replaced.  Nothing here is shared between host threads.
+// when it is full the entries change owner round-robin (aux_for).  Nothing here is shared between host threads.
 struct AuxStream {
     hipStream_t owner = nullptr;
     hipStream_t s = nullptr;
@@ -132,6 +132,16 @@ static AuxStream* aux_for(hipStream_t caller) {
     if (t.n && t.dev != dev) return nullptr;   // one device per host thread (one process per GPU); otherwise stay serial
     for (int k = 0; k < t.n; ++k)
         if (t.e[k].owner == caller) return &t.e[k];
+    if (t.n == MAX_AUX) {
+        // table full: the entries change owner round-robin.  Stream and events are reused, not destroyed -- work the previous
+        // owner's calls queued on the stream simply stays ahead of the new owner's (stream order), waits already enqueued on the
+        // events keep referring to the records they were enqueued after, and nothing here blocks the host, so this is also
+        // legal while the caller's stream is being captured into a graph.
+        AuxStream& e = t.e[t.next_victim];
+        t.next_victim = (t.next_victim + 1) % MAX_AUX;
+        e.owner = caller;
+        return &e;
+    }
     AuxStream a;
     a.owner = caller;
     if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
@@ -141,20 +151,8 @@ static AuxStream* aux_for(hipStream_t caller) {
         return nullptr;
     }
     t.dev = dev;
-    if (t.n < MAX_AUX) {
-        t.e[t.n] = a;
-        return &t.e[t.n++];
-    }
-    // table full: replace the entries round-robin.  This thread has no call in progress on the evicted caller stream (calls of a
-    // thread are sequential and everything of a finished call is already enqueued), and the runtime defers the destruction of a
-    // stream / event until the work queued on it has run.
-    AuxStream& old = t.e[t.next_victim];
-    t.next_victim = (t.next_victim + 1) % MAX_AUX;
-    (void)hipStreamDestroy(old.s);
-    (void)hipEventDestroy(old.fork);
-    (void)hipEventDestroy(old.join);
-    old = a;
-    return &old;
+    t.e[t.n] = a;
+    return &t.e[t.n++];
 }
 
 extern "C" {

@@ -174,6 +174,13 @@ class CoMPredictor(nn.Module):
             # no host synchronisation: the pack kernels run on torch's current stream and `srcs` stays referenced until the next
             # repack (the weights change every training step; a synchronize() here stalled the host once per step)
             self._packed, self._packed_key, self._packed_srcs = packed, key, srcs
+            self._packed_event = torch.cuda.Event()     # as UniTransformer.packed_weights: other streams wait for the pack kernels
+            self._packed_event.record(torch.cuda.current_stream(device))
+            self._packed_seen = {torch.cuda.current_stream(device).cuda_stream}
+        cur = torch.cuda.current_stream(device)
+        if cur.cuda_stream not in self._packed_seen:
+            cur.wait_event(self._packed_event)
+            self._packed_seen.add(cur.cuda_stream)
         return self._packed
 
     def _stream_workspace(self, need, dev):

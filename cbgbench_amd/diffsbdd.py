@@ -54,14 +54,19 @@ class DiffsbddVariationalScheduler(nn.Module):
         self.gamma = PredefinedNoiseSchedule(type, timesteps=num_timestep, precision=5e-4)
 
     @staticmethod
-    def scatter_mean(src, index, n):
-        s = torch.zeros((n,) + src.shape[1:], dtype=src.dtype, device=src.device).index_add_(0, index, src)
-        cnt = torch.zeros(n, dtype=src.dtype, device=src.device).index_add_(
-            0, index, torch.ones(index.shape[0], dtype=src.dtype, device=src.device))
-        return s / cnt.clamp(min=1).view(-1, *[1] * (src.dim() - 1))
+    def scatter_mean(src, index, n, ordered=False):
+        """per-graph mean.  ``ordered`` (index non-decreasing, the collated layout): one sequential sum per graph
+        (torch.segment_reduce) instead of index_add_'s float atomics, whose summation order -- and with it the last bit of the
+        mean, and everything sampled after it -- changes from run to run on the GPU"""
+        cnt = torch.zeros(n, dtype=torch.long, device=src.device).index_add_(0, index, torch.ones_like(index))
+        if ordered:
+            s = torch.segment_reduce(src, "sum", lengths=cnt, axis=0, unsafe=True)
+        else:
+            s = torch.zeros((n,) + src.shape[1:], dtype=src.dtype, device=src.device).index_add_(0, index, src)
+        return s / cnt.clamp(min=1).to(src.dtype).view(-1, *[1] * (src.dim() - 1))
 
-    def remove_mean_batch(self, x_lig, x_rec, bl, br, B):
-        mean = self.scatter_mean(x_lig, bl, B)
+    def remove_mean_batch(self, x_lig, x_rec, bl, br, B, ordered=False):
+        mean = self.scatter_mean(x_lig, bl, B, ordered)
         return x_lig - mean[bl], x_rec - mean[br]
 
     # ---- training side (diffusion_scheduler.py:740-960) ----
@@ -157,12 +162,12 @@ class DiffsbddVariationalScheduler(nn.Module):
         info = {"eps_0": tgt, "eps_pred": pred, "mask_gen": gen_flag}
         return (loss_t + loss_0 + kl).mean(), info
 
-    def sample_normal_zero_com(self, mu_lig, xh0_pocket, sigma, bl, br, B, com=False, eps=None):
+    def sample_normal_zero_com(self, mu_lig, xh0_pocket, sigma, bl, br, B, com=False, eps=None, ordered=False):
         if eps is None:
             eps = torch.randn((bl.shape[0], mu_lig.size(1)), device=mu_lig.device)
         out = mu_lig + sigma[bl] * eps
         if com:
-            return self.remove_mean_batch(out, xh0_pocket, bl, br, B)
+            return self.remove_mean_batch(out, xh0_pocket, bl, br, B, ordered)
         return out
 
     def sample_p_zs_given_zt(self, s, t, zt_lig, xh0_pocket, bl, br, B, eps_t_lig, com=False, eps=None):
@@ -295,10 +300,12 @@ class DiffSBDD(BatchesInFlight, nn.Module):
         x = torch.empty(n_rec + n_lig, 3, dtype=torch.float32, device=dev)
         h = torch.empty(n_rec + n_lig, self.context_embedder.emb_dim, dtype=torch.float32, device=dev)
         h[rec_rows] = self.context_embedder.embed_protein(v_rec, aa)          # step-invariant
-        mu_x = sch.scatter_mean(x_rec, br, B)[bl]
+        # graphs contiguous in both index vectors (the collated layout): deterministic per-graph sums, and the native step
+        bl_ordered, br_ordered = torch.stack([(bl[1:] >= bl[:-1]).all(), (br[1:] >= br[:-1]).all()]).tolist()
+        mu_x = sch.scatter_mean(x_rec, br, B, br_ordered)[bl]
         mu_h = torch.zeros(B, C, device=dev)[bl]
         sigma1 = torch.ones(B, 1, device=dev)
-        x_lig, x_rec = sch.sample_normal_zero_com(mu_x, x_rec, sigma1, bl, br, B, com=True, eps=nxt())
+        x_lig, x_rec = sch.sample_normal_zero_com(mu_x, x_rec, sigma1, bl, br, B, com=True, eps=nxt(), ordered=bl_ordered)
         c_lig = sch.sample_normal_zero_com(mu_h, v_rec, sigma1, bl, br, B, com=False, eps=nxt())
         st = {"B": B, "N": n_rec + n_lig, "n_lig": n_lig, "x": x, "h": h, "x_lig": x_lig, "c_lig": c_lig, "x_rec": x_rec,
               "v_rec": v_rec, "bl": bl, "br": br, "batch_idx": batch_idx, "lig_flag": lig_flag, "gen_flag": gen_flag,
@@ -310,7 +317,7 @@ class DiffSBDD(BatchesInFlight, nn.Module):
             st["traj_x"][T], st["traj_c"][T] = x_lig, c_lig
         # native step (include/cbgx.h: cbgx_diffsbdd_step): the composed x / h are then kept up to date on the device by the
         # step kernel itself (pocket translated in place, ligand rows rewritten), st["x_rec"] is only refreshed on demand
-        st["native"] = dev.type == "cuda" and bool((bl[1:] >= bl[:-1]).all())
+        st["native"] = dev.type == "cuda" and bl_ordered
         if st["native"]:
             st["lig_rows32"] = lig_rows.to(torch.int32).contiguous()
             st["lig8"] = lig_flag.to(torch.uint8).contiguous()

@@ -246,6 +246,14 @@ class UniTransformer(nn.Module):
             # temporary of `srcs` to anyone who writes before they have read it; the references are kept until the next repack
             # anyway.  (A synchronize() here used to stall the host once per training step -- the weights change every step.)
             self._packed, self._packed_key, self._packed_srcs = packed, key, srcs
+            # callers on OTHER streams (batches in flight together) must not read the blob before the pack kernels have run
+            self._packed_event = torch.cuda.Event()
+            self._packed_event.record(torch.cuda.current_stream(device))
+            self._packed_seen = {torch.cuda.current_stream(device).cuda_stream}
+        cur = torch.cuda.current_stream(device)
+        if cur.cuda_stream not in self._packed_seen:
+            cur.wait_event(self._packed_event)
+            self._packed_seen.add(cur.cuda_stream)
         return self._packed
 
     def workspace(self, n_nodes, n_graphs, device):

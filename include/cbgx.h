@@ -13,7 +13,8 @@
  *
  * The only state the library owns, besides the optional profiling hook at the end of this file:
  * one auxiliary non-blocking HIP stream and two events per HOST THREAD AND CALLER STREAM (four per thread, created on the
- * first multi-layer forward on that stream; a fifth caller stream replaces the oldest entry).  cbgx_unitransformer_forward{,_cached} fork the node stage of
+ * first multi-layer forward on that stream; a fifth caller stream takes over the oldest entry's stream and events -- nothing is
+ * destroyed or waited for, so this is legal under stream capture).  cbgx_unitransformer_forward{,_cached} fork the node stage of
  * layer l+1 onto it next to the h2x block of layer l and join it back before returning work to `stream`, so
  * from the caller's point of view everything is still ordered on `stream` (hipGraph capture of `stream`
  * records the fork/join).  One device per host thread (the one-process-per-GPU model): a thread that switches

@@ -203,3 +203,17 @@ def test_diffbp_sampler_plumbing_matches_reference(golden_dir):
     for t in range(-1, T):
         torch.testing.assert_close(traj[t][0], g[f"traj_x_{t}"], rtol=1e-5, atol=1e-5)
         assert torch.equal(traj[t][1], g[f"traj_c_{t}"]), t
+
+
+def test_diffsbdd_ordered_graph_mean_equals_the_scatter_form():
+    """the sequential per-graph sum used for collated (graph-contiguous) batches -- bit-reproducible on the GPU, unlike
+    index_add_'s float atomics -- against the scatter form, empty graphs included"""
+    from cbgbench_amd.diffsbdd import DiffsbddVariationalScheduler as S
+    g = torch.Generator().manual_seed(3)
+    index = torch.tensor([0] * 5 + [1] * 1 + [3] * 40 + [4] * 17)          # graph 2 is empty
+    src = torch.randn(index.numel(), 3, generator=g) * 10
+    a, b = S.scatter_mean(src, index, 6, ordered=True), S.scatter_mean(src, index, 6)
+    torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+    assert torch.equal(a[2], torch.zeros(3)) and torch.equal(a[5], torch.zeros(3))
+    ref = torch.stack([src[index == k].double().mean(0) if (index == k).any() else torch.zeros(3, dtype=torch.double) for k in range(6)])
+    torch.testing.assert_close(a.double(), ref, rtol=1e-6, atol=1e-6)
