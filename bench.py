@@ -297,6 +297,7 @@ def bench_train(args, rank, world, dev):
                                f"Adam lr 5e-4, clip 8.0, one flat-buffer gradient all-reduce "
                                f"({fg.flat.numel()} fp32) per step",
                    "graphs_per_batch_per_gpu": n_graphs, "nodes_per_batch": N, "sharding": f"data-parallel x{world} ranks", "ranks_seen": seen,
+                   "collective_backend": collective_backend(),
                    "allreduce_ms_per_step": round(1e3 * t_ar / max(args.steps, 1), 4)},
     }
     if rank == 0 and not args.no_roofline:
@@ -364,6 +365,11 @@ def ranks_seen(dev):
     return int(one.item())
 
 
+def collective_backend():
+    import torch.distributed as dist
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+
+
 def device_identity(dev):
     """A string that is equal for two ranks exactly when they drive the same physical GPU of this job: host name + the device
     visibility environment + the device index under it (one node, torchrun: indices are node-global; per-rank *_VISIBLE_DEVICES
@@ -382,7 +388,7 @@ def device_hardware_id(dev):
 def distinct_devices(dev, world):
     """number of distinct physical GPUs over all ranks (all-gather of device_identity)"""
     import torch.distributed as dist
-    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+    if not (dist.is_available() and dist.is_initialized()):
         return 1
     ids = [None] * world
     dist.all_gather_object(ids, device_identity(dev))
@@ -408,8 +414,9 @@ def parse_args(argv=None):
                          "stack + score / mask-type step per step, diffsbdd the zero-COM variational step (its pocket moves "
                          "every step: no static-context cache); --workload train trains the class")
     ap.add_argument("--graph", choices=["on", "off"], default="off",
-                    help="replay one captured hipGraph per denoising step instead of stream launches (single batch only; no "
-                         "gain measured: small batches are bound by the dependent-kernel chain on the device)")
+                    help="replay one captured hipGraph per batch and denoising step instead of stream launches.  No gain for one "
+                         "batch (a small batch is bound by its dependent-kernel chain on the device); with many small batches "
+                         "in flight (--streams 8) it removes the host as the limit")
     ap.add_argument("--streams", type=int, default=3,
                     help="resident batches in flight at once, round-robin over this many HIP streams (sampling workloads; default 3, "
                          "capped by the number of resident batches): while one batch sits in its matrix-bound edge kernel the node "
@@ -465,7 +472,7 @@ def main():
         out["secondary"] = secondary_block(args, dev, out)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if collective_backend() is not None:
         sharding.barrier()      # rank 0 may still be in its (untimed) roofline pass: leave together
         torch.distributed.destroy_process_group()
 
@@ -510,19 +517,31 @@ def bench_sampling(args, rank, world, dev):
                 else:
                     model.denoise_step(st, t)
 
-    use_graph = args.graph == "on" and len(states) == 1 and args.warmup + args.steps + 2 < T and args.model == "targetdiff"
+    use_graph = args.graph == "on" and args.warmup + args.steps + 2 < T and args.model == "targetdiff"
     if use_graph:
+        # every resident batch's step captured once as a hipGraph on its stream, replayed once per bench step: the steps of a
+        # batch follow each other (t = T-3, T-4, ...) instead of visiting the five time blocks
         n_blocks = 1
-        replay, done = model.make_step_graph(states[0], warmup=2)
+        made = [model.make_step_graph(st, warmup=2, stream=streams[b % n_streams] if streams else None)
+                for b, st in enumerate(states)]
+
+        def replay_all():
+            for b, (replay, _) in enumerate(made):
+                if streams:
+                    with torch.cuda.stream(streams[b % n_streams]):
+                        replay()
+                else:
+                    replay()
+
         for _ in range(args.warmup):
-            replay()
+            replay_all()
         sharding.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            replay()
+            replay_all()
         torch.cuda.synchronize(); sharding.barrier()
         elapsed = time.perf_counter() - t0
-        t_idx = T - 1 - done - args.warmup - args.steps
+        t_idx = T - 1 - made[0][1] - args.warmup - args.steps
         st = states[0]
         st["x_lig"], st["c_lig"] = st["traj_x"][t_idx + 1].clone(), st["traj_c"][t_idx + 1].clone()
     else:
@@ -558,7 +577,8 @@ def bench_sampling(args, rank, world, dev):
                    "graph_steps_per_bench_step_per_gpu": n_graphs * n_blocks,
                    "ms_per_denoising_step_of_the_job": round(1e3 * el_max / args.steps / n_blocks, 4),
                    "sharding": f"independent pockets x{world} ranks, no data-path collective", "ranks_seen": seen,
-                   "launch": "one hipGraph replay per step" if use_graph else "stream launches",
+                   "collective_backend": collective_backend(),
+                   "launch": "one hipGraph replay per batch and step" if use_graph else "stream launches",
                    "streams": n_streams, "edge_workgroups": edge_wgs or 256},
     }
 
@@ -701,6 +721,12 @@ def secondary_block(args, dev, primary):
                                              keep=("nodes_per_gpu",)))
     guarded("denovo_1_graph", lambda: _row(bench_sampling(ns(pockets=1, samples=1, graphs_per_batch=1, steps=20, warmup=5), 0, 1, dev),
                                            keep=("nodes_per_gpu",)))
+    # the same small batches as a JOB (the reference's loop over batches, sample.py:159-230, here with eight batches in flight on
+    # eight streams -- TargetDiff.sample_many / sample_cli --streams 8): throughput, where the two rows above are one batch's latency
+    guarded("denovo_10_graphs_per_batch_8_in_flight", lambda: _row(bench_sampling(
+        ns(pockets=16, samples=10, graphs_per_batch=10, steps=20, warmup=5, streams=8), 0, 1, dev), keep=("nodes_per_gpu", "streams")))
+    guarded("denovo_1_graph_per_batch_8_in_flight", lambda: _row(bench_sampling(
+        ns(pockets=32, samples=1, graphs_per_batch=1, steps=20, warmup=5, streams=8), 0, 1, dev), keep=("nodes_per_gpu", "streams")))
 
     def e2e():
         r = sample_cli_end_to_end(dev)

@@ -19,7 +19,10 @@ def shard_indices(n_items, rank, world):
 
 def init_process_group(backend=None):
     rank, world, local = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    # CBGX_DIST_FORCE=1: create the group even for one rank, so that a 1-GPU box runs the barrier and the reductions through
+    # RCCL itself (tests/test_gpu_bench.py) -- the code path of the N-GPU job minus the peers
+    force = os.environ.get("CBGX_DIST_FORCE") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if backend is None:

@@ -304,27 +304,47 @@ class BatchesInFlight:
         return have[:n]
 
     @torch.no_grad()
-    def sample_many(self, batches, noise_tapes=None, return_device=None, streams=3):
+    def sample_many(self, batches, noise_tapes=None, return_device=None, streams=3, use_graph=False, noise_log=None):
+        """``use_graph`` (classes with ``make_step_graph``; ignored with ``noise_tapes``): every batch's step is captured once as a
+        hipGraph on its stream and replayed T times -- one host call per batch and step instead of ~50 launches plus the Python
+        around them.  This is what SMALL batches need (the reference's own 10 graphs per batch, sample.py:177-183): one such batch
+        is a chain of ~50 dependent 20 us kernels that leaves most of the chip idle, and the host cannot feed eight of them at once;
+        eight graphs in flight can.  Same kernels on the same data as the stream launches: identical trajectories
+        for identical noise.  ``noise_log`` (tests): a list that receives ``(batch index, t, eps, u)`` after every replay (which
+        synchronises the stream)."""
         dev = batches[0]["ligand_pos"].device
         out_dev = torch.device("cpu") if return_device is None else torch.device(return_device)
         tape = lambda k: None if noise_tapes is None else noise_tapes[k]
-        if dev.type != "cuda" or len(batches) == 1 or streams <= 1:
+        T = self.num_diffusion_timesteps
+        graphs = bool(use_graph) and noise_tapes is None and dev.type == "cuda" and hasattr(self, "make_step_graph")
+        if dev.type != "cuda" or ((len(batches) == 1 or streams <= 1) and not graphs):
             out = []
             for k, b in enumerate(batches):
                 st = self._many_begin(b, tape(k))
-                for t_idx in reversed(range(self.num_diffusion_timesteps)):
+                for t_idx in reversed(range(T)):
                     self._many_step(st, t_idx, tape(k))
                 out.append(self._many_finish(st, out_dev))
             return out
         states = [self._many_begin(b, tape(k)) for k, b in enumerate(batches)]
         cur = torch.cuda.current_stream(dev)
-        side = self._side_streams(dev, min(streams, len(states)))
+        side = self._side_streams(dev, max(1, min(streams, len(states))))
         for sx in side:
             sx.wait_stream(cur)                      # the states were built on the caller's stream
-        for t_idx in reversed(range(self.num_diffusion_timesteps)):
-            for k, st in enumerate(states):
-                with torch.cuda.stream(side[k % len(side)]):
-                    self._many_step(st, t_idx, tape(k))
+        if graphs:
+            made = [self.make_step_graph(st, stream=side[k % len(side)]) for k, st in enumerate(states)]
+            for n in range(T):
+                for k, (st, (replay, done)) in enumerate(zip(states, made)):
+                    if n < T - done:
+                        with torch.cuda.stream(side[k % len(side)]):
+                            replay()
+                            if noise_log is not None:
+                                side[k % len(side)].synchronize()
+                                noise_log.append((k, T - 1 - done - n, st["_noise"][0].clone(), st["_noise"][1].clone()))
+        else:
+            for t_idx in reversed(range(T)):
+                for k, st in enumerate(states):
+                    with torch.cuda.stream(side[k % len(side)]):
+                        self._many_step(st, t_idx, tape(k))
         for sx in side:
             cur.wait_stream(sx)
         return [self._many_finish(st, out_dev) for st in states]
@@ -565,7 +585,7 @@ class TargetDiff(BatchesInFlight, nn.Module):
             _native.ptr(st["x"]), _native.ptr(st["h"]), stream), "cbgx_targetdiff_prologue_traj")
         xo, _, logits = self.denoiser(x=st["x"], h=st["h"], batch_idx=st["batch_idx"], lig_flag=st["lig_flag"],
                                       gen_flag=st["gen_flag"], graph_ptr=st["graph_ptr"], need_h=False,
-                                      static_h=st["static_h"])
+                                      static_h=st["static_h"], workspace=st.get("_ws"))
         eps = torch.randn(n_lig, 3, dtype=torch.float32, device=dev)      # reference draw order: randn then rand
         u = torch.rand(n_lig, C, dtype=torch.float32, device=dev)
         _native.check(lib.cbgx_targetdiff_epilogue_traj(
@@ -575,24 +595,30 @@ class TargetDiff(BatchesInFlight, nn.Module):
         st["_noise"] = (eps, u)     # under capture these are the graph's static buffers: readable after every replay
 
     @torch.no_grad()
-    def make_step_graph(self, st, warmup=2):
+    def make_step_graph(self, st, warmup=2, stream=None):
         """Capture one reverse-diffusion step as a hipGraph.  ``st`` must come from ``begin_sampling(keep_trajectory=True)``
         on the GPU.  Runs ``warmup`` eager steps first (they count: the step index advances), then returns
-        ``(replay, steps_done)``; every ``replay()`` advances the state by one step.  The step index lives in
-        ``st['t_dev']``; after the last step the final state is trajectory slot 0."""
+        ``(replay, steps_done)``; every ``replay()`` advances the state by one step on the CURRENT stream.  The step index lives
+        in ``st['t_dev']``; after the last step the final state is trajectory slot 0.
+        ``stream``: the (non-default) stream the warm-up steps run on and the capture is made on -- the one the replays will be
+        issued on when several states are kept in flight (``sample_many(use_graph=True)``).  The state gets its own denoiser
+        workspace (``st['_ws']``): the graph bakes every pointer in, and two graphs replayed on two streams must not share one."""
         dev = st["x"].device
         T = self.num_diffusion_timesteps
         if dev.type != "cuda" or st["traj_x"] is None or not (self.denoise_structure and self.denoise_atom):
             raise RuntimeError("make_step_graph needs a GPU sampling state with the trajectory kept on the device")
-        st["t_dev"] = torch.full((1,), T - 1, dtype=torch.int32, device=dev)
-        for _ in range(min(warmup, T)):     # eager steps on the current stream: workspaces and weight packs get allocated
-            self._traj_step(st)
-        torch.cuda.synchronize(dev)
+        run_on = stream if stream is not None else torch.cuda.current_stream(dev)
         done = min(warmup, T)
+        with torch.cuda.stream(run_on):
+            st["t_dev"] = torch.full((1,), T - 1, dtype=torch.int32, device=dev)
+            st["_ws"] = torch.empty(self.denoiser.workspace_bytes(st["N"], st["B"]), dtype=torch.uint8, device=dev)
+            for _ in range(done):     # eager steps: the weight pack gets built, the allocator warm
+                self._traj_step(st)
+        run_on.synchronize()
         if done >= T:
             return (lambda: None), done
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, stream=stream):
             self._traj_step(st)
         st["_graph"] = graph        # keeps the graph's private memory pool alive as long as the state
         return graph.replay, done

@@ -200,7 +200,7 @@ class FlatGradients:
 
     def all_reduce_mean(self):
         """sum over ranks / world size; returns the wall time of the collective in seconds (0 when not distributed)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()):     # a one-rank group (CBGX_DIST_FORCE) still reduces: tests
             return 0.0
         sync = self.flat.is_cuda
         if sync:
@@ -220,7 +220,7 @@ class FlatGradients:
 
 def broadcast_parameters(model, src=0):
     """every rank starts from rank ``src``'s weights (what DDP does at construction)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         for t in list(model.parameters()) + list(model.buffers()):
             if dist.get_backend() == "gloo" and t.is_cuda:
                 host = t.detach().cpu()
@@ -263,7 +263,7 @@ def validate(model, batches, loss_weights=None):
         tot += float(sum_weighted_losses(loss_dict, loss_weights)) * B
         n += B
     val = torch.tensor([tot, float(n)], dtype=torch.float64)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         if dist.get_backend() != "gloo":
             val = val.to(next(model.parameters()).device)
         dist.all_reduce(val, op=dist.ReduceOp.SUM)

@@ -256,6 +256,10 @@ class UniTransformer(nn.Module):
             self._packed_seen.add(cur.cuda_stream)
         return self._packed
 
+    @staticmethod
+    def workspace_bytes(n_nodes, n_graphs):
+        return int(_native.lib().cbgx_workspace_bytes(n_nodes, n_graphs))
+
     def workspace(self, n_nodes, n_graphs, device):
         """one workspace per (device, current stream): two forward calls in flight on two streams must not share scratch memory"""
         need = _native.lib().cbgx_workspace_bytes(n_nodes, n_graphs)
@@ -326,7 +330,7 @@ class UniTransformer(nn.Module):
         return (out[0], out[1], nbr.contiguous(), deg, ew, r32sq)
 
     def forward(self, x, h, batch_idx, lig_flag, gen_flag, graph_ptr=None, need_h=True, static_h=None,
-                ligand_outputs_only=False):
+                ligand_outputs_only=False, workspace=None):
         """Same contract as the reference (unitransformer.py:102-123): returns (x', h', logits).
         ``batch_idx`` must be sorted (compose_context guarantees it).  ``graph_ptr`` (int32 CSR
         offsets) may be passed to avoid recomputing it from ``batch_idx`` every call.  ``need_h=False`` (samplers that
@@ -336,7 +340,9 @@ class UniTransformer(nn.Module):
         cannot yet have seen a ligand atom (bit-identical results).
         ``ligand_outputs_only`` (training): the caller promises that its loss reads ``x'`` on ``gen_flag`` rows and the logits
         on ``lig_flag`` rows only and ignores ``h'`` (TargetDiff / DiffSBDD losses); the backward may then be pruned to
-        the receptive field of those rows.  Without the promise the full backward runs."""
+        the receptive field of those rows.  Without the promise the full backward runs.
+        ``workspace`` (inference): caller-owned scratch memory of at least ``workspace_bytes(N, B)`` bytes instead of the per-stream
+        one the module keeps -- a captured hipGraph bakes the pointer in, so every captured sampling state brings its own."""
         if not x.is_cuda:
             raise RuntimeError("UniTransformer.forward runs on an MI355X through libcbgx; got a CPU tensor "
                                "(no CPU fallback exists; use oracle/ for CPU reference results)")
@@ -355,7 +361,12 @@ class UniTransformer(nn.Module):
         x = x.detach().to(torch.float32).contiguous()
         h = h.detach().to(torch.float32).contiguous()
         packed = self.packed_weights(device)
-        ws = self.workspace(N, B, device)
+        if workspace is not None:
+            if workspace.device != device or workspace.dtype != torch.uint8 or workspace.numel() < self.workspace_bytes(N, B):
+                raise ValueError(f"workspace: need a uint8 tensor of >= {self.workspace_bytes(N, B)} bytes on {device}")
+            ws = workspace
+        else:
+            ws = self.workspace(N, B, device)
         x_out = torch.empty_like(x)
         h_out = torch.empty_like(h) if need_h else None
         logits = torch.empty(N, self.out_classes, dtype=torch.float32, device=device)

@@ -38,6 +38,27 @@ def test_bench_line_contract_small_job():
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1.5 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
 
 
+def test_bench_one_rank_through_rccl():
+    """the collectives of the N-GPU job on the backend the driver's run uses: a one-rank RCCL group (CBGX_DIST_FORCE=1) takes
+    bench.py through init_process_group('nccl'), the device identity all-gather, both barriers and the max / sum / count
+    all-reduces on the GPU"""
+    out = _run(["--steps", "2", "--warmup", "1", "--pockets", "2", "--graphs-per-batch", "20", "--no-cpu-baseline", "--no-roofline"],
+               env={"CBGX_DIST_FORCE": "1", "CBGX_DIST_BACKEND": "nccl", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29900 + os.getpid() % 90)})
+    assert out["n_gpus"] == 1 and "ranks" not in out and out["config"]["ranks_seen"] == 1
+    assert out["config"]["collective_backend"] == "nccl"
+    assert abs(out["value"] - 20 * 5 / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]
+
+
+def test_bench_train_one_rank_through_rccl():
+    """the flat-buffer gradient all-reduce (cbgbench_amd/train.py FlatGrads.all_reduce_mean) on RCCL, one rank"""
+    out = _run(["--workload", "train", "--steps", "2", "--warmup", "1", "--pockets", "4", "--no-cpu-baseline", "--no-roofline"],
+               env={"CBGX_DIST_FORCE": "1", "CBGX_DIST_BACKEND": "nccl", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29800 + os.getpid() % 90)})
+    assert out["n_gpus"] == 1 and out["config"]["ranks_seen"] == 1 and out["config"]["collective_backend"] == "nccl"
+    assert out["config"]["allreduce_ms_per_step"] > 0
+
+
 def test_bench_two_ranks_on_one_gpu_gloo():
     """`python bench.py --gpus 2` launches two ranks itself; both take part (ranks_seen from an all-reduce), the value is
     the whole-job aggregate.  gloo because both ranks share this box's single GPU."""

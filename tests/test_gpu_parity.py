@@ -428,6 +428,34 @@ def test_sample_many_equals_sample(synthetic_sd):
             assert torch.equal(a[t][0], b[t][0]) and torch.equal(a[t][1], b[t][1]) and torch.equal(a[t][2], b[t][2])
 
 
+def test_sample_many_with_step_graphs_equals_eager_steps(synthetic_sd):
+    """small batches kept in flight as captured hipGraphs (sample_many(use_graph=True): four batches on two streams, so two graphs
+    share a stream and all four are replayed interleaved, each with its own workspace) against eager steps of the same batches
+    fed the noise the graphs drew: identical final states, every batch"""
+    T = 10
+    m = C.get_model(C.default_targetdiff_config(13, num_diffusion_timesteps=T)).eval()
+    m.load_state_dict(W.synthetic_state_dict(13, 9, seed=0, num_timesteps=T), strict=True)
+    m = m.to(DEV)
+    batches = [synthetic.batch_to(synthetic.denovo_batch(n, seed=70 + n, n_rec_range=(120, 260)), DEV) for n in (1, 3, 2, 1)]
+    torch.manual_seed(5)
+    log = []
+    many = m.sample_many(batches, streams=2, use_graph=True, noise_log=log, return_device=DEV)
+    torch.cuda.synchronize()
+    done = 2                                  # make_step_graph's eager warm-up steps: their noise is not recorded
+    assert len(log) == len(batches) * (T - done)
+    for k, b in enumerate(batches):
+        traj = many[k]
+        assert sorted(traj.keys()) == list(range(-1, T)) and torch.isfinite(traj[-1][0]).all()
+        tape = {t: (eps, u) for kk, t, eps, u in log if kk == k}
+        assert sorted(tape) == list(range(T - done))
+        st = m.begin_sampling(b, keep_trajectory=True)
+        st["x_lig"], st["c_lig"] = traj[T - done - 1][0].clone(), traj[T - done - 1][1].clone()
+        for t in reversed(range(T - done)):
+            m.denoise_step(st, t, noise=tape[t])
+            assert torch.equal(st["x_lig"], traj[t - 1][0]) and torch.equal(st["c_lig"], traj[t - 1][1]), (k, t)
+        assert not torch.equal(traj[-1][0], traj[T - 1][0])
+
+
 @pytest.mark.parametrize("name", ["diffbp", "diffsbdd"])
 def test_sample_many_equals_sample_other_model_classes(name):
     """DiffBP (CoMPredictor with its own per-stream workspace) and DiffSBDD (pocket translated every step) through
