@@ -135,18 +135,26 @@ __device__ __forceinline__ void rbf_tuples(const float (&R)[5], half4 (&B)[4]) {
     B[3] = half4{h[3], h[4], l[4], (_Float16)0.f};
 }
 // The weight pieces of (type, tile) for this lane: T1 = (d0, d1) = [h0 h1 h2 h3], T2 = (d2, d3) = [h4 l0 l1 l2],
-// T3 = (d4, d2) = [l3 l4 h4 l0] -- d2 is read twice, so the table needs no duplicate and is exactly as large as the five
-// fp32 fragments it replaces.  blk = lds_frag + (type * 8 + t) * FRAG_BLK.
+// T3 = (d4, d2) = [l3 l4 h4 l0] -- d2 is used twice, so the table needs no duplicate and is exactly as large as the five
+// fp32 fragments it replaces.  Layout of one type's 8 tiles (8 FRAG_BLK floats), chosen so that EVERY read is
+// `table base + 16 lane + immediate`: two groups of four tiles, each group = four 1 KB planes [lane][d0 d1 d2 d3] followed by one
+// 1 KB plane [lane][d4 of the group's four tiles].  One address register per table and source class; the tile offsets sit in the
+// instructions' immediate fields.  (The former [d0 d1 | d2 d3 | d4] planes per tile needed a VALU add per read: 16-lane and
+// 4-lane strides cannot share a base register, and ds_read2st64_b64 counts its offsets in 512-byte units.)
 struct WTuples { half4 t1, t2, t3; };
-__device__ __forceinline__ WTuples load_wtuples(const float* blk, int lane) {
+constexpr int FRAG_GROUP = 4 * (int)FRAG_BLK;   // floats per group of four tiles
+__device__ __forceinline__ int frag_d0_index(int t, int lane) { return (t >> 2) * FRAG_GROUP + (t & 3) * 256 + 4 * lane; }
+__device__ __forceinline__ int frag_d4_index(int t, int lane) { return (t >> 2) * FRAG_GROUP + 1024 + 4 * lane + (t & 3); }
+__device__ __forceinline__ WTuples load_wtuples(const float* type_base, int t, int lane) {
     typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
     WTuples w;
-    w.t1 = *reinterpret_cast<const half4*>(blk + 2 * lane);
-    w.t2 = *reinterpret_cast<const half4*>(blk + 128 + 2 * lane);
-    const unsigned d4 = *reinterpret_cast<const unsigned*>(blk + 256 + lane);
-    const unsigned d2 = *reinterpret_cast<const unsigned*>(blk + 128 + 2 * lane);
-    const uint2v p = {d4, d2};
-    w.t3 = __builtin_bit_cast(half4, p);
+    const uint4v d = *reinterpret_cast<const uint4v*>(type_base + frag_d0_index(t, lane));
+    const unsigned d4 = *reinterpret_cast<const unsigned*>(type_base + frag_d4_index(t, lane));
+    const uint2v p1 = {d.x, d.y}, p2 = {d.z, d.w}, p3 = {d4, d.z};
+    w.t1 = __builtin_bit_cast(half4, p1);
+    w.t2 = __builtin_bit_cast(half4, p2);
+    w.t3 = __builtin_bit_cast(half4, p3);
     return w;
 }
 // Range-safe split-f16 of the rbf pre-activation (layout.h A_RBF_SC): the weight tuples hold Wr 2^kw, the kernels produce the rbf

@@ -68,7 +68,7 @@ __device__ __forceinline__ floatx4 edge_major_half(floatx4 (&acc)[8], bool lg, i
         const float* fa = lds_frag + (size_t)etype(p == 1, lig_i) * (8 * FRAG_BLK);
 #pragma unroll
         for (int tg = 0; tg < 8; tg += 2) {
-            const WTuples w0 = load_wtuples(fa + (tg + 0) * FRAG_BLK, lane), w1 = load_wtuples(fa + (tg + 1) * FRAG_BLK, lane);
+            const WTuples w0 = load_wtuples(fa, tg, lane), w1 = load_wtuples(fa, tg + 1, lane);
             acc[tg] = MFMAH(w0.t1, B[0], acc[tg]);         acc[tg + 1] = MFMAH(w1.t1, B[0], acc[tg + 1]);
             acc[tg] = MFMAH(w0.t1, B[1], acc[tg]);         acc[tg + 1] = MFMAH(w1.t1, B[1], acc[tg + 1]);
             acc[tg] = MFMAH(w0.t2, B[2], acc[tg]);         acc[tg + 1] = MFMAH(w1.t2, B[2], acc[tg + 1]);
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                     const float* fb = lds_fv + (size_t)etype(p == 1, lig_i) * (8 * FRAG_BLK);
 #pragma unroll
                     for (int tg = 0; tg < 8; tg += 2) {
-                        const WTuples w0 = load_wtuples(fb + (tg + 0) * FRAG_BLK, lane), w1 = load_wtuples(fb + (tg + 1) * FRAG_BLK, lane);
+                        const WTuples w0 = load_wtuples(fb, tg, lane), w1 = load_wtuples(fb, tg + 1, lane);
                         hv[tg] = MFMAH(A[0], w0.t1, hv[tg]);         hv[tg + 1] = MFMAH(A[0], w1.t1, hv[tg + 1]);
                         hv[tg] = MFMAH(A[1], w0.t1, hv[tg]);         hv[tg + 1] = MFMAH(A[1], w1.t1, hv[tg + 1]);
                         hv[tg] = MFMAH(A[2], w0.t2, hv[tg]);         hv[tg + 1] = MFMAH(A[2], w1.t2, hv[tg + 1]);
@@ -509,30 +509,24 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);
             // epilogue: out[8a + cc] = sum_m Wbv[8a + cc][m] S[a][m] + bbv[8a + cc] sum_e alpha e_w ; this lane holds
-            // S[a = c][16q .. 16q+15] and [64 + 16q .. 64 + 16q + 15]; Wbv rows live in LDS with their 16-byte chunks XOR-swizzled by the head index
-            // so the 16 lanes of a row (16 different Wbv rows, same columns) hit 16 different bank groups.
+            // S[a = c][m] for m = 64 hh + 16 q + 4 r + j in s2[4 hh + j][r].  Wbv rows live in LDS as 16-byte chunks
+            // K = 16 hh + 4 q + j holding the four channels r = 0..3 of that (hh, q, j) -- the register quad of s2[4 hh + j], so
+            // the 8 x 32 products are packed FMAs on the accumulators as they are -- with the chunk index XOR-swizzled by the head
+            // so that the 16 lanes of a row (16 different Wbv rows, same chunk) hit 16 different bank groups.
             float o8[8];
             const float* lds_wbv = lds + IMG_WBV;
-            // tiles 2tp, 2tp+1 paired once per node, so that the 8 x 32 products below are packed FMAs against adjacent
-            // weight pairs (same two partial sums, same order as the scalar form)
-            float2v sp[4][4];
-#pragma unroll
-            for (int tp = 0; tp < 4; ++tp)
-#pragma unroll
-                for (int rp = 0; rp < 4; ++rp) sp[tp][rp] = float2v{s2[2 * tp][rp], s2[2 * tp + 1][rp]};
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc) {
                 const float* wrow = lds_wbv + (size_t)(8 * c + cc) * H;
                 float2v a2 = {0.f, 0.f};
 #pragma unroll
-                for (int rp = 0; rp < 4; ++rp) {
-                    const floatx4 wa = f4(ld4(wrow + (((4 * q + rp) ^ c) << 2)));        // channels 16q + 4rp .. +3
-                    const floatx4 wb = f4(ld4(wrow + (((16 + 4 * q + rp) ^ c) << 2)));   // channels 64 + 16q + 4rp .. +3
-                    a2 = lo2(wa) * sp[0][rp] + a2;
-                    a2 = hi2(wa) * sp[1][rp] + a2;
-                    a2 = lo2(wb) * sp[2][rp] + a2;
-                    a2 = hi2(wb) * sp[3][rp] + a2;
-                }
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const floatx4 w4 = f4(ld4(wrow + (((16 * hh + 4 * q + j) ^ c) << 2)));
+                        a2 = lo2(w4) * lo2(s2[4 * hh + j]) + a2;
+                        a2 = hi2(w4) * hi2(s2[4 * hh + j]) + a2;
+                    }
                 o8[cc] = xrow_sum(a2.x + a2.y);
             }
             // lane (c, q) writes outputs n = 8c + 2q, 8c + 2q + 1
@@ -672,12 +666,11 @@ __global__ void pack_frag_kernel(PackBlocks pb) {
         h[s] = (_Float16)w;
         l[s] = (_Float16)(w - (float)h[s]);
     }
-    _Float16* blk = reinterpret_cast<_Float16*>(dst + (size_t)(type * 8 + t) * FRAG_BLK);
-    _Float16* a0 = blk + 4 * lane;            // (d0, d1) = [h0 h1 h2 h3]
-    _Float16* a1 = blk + 256 + 4 * lane;      // (d2, d3) = [h4 l0 l1 l2]
-    _Float16* a2 = blk + 512 + 2 * lane;      //  d4      = [l3 l4]
+    float* tb = dst + (size_t)type * 8 * FRAG_BLK;     // the type's 8 tiles: layout of load_wtuples (edge_common.h)
+    _Float16* a0 = reinterpret_cast<_Float16*>(tb + frag_d0_index(t, lane));   // (d0, d1) = [h0 h1 h2 h3], (d2, d3) = [h4 l0 l1 l2]
+    _Float16* a2 = reinterpret_cast<_Float16*>(tb + frag_d4_index(t, lane));   //  d4      = [l3 l4]
     a0[0] = h[0]; a0[1] = h[1]; a0[2] = h[2]; a0[3] = h[3];
-    a1[0] = h[4]; a1[1] = l[0]; a1[2] = l[1]; a1[3] = l[2];
+    a0[4] = h[4]; a0[5] = l[0]; a0[6] = l[1]; a0[7] = l[2];
     a2[0] = l[3]; a2[1] = l[4];
 }
 
@@ -692,12 +685,14 @@ __global__ void pack_dwt_kernel(PackBlocks pb) {
     att[A_IMG + IMG_WT + idx] = w[(size_t)m * KV_IN + tl] - w[(size_t)m * KV_IN + tp];
 }
 
-// x2h blocks: second v Linear [128 n][128 m] with its 16-byte chunks XOR-swizzled by the head (n >> 3)
+// x2h blocks: second v Linear [128 n][128 m] as the edge kernel's epilogue reads it: column m = 64 hh + 16 q + 4 r + j goes to
+// 16-byte chunk K = 16 hh + 4 q + j, position r; the chunk index is XOR-swizzled by the head (n >> 3)
 __global__ void pack_wbv_swz_kernel(PackBlocks pb) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // n * 128 + m
     if (idx >= H * H || !pb.x2h[blockIdx.y]) return;
     const int n = idx >> 7, m = idx & 127;
-    pb.att[blockIdx.y][A_IMG + IMG_WBV + n * H + ((((m >> 2) ^ ((n >> 3) & 15)) << 2) | (m & 3))] = pb.wv1[blockIdx.y][idx];
+    const int chunk = 16 * (m >> 6) + 4 * ((m >> 4) & 3) + (m & 3), r = (m >> 2) & 3;
+    pb.att[blockIdx.y][A_IMG + IMG_WBV + n * H + (((chunk ^ ((n >> 3) & 15)) << 2) | r)] = pb.wv1[blockIdx.y][idx];
 }
 
 // centre the first Linears of k and v over their 128 output channels: wc = w - colmean(w), bc = b - mean(b)   (w [128][340]);

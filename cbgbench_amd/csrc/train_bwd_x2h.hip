@@ -265,7 +265,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 {
                     const float* fa = frag + (size_t)etype(p1 == 1, lig_i) * (8 * FRAG_BLK);
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) wt[t] = load_wtuples(fa + t * FRAG_BLK, lane);
+                    for (int t = 0; t < 8; ++t) wt[t] = load_wtuples(fa, t, lane);
                 }
                 BX_T(10);
                 SCHED_FENCE();
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     p = 1;
                     const float* fa = frag + (size_t)etype(true, lig_i) * (8 * FRAG_BLK);
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) wt[t] = load_wtuples(fa + t * FRAG_BLK, lane);
+                    for (int t = 0; t < 8; ++t) wt[t] = load_wtuples(fa, t, lane);
                     SCHED_FENCE();
                 }
 #pragma unroll
