@@ -62,7 +62,10 @@ __device__ unsigned long long g_bx_prof[16];
 __constant__ float c_mu_x[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.75f, 3.f,
                                 3.5f, 4.f, 4.5f, 5.f, 5.5f, 6.f, 7.f, 8.f, 9.f, 10.f};
 
-constexpr int BX_WAVES = 8;
+#ifndef CBGX_BX_WAVES
+#define CBGX_BX_WAVES 8      // experiments: scripts/build_variant.py <name> -DCBGX_BX_WAVES=4 (one wave per SIMD, 512 registers)
+#endif
+constexpr int BX_WAVES = CBGX_BX_WAVES;
 constexpr int BX_PITCH = H + 4;                 // transpose tile row pitch (floats): 16-byte aligned rows
 constexpr int BX_TILE = KNN * BX_PITCH;         // 4224 floats per wave
 // the four pad columns of a tile row hold per-edge scalars of the node (row = edge) instead of living in registers across the
