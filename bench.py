@@ -710,6 +710,10 @@ def secondary_block(args, dev, primary):
 
     guarded("linker_256_graphs", lambda: _row(bench_sampling(ns(workload="linker", pockets=256, samples=1, graphs_per_batch=256,
                                                                   steps=4, warmup=2), 0, 1, dev), keep=("nodes_per_gpu",)))
+    # BASELINE configs[3] per-GPU shape: 1000 DISTINCT pockets, one sample each (the driver's --gpus N line shards configs[1] jobs)
+    guarded("denovo_1000_pockets_1_sample", lambda: _row(bench_sampling(ns(pockets=1000, samples=1, graphs_per_batch=200, steps=3,
+                                                                            warmup=1, no_roofline=True), 0, 1, dev),
+                                                         keep=("nodes_per_gpu",)))
     guarded("train_32_graphs", lambda: _row(bench_train(ns(workload="train", pockets=32, steps=10, warmup=3), 0, 1, dev),
                                             keep=("nodes_per_batch",)))
     for m in ("diffbp", "diffsbdd"):

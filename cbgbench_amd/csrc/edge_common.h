@@ -170,6 +170,10 @@ __device__ __forceinline__ RbfScale load_rbf_scale(const float* att, int kv) {
 }
 constexpr float RBF_UP = (float)(1 << RBF_EXP);
 
+// XOR mask of the second v Linear's LDS rows (x2h epilogue): heads {0-3, 12-15} -> 0..7, heads {4-11} -> 8..15, so that the two
+// half-rows of lanes a ds_read_b128 lane group combines never meet on a 16-byte slot (edge_mfma.hip, epilogue)
+__host__ __device__ __forceinline__ int wbv_swizzle(int head) { return head < 4 ? head : (head < 12 ? head + 4 : head - 8); }
+
 // edge type, unitransformer.py:92-97: (src lig, dst lig)->0, (lig, prot)->1, (prot, lig)->2, (prot, prot)->3
 __device__ __forceinline__ int etype(bool src_lig, int lig_i) { return src_lig ? (lig_i ? 0 : 1) : (lig_i ? 2 : 3); }
 

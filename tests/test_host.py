@@ -193,6 +193,28 @@ def test_pocket_sharding_gloo_world2():
         assert elapsed == 2.0 and units == 11.0                  # max over ranks, sum over ranks
 
 
+def _forced_single_rank_worker(port, q):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CBGX_DIST_FORCE="1")
+    r, w, _ = sharding.init_process_group("gloo")
+    ok = torch.distributed.is_initialized() and torch.distributed.get_world_size() == 1
+    sharding.barrier()
+    q.put((r, w, ok, sharding.reduce_max_sum(1.5, 7)))
+    torch.distributed.destroy_process_group()
+
+
+def test_forced_single_rank_group_runs_the_collectives():
+    """CBGX_DIST_FORCE=1: a one-rank group is created so that barrier / reductions run through the backend (on the GPU box this
+    is how the RCCL path is exercised with one GPU, tests/test_gpu_bench.py); without it a single rank stays local"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_single_rank_worker, args=(29950 + (os.getpid() % 40), q))
+    p.start()
+    r, w, ok, red = q.get(timeout=120)
+    p.join(timeout=60)
+    assert (r, w, ok) == (0, 1, True) and red == (1.5, 7.0)
+
+
 def test_diffsbdd_model_class(golden_dir):
     """registry entry, reference-compatible state dict, bit-identical gamma table, scheduler maths vs the oracle."""
     from oracle import diffsbdd as OD
