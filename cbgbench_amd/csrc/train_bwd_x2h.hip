@@ -69,14 +69,15 @@ constexpr int BX_WAVES = CBGX_BX_WAVES;
 constexpr int BX_PITCH = H + 4;                 // transpose tile row pitch (floats): 16-byte aligned rows
 constexpr int BX_TILE = KNN * BX_PITCH;         // 4224 floats per wave
 // the four pad columns of a tile row hold per-edge scalars of the node (row = edge) instead of living in registers across the
-// phases: edge length, neighbour index, d L / d dist; column 131 of rows 0..19 holds the rbf centres
+// phases: edge length, neighbour index, d L / d dist; column 131 of rows 0..19 holds the rbf centres, of rows 20..27 of tiles 0 and 1
+// the 16 locks of the d Wr slab
 constexpr int BX_DIST = H, BX_NBR = H + 1, BX_DDIST = H + 2, BX_MU = H + 3;
 // per-wave slot of the scratch buffer that parks the key path between phase 0 and phase 2: n [2][8][64 lanes][4] + rstd [64][2]
 constexpr int BX_NK_SLOT = KNN * H + 128;
 
 struct BwdX2hLds {
     float tile[BX_WAVES][BX_TILE];              // per-wave E <-> C transposes (and the 32 x 16 E1 transposes)
-    float dwr3[G][2 * H];                       // d Wr of the dominant edge type 3, accumulated with ds_add_f32
+    float dwr3[G][2 * H];                       // d Wr of the dominant edge type 3: read-modify-write under 16 column-block locks
     float wt[NT][2 * H];                        // type-column gradients
     float lng[2 * H], lnb[2 * H];               // LayerNorm affine gradients (k | v)
     float ln[4][H];                             // LayerNorm affine itself: k gamma, k beta, v gamma, v beta
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
     for (int u = tid; u < NT * 2 * H; u += BX_WAVES * 64) (&L.wt[0][0])[u] = 0.f;
     for (int u = tid; u < 2 * H; u += BX_WAVES * 64) { L.lng[u] = 0.f; L.lnb[u] = 0.f; }
     for (int u = tid; u < 4 * H; u += BX_WAVES * 64) (&L.ln[0][0])[u] = att[A_LNK_G + u];
+    if (tid < 16) reinterpret_cast<int*>(&L.tile[tid >> 3][0])[(20 + (tid & 7)) * BX_PITCH + BX_MU] = 0;     // the slab locks
     __threadfence();
     __syncthreads();
     float* tw = L.tile[wave];
@@ -687,12 +689,38 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
             // D of the rbf-column products: lane (c = channel, q) reg r <-> g = 4 q + r (tile 0), 16 + r (tile 1, q == 0)
             auto flush_rbf_columns = [&](int tyc, int col, floatx4 a0, floatx4 a1) {
                 if (tyc == 3) {
+                    // plain read-modify-write under a per-column-block lock instead of 8 ds_add_f32 (64 LDS cycles each: the LDS
+                    // pipe, shared by the 8 waves, was 55 % busy, a third of it these atomics).  16 locks (one per 16 columns):
+                    // waves in different steps of the pass never meet.  Lock words: pad column BX_MU of rows 20..27 of tiles 0, 1.
+                    const int slot = col >> 4;
+                    int* lk = reinterpret_cast<int*>(&L.tile[slot >> 3][(20 + (slot & 7)) * BX_PITCH + BX_MU]);
+                    if (lane == 0) {
+                        int expected = 0;
+                        while (!__hip_atomic_compare_exchange_strong(lk, &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                                      __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                            expected = 0;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    const int cx = col ^ (16 * (q & 1));
+                    float v[4], w4[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(&L.dwr3[4 * q + r][col ^ (16 * (q & 1))], a0[r]);   // swizzle: 2-way banks, not 4
+                    for (int r = 0; r < 4; ++r) v[r] = L.dwr3[4 * q + r][cx];
                     if (q == 0) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) atomicAdd(&L.dwr3[16 + r][col], a1[r]);
+                        for (int r = 0; r < 4; ++r) w4[r] = L.dwr3[16 + r][col];
                     }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) L.dwr3[4 * q + r][cx] = v[r] + a0[r];
+                    if (q == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) L.dwr3[16 + r][col] = w4[r] + a1[r];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) __hip_atomic_store(lk, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
                     float* sl = slab + PB_WR + (size_t)tyc * G * 2 * H + col;
 #pragma unroll

@@ -104,6 +104,10 @@ def test_x2h_backward_kernel_fits_its_budget(tmp_path):
     # 64, folds + d hidden 2 x 64 + 64 again in pass 2, d rbf 128, rbf columns 128 (+ 16 in the mixed-class sweep)
     assert mfma16 == 64 and 500 <= mfma32 <= 560, (mfma16, mfma32)
     assert "flat_load" not in body and "flat_store" not in body and "flat_atomic" not in body
+    # the d Wr slab is updated by plain read-modify-write under 16 LDS locks (round 3: its 96 ds_add_f32 sites -- 144 executed per
+    # node at 64 LDS cycles each -- kept the CU's LDS pipe a third busy on their own); what is left are the 16-lane adds of the type
+    # columns and the LayerNorm affine
+    assert len(re.findall(r"^\s+ds_add_f32", body, flags=re.M)) <= 32 and len(re.findall(r"^\s+ds_cmpst_rtn_b32", body, flags=re.M)) >= 1
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
