@@ -89,6 +89,23 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+// wave-level LDS lock: lane 0 spins on the word, the other lanes wait at the reconvergence point
+__device__ __forceinline__ void lds_lock_w(int* lk, int lane) {
+    if (lane == 0) {
+        int expected = 0;
+        while (!__hip_atomic_compare_exchange_strong(lk, &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            expected = 0;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void lds_unlock_w(int* lk, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_store(lk, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
 
 __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
@@ -688,22 +705,13 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
             }
             // D of the rbf-column products: lane (c = channel, q) reg r <-> g = 4 q + r (tile 0), 16 + r (tile 1, q == 0)
             auto flush_rbf_columns = [&](int tyc, int col, floatx4 a0, floatx4 a1) {
+                const int slot = col >> 4;      // 16 locks, one per 16 columns: pad column BX_MU of rows 20..27 of tiles 0, 1
+                int* lk = reinterpret_cast<int*>(&L.tile[slot >> 3][(20 + (slot & 7)) * BX_PITCH + BX_MU]);
                 if (tyc == 3) {
                     // plain read-modify-write under a per-column-block lock instead of 8 ds_add_f32 (64 LDS cycles each: the LDS
                     // pipe, shared by the 8 waves, was 55 % busy, a third of it these atomics).  16 locks (one per 16 columns):
                     // waves in different steps of the pass never meet.  Lock words: pad column BX_MU of rows 20..27 of tiles 0, 1.
-                    const int slot = col >> 4;
-                    int* lk = reinterpret_cast<int*>(&L.tile[slot >> 3][(20 + (slot & 7)) * BX_PITCH + BX_MU]);
-                    if (lane == 0) {
-                        int expected = 0;
-                        while (!__hip_atomic_compare_exchange_strong(lk, &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
-                                                                      __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                            expected = 0;
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
+                    lds_lock_w(lk, lane);
                     const int cx = col ^ (16 * (q & 1));
                     float v[4], w4[4];
 #pragma unroll
@@ -718,9 +726,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
 #pragma unroll
                         for (int r = 0; r < 4; ++r) L.dwr3[16 + r][col] = w4[r] + a1[r];
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) __hip_atomic_store(lk, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    lds_unlock_w(lk, lane);
                 } else {
                     float* sl = slab + PB_WR + (size_t)tyc * G * 2 * H + col;
 #pragma unroll
