@@ -840,8 +840,10 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
             hipLaunchKernelGGL(node_proj_kernel, dim3(grid, py(CHUNKS_ALL)), dim3(256), 0, s, att, h, lig, P, n_nodes,
                                (const int*)nullptr, (const int*)nullptr, CHUNKS_ALL);
     } else {
+        // the source rows of a destination list are many (most of a pocket is within two hops of the ligand): all four chunks per
+        // workgroup unless the whole input is small (one workgroup per chunk took 88 us per h2x block of a 99.5 k-node batch, this 25)
         if (!two_jobs)
-            hipLaunchKernelGGL(node_proj_kernel, dim3(grid, (tiles <= 128 || src) ? py(CHUNKS_PS) : 1u), dim3(256), 0, s, att, h,
+            hipLaunchKernelGGL(node_proj_kernel, dim3(grid, tiles <= 128 ? py(CHUNKS_PS) : 1u), dim3(256), 0, s, att, h,
                                lig, P, n_nodes, src, src_count, CHUNKS_PS);
         if (!fused)
             hipLaunchKernelGGL(node_proj_kernel, dim3(grid, py(CHUNKS_OWN)), dim3(256), 0, s, att, h, lig, P, n_nodes, act,
