@@ -540,7 +540,7 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
         const int *dst, *dst_n, *src, *src_n;
         layer_lists(0, dst, dst_n, src, src_n);
         HIP_TRY(launch_node_mfma(packed + x2h_off(0), h, lig_flag, n_nodes, Pset[0], qset[0], Qtset[0], dst, dst_n, src,
-                                 src_n, s));
+                                 src_n, s, true));
     }
     for (int l = 0; l < num_layers; ++l) {
         float* hn = (l == num_layers - 1 && h_out) ? h_out : w.hbuf[l & 1];
@@ -566,7 +566,7 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
                 HIP_TRY(hipEventRecord(aux->fork, s));
                 HIP_TRY(hipStreamWaitEvent(aux->s, aux->fork, 0));
                 HIP_TRY(launch_node_mfma(packed + x2h_off(l + 1), hn, lig_flag, n_nodes, Pset[set ^ 1], qset[set ^ 1],
-                                         Qtset[set ^ 1], d2, d2n, s2, s2n, aux->s));
+                                         Qtset[set ^ 1], d2, d2n, s2, s2n, aux->s, true));
                 HIP_TRY(hipEventRecord(aux->join, aux->s));
             }
             HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,

@@ -49,7 +49,7 @@ hipError_t launch_attention(bool x2h, const float* att, const float* x, const fl
 #ifdef CBGX_XCHECK
     if (g_edge_impl == 1) return launch_attention_v1(x2h, att, x, h, nbr, deg, lig, gen, e_w, n_nodes, P, Qt, out, dx_out, s);
 #endif
-    hipError_t e0 = launch_node_mfma(att, h, lig, n_nodes, P, qbuf, Qt, act, act_count, src, src_count, s);
+    hipError_t e0 = launch_node_mfma(att, h, lig, n_nodes, P, qbuf, Qt, act, act_count, src, src_count, s, x2h);
     if (e0 != hipSuccess) return e0;
     return launch_edge_mfma(x2h, att, x, h, P, Qt, nbr, deg, lig, gen, e_w, n_nodes, out, dx_out, act, act_count, s);
 }

@@ -84,9 +84,11 @@ hipError_t launch_mark_from_nbr(const uint8_t* flag, const int32_t* nbr, const i
                                 hipStream_t s);
 hipError_t launch_mark_nbr(const int* list, const int* count, int n_upper, const int32_t* nbr, const int32_t* deg,
                            uint8_t* m, hipStream_t s);
+// large_lists: the destination list (when given) is expected to hold a sizeable part of the nodes (x2h blocks of the cached / pruned
+// layers) rather than the few movable atoms of an h2x block: throughput launches instead of one workgroup per column chunk
 hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,
                             float* Qt, const int* act, const int* act_count, const int* src, const int* src_count,
-                            hipStream_t s);
+                            hipStream_t s, bool large_lists = false);
 // MFMA edge kernel (edge_mfma.hip)
 int set_edge_workgroup_limit(int n);
 hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,

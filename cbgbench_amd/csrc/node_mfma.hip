@@ -822,12 +822,12 @@ constexpr int NODE_STAGE_MAX_ROWS = 8192;   // up to here the latency-built fuse
 
 hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,
                             float* Qt, const int* act, const int* act_count, const int* src, const int* src_count,
-                            hipStream_t s) {
+                            hipStream_t s, bool large_lists) {
     if (n_nodes == 0) return hipSuccess;
     const int tiles = (n_nodes + 63) / 64;
     const int grid = min(tiles, 512);
     // few row tiles (small batches, or a work list): spread the column chunks / heads over workgroups too
-    const bool small = tiles <= 128 || act != nullptr;
+    const bool small = tiles <= 128 || (act != nullptr && !large_lists);
     auto py = [&](unsigned mask) { return small ? (unsigned)__builtin_popcount(mask) : 1u; };
     // Small inputs (n_nodes bounds a work list's length too): ONE launch does projection (own columns, or all of them when
     // every node is a destination), query MLP and query fold -- such launches are bound by kernel boundaries, not throughput.
