@@ -504,144 +504,146 @@ def bench_sampling(args, rank, world, dev):
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else None
     edge_wgs = args.edge_workgroups
     _native.lib().cbgx_set_edge_workgroups(edge_wgs)
-    if streams:
-        for sx in streams:
-            sx.wait_stream(torch.cuda.current_stream(dev))       # the states were built on the current stream
+    try:      # the workgroup limit is process-wide: reset it on every way out
+        if streams:
+            for sx in streams:
+                sx.wait_stream(torch.cuda.current_stream(dev))       # the states were built on the current stream
 
-    def bench_step(i):
-        for t in block_times(i, T):
-            for b, st in enumerate(states):
-                if streams:      # batch b lives on stream b mod S: its steps stay ordered, different batches overlap
-                    with torch.cuda.stream(streams[b % n_streams]):
+        def bench_step(i):
+            for t in block_times(i, T):
+                for b, st in enumerate(states):
+                    if streams:      # batch b lives on stream b mod S: its steps stay ordered, different batches overlap
+                        with torch.cuda.stream(streams[b % n_streams]):
+                            model.denoise_step(st, t)
+                    else:
                         model.denoise_step(st, t)
-                else:
-                    model.denoise_step(st, t)
 
-    use_graph = args.graph == "on" and args.warmup + args.steps + 2 < T and args.model == "targetdiff"
-    if use_graph:
-        # every resident batch's step captured once as a hipGraph on its stream, replayed once per bench step: the steps of a
-        # batch follow each other (t = T-3, T-4, ...) instead of visiting the five time blocks
-        n_blocks = 1
-        made = [model.make_step_graph(st, warmup=2, stream=streams[b % n_streams] if streams else None)
-                for b, st in enumerate(states)]
+        use_graph = args.graph == "on" and args.warmup + args.steps + 2 < T and args.model == "targetdiff"
+        if use_graph:
+            # every resident batch's step captured once as a hipGraph on its stream, replayed once per bench step: the steps of a
+            # batch follow each other (t = T-3, T-4, ...) instead of visiting the five time blocks
+            n_blocks = 1
+            made = [model.make_step_graph(st, warmup=2, stream=streams[b % n_streams] if streams else None)
+                    for b, st in enumerate(states)]
 
-        def replay_all():
-            for b, (replay, _) in enumerate(made):
-                if streams:
-                    with torch.cuda.stream(streams[b % n_streams]):
+            def replay_all():
+                for b, (replay, _) in enumerate(made):
+                    if streams:
+                        with torch.cuda.stream(streams[b % n_streams]):
+                            replay()
+                    else:
                         replay()
-                else:
-                    replay()
 
-        for _ in range(args.warmup):
-            replay_all()
-        sharding.barrier(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            replay_all()
-        torch.cuda.synchronize(); sharding.barrier()
-        elapsed = time.perf_counter() - t0
-        t_idx = T - 1 - made[0][1] - args.warmup - args.steps
-        st = states[0]
-        st["x_lig"], st["c_lig"] = st["traj_x"][t_idx + 1].clone(), st["traj_c"][t_idx + 1].clone()
-    else:
-        for i in range(args.warmup):
-            bench_step(i)
-        sharding.barrier(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.warmup, args.warmup + args.steps):
-            bench_step(i)
-        torch.cuda.synchronize(); sharding.barrier()
-        elapsed = time.perf_counter() - t0
-    el_max, graph_steps = sharding.reduce_max_sum(elapsed, n_graphs * n_blocks * args.steps, device=dev)
-    seen = ranks_seen(dev)
-    if seen != world:
-        raise SystemExit(f"bench.py: all-reduce saw {seen} ranks, expected {world}")
+            for _ in range(args.warmup):
+                replay_all()
+            sharding.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                replay_all()
+            torch.cuda.synchronize(); sharding.barrier()
+            elapsed = time.perf_counter() - t0
+            t_idx = T - 1 - made[0][1] - args.warmup - args.steps
+            st = states[0]
+            st["x_lig"], st["c_lig"] = st["traj_x"][t_idx + 1].clone(), st["traj_c"][t_idx + 1].clone()
+        else:
+            for i in range(args.warmup):
+                bench_step(i)
+            sharding.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.warmup, args.warmup + args.steps):
+                bench_step(i)
+            torch.cuda.synchronize(); sharding.barrier()
+            elapsed = time.perf_counter() - t0
+        el_max, graph_steps = sharding.reduce_max_sum(elapsed, n_graphs * n_blocks * args.steps, device=dev)
+        seen = ranks_seen(dev)
+        if seen != world:
+            raise SystemExit(f"bench.py: all-reduce saw {seen} ranks, expected {world}")
 
-    shape = (f"{args.pockets} pockets x {args.samples} samples = {n_graphs} graphs per GPU as {len(states)} resident "
-             f"batch(es) of <= {ppb * args.samples} graphs")
-    out = {
-        "metric": "denoising graph-steps/s (pocket+ligand graphs x reverse-diffusion steps per second)",
-        "value": round(graph_steps / el_max, 2), "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * el_max / args.steps, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": (f"configs/denovo {args.model} sampling, the whole BASELINE configs[1] job: {shape}, "
-                                f"N_rec~U[350,650], N_lig~U[10,45], k=32, 9 layers, fp32, random-init synthetic weights; one "
-                                f"bench step = one reverse-diffusion step of the whole job at each of {n_blocks} time "
-                                f"blocks (t = 999-i, 749-i, 499-i, 249-i, 24-(i mod 25))") if args.workload == "denovo" else
-                               (f"configs/linker {args.model} sampling (BASELINE configs[2]): {shape} (fragment-pair pockets), "
-                                f"N_rec~U[350,650], 10-35 fixed context atoms + 3-14 generated atoms per graph (partial "
-                                f"gen_flag), k=32, 9 layers, fp32, synthetic weights; one bench step = one reverse-diffusion "
-                                f"step of the job at each of {n_blocks} time blocks"),
-                   "graphs_per_gpu": n_graphs, "nodes_per_gpu": N, "denoising_steps_per_bench_step": n_blocks,
-                   "graph_steps_per_bench_step_per_gpu": n_graphs * n_blocks,
-                   "ms_per_denoising_step_of_the_job": round(1e3 * el_max / args.steps / n_blocks, 4),
-                   "sharding": f"independent pockets x{world} ranks, no data-path collective", "ranks_seen": seen,
-                   "collective_backend": collective_backend(),
-                   "launch": "one hipGraph replay per batch and step" if use_graph else "stream launches",
-                   "streams": n_streams, "edge_workgroups": edge_wgs or 256},
-    }
-
-    if rank == 0 and not args.no_roofline:
-        # live per-kernel timing with HIP events on the launch stream (same inputs, separate pass so the
-        # event records do not perturb `value`); the dominant kernel's launches all cover one whole batch
-        lib = _native.lib()
-        st = states[0]
-        Nb = st["N"]
-        prof_steps = 2
-        names = _native.PROFILE_CLASSES
-
-        _native.check(lib.cbgx_profile_begin(80 * 5 * prof_steps + 64), "cbgx_profile_begin")
-        for i in range(prof_steps):
-            for t in block_times(args.warmup + args.steps + i, T):
-                model.denoise_step(st, t)
-        NCLS = len(names)
-        ms = (ctypes.c_double * NCLS)(); cnt = (ctypes.c_int * NCLS)()
-        _native.check(lib.cbgx_profile_end(ms, cnt, NCLS), "cbgx_profile_end")
-        # class "edge_x2h" = the launches that process all N nodes of the batch (the samplers let the library prune
-        # the last two layers and cache the first two, reported separately as "edge_x2h_listed")
-        per = {n: {"ms_total": round(ms[i], 4), "launches": cnt[i],
-                   "us_avg": round(1e3 * ms[i] / max(cnt[i], 1), 3)} for i, n in enumerate(names)}
-        deg_edges = 32 * Nb  # every node of a >=33-node graph has exactly 32 incoming edges
-        x2h_bytes = X2H_BYTES_PER_EDGE * deg_edges + X2H_BYTES_PER_NODE * Nb
-        x2h_s = 1e-3 * ms[4] / max(cnt[4], 1)
-        achieved = x2h_bytes / x2h_s / 1e9 if x2h_s > 0 else 0.0
-        layer_flops = FLOPS_PER_EDGE_LAYER * deg_edges + FLOPS_PER_NODE_LAYER * Nb
-        dev_s_layer = 1e-3 * (ms[2] + ms[3] + ms[4] + ms[5] + ms[6]) / max(cnt[4] + cnt[6], 1)
-        out["roofline"] = {
-            "bound": "hbm", "kernel": "cbgx::edge_mfma_kernel<x2h> (fused x2h edge kernel)", "achieved": round(achieved, 2),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": measured_traffic(Nb), "traffic_source": TRAFFIC_SOURCE,
-            "nodes_per_launch": Nb, "algorithmic_bytes_per_launch": x2h_bytes, "avg_launch_us": round(1e6 * x2h_s, 3),
-            "note": "algorithmic bytes = SURVEY.md 8d message-passing stage at the reference tensor boundary "
-                    "(1032 B/edge + 1536 B/node) x edges/nodes per launch; the kernel is fused (edge MLP + "
-                    "attention), so real HBM traffic is far lower; timed on the first resident batch",
-            "mfma_view": {
-                "fp32_mfma_tflops": round(X2H_FP32_MFMA_FLOPS_PER_EDGE * deg_edges / x2h_s / 1e12, 3) if x2h_s > 0 else 0,
-                "fp32_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
-                "f16_mfma_tflops_issued": round(X2H_F16_MFMA_FLOPS_PER_NODE * Nb / x2h_s / 1e12, 3) if x2h_s > 0 else 0,
-                "f16_peak_tflops": F16_MFMA_PEAK_TFLOPS,
-                "x2h_kernel_useful_tflops": round((X2H_EXEC_FLOPS_PER_EDGE * deg_edges + X2H_EXEC_FLOPS_PER_NODE * Nb)
-                                                  / x2h_s / 1e12, 3) if x2h_s > 0 else 0,
-                "reference_factored_equiv_tflops": round(layer_flops / dev_s_layer / 1e12, 3) if dev_s_layer else 0,
-                "note": "fp32_mfma = the exact-fp32 MFMAs the x2h kernel issues (scores + aggregation, 8192 flop/edge) / its "
-                        "launch time; f16_mfma_issued = the split-f16 MFMAs of the rbf pre-activation (three f16 products per "
-                        "fp32 product, 128 x 8192 flop per node); useful = fp32-equivalent work of the kernel (18432 flop/edge "
-                        "+ 32768/node).  The kernel is bound by the sum of fp32-MFMA and VALU issue time on a SIMD, not by "
-                        "either peak (DESIGN.md 9).  reference_factored_equiv = SURVEY.md 8d factored flops of a whole layer / "
-                        "device time per layer: it may exceed the fp32 peak because the library moves both second Linears off "
-                        "the edges (query fold, post-aggregation value Linear), caches the ligand-free protein rows and prunes "
-                        "the last layers"},
-            "per_kernel": per,
-            "profiled_sections_per_denoising_step": round(sum(cnt) / (5.0 * prof_steps), 1),
+        shape = (f"{args.pockets} pockets x {args.samples} samples = {n_graphs} graphs per GPU as {len(states)} resident "
+                 f"batch(es) of <= {ppb * args.samples} graphs")
+        out = {
+            "metric": "denoising graph-steps/s (pocket+ligand graphs x reverse-diffusion steps per second)",
+            "value": round(graph_steps / el_max, 2), "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * el_max / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"configs/denovo {args.model} sampling, the whole BASELINE configs[1] job: {shape}, "
+                                    f"N_rec~U[350,650], N_lig~U[10,45], k=32, 9 layers, fp32, random-init synthetic weights; one "
+                                    f"bench step = one reverse-diffusion step of the whole job at each of {n_blocks} time "
+                                    f"blocks (t = 999-i, 749-i, 499-i, 249-i, 24-(i mod 25))") if args.workload == "denovo" else
+                                   (f"configs/linker {args.model} sampling (BASELINE configs[2]): {shape} (fragment-pair pockets), "
+                                    f"N_rec~U[350,650], 10-35 fixed context atoms + 3-14 generated atoms per graph (partial "
+                                    f"gen_flag), k=32, 9 layers, fp32, synthetic weights; one bench step = one reverse-diffusion "
+                                    f"step of the job at each of {n_blocks} time blocks"),
+                       "graphs_per_gpu": n_graphs, "nodes_per_gpu": N, "denoising_steps_per_bench_step": n_blocks,
+                       "graph_steps_per_bench_step_per_gpu": n_graphs * n_blocks,
+                       "ms_per_denoising_step_of_the_job": round(1e3 * el_max / args.steps / n_blocks, 4),
+                       "sharding": f"independent pockets x{world} ranks, no data-path collective", "ranks_seen": seen,
+                       "collective_backend": collective_backend(),
+                       "launch": "one hipGraph replay per batch and step" if use_graph else "stream launches",
+                       "streams": n_streams, "edge_workgroups": edge_wgs or 256},
         }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import weights as OW
-        osd = {"targetdiff": oracle_state_dict, "diffbp": lambda: OW.synthetic_state_dict_diffbp(13, 9, seed=0, num_timesteps=T),
-               "diffsbdd": lambda: OW.synthetic_state_dict_diffsbdd(8, 9, seed=0, num_timesteps=T)}[args.model]()
-        out["cpu_baseline"] = cpu_baseline(osd, seed=1000, model=args.model)
-        out["cpu_baseline"]["all_cores"] = cpu_baseline_concurrent(out["cpu_baseline"]["cores"], model=args.model)
-    _native.lib().cbgx_set_edge_workgroups(0)
+
+        if rank == 0 and not args.no_roofline:
+            # live per-kernel timing with HIP events on the launch stream (same inputs, separate pass so the
+            # event records do not perturb `value`); the dominant kernel's launches all cover one whole batch
+            lib = _native.lib()
+            st = states[0]
+            Nb = st["N"]
+            prof_steps = 2
+            names = _native.PROFILE_CLASSES
+
+            _native.check(lib.cbgx_profile_begin(80 * 5 * prof_steps + 64), "cbgx_profile_begin")
+            for i in range(prof_steps):
+                for t in block_times(args.warmup + args.steps + i, T):
+                    model.denoise_step(st, t)
+            NCLS = len(names)
+            ms = (ctypes.c_double * NCLS)(); cnt = (ctypes.c_int * NCLS)()
+            _native.check(lib.cbgx_profile_end(ms, cnt, NCLS), "cbgx_profile_end")
+            # class "edge_x2h" = the launches that process all N nodes of the batch (the samplers let the library prune
+            # the last two layers and cache the first two, reported separately as "edge_x2h_listed")
+            per = {n: {"ms_total": round(ms[i], 4), "launches": cnt[i],
+                       "us_avg": round(1e3 * ms[i] / max(cnt[i], 1), 3)} for i, n in enumerate(names)}
+            deg_edges = 32 * Nb  # every node of a >=33-node graph has exactly 32 incoming edges
+            x2h_bytes = X2H_BYTES_PER_EDGE * deg_edges + X2H_BYTES_PER_NODE * Nb
+            x2h_s = 1e-3 * ms[4] / max(cnt[4], 1)
+            achieved = x2h_bytes / x2h_s / 1e9 if x2h_s > 0 else 0.0
+            layer_flops = FLOPS_PER_EDGE_LAYER * deg_edges + FLOPS_PER_NODE_LAYER * Nb
+            dev_s_layer = 1e-3 * (ms[2] + ms[3] + ms[4] + ms[5] + ms[6]) / max(cnt[4] + cnt[6], 1)
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "cbgx::edge_mfma_kernel<x2h> (fused x2h edge kernel)", "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": measured_traffic(Nb), "traffic_source": TRAFFIC_SOURCE,
+                "nodes_per_launch": Nb, "algorithmic_bytes_per_launch": x2h_bytes, "avg_launch_us": round(1e6 * x2h_s, 3),
+                "note": "algorithmic bytes = SURVEY.md 8d message-passing stage at the reference tensor boundary "
+                        "(1032 B/edge + 1536 B/node) x edges/nodes per launch; the kernel is fused (edge MLP + "
+                        "attention), so real HBM traffic is far lower; timed on the first resident batch",
+                "mfma_view": {
+                    "fp32_mfma_tflops": round(X2H_FP32_MFMA_FLOPS_PER_EDGE * deg_edges / x2h_s / 1e12, 3) if x2h_s > 0 else 0,
+                    "fp32_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                    "f16_mfma_tflops_issued": round(X2H_F16_MFMA_FLOPS_PER_NODE * Nb / x2h_s / 1e12, 3) if x2h_s > 0 else 0,
+                    "f16_peak_tflops": F16_MFMA_PEAK_TFLOPS,
+                    "x2h_kernel_useful_tflops": round((X2H_EXEC_FLOPS_PER_EDGE * deg_edges + X2H_EXEC_FLOPS_PER_NODE * Nb)
+                                                      / x2h_s / 1e12, 3) if x2h_s > 0 else 0,
+                    "reference_factored_equiv_tflops": round(layer_flops / dev_s_layer / 1e12, 3) if dev_s_layer else 0,
+                    "note": "fp32_mfma = the exact-fp32 MFMAs the x2h kernel issues (scores + aggregation, 8192 flop/edge) / its "
+                            "launch time; f16_mfma_issued = the split-f16 MFMAs of the rbf pre-activation (three f16 products per "
+                            "fp32 product, 128 x 8192 flop per node); useful = fp32-equivalent work of the kernel (18432 flop/edge "
+                            "+ 32768/node).  The kernel is bound by the sum of fp32-MFMA and VALU issue time on a SIMD, not by "
+                            "either peak (DESIGN.md 9).  reference_factored_equiv = SURVEY.md 8d factored flops of a whole layer / "
+                            "device time per layer: it may exceed the fp32 peak because the library moves both second Linears off "
+                            "the edges (query fold, post-aggregation value Linear), caches the ligand-free protein rows and prunes "
+                            "the last layers"},
+                "per_kernel": per,
+                "profiled_sections_per_denoising_step": round(sum(cnt) / (5.0 * prof_steps), 1),
+            }
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from oracle import weights as OW
+            osd = {"targetdiff": oracle_state_dict, "diffbp": lambda: OW.synthetic_state_dict_diffbp(13, 9, seed=0, num_timesteps=T),
+                   "diffsbdd": lambda: OW.synthetic_state_dict_diffsbdd(8, 9, seed=0, num_timesteps=T)}[args.model]()
+            out["cpu_baseline"] = cpu_baseline(osd, seed=1000, model=args.model)
+            out["cpu_baseline"]["all_cores"] = cpu_baseline_concurrent(out["cpu_baseline"]["cores"], model=args.model)
+    finally:
+        _native.lib().cbgx_set_edge_workgroups(0)
     del states, model
     torch.cuda.empty_cache()
     return out

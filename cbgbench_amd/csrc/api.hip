@@ -117,7 +117,7 @@ struct AuxStream {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
-constexpr int MAX_AUX = 4;
+constexpr int MAX_AUX = 8;    // batches a caller can keep in flight without aux streams changing owner (bench --streams 8, sample_many)
 struct AuxTable {
     int dev = -1;
     int n = 0;

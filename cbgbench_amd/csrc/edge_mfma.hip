@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "edge_common.h"
 #include "kernels.h"
 #include "layout.h"
@@ -40,7 +42,7 @@ __constant__ float c_mu[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.
                               3.5f, 4.f, 4.5f, 5.f, 5.5f, 6.f, 7.f, 8.f, 9.f, 10.f};
 
 // ---- edge-major path for one half (16 edges): pre-activation -> LayerNorm -> ReLU -> contraction with a
-// per-lane row of B (Qt[i][a] for scores, Wbv[a] for the h2x values).  Returns the 16x16 result tile:
+// per-lane row of B (Qt[i][a] for scores: registers `pre`; Wbv[a] for the h2x values: LDS `lds_brow`, already lane-offset).  Returns the 16x16 result tile:
 // lane (c = a, q), reg r <-> edge 4q + r + 16hf.  `kv` selects the k (0) or v (1) quarter everywhere.
 // `acc` enters as PD[i] + PS[j] (this node's and the neighbour's projection rows, channels 16t + 4q .. +3), summed by
 // the caller as soon as the gathered rows arrive, so that the registers of the gather can be reused for the next one.
@@ -48,7 +50,7 @@ template <bool PRE>
 __device__ __forceinline__ floatx4 edge_major_half(floatx4 (&acc)[8], bool lg, int kv,
                                                    const float* lds_frag, const float* lds_dwt, const float* lds_ln,
                                                    const float (&R)[5], bool has_prot, bool has_lig, int lig_i,
-                                                   int lane, int q, gptr Brow, unsigned brow_off,
+                                                   int lane, int q, const float* lds_brow,
                                                    const float4 (&pre)[8], const RbfScale sc) {
     if (has_lig) {  // wave-uniform: only nodes with a ligand neighbour pay for the type correction
         const float* dw = lds_dwt + lig_i * 2 * H + kv * H + 4 * q;
@@ -95,7 +97,7 @@ __device__ __forceinline__ floatx4 edge_major_half(floatx4 (&acc)[8], bool lg, i
         const floatx4 g = f4(ld4(lg_ + 16 * t)), b = f4(ld4(lb_ + 16 * t));
         const float2v ya = (lo2(acc[t]) * r2) * lo2(g) + lo2(b);
         const float2v yb = (hi2(acc[t]) * r2) * hi2(g) + hi2(b);
-        const float4 bb = PRE ? pre[t] : ldo4(Brow, brow_off + 64 * t);
+        const float4 bb = PRE ? pre[t] : ld4(lds_brow + 256 * t);    // h2x: Wbv[head c][16 t + 4 q ..] (layout.h, image "wbv")
         out0 = MFMA(fmaxf(ya.x, 0.f), bb.x, out0);
         out1 = MFMA(fmaxf(ya.y, 0.f), bb.y, out1);
         out0 = MFMA(fmaxf(yb.x, 0.f), bb.z, out0);
@@ -207,6 +209,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     if (i_begin >= i_end) return;
     // power-of-two scales of the split-f16 rbf tables (wave-uniform: scalar registers)
     const RbfScale sck = load_rbf_scale(att, 0), scv = load_rbf_scale(att, 1);
+    // h2x: bias of this lane's head, once per launch -- loaded inside the loop it sat behind the next node's 24-row prefetch in the
+    // in-order vmcnt queue, so the wait for this one word drained the whole prefetch before the node's store
+    const float bbv = X2H ? 0.f : att[A_BBV + c];
 
     // ---- first item: geometry and the k-path rows, everything unconditional -------------------------------------
     ItemGeom g;
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         // ---- k path: hidden (edge-major) -> scores -> softmax ------------------------------------------
         floatx4 sc[2];
         sc[0] = edge_major_half<true>(acc0, lg0[0], 0, lds_fk, lds_dwt, lds_ln, R[0], has_prot, has_lig, lig_i, lane, q,
-                                      (gptr)0, 0u, qrow, sck);
+                                      nullptr, qrow, sck);
         __builtin_amdgcn_sched_barrier(0);
         // (b) next item: resolve its neighbour ids (they arrived during the first half), request their flags and
         // coordinates; then the second half of the PS_v gather and the gate values
@@ -348,10 +353,41 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         const unsigned oqe = vop(16 * q);
         ew0 = ldo4(ewp, oqe);
         ew1 = ldo4(ewp, oqe + 64);
+        // h2x: this node's PD_v row and the PS_v rows of half 0 (edge-major), needed after the second k half: the registers of the
+        // first half's accumulators carry them (until round 3 all 24 v rows were requested and waited for in one place, a full
+        // exposed round trip per listed node)
+        float4 vd[8], vs0[8], vs1[8];
+        if (!X2H) {
+            const gptr pdp = sbase(P + (size_t)i * PROW);
+            const unsigned o0 = (unsigned)g.j0[0] * (PROW * 4) + (3 * H + 4 * q) * 4;
+            const unsigned ovd = vop((H + 4 * q) * 4);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { vd[t] = ldo4(pdp, ovd + 64 * t); vs0[t] = ldo4(sbase(P), o0 + 64 * t); }
+        }
         __builtin_amdgcn_sched_barrier(0);
         sc[1] = edge_major_half<true>(acc1, lg0[1], 0, lds_fk, lds_dwt, lds_ln, R[1], has_prot, has_lig, lig_i, lane, q,
-                                      (gptr)0, 0u, qrow, sck);
+                                      nullptr, qrow, sck);
         __builtin_amdgcn_sched_barrier(0);
+        if (!X2H) {   // PS_v rows of half 1: in flight during the softmax and the first v half
+            const unsigned o1 = (unsigned)g.j0[1] * (PROW * 4) + (3 * H + 4 * q) * 4;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) vs1[t] = ldo4(sbase(P), o1 + 64 * t);
+        }
+        // h2x: the neighbours' coordinates in the E1 mapping (equivariant update of the epilogue), requested here (the query
+        // row and the k accumulators are dead) with the ids that came with this node's rows: the epilogue then has no load of its own (it used to run 24 dependent-looking dword loads, each
+        // behind a vmcnt wait that also retired the next node's row prefetch: ~15 L2 round trips per listed node)
+        float xj[2][4][3] = {};
+        if (!X2H) {
+            const int nbv[2][4] = {{nb0.x, nb0.y, nb0.z, nb0.w}, {nb1.x, nb1.y, nb1.z, nb1.w}};
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // invalid slots point at the node itself: rel = 0 and alpha = 0, so they add exactly nothing
+                    const unsigned o = 12u * (unsigned)e1_id(nbv[hf][r], 4 * q + r + 16 * hf, d, i);
+                    xj[hf][r][0] = ldo1(sbase(x), o); xj[hf][r][1] = ldo1(sbase(x), o + 4); xj[hf][r][2] = ldo1(sbase(x), o + 8);
+                }
+        }
         // next item: distances and ligand flags of its edges from the (b) loads
         bool nlg[2];
         float ndist[2];
@@ -544,26 +580,17 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             // ---- h2x: v hidden edge-major, wv[e][a] = Wbv[a] . hid_v[e] + bbv[a] -------------------------------
             floatx4 wv[2];
             {
-                float4 vd[8], vs0[8], vs1[8];
-                const gptr pdp = sbase(P + (size_t)i * PROW);
-                const unsigned o0 = (unsigned)g.j0[0] * (PROW * 4) + (3 * H + 4 * q) * 4, o1 = (unsigned)g.j0[1] * (PROW * 4) + (3 * H + 4 * q) * 4;
-                const unsigned ovd = vop((H + 4 * q) * 4);
-#pragma unroll
-                for (int t = 0; t < 8; ++t) { vd[t] = ldo4(pdp, ovd + 64 * t); vs0[t] = ldo4(sbase(P), o0 + 64 * t); }
-#pragma unroll
-                for (int t = 0; t < 8; ++t) vs1[t] = ldo4(sbase(P), o1 + 64 * t);
-                const gptr wrow = sbase(att + A_WBV);
-                const unsigned wrow_off = vop((c * H + 4 * q) * 4);
+                const float* lds_brow = lds + IMG_WBV + 4 * lane;       // Wbv[head c][16 t + 4 q ..] at 256 t (layout.h)
                 floatx4 acc[8];
 #pragma unroll
                 for (int t = 0; t < 8; ++t) { vd[t] = make_float4(vd[t].x * scv.S, vd[t].y * scv.S, vd[t].z * scv.S, vd[t].w * scv.S); acc[t] = f4(vs0[t]) * scv.S + f4(vd[t]); }
                 wv[0] = edge_major_half<false>(acc, lg0[0], 1, lds_fv, lds_dwt, lds_ln, R[0], has_prot, has_lig, lig_i, lane, q,
-                                               wrow, wrow_off, qrow, scv);
+                                               lds_brow, qrow, scv);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 8; ++t) acc[t] = f4(vs1[t]) * scv.S + f4(vd[t]);
                 wv[1] = edge_major_half<false>(acc, lg0[1], 1, lds_fv, lds_dwt, lds_ln, R[1], has_prot, has_lig, lig_i, lane, q,
-                                               wrow, wrow_off, qrow, scv);
+                                               lds_brow, qrow, scv);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // (c) next item: its PD / PS_k rows
@@ -578,25 +605,21 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                 for (int t = 0; t < 8; ++t) ps1[t] = ldo4(sbase(P), o1 + 64 * t);
             }
             __builtin_amdgcn_sched_barrier(0);
-            const float bbv = ldo1(sbase(att + A_BBV), vop(4 * c));
             {
                 const gptr nrow2 = sbase(nbr + (size_t)inext * KNN);
                 const unsigned oq2 = vop(16 * q);
                 nnb0 = ldoi4(nrow2, oq2); nnb1 = ldoi4(nrow2, oq2 + 64);
             }
-            const int nbv[2][4] = {{nb0.x, nb0.y, nb0.z, nb0.w}, {nb1.x, nb1.y, nb1.z, nb1.w}};
             float dx = 0.f, dy = 0.f, dz = 0.f;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    // invalid slots point at the node itself: rel = 0 and alpha = 0, so they add exactly nothing
-                    const int j = e1_id(nbv[hf][r], 4 * q + r + 16 * hf, d, i);
                     const float coef = (al[hf][r] * inv_den) * ((wv[hf][r] + bbv) * ew[hf][r]);
                     const float cf = 4 * q + r + 16 * hf < d ? coef : 0.f;
-                    dx = fmaf(cf, g.xi - ldo1(sbase(x), 12u * j), dx);
-                    dy = fmaf(cf, g.yi - ldo1(sbase(x), 12u * j + 4), dy);
-                    dz = fmaf(cf, g.zi - ldo1(sbase(x), 12u * j + 8), dz);
+                    dx = fmaf(cf, g.xi - xj[hf][r][0], dx);
+                    dy = fmaf(cf, g.yi - xj[hf][r][1], dy);
+                    dz = fmaf(cf, g.zi - xj[hf][r][2], dz);
                 }
             dx = wave_sum(dx); dy = wave_sum(dy); dz = wave_sum(dz);
             if (lane < 3) {
@@ -636,7 +659,7 @@ __global__ __launch_bounds__(1024) void pack_rbf_scale_kernel(PackBlocks pb) {
     if (threadIdx.x == 0) {
         for (int k = 1; k < 16; ++k) mx = fmaxf(mx, red[k]);
         const int E = (int)((__float_as_uint(mx) >> 23) & 0xffu);      // max in [2^(E-127), 2^(E-126))
-        const int kw = max(-80, min(RBF_KW_MAX, 141 - E));
+        const int kw = max(RBF_KW_MIN, min(RBF_KW_MAX, 141 - E));
         const float S = ldexpf(1.f, kw + RBF_EXP);
         float* sc = att + A_RBF_SC + 4 * kv;
         sc[0] = S;
@@ -693,7 +716,15 @@ __global__ void pack_dwt_kernel(PackBlocks pb) {
 // 16-byte chunk K = 16 hh + 4 q + j, position r; the chunk index is XOR-swizzled by wbv_swizzle(head n >> 3)
 __global__ void pack_wbv_swz_kernel(PackBlocks pb) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // n * 128 + m
-    if (idx >= H * H || !pb.x2h[blockIdx.y]) return;
+    if (idx >= H * H) return;
+    if (!pb.x2h[blockIdx.y]) {
+        // h2x blocks: the 16 head rows [head][m] in the B-operand order of the value contraction (layout.h, image "wbv"):
+        // lane (c = head, q) reads Wbv[c][16 t + 4 q + r] at (64 t + lane) * 4 + r
+        if (idx >= HEADS * H) return;
+        const int head = idx >> 7, m = idx & 127, t = m >> 4, q = (m >> 2) & 3, r = m & 3;
+        pb.att[blockIdx.y][A_IMG + IMG_WBV + ((64 * t + 16 * q + head) << 2) + r] = pb.wv1[blockIdx.y][idx];
+        return;
+    }
     const int n = idx >> 7, m = idx & 127;
     const int chunk = 16 * (m >> 6) + 4 * ((m >> 4) & 3) + (m & 3), r = (m >> 2) & 3;
     pb.att[blockIdx.y][A_IMG + IMG_WBV + n * H + (((chunk ^ wbv_swizzle((n >> 3) & 15)) << 2) | r)] = pb.wv1[blockIdx.y][idx];
@@ -738,12 +769,9 @@ hipError_t launch_pack_stage2(const PackBlocks& pb, hipStream_t s) {
 }
 
 // cbgx_set_edge_workgroups (include/cbgx.h): upper bound of the persistent x2h grid, 0 = one workgroup per CU
-static int g_edge_wg_limit = 0;
-int set_edge_workgroup_limit(int n) {
-    const int old = g_edge_wg_limit;
-    g_edge_wg_limit = n < 0 ? 0 : n;
-    return old;
-}
+// process-wide (the one piece of library state shared between host threads): relaxed atomic, read once per launch
+static std::atomic<int> g_edge_wg_limit{0};
+int set_edge_workgroup_limit(int n) { return g_edge_wg_limit.exchange(n < 0 ? 0 : n, std::memory_order_relaxed); }
 
 hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,
                             const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
@@ -754,7 +782,8 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
     constexpr int W = 8;                        // waves per persistent workgroup: 2 per SIMD at <= 256 VGPRs per lane
     int grid = (n_nodes + W - 1) / W;
     if (grid > 256) grid = 256;                 // persistent: one workgroup per CU (LDS-limited)
-    if (x2h && g_edge_wg_limit >= 8 && grid > g_edge_wg_limit) grid = g_edge_wg_limit;   // the caller keeps CUs free for another stream
+    const int wg_limit = g_edge_wg_limit.load(std::memory_order_relaxed);
+    if (x2h && wg_limit >= 8 && grid > wg_limit) grid = wg_limit;   // the caller keeps CUs free for another stream
     if (grid >= 64) grid &= ~7;                 // multiple of 8 -> XCD-aware node partition
     profile_mark_begin(x2h ? (act ? K_EDGE_X2H_LISTED : K_EDGE_X2H) : K_EDGE_H2X, s);
 #define CBGX_LAUNCH_EDGE(X2H_, L_)                                                                              \

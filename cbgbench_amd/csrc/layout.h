@@ -54,7 +54,9 @@ constexpr size_t A_BBV = A_WBV + (size_t)H * H;   // [128] (h2x: first 16)
 //   frag_v [4][8][320]                    same for v.  x2h: B operand, channel-major; h2x: A operand, edge-major
 //   dwt    [2][256] (+512 unused)         dWt[lig_i][k|v] = Wt[type(src lig, i)] - Wt[type(src prot, i)]
 //   ln     [4][128]                       gamma_k, beta_k, gamma_v, beta_v
-//   wbv_rm [128][128]                     x2h only: second v Linear, row-major (out n, in m)
+//   wbv    x2h: [128][128]                second v Linear, rows (out n) of 16-byte chunks in the epilogue's order (edge_mfma.hip)
+//          h2x: [8 t][64 lanes][4]        the 16 head rows as the B operand of the value contraction: lane (c = head, q) finds
+//                                         Wbv[c][16 t + 4 q .. + 3] at (64 t + lane) * 4 -- a linear, conflict-free ds_read_b128
 constexpr size_t FRAG_BLK = 320;                       // floats per (type, tile)
 constexpr size_t FRAG = (size_t)NT * 8 * FRAG_BLK;     // 10240
 constexpr size_t A_IMG = A_BBV + H;
@@ -63,7 +65,7 @@ constexpr size_t IMG_FRAG_V = IMG_FRAG_K + FRAG;
 constexpr size_t IMG_WT = IMG_FRAG_V + FRAG;
 constexpr size_t IMG_LN = IMG_WT + NT * 2 * H;
 constexpr size_t IMG_WBV = IMG_LN + 4 * H;
-constexpr size_t IMG_SIZE_H2X = IMG_WBV;                 // 22016 floats
+constexpr size_t IMG_SIZE_H2X = IMG_WBV + (size_t)HEADS * H;  // 24064 floats = 96256 B
 constexpr size_t IMG_SIZE_X2H = IMG_WBV + (size_t)H * H; // 38400 floats = 153600 B
 // fragment-ordered tables of the MFMA node kernels (node_mfma.hip)
 constexpr size_t A_NPROJ_FRAG = A_IMG + IMG_SIZE_X2H;              // [10 ch][4 ct][8 s4][64 lanes][4]
@@ -98,6 +100,7 @@ constexpr size_t A_FRAGV_EM = A_WRC + (size_t)NT * G * 2 * H;
 //   A_WQ1_CINV   [128]           same for the query MLP's second Linear (A_WQ1_FRAG)
 // The activations (rows of h, LayerNorm outputs) are scaled per row inside the node kernels.
 constexpr int RBF_EXP = 12;          // rbf values in [0, 1] -> [0, 2^12]
+constexpr int RBF_KW_MIN = -40;      // S >= 2^-28: 1 / (H S^2) stays a finite fp32 number (weights up to 2^54 keep full precision)
 constexpr int RBF_KW_MAX = 20;       // S <= 2^32: sum of squares of 128 scaled pre-activations stays finite up to |pre| = 2^28
 constexpr size_t A_RBF_SC = A_FRAGV_EM + FRAG;
 constexpr size_t A_NPROJ_CINV = A_RBF_SC + 8;

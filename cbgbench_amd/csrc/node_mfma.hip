@@ -70,135 +70,27 @@ __device__ __forceinline__ void split8(const float (&v)[8], float up, half8& hi8
 }
 
 // ------------------------------------------------------------------------------------------------
-// node_proj: 4 waves x 16 rows per workgroup; 10 column chunks of 64; chunk tables double-buffered in LDS.
+// node_proj: P[:, chunk] for one 64-column chunk per workgroup, the chunk's split-f16 table RESIDENT in LDS (32 KB, filled once);
+// a 4-wave workgroup then streams 64-row tiles past it, one wave per 16 rows, with no barrier and no LDS write in the loop.
+// (Round 4.  Until round 3 a workgroup kept its rows and streamed the ten chunk tables through a double-buffered LDS slot: every
+// chunk was load -> wait -> ds_write -> barrier -> 48 MFMAs -> stores with nothing overlapped and two workgroups per CU, 106 us
+// per 99.5 k-node launch against a store floor of 38 us.  Here four workgroups per CU = four waves per SIMD run independent
+// load / split / MFMA / store chains, so one wave's L2 round trip is another wave's MFMA block.)
 // The product runs in split-f16 on v_mfma_f32_16x16x32_f16 (K = 32 per instruction, 8 f16 per lane and operand): the 128
-// features of a row are split once per row tile (hi / lo, 4 + 4 operands per lane), the weights at pack time; 3 x 4 MFMAs per
-// 16 x 16 output tile instead of 32 exact-fp32 ones -- the kernel goes from matrix-bound to bound by its 2.5 KB/row of stores.
+// features of a row are split per row tile and chunk (hi / lo, 4 + 4 operands per lane), the weights at pack time; 3 x 4 MFMAs per
+// 16 x 16 output tile instead of 32 exact-fp32 ones.
 // K slot j of instruction u in lane group q <-> k = 16 (2u + (j >> 2)) + 4q + (j & 3), so the four q-lanes of a row still read
 // one contiguous 64-byte run of h per load.  Chunk table order: [part hi|lo][ct 4][u 4][lane 64][8 f16]
 //   = split(Wn[k(u, q, j)][col = 64 ch + 4c + ct])
+// Same arithmetic per output element as the streaming kernel it replaces (same operands, same MFMA order): P is bit-identical.
 // ------------------------------------------------------------------------------------------------
 constexpr int NP_CHUNK = 2 * 4 * 4 * 64 * 4;  // 8192 floats = 32 KB (two f16 per float slot)
 constexpr int NP_CHUNKS = PROW / 64;          // 10
 
-// `rows` / `n_rows_ptr` (optional): compute only the listed rows (device-side count, no host sync); results are
-// written to their natural positions P[rows[k]].  `chunk_mask`: which of the 10 column chunks to produce.
-__global__ __launch_bounds__(256) void node_proj_kernel(const float* __restrict__ att, const float* __restrict__ h,
-                                                        const uint8_t* __restrict__ lig, float* __restrict__ P,
-                                                        int n_nodes, const int* __restrict__ rows,
-                                                        const int* __restrict__ n_rows_ptr, unsigned chunk_mask) {
-    __shared__ __attribute__((aligned(16))) float lds[2][NP_CHUNK];
-    const float* frag = att + A_NPROJ_FRAG;
-    const float* bias = att + A_BN2;  // [dst class][640]: bias + type column of a protein source
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
-    const int n_rows = rows ? *n_rows_ptr : n_nodes;
-    const int n_tiles = (n_rows + 63) / 64;
-    if (gridDim.y > 1) {   // small inputs: one workgroup per (row tile, column chunk) instead of looping over chunks
-        unsigned m = chunk_mask;
-        for (unsigned k = 0; k < blockIdx.y; ++k) m &= m - 1;
-        chunk_mask = m & (0u - m);
-    }
-    if ((int)blockIdx.x >= n_tiles || chunk_mask == 0) return;   // whole workgroup: nothing to do
-    const int first_chunk = __ffs(chunk_mask) - 1;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int row0 = tile * 64 + wave * 16;
-        const int ak = min(row0 + c, n_rows - 1);
-        const int arow = rows ? rows[ak] : ak;
-        int orow[4];
-        bool lgr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = row0 + 4 * q + r;
-            const int kk = min(k, n_rows - 1);
-            orow[r] = k < n_rows ? (rows ? rows[kk] : kk) : -1;
-            lgr[r] = lig[rows ? rows[kk] : kk] != 0;
-        }
-        half8 ah[4], al[4];
-        float rinv[4];
-        {
-            float hv[4][8];
-            float mx = 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 v0 = nld4(h + (size_t)arow * H + 32 * u + 4 * q), v1 = nld4(h + (size_t)arow * H + 32 * u + 16 + 4 * q);
-                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { hv[u][j] = v[j]; mx = fmaxf(mx, fabsf(v[j])); }
-            }
-            float inv;
-            const float up = row_pow2(nxrow_max(mx), inv);
-            rows_to_c_layout(inv, q, rinv);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) split8(hv[u], up, ah[u], al[u]);
-        }
-        __syncthreads();  // previous tile's readers of lds[0] are done
-        {
-            const float4* src = reinterpret_cast<const float4*>(frag + (size_t)first_chunk * NP_CHUNK);
-            float4* dst = reinterpret_cast<float4*>(lds[0]);
-#pragma unroll
-            for (int u = 0; u < NP_CHUNK / 4 / 256; ++u) dst[tid + 256 * u] = src[tid + 256 * u];
-        }
-        __syncthreads();
-        unsigned todo = chunk_mask;
-        for (int is = 0; todo != 0; ++is) {
-            const int ch = __ffs(todo) - 1;      // wave-uniform scalar bit scan over the selected chunks
-            todo &= todo - 1;
-            // prefetch the next selected chunk into registers (unconditional: the last iteration re-reads its own
-            // chunk and writes it to the idle buffer, which keeps `stage` in registers instead of scratch)
-            const int chn = todo != 0 ? __ffs(todo) - 1 : ch;
-            float4 stage[NP_CHUNK / 4 / 256];
-            {
-                const float4* src = reinterpret_cast<const float4*>(frag + (size_t)chn * NP_CHUNK);
-#pragma unroll
-                for (int u = 0; u < NP_CHUNK / 4 / 256; ++u) stage[u] = src[tid + 256 * u];
-            }
-            const half8* Bh = reinterpret_cast<const half8*>(lds[is & 1]) + lane;   // [ct][u][lane]
-            const half8* Bl = Bh + 4 * 4 * 64;
-            const float4 bP = nld4(bias + 64 * ch + 4 * c), bL = nld4(bias + PROW + 64 * ch + 4 * c);
-            const float4 ci = nld4(att + A_NPROJ_CINV + 64 * ch + 4 * c);     // 2^-kc of this lane's four columns
-            floatx4 acc[4];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                half8 bh[4], bl[4];
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) { bh[ct] = Bh[(ct * 4 + u) * 64]; bl[ct] = Bl[(ct * 4 + u) * 64]; }
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(ah[u], bl[ct], acc[ct]);
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(al[u], bh[ct], acc[ct]);
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(ah[u], bh[ct], acc[ct]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (orow[r] >= 0) {
-                    const float4 b = lgr[r] ? bL : bP;
-                    float4 o = {fmaf(acc[0][r] * rinv[r], ci.x, b.x), fmaf(acc[1][r] * rinv[r], ci.y, b.y),
-                                fmaf(acc[2][r] * rinv[r], ci.z, b.z), fmaf(acc[3][r] * rinv[r], ci.w, b.w)};
-                    *reinterpret_cast<float4*>(P + (size_t)orow[r] * PROW + 64 * ch + 4 * c) = o;
-                }
-            }
-            {
-                float4* dst = reinterpret_cast<float4*>(lds[(is + 1) & 1]);
-#pragma unroll
-                for (int u = 0; u < NP_CHUNK / 4 / 256; ++u) dst[tid + 256 * u] = stage[u];
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// node_qmlp: LayerNorm + ReLU on the q-hidden quarter of P (A layout: LN is in-lane + across q), then
-// q = z @ Wq1^T + bq1 in split-f16 (K = 32 per MFMA, same slot map as node_proj).
-// Wq1 tables [part hi|lo][nt 8][u 4][lane][8 f16] = split(Wq1[n = 64(nt>>2) + 4c + (nt&3)][k = 16 (2u + (j>>2)) + 4q + (j&3)]).
-// ------------------------------------------------------------------------------------------------
+typedef float lds_fx4 __attribute__((ext_vector_type(4)));
 // LDS fill of the float4 range [begin, end) by 256 threads with every load of a thread requested before its first store (at most
 // MAXV per thread).  Written as a plain loop the compiler emits load -> wait -> ds_write per iteration: up to 16 dependent L2 round
-// trips (~11 us) at the head of every launch of the query kernels.
-typedef float lds_fx4 __attribute__((ext_vector_type(4)));
+// trips (~11 us) at the head of every launch.
 template <int MAXV>
 __device__ __forceinline__ void lds_fill_f4(float* lds, const float* src_base, int begin, int end, int tid) {
     const lds_fx4* src = reinterpret_cast<const lds_fx4*>(src_base);
@@ -217,6 +109,144 @@ __device__ __forceinline__ void lds_fill_f4(float* lds, const float* src_base, i
     }
 }
 
+// One wave's view of a 16-row tile, in two stages so that no load of the loop waits for another one of the same iteration:
+//   ProjIdx  the row numbers (A-operand row of lane c; the four output rows 4q + r of the C layout), requested TWO tiles ahead --
+//            with a work list they are a gather through `rows`;
+//   ProjTile the raw feature rows in A-operand order and the destination classes, requested ONE tile ahead from the indices
+//            that arrived during the previous tile.
+// Rows past the end are clamped to the last row (orow = -1 masks their stores): every load is unconditional -- a predicated load
+// compiles to branch + load + wait per element.
+struct ProjIdx { int arow; int orow[4]; };
+struct ProjTile {
+    float4 hv[8];       // h[arow][32u + 4q ..], h[arow][32u + 16 + 4q ..]  (u = 0..3)
+    int orow[4];        // output row, -1 past the end
+    int lgr;            // bit r: output row r is a ligand atom
+};
+template <bool LISTED>
+__device__ __forceinline__ ProjIdx proj_idx_load(const int* __restrict__ rows, int n_rows, int row0, int c, int q) {
+    ProjIdx x;
+    const int ak = min(row0 + c, n_rows - 1);
+    x.arow = LISTED ? rows[ak] : ak;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = row0 + 4 * q + r;
+        const int kk = min(k, n_rows - 1);
+        const int row = LISTED ? rows[kk] : kk;
+        x.orow[r] = k < n_rows ? row : -1 - row;       // past the end: the clamped row, encoded negative
+    }
+    return x;
+}
+__device__ __forceinline__ ProjTile proj_tile_load(const float* __restrict__ h, const uint8_t* __restrict__ lig, const ProjIdx& x,
+                                                   int q) {
+    ProjTile t;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        t.hv[2 * u] = nld4(h + (size_t)x.arow * H + 32 * u + 4 * q);
+        t.hv[2 * u + 1] = nld4(h + (size_t)x.arow * H + 32 * u + 16 + 4 * q);
+    }
+    int flags[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        t.orow[r] = x.orow[r] >= 0 ? x.orow[r] : -1;
+        flags[r] = lig[x.orow[r] >= 0 ? x.orow[r] : -1 - x.orow[r]];
+    }
+    t.lgr = (flags[0] != 0) | ((flags[1] != 0) << 1) | ((flags[2] != 0) << 2) | ((flags[3] != 0) << 3);
+    return t;
+}
+
+// `rows` / `n_rows_ptr` (LISTED): compute only the listed rows (device-side count, no host sync); results are
+// written to their natural positions P[rows[k]].  `chunk_mask`: which of the 10 column chunks to produce; workgroup (x, y) owns
+// the y-th selected chunk and the row tiles x, x + gridDim.x, ...
+template <bool LISTED>
+__global__ __launch_bounds__(256, 3) void node_proj_kernel(const float* __restrict__ att, const float* __restrict__ h,
+                                                           const uint8_t* __restrict__ lig, float* __restrict__ P,
+                                                           int n_nodes, const int* __restrict__ rows,
+                                                           const int* __restrict__ n_rows_ptr, unsigned chunk_mask) {
+    __shared__ __attribute__((aligned(16))) float lds[NP_CHUNK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
+    const int n_rows = LISTED ? *n_rows_ptr : n_nodes;
+    const int n_tiles = (n_rows + 63) / 64;
+    {
+        unsigned m = chunk_mask;
+        for (unsigned k = 0; k < blockIdx.y; ++k) m &= m - 1;
+        chunk_mask = m & (0u - m);
+    }
+    if ((int)blockIdx.x >= n_tiles || chunk_mask == 0) return;   // whole workgroup: nothing to do
+    const int ch = __ffs(chunk_mask) - 1;
+    const int step = 64 * (int)gridDim.x;
+    int row0 = blockIdx.x * 64 + wave * 16;
+    // first tile's rows requested before the table fill: the round trips overlap
+    ProjTile cur;
+    ProjIdx idx1;
+    {
+        const ProjIdx idx0 = proj_idx_load<LISTED>(rows, n_rows, row0, c, q);
+        idx1 = proj_idx_load<LISTED>(rows, n_rows, row0 + step, c, q);
+        cur = proj_tile_load(h, lig, idx0, q);
+    }
+    lds_fill_f4<NP_CHUNK / 4 / 256>(lds, att + A_NPROJ_FRAG + (size_t)ch * NP_CHUNK, 0, NP_CHUNK / 4, tid);
+    const float* bias = att + A_BN2;  // [dst class][640]: bias + type column of a protein source
+    const float4 bP = nld4(bias + 64 * ch + 4 * c), bL = nld4(bias + PROW + 64 * ch + 4 * c);
+    const float4 ci = nld4(att + A_NPROJ_CINV + 64 * ch + 4 * c);     // 2^-kc of this lane's four columns
+    __syncthreads();
+    const half8* Bh = reinterpret_cast<const half8*>(lds) + lane;   // [ct][u][lane]
+    const half8* Bl = Bh + 4 * 4 * 64;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, row0 += step) {
+        // the next tile's rows (indices arrived during the previous tile) and the indices of the tile after it: in flight during
+        // the split and the MFMAs below
+        const ProjTile nxt = proj_tile_load(h, lig, idx1, q);
+        const ProjIdx idx2 = proj_idx_load<LISTED>(rows, n_rows, row0 + 2 * step, c, q);
+        __builtin_amdgcn_sched_barrier(0);
+        half8 ah[4], al[4];
+        float rinv[4];
+        {
+            float mx = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(cur.hv[u].x), fabsf(cur.hv[u].y))), fmaxf(fabsf(cur.hv[u].z), fabsf(cur.hv[u].w)));
+            float inv;
+            const float up = row_pow2(nxrow_max(mx), inv);
+            rows_to_c_layout(inv, q, rinv);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 v0 = cur.hv[2 * u], v1 = cur.hv[2 * u + 1];
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                split8(v, up, ah[u], al[u]);
+            }
+        }
+        floatx4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            half8 bh[4], bl[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) { bh[ct] = Bh[(ct * 4 + u) * 64]; bl[ct] = Bl[(ct * 4 + u) * 64]; }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(ah[u], bl[ct], acc[ct]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(al[u], bh[ct], acc[ct]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(ah[u], bh[ct], acc[ct]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (cur.orow[r] >= 0) {
+                const float4 b = ((cur.lgr >> r) & 1) ? bL : bP;
+                float4 o = {fmaf(acc[0][r] * rinv[r], ci.x, b.x), fmaf(acc[1][r] * rinv[r], ci.y, b.y),
+                            fmaf(acc[2][r] * rinv[r], ci.z, b.z), fmaf(acc[3][r] * rinv[r], ci.w, b.w)};
+                *reinterpret_cast<float4*>(P + (size_t)cur.orow[r] * PROW + 64 * ch + 4 * c) = o;
+            }
+        }
+        cur = nxt;
+        idx1 = idx2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// node_qmlp: LayerNorm + ReLU on the q-hidden quarter of P (A layout: LN is in-lane + across q), then
+// q = z @ Wq1^T + bq1 in split-f16 (K = 32 per MFMA, same slot map as node_proj).
+// Wq1 tables [part hi|lo][nt 8][u 4][lane][8 f16] = split(Wq1[n = 64(nt>>2) + 4c + (nt&3)][k = 16 (2u + (j>>2)) + 4q + (j&3)]).
+// ------------------------------------------------------------------------------------------------
 constexpr int NQ_FRAG = 8 * 8 * 64 * 4;  // 16384 floats = 64 KB
 
 __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict__ att, const float* __restrict__ P,
@@ -826,9 +856,17 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
     if (n_nodes == 0) return hipSuccess;
     const int tiles = (n_nodes + 63) / 64;
     const int grid = min(tiles, 512);
-    // few row tiles (small batches, or a work list): spread the column chunks / heads over workgroups too
+    // few row tiles (small batches, or a work list): spread the heads of the fold / the halves of the query MLP over workgroups too
     const bool small = tiles <= 128 || (act != nullptr && !large_lists);
-    auto py = [&](unsigned mask) { return small ? (unsigned)__builtin_popcount(mask) : 1u; };
+    // node_proj_kernel: one workgroup per (row-tile column x, selected chunk); all of them resident at once (four per CU), and
+    // gridDim.x a multiple of 8 so that the workgroups of one row tile -- linear ids x + y gridDim.x -- land on one XCD and its
+    // L2 serves the tile's rows to all of them
+    auto proj_grid = [&](unsigned mask) {
+        const int py = __builtin_popcount(mask);
+        int gx = 1024 / py;
+        if (gx >= 8) gx &= ~7;
+        return dim3((unsigned)min(tiles, gx), (unsigned)py);
+    };
     // Small inputs (n_nodes bounds a work list's length too): ONE launch does projection (own columns, or all of them when
     // every node is a destination), query MLP and query fold -- such launches are bound by kernel boundaries, not throughput.
     const bool fused = n_nodes <= NODE_STAGE_MAX_ROWS;
@@ -837,17 +875,15 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
     const bool two_jobs = fused && act != nullptr;
     if (!act) {
         if (!fused)
-            hipLaunchKernelGGL(node_proj_kernel, dim3(grid, py(CHUNKS_ALL)), dim3(256), 0, s, att, h, lig, P, n_nodes,
+            hipLaunchKernelGGL(node_proj_kernel<false>, proj_grid(CHUNKS_ALL), dim3(256), 0, s, att, h, lig, P, n_nodes,
                                (const int*)nullptr, (const int*)nullptr, CHUNKS_ALL);
     } else {
-        // the source rows of a destination list are many (most of a pocket is within two hops of the ligand): all four chunks per
-        // workgroup unless the whole input is small (one workgroup per chunk took 88 us per h2x block of a 99.5 k-node batch, this 25)
         if (!two_jobs)
-            hipLaunchKernelGGL(node_proj_kernel, dim3(grid, tiles <= 128 ? py(CHUNKS_PS) : 1u), dim3(256), 0, s, att, h,
-                               lig, P, n_nodes, src, src_count, CHUNKS_PS);
+            hipLaunchKernelGGL(node_proj_kernel<true>, proj_grid(CHUNKS_PS), dim3(256), 0, s, att, h, lig, P, n_nodes, src, src_count,
+                               CHUNKS_PS);
         if (!fused)
-            hipLaunchKernelGGL(node_proj_kernel, dim3(grid, py(CHUNKS_OWN)), dim3(256), 0, s, att, h, lig, P, n_nodes, act,
-                               act_count, CHUNKS_OWN);
+            hipLaunchKernelGGL(node_proj_kernel<true>, proj_grid(CHUNKS_OWN), dim3(256), 0, s, att, h, lig, P, n_nodes, act, act_count,
+                               CHUNKS_OWN);
     }
     profile_mark_end(s);
     hipError_t e = hipGetLastError();

@@ -426,14 +426,16 @@ class DiffSBDD(BatchesInFlight, nn.Module):
         nxt() if st["drawn"] else torch.randn(st["n_lig"], C, device=dev)   # the reference draws and discards it
         return x_fin, st["c_lig"] * 4.0
 
-    @torch.no_grad()
     # hooks of BatchesInFlight.sample_many (the tape of a batch = its list of randn draws in the reference's order)
+    @torch.no_grad()
     def _many_begin(self, batch, tape):
         return self.begin_sampling(batch, keep_trajectory=True, noise_draws=tape)
 
+    @torch.no_grad()
     def _many_step(self, st, t_idx, tape):
         self.denoise_step(st, t_idx)
 
+    @torch.no_grad()
     def _many_finish(self, st, out_dev):
         T = self.num_diffusion_timesteps
         x_fin, c_fin = self.finish_sampling(st)
@@ -442,6 +444,7 @@ class DiffSBDD(BatchesInFlight, nn.Module):
         traj[0] = (x_fin.to(out_dev), c_fin.to(out_dev), bl_out)
         return traj
 
+    @torch.no_grad()
     def sample(self, batch, noise_draws=None, return_device=None):
         """diffsbdd.py:240-319. ``noise_draws`` (tests): list of the randn tensors in the reference's draw order."""
         T = self.num_diffusion_timesteps

@@ -612,7 +612,8 @@ class TargetDiff(BatchesInFlight, nn.Module):
         with torch.cuda.stream(run_on):
             st["t_dev"] = torch.full((1,), T - 1, dtype=torch.int32, device=dev)
             st["_ws"] = torch.empty(self.denoiser.workspace_bytes(st["N"], st["B"]), dtype=torch.uint8, device=dev)
-            for _ in range(done):     # eager steps: the weight pack gets built, the allocator warm
+            self.denoiser.packed_weights(dev)   # built (and waited for, below) BEFORE the capture: a capturing stream must not wait
+            for _ in range(done):               # on the pack's event; then the eager steps: the allocator warm
                 self._traj_step(st)
         run_on.synchronize()
         if done >= T:

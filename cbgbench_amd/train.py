@@ -249,22 +249,36 @@ def train_step(model, batch, optimizer, flat_grads, loss_weights=None, max_grad_
 
 
 @torch.no_grad()
-def validate(model, batches, loss_weights=None):
-    """train.py:207-246 without the RDKit/auroc evaluator: mean weighted loss over the batches at the model's
-    evenly spaced evaluation times (each batch weighted by its graph count), all-reduced so every rank sees the same value
-    (ReduceLROnPlateau input)."""
+def validate(model, batches, loss_weights=None, evaluator=None):
+    """train.py:207-246: mean weighted loss over the batches at the model's evenly spaced evaluation times (each batch weighted
+    by its graph count, like the reference's ScalarMetricAccumulator, train.py:222-238), all-reduced so every rank sees the same
+    value (ReduceLROnPlateau input).  ``evaluator`` (``evaluate.Evaluator``, the config's ``eval.metrics``): its metrics of every
+    batch's ``results`` are averaged and all-reduced the same way; the call then returns ``(avg_loss, {metric: value})``."""
     model.eval()
-    tot, n = 0.0, 0
-    for batch in batches:
-        loss_dict, _ = model(batch)
-        # weighted by the number of graphs, like the reference's ScalarMetricAccumulator (train.py:222-232)
-        bl = batch.get("ligand_element_batch", None) if isinstance(batch, dict) else None
-        B = int(bl.max().item()) + 1 if bl is not None and bl.numel() else 1
-        tot += float(sum_weighted_losses(loss_dict, loss_weights)) * B
-        n += B
-    val = torch.tensor([tot, float(n)], dtype=torch.float64)
+    names = sorted(evaluator.evaluators) if evaluator is not None and len(evaluator) else []
+    acc = [0.0] * (2 + len(names))          # [sum loss * B, sum B, sum metric_k * B ...]
+    with torch.no_grad():
+        for batch in batches:
+            loss_dict, results = model(batch)
+            # weighted by the number of graphs, like the reference's ScalarMetricAccumulator (train.py:222-232)
+            bl = batch.get("ligand_element_batch", None) if isinstance(batch, dict) else None
+            B = batch.get("num_graphs") if isinstance(batch, dict) and batch.get("num_graphs") else (
+                int(bl.max().item()) + 1 if bl is not None and bl.numel() else 1)
+            acc[0] += float(sum_weighted_losses(loss_dict, loss_weights)) * B
+            acc[1] += B
+            if names:
+                md = evaluator(results)
+                for k, nm in enumerate(names):
+                    v = float(md[nm])
+                    acc[2 + k] += (v if v == v else 0.0) * B          # an undefined metric (no masked atom) counts as 0
+    val = torch.tensor(acc, dtype=torch.float64)
     if dist.is_available() and dist.is_initialized():
         if dist.get_backend() != "gloo":
             val = val.to(next(model.parameters()).device)
         dist.all_reduce(val, op=dist.ReduceOp.SUM)
-    return float(val[0] / max(float(val[1]), 1.0))
+    val = val.cpu()
+    n = max(float(val[1]), 1.0)
+    avg = float(val[0] / n)
+    if evaluator is None:
+        return avg
+    return avg, {nm: float(val[2 + k] / n) for k, nm in enumerate(names)}

@@ -1,13 +1,14 @@
 """Training driver: the role of the reference's ``train.py`` (config -> model / optimizer / scheduler -> the iteration loop
-with periodic validation and best-so-far checkpoints, ``train.py:99-273``), minus the LMDB datasets, tensorboard and the
-RDKit/auroc evaluator (out of scope), made data-parallel the way SURVEY.md 8e/8f-4 asks:
+with periodic validation -- loss and the config's ``eval.metrics`` (the type-prediction AUROC, ``cbgbench_amd/evaluate.py``) -- and
+best-so-far checkpoints, ``train.py:99-273``), minus the LMDB datasets and tensorboard (out of scope), made
+data-parallel the way SURVEY.md 8e/8f-4 asks:
 
 * one process per GPU (``torchrun --nproc-per-node N -m cbgbench_amd.train_cli ...``), every rank holds a full replica;
 * a rank-aware loader: one permutation of the training complexes per epoch, seeded identically everywhere, of which rank r
   takes the entries r, r+W, ... -- no sampler object, no collective;
 * gradients of all ranks summed by ONE RCCL all-reduce of the flat fp32 gradient buffer per step (``train.FlatGradients``),
   averaged before clipping so that ``clip_grad_norm_`` sees the global gradient;
-* validation loss all-reduced so that ``ReduceLROnPlateau`` takes the same decision on every rank; checkpoints written by
+* validation loss and metrics all-reduced so that ``ReduceLROnPlateau`` takes the same decision on every rank; checkpoints written by
   rank 0 only, in the reference's format ``{'config', 'model', 'optimizer', 'scheduler', 'iteration', 'avg_val_loss'}``
   under ``{logdir}/{tag}/checkpoints/{it}.pt`` (``train.py:266-273``); ``--resume`` restores all of it on every rank
   (``train.py:160-175``; ``--finetune`` keeps only the weights).
@@ -29,6 +30,7 @@ import torch
 
 from . import get_model, load_config, set_num_atom_type, sharding, synthetic
 from .config import checkpoint_config, load_checkpoint_file
+from .evaluate import Evaluator
 from .train import FlatGradients, broadcast_parameters, get_optimizer, get_scheduler, train_step, validate
 
 
@@ -167,6 +169,7 @@ def run(config, config_name, train_set, val_set, dev, logdir, tag="", resume=Non
     model = get_model(config.model).to(dev)
     optimizer = get_optimizer(tc.optimizer, model)
     scheduler = get_scheduler(tc.get("scheduler", None), optimizer)
+    evaluator = Evaluator(ec.get("metrics", []))                  # train.py:141
     it_first = 1
     if resume:
         it_first, missing, unexpected = load_checkpoint(resume, model, optimizer, scheduler, finetune, device=dev)
@@ -178,7 +181,7 @@ def run(config, config_name, train_set, val_set, dev, logdir, tag="", resume=Non
     train_it = iter(ShardedLoader(len(train_set), int(tc.batch_size), rank, world, seed=int(tc.get("seed", 2022))))
     val_batches = ShardedLoader(len(val_set), int(tc.batch_size), rank, world, shuffle=False).epoch(0)
     ckpt_dir = os.path.join(logdir, tag or config_name, "checkpoints")
-    best_loss, best_iter, history = None, None, []
+    best_loss, best_iter, history, metric_history = None, None, [], []
     t_last = time.perf_counter()
     for it in range(it_first, max_iters + 1):
         batch = train_set.collate(next(train_it), dev)
@@ -192,8 +195,9 @@ def run(config, config_name, train_set, val_set, dev, logdir, tag="", resume=Non
                 f"(all-reduce {1e3 * t_ar:.2f} ms)")
             t_last = now
         if it % val_freq == 0:
-            avg = validate(model, (val_set.collate(ids, dev) for ids in val_batches), weights)
+            avg, metrics = validate(model, (val_set.collate(ids, dev) for ids in val_batches), weights, evaluator)
             history.append((it, avg))
+            metric_history.append((it, metrics))
             if scheduler is not None and it != it_first:         # train.py:247-251
                 scheduler.step(avg) if tc.scheduler.type == "plateau" else scheduler.step()
             improved = best_loss is None or avg < best_loss or it % int(ec.get("force_save_freq", 1000000)) == 0
@@ -202,10 +206,12 @@ def run(config, config_name, train_set, val_set, dev, logdir, tag="", resume=Non
                 if rank == 0:
                     save_checkpoint(os.path.join(ckpt_dir, "%d.pt" % it), config, model, optimizer, scheduler, it, avg)
             if rank == 0:
-                log(f"[validate] iter {it:05d} | loss {avg:.6f} | " + ("saved" if improved else
+                log(f"[validate] iter {it:05d} | loss {avg:.6f} | " + "".join(f"{k} {v:.4f} | " for k, v in metrics.items()) +
+                    ("saved" if improved else
                     f"not improved (best {best_loss:.6f} at iter {best_iter})"))
             sharding.barrier()
-    return {"model": model, "optimizer": optimizer, "scheduler": scheduler, "history": history, "best_iter": best_iter,
+    return {"model": model, "optimizer": optimizer, "scheduler": scheduler, "history": history, "metrics": metric_history,
+            "best_iter": best_iter,
             "ckpt_dir": ckpt_dir}
 
 

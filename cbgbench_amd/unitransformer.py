@@ -251,7 +251,9 @@ class UniTransformer(nn.Module):
             self._packed_event.record(torch.cuda.current_stream(device))
             self._packed_seen = {torch.cuda.current_stream(device).cuda_stream}
         cur = torch.cuda.current_stream(device)
-        if cur.cuda_stream not in self._packed_seen:
+        if cur.cuda_stream not in self._packed_seen and not torch.cuda.is_current_stream_capturing():
+            # (a capturing stream must not wait on an event recorded outside the capture; make_step_graph orders the capture
+            # stream behind the pack before the capture begins)
             cur.wait_event(self._packed_event)
             self._packed_seen.add(cur.cuda_stream)
         return self._packed

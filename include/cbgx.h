@@ -12,9 +12,11 @@
  * device memory: the caller owns inputs, outputs and the workspace.
  *
  * The only state the library owns, besides the optional profiling hook at the end of this file:
- * one auxiliary non-blocking HIP stream and two events per HOST THREAD AND CALLER STREAM (four per thread, created on the
- * first multi-layer forward on that stream; a fifth caller stream takes over the oldest entry's stream and events -- nothing is
- * destroyed or waited for, so this is legal under stream capture).  cbgx_unitransformer_forward{,_cached} fork the node stage of
+ * one auxiliary non-blocking HIP stream and two events per HOST THREAD AND CALLER STREAM (at most eight per thread, created on the
+ * first multi-layer forward on that stream; a ninth caller stream takes over the oldest entry's stream and events -- nothing is
+ * destroyed or waited for, so this is legal under stream capture; results stay correct, only the overlap of that caller's node
+ * stages with its other calls is lost), and the process-wide workgroup limit of cbgx_set_edge_workgroups (a relaxed atomic int:
+ * the one value shared between host threads).  cbgx_unitransformer_forward{,_cached} fork the node stage of
  * layer l+1 onto it next to the h2x block of layer l and join it back before returning work to `stream`, so
  * from the caller's point of view everything is still ordered on `stream` (hipGraph capture of `stream`
  * records the fork/join).  One device per host thread (the one-process-per-GPU model): a thread that switches
@@ -27,10 +29,14 @@
  * radial-basis part of the edge pre-activation run on the f16 matrix pipe as "split-f16" products (every fp32 operand v is carried
  * as hi = f16(v 2^k), lo = f16(v 2^k - hi) with 2^k an exact power of two chosen per weight column / per table at pack time and per
  * row of activations at run time; three f16 products hi hi + hi lo + lo hi, fp32 accumulation, 2^-k applied to the fp32 result),
- * everything else on fp32 MFMA / VALU.  The result is fp32-grade for ANY finite fp32 input and weight: error <= ~2^-21 of
+ * everything else on fp32 MFMA / VALU.  The result is fp32-grade over the range the scale exponents cover: error <= ~2^-21 of
  * sum |a||b| per dot product, measured 5 - 8e-8 against 1.3 - 2.5e-7 for a plain fp32 FMA chain over weight scales 1e-4 .. 30 and
- * activations 1e-3 .. 1e5 (tests/test_splitf16_range.py, tests/test_gpu_range.py; |h| > 65 504 is fine).  There is no input
- * range to respect and hence no range error code; non-finite inputs propagate as in the reference.
+ * activations 1e-3 .. 1e5 (tests/test_splitf16_range.py, tests/test_gpu_range.py; |h| > 65 504 is fine).  That is the supported and
+ * tested range.  The scale exponents are clamped so that every factor stays a normal fp32 number (rbf tables: 2^-40 .. 2^20, node
+ * tables 2^-100 .. 2^60, activation rows 2^-100 .. 2^100); outside of what they can compensate (rbf columns above 2^54, rows whose
+ * largest entry is denormal) accuracy degrades gradually towards plain f16 -- never an error code, and finite inputs never give a
+ * non-finite result because of the scaling.
+ * Non-finite inputs propagate as in the reference.
  *
  * Node order (as produced by compose_context, repo/modules/common.py:189-214):
  * nodes sorted by graph; graph g owns rows [graph_ptr[g], graph_ptr[g+1]).

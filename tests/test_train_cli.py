@@ -161,10 +161,24 @@ train:
   max_grad_norm: 8.0
   optimizer: {type: adam, lr: 5.e-4, weight_decay: 0.0, beta1: 0.95, beta2: 0.999}
   scheduler: {type: plateau, factor: 0.6, patience: 10, min_lr: 1.e-6}
-eval: {val_freq: 2}
+eval:
+  val_freq: 2
+  metrics:
+    - {name: auroc, true_key: v0, pred_key: c_pred, mask_key: mask_gen}
 """)
     logdir = str(tmp_path / "logs")
-    assert train_cli.main(["--config", str(cfg), "--logdir", logdir, "--synthetic", "12"]) == 0
+    lines = []
+    orig_run = train_cli.run
+    train_cli.run = lambda *a, **kw: orig_run(*a, **{**kw, "log": lines.append})
+    try:
+        assert train_cli.main(["--config", str(cfg), "--logdir", logdir, "--synthetic", "12"]) == 0
+    finally:
+        train_cli.run = orig_run
+    # the config's metric (type-prediction AUROC, repo/utils/evaluate.py:35-73) is part of every validation report
+    val = [l for l in lines if l.startswith("[validate]")]
+    assert len(val) == 2 and all("auroc_atom" in l for l in val)
+    a = float(val[0].split("auroc_atom")[1].split("|")[0])
+    assert 0.0 <= a <= 1.0
     ck = os.path.join(logdir, "targetdiff_train", "checkpoints", "2.pt")
     assert os.path.exists(ck)
     saved = torch.load(ck, weights_only=False)
