@@ -79,9 +79,7 @@ def measured_traffic(n_nodes):
     return int(round((t["fetch_bytes_per_node"] + t["write_bytes_per_node"]) * n_nodes))
 
 
-TRAFFIC_SOURCE = ("NOT measured in this run: per-node bytes from profiles/traffic_x2h.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE "
-                  "in separate passes of this command, corrected as MI355X_MICROARCH.md prescribes; scripts/gpu_pmc_traffic.sh) x the "
-                  "nodes of this launch")
+TRAFFIC_SOURCE = "committed constant: profiles/traffic_x2h.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes) x nodes"
 
 
 def build_batch(pockets, samples, seed, num_classes=13):
@@ -183,12 +181,9 @@ def cpu_baseline(sd, seed, max_seconds=20.0, model="targetdiff", threads=None):
             if el > max_seconds or steps >= 8:
                 break
     return {"value": round(10 * steps / el, 4), "unit": "graph-steps/s", "cores": threads,
-            "kind": "port", "sample": f"{steps} full denoising steps of one 10-graph batch (1 pocket x 10 samples, "
-            f"N={batch['protein_pos'].shape[0] + n_lig} nodes: the batch sample.py:177-183 builds), oracle/{model}.py "
-            f"= the PyTorch-CPU port of the reference step in the reference's own formulation, bit-identical to the "
-            f"unmodified reference on tests/golden (tests/test_oracle_golden.py; /root/reference does not exist on this box; "
-            f"the reference itself timed on the build container: BASELINE.md section 2), fp32, {threads} threads "
-            f"(best of 4..64 on this {os.cpu_count()}-core host), {el:.1f} s"}
+            "kind": "port", "sample": f"{steps} denoising steps of one 10-graph batch (N={batch['protein_pos'].shape[0] + n_lig} nodes, "
+            f"sample.py:177-183), oracle/{model}.py on PyTorch-CPU fp32, {threads} threads (best of 4..64 of {os.cpu_count()} "
+            f"cores), {el:.1f} s"}
 
 
 def cpu_worker(argv):
@@ -221,8 +216,7 @@ def cpu_baseline_concurrent(threads, model="targetdiff", seconds=12.0):
             p.kill()
     return {"value": round(float(sum(vals)), 4), "unit": "graph-steps/s", "processes": procs, "processes_reported": len(vals),
             "threads_each": threads, "cores": procs * threads,
-            "sample": f"{procs} concurrent processes x {threads} threads, each the single-process sample above for ~{seconds:.0f} s "
-                      f"(sum of the per-process rates; {time.perf_counter() - t0:.0f} s wall incl. process start-up)"}
+            "sample": f"{procs} processes x {threads} threads side by side, ~{seconds:.0f} s each, rates summed"}
 
 
 # backward of the message-passing stage at the reference's tensor boundary (autograd of x2h_attention.py:80-97):
@@ -249,9 +243,8 @@ def cpu_train_baseline(sd, seed, max_seconds=25.0):
         if el > max_seconds or steps >= 4:
             break
     return {"value": round(4 * steps / el, 4), "unit": "graph-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} forward+backward passes (no optimiser step) of one 4-graph batch, oracle/training.py "
-                      f"with torch.autograd on PyTorch-CPU fp32, {threads} threads (best of 4..64 on this "
-                      f"{os.cpu_count()}-core host), {el:.1f} s"}
+            "sample": f"{steps} forward+backward passes of one 4-graph batch, oracle/training.py (torch.autograd, PyTorch-CPU fp32), "
+                      f"{threads} threads, {el:.1f} s"}
 
 
 def bench_train(args, rank, world, dev):
@@ -292,10 +285,8 @@ def bench_train(args, rank, world, dev):
         "value": round(units / el_max, 2), "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * el_max / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs/denovo {args.model} training (BASELINE configs[4] shape): {n_graphs} graphs per GPU "
-                               f"per step, N_rec~U[350,650], N_lig~U[10,45], the config's time sampler and loss weights, "
-                               f"Adam lr 5e-4, clip 8.0, one flat-buffer gradient all-reduce "
-                               f"({fg.flat.numel()} fp32) per step",
+        "config": {"workload": f"configs/denovo {args.model} training (BASELINE configs[4] shape): {n_graphs} graphs per GPU per step, "
+                               f"Adam lr 5e-4, clip 8.0, one flat gradient all-reduce ({fg.flat.numel()} fp32) per step",
                    "graphs_per_batch_per_gpu": n_graphs, "nodes_per_batch": N, "sharding": f"data-parallel x{world} ranks", "ranks_seen": seen,
                    "collective_backend": collective_backend(),
                    "allreduce_ms_per_step": round(1e3 * t_ar / max(args.steps, 1), 4)},
@@ -310,19 +301,18 @@ def bench_train(args, rank, world, dev):
         NCLS = len(names)
         ms = (ctypes.c_double * NCLS)(); cnt = (ctypes.c_int * NCLS)()
         _native.check(lib.cbgx_profile_end(ms, cnt, NCLS), "cbgx_profile_end")
-        per = {n: {"ms_total": round(ms[i], 4), "launches": cnt[i],
-                   "us_avg": round(1e3 * ms[i] / max(cnt[i], 1), 3)} for i, n in enumerate(names)}
+        per = {n: [round(1e3 * ms[i] / max(cnt[i], 1), 1), cnt[i]] for i, n in enumerate(names) if cnt[i]}
         k = names.index("edge_x2h_bwd")
         bwd_bytes = X2H_BWD_BYTES_PER_EDGE * 32 * N + X2H_BWD_BYTES_PER_NODE * N
         bwd_s = 1e-3 * ms[k] / max(cnt[k], 1)
         achieved = bwd_bytes / bwd_s / 1e9 if bwd_s > 0 else 0.0
         out["roofline"] = {
-            "bound": "hbm", "kernel": "cbgx::edge_backward_x2h_kernel (backward of the x2h block: one wavefront per node, per-node recompute in registers, MFMA contractions)",
+            # algorithmic bytes = backward of the message-passing stage at the reference tensor boundary (2056 B/edge + 2048 B/node);
+            # the kernel recomputes the per-edge forward instead of reading it
+            "bound": "hbm", "kernel": "cbgx::edge_backward_x2h_kernel (backward of the x2h block)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": None, "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_us": round(1e6 * bwd_s, 3),
-            "note": "algorithmic bytes = backward of the message-passing stage at the reference tensor boundary "
-                    "(2056 B/edge + 2048 B/node); the kernel recomputes the per-edge forward instead of reading it",
-            "per_kernel": per,
+            "per_kernel_us_avg_and_launches": per,
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "targetdiff":
         out["cpu_baseline"] = cpu_train_baseline(oracle_state_dict(), seed=3000)
@@ -385,14 +375,29 @@ def device_hardware_id(dev):
     return {a: str(getattr(pr, a)) for a in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id") if hasattr(pr, a)}
 
 
+def usable_uuid(hw):
+    """the hardware uuid when torch exposes a real one (some ROCm builds leave it empty or all zeros)"""
+    u = hw.get("uuid", "")
+    return u if u and u.strip("0-") else None
+
+
 def distinct_devices(dev, world):
-    """number of distinct physical GPUs over all ranks (all-gather of device_identity)"""
+    """Number of distinct physical GPUs over all ranks: all-gather of device_identity (environment + index) AND of the hardware
+    uuid / PCI address.  When every rank reports a usable uuid the two counts must agree -- a launch whose environment says
+    "N different devices" while the uuids say otherwise (or the reverse) is refused rather than mislabelled."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return 1
     ids = [None] * world
-    dist.all_gather_object(ids, device_identity(dev))
-    return len(set(ids))
+    dist.all_gather_object(ids, (device_identity(dev), device_hardware_id(dev)))
+    n_env = len(set(i for i, _ in ids))
+    uuids = [usable_uuid(hw) for _, hw in ids]
+    if all(u is not None for u in uuids):
+        n_uuid = len(set(uuids))
+        if n_uuid != n_env:
+            raise SystemExit(f"bench.py: the ranks' device environment names {n_env} distinct GPU(s) but their hardware uuids "
+                             f"{n_uuid}: refusing to report n_gpus ({sorted(set(uuids))})")
+    return n_env
 
 
 def parse_args(argv=None):
@@ -424,6 +429,9 @@ def parse_args(argv=None):
     ap.add_argument("--edge-workgroups", type=int, default=0,
                     help="cbgx_set_edge_workgroups: CUs the persistent x2h edge kernel may take (default 0 = all; leaving CUs free "
                          "for the other streams measured slower at every setting, profiles/README.md)")
+    ap.add_argument("--split-job", action="store_true",
+                    help="strong scaling: ONE --pockets x --samples job sharded over the ranks (rank r takes pockets r, r + W, ...: "
+                         "what the pocket loop of sample.py:159 gives a user who adds GPUs) instead of one such job per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -488,14 +496,18 @@ def bench_sampling(args, rank, world, dev):
     if args.workload == "linker":
         args.samples = 1
     ppb = max(1, args.graphs_per_batch // args.samples)          # pockets per batch
-    chunks = [min(ppb, args.pockets - s) for s in range(0, args.pockets, ppb)]
+    split = bool(getattr(args, "split_job", False)) and world > 1
+    # --split-job: the job's pockets 0 .. P-1 are dealt round-robin (cbgbench_amd/sharding.py, the rule sample_cli uses); this rank
+    # builds and runs only its own
+    my_pockets = len(sharding.shard_indices(args.pockets, rank, world)) if split else args.pockets
+    chunks = [min(ppb, my_pockets - s) for s in range(0, my_pockets, ppb)]
     states = []
     for b, npk in enumerate(chunks):
         seed = 1000 + 97 * rank + 7919 * b
         batch = (synthetic.linker_batch(npk, seed=seed) if args.workload == "linker"
                  else build_batch(npk, args.samples, seed=seed, num_classes=num_classes))
         states.append(model.begin_sampling(synthetic.batch_to(batch, dev), keep_trajectory=True))
-    n_graphs = args.pockets * args.samples
+    n_graphs = my_pockets * args.samples
     N = sum(st["N"] for st in states)
     torch.manual_seed(2024 + rank)   # sample.py:106 seed (+rank: independent streams per shard)
     n_blocks = len(T_BLOCKS)
@@ -559,27 +571,27 @@ def bench_sampling(args, rank, world, dev):
         if seen != world:
             raise SystemExit(f"bench.py: all-reduce saw {seen} ranks, expected {world}")
 
-        shape = (f"{args.pockets} pockets x {args.samples} samples = {n_graphs} graphs per GPU as {len(states)} resident "
-                 f"batch(es) of <= {ppb * args.samples} graphs")
+        shape = (f"{my_pockets} pockets x {args.samples} samples = {n_graphs} graphs per GPU, {len(states)} resident batch(es) of <= "
+                 f"{ppb * args.samples}")
+        # the line must fit the driver's 8 KB tail: every description is one short string, the long-form text is DESIGN.md section 6
         out = {
             "metric": "denoising graph-steps/s (pocket+ligand graphs x reverse-diffusion steps per second)",
             "value": round(graph_steps / el_max, 2), "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * el_max / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"configs/denovo {args.model} sampling, the whole BASELINE configs[1] job: {shape}, "
-                                    f"N_rec~U[350,650], N_lig~U[10,45], k=32, 9 layers, fp32, random-init synthetic weights; one "
-                                    f"bench step = one reverse-diffusion step of the whole job at each of {n_blocks} time "
-                                    f"blocks (t = 999-i, 749-i, 499-i, 249-i, 24-(i mod 25))") if args.workload == "denovo" else
-                                   (f"configs/linker {args.model} sampling (BASELINE configs[2]): {shape} (fragment-pair pockets), "
-                                    f"N_rec~U[350,650], 10-35 fixed context atoms + 3-14 generated atoms per graph (partial "
-                                    f"gen_flag), k=32, 9 layers, fp32, synthetic weights; one bench step = one reverse-diffusion "
-                                    f"step of the job at each of {n_blocks} time blocks"),
+            "scaling": "strong" if split else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"configs/denovo {args.model} sampling, BASELINE configs[1] job: {shape}; N_rec~U[350,650], "
+                                    f"N_lig~U[10,45], k=32, 9 layers; bench step = 1 reverse-diffusion step of the job at each of "
+                                    f"{n_blocks} time blocks") if args.workload == "denovo" else
+                                   (f"configs/linker {args.model} sampling, BASELINE configs[2]: {shape} fragment-pair pockets, "
+                                    f"10-35 context + 3-14 generated atoms (partial gen_flag); bench step = 1 step at each of "
+                                    f"{n_blocks} time blocks"),
                        "graphs_per_gpu": n_graphs, "nodes_per_gpu": N, "denoising_steps_per_bench_step": n_blocks,
                        "graph_steps_per_bench_step_per_gpu": n_graphs * n_blocks,
                        "ms_per_denoising_step_of_the_job": round(1e3 * el_max / args.steps / n_blocks, 4),
-                       "sharding": f"independent pockets x{world} ranks, no data-path collective", "ranks_seen": seen,
-                       "collective_backend": collective_backend(),
-                       "launch": "one hipGraph replay per batch and step" if use_graph else "stream launches",
+                       "sharding": (f"ONE job of {args.pockets} pockets split over {world} ranks" if split else
+                                    f"independent pockets x{world} ranks") + ", no data-path collective",
+                       "ranks_seen": seen, "collective_backend": collective_backend(),
+                       "launch": "hipGraph replay per batch and step" if use_graph else "stream launches",
                        "streams": n_streams, "edge_workgroups": edge_wgs or 256},
         }
 
@@ -601,39 +613,28 @@ def bench_sampling(args, rank, world, dev):
             _native.check(lib.cbgx_profile_end(ms, cnt, NCLS), "cbgx_profile_end")
             # class "edge_x2h" = the launches that process all N nodes of the batch (the samplers let the library prune
             # the last two layers and cache the first two, reported separately as "edge_x2h_listed")
-            per = {n: {"ms_total": round(ms[i], 4), "launches": cnt[i],
-                       "us_avg": round(1e3 * ms[i] / max(cnt[i], 1), 3)} for i, n in enumerate(names)}
+            per = {n: [round(1e3 * ms[i] / max(cnt[i], 1), 1), cnt[i]] for i, n in enumerate(names) if cnt[i]}
             deg_edges = 32 * Nb  # every node of a >=33-node graph has exactly 32 incoming edges
             x2h_bytes = X2H_BYTES_PER_EDGE * deg_edges + X2H_BYTES_PER_NODE * Nb
             x2h_s = 1e-3 * ms[4] / max(cnt[4], 1)
             achieved = x2h_bytes / x2h_s / 1e9 if x2h_s > 0 else 0.0
             layer_flops = FLOPS_PER_EDGE_LAYER * deg_edges + FLOPS_PER_NODE_LAYER * Nb
             dev_s_layer = 1e-3 * (ms[2] + ms[3] + ms[4] + ms[5] + ms[6]) / max(cnt[4] + cnt[6], 1)
+            tf = lambda flops: round(flops / x2h_s / 1e12, 2) if x2h_s > 0 else 0
             out["roofline"] = {
-                "bound": "hbm", "kernel": "cbgx::edge_mfma_kernel<x2h> (fused x2h edge kernel)", "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                # dominant kernel = the x2h edge stage of a layer that covers all N nodes of a batch: ONE launch of
+                # edge_x2h_dual_kernel (protein-only role with the query folded in registers + general role); achieved =
+                # algorithmic bytes at the reference tensor boundary (1032 B/edge + 1536 B/node) / launch time,
+                # HIP events on the launch stream, first resident batch.  Long-form reading: DESIGN.md section 6.
+                "bound": "hbm", "kernel": "cbgx::edge_x2h_dual_kernel (fused x2h edge stage, all nodes of a layer)",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": measured_traffic(Nb), "traffic_source": TRAFFIC_SOURCE,
                 "nodes_per_launch": Nb, "algorithmic_bytes_per_launch": x2h_bytes, "avg_launch_us": round(1e6 * x2h_s, 3),
-                "note": "algorithmic bytes = SURVEY.md 8d message-passing stage at the reference tensor boundary "
-                        "(1032 B/edge + 1536 B/node) x edges/nodes per launch; the kernel is fused (edge MLP + "
-                        "attention), so real HBM traffic is far lower; timed on the first resident batch",
-                "mfma_view": {
-                    "fp32_mfma_tflops": round(X2H_FP32_MFMA_FLOPS_PER_EDGE * deg_edges / x2h_s / 1e12, 3) if x2h_s > 0 else 0,
-                    "fp32_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
-                    "f16_mfma_tflops_issued": round(X2H_F16_MFMA_FLOPS_PER_NODE * Nb / x2h_s / 1e12, 3) if x2h_s > 0 else 0,
-                    "f16_peak_tflops": F16_MFMA_PEAK_TFLOPS,
-                    "x2h_kernel_useful_tflops": round((X2H_EXEC_FLOPS_PER_EDGE * deg_edges + X2H_EXEC_FLOPS_PER_NODE * Nb)
-                                                      / x2h_s / 1e12, 3) if x2h_s > 0 else 0,
-                    "reference_factored_equiv_tflops": round(layer_flops / dev_s_layer / 1e12, 3) if dev_s_layer else 0,
-                    "note": "fp32_mfma = the exact-fp32 MFMAs the x2h kernel issues (scores + aggregation, 8192 flop/edge) / its "
-                            "launch time; f16_mfma_issued = the split-f16 MFMAs of the rbf pre-activation (three f16 products per "
-                            "fp32 product, 128 x 8192 flop per node); useful = fp32-equivalent work of the kernel (18432 flop/edge "
-                            "+ 32768/node).  The kernel is bound by the sum of fp32-MFMA and VALU issue time on a SIMD, not by "
-                            "either peak (DESIGN.md 9).  reference_factored_equiv = SURVEY.md 8d factored flops of a whole layer / "
-                            "device time per layer: it may exceed the fp32 peak because the library moves both second Linears off "
-                            "the edges (query fold, post-aggregation value Linear), caches the ligand-free protein rows and prunes "
-                            "the last layers"},
-                "per_kernel": per,
+                "mfma_view": {"fp32_mfma_tflops": tf(X2H_FP32_MFMA_FLOPS_PER_EDGE * deg_edges), "fp32_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                              "f16_mfma_tflops_issued": tf(X2H_F16_MFMA_FLOPS_PER_NODE * Nb), "f16_peak_tflops": F16_MFMA_PEAK_TFLOPS,
+                              "useful_tflops": tf(X2H_EXEC_FLOPS_PER_EDGE * deg_edges + X2H_EXEC_FLOPS_PER_NODE * Nb),
+                              "reference_factored_equiv_tflops": round(layer_flops / dev_s_layer / 1e12, 2) if dev_s_layer else 0},
+                "per_kernel_us_avg_and_launches": per,
                 "profiled_sections_per_denoising_step": round(sum(cnt) / (5.0 * prof_steps), 1),
             }
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -650,13 +651,13 @@ def bench_sampling(args, rank, world, dev):
 
 
 def _row(out, keep=()):
-    """the fields of a full line that a secondary row keeps"""
-    r = {"value": out["value"], "unit": out["unit"], "ms_per_step": out["ms_per_step"], "steps": out["steps"], "warmup": out["warmup"],
-         "workload": out["config"]["workload"]}
+    """the fields of a full line that a secondary row keeps (compact: the whole line has to fit the driver's 8 KB tail)"""
+    r = {"value": out["value"], "ms_per_step": out["ms_per_step"], "steps": out["steps"]}
     if "roofline" in out:
         rf = out["roofline"]
-        r["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us") if k in rf}
-        r["roofline"]["per_kernel_us_avg"] = {k: v["us_avg"] for k, v in rf["per_kernel"].items() if v["launches"]}
+        r["frac"] = round(rf["frac"], 4)
+        r["dominant_us"] = round(rf["avg_launch_us"], 1)
+        r["us"] = {k: round(v[0]) for k, v in rf["per_kernel_us_avg_and_launches"].items()}
     for k in keep:
         r[k] = out["config"][k]
     return r
@@ -688,11 +689,8 @@ def sample_cli_end_to_end(dev, pockets=20, samples=10):
     gs = pockets * samples * 1000
     return {"value": round(gs / wall, 2), "unit": "graph-steps/s", "wall_s": round(wall, 3), "graphs": pockets * samples,
             "denoising_steps": 1000, "result_files": len(files), "result_bytes": nbytes,
-            "phases_s": {k: round(v, 3) for k, v in stats.items()},
-            "workload": f"python -m cbgbench_amd.sample_cli --config tests/fixtures/targetdiff_test.yml --synthetic {pockets} "
-                        f"--num_samples {samples} --pockets_per_batch {pockets} --random_init: one {pockets * samples}-graph "
-                        f"batch, all 1000 reverse-diffusion steps, wall time from config load to the last result file (model "
-                        f"construction + weight init + first-call library load included)"}
+            "phases_s": {k: round(v, 2) for k, v in stats.items()},
+            "what": "python -m cbgbench_amd.sample_cli, T = 1000, wall time config load -> last result file"}
 
 
 def secondary_block(args, dev, primary):

@@ -69,6 +69,12 @@ struct Workspace {
     int* fw_count;       // [4], 64 B apart
     float* hbuf[2];
     float* xbuf[2];
+    // x2h layers run as ONE launch over two work lists (edge_mfma.hip, edge_x2h_dual_kernel): destinations with a ligand atom among
+    // themselves and their neighbours (d1flag; general role, folded query from Qt) and protein-only ones (query folded in registers)
+    uint8_t* d1flag;
+    int* sp_list[4][2];  // [all nodes | cached layer 1 (D2) | pruned A1 | pruned A2][1 = general, 0 = protein-only]
+    int* sp_count;       // per set one 128-byte region: general count at +0, protein-only count at +64 bytes
+    int* zero_count;     // an always-empty list's count
     size_t total;
 };
 
@@ -103,6 +109,10 @@ static Workspace carve(void* base, int n) {
     w.hbuf[1] = (float*)take(N * H * 4);
     w.xbuf[0] = (float*)take(N * 3 * 4);
     w.xbuf[1] = (float*)take(N * 3 * 4);
+    w.d1flag = (uint8_t*)take(N);
+    for (int k = 0; k < 4; ++k) { w.sp_list[k][1] = (int*)take(N * 4); w.sp_list[k][0] = (int*)take(N * 4); }
+    w.sp_count = (int*)take(4 * 128);
+    w.zero_count = (int*)take(256);
     w.total = off;
     return w;
 }
@@ -363,9 +373,18 @@ int cbgx_h2x_stack_forward(const float* packed, int num_layers, const float* x, 
     if (workspace_bytes < w.total)
         return fail(CBGX_E_WORKSPACE, "h2x_stack: workspace %zu < %zu", workspace_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s));
-    HIP_TRY(launch_gate(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s));
     HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, s));
+    if (g_edge_impl == 1) {
+        HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s));
+        HIP_TRY(launch_gate(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s));
+    } else {
+        // An H2X block only ever reads the neighbour list and the gate values of the nodes it moves (edge kernel and source marking
+        // both run over the gen_flag list), and the stack's graph is built once from the input coordinates (diffbp.py:84-93): the
+        // kNN search and the gate MLP run on the listed rows only -- the ligand atoms, ~5 % of a pocket -- instead of on every node
+        // (DiffBP paid 415 + 276 us per step for them at 200 graphs, against 163 + 112 us for the denoiser's cached graph).
+        HIP_TRY(launch_knn_reg(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s, w.act, w.act_count));
+        HIP_TRY(launch_gate_mfma(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s, w.act, w.act_count));
+    }
     const float* xc = x;
     for (int l = 0; l < num_layers; ++l) {
         float* xn = (l == num_layers - 1) ? x_out : w.xbuf[l & 1];
@@ -399,6 +418,13 @@ int cbgx_edge_gate(const float* packed, const float* x, const int32_t* nbr, cons
     return CBGX_OK;
 }
 
+// (general, protein-only) list pair `set` of the workspace from a destination list (NULL = all nodes) and the d1 flags
+static int split_by_d1(const Workspace& w, int set, const int* list, const int* count, int n_nodes, hipStream_t s) {
+    HIP_TRY(launch_split_list(list, count, n_nodes, w.d1flag, w.sp_list[set][1], w.sp_count + 32 * set, w.sp_list[set][0],
+                              w.sp_count + 32 * set + 16, s));
+    return CBGX_OK;
+}
+
 int cbgx_x2h_attention(const float* packed, int layer, const float* x, const float* h, const int32_t* nbr,
                        const int32_t* deg, const uint8_t* lig_flag, const float* e_w, int n_nodes, float* h_out,
                        void* workspace, size_t workspace_bytes, void* stream) {
@@ -408,8 +434,21 @@ int cbgx_x2h_attention(const float* packed, int layer, const float* x, const flo
     Workspace w = carve(workspace, n_nodes);
     if (workspace_bytes < w.total)
         return fail(CBGX_E_WORKSPACE, "x2h_attention: workspace %zu < %zu", workspace_bytes, w.total);
-    HIP_TRY(launch_attention(true, packed + x2h_off(layer), x, h, nbr, deg, lig_flag, nullptr, e_w, n_nodes, w.P,
-                             w.Qt, w.q, h_out, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    if (g_edge_impl == 1) {
+        HIP_TRY(launch_attention(true, packed + x2h_off(layer), x, h, nbr, deg, lig_flag, nullptr, e_w, n_nodes, w.P,
+                                 w.Qt, w.q, h_out, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+        return CBGX_OK;
+    }
+    // what a layer of cbgx_unitransformer_forward runs: protein-only destinations fold their query in registers, Qt is
+    // produced for the others only, one two-role edge launch
+    HIP_TRY(launch_mark_from_nbr(lig_flag, nbr, deg, n_nodes, w.d1flag, s));
+    { int rc = split_by_d1(w, 0, nullptr, nullptr, n_nodes, s); if (rc) return rc; }
+    const float* att = packed + x2h_off(layer);
+    HIP_TRY(launch_node_mfma(att, h, lig_flag, n_nodes, w.P, w.q, w.Qt, nullptr, nullptr, nullptr, nullptr, s, true,
+                             w.sp_list[0][1], w.sp_count));
+    HIP_TRY(launch_edge_x2h_dual(att, x, h, w.P, w.Qt, w.q, nbr, deg, lig_flag, nullptr, e_w, n_nodes, h_out, w.sp_list[0][0],
+                                 w.sp_count + 16, w.sp_list[0][1], w.sp_count, true, s));
     return CBGX_OK;
 }
 
@@ -512,6 +551,26 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
         HIP_TRY(launch_mark_nbr(w.fw_list[2], w.fw_count + 32, n_nodes, w.nbr, w.deg, w.fmask[1], s));      // S2
         HIP_TRY(launch_build_active(w.fmask[1], n_nodes, w.fw_list[3], w.fw_count + 48, s));
     }
+    // (general, protein-only) list pairs of the x2h layers, from the neighbour lists this call works with: d1flag = the node or
+    // one of its neighbours is a ligand atom.  Set 0 all nodes, 1 the cached layer 1 (D2), 2 / 3 the pruned layers (A1 / A2).
+    const bool dual = g_edge_impl != 1;
+    if (dual) {
+        HIP_TRY(launch_mark_from_nbr(lig_flag, w.nbr, w.deg, n_nodes, w.d1flag, s));
+        HIP_TRY(hipMemsetAsync(w.zero_count, 0, sizeof(int), s));
+        { int rc = split_by_d1(w, 0, nullptr, nullptr, n_nodes, s); if (rc) return rc; }
+        if (cached) { int rc = split_by_d1(w, 1, w.fw_list[2], w.fw_count + 32, n_nodes, s); if (rc) return rc; }
+        if (prune)
+            for (int k = 0; k < 2; ++k) { int rc = split_by_d1(w, 2 + k, w.rf_list[k], w.rf_count + 16 * k, n_nodes, s); if (rc) return rc; }
+    }
+    struct X2HLists { const int *gen, *gen_n, *pp, *pp_n; bool full; };
+    auto x2h_lists = [&](int l) {
+        X2HLists r{w.sp_list[0][1], w.sp_count, w.sp_list[0][0], w.sp_count + 16, true};
+        auto set = [&](int k) { r = X2HLists{w.sp_list[k][1], w.sp_count + 32 * k, w.sp_list[k][0], w.sp_count + 32 * k + 16, false}; };
+        if (cached && l == 0) r = X2HLists{w.fw_list[0], w.fw_count, w.sp_list[0][0], w.zero_count, false};   // D1: general role only
+        if (cached && l == 1) set(1);
+        if (prune && l >= num_layers - 2) set(2 + (num_layers - 1 - l));
+        return r;
+    };
     // Two-stream schedule (MFMA kernels, profiling off): the node stage of x2h(l+1) only needs h_{l+1}, which exists as
     // soon as the x2h edge kernel of layer l has run, while the h2x block of layer l (which only moves coordinates) is
     // still to come -- so it runs on an auxiliary stream next to that h2x block.  Three node-stage buffer sets: x2h
@@ -539,8 +598,9 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
     if (overlap) {
         const int *dst, *dst_n, *src, *src_n;
         layer_lists(0, dst, dst_n, src, src_n);
+        const X2HLists xl = x2h_lists(0);
         HIP_TRY(launch_node_mfma(packed + x2h_off(0), h, lig_flag, n_nodes, Pset[0], qset[0], Qtset[0], dst, dst_n, src,
-                                 src_n, s, true));
+                                 src_n, s, true, xl.gen, xl.gen_n));
     }
     for (int l = 0; l < num_layers; ++l) {
         float* hn = (l == num_layers - 1 && h_out) ? h_out : w.hbuf[l & 1];
@@ -550,23 +610,32 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
         if (cached && l < 2)
             HIP_TRY(hipMemcpyAsync(hn, l == 0 ? static_h1 : static_h2, (size_t)n_nodes * H * sizeof(float),
                                    hipMemcpyDeviceToDevice, s));
+        const X2HLists xl = x2h_lists(l);
         if (!overlap) {
-            HIP_TRY(launch_attention(true, packed + x2h_off(l), xc, hc, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
-                                     w.P, w.Qt, w.q, hn, nullptr, dst, dst_n, src, src_n, s));
+            if (dual) {
+                HIP_TRY(launch_node_mfma(packed + x2h_off(l), hc, lig_flag, n_nodes, w.P, w.q, w.Qt, dst, dst_n, src, src_n, s, true,
+                                         xl.gen, xl.gen_n));
+                HIP_TRY(launch_edge_x2h_dual(packed + x2h_off(l), xc, hc, w.P, w.Qt, w.q, w.nbr, w.deg, lig_flag, gen_flag, w.e_w,
+                                             n_nodes, hn, xl.pp, xl.pp_n, xl.gen, xl.gen_n, xl.full, s));
+            } else {
+                HIP_TRY(launch_attention(true, packed + x2h_off(l), xc, hc, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
+                                         w.P, w.Qt, w.q, hn, nullptr, dst, dst_n, src, src_n, s));
+            }
             HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,
                                      w.P, w.Qt, w.q, xn, nullptr, w.act, w.act_count, w.rf_list[0], w.rf_count, s));
         } else {
             const int set = l & 1;
             if (l > 0) HIP_TRY(hipStreamWaitEvent(s, aux->join, 0));       // node stage of this layer (aux stream) done
-            HIP_TRY(launch_edge_mfma(true, packed + x2h_off(l), xc, hc, Pset[set], Qtset[set], w.nbr, w.deg, lig_flag,
-                                     gen_flag, w.e_w, n_nodes, hn, nullptr, dst, dst_n, s));
+            HIP_TRY(launch_edge_x2h_dual(packed + x2h_off(l), xc, hc, Pset[set], Qtset[set], qset[set], w.nbr, w.deg, lig_flag,
+                                         gen_flag, w.e_w, n_nodes, hn, xl.pp, xl.pp_n, xl.gen, xl.gen_n, xl.full, s));
             if (l + 1 < num_layers) {
                 const int *d2, *d2n, *s2, *s2n;
                 layer_lists(l + 1, d2, d2n, s2, s2n);
                 HIP_TRY(hipEventRecord(aux->fork, s));
                 HIP_TRY(hipStreamWaitEvent(aux->s, aux->fork, 0));
+                const X2HLists xn = x2h_lists(l + 1);
                 HIP_TRY(launch_node_mfma(packed + x2h_off(l + 1), hn, lig_flag, n_nodes, Pset[set ^ 1], qset[set ^ 1],
-                                         Qtset[set ^ 1], d2, d2n, s2, s2n, aux->s, true));
+                                         Qtset[set ^ 1], d2, d2n, s2, s2n, aux->s, true, xn.gen, xn.gen_n));
                 HIP_TRY(hipEventRecord(aux->join, aux->s));
             }
             HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, w.nbr, w.deg, lig_flag, gen_flag, w.e_w, n_nodes,

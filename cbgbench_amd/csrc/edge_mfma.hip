@@ -46,12 +46,17 @@ __constant__ float c_mu[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.
 // lane (c = a, q), reg r <-> edge 4q + r + 16hf.  `kv` selects the k (0) or v (1) quarter everywhere.
 // `acc` enters as PD[i] + PS[j] (this node's and the neighbour's projection rows, channels 16t + 4q .. +3), summed by
 // the caller as soon as the gathered rows arrive, so that the registers of the gather can be reused for the next one.
-template <bool PRE>
+// FOLD (protein-only x2h kernel, first k half): `pre` is an OUTPUT here -- the folded query row Qt[i][a = c][16 t + 4 q ..] is
+// computed from the node's eight query channels of head c (`q8`) and the fold table in LDS (layout.h PP_WFOLD) between the rbf MFMA
+// block and the LayerNorm tail, i.e. after the q row has had a whole MFMA block to arrive: Qt never exists in memory.
+template <bool PRE, bool FOLD = false>
 __device__ __forceinline__ floatx4 edge_major_half(floatx4 (&acc)[8], bool lg, int kv,
                                                    const float* lds_frag, const float* lds_dwt, const float* lds_ln,
                                                    const float (&R)[5], bool has_prot, bool has_lig, int lig_i,
                                                    int lane, int q, const float* lds_brow,
-                                                   const float4 (&pre)[8], const RbfScale sc) {
+                                                   float4 (&pre)[8], const RbfScale sc,
+                                                   const float4 q8a = float4{0.f, 0.f, 0.f, 0.f},
+                                                   const float4 q8b = float4{0.f, 0.f, 0.f, 0.f}) {
     if (has_lig) {  // wave-uniform: only nodes with a ligand neighbour pay for the type correction
         const float* dw = lds_dwt + lig_i * 2 * H + kv * H + 4 * q;
         const float m = lg ? sc.S : 0.f;     // the tile is carried scaled by S (edge_common.h RbfScale)
@@ -78,6 +83,24 @@ __device__ __forceinline__ floatx4 edge_major_half(floatx4 (&acc)[8], bool lg, i
         }
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the tail's operand loads (g, b, B row) below the MFMA block
+    if (FOLD) {
+        // Qt[c][16 t + 4 q + r] = sum_d q[8 c + d] Wbk[8 c + d][16 t + 4 q + r] / sqrt(8): 64 conflict-free ds_read_b128 and 128
+        // packed FMAs per node instead of 8 KB of Qt written by node_qfold_kernel and read back here
+        const float qd[8] = {q8a.x, q8a.y, q8a.z, q8a.w, q8b.x, q8b.y, q8b.z, q8b.w};
+        const float* wf = lds_brow;     // fold table, already lane-offset: (t, d) at 2048 t + 256 d floats
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float2v lo = {0.f, 0.f}, hi = {0.f, 0.f};
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const floatx4 w4 = f4(ld4(wf + 2048 * t + 256 * d));
+                const float2v qq = splat2(qd[d]);
+                lo = lo2(w4) * qq + lo;
+                hi = hi2(w4) * qq + hi;
+            }
+            pre[t] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+    }
     // LayerNorm: the first Linear is centred, so mean(pre) == 0 and var = mean(pre^2)
     float2v v2 = {0.f, 0.f};
 #pragma unroll
@@ -129,20 +152,27 @@ __device__ __forceinline__ int e1_id(int raw, int e, int d, int self) { return e
 //   after k half 0       PS_v gathers of half 1 (x2h), e_w; coordinates / flags of the next node's neighbours (b)
 //   after k half 1       distances / flags of the next node's edges
 //   before the epilogue  PD / PS_k rows of the next node (c)
-template <bool X2H, int WAVES, bool LISTED>
-__global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
+// PP (x2h, listed): the protein-only specialisation -- every listed destination and all of its neighbours are protein atoms (the
+// launcher's list guarantees it), so only the type-3 rbf tables are needed and the LDS image (layout.h A_IMG_PP) carries the second
+// k Linear instead of the other three types: the query fold happens in registers, `Qt` is then the UNFOLDED query q[N,128].
+// The body is a device function over (`wg`, `n_wg`) = this workgroup's index and the number of workgroups that share the item list:
+// the plain kernels pass blockIdx.x / gridDim.x, the two-role x2h kernel (edge_x2h_dual_kernel) gives each role its own range.
+// `lds` [IMG floats], `lds_mu` [G floats]: the calling kernel's shared arrays.
+template <bool X2H, int WAVES, bool LISTED, bool PP>
+__device__ __forceinline__ void edge_body(
+    float* __restrict__ lds, float* __restrict__ lds_mu, const int wg, const int n_wg,
     const float* __restrict__ att, const float* __restrict__ x, const float* __restrict__ h,
     const float* __restrict__ P, const float* __restrict__ Qt, const int32_t* __restrict__ nbr,
     const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig, const uint8_t* __restrict__ gen,
     const float* __restrict__ e_w, int n_nodes, float* __restrict__ out, float* __restrict__ dx_out,
     const int* __restrict__ act_arg, const int* __restrict__ act_count) {
     const int* __restrict__ act = LISTED ? act_arg : nullptr;
+    static_assert(!PP || (X2H && LISTED), "the protein-only kernel is an x2h work-list kernel");
+    static_assert(PP_IMG_SIZE == IMG_SIZE_X2H, "both x2h images fill the same LDS array");
     constexpr int IMG = X2H ? (int)IMG_SIZE_X2H : (int)IMG_SIZE_H2X;
-    __shared__ __attribute__((aligned(16))) float lds[IMG];
-    __shared__ float lds_mu[G];
     if (!X2H && act) {
         // work list mode: x_out = x for every node that cannot move (done by all workgroups, before any early exit)
-        for (int n = blockIdx.x * (WAVES * 64) + threadIdx.x; n < n_nodes; n += gridDim.x * WAVES * 64)
+        for (int n = wg * (WAVES * 64) + threadIdx.x; n < n_nodes; n += n_wg * WAVES * 64)
             if (!gen[n]) {
                 out[3 * n] = x[3 * n]; out[3 * n + 1] = x[3 * n + 1]; out[3 * n + 2] = x[3 * n + 2];
                 if (dx_out) { dx_out[3 * n] = 0.f; dx_out[3 * n + 1] = 0.f; dx_out[3 * n + 2] = 0.f; }
@@ -151,12 +181,12 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     const int n_items = act ? *act_count : n_nodes;
     {   // a workgroup with no item skips the LDS fill altogether
         int first;
-        if ((gridDim.x & 7) == 0) {
+        if ((n_wg & 7) == 0) {
             const int per_xcd = (((n_items + 7) >> 3) + WAVES - 1) / WAVES * WAVES;
-            first = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) * WAVES;
-            if (first >= min(n_items, ((int)(blockIdx.x & 7) + 1) * per_xcd)) return;
+            first = (wg & 7) * per_xcd + (wg >> 3) * WAVES;
+            if (first >= min(n_items, ((int)(wg & 7) + 1) * per_xcd)) return;
         } else {
-            first = blockIdx.x * WAVES;
+            first = wg * WAVES;
             if (first >= n_items) return;
         }
     }
@@ -164,7 +194,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         // LDS fill: every load of the thread is requested before the first is written (19 float4 per thread for the x2h image).
         // Left as a plain loop the compiler emits load -> wait -> ds_write per iteration: 19 dependent L2 round trips, ~25 us at
         // the head of EVERY launch -- the whole duration of a small one (a 1-graph step is 18 such launches).
-        const floatx4* src = reinterpret_cast<const floatx4*>(att + A_IMG);
+        const floatx4* src = reinterpret_cast<const floatx4*>(att + (PP ? A_IMG_PP : A_IMG));
         floatx4* dst = reinterpret_cast<floatx4*>(lds);
         constexpr int NV = (IMG / 4 + WAVES * 64 - 1) / (WAVES * 64);
         floatx4 v[NV];
@@ -182,10 +212,11 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         if (threadIdx.x < G) lds_mu[threadIdx.x] = c_mu[threadIdx.x];
     }
     __syncthreads();
-    const float* lds_fk = lds + IMG_FRAG_K;
-    const float* lds_fv = lds + IMG_FRAG_V;
-    const float* lds_dwt = lds + IMG_WT;
-    const float* lds_ln = lds + IMG_LN;
+    // PP: the tables of edge type 3 sit at the head of the image; the table bases are biased so that etype() = 3 indexes them
+    const float* lds_fk = PP ? lds + PP_FRAG_K - 3 * 8 * (int)FRAG_BLK : lds + IMG_FRAG_K;
+    const float* lds_fv = PP ? lds + PP_FRAG_V - 3 * 8 * (int)FRAG_BLK : lds + IMG_FRAG_V;
+    const float* lds_dwt = lds + IMG_WT;     // (never read by PP: no ligand source)
+    const float* lds_ln = lds + (PP ? PP_LN : IMG_LN);
 
     // the wave index -- and with it every node index of the persistent loop -- lives in scalar registers: node-level values
     // (degree, flag, position, row bases) are then scalar loads and SGPR operands instead of 64 identical lanes
@@ -193,18 +224,19 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     const int c = lane & 15, q = lane >> 4;
 
     // XCD-aware persistent schedule: workgroup b runs on XCD b % 8 (observed dispatch order), so give every
-    // XCD one contiguous eighth of the item range: a graph's PS / Qt rows are then pulled into one L2 only.
+    // XCD one contiguous eighth of the item range: a graph's PS / Qt rows are then pulled into one L2 only.  (A role of the
+    // two-role kernel starts at a multiple of 8, so wg % 8 is still the XCD.)
     int i_begin, i_end, i_step;
-    if ((gridDim.x & 7) == 0) {
+    if ((n_wg & 7) == 0) {
         const int per_xcd = (((n_items + 7) >> 3) + WAVES - 1) / WAVES * WAVES;
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int xcd = wg & 7, slot = wg >> 3;
         i_begin = xcd * per_xcd + slot * WAVES + wave;
         i_end = min(n_items, (xcd + 1) * per_xcd);
-        i_step = (gridDim.x >> 3) * WAVES;
+        i_step = (n_wg >> 3) * WAVES;
     } else {
-        i_begin = blockIdx.x * WAVES + wave;
+        i_begin = wg * WAVES + wave;
         i_end = n_items;
-        i_step = gridDim.x * WAVES;
+        i_step = n_wg * WAVES;
     }
     if (i_begin >= i_end) return;
     // power-of-two scales of the split-f16 rbf tables (wave-uniform: scalar registers)
@@ -222,7 +254,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     {
         const int i = __builtin_amdgcn_readfirstlane(act ? act[i_begin] : i_begin);
         g.node = i;
-        g.d = deg[i]; g.lig_i = lig[i];
+        g.d = deg[i]; g.lig_i = PP ? 0 : lig[i];
         g.xi = x[3 * i]; g.yi = x[3 * i + 1]; g.zi = x[3 * i + 2];
         const gptr nrow = sbase(nbr + (size_t)i * KNN);
         const unsigned oc = vop(4 * c), oq = vop(16 * q);
@@ -233,7 +265,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int j = g.j0[hf];
-            const int lj = ldob(sbase(lig), (unsigned)j);
+            const int lj = PP ? 0 : ldob(sbase(lig), (unsigned)j);
             lg0[hf] = (c + 16 * hf < g.d) && lj;
             dist0[hf] = edge_len(g.xi, g.yi, g.zi, ldo1(sbase(x), 12u * j), ldo1(sbase(x), 12u * j + 4), ldo1(sbase(x), 12u * j + 8));
         }
@@ -265,7 +297,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         const int inext = __builtin_amdgcn_readfirstlane(more ? (act ? act[k + i_step] : k + i_step) : i);
         ng.node = inext;
         const int nd_raw = deg[inext];
-        const int nlig_raw = ldob(sbase(lig), vop((unsigned)inext));
+        const int nlig_raw = PP ? 0 : ldob(sbase(lig), vop((unsigned)inext));
         const gptr xrow = sbase(x + 3 * (size_t)inext);
         const unsigned ozero = vop(0u);
         const float nx_raw = ldo1(xrow, ozero), ny_raw = ldo1(xrow, ozero + 4), nz_raw = ldo1(xrow, ozero + 8);
@@ -275,7 +307,12 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         __builtin_amdgcn_sched_barrier(0);
         // this node's folded query row (B operand of the score MFMAs): consumed after the first pre-activation block
         float4 qrow[8];
-        {
+        float4 q8a = {0.f, 0.f, 0.f, 0.f}, q8b = {0.f, 0.f, 0.f, 0.f};
+        if (PP) {   // the eight query channels of head c (32 bytes per lane instead of the 512 of a folded row); folded in k half 0
+            const gptr qp = sbase(Qt + (size_t)i * H);
+            const unsigned oq8 = vop(32 * c);
+            q8a = ldo4(qp, oq8); q8b = ldo4(qp, oq8 + 16);
+        } else {
             const gptr qp = sbase(Qt + (size_t)i * HEADS * H);
             const unsigned oqr = vop((c * H + 4 * q) * 4);
 #pragma unroll
@@ -312,13 +349,13 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         const unsigned long long b0 = __ballot(lg0[0]), b1 = __ballot(lg0[1]);
         const unsigned mask_lig = (unsigned)(b0 & 0xffffull) | ((unsigned)(b1 & 0xffffull) << 16);
         const unsigned mask_valid = d >= 32 ? 0xffffffffu : ((1u << d) - 1u);
-        const bool has_lig = (mask_lig & mask_valid) != 0;
-        const bool has_prot = ((~mask_lig) & mask_valid) != 0 || d == 0;
+        const bool has_lig = PP ? false : (mask_lig & mask_valid) != 0;
+        const bool has_prot = PP ? true : ((~mask_lig) & mask_valid) != 0 || d == 0;
 
         // ---- k path: hidden (edge-major) -> scores -> softmax ------------------------------------------
         floatx4 sc[2];
-        sc[0] = edge_major_half<true>(acc0, lg0[0], 0, lds_fk, lds_dwt, lds_ln, R[0], has_prot, has_lig, lig_i, lane, q,
-                                      nullptr, qrow, sck);
+        sc[0] = edge_major_half<true, PP>(acc0, lg0[0], 0, lds_fk, lds_dwt, lds_ln, R[0], has_prot, has_lig, lig_i, lane, q,
+                                          PP ? lds + PP_WFOLD + 4 * lane : nullptr, qrow, sck, q8a, q8b);
         __builtin_amdgcn_sched_barrier(0);
         // (b) next item: resolve its neighbour ids (they arrived during the first half), request their flags and
         // coordinates; then the second half of the PS_v gather and the gate values
@@ -335,7 +372,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int j = ng.j0[hf];
-                nlj[hf] = ldob(sbase(lig), (unsigned)j);
+                nlj[hf] = PP ? 0 : ldob(sbase(lig), (unsigned)j);
                 nxj[hf][0] = ldo1(sbase(x), 12u * j); nxj[hf][1] = ldo1(sbase(x), 12u * j + 4); nxj[hf][2] = ldo1(sbase(x), 12u * j + 8);
             }
         }
@@ -553,7 +590,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
             // group land on 16 different 16-byte slots (XOR with the head index itself was 2-way conflicted on every read:
             // 256 of the node's 880 LDS cycles).
             float o8[8];
-            const float* lds_wbv = lds + IMG_WBV;
+            const float* lds_wbv = lds + (PP ? PP_WBV : IMG_WBV);
             const int swz = wbv_swizzle(c);
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc) {
@@ -634,6 +671,55 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
         lg0[0] = nlg[0]; lg0[1] = nlg[1]; dist0[0] = ndist[0]; dist0[1] = ndist[1];
         g = ng;
     }
+}
+
+template <bool X2H, int WAVES, bool LISTED>
+__global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
+    const float* __restrict__ att, const float* __restrict__ x, const float* __restrict__ h,
+    const float* __restrict__ P, const float* __restrict__ Qt, const int32_t* __restrict__ nbr,
+    const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig, const uint8_t* __restrict__ gen,
+    const float* __restrict__ e_w, int n_nodes, float* __restrict__ out, float* __restrict__ dx_out,
+    const int* __restrict__ act, const int* __restrict__ act_count) {
+    __shared__ __attribute__((aligned(16))) float lds[X2H ? (int)IMG_SIZE_X2H : (int)IMG_SIZE_H2X];
+    __shared__ float lds_mu[G];
+    edge_body<X2H, WAVES, LISTED, false>(lds, lds_mu, blockIdx.x, gridDim.x, att, x, h, P, Qt, nbr, deg, lig, gen, e_w, n_nodes, out,
+                                         dx_out, act, act_count);
+}
+
+// x2h over TWO work lists in one launch: the protein-only destinations (`list_pp`: the node and all its neighbours are protein
+// atoms; query folded in registers from q[N,128]) and the rest (`list_gen`: general kernel, folded rows from Qt[N,16,128], which
+// node_qfold_kernel has produced for THESE nodes only).  The first `n_pp_wg` workgroups play the protein-only role, the others
+// the general one; the split follows the list lengths (device-side counts; a general node is priced at 1.3 protein-only ones:
+// mixed neighbourhoods run both source-class passes and read 8 KB of Qt) in multiples of 8 workgroups, so that a role's
+// workgroup index modulo 8 is still its XCD.  One launch per layer, one LDS fill per workgroup, both lists' tails overlap.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void edge_x2h_dual_kernel(
+    const float* __restrict__ att, const float* __restrict__ x, const float* __restrict__ h,
+    const float* __restrict__ P, const float* __restrict__ Qt, const float* __restrict__ qbuf,
+    const int32_t* __restrict__ nbr, const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig,
+    const uint8_t* __restrict__ gen, const float* __restrict__ e_w, int n_nodes, float* __restrict__ out,
+    const int* __restrict__ list_pp, const int* __restrict__ count_pp, const int* __restrict__ list_gen,
+    const int* __restrict__ count_gen) {
+    __shared__ __attribute__((aligned(16))) float lds[IMG_SIZE_X2H];
+    __shared__ float lds_mu[G];
+    const int c_pp = *count_pp, c_gen = *count_gen;
+    const int n_wg = gridDim.x;
+    int n_pp_wg;
+    if (c_gen == 0) n_pp_wg = n_wg;
+    else if (c_pp == 0) n_pp_wg = 0;
+    else {
+        const float share = (float)c_pp / ((float)c_pp + 1.3f * (float)c_gen);
+        const int unit = n_wg >= 64 ? 8 : 1;
+        n_pp_wg = (int)(share * (float)(n_wg / unit) + 0.5f) * unit;
+        n_pp_wg = max(unit, min(n_wg - unit, n_pp_wg));
+        if (n_wg < 2) n_pp_wg = 0;            // a single workgroup cannot play both roles: see the launcher (grid >= 2)
+    }
+    if ((int)blockIdx.x < n_pp_wg)
+        edge_body<true, WAVES, true, true>(lds, lds_mu, blockIdx.x, n_pp_wg, att, x, h, P, qbuf, nbr, deg, lig, gen, e_w, n_nodes,
+                                           out, nullptr, list_pp, count_pp);
+    else
+        edge_body<true, WAVES, true, false>(lds, lds_mu, (int)blockIdx.x - n_pp_wg, n_wg - n_pp_wg, att, x, h, P, Qt, nbr, deg, lig,
+                                            gen, e_w, n_nodes, out, nullptr, list_gen, count_gen);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -730,6 +816,27 @@ __global__ void pack_wbv_swz_kernel(PackBlocks pb) {
     pb.att[blockIdx.y][A_IMG + IMG_WBV + n * H + (((chunk ^ wbv_swizzle((n >> 3) & 15)) << 2) | r)] = pb.wv1[blockIdx.y][idx];
 }
 
+// x2h blocks: the LDS image of the protein-only kernel (layout.h A_IMG_PP), assembled from the general image this stream has just
+// written (type-3 table slices, LayerNorm affine, swizzled second v Linear) plus the fold table of the second k Linear
+__global__ void pack_pp_image_kernel(PackBlocks pb) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int)PP_IMG_SIZE || !pb.x2h[blockIdx.y]) return;
+    float* att = pb.att[blockIdx.y];
+    const float* img = att + A_IMG;
+    float v;
+    if (idx < (int)PP_FRAG_V) v = img[IMG_FRAG_K + 3 * 8 * FRAG_BLK + idx];
+    else if (idx < (int)PP_LN) v = img[IMG_FRAG_V + 3 * 8 * FRAG_BLK + (idx - PP_FRAG_V)];
+    else if (idx < (int)PP_WBV) v = img[IMG_LN + (idx - PP_LN)];
+    else if (idx < (int)PP_WFOLD) v = img[IMG_WBV + (idx - PP_WBV)];
+    else {
+        const int u = idx - (int)PP_WFOLD;                      // ((t * 8 + d) * 64 + lane) * 4 + r
+        const int r = u & 3, lane = (u >> 2) & 63, d = (u >> 8) & 7, t = u >> 11;
+        const int c = lane & 15, q = lane >> 4;
+        v = pb.wk1[blockIdx.y][(size_t)(8 * c + d) * H + 16 * t + 4 * q + r] * 0.35355339059327376220f;   // same factor as A_WBK_FRAG
+    }
+    att[A_IMG_PP + idx] = v;
+}
+
 // centre the first Linears of k and v over their 128 output channels: wc = w - colmean(w), bc = b - mean(b)   (w [128][340]);
 // blockIdx.x = column (KV_IN -> the bias), blockIdx.y = 2 block + (k | v)
 __global__ void center_linear_kernel(PackBlocks pb) {
@@ -765,6 +872,7 @@ hipError_t launch_pack_stage2(const PackBlocks& pb, hipStream_t s) {
     hipLaunchKernelGGL(pack_frag_kernel, dim3(NT * 8 * 64 / 256, pb.n, 3), dim3(256), 0, s, pb);
     hipLaunchKernelGGL(pack_dwt_kernel, dim3(2, pb.n), dim3(256), 0, s, pb);
     hipLaunchKernelGGL(pack_wbv_swz_kernel, dim3(H * H / 256, pb.n), dim3(256), 0, s, pb);
+    hipLaunchKernelGGL(pack_pp_image_kernel, dim3((PP_IMG_SIZE + 255) / 256, pb.n), dim3(256), 0, s, pb);
     return hipGetLastError();
 }
 
@@ -795,6 +903,28 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
         if (act) CBGX_LAUNCH_EDGE(false, true); else CBGX_LAUNCH_EDGE(false, false);
     }
 #undef CBGX_LAUNCH_EDGE
+    profile_mark_end(s);
+    return hipGetLastError();
+}
+
+// x2h edge stage over the (protein-only, general) list pair of a layer: one launch of edge_x2h_dual_kernel.  `full_layer`: the two
+// lists together are all N nodes (profile class of the dominant kernel) -- otherwise a cached / pruned layer.
+hipError_t launch_edge_x2h_dual(const float* att, const float* x, const float* h, const float* P, const float* Qt,
+                                const float* qbuf, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
+                                const uint8_t* gen, const float* e_w, int n_nodes, float* out, const int* list_pp,
+                                const int* count_pp, const int* list_gen, const int* count_gen, bool full_layer, hipStream_t s) {
+    if (n_nodes == 0) return hipSuccess;
+    if ((size_t)n_nodes * PROW * sizeof(float) >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit byte offsets into P
+    constexpr int W = 8;
+    int grid = (n_nodes + W - 1) / W;
+    if (grid > 256) grid = 256;
+    const int wg_limit = g_edge_wg_limit.load(std::memory_order_relaxed);
+    if (wg_limit >= 8 && grid > wg_limit) grid = wg_limit;
+    if (grid >= 64) grid &= ~7;
+    if (grid < 2) grid = 2;                     // one workgroup per role at least
+    profile_mark_begin(full_layer ? K_EDGE_X2H : K_EDGE_X2H_LISTED, s);
+    hipLaunchKernelGGL((edge_x2h_dual_kernel<W>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qt, qbuf, nbr, deg, lig, gen, e_w,
+                       n_nodes, out, list_pp, count_pp, list_gen, count_gen);
     profile_mark_end(s);
     return hipGetLastError();
 }

@@ -88,13 +88,19 @@ hipError_t launch_mark_nbr(const int* list, const int* count, int n_upper, const
 // layers) rather than the few movable atoms of an h2x block: throughput launches instead of one workgroup per column chunk
 hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,
                             float* Qt, const int* act, const int* act_count, const int* src, const int* src_count,
-                            hipStream_t s, bool large_lists = false);
+                            hipStream_t s, bool large_lists = false, const int* fold = nullptr, const int* fold_count = nullptr);
+hipError_t launch_split_list(const int* list, const int* count, int n, const uint8_t* flag, int* out1, int* cnt1, int* out0,
+                             int* cnt0, hipStream_t s);
 // MFMA edge kernel (edge_mfma.hip)
 int set_edge_workgroup_limit(int n);
 hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,
                             const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                             const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,
                             const int* act, const int* act_count, hipStream_t s);
+hipError_t launch_edge_x2h_dual(const float* att, const float* x, const float* h, const float* P, const float* Qt,
+                                const float* qbuf, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
+                                const uint8_t* gen, const float* e_w, int n_nodes, float* out, const int* list_pp,
+                                const int* count_pp, const int* list_gen, const int* count_gen, bool full_layer, hipStream_t s);
 // TargetDiff step prologue / epilogue (step.hip)
 hipError_t launch_step_prologue(const float* x_lig, const float* c_lig, const int32_t* lig_rows, int n_lig, int C,
                                 const float* emb_w, const float* emb_b, const float* ind_w, const float* ind_b, float* x,

@@ -105,7 +105,22 @@ constexpr int RBF_KW_MAX = 20;       // S <= 2^32: sum of squares of 128 scaled 
 constexpr size_t A_RBF_SC = A_FRAGV_EM + FRAG;
 constexpr size_t A_NPROJ_CINV = A_RBF_SC + 8;
 constexpr size_t A_WQ1_CINV = A_NPROJ_CINV + PROW;
-constexpr size_t ATT_SIZE = A_WQ1_CINV + H;
+// ---- x2h blocks: LDS image of the edge kernel's PROTEIN-ONLY specialisation (edge_mfma.hip, PP = true): destinations whose 32
+// neighbours and themselves are protein atoms (~ 3 of 4 nodes of a pocket) need the rbf tables of edge type 3 only, which leaves
+// room for the second k Linear next to the second v Linear -- the query is then folded in registers and Qt[N,16,128] (8 KB
+// written + 8 KB read per node and block) never exists for those nodes.  One contiguous region, copied verbatim into LDS:
+//   frag_k [8 t][320]   type-3 slice of IMG_FRAG_K          frag_v [8 t][320]   type-3 slice of IMG_FRAG_V
+//   ln [4][128]         as IMG_LN                           wbv [128][128]      as IMG_WBV (swizzled chunks)
+//   wfold [8 t][8 d][64 lanes][4]   Wbk[8c + d][16t + 4q + r] / sqrt(8) for lane (c, q): lane (c = head, q) folds
+//                       Qt[c][16t + 4q + r] = sum_d q[8c + d] wfold[t][d][lane][r] with conflict-free linear ds_read_b128
+constexpr size_t PP_FRAG_K = 0;
+constexpr size_t PP_FRAG_V = PP_FRAG_K + 8 * FRAG_BLK;
+constexpr size_t PP_LN = PP_FRAG_V + 8 * FRAG_BLK;
+constexpr size_t PP_WBV = PP_LN + 4 * H;
+constexpr size_t PP_WFOLD = PP_WBV + (size_t)H * H;
+constexpr size_t PP_IMG_SIZE = PP_WFOLD + (size_t)H * H;      // 38400 floats = 153600 B, the size of the general image
+constexpr size_t A_IMG_PP = A_WQ1_CINV + H;
+constexpr size_t ATT_SIZE = A_IMG_PP + PP_IMG_SIZE;
 
 constexpr size_t LAYER_SIZE = 2 * ATT_SIZE;       // x2h then h2x
 

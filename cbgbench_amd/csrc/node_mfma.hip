@@ -86,6 +86,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], float up, half8& hi8
 // ------------------------------------------------------------------------------------------------
 constexpr int NP_CHUNK = 2 * 4 * 4 * 64 * 4;  // 8192 floats = 32 KB (two f16 per float slot)
 constexpr int NP_CHUNKS = PROW / 64;          // 10
+constexpr int NP_WGS_PER_CU = 3;              // node_proj_kernel: __launch_bounds__(256, NP_WGS_PER_CU), 32 KB of LDS each
+constexpr int NP_RESIDENT_WGS = 256 * NP_WGS_PER_CU;
 
 typedef float lds_fx4 __attribute__((ext_vector_type(4)));
 // LDS fill of the float4 range [begin, end) by 256 threads with every load of a thread requested before its first store (at most
@@ -158,7 +160,7 @@ __device__ __forceinline__ ProjTile proj_tile_load(const float* __restrict__ h, 
 // written to their natural positions P[rows[k]].  `chunk_mask`: which of the 10 column chunks to produce; workgroup (x, y) owns
 // the y-th selected chunk and the row tiles x, x + gridDim.x, ...
 template <bool LISTED>
-__global__ __launch_bounds__(256, 3) void node_proj_kernel(const float* __restrict__ att, const float* __restrict__ h,
+__global__ __launch_bounds__(256, NP_WGS_PER_CU) void node_proj_kernel(const float* __restrict__ att, const float* __restrict__ h,
                                                            const uint8_t* __restrict__ lig, float* __restrict__ P,
                                                            int n_nodes, const int* __restrict__ rows,
                                                            const int* __restrict__ n_rows_ptr, unsigned chunk_mask) {
@@ -198,6 +200,15 @@ __global__ __launch_bounds__(256, 3) void node_proj_kernel(const float* __restri
         __builtin_amdgcn_sched_barrier(0);
         half8 ah[4], al[4];
         float rinv[4];
+#if defined(CBGX_ABLATE) && (CBGX_ABL_NPROJ & 1)
+        // timing ablation (WRONG results, libcbgx_ablate.so only): no row scale, no split -- the raw bits serve as operands
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ah[u] = __builtin_bit_cast(half8, cur.hv[2 * u]);
+            al[u] = __builtin_bit_cast(half8, cur.hv[2 * u + 1]);
+        }
+        rinv[0] = rinv[1] = rinv[2] = rinv[3] = 1.f;
+#else
         {
             float mx = 0.f;
 #pragma unroll
@@ -213,6 +224,7 @@ __global__ __launch_bounds__(256, 3) void node_proj_kernel(const float* __restri
                 split8(v, up, ah[u], al[u]);
             }
         }
+#endif
         floatx4 acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -230,7 +242,11 @@ __global__ __launch_bounds__(256, 3) void node_proj_kernel(const float* __restri
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+#if defined(CBGX_ABLATE) && (CBGX_ABL_NPROJ & 2)
+            if (cur.orow[r] == -12345) {     // timing ablation: no stores
+#else
             if (cur.orow[r] >= 0) {
+#endif
                 const float4 b = ((cur.lgr >> r) & 1) ? bL : bP;
                 float4 o = {fmaf(acc[0][r] * rinv[r], ci.x, b.x), fmaf(acc[1][r] * rinv[r], ci.y, b.y),
                             fmaf(acc[2][r] * rinv[r], ci.z, b.z), fmaf(acc[3][r] * rinv[r], ci.w, b.w)};
@@ -780,6 +796,48 @@ __global__ __launch_bounds__(BA_THREADS) void build_active_kernel(const uint8_t*
     if (a) list[s_base + s_cnt[wave] + __popcll(m & ((1ull << lane) - 1ull))] = idx;
 }
 
+// split a work list (or, without one, the nodes 0 .. n-1) by a per-node flag: flagged nodes -> out1, the others -> out0, each with its
+// own device-side count (both zero on entry).  Same aggregation as build_active_kernel: one returning atomic per list and workgroup.
+// Used for the (general, protein-only) list pair of every x2h layer (edge_mfma.hip, edge_x2h_dual_kernel).
+__global__ __launch_bounds__(BA_THREADS) void split_list_kernel(const int* __restrict__ list, const int* __restrict__ count, int n,
+                                                                const uint8_t* __restrict__ flag, int* __restrict__ out1,
+                                                                int* __restrict__ cnt1, int* __restrict__ out0,
+                                                                int* __restrict__ cnt0) {
+    __shared__ int s_cnt[2][BA_THREADS / 64];
+    __shared__ int s_base[2];
+    const int idx = blockIdx.x * BA_THREADS + threadIdx.x;
+    const int n_items = list ? *count : n;
+    const bool valid = idx < n_items;
+    const int node = valid ? (list ? list[idx] : idx) : 0;
+    const bool f = valid && flag[node] != 0;
+    const unsigned long long m1 = __ballot(f), m0 = __ballot(valid && !f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_cnt[1][wave] = __popcll(m1); s_cnt[0][wave] = __popcll(m0); }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int k = threadIdx.x;
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < BA_THREADS / 64; ++w) { const int c = s_cnt[k][w]; s_cnt[k][w] = tot; tot += c; }   // exclusive prefix
+        s_base[k] = tot ? atomicAdd(k ? cnt1 : cnt0, tot) : 0;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (f) out1[s_base[1] + s_cnt[1][wave] + __popcll(m1 & below)] = node;
+    else if (valid) out0[s_base[0] + s_cnt[0][wave] + __popcll(m0 & below)] = node;
+}
+
+hipError_t launch_split_list(const int* list, const int* count, int n, const uint8_t* flag, int* out1, int* cnt1, int* out0,
+                             int* cnt0, hipStream_t s) {
+    // the two counters live in one 128-byte region (cnt1 first): one memset
+    hipError_t e = hipMemsetAsync(cnt1, 0, (size_t)((char*)cnt0 - (char*)cnt1) + sizeof(int), s);
+    if (e != hipSuccess) return e;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(split_list_kernel, dim3((n + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, s, list, count, n, flag,
+                       out1, cnt1, out0, cnt0);
+    return hipGetLastError();
+}
+
 // ---- receptive-field pruning helpers ---------------------------------------------------------------
 __global__ void mark_seed_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int n,
                                  uint8_t* __restrict__ m) {
@@ -850,20 +908,24 @@ constexpr unsigned CHUNKS_OWN = 0x30fu;   // PDk | PDv | qh: what the destinatio
 // (optional): the nodes that can be *sources* of those destinations; without it PS is produced for every node.
 constexpr int NODE_STAGE_MAX_ROWS = 8192;   // up to here the latency-built fused kernel replaces the three-kernel chain
 
+// `fold` / `fold_count` (optional, x2h blocks of the inference path): the rows whose folded query Qt the edge stage will read -- the
+// GENERAL list of the layer; protein-only destinations fold in registers (edge_mfma.hip) and only need q.  Without it Qt is
+// produced for every destination.
 hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,
                             float* Qt, const int* act, const int* act_count, const int* src, const int* src_count,
-                            hipStream_t s, bool large_lists) {
+                            hipStream_t s, bool large_lists, const int* fold, const int* fold_count) {
     if (n_nodes == 0) return hipSuccess;
     const int tiles = (n_nodes + 63) / 64;
     const int grid = min(tiles, 512);
     // few row tiles (small batches, or a work list): spread the heads of the fold / the halves of the query MLP over workgroups too
     const bool small = tiles <= 128 || (act != nullptr && !large_lists);
-    // node_proj_kernel: one workgroup per (row-tile column x, selected chunk); all of them resident at once (four per CU), and
-    // gridDim.x a multiple of 8 so that the workgroups of one row tile -- linear ids x + y gridDim.x -- land on one XCD and its
-    // L2 serves the tile's rows to all of them
+    // node_proj_kernel: one workgroup per (row-tile column x, selected chunk); ALL of them resident at once -- the kernel's
+    // __launch_bounds__(256, 3) give three 4-wave workgroups per CU = 768 slots (a grid of 960 ran as two rounds, the second a
+    // quarter full: 100 us instead of 67) -- and gridDim.x a multiple of 8 so that the workgroups of one row tile -- linear ids
+    // x + y gridDim.x -- land on one XCD and its L2 serves the tile's rows to all of them
     auto proj_grid = [&](unsigned mask) {
         const int py = __builtin_popcount(mask);
-        int gx = 1024 / py;
+        int gx = NP_RESIDENT_WGS / py;
         if (gx >= 8) gx &= ~7;
         return dim3((unsigned)min(tiles, gx), (unsigned)py);
     };
@@ -878,9 +940,14 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
             hipLaunchKernelGGL(node_proj_kernel<false>, proj_grid(CHUNKS_ALL), dim3(256), 0, s, att, h, lig, P, n_nodes,
                                (const int*)nullptr, (const int*)nullptr, CHUNKS_ALL);
     } else {
-        if (!two_jobs)
-            hipLaunchKernelGGL(node_proj_kernel<true>, proj_grid(CHUNKS_PS), dim3(256), 0, s, att, h, lig, P, n_nodes, src, src_count,
-                               CHUNKS_PS);
+        if (!two_jobs) {     // without a source list the PS columns are produced for every node
+            if (src)
+                hipLaunchKernelGGL(node_proj_kernel<true>, proj_grid(CHUNKS_PS), dim3(256), 0, s, att, h, lig, P, n_nodes, src,
+                                   src_count, CHUNKS_PS);
+            else
+                hipLaunchKernelGGL(node_proj_kernel<false>, proj_grid(CHUNKS_PS), dim3(256), 0, s, att, h, lig, P, n_nodes,
+                                   (const int*)nullptr, (const int*)nullptr, CHUNKS_PS);
+        }
         if (!fused)
             hipLaunchKernelGGL(node_proj_kernel<true>, proj_grid(CHUNKS_OWN), dim3(256), 0, s, att, h, lig, P, n_nodes, act, act_count,
                                CHUNKS_OWN);
@@ -894,8 +961,11 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
                            qbuf, Qt, n_nodes, act, act_count, act ? CHUNKS_OWN : CHUNKS_ALL, src, src_count, CHUNKS_PS);
     } else {
         hipLaunchKernelGGL(node_qmlp_kernel, dim3(grid, small ? 2 : 1), dim3(256), 0, s, att, P, qbuf, n_nodes, act, act_count);
-        hipLaunchKernelGGL(node_qfold_kernel, dim3(grid, small ? 4 : 1), dim3(256), 0, s, att, qbuf, Qt, n_nodes, act,
-                           act_count);
+        if (fold)    // heads spread over four workgroups per row tile: the list is a fraction of the nodes, of unknown length
+            hipLaunchKernelGGL(node_qfold_kernel, dim3(grid, 4), dim3(256), 0, s, att, qbuf, Qt, n_nodes, fold, fold_count);
+        else
+            hipLaunchKernelGGL(node_qfold_kernel, dim3(grid, small ? 4 : 1), dim3(256), 0, s, att, qbuf, Qt, n_nodes, act,
+                               act_count);
     }
     profile_mark_end(s);
     return hipGetLastError();

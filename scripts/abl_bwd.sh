@@ -9,6 +9,6 @@ export CBGX_LIBRARY=$(pwd)/cbgbench_amd/lib/libcbgx_ablate.so
 for a in ${ABLS:-0 1 2 4 8 16 32 24}; do
   CBGX_BWD_ABL=$a python bench.py --workload train --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); k=d['roofline']['per_kernel']
+d=json.loads(sys.stdin.read()); k={n: {'us_avg': v[0], 'launches': v[1]} for n, v in d['roofline']['per_kernel_us_avg_and_launches'].items()}
 print('abl=$a', 'x2h_bwd us', k['edge_x2h_bwd']['us_avg'], 'h2x_bwd us', k['edge_h2x_bwd']['us_avg'], 'ms/step', d['ms_per_step'])"
 done

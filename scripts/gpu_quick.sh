@@ -14,4 +14,4 @@ timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail 
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
 print('value', d['value'], 'ms/denoise-step', d['config']['ms_per_denoising_step_of_the_job'], 'x2h us', r['avg_launch_us'], 'frac', r['frac'])
-print({k: round(v['us_avg'],1) for k,v in r['per_kernel'].items() if v['launches']})"
+print({k: round(v['us_avg'],1) for k,v in {n: {'us_avg': v[0], 'launches': v[1]} for n, v in r['per_kernel_us_avg_and_launches'].items()}.items() if v['launches']})"

@@ -8,5 +8,5 @@ for cfg in "1 1" "1 10" "4 10"; do
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
 print('pockets $1 samples $2:', d['value'], d['unit'], 'ms/denoise-step', d['config']['ms_per_denoising_step_of_the_job'])
-print('   ', {k: round(v['us_avg'],1) for k,v in r['per_kernel'].items() if v['launches']})"
+print('   ', {k: round(v['us_avg'],1) for k,v in {n: {'us_avg': v[0], 'launches': v[1]} for n, v in r['per_kernel_us_avg_and_launches'].items()}.items() if v['launches']})"
 done

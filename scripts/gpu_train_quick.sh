@@ -10,4 +10,4 @@ timeout 600 python bench.py --workload train --steps 6 --warmup 2 --no-cpu-basel
 import json,sys
 d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}
 print('value', d['value'], d['unit'], 'ms/step', d['ms_per_step'])
-print({k: (round(v['us_avg'],1), v['launches']) for k,v in (r.get('per_kernel') or {}).items() if v['launches']})"
+print({k: (round(v['us_avg'],1), v['launches']) for k,v in {n: {'us_avg': v[0], 'launches': v[1]} for n, v in (r.get('per_kernel_us_avg_and_launches') or {}).items()}.items() if v['launches']})"

@@ -69,6 +69,16 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert abs(out["value"] - 2 * 20 * 5 / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]
 
 
+def test_bench_split_job_two_ranks_gloo():
+    """--split-job: ONE job's pockets dealt over the ranks (strong scaling, what sample.py:159's pocket loop gives a user who adds
+    GPUs): 5 pockets x 10 samples over two ranks = 3 + 2 pockets, 50 graphs in total, not 50 per rank"""
+    out = _run(["--gpus", "2", "--split-job", "--steps", "2", "--warmup", "1", "--pockets", "5", "--graphs-per-batch", "20",
+                "--no-cpu-baseline", "--no-roofline"], env={"CBGX_DIST_BACKEND": "gloo"})
+    assert out["ranks"] == 2 and out["config"]["ranks_seen"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["graphs_per_gpu"] == 30            # rank 0 holds pockets 0, 2, 4
+    assert abs(out["value"] - 50 * 5 / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]
+
+
 def test_bench_train_two_ranks_on_one_gpu_gloo():
     out = _run(["--gpus", "2", "--workload", "train", "--steps", "2", "--warmup", "1", "--pockets", "4",
                 "--no-cpu-baseline", "--no-roofline"], env={"CBGX_DIST_BACKEND": "gloo"})
