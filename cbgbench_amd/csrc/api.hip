@@ -729,7 +729,7 @@ int cbgx_diffsbdd_step(const float* x_den, const float* logits, const int32_t* g
                        int n_graphs, int num_classes, float inv_alpha, float coef, float sigma, int update_positions,
                        int update_types, const float* eps_x, const float* eps_c, const float* lig_emb_w,
                        const float* lig_emb_b, const float* ind_w, const float* ind_b, float* x_next, float* c_next,
-                       float* x, float* h, float* shift, void* stream) {
+                       float* x, float* h, float* shift, float* frame_shift, void* stream) {
     if (n_lig == 0 || n_graphs == 0) return CBGX_OK;
     if (n_lig < 0 || n_graphs < 0 || num_classes < 1 || num_classes > 32)
         return fail(CBGX_E_INVALID, "diffsbdd_step: bad sizes (n_lig=%d B=%d C=%d)", n_lig, n_graphs, num_classes);
@@ -738,7 +738,7 @@ int cbgx_diffsbdd_step(const float* x_den, const float* logits, const int32_t* g
         return fail(CBGX_E_INVALID, "diffsbdd_step: NULL pointer");
     HIP_TRY(launch_diffsbdd_step(x_den, logits, graph_ptr, lig_rows, lig_ptr, lig_flag, x_lig, c_lig, n_graphs, num_classes,
                                  inv_alpha, coef, sigma, update_positions, update_types, eps_x, eps_c, lig_emb_w, lig_emb_b, ind_w,
-                                 ind_b, x_next, c_next, x, h, shift, (hipStream_t)stream));
+                                 ind_b, x_next, c_next, x, h, shift, frame_shift, (hipStream_t)stream));
     return CBGX_OK;
 }
 

@@ -119,7 +119,7 @@ hipError_t launch_diffsbdd_step(const float* x_den, const float* logits, const i
                                 int n_graphs, int C, float inv_alpha, float coef, float sigma, int do_x, int do_c,
                                 const float* eps_x, const float* eps_c, const float* emb_w, const float* emb_b,
                                 const float* ind_w, const float* ind_b, float* x_next, float* c_next, float* x, float* h,
-                                float* shift_out, hipStream_t s);
+                                float* shift_out, float* frame, hipStream_t s);
 constexpr int PACK_MAX = 64;
 struct PackPiece {
     const float* src; float* dst; int src_ld, src_off, transpose, dst_ld, rows, cols;

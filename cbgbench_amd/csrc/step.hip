@@ -178,6 +178,12 @@ __global__ __launch_bounds__(64) void diffbp_epilogue_kernel(
 //   the host builds once with the scheduler's own expressions (cbgbench_amd/diffsbdd.py::step_tables).
 // Besides the next ligand state the kernel leaves the NEXT step's composed inputs in place: x[rows of the graph] (moved
 // pocket, new ligand positions) and h[ligand rows] = ligand_atom_emb(c) + ligand_indicator (context_emb.py:179-230).
+// FRAMED mode (`frame` != NULL, [B][3], in / out): the composed x stays in the POCKET'S OWN FRAME -- the pocket rows are never
+// touched, so the denoiser's static-context cache (its kNN lists, gate values and ligand-free layer-0/1 features) holds for all T
+// steps -- and the translation the reference applies to the pocket every step is carried as the per-graph sum S of the removed
+// means: true position = frame position - S.  The denoiser is translation-equivariant in x, so x_den (frame) - S is what the
+// reference's network call returns; the ligand state x_next is kept in TRUE coordinates (trajectory output), the composed ligand
+// rows get x_next + S_new = z_s + S_old.
 __global__ __launch_bounds__(64) void diffsbdd_step_kernel(
     const float* __restrict__ x_den, const float* __restrict__ logits, const int32_t* __restrict__ graph_ptr,
     const int32_t* __restrict__ lig_rows, const int32_t* __restrict__ lig_ptr, const uint8_t* __restrict__ lig_flag,
@@ -185,16 +191,18 @@ __global__ __launch_bounds__(64) void diffsbdd_step_kernel(
     int do_x, int do_c, const float* __restrict__ eps_x, const float* __restrict__ eps_c, const float* __restrict__ emb_w,
     const float* __restrict__ emb_b, const float* __restrict__ ind_w, const float* __restrict__ ind_b,
     float* __restrict__ x_next, float* __restrict__ c_next, float* __restrict__ x, float* __restrict__ h,
-    float* __restrict__ shift_out) {
+    float* __restrict__ shift_out, float* __restrict__ frame) {
     const int g = blockIdx.x, lane = threadIdx.x;
     const int a0 = lig_ptr[g], a1 = lig_ptr[g + 1];
     float sm[3] = {0.f, 0.f, 0.f};
+    float S[3] = {0.f, 0.f, 0.f};
+    if (frame) { S[0] = frame[3 * g]; S[1] = frame[3 * g + 1]; S[2] = frame[3 * g + 2]; }
     if (do_x) {
         for (int a = a0 + lane; a < a1; a += 64) {
             const int row = lig_rows[a];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const float zs = (x_lig[3 * a + k] * inv_alpha - coef * x_den[3 * row + k]) + sigma * eps_x[3 * a + k];
+                const float zs = (x_lig[3 * a + k] * inv_alpha - coef * (x_den[3 * row + k] - S[k])) + sigma * eps_x[3 * a + k];
                 x_next[3 * a + k] = zs;     // mean removed below
                 sm[k] += zs;
             }
@@ -205,6 +213,11 @@ __global__ __launch_bounds__(64) void diffsbdd_step_kernel(
 #pragma unroll
     for (int k = 0; k < 3; ++k) mean[k] = do_x ? wave_sum64(sm[k]) * inv : 0.f;
     if (lane < 3 && shift_out) shift_out[3 * g + lane] = mean[lane];
+    float Sn[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Sn[k] = S[k] + mean[k];
+    __syncthreads();     // (one wave) every lane has read frame[] before lanes 0..2 overwrite it
+    if (lane < 3 && frame) frame[3 * g + lane] = Sn[lane];
     // ligand atoms: centred positions, next types, and the composed rows of the next step
     for (int a = a0 + lane; a < a1; a += 64) {
         const int row = lig_rows[a];
@@ -212,15 +225,15 @@ __global__ __launch_bounds__(64) void diffsbdd_step_kernel(
         for (int k = 0; k < 3; ++k) {
             const float v = do_x ? x_next[3 * a + k] - mean[k] : x_lig[3 * a + k];
             x_next[3 * a + k] = v;
-            x[3 * row + k] = v;
+            x[3 * row + k] = v + Sn[k];      // (Sn = 0 without a frame)
         }
         for (int k = 0; k < C; ++k) {
             const float ck = c_lig[(size_t)a * C + k];
             c_next[(size_t)a * C + k] = do_c ? (ck * inv_alpha - coef * logits[(size_t)row * C + k]) + sigma * eps_c[(size_t)a * C + k] : ck;
         }
     }
-    // pocket atoms of this graph move with the ligand's centre of mass
-    if (do_x) {
+    // pocket atoms of this graph move with the ligand's centre of mass (framed mode: they stay, S carries the move)
+    if (do_x && !frame) {
         for (int row = graph_ptr[g] + lane; row < graph_ptr[g + 1]; row += 64)
             if (!lig_flag[row]) {
 #pragma unroll
@@ -277,11 +290,11 @@ hipError_t launch_diffsbdd_step(const float* x_den, const float* logits, const i
                                 int n_graphs, int C, float inv_alpha, float coef, float sigma, int do_x, int do_c,
                                 const float* eps_x, const float* eps_c, const float* emb_w, const float* emb_b,
                                 const float* ind_w, const float* ind_b, float* x_next, float* c_next, float* x, float* h,
-                                float* shift_out, hipStream_t s) {
+                                float* shift_out, float* frame, hipStream_t s) {
     if (n_graphs == 0) return hipSuccess;
     hipLaunchKernelGGL(diffsbdd_step_kernel, dim3(n_graphs), dim3(64), 0, s, x_den, logits, graph_ptr, lig_rows, lig_ptr,
                        lig_flag, x_lig, c_lig, C, inv_alpha, coef, sigma, do_x, do_c, eps_x, eps_c, emb_w, emb_b, ind_w, ind_b,
-                       x_next, c_next, x, h, shift_out);
+                       x_next, c_next, x, h, shift_out, frame);
     return hipGetLastError();
 }
 

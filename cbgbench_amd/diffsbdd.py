@@ -277,9 +277,14 @@ class DiffSBDD(BatchesInFlight, nn.Module):
         return {"pos": loss_pos, "atom": loss_atom}, results
 
     @torch.no_grad()
-    def begin_sampling(self, batch, keep_trajectory=True, noise_draws=None):
+    def begin_sampling(self, batch, keep_trajectory=True, noise_draws=None, static_cache=True):
         """Everything of ``sample`` (diffsbdd.py:240-319) before the loop: composition plan, protein features, the initial
-        zero-COM draws.  ``noise_draws`` (tests): the randn tensors in the reference's draw order, consumed across the steps."""
+        zero-COM draws.  ``noise_draws`` (tests): the randn tensors in the reference's draw order, consumed across the steps.
+        ``static_cache`` (native step only): keep the composed coordinates in the pocket's own frame -- the reference translates the
+        whole pocket by the ligand's new centre of mass every step (diffsbdd.py:296-304), a rigid motion that changes neither the
+        pocket's neighbour lists, nor its gate values, nor its ligand-free layer-0/1 features -- and carry the accumulated
+        translation per graph in ``st['frame']`` (true position = frame position - frame[graph]; the network is
+        translation-equivariant), so that the denoiser's static-context cache holds for all T steps as it does for TargetDiff."""
         sch = self.pos_scheduler
         x_rec = batch["protein_pos"].float()
         dev = x_rec.device
@@ -310,7 +315,7 @@ class DiffSBDD(BatchesInFlight, nn.Module):
         st = {"B": B, "N": n_rec + n_lig, "n_lig": n_lig, "x": x, "h": h, "x_lig": x_lig, "c_lig": c_lig, "x_rec": x_rec,
               "v_rec": v_rec, "bl": bl, "br": br, "batch_idx": batch_idx, "lig_flag": lig_flag, "gen_flag": gen_flag,
               "lig_rows": lig_rows, "rec_rows": rec_rows, "graph_ptr": graph_ptr, "nxt": nxt, "drawn": draws is not None,
-              "traj_x": None, "traj_c": None}
+              "traj_x": None, "traj_c": None, "static_h": None, "frame": None}
         if keep_trajectory:
             st["traj_x"] = torch.empty(T + 1, n_lig, 3, dtype=torch.float32, device=dev)
             st["traj_c"] = torch.empty(T + 1, n_lig, C, dtype=torch.float32, device=dev)
@@ -327,7 +332,19 @@ class DiffSBDD(BatchesInFlight, nn.Module):
             st["x_lig"], st["c_lig"] = x_lig.contiguous(), c_lig.contiguous()
             x[rec_rows], x[lig_rows] = x_rec, x_lig
             h[lig_rows] = self.context_embedder.embed_ligand(c_lig)
+            if static_cache and not bool(gen_r.any()):
+                st["static_h"] = self.denoiser.static_context(x_rec, h[rec_rows], br, rec_rows, n_rec + n_lig)
+                if st["static_h"] is not None:
+                    st["frame"] = torch.zeros(B, 3, dtype=torch.float32, device=dev)     # sum of the removed means so far
         return st
+
+    @staticmethod
+    def pocket_positions(st):
+        """the pocket atoms' TRUE positions (the reference's x_rec_0 after the steps taken so far)"""
+        if st.get("x_rec") is not None:
+            return st["x_rec"]
+        x_rec = st["x"][st["rec_rows"]]
+        return x_rec - st["frame"][st["br"]] if st.get("frame") is not None else x_rec
 
     def step_tables(self):
         """(1 / alpha_ts, sigma2_ts / alpha_ts / sigma_t, sigma_ts sigma_s / sigma_t) of every step s = k / T <- t = (k + 1) / T
@@ -347,8 +364,12 @@ class DiffSBDD(BatchesInFlight, nn.Module):
         x, h = st["x"], st["h"]
         if st.get("native"):   # x / h already hold the current state
             xo, _, logits = self.denoiser(x=x, h=h, batch_idx=st["batch_idx"], lig_flag=st["lig_flag"],
-                                          gen_flag=st["gen_flag"], graph_ptr=st["graph_ptr"], need_h=False)
-            return xo[st["lig_rows"]], logits[st["lig_rows"]]
+                                          gen_flag=st["gen_flag"], graph_ptr=st["graph_ptr"], need_h=False,
+                                          static_h=st.get("static_h"))
+            x_pred = xo[st["lig_rows"]]
+            if st.get("frame") is not None:       # the composed x lives in the pocket's frame: back to true coordinates
+                x_pred = x_pred - st["frame"][st["bl"]]
+            return x_pred, logits[st["lig_rows"]]
         x[st["rec_rows"]] = st["x_rec"]                                       # the pocket is translated every draw
         x[st["lig_rows"]] = st["x_lig"]
         h[st["lig_rows"]] = self.context_embedder.embed_ligand(st["c_lig"])
@@ -383,7 +404,7 @@ class DiffSBDD(BatchesInFlight, nn.Module):
         n_lig, C, B = st["n_lig"], self.num_classes, st["B"]
         x, h, x_lig, c_lig, nxt = st["x"], st["h"], st["x_lig"], st["c_lig"], st["nxt"]
         xo, _, logits = self.denoiser(x=x, h=h, batch_idx=st["batch_idx"], lig_flag=st["lig_flag"], gen_flag=st["gen_flag"],
-                                      graph_ptr=st["graph_ptr"], need_h=False)
+                                      graph_ptr=st["graph_ptr"], need_h=False, static_h=st.get("static_h"))
         eps_x = eps_c = None
         if self.denoise_structure:      # the reference's draw order: positions, then types
             eps_x = nxt()
@@ -403,7 +424,8 @@ class DiffSBDD(BatchesInFlight, nn.Module):
             inv_alpha, coef, sigma, int(self.denoise_structure), int(self.denoise_atom), _native.ptr(eps_x), _native.ptr(eps_c),
             _native.ptr(emb.ligand_atom_emb.weight), _native.ptr(emb.ligand_atom_emb.bias),
             _native.ptr(emb.ligand_indicator.weight), _native.ptr(emb.ligand_indicator.bias), _native.ptr(x_next),
-            _native.ptr(c_next), _native.ptr(x), _native.ptr(h), None, _native.current_stream(dev)), "cbgx_diffsbdd_step")
+            _native.ptr(c_next), _native.ptr(x), _native.ptr(h), None, _native.ptr(st.get("frame")),
+            _native.current_stream(dev)), "cbgx_diffsbdd_step")
         st["x_lig"], st["c_lig"] = x_next, c_next
         st["x_rec"] = None      # lives in x[rec_rows] now
         return st
@@ -418,7 +440,7 @@ class DiffSBDD(BatchesInFlight, nn.Module):
         sigma0 = torch.exp(0.5 * g0).unsqueeze(1)
         x_pred, c_out = self._denoise(st)
         if st["x_rec"] is None:
-            st["x_rec"] = st["x"][st["rec_rows"]]
+            st["x_rec"] = self.pocket_positions(st)
         sig_t = torch.sqrt(torch.sigmoid(g0)).view(-1, 1)
         alp_t = torch.sqrt(torch.sigmoid(-g0)).view(-1, 1)
         mu_x = 1.0 / alp_t[bl] * (st["x_lig"] - sig_t[bl] * x_pred)

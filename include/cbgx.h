@@ -53,7 +53,7 @@ extern "C" {
 
 /* 2: the packed-weight layout carries the power-of-two scales of the split-f16 tables (range-safe arithmetic, below); a blob
  * packed by a version-1 library is not understood by version 2 and vice versa -- re-pack with the library that consumes it. */
-#define CBGX_ABI_VERSION 2
+#define CBGX_ABI_VERSION 3
 
 #define CBGX_OK 0
 #define CBGX_E_INVALID (-1)   /* bad argument (shape, NULL pointer, unsupported hyper-parameter) */
@@ -223,7 +223,12 @@ int cbgx_targetdiff_epilogue_traj(const float *x_den, const float *logits, const
  *   the ligand's centre of mass removed and the pocket translated with it, and for types; diffusion_scheduler.py:1012-1040).
  *   inv_alpha, coef, sigma: 1 / alpha_ts, sigma2_ts / alpha_ts / sigma_t and sigma_ts sigma_s / sigma_t of the step.  Updates
  *   the composed x IN PLACE (pocket rows of every graph, ligand rows) and writes h on ligand rows from the new types, so
- *   that the next denoiser call needs no prologue; shift [B,3] (may be NULL) receives the removed mean per graph. */
+ *   that the next denoiser call needs no prologue; shift [B,3] (may be NULL) receives the removed mean per graph.
+ *   frame_shift [B,3] (in / out, may be NULL) selects the FRAMED mode: the pocket rows of x are left where they are (so the
+ *   static-context cache of cbgx_unitransformer_forward_cached holds for the whole run) and the translation the reference applies
+ *   to the pocket is accumulated in frame_shift instead: true position = position in x - frame_shift[graph].  x_den is then the
+ *   denoiser's output in the frame of x (the network is translation-equivariant), x_lig / x_next stay in true coordinates, the
+ *   ligand rows of x get x_next + frame_shift.  Start with frame_shift = 0. */
 int cbgx_diffbp_epilogue(const float *x_den, const float *x_com, const float *x_in, const float *logits,
                          const int32_t *lig_rows, const int32_t *lig_ptr, const float *x_lig, const float *c_lig,
                          const uint8_t *gen_lig, int n_lig, int n_graphs, int num_classes, int t, int num_timesteps,
@@ -234,7 +239,7 @@ int cbgx_diffsbdd_step(const float *x_den, const float *logits, const int32_t *g
                        int n_graphs, int num_classes, float inv_alpha, float coef, float sigma, int update_positions,
                        int update_types, const float *eps_x, const float *eps_c, const float *lig_emb_w,
                        const float *lig_emb_b, const float *ind_w, const float *ind_b, float *x_next, float *c_next,
-                       float *x, float *h, float *shift, void *stream);
+                       float *x, float *h, float *shift, float *frame_shift, void *stream);
 
 /* ---- training: taped forward and backward -----------------------------------------------------------
  * train.py:185-189 runs `loss_dict, _ = model(batch); loss.backward()`; autograd walks UniTransformer.forward

@@ -298,7 +298,7 @@ def test_native_step_kernels_match_the_torch_step(name):
         for k, t in enumerate((999, 998, 420)):
             m.denoise_step(st, t, noise[k]) if name == "diffbp" else m.denoise_step(st, t)
         # the pocket: never moves in DiffBP (protein rows of the composed x); translated every step in DiffSBDD
-        x_rec = st["x"][~st["lig_flag"]] if (native or name == "diffbp") else st["x_rec"]
+        x_rec = st["x"][~st["lig_flag"]] if name == "diffbp" else m.pocket_positions(st)
         outs.append((st["x_lig"].clone(), st["c_lig"].clone(), x_rec.clone()))
     (xa, ca, ra), (xb, cb, rb) = outs
     assert float((xa - xb).abs().max()) <= 2e-6 * max(1.0, float(xb.abs().max())), float((xa - xb).abs().max())
@@ -454,3 +454,35 @@ def test_targetdiff_rollout_200_steps_real_pocket(synthetic_sd):
             assert bool((err <= 5e-4 + 1e-4 * x.double().abs()).all()), (k, t, float(err.max()))
     print(f"200-step roll-out: max |x - x_oracle| = {worst:.3e}; near-tie re-synchronisations: {resyncs}")
     assert len(resyncs) <= 2, resyncs
+
+
+def test_diffsbdd_pocket_frame_equals_moving_pocket():
+    """DiffSBDD with the composed coordinates kept in the pocket's own frame (static-context cache on, the default of the native
+    step: cbgx_diffsbdd_step frame_shift) against the same native step with the pocket translated in place every step
+    (static_cache=False; diffsbdd.py:296-304 literally): 12 free-running steps on real-size pockets, shared Gaussian draws.
+    The two differ by fp32 rounding of a translation (|S| <~ a few Angstrom on coordinates of O(10)): ligand positions, type
+    features and the pocket's true positions within 2e-5 absolute + 1e-5 relative."""
+    Cn = 8
+    m = C.get_model(C.default_diffsbdd_config(Cn)).eval()
+    m.load_state_dict(W.synthetic_state_dict_diffsbdd(Cn, 9, seed=0, num_timesteps=1000), strict=True)
+    m = m.to(DEV)
+    batch = synthetic.batch_to(synthetic.denovo_batch(4, seed=53, num_classes=Cn), DEV)
+    n_lig = batch["ligand_pos"].shape[0]
+    g = torch.Generator(device=DEV).manual_seed(10)
+    steps = list(range(999, 993, -1)) + list(range(5, -1, -1))
+    draws = [torch.randn(n_lig, k, device=DEV, generator=g) for _ in range(len(steps) + 1) for k in (3, Cn)]
+    outs = []
+    for cache in (True, False):
+        st = m.begin_sampling(batch, keep_trajectory=False, noise_draws=[d.clone() for d in draws], static_cache=cache)
+        assert st["native"] and (st["frame"] is not None) == cache and (st["static_h"] is not None) == cache
+        for t in steps:
+            m.denoise_step(st, t)
+        outs.append((st["x_lig"].clone(), st["c_lig"].clone(), m.pocket_positions(st).clone()))
+    for a, b, what in zip(outs[0], outs[1], ("x_lig", "c_lig", "x_rec")):
+        err = (a.double() - b.double()).abs()
+        assert bool((err <= 2e-5 + 1e-5 * b.double().abs()).all()), (what, float(err.max()))
+    # the pocket has really moved (the frame carries it): the true positions differ from the frame's by the accumulated shift
+    st = m.begin_sampling(batch, keep_trajectory=False, noise_draws=[d.clone() for d in draws])
+    p0 = m.pocket_positions(st).clone()
+    m.denoise_step(st, 999)
+    assert float((m.pocket_positions(st) - p0).abs().max()) > 1e-3 and torch.equal(st["x"][st["rec_rows"]], p0)
