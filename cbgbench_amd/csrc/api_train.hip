@@ -181,7 +181,7 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
             HIP_TRY(launch_node_query_v1(att, w.P, w.Qt, n, s));
         } else
 #endif
-            HIP_TRY(launch_node_mfma(att, h_in, lig, n, w.P, w.qs, w.Qt, rows, n_rows, nullptr, nullptr, s));
+            HIP_TRY(launch_node_mfma(att, h_in, lig, n, w.P, w.qs, w.Qt, rows, n_rows, nullptr, nullptr, s, x2h));
     }
     if (x2h) HIP_TRY(launch_fold_grad(att, g_out, n, w.Gt, w.gb, s));
     HIP_TRY(hipMemsetAsync(w.dP, 0, (size_t)n * PROW * sizeof(float), s));

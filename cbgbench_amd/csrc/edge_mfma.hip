@@ -692,6 +692,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 // the general one; the split follows the list lengths (device-side counts; a general node is priced at 1.3 protein-only ones:
 // mixed neighbourhoods run both source-class passes and read 8 KB of Qt) in multiples of 8 workgroups, so that a role's
 // workgroup index modulo 8 is still its XCD.  One launch per layer, one LDS fill per workgroup, both lists' tails overlap.
+#ifndef CBGX_DUAL_GEN_COST
+#define CBGX_DUAL_GEN_COST 1.3f       // (an A/B knob of scripts/build_variant.py; the product build uses this value)
+#endif
+constexpr float DUAL_GEN_COST = CBGX_DUAL_GEN_COST;
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void edge_x2h_dual_kernel(
     const float* __restrict__ att, const float* __restrict__ x, const float* __restrict__ h,
@@ -708,7 +712,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_x2h_dual_kernel(
     if (c_gen == 0) n_pp_wg = n_wg;
     else if (c_pp == 0) n_pp_wg = 0;
     else {
-        const float share = (float)c_pp / ((float)c_pp + 1.3f * (float)c_gen);
+        const float share = (float)c_pp / ((float)c_pp + DUAL_GEN_COST * (float)c_gen);
         const int unit = n_wg >= 64 ? 8 : 1;
         n_pp_wg = (int)(share * (float)(n_wg / unit) + 0.5f) * unit;
         n_pp_wg = max(unit, min(n_wg - unit, n_pp_wg));

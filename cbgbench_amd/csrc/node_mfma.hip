@@ -931,6 +931,9 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
     };
     // Small inputs (n_nodes bounds a work list's length too): ONE launch does projection (own columns, or all of them when
     // every node is a destination), query MLP and query fold -- such launches are bound by kernel boundaries, not throughput.
+    // (A short destination list on a LARGE input -- the h2x blocks, ~5 k movable atoms of a 99.5 k-node batch -- stays on the
+    // three-kernel chain: the fused kernel was measured there in round 4, 40 us against 10 + 8 + 12: its 16-wave workgroups, one
+    // per CU, need two rounds for 313 row tiles.)
     const bool fused = n_nodes <= NODE_STAGE_MAX_ROWS;
     profile_mark_begin(K_NODE_GEMM, s);
     // fused with a destination list: the source rows' PS columns are the second job of the node_stage_kernel launch below

@@ -51,7 +51,7 @@ class ChunkedOracle:
     chunk can be re-evaluated with ONE identified unit forced to the other side of zero."""
 
     def __init__(self, B, chunk, run):
-        from test_gpu_training import relu_margins
+        from tests.relu_flip import relu_margins
         self._margins = relu_margins
         self.run, self.chunks = run, [(g0, min(g0 + chunk, B)) for g0 in range(0, B, chunk)]
         self.losses, self.per_chunk, self.near = {}, [], []
@@ -415,8 +415,8 @@ def test_targetdiff_rollout_200_steps_real_pocket(synthetic_sd):
     So the test asserts, at every step, identical types AND positions within tolerance -- unless the oracle itself says the
     differing atoms' draws were near-ties (gap < 1e-3 in log space), in which case the step and the gaps are REPORTED, the GPU
     state is re-synchronised with the oracle's and the roll-out continues; at most two such events are accepted.
-    Position tolerance: 5e-4 absolute + 1e-4 relative (the 24-step test holds 1e-4; the measured maximum is printed and
-    recorded in profiles/parity_errors_r04.md)."""
+    Position tolerance: 1e-5 absolute + 1e-5 relative = 3 x the measured maximum (3.3e-6 over the 200 steps, no
+    re-synchronisation needed: profiles/pytest_gpu_r04d.log)."""
     _oracle_threads()
     T = 1000
     m = C.get_model(C.default_targetdiff_config(13)).eval()
@@ -451,7 +451,7 @@ def test_targetdiff_rollout_200_steps_real_pocket(synthetic_sd):
                 st["x_lig"], st["c_lig"] = x.to(DEV).contiguous(), c.to(DEV).contiguous()
                 continue
             worst = max(worst, float(err.max()))
-            assert bool((err <= 5e-4 + 1e-4 * x.double().abs()).all()), (k, t, float(err.max()))
+            assert bool((err <= 1e-5 + 1e-5 * x.double().abs()).all()), (k, t, float(err.max()))
     print(f"200-step roll-out: max |x - x_oracle| = {worst:.3e}; near-tie re-synchronisations: {resyncs}")
     assert len(resyncs) <= 2, resyncs
 
@@ -459,9 +459,15 @@ def test_targetdiff_rollout_200_steps_real_pocket(synthetic_sd):
 def test_diffsbdd_pocket_frame_equals_moving_pocket():
     """DiffSBDD with the composed coordinates kept in the pocket's own frame (static-context cache on, the default of the native
     step: cbgx_diffsbdd_step frame_shift) against the same native step with the pocket translated in place every step
-    (static_cache=False; diffsbdd.py:296-304 literally): 12 free-running steps on real-size pockets, shared Gaussian draws.
-    The two differ by fp32 rounding of a translation (|S| <~ a few Angstrom on coordinates of O(10)): ligand positions, type
-    features and the pocket's true positions within 2e-5 absolute + 1e-5 relative."""
+    (static_cache=False; diffsbdd.py:296-304 literally): free-running steps on real-size pockets, shared Gaussian draws.
+    The two evaluate the network on coordinates that differ by a translation, i.e. by fp32 rounding -- and the network is NOT
+    continuous in its coordinates: a kNN graph keeps the 32 nearest atoms, so a 1e-7 relative change of two nearly equal
+    distances can swap the 32nd neighbour of a node (expected once per ~1e4 neighbour selections; measured here: the first swap
+    within a few steps of a 2 000-atom batch), after which the two runs are different, equally valid roll-outs that drift apart at
+    the 1e-3 level.  So the test compares the neighbour lists of the two runs at every step: as long as they are identical the
+    states must agree within 2e-5 absolute + 1e-5 relative (ligand positions, type features, true pocket positions); from the first
+    swap on only a sanity bound (5e-2) is asserted.  At least the first two steps must be swap-free for the test to count."""
+    from cbgbench_amd import stages
     Cn = 8
     m = C.get_model(C.default_diffsbdd_config(Cn)).eval()
     m.load_state_dict(W.synthetic_state_dict_diffsbdd(Cn, 9, seed=0, num_timesteps=1000), strict=True)
@@ -471,18 +477,28 @@ def test_diffsbdd_pocket_frame_equals_moving_pocket():
     g = torch.Generator(device=DEV).manual_seed(10)
     steps = list(range(999, 993, -1)) + list(range(5, -1, -1))
     draws = [torch.randn(n_lig, k, device=DEV, generator=g) for _ in range(len(steps) + 1) for k in (3, Cn)]
-    outs = []
-    for cache in (True, False):
-        st = m.begin_sampling(batch, keep_trajectory=False, noise_draws=[d.clone() for d in draws], static_cache=cache)
-        assert st["native"] and (st["frame"] is not None) == cache and (st["static_h"] is not None) == cache
-        for t in steps:
-            m.denoise_step(st, t)
-        outs.append((st["x_lig"].clone(), st["c_lig"].clone(), m.pocket_positions(st).clone()))
-    for a, b, what in zip(outs[0], outs[1], ("x_lig", "c_lig", "x_rec")):
-        err = (a.double() - b.double()).abs()
-        assert bool((err <= 2e-5 + 1e-5 * b.double().abs()).all()), (what, float(err.max()))
-    # the pocket has really moved (the frame carries it): the true positions differ from the frame's by the accumulated shift
-    st = m.begin_sampling(batch, keep_trajectory=False, noise_draws=[d.clone() for d in draws])
-    p0 = m.pocket_positions(st).clone()
-    m.denoise_step(st, 999)
-    assert float((m.pocket_positions(st) - p0).abs().max()) > 1e-3 and torch.equal(st["x"][st["rec_rows"]], p0)
+    sa = m.begin_sampling(batch, keep_trajectory=False, noise_draws=[d.clone() for d in draws], static_cache=True)
+    sb = m.begin_sampling(batch, keep_trajectory=False, noise_draws=[d.clone() for d in draws], static_cache=False)
+    assert sa["native"] and sa["frame"] is not None and sa["static_h"] is not None
+    assert sb["native"] and sb["frame"] is None and sb["static_h"] is None
+    p0 = m.pocket_positions(sa).clone()
+    gptr = sa["graph_ptr"].to(torch.int32).contiguous()
+    tight_steps, swapped = 0, False
+    for t in steps:
+        # the graphs the two denoiser calls of this step are about to build
+        na, _ = stages.knn_graph(sa["x"].contiguous(), gptr)
+        nb, _ = stages.knn_graph(sb["x"].contiguous(), gptr)
+        swapped = swapped or not torch.equal(na.sort(dim=1).values, nb.sort(dim=1).values)
+        m.denoise_step(sa, t)
+        m.denoise_step(sb, t)
+        for a, b, what in ((sa["x_lig"], sb["x_lig"], "x_lig"), (sa["c_lig"], sb["c_lig"], "c_lig"),
+                           (m.pocket_positions(sa), m.pocket_positions(sb), "x_rec")):
+            err = (a.double() - b.double()).abs()
+            if not swapped:
+                assert bool((err <= 2e-5 + 1e-5 * b.double().abs()).all()), (t, what, float(err.max()))
+            assert float(err.max()) < 5e-2, (t, what, float(err.max()))
+        tight_steps += not swapped
+    print(f"pocket frame vs moving pocket: {tight_steps} of {len(steps)} steps before the first neighbour swap")
+    assert tight_steps >= 2
+    # the pocket has really moved (the frame carries it) while its rows in the composed x never changed
+    assert float((m.pocket_positions(sa) - p0).abs().max()) > 1e-3 and torch.equal(sa["x"][sa["rec_rows"]], p0)
