@@ -6,9 +6,10 @@
 
 Workload = the whole BASELINE.json configs[1] job ("configs/denovo, 100 pockets x 10 samples each, 1000 steps, fp32,
 1 MI355X"): 100 distinct pockets x 10 samples of each (sample.py:177 replicates one pocket num_samples times) = 1000
-pocket+ligand graphs (~5.3e5 nodes, 1.7e7 edges) resident in HBM as --graphs-per-batch sized batches (default 200
-graphs = 20 pockets x 10 samples: independent pockets are batched together because one pocket's 10 graphs cannot fill
-256 CUs).  A reverse-diffusion step of a batch = ligand embedding + pocket/ligand composition + the 9-layer equivariant
+pocket+ligand graphs (~5.3e5 nodes, 1.7e7 edges) resident in HBM as --graphs-per-batch sized batches (default 340
+graphs = 34 pockets x 10 samples: three batches, all in flight on three streams; independent pockets are batched together because
+one pocket's 10 graphs cannot fill 256 CUs; round 4 sweep: 200 / 250 / 340 / 500 graphs per batch = 28.26 / 28.24 / 28.49 / 27.80 k
+graph-steps/s, profiles/sweep_r04e.log).  A reverse-diffusion step of a batch = ligand embedding + pocket/ligand composition + the 9-layer equivariant
 denoiser in libcbgx + position/type posterior sampling + trajectory store.  One bench "step" advances the WHOLE job
 (all batches) by one reverse-diffusion step at each of the five time blocks t = 999-i, 749-i, 499-i, 249-i, 24-(i mod 25)
 (the network has no time input in the shipped configs; t selects the posterior coefficients and the noise scale, down
@@ -408,8 +409,9 @@ def parse_args(argv=None):
     ap.add_argument("--pockets", type=int, default=None,
                     help="distinct pockets of the job per GPU (default 100 -> 1000 graphs; linker: 256 graphs; train: 32 graphs)")
     ap.add_argument("--samples", type=int, default=10, help="samples (graphs) per pocket")
-    ap.add_argument("--graphs-per-batch", type=int, default=200,
-                    help="graphs per resident batch (whole pockets; default 200 = 20 pockets x 10 samples, ~100 k nodes)")
+    ap.add_argument("--graphs-per-batch", type=int, default=340,
+                    help="graphs per resident batch (whole pockets; default 340 = 34 pockets x 10 samples, ~170 k nodes: the "
+                         "1000-graph job as three batches)")
     ap.add_argument("--workload", choices=["denovo", "linker", "train"], default="denovo",
                     help="denovo = BASELINE configs[1] (default); linker = configs[2]: --pockets distinct pockets, one "
                          "graph each, fixed context atoms + a few generated linker atoms (partial gen_flag); train = "
@@ -470,7 +472,7 @@ def main():
     if args.pockets is None:
         args.pockets = {"train": 32, "linker": 256}.get(args.workload, 100)
     primary_default = (args.workload == "denovo" and args.model == "targetdiff" and args.pockets == 100 and args.samples == 10
-                       and args.graphs_per_batch == 200 and args.graph == "off")
+                       and args.graphs_per_batch == 340 and args.graph == "off")
     out = bench_train(args, rank, world, dev) if args.workload == "train" else bench_sampling(args, rank, world, dev)
     out["n_gpus"] = n_dev
     if n_dev != world:

@@ -61,20 +61,23 @@ struct Workspace {
     float* q3;
     int* act;        // indices of gen_flag nodes (h2x work list)
     int* act_count;
-    uint8_t* mask;   // receptive-field pruning: reachability mask and the three node lists derived from it
-    int* rf_list[3];
+    int* rf_list[3]; // receptive-field pruning: A1, A2, A3
     int* rf_count;   // [3], 64 B apart
-    uint8_t* fmask[2];   // static-context cache: "differs from the ligand-free pocket" masks (ping-pong)
-    int* fw_list[4];     // D1, S1 = D1 | nbr(D1), D2, S2
+    int* fw_list[4];     // static-context cache: D1, S1 = D1 | nbr(D1), D2, S2
     int* fw_count;       // [4], 64 B apart
+    // per-node flags behind the lists (node_mfma.hip, list_level_kernel), zeroed with the counters by ONE fill per forward call:
+    // receptive-field sets a1 a2 a3; "differs from the ligand-free pocket" D1 (proximity flags of the graph cache) D2 S1 S2; d1flag
+    uint8_t *fa1, *fa2, *fa3, *fD1, *fD2, *fS1, *fS2;
     float* hbuf[2];
     float* xbuf[2];
     // x2h layers run as ONE launch over two work lists (edge_mfma.hip, edge_x2h_dual_kernel): destinations with a ligand atom among
     // themselves and their neighbours (d1flag; general role, folded query from Qt) and protein-only ones (query folded in registers)
-    uint8_t* d1flag;
+    uint8_t* d1flag;     // the node or one of its neighbours is a ligand atom: general role of the x2h edge stage
     int* sp_list[4][2];  // [all nodes | cached layer 1 (D2) | pruned A1 | pruned A2][1 = general, 0 = protein-only]
     int* sp_count;       // per set one 128-byte region: general count at +0, protein-only count at +64 bytes
     int* zero_count;     // an always-empty list's count
+    void* counters;      // flags + act_count, rf_count, fw_count, sp_count, zero_count are carved from ONE block: one fill per call
+    size_t counters_bytes;
     size_t total;
 };
 
@@ -97,22 +100,31 @@ static Workspace carve(void* base, int n) {
     w.Qt3 = (float*)take(N * HEADS * H * 4);
     w.q3 = (float*)take(N * H * 4);
     w.act = (int*)take(N * 4);
-    w.act_count = (int*)take(256);
-    w.mask = (uint8_t*)take(N);
+    w.act_count = nullptr;       // (carved from the counter block below)
     for (int k = 0; k < 3; ++k) w.rf_list[k] = (int*)take(N * 4);
-    w.rf_count = (int*)take(256);
-    w.fmask[0] = (uint8_t*)take(N);
-    w.fmask[1] = (uint8_t*)take(N);
+    w.rf_count = nullptr;
     for (int k = 0; k < 4; ++k) w.fw_list[k] = (int*)take(N * 4);
-    w.fw_count = (int*)take(256);
+    w.fw_count = nullptr;
     w.hbuf[0] = (float*)take(N * H * 4);
     w.hbuf[1] = (float*)take(N * H * 4);
     w.xbuf[0] = (float*)take(N * 3 * 4);
     w.xbuf[1] = (float*)take(N * 3 * 4);
-    w.d1flag = (uint8_t*)take(N);
     for (int k = 0; k < 4; ++k) { w.sp_list[k][1] = (int*)take(N * 4); w.sp_list[k][0] = (int*)take(N * 4); }
-    w.sp_count = (int*)take(4 * 128);
-    w.zero_count = (int*)take(256);
+    {
+        // every device-side list count of a forward call, 64 bytes apart (a counter word is hammered by returning atomics)
+        const size_t fl = align_up(N);
+        w.counters_bytes = 8 * fl + 256 + 256 + 256 + 4 * 128 + 256;
+        char* c = take(w.counters_bytes);
+        w.counters = c;
+        w.d1flag = (uint8_t*)c; w.fa1 = w.d1flag + fl; w.fa2 = w.fa1 + fl; w.fa3 = w.fa2 + fl;
+        w.fD1 = w.fa3 + fl; w.fD2 = w.fD1 + fl; w.fS1 = w.fD2 + fl; w.fS2 = w.fS1 + fl;
+        c += 8 * fl;
+        w.act_count = (int*)c;
+        w.rf_count = (int*)(c + 256);
+        w.fw_count = (int*)(c + 512);
+        w.sp_count = (int*)(c + 768);
+        w.zero_count = (int*)(c + 768 + 4 * 128);
+    }
     w.total = off;
     return w;
 }
@@ -419,9 +431,10 @@ int cbgx_edge_gate(const float* packed, const float* x, const int32_t* nbr, cons
 }
 
 // (general, protein-only) list pair `set` of the workspace from a destination list (NULL = all nodes) and the d1 flags
-static int split_by_d1(const Workspace& w, int set, const int* list, const int* count, int n_nodes, hipStream_t s) {
+static int split_by_d1(const Workspace& w, int set, const int* list, const int* count, int n_nodes, hipStream_t s,
+                       bool counters_zeroed = false) {
     HIP_TRY(launch_split_list(list, count, n_nodes, w.d1flag, w.sp_list[set][1], w.sp_count + 32 * set, w.sp_list[set][0],
-                              w.sp_count + 32 * set + 16, s));
+                              w.sp_count + 32 * set + 16, s, counters_zeroed));
     return CBGX_OK;
 }
 
@@ -499,68 +512,73 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
     if (workspace_bytes < w.total)
         return fail(CBGX_E_WORKSPACE, "forward: workspace %zu < %zu", workspace_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(w.counters, 0, w.counters_bytes, s));      // every list count of this call: one fill instead of ~15
     const bool cached = static_h1 && static_h2 && num_layers >= 4;
     // with the graph part of the cache, only the nodes that have a ligand atom within reach get a fresh neighbour list
     // and gate: everything else about the pocket's own graph was computed once (same order, same bits)
     const bool graph_cached = cached && static_nbr && static_deg && static_ew && static_r32sq && g_edge_impl != 1;
+    // H2X only ever moves gen_flag nodes (x_out = x + dx * gen_flag): they are listed once (`act`), every h2x block runs on the list.
+    // Receptive-field pruning (only when the caller does not ask for h_out): the outputs that remain are x_out and the
+    // logits of ligand rows, so the last x2h blocks only have to produce features that can still reach them:
+    //   A1 = gen | lig | nbr(gen)      destinations of the last x2h (classifier rows, the last h2x's own + source rows)
+    //   A2 = A1 | nbr(A1)              its sources = destinations of the x2h before it;   A3 = A2 | nbr(A2) its sources
+    // Rows outside these sets are simply not written in the last two feature buffers (and never read).  A1 is built in every
+    // call: it is also the set of possible *sources* of an H2X block, so the h2x node projection PS is produced for those rows only.
+    const bool prune = (h_out == nullptr) && num_layers >= 3;
+    // Static-context cache (optional): static_h1 / static_h2 [N,128] hold the features that leave layer 0 / layer 1 in
+    // the ligand-free pocket (rows of ligand atoms unused).  A protein node with no ligand atom among its neighbours sees
+    // exactly that pocket in layer 0, so its output is the cached row; the set that differs grows by one hop per layer:
+    //   D1 = lig | {i : nbr(i) has a ligand atom},   D2 = D1 | {i : nbr(i) meets D1};   sources S_k = D_k | nbr(D_k).
+    // Layers 0 and 1 then run on D1 / D2 only, every other row of their output is a copy of the cache.
+    // x2h layers run their (general, protein-only) list pairs: d1flag = the node or one of its neighbours is a ligand atom, from
+    // the neighbour lists this call works with.  Set 0 all nodes, 1 the cached layer 1 (D2), 2 / 3 the pruned layers (A1 / A2).
+    const bool dual = g_edge_impl != 1;
+    GraphFlags gf{gen_flag, lig_flag, graph_cached ? w.fD1 : w.d1flag, w.d1flag, w.fa1, w.fa2, w.fa3, w.fD2, w.fS1, w.fS2};
     if (graph_cached) {
-        HIP_TRY(launch_lig_proximity(x, graph_ptr, n_graphs, lig_flag, static_r32sq, n_nodes, w.fmask[0], s));   // D1
-        HIP_TRY(launch_build_active(w.fmask[0], n_nodes, w.fw_list[0], w.fw_count, s));
-        HIP_TRY(hipMemcpyAsync(w.nbr, static_nbr, (size_t)n_nodes * KNN * 4, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipMemcpyAsync(w.deg, static_deg, (size_t)n_nodes * 4, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipMemcpyAsync(w.e_w, static_ew, (size_t)n_nodes * KNN * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(launch_lig_proximity(x, graph_ptr, n_graphs, lig_flag, static_r32sq, n_nodes, w.fD1, s));   // D1
+        HIP_TRY(launch_build_active(w.fD1, n_nodes, w.fw_list[0], w.fw_count, s, true));
+        HIP_TRY(launch_restore_graph(static_nbr, static_deg, static_ew, n_nodes, w.nbr, w.deg, w.e_w, s));
         HIP_TRY(launch_knn_reg(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s, w.fw_list[0], w.fw_count));
         HIP_TRY(launch_gate_mfma(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s, w.fw_list[0], w.fw_count));
     } else {
         HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s));
         HIP_TRY(launch_gate(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s));
     }
-    // H2X only ever moves gen_flag nodes (x_out = x + dx * gen_flag): list them once, run every h2x block on the list
-    HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, s));
-    // Receptive-field pruning (only when the caller does not ask for h_out): the outputs that remain are x_out and the
-    // logits of ligand rows, so the last x2h blocks only have to produce features that can still reach them:
-    //   A1 = gen | lig | nbr(gen)      destinations of the last x2h (classifier rows, the last h2x's own + source rows)
-    //   A2 = A1 | nbr(A1)              its sources = destinations of the x2h before it;   A3 = A2 | nbr(A2) its sources
-    // Rows outside these sets are simply not written in the last two feature buffers (and never read).
-    const bool prune = (h_out == nullptr) && num_layers >= 3;
-    // A1 is built in every call: it is also the set of possible *sources* of an H2X block (gen | nbr(gen), plus the
-    // non-generated ligand rows), so the h2x node projection PS is produced for those rows only.
-    HIP_TRY(launch_mark_seed(gen_flag, lig_flag, n_nodes, w.mask, s));
-    HIP_TRY(launch_mark_nbr(w.act, w.act_count, n_nodes, w.nbr, w.deg, w.mask, s));
-    HIP_TRY(launch_build_active(w.mask, n_nodes, w.rf_list[0], w.rf_count, s));
-    if (prune) {
-        for (int k = 1; k < 3; ++k) {
-            HIP_TRY(launch_mark_nbr(w.rf_list[k - 1], w.rf_count + 16 * (k - 1), n_nodes, w.nbr, w.deg, w.mask, s));
-            HIP_TRY(launch_build_active(w.mask, n_nodes, w.rf_list[k], w.rf_count + 16 * k, s));
-        }
+    // every list of the call: three level kernels over the flags (a level reads what the previous one completed), one compaction
+    HIP_TRY(launch_list_level(gf, w.nbr, w.deg, n_nodes, 0, cached, prune, s));
+    if (cached || prune) {
+        HIP_TRY(launch_list_level(gf, w.nbr, w.deg, n_nodes, 1, cached, prune, s));
+        HIP_TRY(launch_list_level(gf, w.nbr, w.deg, n_nodes, 2, cached, prune, s));
     }
-    // Static-context cache (optional): static_h1 / static_h2 [N,128] hold the features that leave layer 0 / layer 1 in
-    // the ligand-free pocket (rows of ligand atoms unused).  A protein node with no ligand atom among its neighbours sees
-    // exactly that pocket in layer 0, so its output is the cached row; the set that differs grows by one hop per layer:
-    //   D1 = lig | {i : nbr(i) has a ligand atom},   D2 = D1 | {i : nbr(i) meets D1};   sources S_k = D_k | nbr(D_k).
-    // Layers 0 and 1 then run on D1 / D2 only, every other row of their output is a copy of the cache.
-    if (cached) {
-        if (!graph_cached) {
-            HIP_TRY(launch_mark_from_nbr(lig_flag, w.nbr, w.deg, n_nodes, w.fmask[0], s));                   // D1
-            HIP_TRY(launch_build_active(w.fmask[0], n_nodes, w.fw_list[0], w.fw_count, s));
+    {
+        ListJobs jobs;
+        memset(&jobs, 0, sizeof(jobs));
+        auto add = [&](const uint8_t* f, const uint8_t* f2, int want2, int* list, int* count) {
+            const int k = jobs.n_jobs++;
+            jobs.flag[k] = f; jobs.flag2[k] = f2; jobs.want2[k] = want2; jobs.list[k] = list; jobs.count[k] = count;
+        };
+        add(gen_flag, nullptr, 0, w.act, w.act_count);
+        add(w.fa1, nullptr, 0, w.rf_list[0], w.rf_count);
+        if (prune) {
+            add(w.fa2, nullptr, 0, w.rf_list[1], w.rf_count + 16);
+            add(w.fa3, nullptr, 0, w.rf_list[2], w.rf_count + 32);
         }
-        HIP_TRY(launch_mark_from_nbr(w.fmask[0], w.nbr, w.deg, n_nodes, w.fmask[1], s));                    // D2
-        HIP_TRY(launch_build_active(w.fmask[1], n_nodes, w.fw_list[2], w.fw_count + 32, s));
-        HIP_TRY(launch_mark_nbr(w.fw_list[0], w.fw_count, n_nodes, w.nbr, w.deg, w.fmask[0], s));           // S1
-        HIP_TRY(launch_build_active(w.fmask[0], n_nodes, w.fw_list[1], w.fw_count + 16, s));
-        HIP_TRY(launch_mark_nbr(w.fw_list[2], w.fw_count + 32, n_nodes, w.nbr, w.deg, w.fmask[1], s));      // S2
-        HIP_TRY(launch_build_active(w.fmask[1], n_nodes, w.fw_list[3], w.fw_count + 48, s));
-    }
-    // (general, protein-only) list pairs of the x2h layers, from the neighbour lists this call works with: d1flag = the node or
-    // one of its neighbours is a ligand atom.  Set 0 all nodes, 1 the cached layer 1 (D2), 2 / 3 the pruned layers (A1 / A2).
-    const bool dual = g_edge_impl != 1;
-    if (dual) {
-        HIP_TRY(launch_mark_from_nbr(lig_flag, w.nbr, w.deg, n_nodes, w.d1flag, s));
-        HIP_TRY(hipMemsetAsync(w.zero_count, 0, sizeof(int), s));
-        { int rc = split_by_d1(w, 0, nullptr, nullptr, n_nodes, s); if (rc) return rc; }
-        if (cached) { int rc = split_by_d1(w, 1, w.fw_list[2], w.fw_count + 32, n_nodes, s); if (rc) return rc; }
-        if (prune)
-            for (int k = 0; k < 2; ++k) { int rc = split_by_d1(w, 2 + k, w.rf_list[k], w.rf_count + 16 * k, n_nodes, s); if (rc) return rc; }
+        if (cached) {
+            if (!graph_cached) add(w.d1flag, nullptr, 0, w.fw_list[0], w.fw_count);
+            add(w.fD2, nullptr, 0, w.fw_list[2], w.fw_count + 32);
+            add(w.fS1, nullptr, 0, w.fw_list[1], w.fw_count + 16);
+            add(w.fS2, nullptr, 0, w.fw_list[3], w.fw_count + 48);
+        }
+        if (dual) {
+            auto pair = [&](int set, const uint8_t* f) {
+                add(f, w.d1flag, 1, w.sp_list[set][1], w.sp_count + 32 * set);
+                add(f, w.d1flag, 0, w.sp_list[set][0], w.sp_count + 32 * set + 16);
+            };
+            pair(0, nullptr);
+            if (cached) pair(1, w.fD2);
+            if (prune) { pair(2, w.fa1); pair(3, w.fa2); }
+        }
+        HIP_TRY(launch_build_lists(jobs, n_nodes, s));
     }
     struct X2HLists { const int *gen, *gen_n, *pp, *pp_n; bool full; };
     auto x2h_lists = [&](int l) {

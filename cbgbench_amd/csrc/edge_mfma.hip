@@ -689,11 +689,12 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
 // x2h over TWO work lists in one launch: the protein-only destinations (`list_pp`: the node and all its neighbours are protein
 // atoms; query folded in registers from q[N,128]) and the rest (`list_gen`: general kernel, folded rows from Qt[N,16,128], which
 // node_qfold_kernel has produced for THESE nodes only).  The first `n_pp_wg` workgroups play the protein-only role, the others
-// the general one; the split follows the list lengths (device-side counts; a general node is priced at 1.3 protein-only ones:
+// the general one; the split follows the list lengths (device-side counts; a general node is priced at 1.15 protein-only ones:
 // mixed neighbourhoods run both source-class passes and read 8 KB of Qt) in multiples of 8 workgroups, so that a role's
 // workgroup index modulo 8 is still its XCD.  One launch per layer, one LDS fill per workgroup, both lists' tails overlap.
 #ifndef CBGX_DUAL_GEN_COST
-#define CBGX_DUAL_GEN_COST 1.3f       // (an A/B knob of scripts/build_variant.py; the product build uses this value)
+#define CBGX_DUAL_GEN_COST 1.15f      // (an A/B knob of scripts/build_variant.py; the product build uses this value:
+                                      //  1.0 / 1.15 / 1.3 / 1.45 / 1.7 -> 768 / 1185 / 1222 / 1220 / 748 us per launch in their sessions, profiles/ab_fwd_r04[df].log)
 #endif
 constexpr float DUAL_GEN_COST = CBGX_DUAL_GEN_COST;
 template <int WAVES>

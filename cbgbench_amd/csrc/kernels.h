@@ -78,7 +78,9 @@ hipError_t launch_lig_proximity(const float* x, const int32_t* graph_ptr, int n_
                                 const float* r32sq, int n_nodes, uint8_t* dirty, hipStream_t s);
 // MFMA node kernels (node_mfma.hip): P = h Wn + bn, q = MLP tail, Qt = folded query
 hipError_t launch_pack_node_tables(const PackBlocks& pb, hipStream_t s);     // node_mfma.hip part of stage 2
-hipError_t launch_build_active(const uint8_t* flag, int n, int* list, int* count, hipStream_t s);
+// counter_zeroed: the caller has already set *count to zero on this stream (cbgx_unitransformer_forward zeroes all its list counters
+// with ONE memset instead of one per list: ~15 fills of 4.6 us per denoising step)
+hipError_t launch_build_active(const uint8_t* flag, int n, int* list, int* count, hipStream_t s, bool counter_zeroed = false);
 hipError_t launch_mark_seed(const uint8_t* a, const uint8_t* b, int n, uint8_t* m, hipStream_t s);
 hipError_t launch_mark_from_nbr(const uint8_t* flag, const int32_t* nbr, const int32_t* deg, int n, uint8_t* out,
                                 hipStream_t s);
@@ -89,8 +91,28 @@ hipError_t launch_mark_nbr(const int* list, const int* count, int n_upper, const
 hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,
                             float* Qt, const int* act, const int* act_count, const int* src, const int* src_count,
                             hipStream_t s, bool large_lists = false, const int* fold = nullptr, const int* fold_count = nullptr);
+// all node lists of a forward call in four launches (node_mfma.hip): three level kernels over flags + one multi-job compaction
+struct GraphFlags {
+    const uint8_t *gen, *lig;
+    const uint8_t* D1;            // input of the cached levels (may alias d1)
+    uint8_t *d1, *a1, *a2, *a3, *D2, *S1, *S2;
+};
+constexpr int LIST_JOBS_MAX = 16;
+struct ListJobs {
+    const uint8_t* flag[LIST_JOBS_MAX];      // member if flag != 0 (NULL: every node) ...
+    const uint8_t* flag2[LIST_JOBS_MAX];     // ... and (flag2 != 0) == want2 when flag2 is given
+    int want2[LIST_JOBS_MAX];
+    int* list[LIST_JOBS_MAX];
+    int* count[LIST_JOBS_MAX];
+    int n_jobs;
+};
+hipError_t launch_list_level(const GraphFlags& f, const int32_t* nbr, const int32_t* deg, int n, int level, bool cached, bool prune,
+                             hipStream_t s);
+hipError_t launch_build_lists(const ListJobs& jobs, int n, hipStream_t s);
+hipError_t launch_restore_graph(const int32_t* s_nbr, const int32_t* s_deg, const float* s_ew, int n, int32_t* nbr, int32_t* deg,
+                                float* ew, hipStream_t s);
 hipError_t launch_split_list(const int* list, const int* count, int n, const uint8_t* flag, int* out1, int* cnt1, int* out0,
-                             int* cnt0, hipStream_t s);
+                             int* cnt0, hipStream_t s, bool counters_zeroed = false);
 // MFMA edge kernel (edge_mfma.hip)
 int set_edge_workgroup_limit(int n);
 hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,

@@ -828,13 +828,123 @@ __global__ __launch_bounds__(BA_THREADS) void split_list_kernel(const int* __res
 }
 
 hipError_t launch_split_list(const int* list, const int* count, int n, const uint8_t* flag, int* out1, int* cnt1, int* out0,
-                             int* cnt0, hipStream_t s) {
-    // the two counters live in one 128-byte region (cnt1 first): one memset
-    hipError_t e = hipMemsetAsync(cnt1, 0, (size_t)((char*)cnt0 - (char*)cnt1) + sizeof(int), s);
-    if (e != hipSuccess) return e;
+                             int* cnt0, hipStream_t s, bool counters_zeroed) {
+    if (!counters_zeroed) {   // the two counters live in one 128-byte region (cnt1 first): one memset
+        hipError_t e = hipMemsetAsync(cnt1, 0, (size_t)((char*)cnt0 - (char*)cnt1) + sizeof(int), s);
+        if (e != hipSuccess) return e;
+    }
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(split_list_kernel, dim3((n + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, s, list, count, n, flag,
                        out1, cnt1, out0, cnt0);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Every node list of one cbgx_unitransformer_forward call in FOUR launches (round 4; they were ~21: a mark kernel and a
+// compaction with its own counter fill per list -- 100 us of a 1-graph step that is ~1 ms of dependent ~5 us launches).
+// All flag arrays and counters are zero on entry (ONE fill of the workspace region that holds them).  Three level kernels over
+// (node, neighbour slot) pairs -- a level only reads flags the previous level has completed --
+//   level 0:  a1 = gen | lig | nbr(gen)              d1 = lig | {i : nbr(i) has a ligand atom}
+//   level 1:  a2 = a1 | nbr(a1)     D2 = D1 | {i : nbr(i) meets D1}     S1 = D1 | nbr(D1)
+//   level 2:  a3 = a2 | nbr(a2)     S2 = D2 | nbr(D2)
+// (nbr(set) = the in-neighbours of its members = the sources their edge kernels read; D1 = the caller's "differs from the
+// ligand-free pocket" flags: the proximity flags of the graph cache, or d1 itself) and one compaction launch, blockIdx.y = job.
+// List order is irrelevant: every node is computed independently of its position in a list.
+// ------------------------------------------------------------------------------------------------
+__global__ void list_level_kernel(GraphFlags f, const int32_t* __restrict__ nbr, const int32_t* __restrict__ deg, int n, int level,
+                                  int cached, int prune) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(t >> 5), e = (int)(t & 31);
+    if (i >= n) return;
+    const bool valid = e < deg[i];
+    const int j = valid ? nbr[(size_t)i * KNN + e] : i;
+    if (level == 0) {
+        const bool g = f.gen[i] != 0, l = f.lig[i] != 0;
+        if (e == 0 && (g || l)) f.a1[i] = 1;
+        if (g && valid) f.a1[j] = 1;
+        if ((e == 0 && l) || (valid && f.lig[j])) f.d1[i] = 1;
+    } else if (level == 1) {
+        if (prune) {
+            const bool a = f.a1[i] != 0;
+            if (e == 0 && a) f.a2[i] = 1;
+            if (a && valid) f.a2[j] = 1;
+        }
+        if (cached) {
+            const bool d = f.D1[i] != 0;
+            if ((e == 0 && d) || (valid && f.D1[j])) f.D2[i] = 1;
+            if (e == 0 && d) f.S1[i] = 1;
+            if (d && valid) f.S1[j] = 1;
+        }
+    } else {
+        if (prune) {
+            const bool a = f.a2[i] != 0;
+            if (e == 0 && a) f.a3[i] = 1;
+            if (a && valid) f.a3[j] = 1;
+        }
+        if (cached) {
+            const bool d = f.D2[i] != 0;
+            if (e == 0 && d) f.S2[i] = 1;
+            if (d && valid) f.S2[j] = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BA_THREADS) void build_lists_kernel(ListJobs jobs, int n) {
+    __shared__ int s_cnt[BA_THREADS / 64];
+    __shared__ int s_base;
+    const int job = blockIdx.y;
+    const uint8_t* __restrict__ fa = jobs.flag[job];
+    const uint8_t* __restrict__ fb = jobs.flag2[job];
+    const int idx = blockIdx.x * BA_THREADS + threadIdx.x;
+    bool a = idx < n && (fa == nullptr || fa[idx] != 0);
+    if (a && fb) a = (fb[idx] != 0) == (jobs.want2[job] != 0);
+    const unsigned long long m = __ballot(a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < BA_THREADS / 64; ++w) { const int c = s_cnt[w]; s_cnt[w] = tot; tot += c; }   // exclusive prefix
+        s_base = tot ? atomicAdd(jobs.count[job], tot) : 0;
+    }
+    __syncthreads();
+    if (a) jobs.list[job][s_base + s_cnt[wave] + __popcll(m & ((1ull << lane) - 1ull))] = idx;
+}
+
+hipError_t launch_list_level(const GraphFlags& f, const int32_t* nbr, const int32_t* deg, int n, int level, bool cached, bool prune,
+                             hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const long threads = (long)n * 32;
+    hipLaunchKernelGGL(list_level_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, f, nbr, deg, n, level,
+                       cached ? 1 : 0, prune ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_lists(const ListJobs& jobs, int n, hipStream_t s) {
+    if (n == 0 || jobs.n_jobs == 0) return hipSuccess;
+    hipLaunchKernelGGL(build_lists_kernel, dim3((n + BA_THREADS - 1) / BA_THREADS, jobs.n_jobs), dim3(BA_THREADS), 0, s, jobs, n);
+    return hipGetLastError();
+}
+
+// the pocket's own neighbour lists, degrees and gate values (static-context cache) into the call's working arrays: one launch
+// instead of three device-to-device copies
+__global__ void restore_graph_kernel(const int32_t* __restrict__ s_nbr, const int32_t* __restrict__ s_deg,
+                                     const float* __restrict__ s_ew, int n, int32_t* __restrict__ nbr, int32_t* __restrict__ deg,
+                                     float* __restrict__ ew) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 4 neighbour slots
+    if (t >= (long)n * (KNN / 4)) return;
+    reinterpret_cast<int4*>(nbr)[t] = reinterpret_cast<const int4*>(s_nbr)[t];
+    reinterpret_cast<float4*>(ew)[t] = reinterpret_cast<const float4*>(s_ew)[t];
+    if ((t & (KNN / 4 - 1)) == 0) deg[t / (KNN / 4)] = s_deg[t / (KNN / 4)];
+}
+
+hipError_t launch_restore_graph(const int32_t* s_nbr, const int32_t* s_deg, const float* s_ew, int n, int32_t* nbr, int32_t* deg,
+                                float* ew, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const long threads = (long)n * (KNN / 4);
+    hipLaunchKernelGGL(restore_graph_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, s_nbr, s_deg, s_ew, n, nbr,
+                       deg, ew);
     return hipGetLastError();
 }
 
@@ -890,9 +1000,11 @@ hipError_t launch_mark_nbr(const int* list, const int* count, int n_upper, const
     return hipGetLastError();
 }
 
-hipError_t launch_build_active(const uint8_t* flag, int n, int* list, int* count, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s);
-    if (e != hipSuccess) return e;
+hipError_t launch_build_active(const uint8_t* flag, int n, int* list, int* count, hipStream_t s, bool counter_zeroed) {
+    if (!counter_zeroed) {
+        hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s);
+        if (e != hipSuccess) return e;
+    }
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(build_active_kernel, dim3((n + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, s, flag, n, list, count);
     return hipGetLastError();

@@ -12,7 +12,7 @@ i=0
 while read -r GROUP; do
   [ -z "$GROUP" ] && continue
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $GROUP --kernel-include-regex "edge_mfma_kernel|edge_x2h" --output-format csv -d $OUT/p$i -o pmc -- $CMD > $OUT/p$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $GROUP --kernel-include-regex "edge_x2h_dual_kernel" --output-format csv -d $OUT/p$i -o pmc -- $CMD > $OUT/p$i.log 2>&1
   f=$(find $OUT/p$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp "$f" $OUT/pass$i.csv && rm -rf $OUT/p$i
 done <<'GROUPS'

@@ -459,14 +459,15 @@ def test_targetdiff_rollout_200_steps_real_pocket(synthetic_sd):
 def test_diffsbdd_pocket_frame_equals_moving_pocket():
     """DiffSBDD with the composed coordinates kept in the pocket's own frame (static-context cache on, the default of the native
     step: cbgx_diffsbdd_step frame_shift) against the same native step with the pocket translated in place every step
-    (static_cache=False; diffsbdd.py:296-304 literally): free-running steps on real-size pockets, shared Gaussian draws.
+    (static_cache=False; diffsbdd.py:296-304 literally), shared Gaussian draws, real-size pockets.
     The two evaluate the network on coordinates that differ by a translation, i.e. by fp32 rounding -- and the network is NOT
-    continuous in its coordinates: a kNN graph keeps the 32 nearest atoms, so a 1e-7 relative change of two nearly equal
-    distances can swap the 32nd neighbour of a node (expected once per ~1e4 neighbour selections; measured here: the first swap
-    within a few steps of a 2 000-atom batch), after which the two runs are different, equally valid roll-outs that drift apart at
-    the 1e-3 level.  So the test compares the neighbour lists of the two runs at every step: as long as they are identical the
-    states must agree within 2e-5 absolute + 1e-5 relative (ligand positions, type features, true pocket positions); from the first
-    swap on only a sanity bound (5e-2) is asserted.  At least the first two steps must be swap-free for the test to count."""
+    continuous in its coordinates: a kNN graph keeps the 32 nearest atoms, so a 1e-6 change of two nearly equal distances can swap
+    the 32nd neighbour of some node (a ~10 % event per step of a 2 000-atom batch), after which the step's outputs differ at the
+    1e-3 level -- two equally valid evaluations.  So: run A (frame) runs freely for 12 steps; before every step run B (moving pocket)
+    is set to A's TRUE state (ligand, pocket = frame - shift), both take the step, and the neighbour lists the two denoiser calls
+    built are compared.  Steps whose lists are identical must agree within 2e-5 absolute + 1e-5 relative (next ligand positions and
+    type features, true pocket positions); steps with a swap only within the sanity bound 5e-2.  At least 8 of the 12 steps must be
+    swap-free (measured: see profiles/pytest_gpu_r04*.log)."""
     from cbgbench_amd import stages
     Cn = 8
     m = C.get_model(C.default_diffsbdd_config(Cn)).eval()
@@ -483,22 +484,31 @@ def test_diffsbdd_pocket_frame_equals_moving_pocket():
     assert sb["native"] and sb["frame"] is None and sb["static_h"] is None
     p0 = m.pocket_positions(sa).clone()
     gptr = sa["graph_ptr"].to(torch.int32).contiguous()
-    tight_steps, swapped = 0, False
+    emb = m.context_embedder
+    tight, worst_tight, worst_swapped = 0, 0.0, 0.0
     for t in steps:
-        # the graphs the two denoiser calls of this step are about to build
+        # B <- A's true state (the composed x / h of the native step are kept current by the step kernel: rewrite them here)
+        sb["x_lig"], sb["c_lig"] = sa["x_lig"].clone(), sa["c_lig"].clone()
+        sb["x"][sb["rec_rows"]] = m.pocket_positions(sa)
+        sb["x"][sb["lig_rows"]] = sb["x_lig"]
+        sb["h"][sb["lig_rows"]] = emb.embed_ligand(sb["c_lig"])
         na, _ = stages.knn_graph(sa["x"].contiguous(), gptr)
         nb, _ = stages.knn_graph(sb["x"].contiguous(), gptr)
-        swapped = swapped or not torch.equal(na.sort(dim=1).values, nb.sort(dim=1).values)
+        swapped = not torch.equal(na.sort(dim=1).values, nb.sort(dim=1).values)
         m.denoise_step(sa, t)
         m.denoise_step(sb, t)
         for a, b, what in ((sa["x_lig"], sb["x_lig"], "x_lig"), (sa["c_lig"], sb["c_lig"], "c_lig"),
                            (m.pocket_positions(sa), m.pocket_positions(sb), "x_rec")):
             err = (a.double() - b.double()).abs()
             if not swapped:
+                worst_tight = max(worst_tight, float(err.max()))
                 assert bool((err <= 2e-5 + 1e-5 * b.double().abs()).all()), (t, what, float(err.max()))
+            else:
+                worst_swapped = max(worst_swapped, float(err.max()))
             assert float(err.max()) < 5e-2, (t, what, float(err.max()))
-        tight_steps += not swapped
-    print(f"pocket frame vs moving pocket: {tight_steps} of {len(steps)} steps before the first neighbour swap")
-    assert tight_steps >= 2
+        tight += not swapped
+    print(f"pocket frame vs moving pocket: {tight} of {len(steps)} steps without a neighbour swap, max err {worst_tight:.2e} on those, "
+          f"{worst_swapped:.2e} on the others")
+    assert tight >= 8
     # the pocket has really moved (the frame carries it) while its rows in the composed x never changed
     assert float((m.pocket_positions(sa) - p0).abs().max()) > 1e-3 and torch.equal(sa["x"][sa["rec_rows"]], p0)

@@ -1,7 +1,10 @@
 """Parity of the HIP path (through the C ABI) against golden vectors made by the reference itself and
 against the CPU oracle.  Tolerances: fp32, summation-order differences only -> 1e-4 relative + 1e-5
-absolute on x / h / delta_x / logits, identical atom-type argmax on ligand rows,
-bit-exact neighbour lists."""
+absolute on x / h / delta_x / logits (round 4: h and the logits no longer get a tenfold absolute
+allowance -- the measured maxima over all goldens are 2.1e-6 / 1.9e-6, profiles/parity_errors_r04f.md, written by the last test of
+this file on every GPU run), identical atom-type argmax on ligand rows, bit-exact neighbour lists.  Only the 5-step DiffSBDD
+trajectory keeps a 1e-4 absolute term: its update divides by alpha_ts every step (measured 8.6e-6 on x, 7.3e-4 on type features of
+magnitude 1.6e3)."""
 import os
 
 import numpy as np
@@ -22,10 +25,17 @@ DENOISER_CASES = ["denoiser_2graphs", "denoiser_small_graphs", "denoiser_linker"
                   "denoiser_adrb1_pocket10", "denoiser_drd2_pocket10", "denoiser_smarca2_pocket10"]
 
 
+MEASURED = {}     # what -> (max abs err, max |ref|, max of err / (ATOL scale + RTOL |ref|)) over every check of this session
+
+
 def close(a, b, what, scale=1.0):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     err = (a - b).abs()
     tol = ATOL * scale + RTOL * b.abs()
+    key = what.split("[")[0].strip()
+    m = MEASURED.get(key, (0.0, 0.0, 0.0))
+    if err.numel():
+        MEASURED[key] = (max(m[0], float(err.max())), max(m[1], float(b.abs().max())), max(m[2], float((err / tol).max())))
     assert bool((err <= tol).all()), f"{what}: max abs err {err.max():.3e} (|ref| max {b.abs().max():.3e})"
 
 
@@ -109,8 +119,8 @@ def test_full_denoiser_matches_reference(golden_dir, model, case):
         xo, ho, lo = model.denoiser(x=g["x"].to(DEV), h=g["h"].to(DEV), batch_idx=g["batch_idx"].to(DEV),
                                     lig_flag=g["lig_flag"].to(DEV), gen_flag=g["gen_flag"].to(DEV))
     close(xo, g["x_out"], "x_out")
-    close(ho, g["h_out"], "h_out", scale=10.0)   # |h| grows to O(10) over 9 residual layers
-    close(lo, g["logits"], "logits", scale=10.0)
+    close(ho, g["h_out"], "h_out")   # measured 2.1e-6 on |h| up to 5.2 (profiles/parity_errors_r04f.md)
+    close(lo, g["logits"], "logits")
     lig = g["lig_flag"]
     assert torch.equal(lo.cpu()[lig].argmax(-1), g["logits"][lig].argmax(-1))
     assert torch.equal(xo.cpu()[~g["gen_flag"]], g["x"][~g["gen_flag"]])
@@ -157,7 +167,7 @@ def test_teacher_forced_step(golden_dir, model, case):
         xo, _, lo = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
         x_pred, c_pred = xo[lig_rows], lo[lig_rows]
         close(x_pred, g["x_pred"], "x0 prediction")
-        close(c_pred, g["c_pred"], "type logits", scale=10.0)
+        close(c_pred, g["c_pred"], "type logits")
         assert torch.equal(c_pred.argmax(-1).cpu(), g["c_pred"].argmax(-1))
         B = int(bl.max()) + 1
         t = torch.full((B,), t_idx, dtype=torch.long, device=DEV)
@@ -192,8 +202,8 @@ def test_config_sized_graphs_vs_oracle(model, synthetic_sd, maker, n):
         xo, ho, lo = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
     rx, rh, rl = OU.unitransformer_forward(synthetic_sd, x.cpu(), h.cpu(), batch_idx.cpu(), lig_flag.cpu(), gen.cpu())
     close(xo, rx, "x_out")
-    close(ho, rh, "h_out", scale=10.0)
-    close(lo, rl, "logits", scale=10.0)
+    close(ho, rh, "h_out")
+    close(lo, rl, "logits")
     lig = lig_flag.cpu()
     assert torch.equal(lo.cpu()[lig].argmax(-1), rl[lig].argmax(-1))
 
@@ -222,8 +232,8 @@ def test_properties_at_full_batch(model):
         R = _rand_rotation(1).to(DEV)
         tr = torch.tensor([3.0, -2.0, 5.0], device=DEV)
         xr, hr, lr = den(x=x @ R.T + tr, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
-        close(xr, xo @ R.T + tr, "equivariance of x", scale=10.0)
-        close(hr, ho, "invariance of h", scale=10.0)
+        close(xr, xo @ R.T + tr, "equivariance of x")
+        close(hr, ho, "invariance of h")
         assert torch.equal(lr[lig_flag].argmax(-1), lo[lig_flag].argmax(-1))
         # batch independence: graph 3 alone gives the same rows
         s, e = int(gp[3]), int(gp[4])
@@ -255,7 +265,7 @@ def test_permutation_of_atoms_within_a_graph(model):
         xp, hp, lp = den(x=x[perm].contiguous(), h=h[perm].contiguous(), batch_idx=batch_idx, lig_flag=lig_flag[perm].contiguous(),
                          gen_flag=gen[perm].contiguous(), graph_ptr=gp)
     close(xp, xo[perm], "x_out under an atom permutation")
-    close(hp, ho[perm], "h_out under an atom permutation", scale=10.0)
+    close(hp, ho[perm], "h_out under an atom permutation")
     lig = lig_flag[perm]
     assert torch.equal(lp[lig].argmax(-1), lo[perm][lig].argmax(-1))
 
@@ -287,7 +297,7 @@ def test_full_config2_job_in_one_batch(model, synthetic_sd):
     rx, rh, rl = OU.unitransformer_forward(synthetic_sd, x[s:e].cpu(), h[s:e].cpu(), torch.zeros(e - s, dtype=torch.long),
                                            lig_flag[s:e].cpu(), gen[s:e].cpu())
     close(xo[s:e], rx, "x_out (graph 999 of 1000)")
-    close(ho[s:e], rh, "h_out (graph 999 of 1000)", scale=10.0)
+    close(ho[s:e], rh, "h_out (graph 999 of 1000)")
     lig = lig_flag[s:e].cpu()
     assert torch.equal(lo[s:e].cpu()[lig].argmax(-1), rl[lig].argmax(-1))
 
@@ -306,7 +316,7 @@ def test_linker_256_graphs_runs_and_freezes_context(model):
     with _native.first_generation_kernels(), torch.no_grad():
         xv, hv, lv = model.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen, graph_ptr=gp)
     close(xo, xv, "x_out mfma vs valu kernels (256 graphs)")
-    close(ho, hv, "h_out mfma vs valu kernels (256 graphs)", scale=10.0)
+    close(ho, hv, "h_out mfma vs valu kernels (256 graphs)")
     assert torch.equal(lo[lig_flag].argmax(-1), lv[lig_flag].argmax(-1))
     # one of the 256 graphs against the oracle (the oracle on the whole batch would take minutes)
     gidx = 17
@@ -315,7 +325,7 @@ def test_linker_256_graphs_runs_and_freezes_context(model):
     rx, rh, rl = OU.unitransformer_forward(sd, x[s:e].cpu(), h[s:e].cpu(), torch.zeros(e - s, dtype=torch.long),
                                            lig_flag[s:e].cpu(), gen[s:e].cpu())
     close(xo[s:e], rx, "x_out (graph 17 of 256)")
-    close(ho[s:e], rh, "h_out (graph 17 of 256)", scale=10.0)
+    close(ho[s:e], rh, "h_out (graph 17 of 256)")
 
 
 def test_no_movable_nodes(model, golden_dir):
@@ -630,3 +640,19 @@ def test_static_context_cache_edge_cases(model):
         outs.append((st["x_lig"].clone(), st["c_lig"].clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.isfinite(outs[0][0]).all()
+
+
+def test_zz_report_measured_errors():
+    """not a check: writes what the checks of this file measured (max |err| per output over all goldens, against the tolerance
+    in force) to gpurun_out/parity_errors.md, so that the tolerances can be read against measurements (copied to profiles/)"""
+    root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out")
+    if not MEASURED or not os.path.isdir(out):
+        pytest.skip("nothing measured in this session, or no gpurun_out/")
+    lines = ["| output (all goldens of tests/test_gpu_parity.py) | max abs err | max abs ref | worst err / tolerance |", "|---|---|---|---|"]
+    for k in sorted(MEASURED):
+        e, r, f = MEASURED[k]
+        lines.append(f"| {k} | {e:.3e} | {r:.3e} | {f:.3f} |")
+    with open(os.path.join(out, "parity_errors.md"), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    print("\n".join(lines))

@@ -49,7 +49,10 @@ def test_forward_edge_kernels_fit_their_budget(tmp_path):
     x2h = find(res, "edge_mfma_kernelILb1ELi8ELb0E")
     x2h_listed = find(res, "edge_mfma_kernelILb1ELi8ELb1E")
     h2x_listed = find(res, "edge_mfma_kernelILb0ELi8ELb1E")
-    for k in (x2h, x2h_listed):
+    # round 4: the inference path's x2h stage = edge_x2h_dual_kernel (protein-only role with the in-register query fold + general
+    # role in one launch); the plain x2h kernels remain for the taped training forward
+    dual = find(res, "edge_x2h_dual_kernelILi8E")
+    for k in (x2h, x2h_listed, dual):
         assert k["scratch"] == 0 and k["vgpr"] <= 256          # 8 waves per CU = 2 per SIMD need <= 256 registers
         assert k["lds"] <= 160 * 1024
     # no spill anywhere: a scratch reload is a VMEM operation, and the `s_waitcnt vmcnt(0)` in front of its first use would
@@ -67,6 +70,13 @@ def test_forward_edge_kernels_fit_their_budget(tmp_path):
     # static counts: 128 exact-fp32 MFMAs (scores + aggregation); the rbf pre-activation as split-f16 MFMAs, 4 blocks (k / v x two
     # halves) x 2 source-class passes x 8 tiles x 4; 2 179 VALU instructions before the packed-fp32 pass, 1 344 before split-f16
     assert mfma32 == 128 and mfma16 == 256 and valu <= 1800, (mfma32, mfma16, valu)
+    # the two-role kernel: both bodies inlined -- 2 x 128 exact-fp32 MFMAs; the protein-only body runs ONE source-class pass
+    # (128 split-f16 MFMAs), the general body both (256); the fold's 64 ds_read_b128 + 128 packed FMAs sit in the first
+    start = re.search(r"^_ZN4cbgx20edge_x2h_dual_kernelILi8E\S*:", text, flags=re.M).start()
+    body = text[start:text.index(".end_amdhsa_kernel", start)]
+    mfma32 = len(re.findall(r"^\s+v_mfma_f32_16x16x4", body, flags=re.M))
+    mfma16 = len(re.findall(r"^\s+v_mfma_f32_16x16x16_f16", body, flags=re.M))
+    assert mfma32 == 256 and mfma16 == 384, (mfma32, mfma16)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
