@@ -538,7 +538,8 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
         HIP_TRY(launch_lig_proximity(x, graph_ptr, n_graphs, lig_flag, static_r32sq, n_nodes, w.fD1, s));   // D1
         HIP_TRY(launch_build_active(w.fD1, n_nodes, w.fw_list[0], w.fw_count, s, true));
         HIP_TRY(launch_restore_graph(static_nbr, static_deg, static_ew, n_nodes, w.nbr, w.deg, w.e_w, s));
-        HIP_TRY(launch_knn_reg(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s, w.fw_list[0], w.fw_count));
+        HIP_TRY(launch_knn_merge(x, graph_ptr, n_graphs, n_nodes, lig_flag, static_nbr, static_deg, w.nbr, w.deg, s, w.fw_list[0],
+                                 w.fw_count));
         HIP_TRY(launch_gate_mfma(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s, w.fw_list[0], w.fw_count));
     } else {
         HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s));

@@ -69,15 +69,9 @@ __device__ __forceinline__ float dist2_exact2(float ax, float ay, float az, floa
 // to the oracle (d2 computed with contraction off).  Graphs larger than 64 * KNN_SLOTS use knn_graph_kernel.
 constexpr int KNN_SLOTS = 12;
 
-__global__ __launch_bounds__(256) void knn_graph_reg_kernel(const float* __restrict__ x,
-                                                            const int32_t* __restrict__ graph_ptr, int n_graphs,
-                                                            int n_nodes, int32_t* __restrict__ nbr,
-                                                            int32_t* __restrict__ deg, const int* __restrict__ rows,
-                                                            const int* __restrict__ n_rows_ptr) {
-    const int lane = threadIdx.x & 63;
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (idx >= (rows ? *n_rows_ptr : n_nodes)) return;
-    const int i = rows ? rows[idx] : idx;      // optional centre list (static-context cache: only the nodes near a ligand)
+// the search of one centre node i by the wave it is called from: every candidate of the graph is scanned
+__device__ __forceinline__ void knn_scan_node(const float* __restrict__ x, const int32_t* __restrict__ graph_ptr, int n_graphs,
+                                              int i, int lane, int32_t* __restrict__ nbr, int32_t* __restrict__ deg) {
     int lo_g = 0, hi_g = n_graphs;
     while (hi_g - lo_g > 1) {
         const int mid = (lo_g + hi_g) >> 1;
@@ -132,6 +126,98 @@ __global__ __launch_bounds__(256) void knn_graph_reg_kernel(const float* __restr
     }
     if (lane < KNN) nbr[(size_t)i * KNN + lane] = mine;
     if (lane == 0) deg[i] = d < 0 ? 0 : d;
+}
+
+__global__ __launch_bounds__(256) void knn_graph_reg_kernel(const float* __restrict__ x,
+                                                            const int32_t* __restrict__ graph_ptr, int n_graphs,
+                                                            int n_nodes, int32_t* __restrict__ nbr,
+                                                            int32_t* __restrict__ deg, const int* __restrict__ rows,
+                                                            const int* __restrict__ n_rows_ptr) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= (rows ? *n_rows_ptr : n_nodes)) return;
+    const int i = rows ? rows[idx] : idx;      // optional centre list (static-context cache: only the nodes near a ligand)
+    knn_scan_node(x, graph_ptr, n_graphs, i, lane, nbr, deg);
+}
+
+// Graph-cached calls (static-context cache): the listed centres are the nodes near a ligand.  A PROTEIN centre's new neighbour
+// list is the 32 smallest of (its own pocket list: 32 protein atoms, sorted by (d2, index), distances unchanged because protein
+// atoms do not move) U (the ligand atoms of its graph) -- any other protein atom is beaten by all 32 of the pocket list.  Instead
+// of scanning the ~550 atoms of the graph through 32 rounds of a wave-wide minimum, every candidate's RANK in the union is counted:
+//   pocket entry p:   p + #{ligand keys < its key}          ligand atom:   #{pocket keys < key} + #{ligand keys < key}
+// (keys = (bits(d2), index), compared lexicographically, d2 evaluated exactly as in the scan: the result is bit-identical to it --
+// tests/test_gpu_parity.py::test_static_context_cache_is_exact compares the two paths on every node).  The ligand atoms close a
+// graph's rows (compose_context, common.py:200); up to 128 of them are handled here.  Ligand centres, graphs with more ligand atoms
+// and graphs above the register-cached size take the scan.
+__device__ __forceinline__ bool key_less(unsigned ah, unsigned al, unsigned bh, unsigned bl) { return ah < bh || (ah == bh && al < bl); }
+
+__global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ x, const int32_t* __restrict__ graph_ptr,
+                                                        int n_graphs, const uint8_t* __restrict__ lig,
+                                                        const int32_t* __restrict__ s_nbr, const int32_t* __restrict__ s_deg,
+                                                        int32_t* __restrict__ nbr, int32_t* __restrict__ deg,
+                                                        const int* __restrict__ rows, const int* __restrict__ n_rows_ptr) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= *n_rows_ptr) return;
+    const int i = rows[idx];
+    int lo_g = 0, hi_g = n_graphs;
+    while (hi_g - lo_g > 1) {
+        const int mid = (lo_g + hi_g) >> 1;
+        if (graph_ptr[mid] <= i) lo_g = mid; else hi_g = mid;
+    }
+    const int gs = graph_ptr[lo_g], ge = graph_ptr[lo_g + 1];
+    // ligand atoms of the graph: the run of flagged rows at its end, counted over the last 128 rows
+    const int r0 = ge - 1 - lane, r1 = ge - 65 - lane;
+    const unsigned long long b0 = __ballot(r0 >= gs && lig[r0 >= gs ? r0 : gs] != 0);
+    const unsigned long long b1 = __ballot(r1 >= gs && lig[r1 >= gs ? r1 : gs] != 0);
+    const int n0 = b0 == ~0ull ? 64 : __builtin_ctzll(~b0);
+    const int n1 = n0 < 64 ? 0 : (b1 == ~0ull ? 64 : __builtin_ctzll(~b1));
+    const int nl = n0 + n1;
+    if (lig[i] != 0 || nl >= 128 || ge - gs > 64 * KNN_SLOTS) {      // wave-uniform
+        knn_scan_node(x, graph_ptr, n_graphs, i, lane, nbr, deg);
+        return;
+    }
+    const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
+    const unsigned NONE = 0xffffffffu;
+    // pocket candidates: lane p < sd holds entry p of the static list
+    const int sd = s_deg[i];
+    const bool vs = lane < sd && lane < KNN;
+    const int js = vs ? s_nbr[(size_t)i * KNN + lane] : i;
+    const unsigned ks_h = vs ? __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * js], x[3 * js + 1], x[3 * js + 2])) : NONE;
+    const unsigned ks_l = vs ? (unsigned)js : NONE;
+    // ligand candidates: rows ls .. ge-1, two per lane
+    const int ls = ge - nl;
+    const bool v0 = lane < nl, v1 = lane + 64 < nl;
+    const int j0 = v0 ? ls + lane : i, j1 = v1 ? ls + 64 + lane : i;
+    const unsigned k0_h = v0 ? __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * j0], x[3 * j0 + 1], x[3 * j0 + 2])) : NONE;
+    const unsigned k1_h = v1 ? __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * j1], x[3 * j1 + 1], x[3 * j1 + 2])) : NONE;
+    const unsigned k0_l = v0 ? (unsigned)j0 : NONE, k1_l = v1 ? (unsigned)j1 : NONE;
+    int rs = lane, r0k = 0, r1k = 0;      // ranks in the union
+    // every ligand key against every candidate of this lane (the loop index is wave-uniform: v_readlane broadcasts key t)
+    for (int t = 0; t < min(nl, 64); ++t) {
+        const unsigned bh = __builtin_amdgcn_readlane(k0_h, t), bl = __builtin_amdgcn_readlane(k0_l, t);
+        rs += key_less(bh, bl, ks_h, ks_l) ? 1 : 0;
+        r0k += key_less(bh, bl, k0_h, k0_l) ? 1 : 0;
+        r1k += key_less(bh, bl, k1_h, k1_l) ? 1 : 0;
+    }
+    for (int t = 0; t < nl - 64; ++t) {
+        const unsigned bh = __builtin_amdgcn_readlane(k1_h, t), bl = __builtin_amdgcn_readlane(k1_l, t);
+        rs += key_less(bh, bl, ks_h, ks_l) ? 1 : 0;
+        r0k += key_less(bh, bl, k0_h, k0_l) ? 1 : 0;
+        r1k += key_less(bh, bl, k1_h, k1_l) ? 1 : 0;
+    }
+    for (int p = 0; p < min(sd, KNN); ++p) {   // every pocket key against this lane's ligand candidates
+        const unsigned bh = __builtin_amdgcn_readlane(ks_h, p), bl = __builtin_amdgcn_readlane(ks_l, p);
+        r0k += key_less(bh, bl, k0_h, k0_l) ? 1 : 0;
+        r1k += key_less(bh, bl, k1_h, k1_l) ? 1 : 0;
+    }
+    const int d = min(KNN, min(sd, KNN) + nl);
+    int32_t* out = nbr + (size_t)i * KNN;
+    if (lane >= d && lane < KNN) out[lane] = -1;
+    if (vs && rs < KNN) out[rs] = js;
+    if (v0 && r0k < KNN) out[r0k] = j0;
+    if (v1 && r1k < KNN) out[r1k] = j1;
+    if (lane == 0) deg[i] = d;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -291,6 +377,17 @@ hipError_t launch_knn_reg(const float* x, const int32_t* graph_ptr, int n_graphs
     profile_mark_begin(K_KNN, s);
     hipLaunchKernelGGL(knn_graph_reg_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, x, graph_ptr, n_graphs, n_nodes,
                        nbr, deg, rows, n_rows);
+    profile_mark_end(s);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_merge(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, const uint8_t* lig,
+                            const int32_t* s_nbr, const int32_t* s_deg, int32_t* nbr, int32_t* deg, hipStream_t s, const int* rows,
+                            const int* n_rows) {
+    if (n_nodes == 0) return hipSuccess;
+    profile_mark_begin(K_KNN, s);
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, x, graph_ptr, n_graphs, lig, s_nbr, s_deg, nbr,
+                       deg, rows, n_rows);
     profile_mark_end(s);
     return hipGetLastError();
 }

@@ -72,6 +72,10 @@ hipError_t launch_pack_gate_img(const float* w1, const float* b1, const float* g
                                 float* img, hipStream_t s);
 hipError_t launch_knn_reg(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, int32_t* nbr,
                           int32_t* deg, hipStream_t s, const int* rows = nullptr, const int* n_rows = nullptr);
+// graph-cached calls: the listed centres' lists from (pocket list U the graph's ligand atoms) by rank counting (graph_mfma.hip)
+hipError_t launch_knn_merge(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, const uint8_t* lig,
+                            const int32_t* s_nbr, const int32_t* s_deg, int32_t* nbr, int32_t* deg, hipStream_t s, const int* rows,
+                            const int* n_rows);
 hipError_t launch_gate_mfma(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
                             float* e_w, hipStream_t s, const int* rows = nullptr, const int* n_rows = nullptr);
 hipError_t launch_lig_proximity(const float* x, const int32_t* graph_ptr, int n_graphs, const uint8_t* lig,

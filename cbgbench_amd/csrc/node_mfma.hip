@@ -156,6 +156,55 @@ __device__ __forceinline__ ProjTile proj_tile_load(const float* __restrict__ h, 
     return t;
 }
 
+// one 16-row tile of one wave against the resident chunk: row scale + split, 48 MFMAs (B from LDS), scaled stores
+__device__ __forceinline__ void proj_tile_compute(const ProjTile& cur, const half8* __restrict__ Bh, const half8* __restrict__ Bl,
+                                                  const float4 bP, const float4 bL, const float4 ci, float* __restrict__ P, int ch,
+                                                  int c, int q) {
+    half8 ah[4], al[4];
+    float rinv[4];
+    {
+        float mx = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {     // chains of max(max(m, |a|), |b|): one v_max3_f32 with |.| source modifiers each
+            mx = fmaxf(fmaxf(mx, fabsf(cur.hv[u].x)), fabsf(cur.hv[u].y));
+            mx = fmaxf(fmaxf(mx, fabsf(cur.hv[u].z)), fabsf(cur.hv[u].w));
+        }
+        float inv;
+        const float up = row_pow2(nxrow_max(mx), inv);
+        rows_to_c_layout(inv, q, rinv);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 v0 = cur.hv[2 * u], v1 = cur.hv[2 * u + 1];
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            split8(v, up, ah[u], al[u]);
+        }
+    }
+    floatx4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        half8 bh[4], bl[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { bh[ct] = Bh[(ct * 4 + u) * 64]; bl[ct] = Bl[(ct * 4 + u) * 64]; }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(ah[u], bl[ct], acc[ct]);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(al[u], bh[ct], acc[ct]);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(ah[u], bh[ct], acc[ct]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (cur.orow[r] >= 0) {
+            const float4 b = ((cur.lgr >> r) & 1) ? bL : bP;
+            float4 o = {fmaf(acc[0][r] * rinv[r], ci.x, b.x), fmaf(acc[1][r] * rinv[r], ci.y, b.y),
+                        fmaf(acc[2][r] * rinv[r], ci.z, b.z), fmaf(acc[3][r] * rinv[r], ci.w, b.w)};
+            *reinterpret_cast<float4*>(P + (size_t)cur.orow[r] * PROW + 64 * ch + 4 * c) = o;
+        }
+    }
+}
+
 // `rows` / `n_rows_ptr` (LISTED): compute only the listed rows (device-side count, no host sync); results are
 // written to their natural positions P[rows[k]].  `chunk_mask`: which of the 10 column chunks to produce; workgroup (x, y) owns
 // the y-th selected chunk and the row tiles x, x + gridDim.x, ...
@@ -192,69 +241,21 @@ __global__ __launch_bounds__(256, NP_WGS_PER_CU) void node_proj_kernel(const flo
     __syncthreads();
     const half8* Bh = reinterpret_cast<const half8*>(lds) + lane;   // [ct][u][lane]
     const half8* Bl = Bh + 4 * 4 * 64;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, row0 += step) {
+    // two tiles per trip, (current, next) tile registers swapping roles instead of being copied (40 registers per tile)
+    ProjTile other;
+    ProjIdx idx2;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += 2 * gridDim.x, row0 += 2 * step) {
         // the next tile's rows (indices arrived during the previous tile) and the indices of the tile after it: in flight during
         // the split and the MFMAs below
-        const ProjTile nxt = proj_tile_load(h, lig, idx1, q);
-        const ProjIdx idx2 = proj_idx_load<LISTED>(rows, n_rows, row0 + 2 * step, c, q);
+        other = proj_tile_load(h, lig, idx1, q);
+        idx2 = proj_idx_load<LISTED>(rows, n_rows, row0 + 2 * step, c, q);
         __builtin_amdgcn_sched_barrier(0);
-        half8 ah[4], al[4];
-        float rinv[4];
-#if defined(CBGX_ABLATE) && (CBGX_ABL_NPROJ & 1)
-        // timing ablation (WRONG results, libcbgx_ablate.so only): no row scale, no split -- the raw bits serve as operands
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            ah[u] = __builtin_bit_cast(half8, cur.hv[2 * u]);
-            al[u] = __builtin_bit_cast(half8, cur.hv[2 * u + 1]);
-        }
-        rinv[0] = rinv[1] = rinv[2] = rinv[3] = 1.f;
-#else
-        {
-            float mx = 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(cur.hv[u].x), fabsf(cur.hv[u].y))), fmaxf(fabsf(cur.hv[u].z), fabsf(cur.hv[u].w)));
-            float inv;
-            const float up = row_pow2(nxrow_max(mx), inv);
-            rows_to_c_layout(inv, q, rinv);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 v0 = cur.hv[2 * u], v1 = cur.hv[2 * u + 1];
-                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                split8(v, up, ah[u], al[u]);
-            }
-        }
-#endif
-        floatx4 acc[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            half8 bh[4], bl[4];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) { bh[ct] = Bh[(ct * 4 + u) * 64]; bl[ct] = Bl[(ct * 4 + u) * 64]; }
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(ah[u], bl[ct], acc[ct]);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(al[u], bh[ct], acc[ct]);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(ah[u], bh[ct], acc[ct]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#if defined(CBGX_ABLATE) && (CBGX_ABL_NPROJ & 2)
-            if (cur.orow[r] == -12345) {     // timing ablation: no stores
-#else
-            if (cur.orow[r] >= 0) {
-#endif
-                const float4 b = ((cur.lgr >> r) & 1) ? bL : bP;
-                float4 o = {fmaf(acc[0][r] * rinv[r], ci.x, b.x), fmaf(acc[1][r] * rinv[r], ci.y, b.y),
-                            fmaf(acc[2][r] * rinv[r], ci.z, b.z), fmaf(acc[3][r] * rinv[r], ci.w, b.w)};
-                *reinterpret_cast<float4*>(P + (size_t)cur.orow[r] * PROW + 64 * ch + 4 * c) = o;
-            }
-        }
-        cur = nxt;
-        idx1 = idx2;
+        proj_tile_compute(cur, Bh, Bl, bP, bL, ci, P, ch, c, q);
+        if (tile + (int)gridDim.x >= n_tiles) break;
+        cur = proj_tile_load(h, lig, idx2, q);
+        idx1 = proj_idx_load<LISTED>(rows, n_rows, row0 + 3 * step, c, q);
+        __builtin_amdgcn_sched_barrier(0);
+        proj_tile_compute(other, Bh, Bl, bP, bL, ci, P, ch, c, q);
     }
 }
 
