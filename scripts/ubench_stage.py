@@ -15,6 +15,7 @@ import bench  # noqa: E402
 from cbgbench_amd import _native, stages, synthetic  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+only_x2h = len(sys.argv) > 2 and sys.argv[2] == "x2h"      # node_gemm class = the full projection launch alone
 dev = torch.device("cuda", 0)
 model = bench.make_model(dev)
 st = model.begin_sampling(synthetic.batch_to(bench.build_batch(20, 10, seed=1000), dev), keep_trajectory=False)
@@ -34,7 +35,8 @@ torch.cuda.synchronize()
 _native.check(lib.cbgx_profile_begin(16 * reps + 64), "cbgx_profile_begin")
 for _ in range(reps):
     stages.x2h_attention(packed, 3, x, h, nbr, deg, lig, e_w)
-    stages.h2x_attention(packed, 3, x, h, nbr, deg, lig, gen, e_w)
+    if not only_x2h:
+        stages.h2x_attention(packed, 3, x, h, nbr, deg, lig, gen, e_w)
 n = len(names)
 ms = (ctypes.c_double * n)(); cnt = (ctypes.c_int * n)()
 _native.check(lib.cbgx_profile_end(ms, cnt, n), "cbgx_profile_end")
