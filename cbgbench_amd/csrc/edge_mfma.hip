@@ -697,7 +697,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
                                       //  1.0 / 1.15 / 1.3 / 1.45 / 1.7 -> 768 / 1185 / 1222 / 1220 / 748 us per launch in their sessions, profiles/ab_fwd_r04[df].log)
 #endif
 constexpr float DUAL_GEN_COST = CBGX_DUAL_GEN_COST;
-template <int WAVES>
+// FULL_LAYER changes no code: the launches whose two lists together are all N nodes of a batch (the dominant kernel of the roofline)
+// get their own kernel name, so that rocprofv3 --stats reports them apart from the cached / pruned layers' launches.
+template <int WAVES, bool FULL_LAYER>
 __global__ __launch_bounds__(WAVES * 64) void edge_x2h_dual_kernel(
     const float* __restrict__ att, const float* __restrict__ x, const float* __restrict__ h,
     const float* __restrict__ P, const float* __restrict__ Qt, const float* __restrict__ qbuf,
@@ -710,8 +712,12 @@ __global__ __launch_bounds__(WAVES * 64) void edge_x2h_dual_kernel(
     const int c_pp = *count_pp, c_gen = *count_gen;
     const int n_wg = gridDim.x;
     int n_pp_wg;
+    const int need_pp = (c_pp + WAVES - 1) / WAVES, need_gen = (c_gen + WAVES - 1) / WAVES;
     if (c_gen == 0) n_pp_wg = n_wg;
     else if (c_pp == 0) n_pp_wg = 0;
+    else if (need_pp + need_gen <= n_wg) n_pp_wg = need_pp;      // small input: one node per wave in both roles (the launcher adds a
+                                                                 // workgroup for the second role's remainder): a proportional split
+                                                                 // left one role two nodes per wave, 36 instead of 27 us at one graph
     else {
         const float share = (float)c_pp / ((float)c_pp + DUAL_GEN_COST * (float)c_gen);
         const int unit = n_wg >= 64 ? 8 : 1;
@@ -921,15 +927,18 @@ hipError_t launch_edge_x2h_dual(const float* att, const float* x, const float* h
     if (n_nodes == 0) return hipSuccess;
     if ((size_t)n_nodes * PROW * sizeof(float) >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit byte offsets into P
     constexpr int W = 8;
-    int grid = (n_nodes + W - 1) / W;
-    if (grid > 256) grid = 256;
+    int grid = (n_nodes + W - 1) / W + 1;       // + 1: each role rounds its list up to whole workgroups
+    if (grid > 256) grid = 256;                 // persistent: one workgroup per CU (a multiple of 8 -> XCD-aware partition per role)
     const int wg_limit = g_edge_wg_limit.load(std::memory_order_relaxed);
-    if (wg_limit >= 8 && grid > wg_limit) grid = wg_limit;
-    if (grid >= 64) grid &= ~7;
+    if (wg_limit >= 8 && grid > wg_limit) grid = wg_limit & ~7;
     if (grid < 2) grid = 2;                     // one workgroup per role at least
     profile_mark_begin(full_layer ? K_EDGE_X2H : K_EDGE_X2H_LISTED, s);
-    hipLaunchKernelGGL((edge_x2h_dual_kernel<W>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qt, qbuf, nbr, deg, lig, gen, e_w,
-                       n_nodes, out, list_pp, count_pp, list_gen, count_gen);
+    if (full_layer)
+        hipLaunchKernelGGL((edge_x2h_dual_kernel<W, true>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qt, qbuf, nbr, deg, lig, gen,
+                           e_w, n_nodes, out, list_pp, count_pp, list_gen, count_gen);
+    else
+        hipLaunchKernelGGL((edge_x2h_dual_kernel<W, false>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qt, qbuf, nbr, deg, lig, gen,
+                           e_w, n_nodes, out, list_pp, count_pp, list_gen, count_gen);
     profile_mark_end(s);
     return hipGetLastError();
 }

@@ -51,7 +51,7 @@ def test_forward_edge_kernels_fit_their_budget(tmp_path):
     h2x_listed = find(res, "edge_mfma_kernelILb0ELi8ELb1E")
     # round 4: the inference path's x2h stage = edge_x2h_dual_kernel (protein-only role with the in-register query fold + general
     # role in one launch); the plain x2h kernels remain for the taped training forward
-    dual = find(res, "edge_x2h_dual_kernelILi8E")
+    dual = find(res, "edge_x2h_dual_kernelILi8ELb1E")
     for k in (x2h, x2h_listed, dual):
         assert k["scratch"] == 0 and k["vgpr"] <= 256          # 8 waves per CU = 2 per SIMD need <= 256 registers
         assert k["lds"] <= 160 * 1024
