@@ -51,6 +51,11 @@ def model(synthetic_sd):
     return m.to(DEV)
 
 
+def model_sd(m):
+    """the model's weights as the CPU state dict the oracle takes"""
+    return {k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+
 def dev_inputs(g):
     x, h = g["x"].to(DEV), g["h"].to(DEV)
     gp = graph_ptr_from_batch(g["batch_idx"].to(DEV))
@@ -588,6 +593,40 @@ def test_static_context_cache_is_exact(model):
     lig = st["lig_flag"]
     has_lig_nbr = (lig[nbr.clamp(min=0).long()] & (nbr >= 0)).any(1) | lig
     assert 0.02 < float(has_lig_nbr.float().mean()) < 0.6
+
+
+def test_static_context_cache_is_exact_on_odd_graphs(model):
+    """the same bit-identity on the graphs that take the other branches of round 4's list / kNN code: a pocket smaller than the
+    neighbour count (pocket lists shorter than 32), 70 ligand atoms (second candidate slot of the rank-counting kNN merge), 130
+    (more than it handles: the scan), 900 pocket atoms (above the register-cached kNN size), a 2-atom ligand, and the whole thing
+    again as a linker batch (ligand atoms that cannot move).  Three steps with and without the cache; also every neighbour list the
+    cached call builds must equal the full search's (checked through the outputs: one swapped neighbour changes them)."""
+    rng = np.random.default_rng(123)
+    sizes = [(20, 5), (300, 70), (260, 130), (900, 12), (400, 2), (33, 40)]
+    pockets = [synthetic.make_pocket(rng, n) for n, _ in sizes]
+    for n_ctx in (None, [2, 30, 60, 5, 1, 10]):
+        batch = synthetic.make_batch(pockets, [m for _, m in sizes], rng, 13, n_ctx_list=n_ctx)
+        batch = synthetic.batch_to(batch, DEV)
+        n_lig = batch["ligand_pos"].shape[0]
+        g = torch.Generator(device=DEV).manual_seed(4)
+        noise = [(torch.randn(n_lig, 3, device=DEV, generator=g), torch.rand(n_lig, 13, device=DEV, generator=g)) for _ in range(3)]
+        outs = []
+        for cache in (True, False):
+            st = model.begin_sampling(batch, keep_trajectory=False, static_cache=cache)
+            assert (st["static_h"] is not None) == cache
+            for k, t in enumerate((999, 500, 3)):
+                model.denoise_step(st, t, noise=noise[k])
+            outs.append((st["x_lig"].clone(), st["c_lig"].clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "linker" if n_ctx else "denovo"
+        assert bool(torch.isfinite(outs[0][0]).all())
+        # and one step of the same batch against the CPU oracle (the reference's formulation)
+        cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        st = model.begin_sampling(batch, keep_trajectory=False)
+        model.denoise_step(st, 500, noise=noise[1])
+        c0 = torch.nn.functional.one_hot(cpu["ligand_atom_type"], 13).float()
+        x_ref, c_ref = OT.denoise_step(model_sd(model), cpu, cpu["ligand_pos"], c0, 500, noise[1][0].cpu(), noise[1][1].cpu(), 13)
+        close(st["x_lig"], x_ref, "x_{t-1} on odd graphs")
+        assert torch.equal(st["c_lig"].cpu().argmax(-1), c_ref.argmax(-1))
 
 
 def test_graph_replay_equals_eager_steps(golden_dir):
