@@ -24,7 +24,7 @@ EXPORTS = {
     "cbgx_workspace_bytes": (_sz, [_i, _i]),
     "cbgx_unitransformer_forward": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "cbgx_unitransformer_forward_cached": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                                                _vp, _vp, _vp, _vp, _sz, _vp]),
+                                                _vp, _vp, _vp, ctypes.c_uint, _vp, _sz, _vp]),
     "cbgx_knn_graph": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "cbgx_edge_gate": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "cbgx_x2h_attention": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),

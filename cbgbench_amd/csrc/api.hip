@@ -397,11 +397,21 @@ int cbgx_h2x_stack_forward(const float* packed, int num_layers, const float* x, 
         HIP_TRY(launch_knn_reg(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s, w.act, w.act_count));
         HIP_TRY(launch_gate_mfma(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s, w.act, w.act_count));
     }
+    // The source rows of the stack: the in-neighbours of the movable rows (and those rows themselves).  Only their PS columns are
+    // ever gathered, so only they are projected -- and only their rows of h are read, which is what lets the denoiser in front
+    // (cbgx_unitransformer_forward_cached, CBGX_FWD_H_ON_SOURCES) skip every other row of its last layers.
+    const int *src = nullptr, *src_n = nullptr;
+    if (g_edge_impl != 1) {
+        HIP_TRY(launch_mark_seed(gen_flag, gen_flag, n_nodes, w.fa1, s));
+        HIP_TRY(launch_mark_nbr(w.act, w.act_count, n_nodes, w.nbr, w.deg, w.fa1, s));
+        HIP_TRY(launch_build_active(w.fa1, n_nodes, w.rf_list[0], w.rf_count, s));
+        src = w.rf_list[0]; src_n = w.rf_count;
+    }
     const float* xc = x;
     for (int l = 0; l < num_layers; ++l) {
         float* xn = (l == num_layers - 1) ? x_out : w.xbuf[l & 1];
         HIP_TRY(launch_attention(false, packed + GATE_SIZE + (size_t)l * ATT_SIZE, xc, h, w.nbr, w.deg, lig_flag, gen_flag,
-                                 w.e_w, n_nodes, w.P, w.Qt, w.q, xn, nullptr, w.act, w.act_count, nullptr, nullptr, s));
+                                 w.e_w, n_nodes, w.P, w.Qt, w.q, xn, nullptr, w.act, w.act_count, src, src_n, s));
         xc = xn;
     }
     return CBGX_OK;
@@ -501,9 +511,10 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
                         const int32_t* graph_ptr, const uint8_t* lig_flag, const uint8_t* gen_flag, int n_nodes,
                         int n_graphs, float* x_out, float* h_out, float* logits, const float* static_h1,
                         const float* static_h2, const int32_t* static_nbr, const int32_t* static_deg,
-                        const float* static_ew, const float* static_r32sq, void* workspace, size_t workspace_bytes,
-                        void* stream) {
+                        const float* static_ew, const float* static_r32sq, unsigned flags, void* workspace,
+                        size_t workspace_bytes, void* stream) {
     if (n_nodes < 0 || n_graphs < 0 || num_layers < 1) return fail(CBGX_E_INVALID, "forward: bad sizes");
+    if (flags & ~CBGX_FWD_H_ON_SOURCES) return fail(CBGX_E_INVALID, "forward: unknown flags 0x%x", flags);
     if (n_nodes == 0) return CBGX_OK;
     if (!packed || !x || !h || !graph_ptr || !lig_flag || !gen_flag || !x_out || !workspace)
         return fail(CBGX_E_INVALID, "forward: NULL pointer");
@@ -524,7 +535,8 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
     //   A2 = A1 | nbr(A1)              its sources = destinations of the x2h before it;   A3 = A2 | nbr(A2) its sources
     // Rows outside these sets are simply not written in the last two feature buffers (and never read).  A1 is built in every
     // call: it is also the set of possible *sources* of an H2X block, so the h2x node projection PS is produced for those rows only.
-    const bool prune = (h_out == nullptr) && num_layers >= 3;
+    // (CBGX_FWD_H_ON_SOURCES: h_out is wanted on A1 only -- the destinations of the last x2h block -- so the same pruning holds)
+    const bool prune = (h_out == nullptr || (flags & CBGX_FWD_H_ON_SOURCES)) && num_layers >= 3;
     // Static-context cache (optional): static_h1 / static_h2 [N,128] hold the features that leave layer 0 / layer 1 in
     // the ligand-free pocket (rows of ligand atoms unused).  A protein node with no ligand atom among its neighbours sees
     // exactly that pocket in layer 0, so its output is the cached row; the set that differs grows by one hop per layer:
@@ -680,7 +692,7 @@ int cbgx_unitransformer_forward(const float* packed, int num_layers, int num_cla
                                 int n_nodes, int n_graphs, float* x_out, float* h_out, float* logits, void* workspace,
                                 size_t workspace_bytes, void* stream) {
     return forward_impl(packed, num_layers, num_classes, x, h, graph_ptr, lig_flag, gen_flag, n_nodes, n_graphs, x_out,
-                        h_out, logits, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes,
+                        h_out, logits, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, workspace, workspace_bytes,
                         stream);
 }
 
@@ -689,10 +701,10 @@ int cbgx_unitransformer_forward_cached(const float* packed, int num_layers, int 
                                        const uint8_t* gen_flag, int n_nodes, int n_graphs, const float* static_h1,
                                        const float* static_h2, const int32_t* static_nbr, const int32_t* static_deg,
                                        const float* static_ew, const float* static_r32sq, float* x_out, float* h_out,
-                                       float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+                                       float* logits, unsigned flags, void* workspace, size_t workspace_bytes, void* stream) {
     if (!static_h1 || !static_h2) return fail(CBGX_E_INVALID, "forward_cached: NULL static context");
     return forward_impl(packed, num_layers, num_classes, x, h, graph_ptr, lig_flag, gen_flag, n_nodes, n_graphs, x_out,
-                        h_out, logits, static_h1, static_h2, static_nbr, static_deg, static_ew, static_r32sq, workspace,
+                        h_out, logits, static_h1, static_h2, static_nbr, static_deg, static_ew, static_r32sq, flags, workspace,
                         workspace_bytes, stream);
 }
 

@@ -407,7 +407,8 @@ class DiffBP(BatchesInFlight, nn.Module):
         x[lig_rows] = st["x_lig"]
         h[lig_rows] = self.context_embedder.embed_ligand(st["c_lig"])
         xo, ho, logits = self.denoiser(x=x, h=h, batch_idx=st["batch_idx"], lig_flag=st["lig_flag"], gen_flag=st["gen_flag"],
-                                       graph_ptr=st["graph_ptr"], static_h=st["static_h"])
+                                       graph_ptr=st["graph_ptr"], static_h=st["static_h"],
+                                       h_on_sources=st["static_h"] is not None)      # h' is only read by the CoM stack (its source rows)
         eps_t, eps_com = self.com_head(xo[lig_rows], bl, x, ho, st["gen_flag"], st["lig_flag"], st["batch_idx"],
                                        graph_ptr=st["graph_ptr"])
         eps, u = noise if noise is not None else (None, None)
@@ -435,7 +436,8 @@ class DiffBP(BatchesInFlight, nn.Module):
             _native.ptr(emb.ligand_indicator.weight), _native.ptr(emb.ligand_indicator.bias),
             _native.ptr(x), _native.ptr(h), stream), "cbgx_targetdiff_prologue")
         xo, ho, logits = self.denoiser(x=x, h=h, batch_idx=st["batch_idx"], lig_flag=st["lig_flag"], gen_flag=st["gen_flag"],
-                                       graph_ptr=st["graph_ptr"], static_h=st["static_h"])
+                                       graph_ptr=st["graph_ptr"], static_h=st["static_h"],
+                                       h_on_sources=st["static_h"] is not None)      # h' is only read by the CoM stack (its source rows)
         x_com = self.com_head.stack_forward(x, ho, st["graph_ptr"], st["lig8"], st["gen8"])
         if noise is not None:
             eps, u = noise[0].float().contiguous(), noise[1].float().contiguous()

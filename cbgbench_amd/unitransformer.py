@@ -332,7 +332,7 @@ class UniTransformer(nn.Module):
         return (out[0], out[1], nbr.contiguous(), deg, ew, r32sq)
 
     def forward(self, x, h, batch_idx, lig_flag, gen_flag, graph_ptr=None, need_h=True, static_h=None,
-                ligand_outputs_only=False, workspace=None):
+                ligand_outputs_only=False, workspace=None, h_on_sources=False):
         """Same contract as the reference (unitransformer.py:102-123): returns (x', h', logits).
         ``batch_idx`` must be sorted (compose_context guarantees it).  ``graph_ptr`` (int32 CSR
         offsets) may be passed to avoid recomputing it from ``batch_idx`` every call.  ``need_h=False`` (samplers that
@@ -343,6 +343,9 @@ class UniTransformer(nn.Module):
         ``ligand_outputs_only`` (training): the caller promises that its loss reads ``x'`` on ``gen_flag`` rows and the logits
         on ``lig_flag`` rows only and ignores ``h'`` (TargetDiff / DiffSBDD losses); the backward may then be pruned to
         the receptive field of those rows.  Without the promise the full backward runs.
+        ``h_on_sources`` (inference, with ``static_h``): the caller reads ``h'`` only on the rows gen | lig | in-neighbours of gen
+        rows -- what an H2X stack on the same coordinates reads (DiffBP's CoMPredictor) -- so the last two layers are pruned as
+        with ``need_h=False``; the other rows of ``h'`` are undefined, the logits are defined on those rows only.
         ``workspace`` (inference): caller-owned scratch memory of at least ``workspace_bytes(N, B)`` bytes instead of the per-stream
         one the module keeps -- a captured hipGraph bakes the pointer in, so every captured sampling state brings its own."""
         if not x.is_cuda:
@@ -378,7 +381,8 @@ class UniTransformer(nn.Module):
                 _native.ptr(packed), self.num_layers, self.out_classes, _native.ptr(x), _native.ptr(h),
                 _native.ptr(graph_ptr), _native.ptr(lig), _native.ptr(gen), N, B, _native.ptr(static_h[0]),
                 _native.ptr(static_h[1]), *[_native.ptr(t) for t in static_h[2:6]], _native.ptr(x_out),
-                _native.ptr(h_out), _native.ptr(logits), _native.ptr(ws), ws.numel(), _native.current_stream(device))
+                _native.ptr(h_out), _native.ptr(logits), 1 if (h_on_sources and need_h) else 0, _native.ptr(ws), ws.numel(),
+                _native.current_stream(device))
         else:
             rc = lib.cbgx_unitransformer_forward(
                 _native.ptr(packed), self.num_layers, self.out_classes, _native.ptr(x), _native.ptr(h),

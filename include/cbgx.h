@@ -122,14 +122,19 @@ int cbgx_unitransformer_forward(const float *packed, int num_layers, int num_cla
  * ligand-free pockets' cbgx_knn_graph lists (in composed row numbers) and cbgx_edge_gate values, static_r32sq [N] = squared
  * distance to the last (32nd) of those neighbours, +inf where deg < 32.  A protein node whose nearest ligand atom is not
  * closer than that keeps its cached list and gate; only the others get fresh ones.
- * Results are bit-identical to cbgx_unitransformer_forward.  Requires num_layers >= 4 (otherwise the cache is ignored). */
+ * Results are bit-identical to cbgx_unitransformer_forward.  Requires num_layers >= 4 (otherwise the cache is ignored).
+ * flags: CBGX_FWD_H_ON_SOURCES -- the caller reads h_out only on the rows A1 = gen_flag | lig_flag | in-neighbours of gen_flag rows
+ *   (what an H2X stack run on the same coordinates reads: DiffBP's CoMPredictor, diffbp.py:79-101; pass the same rows to
+ *   cbgx_h2x_stack_forward).  The last two x2h blocks are then pruned to the receptive field of those rows exactly as when
+ *   h_out is NULL; rows of h_out outside A1 are left unwritten.  Without the flag h_out is defined on every row (no pruning). */
+#define CBGX_FWD_H_ON_SOURCES 1u
 int cbgx_unitransformer_forward_cached(const float *packed, int num_layers, int num_classes,
                                        const float *x, const float *h, const int32_t *graph_ptr,
                                        const uint8_t *lig_flag, const uint8_t *gen_flag, int n_nodes, int n_graphs,
                                        const float *static_h1, const float *static_h2,
                                        const int32_t *static_nbr, const int32_t *static_deg,
                                        const float *static_ew, const float *static_r32sq,
-                                       float *x_out, float *h_out, float *logits,
+                                       float *x_out, float *h_out, float *logits, unsigned flags,
                                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- stages (also what the parity tests call one by one) ------------------------------------- */
