@@ -383,22 +383,20 @@ def usable_uuid(hw):
 
 
 def distinct_devices(dev, world):
-    """Number of distinct physical GPUs over all ranks: all-gather of device_identity (environment + index) AND of the hardware
-    uuid / PCI address.  When every rank reports a usable uuid the two counts must agree -- a launch whose environment says
-    "N different devices" while the uuids say otherwise (or the reverse) is refused rather than mislabelled."""
+    """(n_env, n_uuid): the number of distinct physical GPUs over all ranks by device_identity (environment + index: what decides)
+    and by hardware uuid (None unless every rank reports a usable one).  The uuid count is a CROSS-CHECK that is reported, not
+    enforced: some ROCm builds return the same uuid for every GPU, which must not stop a correct 8-GPU launch -- RCCL itself refuses
+    two ranks on one device."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
-        return 1
+        u = usable_uuid(device_hardware_id(dev))
+        return 1, (1 if u else None)
     ids = [None] * world
     dist.all_gather_object(ids, (device_identity(dev), device_hardware_id(dev)))
     n_env = len(set(i for i, _ in ids))
     uuids = [usable_uuid(hw) for _, hw in ids]
-    if all(u is not None for u in uuids):
-        n_uuid = len(set(uuids))
-        if n_uuid != n_env:
-            raise SystemExit(f"bench.py: the ranks' device environment names {n_env} distinct GPU(s) but their hardware uuids "
-                             f"{n_uuid}: refusing to report n_gpus ({sorted(set(uuids))})")
-    return n_env
+    n_uuid = len(set(uuids)) if all(u is not None for u in uuids) else None
+    return n_env, n_uuid
 
 
 def parse_args(argv=None):
@@ -465,7 +463,7 @@ def main():
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     # n_gpus must mean physical GPUs: every rank names its device, and a launch whose ranks share GPUs is refused -- unless it is
     # the declared gloo dry run of the multi-rank path on one GPU, which then reports the devices it really used next to `ranks`
-    n_dev = distinct_devices(dev, world)
+    n_dev, n_uuid = distinct_devices(dev, world)
     if n_dev != world and not gloo_shared:
         raise SystemExit(f"bench.py: {world} ranks on {n_dev} distinct GPU(s); one GPU per rank is required "
                          f"(CBGX_DIST_BACKEND=gloo declares a shared-GPU dry run)")
@@ -475,6 +473,10 @@ def main():
                        and args.graphs_per_batch == 340 and args.graph == "off")
     out = bench_train(args, rank, world, dev) if args.workload == "train" else bench_sampling(args, rank, world, dev)
     out["n_gpus"] = n_dev
+    if n_uuid is not None:
+        out["config"]["devices_by_uuid"] = n_uuid      # hardware cross-check of n_gpus (informative: see distinct_devices)
+        if n_uuid != n_dev:
+            out["config"]["note_uuid"] = f"device uuids name {n_uuid} distinct GPU(s), the launch environment {n_dev}"
     if n_dev != world:
         out["ranks"] = world
         out["config"]["note_shared_gpus"] = f"{world} ranks shared {n_dev} GPU(s) over gloo: a dry run of the multi-rank path, not a scaling point"
