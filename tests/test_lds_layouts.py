@@ -71,3 +71,41 @@ def test_wbv_swizzle_is_conflict_free_where_the_plain_head_xor_was_two_way():
                     slots = [((16 * hh + 4 * (lane >> 4) + j) ^ mask(lane & 15)) % 16 for lane in g]
                     worst[name] = max(worst[name], max(slots.count(s) for s in set(slots)))
     assert worst == {"head": 2, "swizzle": 1}
+
+
+def test_protein_only_image_and_fold_table():
+    """Round 4: the LDS image of the protein-only x2h role (layout.h A_IMG_PP) fills exactly the array of the general image, and the
+    fold table [t 8][d 8][lane 64][4] read as `base + 4 lane + 2048 t + 256 d` (edge_mfma.hip, edge_major_half<.., FOLD>) gives
+    lane (c = head, q) the 32 values Qt[c][16 t + 4 q + r] = sum_d q[8c + d] Wbk[8c + d][16 t + 4 q + r] / sqrt(8) -- the operand order
+    of the score MFMAs -- with conflict-free linear ds_read_b128.  Restated with numpy against the plain definition."""
+    import numpy as np
+    layout = open(os.path.join(ROOT, "cbgbench_amd", "csrc", "layout.h")).read()
+    H, NT = 128, 4
+    img_general = 2 * NT * 8 * FRAG_BLK + NT * 2 * H + 4 * H + H * H            # frag_k | frag_v | dwt | ln | wbv
+    img_pp = 2 * 8 * FRAG_BLK + 4 * H + H * H + H * H                            # type-3 k | type-3 v | ln | wbv | wfold
+    assert img_general == img_pp == 38400
+    assert "constexpr size_t PP_IMG_SIZE = PP_WFOLD + (size_t)H * H;" in layout
+    src = open(os.path.join(ROOT, "cbgbench_amd", "csrc", "edge_mfma.hip")).read()
+    assert "wf + 2048 * t + 256 * d" in src and "lds + PP_WFOLD + 4 * lane" in src
+    assert "const int r = u & 3, lane = (u >> 2) & 63, d = (u >> 8) & 7, t = u >> 11;" in src      # pack_pp_image_kernel
+    rng = np.random.default_rng(0)
+    wbk = rng.standard_normal((H, H)).astype(np.float32)          # (out n, in m): the second k Linear
+    q = rng.standard_normal(H).astype(np.float32)
+    table = np.empty(H * H, np.float32)
+    for u in range(H * H):                                        # pack_pp_image_kernel
+        r, lane, d, t = u & 3, (u >> 2) & 63, (u >> 8) & 7, u >> 11
+        c, qq = lane & 15, lane >> 4
+        table[u] = wbk[8 * c + d, 16 * t + 4 * qq + r] * np.float32(0.35355339059327376220)
+    qt_ref = np.stack([(q[8 * a:8 * a + 8, None] * wbk[8 * a:8 * a + 8, :]).sum(0) for a in range(16)]) / np.sqrt(8.0)   # [head][m]
+    for lane in range(64):
+        c, qq = lane & 15, lane >> 4
+        for t in range(8):
+            acc = np.zeros(4, np.float64)
+            for d in range(8):
+                base = 4 * lane + 2048 * t + 256 * d
+                assert base % 4 == 0                               # one aligned 16-byte read, lane stride 16 bytes: no bank conflict
+                acc += np.float64(q[8 * c + d]) * table[base:base + 4]
+            np.testing.assert_allclose(acc, qt_ref[c, 16 * t + 4 * qq:16 * t + 4 * qq + 4], rtol=2e-6, atol=2e-6)
+    # the h2x image's head rows of the second v Linear (B operand of the value contraction): lane (c = head, q) at (64 t + lane) * 4
+    assert "pb.att[blockIdx.y][A_IMG + IMG_WBV + ((64 * t + 16 * q + head) << 2) + r] = pb.wv1[blockIdx.y][idx];" in src
+    assert "lds + IMG_WBV + 4 * lane" in src and "ld4(lds_brow + 256 * t)" in src
