@@ -86,7 +86,11 @@ __device__ __forceinline__ void split8(const float (&v)[8], float up, half8& hi8
 // ------------------------------------------------------------------------------------------------
 constexpr int NP_CHUNK = 2 * 4 * 4 * 64 * 4;  // 8192 floats = 32 KB (two f16 per float slot)
 constexpr int NP_CHUNKS = PROW / 64;          // 10
-constexpr int NP_WGS_PER_CU = 3;              // node_proj_kernel: __launch_bounds__(256, NP_WGS_PER_CU), 32 KB of LDS each
+#ifndef CBGX_NPROJ_CPW
+#define CBGX_NPROJ_CPW 2              // column chunks per workgroup (A/B knob of scripts/build_variant.py: 2 = two resident tables,
+#endif                                // the rows of a tile loaded and split once per TWO chunks, two workgroups per CU)
+constexpr int NP_CPW = CBGX_NPROJ_CPW;
+constexpr int NP_WGS_PER_CU = NP_CPW == 1 ? 3 : 2;   // node_proj_kernel: __launch_bounds__(256, NP_WGS_PER_CU), NP_CPW x 32 KB of LDS each
 constexpr int NP_RESIDENT_WGS = 256 * NP_WGS_PER_CU;
 
 typedef float lds_fx4 __attribute__((ext_vector_type(4)));
@@ -156,10 +160,11 @@ __device__ __forceinline__ ProjTile proj_tile_load(const float* __restrict__ h, 
     return t;
 }
 
-// one 16-row tile of one wave against the resident chunk: row scale + split, 48 MFMAs (B from LDS), scaled stores
-__device__ __forceinline__ void proj_tile_compute(const ProjTile& cur, const half8* __restrict__ Bh, const half8* __restrict__ Bl,
-                                                  const float4 bP, const float4 bL, const float4 ci, float* __restrict__ P, int ch,
-                                                  int c, int q) {
+// one 16-row tile of one wave against the workgroup's resident chunk(s): row scale + split ONCE, then per chunk 48 MFMAs (B from LDS)
+// and the scaled stores
+struct ProjChunk { float4 bP, bL, ci; int ch; };
+__device__ __forceinline__ void proj_tile_compute(const ProjTile& cur, const half8* __restrict__ Bh0, const ProjChunk (&pc)[NP_CPW],
+                                                  int n_ch, float* __restrict__ P, int c, int q) {
     half8 ah[4], al[4];
     float rinv[4];
     {
@@ -179,28 +184,36 @@ __device__ __forceinline__ void proj_tile_compute(const ProjTile& cur, const hal
             split8(v, up, ah[u], al[u]);
         }
     }
-    floatx4 acc[4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < NP_CPW; ++k) {
+        if (k >= n_ch) break;          // workgroup-uniform: the last group of a launch may hold fewer chunks
+        const half8* Bh = Bh0 + (size_t)k * (NP_CHUNK / 4);      // chunk k's table: NP_CHUNK floats = NP_CHUNK / 4 half8
+        const half8* Bl = Bh + 4 * 4 * 64;
+        floatx4 acc[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        half8 bh[4], bl[4];
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) { bh[ct] = Bh[(ct * 4 + u) * 64]; bl[ct] = Bl[(ct * 4 + u) * 64]; }
+        for (int u = 0; u < 4; ++u) {
+            half8 bh[4], bl[4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(ah[u], bl[ct], acc[ct]);
+            for (int ct = 0; ct < 4; ++ct) { bh[ct] = Bh[(ct * 4 + u) * 64]; bl[ct] = Bl[(ct * 4 + u) * 64]; }
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(al[u], bh[ct], acc[ct]);
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(ah[u], bl[ct], acc[ct]);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(ah[u], bh[ct], acc[ct]);
-    }
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(al[u], bh[ct], acc[ct]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (cur.orow[r] >= 0) {
-            const float4 b = ((cur.lgr >> r) & 1) ? bL : bP;
-            float4 o = {fmaf(acc[0][r] * rinv[r], ci.x, b.x), fmaf(acc[1][r] * rinv[r], ci.y, b.y),
-                        fmaf(acc[2][r] * rinv[r], ci.z, b.z), fmaf(acc[3][r] * rinv[r], ci.w, b.w)};
-            *reinterpret_cast<float4*>(P + (size_t)cur.orow[r] * PROW + 64 * ch + 4 * c) = o;
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMAH32(ah[u], bh[ct], acc[ct]);
+        }
+        const float4 bP = pc[k].bP, bL = pc[k].bL, ci = pc[k].ci;
+        const int ch = pc[k].ch;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (cur.orow[r] >= 0) {
+                const float4 b = ((cur.lgr >> r) & 1) ? bL : bP;
+                float4 o = {fmaf(acc[0][r] * rinv[r], ci.x, b.x), fmaf(acc[1][r] * rinv[r], ci.y, b.y),
+                            fmaf(acc[2][r] * rinv[r], ci.z, b.z), fmaf(acc[3][r] * rinv[r], ci.w, b.w)};
+                *reinterpret_cast<float4*>(P + (size_t)cur.orow[r] * PROW + 64 * ch + 4 * c) = o;
+            }
         }
     }
 }
@@ -213,17 +226,22 @@ __global__ __launch_bounds__(256, NP_WGS_PER_CU) void node_proj_kernel(const flo
                                                            const uint8_t* __restrict__ lig, float* __restrict__ P,
                                                            int n_nodes, const int* __restrict__ rows,
                                                            const int* __restrict__ n_rows_ptr, unsigned chunk_mask) {
-    __shared__ __attribute__((aligned(16))) float lds[NP_CHUNK];
+    __shared__ __attribute__((aligned(16))) float lds[NP_CPW * NP_CHUNK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
     const int n_rows = LISTED ? *n_rows_ptr : n_nodes;
     const int n_tiles = (n_rows + 63) / 64;
+    int chs[NP_CPW], n_ch = 0;       // workgroup (x, y) owns the selected chunks NP_CPW y .. NP_CPW y + NP_CPW - 1
     {
         unsigned m = chunk_mask;
-        for (unsigned k = 0; k < blockIdx.y; ++k) m &= m - 1;
-        chunk_mask = m & (0u - m);
+        for (unsigned k = 0; k < NP_CPW * blockIdx.y; ++k) m &= m - 1;
+#pragma unroll
+        for (int k = 0; k < NP_CPW; ++k) {
+            chs[k] = m ? __ffs(m) - 1 : 0;
+            n_ch += m != 0;
+            m &= m - 1;
+        }
     }
-    if ((int)blockIdx.x >= n_tiles || chunk_mask == 0) return;   // whole workgroup: nothing to do
-    const int ch = __ffs(chunk_mask) - 1;
+    if ((int)blockIdx.x >= n_tiles || n_ch == 0) return;   // whole workgroup: nothing to do
     const int step = 64 * (int)gridDim.x;
     int row0 = blockIdx.x * 64 + wave * 16;
     // first tile's rows requested before the table fill: the round trips overlap
@@ -234,13 +252,18 @@ __global__ __launch_bounds__(256, NP_WGS_PER_CU) void node_proj_kernel(const flo
         idx1 = proj_idx_load<LISTED>(rows, n_rows, row0 + step, c, q);
         cur = proj_tile_load(h, lig, idx0, q);
     }
-    lds_fill_f4<NP_CHUNK / 4 / 256>(lds, att + A_NPROJ_FRAG + (size_t)ch * NP_CHUNK, 0, NP_CHUNK / 4, tid);
     const float* bias = att + A_BN2;  // [dst class][640]: bias + type column of a protein source
-    const float4 bP = nld4(bias + 64 * ch + 4 * c), bL = nld4(bias + PROW + 64 * ch + 4 * c);
-    const float4 ci = nld4(att + A_NPROJ_CINV + 64 * ch + 4 * c);     // 2^-kc of this lane's four columns
+    ProjChunk pc[NP_CPW];
+#pragma unroll
+    for (int k = 0; k < NP_CPW; ++k) {
+        const int ch = chs[k];
+        if (k < n_ch) lds_fill_f4<NP_CHUNK / 4 / 256>(lds + (size_t)k * NP_CHUNK, att + A_NPROJ_FRAG + (size_t)ch * NP_CHUNK, 0, NP_CHUNK / 4, tid);
+        pc[k].ch = ch;
+        pc[k].bP = nld4(bias + 64 * ch + 4 * c); pc[k].bL = nld4(bias + PROW + 64 * ch + 4 * c);
+        pc[k].ci = nld4(att + A_NPROJ_CINV + 64 * ch + 4 * c);     // 2^-kc of this lane's four columns
+    }
     __syncthreads();
-    const half8* Bh = reinterpret_cast<const half8*>(lds) + lane;   // [ct][u][lane]
-    const half8* Bl = Bh + 4 * 4 * 64;
+    const half8* Bh = reinterpret_cast<const half8*>(lds) + lane;   // chunk k at + k NP_CHUNK / 4: [ct][u][lane]
     // two tiles per trip, (current, next) tile registers swapping roles instead of being copied (40 registers per tile)
     ProjTile other;
     ProjIdx idx2;
@@ -250,12 +273,12 @@ __global__ __launch_bounds__(256, NP_WGS_PER_CU) void node_proj_kernel(const flo
         other = proj_tile_load(h, lig, idx1, q);
         idx2 = proj_idx_load<LISTED>(rows, n_rows, row0 + 2 * step, c, q);
         __builtin_amdgcn_sched_barrier(0);
-        proj_tile_compute(cur, Bh, Bl, bP, bL, ci, P, ch, c, q);
+        proj_tile_compute(cur, Bh, pc, n_ch, P, c, q);
         if (tile + (int)gridDim.x >= n_tiles) break;
         cur = proj_tile_load(h, lig, idx2, q);
         idx1 = proj_idx_load<LISTED>(rows, n_rows, row0 + 3 * step, c, q);
         __builtin_amdgcn_sched_barrier(0);
-        proj_tile_compute(other, Bh, Bl, bP, bL, ci, P, ch, c, q);
+        proj_tile_compute(other, Bh, pc, n_ch, P, c, q);
     }
 }
 
@@ -1037,7 +1060,7 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
     // quarter full: 100 us instead of 67) -- and gridDim.x a multiple of 8 so that the workgroups of one row tile -- linear ids
     // x + y gridDim.x -- land on one XCD and its L2 serves the tile's rows to all of them
     auto proj_grid = [&](unsigned mask) {
-        const int py = __builtin_popcount(mask);
+        const int py = (__builtin_popcount(mask) + NP_CPW - 1) / NP_CPW;
         int gx = NP_RESIDENT_WGS / py;
         if (gx >= 8) gx &= ~7;
         return dim3((unsigned)min(tiles, gx), (unsigned)py);

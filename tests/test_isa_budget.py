@@ -127,10 +127,10 @@ def test_node_and_graph_kernels_do_not_spill(tmp_path):
         k = find(res, name)
         assert k["scratch"] == 0 and k["lds"] <= 64 * 1024 and k["vgpr"] <= 256, (name, k)   # 64 KB: two workgroups per CU
     for name in ("node_proj_kernelILb0E", "node_proj_kernelILb1E"):
-        # one resident 32 KB chunk table per workgroup, three 4-wave workgroups per CU (3 waves per SIMD: <= 168 registers), and no
+        # two resident 32 KB chunk tables per workgroup, two 4-wave workgroups per CU (2 waves per SIMD: <= 256 registers), and no
         # spill: a scratch reload's vmcnt(0) would drain the next tile's rows, which are in flight across the whole MFMA block
         k = find(res, name)
-        assert k["scratch"] == 0 and k["lds"] <= 32 * 1024 and k["vgpr"] <= 168, (name, k)
+        assert k["scratch"] == 0 and k["lds"] <= 64 * 1024 and k["vgpr"] <= 256, (name, k)
     res, _ = kernel_resources("graph_mfma.hip", tmp_path)
     for name in ("knn_graph_reg_kernel", "edge_gate_mfma_kernel"):
         k = find(res, name)
