@@ -42,6 +42,10 @@ EXPORTS = {
                                   _vp, _vp]),
     "cbgx_diffsbdd_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_float, ctypes.c_float,
                                 ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cbgx_targetdiff_train_noise": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cbgx_targetdiff_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(_vp), _vp, _vp, _vp,
+                                  _vp, _vp, _vp]),
+    "cbgx_targetdiff_loss_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cbgx_train_tape_bytes": (_sz, [_i, _i]),
     "cbgx_train_workspace_bytes": (_sz, [_i]),
     "cbgx_unitransformer_forward_train": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz,

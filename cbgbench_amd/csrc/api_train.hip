@@ -2,6 +2,7 @@
 // attention blocks (what the parity tests call) and of the whole denoiser.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 
@@ -32,6 +33,7 @@ constexpr int NODE_GRID = 256;    // persistent workgroups of the node-level red
 constexpr int FOLD = 8;           // slab reductions are two-level: n_slabs -> FOLD (slab_fold_kernel) -> 1 (reduce_store)
 constexpr int GATE_GRID = 1024;  // gate weight-gradient kernel: 160-thread workgroups, four per CU keep every SIMD busy
 constexpr int MAX_SPLITS = 128;   // node groups of the weight-gradient products (one [128 x 640] partial slab each)
+constexpr int QLN_SLOTS = 64;     // query-LayerNorm affine gradient accumulators (atomics): one zeroed slot per attention block of a backward
 
 // ---- tape: what the taped forward keeps for the backward ------------------------------------------------
 struct Tape {
@@ -68,6 +70,9 @@ static Tape carve_tape(void* base, int n, int L) {
 // ---- backward workspace -----------------------------------------------------------------------------------
 struct TrainWs {
     float *P, *Qt, *Gt, *T, *S, *gb, *sw, *qs, *dqb, *zb, *dP, *gh, *gx[2], *de_w, *E8, *tmp, *partial, *folded, *qln, *nk;
+    // an attention block's three slab sets live side by side (edge slabs in `partial`), so that ONE fold launch and ONE
+    // reduce-and-store launch per block serve all of them
+    float *partial_node, *partial_wgrad, *folded_node, *folded_wgrad;
     int *act, *act_count;
     uint8_t* mask;        // receptive field of the loss, walked backwards (see cbgx_unitransformer_backward)
     int *rf_list[2], *rf_count;
@@ -117,7 +122,11 @@ static TrainWs carve_train(void* base, int n) {
     w.partial_floats = partial_floats_needed();
     w.partial = (float*)take(w.partial_floats * 4);
     w.folded = (float*)take((size_t)FOLD * H * PROW * 4);
-    w.qln = (float*)take(2 * H * 4);
+    w.qln = (float*)take((size_t)QLN_SLOTS * 2 * H * 4);
+    w.partial_node = (float*)take((size_t)NODE_GRID * NS_SIZE * 4);
+    w.partial_wgrad = (float*)take((size_t)MAX_SPLITS * H * PROW * 4);
+    w.folded_node = (float*)take((size_t)FOLD * NS_SIZE * 4);
+    w.folded_wgrad = (float*)take((size_t)FOLD * H * PROW * 4);
     w.nk = (float*)take(BX_NK_FLOATS * 4);     // x2h edge backward: the key path of every wave in flight, parked between two phases
     w.total = off;
     return w;
@@ -159,7 +168,9 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
                                     const int32_t* nbr, const int32_t* deg, const uint8_t* lig, const float* e_w,
                                     const int* rows, const int* n_rows, int n, TrainWs& w, float* gh, float* dx,
                                     float* de_w, float* const* grads, hipStream_t s, const float* P_saved = nullptr,
-                                    const float* Qt_saved = nullptr) {
+                                    const float* Qt_saved = nullptr, float* qln = nullptr, const float* gh_src = nullptr) {
+    // `qln` [2][128]: zeroed accumulator of the query LayerNorm's affine gradients (nullptr: w.qln, zeroed here);
+    // `gh_src`: gh = gh_src + (this block's contribution) instead of gh += (the caller then needs no snapshot of g_out == gh_src)
     // x2h blocks run the one-wave-per-node backward (8 nodes in flight per workgroup); h2x blocks and, in libcbgx_xcheck.so,
     // cbgx_debug_set_edge_kernel(2) the second-generation workgroup-per-node kernel
     const bool gen3 = x2h && g_edge_impl == 0;
@@ -185,6 +196,10 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     }
     if (x2h) HIP_TRY(launch_fold_grad(att, g_out, n, w.Gt, w.gb, s));
     HIP_TRY(hipMemsetAsync(w.dP, 0, (size_t)n * PROW * sizeof(float), s));
+    if (!qln) {
+        qln = w.qln;
+        HIP_TRY(hipMemsetAsync(qln, 0, 2 * H * sizeof(float), s));
+    }
     // libcbgx_xcheck.so only: cbgx_debug_set_edge_kernel(1) selects the first-generation (VALU) backward kernels as an
     // on-device cross-check
 #ifdef CBGX_XCHECK
@@ -202,13 +217,24 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     float *k0w = grads[0], *k0b = grads[1], *kg = grads[2], *kb = grads[3], *k1w = grads[4], *k1b = grads[5];
     float *v0w = grads[6], *v0b = grads[7], *vg = grads[8], *vb = grads[9], *v1w = grads[10], *v1b = grads[11];
     float *q0w = grads[12], *q0b = grads[13], *qg = grads[14], *qb = grads[15], *q1w = grads[16], *q1b = grads[17];
+    // The block's three slab sets (edge kernel, node-level reductions, dense projection) are reduced at its end: one first-level
+    // fold launch for the sets with more than FOLD slabs, one reduce-and-store launch for every gradient tensor of the block
+    // (six launches and three 512-byte fills per block before; the sums are the same, slab by slab).
     RsBatch rb;
     rb.n = 0;
+    FoldBatch fb;
+    fb.n = 0;
     auto piece = [&](const float* src, int nsl, size_t stride, int ld, int rws, int cls, float* dst, int dld, int tr) {
         rb.p[rb.n++] = RsPiece{src, dst, stride, nsl, ld, rws, cls, dld, tr};
     };
+    const float* fz; int fn; size_t fs;
+    auto folded = [&](const float* src, int nsl, size_t stride, int size, float* dst) {
+        if (nsl <= FOLD) { fz = src; fn = nsl; fs = stride; return; }
+        fb.j[fb.n++] = FoldJob{src, dst, stride, nsl, size};
+        fz = dst; fn = FOLD; fs = (size_t)size;
+    };
     {   // edge-indexed weight gradients: type / rbf columns of the first Linears, LayerNorm affine
-        FOLDED(w.partial, eg, PB_SIZE, PB_SIZE);
+        folded(w.partial, eg, PB_SIZE, PB_SIZE, w.folded);
         piece(fz + PB_WT, fn, fs, 2 * H, NT, H, k0w, KV_IN, 1);
         piece(fz + PB_WT + H, fn, fs, 2 * H, NT, H, v0w, KV_IN, 1);
         piece(fz + PB_WR, fn, fs, 2 * H, NT * G, H, k0w + NT, KV_IN, 1);
@@ -221,18 +247,15 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
             piece(fz + PB_WBV16, fn, fs, H, HEADS, H, v1w, H, 0);
             piece(fz + PB_BBV16, fn, fs, HEADS, 1, HEADS, v1b, HEADS, 0);
         }
-        HIP_TRY(launch_reduce_store_multi(rb, s));
-        rb.n = 0;
     }
-    // query MLP backward (fills dP[:, 512:640]); its LayerNorm affine gradients are accumulated into w.qln by atomics
+    // query MLP backward (fills dP[:, 512:640]); its LayerNorm affine gradients are accumulated into qln by atomics
     {
         const int tiles = (n + 15) / 16, qgrid = tiles < 4 * NODE_GRID ? tiles : 4 * NODE_GRID;   // ~43 KB LDS: 3 per CU
-        HIP_TRY(hipMemsetAsync(w.qln, 0, 2 * H * sizeof(float), s));
 #ifdef CBGX_XCHECK
-        if (!mfma) HIP_TRY(launch_q_backward(att, Pn, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, w.qln, qgrid, s));
+        if (!mfma) HIP_TRY(launch_q_backward(att, Pn, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, qln, qgrid, s));
         else
 #endif
-            HIP_TRY(launch_q_backward_mfma(att, Pn, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, w.qln, qgrid, s));
+            HIP_TRY(launch_q_backward_mfma(att, Pn, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, qln, qgrid, s));
     }
     // node-level reductions, all into one slab per workgroup (NS_* layout), folded and scattered once:
     //   second Linears: dWbk = sum_i (q_i / sqrt 8) (x) T_i ;  x2h: dWbv = sum_i G_i (x) S_i ;  dWq1 = sum_i dq_i (x) z_i
@@ -242,17 +265,17 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
 #else
     const auto outer = launch_outer_accum_mfma;
 #endif
-    HIP_TRY(outer(true, w.qs, w.T, rows, n_rows, n, w.partial + NS_WBK, NS_SIZE, ng, s));
+    float* pn = w.partial_node;
+    HIP_TRY(outer(true, w.qs, w.T, rows, n_rows, n, pn + NS_WBK, NS_SIZE, ng, s));
     if (x2h) {
-        HIP_TRY(outer(true, g_out, w.S, rows, n_rows, n, w.partial + NS_WBV, NS_SIZE, ng, s));
-        HIP_TRY(launch_colsum(g_out, H, H, w.sw, rows, n_rows, n, w.partial + NS_V1B, NS_SIZE, ng, s));
+        HIP_TRY(outer(true, g_out, w.S, rows, n_rows, n, pn + NS_WBV, NS_SIZE, ng, s));
+        HIP_TRY(launch_colsum(g_out, H, H, w.sw, rows, n_rows, n, pn + NS_V1B, NS_SIZE, ng, s));
     }
-    HIP_TRY(outer(false, w.dqb, w.zb, rows, n_rows, n, w.partial + NS_WQ1, NS_SIZE, ng, s));
-    HIP_TRY(launch_colsum(w.dqb, H, H, nullptr, rows, n_rows, n, w.partial + NS_Q1B, NS_SIZE, ng, s));
-    HIP_TRY(launch_colsum(w.dP, PROW, PROW, nullptr, nullptr, nullptr, n, w.partial + NS_DP, NS_SIZE, ng, s));
-    HIP_TRY(hipMemsetAsync(k1b, 0, H * sizeof(float), s));   // the key bias cancels in the softmax
+    HIP_TRY(outer(false, w.dqb, w.zb, rows, n_rows, n, pn + NS_WQ1, NS_SIZE, ng, s));
+    HIP_TRY(launch_colsum(w.dqb, H, H, nullptr, rows, n_rows, n, pn + NS_Q1B, NS_SIZE, ng, s));
+    HIP_TRY(launch_colsum(w.dP, PROW, PROW, nullptr, nullptr, nullptr, n, pn + NS_DP, NS_SIZE, ng, s));
     {
-        FOLDED(w.partial, ng, NS_SIZE, NS_SIZE);
+        folded(pn, ng, NS_SIZE, NS_SIZE, w.folded_node);
         piece(fz + NS_WBK, fn, fs, H, H, H, k1w, H, 0);
         piece(fz + NS_WQ1, fn, fs, H, H, H, q1w, H, 0);
         piece(fz + NS_Q1B, fn, fs, H, 1, H, q1b, H, 0);
@@ -263,32 +286,33 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
             piece(fz + NS_WBV, fn, fs, H, H, H, v1w, H, 0);
             piece(fz + NS_V1B, fn, fs, H, 1, H, v1b, H, 0);
         }
-        piece(w.qln, 1, 0, H, 1, H, qg, H, 0);
-        piece(w.qln + H, 1, 0, H, 1, H, qb, H, 0);
-        HIP_TRY(launch_reduce_store_multi(rb, s));
-        rb.n = 0;
+        piece(qln, 1, 0, H, 1, H, qg, H, 0);
+        piece(qln + H, 1, 0, H, 1, H, qb, H, 0);
+        piece(qln, 0, 0, H, 1, H, k1b, H, 0);      // a sum over zero slabs: the key bias cancels in the softmax, its gradient is 0
     }
     // dense projection: dWn[k][n] = sum_i h_in[i][k] dP[i][n]  -> h_dst / h_src / q columns of the first Linears
     const int sp = mfma ? wgrad_groups(n) : (splits_for(n) > 32 ? 32 : splits_for(n));
     if (mfma)
-        HIP_TRY(launch_wgrad_mfma(h_in, H, w.dP, PROW, n, PROW / H, w.partial, PROW, (size_t)H * PROW, sp, s));
+        HIP_TRY(launch_wgrad_mfma(h_in, H, w.dP, PROW, n, PROW / H, w.partial_wgrad, PROW, (size_t)H * PROW, sp, s));
     else
-        HIP_TRY(launch_sgemm(true, false, h_in, H, w.dP, PROW, w.partial, PROW, H, PROW, n, sp, (size_t)H * PROW, 0, s));
+        HIP_TRY(launch_sgemm(true, false, h_in, H, w.dP, PROW, w.partial_wgrad, PROW, H, PROW, n, sp, (size_t)H * PROW, 0, s));
     {
-        FOLDED(w.partial, sp, (size_t)H * PROW, H * PROW);
+        folded(w.partial_wgrad, sp, (size_t)H * PROW, H * PROW, w.folded_wgrad);
         piece(fz + 0 * H, fn, fs, PROW, H, H, k0w + NT + NT * G, KV_IN, 1);
         piece(fz + 1 * H, fn, fs, PROW, H, H, v0w + NT + NT * G, KV_IN, 1);
         piece(fz + 2 * H, fn, fs, PROW, H, H, k0w + NT + NT * G + H, KV_IN, 1);
         piece(fz + 3 * H, fn, fs, PROW, H, H, v0w + NT + NT * G + H, KV_IN, 1);
         piece(fz + 4 * H, fn, fs, PROW, H, H, q0w, H, 1);
-        HIP_TRY(launch_reduce_store_multi(rb, s));
-        rb.n = 0;
     }
-    // dL/dh_in += dP Wn^T
+    HIP_TRY(launch_slab_fold_multi(fb, FOLD, s));
+    HIP_TRY(launch_reduce_store_multi(rb, s));
+    // dL/dh_in = (gh_src or gh itself) + dP Wn^T
     if (mfma)
-        HIP_TRY(launch_dgrad_mfma(w.dP, PROW, att + A_WN, PROW, gh, H, n, PROW, 1, s));
-    else
+        HIP_TRY(launch_dgrad_mfma(w.dP, PROW, att + A_WN, PROW, gh, H, n, PROW, 1, s, gh_src));
+    else {
+        if (gh_src && gh_src != gh) HIP_TRY(hipMemcpyAsync(gh, gh_src, (size_t)n * H * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(launch_sgemm(false, true, w.dP, PROW, att + A_WN, PROW, gh, H, n, H, PROW, 1, 0, 1, s));
+    }
     return CBGX_OK;
 }
 
@@ -478,6 +502,12 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         HIP_TRY(launch_build_active(w.mask, n, w.rf_list[1], w.rf_count + 16, s));
     }
 
+    // one zeroed accumulator per attention block for the query LayerNorm's affine gradients (atomics): a single fill here
+    // instead of one per block
+    const bool qln_slots = 2 * L <= QLN_SLOTS;
+    if (qln_slots) HIP_TRY(hipMemsetAsync(w.qln, 0, (size_t)2 * L * 2 * H * sizeof(float), s));
+    float* gh_cur = w.gh;       // dL/dh of the layer boundary being crossed; the x2h blocks write the other buffer (no snapshot copy)
+    float* gh_oth = w.tmp;
     for (int l = L - 1; l >= 0; --l) {
         const float* xl = tp.xs + (size_t)l * nx;
         const float* h_in = tp.hs + (size_t)l * nh;
@@ -489,19 +519,21 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         const float* Px = tp.P + (size_t)(2 * l) * n * PROW;
         const float* Qx = tp.Qt + (size_t)(2 * l) * n * HEADS * H;
         RC_TRY(attention_block_backward(false, packed + h2x_off(l), xl, h_mid, w.gx[cur], tp.nbr, tp.deg, lig_flag, tp.e_w,
-                                        w.act, w.act_count, n, w, w.gh, w.gx[nxt], w.de_w, g + 18, s,
-                                        Px + (size_t)n * PROW, Qx + (size_t)n * HEADS * H));
-        // h_mid = h_in + X2H(x_l, h_in): w.gh holds dL/dh_mid, which is also the residual part of dL/dh_in.  The edge
-        // kernel reads it (through the fold) before the final GEMM accumulates into it, so a snapshot is needed.
-        HIP_TRY(hipMemcpyAsync(w.tmp, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
+                                        w.act, w.act_count, n, w, gh_cur, w.gx[nxt], w.de_w, g + 18, s,
+                                        Px + (size_t)n * PROW, Qx + (size_t)n * HEADS * H,
+                                        qln_slots ? w.qln + (size_t)(2 * l + 1) * 2 * H : nullptr));
+        // h_mid = h_in + X2H(x_l, h_in): gh_cur holds dL/dh_mid, which is also the residual part of dL/dh_in.  The block reads it
+        // (fold, outer products, bias sums) and writes dL/dh_in = gh_cur + dP Wn^T into the OTHER buffer.
         const int k = L - 1 - l;      // 0 for the last layer
         const int* rows = (prune && k < 2) ? w.rf_list[k] : nullptr;
         const int* n_rows = (prune && k < 2) ? w.rf_count + 16 * k : nullptr;
-        RC_TRY(attention_block_backward(true, packed + x2h_off(l), xl, h_in, w.tmp, tp.nbr, tp.deg, lig_flag, tp.e_w,
-                                        rows, n_rows, n, w, w.gh, w.gx[nxt], w.de_w, g, s, Px, Qx));
+        RC_TRY(attention_block_backward(true, packed + x2h_off(l), xl, h_in, gh_cur, tp.nbr, tp.deg, lig_flag, tp.e_w,
+                                        rows, n_rows, n, w, gh_oth, w.gx[nxt], w.de_w, g, s, Px, Qx,
+                                        qln_slots ? w.qln + (size_t)(2 * l) * 2 * H : nullptr, gh_cur));
+        { float* t = gh_cur; gh_cur = gh_oth; gh_oth = t; }
         cur = nxt;
     }
-    if (grad_h_in) HIP_TRY(hipMemcpyAsync(grad_h_in, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
+    if (grad_h_in) HIP_TRY(hipMemcpyAsync(grad_h_in, gh_cur, nh * 4, hipMemcpyDeviceToDevice, s));
     // distance gate (computed once from the input coordinates, used by all 2L blocks)
     HIP_TRY(launch_gate_backward(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.E8, w.partial, GATE_GRID, s));
     FOLDED(w.partial, GATE_GRID, GB_SIZE, GB_SIZE);
@@ -602,6 +634,57 @@ int cbgx_h2x_stack_backward(const float* packed, int num_layers, const void* tap
     RS(fz + GB_LNB, fn, fs, GH, 1, GH, grads[3], GH, 0);
     RS(fz + GB_W2, fn, fs, GH, 1, GH, grads[4], GH, 0);
     RS(fz + GB_B2, fn, fs, 1, 1, 1, grads[5], 1, 0);
+    return CBGX_OK;
+}
+
+// ---- TargetDiff's training arithmetic around the denoiser (train_loss.hip) ---------------------------------------------------------
+constexpr int LOSS_MAX_GRAPHS = 4096;     // per-graph sums of the loss kernel live in LDS (3 floats per graph)
+
+int cbgx_targetdiff_train_noise(const float* x0, const int64_t* v0, const int64_t* t, const int64_t* batch, const uint8_t* gen,
+                                int n_lig, int num_classes, const float* alphas_cumprod, const float* log_alphas_cumprod,
+                                const float* log_one_minus_alphas_cumprod, const float* eps, const float* u, float* x_t,
+                                float* c_t, int64_t* v_t, void* stream) {
+    if (n_lig == 0) return CBGX_OK;
+    if (n_lig < 0 || num_classes < 1 || num_classes > 32)
+        return set_error(CBGX_E_INVALID, "train_noise: bad sizes (n_lig=%d C=%d)", n_lig, num_classes);
+    if (!x0 || !v0 || !t || !batch || !gen || !alphas_cumprod || !log_alphas_cumprod || !log_one_minus_alphas_cumprod || !eps ||
+        !u || !x_t || !c_t || !v_t)
+        return set_error(CBGX_E_INVALID, "train_noise: NULL pointer");
+    HIP_TRY(launch_train_noise(x0, v0, t, batch, gen, n_lig, num_classes, alphas_cumprod, log_alphas_cumprod,
+                               log_one_minus_alphas_cumprod, (float)log((double)num_classes), eps, u, x_t, c_t, v_t,
+                               (hipStream_t)stream));
+    return CBGX_OK;
+}
+
+int cbgx_targetdiff_loss(const float* x_out, const float* logits, const int64_t* lig_rows, const float* x0, const int64_t* v0,
+                         const int64_t* v_t, const int64_t* t, const int64_t* batch, const uint8_t* gen, int n_lig, int n_graphs,
+                         int num_classes, const float* const* tables, float* losses, float* x_pred, float* c_pred,
+                         float* grad_pos, float* grad_logit, void* stream) {
+    if (n_lig <= 0 || n_graphs <= 0 || n_graphs > LOSS_MAX_GRAPHS || num_classes < 1 || num_classes > 32)
+        return set_error(CBGX_E_INVALID, "targetdiff_loss: bad sizes (n_lig=%d B=%d (max %d) C=%d)", n_lig, n_graphs,
+                         LOSS_MAX_GRAPHS, num_classes);
+    if (!x_out || !logits || !lig_rows || !x0 || !v0 || !v_t || !t || !batch || !gen || !tables || !losses || !grad_pos ||
+        !grad_logit)
+        return set_error(CBGX_E_INVALID, "targetdiff_loss: NULL pointer");
+    for (int i = 0; i < 4; ++i)
+        if (!tables[i]) return set_error(CBGX_E_INVALID, "targetdiff_loss: table %d is NULL", i);
+    HIP_TRY(launch_train_loss(x_out, logits, lig_rows, x0, v0, v_t, t, batch, gen, n_lig, n_graphs, num_classes, tables,
+                              (float)log((double)num_classes), losses, x_pred, c_pred, grad_pos, grad_logit,
+                              (hipStream_t)stream));
+    return CBGX_OK;
+}
+
+int cbgx_targetdiff_loss_backward(const float* grad_pos, const float* grad_logit, const int64_t* sort_idx, int n_protein,
+                                  int n_nodes, int num_classes, const float* g_loss_pos, const float* g_loss_atom,
+                                  float* grad_x_out, float* grad_logits, void* stream) {
+    if (n_nodes == 0) return CBGX_OK;
+    if (n_nodes < 0 || n_protein < 0 || n_protein > n_nodes || num_classes < 1 || num_classes > 32)
+        return set_error(CBGX_E_INVALID, "targetdiff_loss_backward: bad sizes (N=%d N_protein=%d C=%d)", n_nodes, n_protein,
+                         num_classes);
+    if (!grad_pos || !grad_logit || !sort_idx || !grad_x_out || !grad_logits)
+        return set_error(CBGX_E_INVALID, "targetdiff_loss_backward: NULL pointer");
+    HIP_TRY(launch_train_loss_bwd(grad_pos, grad_logit, sort_idx, n_protein, n_nodes, num_classes, g_loss_pos, g_loss_atom,
+                                  grad_x_out, grad_logits, (hipStream_t)stream));
     return CBGX_OK;
 }
 

@@ -60,8 +60,9 @@ hipError_t launch_outer_accum_mfma(bool headed, const float* Lm, const float* R,
                                    int n_nodes, float* partial, size_t slab_stride, int grid, hipStream_t s);
 hipError_t launch_wgrad_mfma(const float* Lm, int ldl, const float* R, int ldr, int n_nodes, int col_blocks, float* partial,
                              int ldo, size_t slab_stride, int groups, hipStream_t s);
+// `C_in` (accumulate only): the addend is read from C_in instead of C (same leading dimension) -- C = C_in + A B^T out of place
 hipError_t launch_dgrad_mfma(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K,
-                             int accumulate, hipStream_t s);
+                             int accumulate, hipStream_t s, const float* C_in = nullptr);
 hipError_t launch_q_backward_mfma(const float* att, const float* P, const float* T, const int* rows, const int* n_rows,
                                   int n_nodes, float* qs, float* dqb, float* zb, float* dP, float* partial, int grid,
                                   hipStream_t s);
@@ -77,7 +78,7 @@ hipError_t launch_outer_accum(bool headed, const float* Lm, const float* R, cons
 hipError_t launch_colsum(const float* A, int lda, int cols, const float* scale, const int* rows, const int* n_rows_ptr,
                          int n_rows, float* partial, size_t slab_stride, int grid, hipStream_t s);
 // up to RS_MAX reduce_store pieces in one launch
-constexpr int RS_MAX = 12;
+constexpr int RS_MAX = 32;
 struct RsPiece {
     const float* src; float* dst; size_t stride; int n_slabs, src_ld, rows, cols, dst_ld, transpose;
 };
@@ -87,6 +88,11 @@ struct RsBatch {
 hipError_t launch_reduce_store_multi(const RsBatch& b, hipStream_t s);
 hipError_t launch_slab_fold(const float* src, int n_slabs, size_t slab_stride, int size, int groups, float* dst,
                             hipStream_t s);
+// up to FOLD_JOBS_MAX first-level slab folds in one launch (blockIdx.z = job); every job folds into `groups` slabs
+constexpr int FOLD_JOBS_MAX = 4;
+struct FoldJob { const float* src; float* dst; size_t stride; int n_slabs, size; };
+struct FoldBatch { FoldJob j[FOLD_JOBS_MAX]; int n; };
+hipError_t launch_slab_fold_multi(const FoldBatch& b, int groups, hipStream_t s);
 hipError_t launch_reduce_store(const float* src, int n_slabs, size_t slab_stride, int src_ld, int rows, int cols,
                                float* dst, int dst_ld, int transpose, hipStream_t s);
 // C[z] (+)= op(A) op(B); A is [M,K] (ta: stored [K,M]), B is [K,N] (tb: stored [N,K]); `splits` partitions K and
@@ -96,6 +102,16 @@ hipError_t launch_sgemm(bool ta, bool tb, const float* A, int lda, const float* 
 hipError_t launch_gate_backward(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
                                 const float* de_w, float* E8, float* partial, int grid, hipStream_t s);
 hipError_t launch_ssp_backward(const float* pre, const float* dact, long n, float* dpre, hipStream_t s);
+// train_loss.hip: TargetDiff's forward noising, its two losses with their gradients, and the scatter of those gradients
+hipError_t launch_train_noise(const float* x0, const int64_t* v0, const int64_t* t, const int64_t* batch, const uint8_t* gen,
+                              int n_lig, int C, const float* acp, const float* log_acp, const float* log_1m_acp, float log_c,
+                              const float* eps, const float* u, float* x_t, float* c_t, int64_t* v_t, hipStream_t s);
+hipError_t launch_train_loss(const float* x_out, const float* logits, const int64_t* lig_rows, const float* x0,
+                             const int64_t* v0, const int64_t* vt, const int64_t* t, const int64_t* batch, const uint8_t* gen,
+                             int n_lig, int B, int C, const float* const* tables, float log_c, float* losses, float* x_pred,
+                             float* c_pred, float* gpos, float* gz, hipStream_t s);
+hipError_t launch_train_loss_bwd(const float* gpos, const float* gz, const int64_t* sort_idx, int n_rec, int n_nodes, int C,
+                                 const float* g_pos, const float* g_typ, float* grad_x, float* grad_logits, hipStream_t s);
 hipError_t launch_add_inplace(float* dst, const float* src, long n, hipStream_t s);
 
 }  // namespace cbgx

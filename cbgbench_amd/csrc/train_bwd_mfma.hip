@@ -988,8 +988,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const float* __restrict
 constexpr int DG_KC = 32, DG_PITCH = DG_KC + 4;
 template <int TR>      // 16 TR rows per workgroup
 __global__ __launch_bounds__(256) void dgrad_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
-                                                         int ldb, float* __restrict__ C, int ldc, int M, int K,
-                                                         int accumulate) {
+                                                         int ldb, float* C, int ldc, int M, int K,
+                                                         int accumulate, const float* C_in) {
     constexpr int DG_ROWS = 16 * TR;
     __shared__ __attribute__((aligned(16))) float sA[2][DG_ROWS][DG_PITCH];
     __shared__ __attribute__((aligned(16))) float sB[2][H][DG_PITCH];
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(256) void dgrad_mfma_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const unsigned row = (unsigned)min(row0 + 16 * tr + 4 * kq + r, M - 1);
-                cold[tc][r] = accumulate ? C[row * ldc + 32 * w + 16 * tc + i] : 0.f;
+                cold[tc][r] = accumulate ? C_in[row * ldc + 32 * w + 16 * tc + i] : 0.f;
             }
 #pragma unroll
         for (int tc = 0; tc < 2; ++tc)
@@ -1164,7 +1164,7 @@ hipError_t launch_wgrad_mfma(const float* Lm, int ldl, const float* R, int ldr, 
 
 // C[M][128] (+)= A[M][K] B[128][K]^T, K a multiple of 64
 hipError_t launch_dgrad_mfma(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K,
-                             int accumulate, hipStream_t s) {
+                             int accumulate, hipStream_t s, const float* C_in) {
     if (M <= 0) return hipSuccess;
     if (K % 64 != 0 || (long)M * (lda > ldc ? lda : ldc) >= (1L << 32)) return hipErrorInvalidValue;
     profile_mark_begin(K_TRAIN_GEMM, s);
@@ -1176,7 +1176,8 @@ hipError_t launch_dgrad_mfma(const float* A, int lda, const float* B, int ldb, f
     }
 #endif
     // two workgroups of 32 rows per CU overlap each other's barriers and loads better than one of 64 (measured: 51.7 vs ... us)
-    hipLaunchKernelGGL(dgrad_mfma_kernel<2>, dim3((M + 31) / 32), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, accumulate);
+    hipLaunchKernelGGL(dgrad_mfma_kernel<2>, dim3((M + 31) / 32), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, accumulate,
+                       C_in ? C_in : C);
     profile_mark_end(s);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;

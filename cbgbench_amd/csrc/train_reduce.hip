@@ -103,6 +103,27 @@ __global__ __launch_bounds__(256) void slab_fold_kernel(const float* __restrict_
     dst[(size_t)g * size + c] = acc;
 }
 
+// the same fold for several slab sets in one launch (blockIdx.z = job): bit-identical sums, one launch instead of one per set
+__global__ __launch_bounds__(256) void slab_fold_multi_kernel(FoldBatch b, int groups) {
+    const FoldJob& jb = b.j[blockIdx.z];
+    const int c = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (c >= jb.size) return;
+    const float* __restrict__ src = jb.src;
+    const size_t slab_stride = jb.stride;
+    const int n_slabs = jb.n_slabs;
+    float acc = 0.f;
+    int s = g;
+    for (; s + 7 * groups < n_slabs; s += 8 * groups) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + u * groups) * slab_stride + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; s < n_slabs; s += groups) acc += src[(size_t)s * slab_stride + c];
+    jb.dst[(size_t)g * jb.size + c] = acc;
+}
+
 // dst[r][c] (or dst[c][r] if transpose) = sum_s src[s * slab_stride + r * src_ld + c]
 __global__ void reduce_store_kernel(const float* __restrict__ src, int n_slabs, size_t slab_stride, int src_ld,
                                     int rows, int cols, float* __restrict__ dst, int dst_ld, int transpose) {
@@ -389,6 +410,15 @@ hipError_t launch_slab_fold(const float* src, int n_slabs, size_t slab_stride, i
                             hipStream_t s) {
     hipLaunchKernelGGL(slab_fold_kernel, dim3((size + 255) / 256, groups), dim3(256), 0, s, src, n_slabs, slab_stride, size,
                        groups, dst);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_slab_fold_multi(const FoldBatch& b, int groups, hipStream_t s) {
+    if (b.n == 0) return hipSuccess;
+    int mx = 0;
+    for (int k = 0; k < b.n; ++k) mx = b.j[k].size > mx ? b.j[k].size : mx;
+    hipLaunchKernelGGL(slab_fold_multi_kernel, dim3((mx + 255) / 256, groups, b.n), dim3(256), 0, s, b, groups);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -12,14 +12,14 @@ What differs by design:
   ``.cpu()`` per step (targetdiff.py:182), preserving the returned structure
   ``traj[t] = (pos, type_onehot, batch_idx)`` for t = T-1 .. -1.
 """
+import ctypes
 import math
+import os
 
 import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
-
-import ctypes
 
 from . import _native
 from .registry import get_e3_gnn, register_model
@@ -255,6 +255,67 @@ class TypeVPScheduler(VPSchedule):
         return F.one_hot(v_next, self.num_classes).to(ct.dtype), v_next
 
 
+def _native_noise(pos_sched, type_sched, x0, v0, t, bl, gen_l, eps, u):
+    """q(x_t | x_0) and q(v_t | v_0) of ``CTNVPScheduler.forward_add_noise`` / ``TypeVPScheduler.forward_add_noise`` in ONE launch
+    (csrc/train_loss.hip, cbgx_targetdiff_train_noise).  The draws are made here, in the order and shapes of the tensor path, so a
+    seeded run sees the same noise on both."""
+    C = type_sched.num_classes
+    if eps is None:
+        eps = torch.randn_like(x0)
+    if u is None:
+        u = torch.rand(x0.shape[0], C, dtype=torch.float32, device=x0.device)
+    eps, u = eps.float().contiguous(), u.float().contiguous()
+    x_t = torch.empty_like(x0)
+    c_t = torch.empty(x0.shape[0], C, dtype=torch.float32, device=x0.device)
+    v_t = torch.empty_like(v0)
+    _native.check(_native.lib().cbgx_targetdiff_train_noise(
+        _native.ptr(x0), _native.ptr(v0), _native.ptr(t), _native.ptr(bl), _native.ptr(gen_l), x0.shape[0], C,
+        _native.ptr(pos_sched.alphas_cumprod), _native.ptr(type_sched.log_alphas_cumprod_v),
+        _native.ptr(type_sched.log_one_minus_alphas_cumprod_v), _native.ptr(eps), _native.ptr(u), _native.ptr(x_t),
+        _native.ptr(c_t), _native.ptr(v_t), _native.current_stream(x0.device)), "cbgx_targetdiff_train_noise")
+    return x_t, c_t, v_t
+
+
+class _TargetDiffLossFunction(torch.autograd.Function):
+    """``CTNVPScheduler.get_loss(type='denoise')`` + ``TypeVPScheduler.get_loss`` on the ligand rows of the denoiser outputs
+    (targetdiff.py:103-121) as one launch, which also leaves the gradients of both losses with respect to those rows; the backward
+    is one more launch that scatters them, scaled by the upstream gradients, into full-size dL/dx_out and dL/dlogits.  The tensor
+    path (``get_loss(..., fused=False)``) takes ~220 small launches for the same numbers."""
+
+    @staticmethod
+    def forward(ctx, xo, logits, lig_rows, sort_idx, n_rec, x0, v0, vt, t, bl, gen_l, tables):
+        dev = xo.device
+        n_lig, C, B = x0.shape[0], logits.shape[1], t.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        losses = torch.empty(2, **f32)
+        x_pred, c_pred = torch.empty(n_lig, 3, **f32), torch.empty(n_lig, C, **f32)
+        gpos, gz = torch.empty(n_lig, 3, **f32), torch.empty(n_lig, C, **f32)
+        arr = (ctypes.c_void_p * 4)(*[tb.data_ptr() for tb in tables])
+        _native.check(_native.lib().cbgx_targetdiff_loss(
+            _native.ptr(xo), _native.ptr(logits), _native.ptr(lig_rows), _native.ptr(x0), _native.ptr(v0), _native.ptr(vt),
+            _native.ptr(t), _native.ptr(bl), _native.ptr(gen_l), n_lig, B, C, arr, _native.ptr(losses), _native.ptr(x_pred),
+            _native.ptr(c_pred), _native.ptr(gpos), _native.ptr(gz), _native.current_stream(dev)), "cbgx_targetdiff_loss")
+        ctx.saved = (gpos, gz, sort_idx)
+        ctx.dims = (int(n_rec), xo.shape[0], C)
+        ctx.mark_non_differentiable(x_pred, c_pred)
+        loss_pos, loss_atom = losses.unbind(0)
+        return loss_pos, loss_atom, x_pred, c_pred
+
+    @staticmethod
+    def backward(ctx, g_pos, g_atom, _gx, _gc):
+        gpos, gz, sort_idx = ctx.saved
+        n_rec, N, C = ctx.dims
+        dev = gpos.device
+        cont = lambda g: None if g is None else g.to(torch.float32).contiguous()
+        g_pos, g_atom = cont(g_pos), cont(g_atom)
+        grad_x = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        grad_logits = torch.empty(N, C, dtype=torch.float32, device=dev)
+        _native.check(_native.lib().cbgx_targetdiff_loss_backward(
+            _native.ptr(gpos), _native.ptr(gz), _native.ptr(sort_idx), n_rec, N, C, _native.ptr(g_pos), _native.ptr(g_atom),
+            _native.ptr(grad_x), _native.ptr(grad_logits), _native.current_stream(dev)), "cbgx_targetdiff_loss_backward")
+        return (grad_x, grad_logits) + (None,) * 10
+
+
 class PLContextEmbedder(nn.Module):
     """Linear atom / residue / ligand-indicator embeddings (repo/modules/context_emb.py:137-230) for the
     shipped embedder config (atom: linear, residue: linear; no time, no vec)."""
@@ -372,6 +433,10 @@ class TargetDiff(BatchesInFlight, nn.Module):
             raise ValueError("only the full-atom context embedder ('fa') is supported")
         self.context_embedder = PLContextEmbedder(cfg.embedder)
         self.denoiser = get_e3_gnn(cfg.encoder, num_classes=self.num_classes)
+        # forward noising and the two losses as single launches of libcbgx (csrc/train_loss.hip) instead of tensor operations;
+        # False keeps the tensor path (the restatement of the reference's schedulers above), which the tests compare against
+        # (CBGX_FUSED_TRAINING_OPS=0 in the environment: A/B runs of bench.py --workload train)
+        self.fused_training_ops = os.environ.get("CBGX_FUSED_TRAINING_OPS", "1") != "0"
 
     # ---- training (targetdiff.py:40-124) ---------------------------------------------------------
     def sample_time(self, batch_size, device="cuda", draws=None):
@@ -417,11 +482,19 @@ class TargetDiff(BatchesInFlight, nn.Module):
         gen_r = batch.get("protein_gen_flag", torch.zeros_like(batch["protein_lig_flag"])).bool()
         bl, br = batch["ligand_element_batch"], batch["protein_element_batch"]
         eps, u = noise if noise is not None else (None, None)
-        x_t = self.pos_scheduler.forward_add_noise(x0, t, bl, gen_l, noise=eps)[0] if self.denoise_structure else x0
-        if self.denoise_atom:
-            c_t, v_t = self.type_scheduler.forward_add_noise(v0, t, bl, gen_l, uniform=u)
+        # one launch for the noising, one for both losses (+ one in the backward) when everything is in the shape the kernels take
+        fused = (self.fused_training_ops and x0.is_cuda and self.denoise_structure and self.denoise_atom
+                 and self.num_classes <= 32 and 0 < int(t.shape[0]) <= 4096 and x0.shape[0] > 0
+                 and v0.dtype == torch.int64 and t.dtype == torch.int64 and bl.dtype == torch.int64)
+        if fused:
+            x0, v0, t, bl, gen_l = x0.contiguous(), v0.contiguous(), t.contiguous(), bl.contiguous(), gen_l.contiguous()
+            x_t, c_t, v_t = _native_noise(self.pos_scheduler, self.type_scheduler, x0, v0, t, bl, gen_l, eps, u)
         else:
-            c_t, v_t = F.one_hot(v0, self.num_classes).float(), v0
+            x_t = self.pos_scheduler.forward_add_noise(x0, t, bl, gen_l, noise=eps)[0] if self.denoise_structure else x0
+            if self.denoise_atom:
+                c_t, v_t = self.type_scheduler.forward_add_noise(v0, t, bl, gen_l, uniform=u)
+            else:
+                c_t, v_t = F.one_hot(v0, self.num_classes).float(), v0
         aa = F.one_hot(batch["protein_aa_type"], NUM_AA).float()
         h_lig = self.context_embedder.embed_ligand(c_t)
         h_rec = self.context_embedder.embed_protein(batch["protein_atom_feature"].float(), aa)
@@ -431,6 +504,13 @@ class TargetDiff(BatchesInFlight, nn.Module):
         gen_flag = torch.cat([gen_r, gen_l], 0)[sort_idx]
         xo, _, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
                                       graph_ptr=graph_ptr, ligand_outputs_only=True)
+        if fused:
+            ts = self.type_scheduler
+            loss_pos, loss_atom, x_pred, c_prob = _TargetDiffLossFunction.apply(
+                xo, logits, lig_rows.contiguous(), sort_idx.contiguous(), x_rec.shape[0], x0, v0, v_t, t, bl, gen_l,
+                (ts.log_alphas_v, ts.log_one_minus_alphas_v, ts.log_alphas_cumprod_v, ts.log_one_minus_alphas_cumprod_v))
+            results = {"x0": x0, "xt": x_t, "x_pred": x_pred, "mask_gen": gen_l, "v0": v0, "vt": v_t, "c_pred": c_prob}
+            return {"pos": loss_pos, "atom": loss_atom}, results
         x_pred, c_pred = xo[lig_rows], logits[lig_rows]
         results = {}
         if self.denoise_structure:

@@ -305,6 +305,34 @@ int cbgx_h2x_stack_backward(const float *packed, int num_layers, const void *tap
                             float *const *grads, int num_grads, float *grad_h, void *workspace,
                             size_t workspace_bytes, void *stream);
 
+/* TargetDiff's training arithmetic around the denoiser call (targetdiff.py:82-124), one launch each instead of the ~260 small
+ * launches the same formulas take as tensor operations (a training step is bound by its launch count as much as by its kernels).
+ * Index tensors are int64 as PyTorch holds them (no conversion launches); gen / masks are bytes.
+ * cbgx_targetdiff_train_noise: q(x_t | x_0) on gen rows (CTNVPScheduler.forward_add_noise, diffusion_scheduler.py:117-134) and
+ *   q(v_t | v_0) by Gumbel-argmax (TypeVPScheduler.forward_add_noise, :339-365).  t [B] per graph, batch [n_lig] graph of each
+ *   ligand atom; eps [n_lig,3] ~ N(0,1), u [n_lig,C] ~ U(0,1) are inputs.  Outputs x_t [n_lig,3], c_t [n_lig,C] one-hot, v_t [n_lig].
+ * cbgx_targetdiff_loss: position loss (type 'denoise': sum of squares against x0, :185-201) and atom-type loss (KL between
+ *   q(v_{t-1} | v_t, v_0) and q(v_{t-1} | v_t, softmax(logits)); the decoder NLL for graphs at t = 0; :380-441), each the mean over
+ *   the gen atoms of a graph, then over the graphs (targetdiff.py:103-121).  x_out [N,3] / logits [N,C] are the denoiser outputs,
+ *   lig_rows [n_lig] the composed row of each ligand atom; tables = {log_alphas_v, log_one_minus_alphas_v, log_alphas_cumprod_v,
+ *   log_one_minus_alphas_cumprod_v} [T].  losses [2] = {pos, atom}; x_pred [n_lig,3], c_pred [n_lig,C] = softmax(logits) (the
+ *   `results` of the reference; may be NULL); grad_pos [n_lig,3], grad_logit [n_lig,C] receive d loss_pos / d x_out[row] and
+ *   d loss_atom / d logits[row].  n_graphs <= 4096.
+ * cbgx_targetdiff_loss_backward: grad_x_out [N,3] = *g_loss_pos * grad_pos and grad_logits [N,C] = *g_loss_atom * grad_logit on
+ *   ligand rows, zero on protein rows; sort_idx [N] is the composition permutation (composed row r holds entry sort_idx[r] of
+ *   cat(protein, ligand)); g_loss_* are DEVICE scalars (NULL = 0). */
+int cbgx_targetdiff_train_noise(const float *x0, const int64_t *v0, const int64_t *t, const int64_t *batch,
+                                const uint8_t *gen, int n_lig, int num_classes, const float *alphas_cumprod,
+                                const float *log_alphas_cumprod, const float *log_one_minus_alphas_cumprod,
+                                const float *eps, const float *u, float *x_t, float *c_t, int64_t *v_t, void *stream);
+int cbgx_targetdiff_loss(const float *x_out, const float *logits, const int64_t *lig_rows, const float *x0,
+                         const int64_t *v0, const int64_t *v_t, const int64_t *t, const int64_t *batch, const uint8_t *gen,
+                         int n_lig, int n_graphs, int num_classes, const float *const *tables, float *losses, float *x_pred,
+                         float *c_pred, float *grad_pos, float *grad_logit, void *stream);
+int cbgx_targetdiff_loss_backward(const float *grad_pos, const float *grad_logit, const int64_t *sort_idx, int n_protein,
+                                  int n_nodes, int num_classes, const float *g_loss_pos, const float *g_loss_atom,
+                                  float *grad_x_out, float *grad_logits, void *stream);
+
 /* ---- measurement hook (bench.py) ----------------------------------------------------------------
  * Between cbgx_profile_begin() and cbgx_profile_end() every kernel launch is bracketed by HIP events on
  * its own stream.  cbgx_profile_end() synchronises them and returns, per kernel class, the summed

@@ -1,0 +1,149 @@
+"""TargetDiff's training arithmetic around the denoiser as single launches of libcbgx (csrc/train_loss.hip: forward noising, the two
+losses with their gradients) against the tensor path -- the restatement of the reference's schedulers in cbgbench_amd/targetdiff.py
+(diffusion_scheduler.py:117-134, 185-201, 339-441), which tests/test_host.py pins to the oracle on the CPU -- on the same device
+tensors.  The golden training tests (tests/test_gpu_training.py) run through the fused path and pin it to the reference's own losses and
+gradients; here the two paths are compared directly on shapes the goldens do not hold (graphs at t = 0, graphs without a generated atom,
+frozen atoms, the largest class count).
+
+Tolerances: the yardstick is the tensor path in fp64; the fused kernels must be as close to it as the fp32 tensor path is (the KL of
+two nearly equal posteriors is ill-conditioned in fp32: ~1e-5 relative on either path)."""
+import numpy as np
+import pytest
+import torch
+
+import cbgbench_amd as C
+from cbgbench_amd import targetdiff as TD
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _schedulers(C_):
+    m = C.get_model(C.default_targetdiff_config(C_))
+    return m.pos_scheduler.to(DEV), m.type_scheduler.to(DEV)
+
+
+def _case(seed, B, C_, t_list=None, freeze=0.2, empty_graph=True):
+    """ligand / protein batch vectors (sorted, as a collate makes them), flags, data, draws"""
+    g = torch.Generator().manual_seed(seed)
+    n_lig_g = torch.randint(3, 30, (B,), generator=g)
+    n_rec_g = torch.randint(20, 60, (B,), generator=g)
+    bl = torch.repeat_interleave(torch.arange(B), n_lig_g)
+    br = torch.repeat_interleave(torch.arange(B), n_rec_g)
+    n_lig = int(n_lig_g.sum())
+    gen = torch.rand(n_lig, generator=g) >= freeze
+    if empty_graph and B > 2:
+        gen[bl == 1] = False            # a graph without a generated atom: contributes 0 to the numerator, 1 to the graph count
+    t = torch.randint(0, 1000, (B,), generator=g)
+    if t_list is not None:
+        t[:len(t_list)] = torch.tensor(t_list)
+    d = dict(bl=bl, br=br, gen=gen, t=t, x0=torch.randn(n_lig, 3, generator=g) * 3, v0=torch.randint(0, C_, (n_lig,), generator=g),
+             eps=torch.randn(n_lig, 3, generator=g), u=torch.rand(n_lig, C_, generator=g))
+    return {k: v.to(DEV) for k, v in d.items()}
+
+
+@pytest.mark.parametrize("C_,B", [(13, 6), (8, 3), (32, 17), (13, 300)])
+def test_fused_noising_equals_tensor_path(C_, B):
+    ps, ts = _schedulers(C_)
+    c = _case(1 + C_, B, C_, t_list=[0, 999, 1])
+    x_t, c_t, v_t = TD._native_noise(ps, ts, c["x0"], c["v0"], c["t"], c["bl"], c["gen"], c["eps"], c["u"])
+    x_ref = ps.forward_add_noise(c["x0"], c["t"], c["bl"], c["gen"], noise=c["eps"])[0]
+    c_ref, v_ref = ts.forward_add_noise(c["v0"], c["t"], c["bl"], c["gen"], uniform=c["u"])
+    assert torch.equal(v_t, v_ref) and torch.equal(c_t, c_ref)
+    assert v_t.dtype == torch.int64 and torch.equal(v_t[~c["gen"]], c["v0"][~c["gen"]])
+    assert torch.allclose(x_t, x_ref, rtol=0, atol=0) or float((x_t - x_ref).abs().max()) <= 4e-7 * float(x_ref.abs().max())
+    assert torch.equal(x_t[~c["gen"]], c["x0"][~c["gen"]])
+    # without given draws: the generator is consumed in the tensor path's order and shapes
+    torch.manual_seed(7)
+    a = TD._native_noise(ps, ts, c["x0"], c["v0"], c["t"], c["bl"], c["gen"], None, None)
+    torch.manual_seed(7)
+    xr = ps.forward_add_noise(c["x0"], c["t"], c["bl"], c["gen"])[0]
+    vr = ts.forward_add_noise(c["v0"], c["t"], c["bl"], c["gen"])[1]
+    assert torch.equal(a[2], vr) and float((a[0] - xr).abs().max()) <= 4e-7 * float(xr.abs().max())
+
+
+def _three_ways(C_, B, seed, t_list, scale):
+    """(tensor path in fp64, tensor path in fp32, fused kernels) -> (loss_pos, loss_atom, d/dx_out, d/dlogits, x_pred, c_pred) each"""
+    ps, ts = _schedulers(C_)
+    c = _case(seed, B, C_, t_list=t_list)
+    sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = TD.TargetDiff.compose_plan(c["bl"], c["br"], B)
+    N, n_rec = sort_idx.numel(), c["br"].numel()
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    xo32 = torch.randn(N, 3, device=DEV, generator=g) * 3
+    lg32 = torch.randn(N, C_, device=DEV, generator=g) * scale
+    v_t = ts.forward_add_noise(c["v0"], c["t"], c["bl"], c["gen"], uniform=c["u"])[1]
+    x_t = ps.forward_add_noise(c["x0"], c["t"], c["bl"], c["gen"], noise=c["eps"])[0]
+    out = []
+    for dt in (torch.float64, torch.float32):       # tensor path (targetdiff.py get_loss with fused_training_ops = False)
+        xo, logits = xo32.to(dt).requires_grad_(True), lg32.to(dt).requires_grad_(True)
+        lp, ip = ps.get_loss(xo[lig_rows], c["x0"].to(dt), x_t.to(dt), c["t"], c["gen"], c["bl"], type="denoise")
+        la, ia = ts.get_loss(logits[lig_rows], c["v0"], v_t, c["t"], c["gen"], c["bl"], pred_logit=True)
+        (1.0 * lp + 100.0 * la).backward()
+        out.append((lp.detach(), la.detach(), xo.grad, logits.grad, ip["x_pred"].detach(), ia["c_pred"].detach()))
+    xo, logits = xo32.clone().requires_grad_(True), lg32.clone().requires_grad_(True)
+    tables = (ts.log_alphas_v, ts.log_one_minus_alphas_v, ts.log_alphas_cumprod_v, ts.log_one_minus_alphas_cumprod_v)
+    fp, fa, x_pred, c_pred = TD._TargetDiffLossFunction.apply(xo, logits, lig_rows.contiguous(), sort_idx.contiguous(), n_rec, c["x0"],
+                                                              c["v0"], v_t, c["t"], c["bl"], c["gen"], tables)
+    (1.0 * fp + 100.0 * fa).backward()
+    out.append((fp.detach(), fa.detach(), xo.grad, logits.grad, x_pred, c_pred))
+    return out, lig_flag
+
+
+@pytest.mark.parametrize("C_,B,t_list,scale", [(13, 6, [0, 999, 1, 0], 1.0), (8, 3, [500], 4.0), (32, 17, [0, 0, 2], 0.5),
+                                               (13, 300, [0, 1, 999], 2.0), (13, 2, [0, 0], 8.0)])
+def test_fused_losses_and_their_gradients_equal_tensor_path(C_, B, t_list, scale):
+    """The KL between two nearly equal posteriors is a sum of cancelling terms: in fp32 its value moves by ~1e-5 of itself with the
+    association order (measured on the tensor path itself, fp32 against fp64).  So the yardstick is the tensor path in fp64, and the
+    fused kernels must be as close to it as the fp32 tensor path is (within a factor 4, or 5e-6 when that path happens to be exact)."""
+    (r64, r32, got), lig_flag = _three_ways(C_, B, 11 + B, t_list, scale)
+    report = []
+    for k, name in ((0, "loss_pos"), (1, "loss_atom"), (2, "d/dx_out"), (3, "d/dlogits")):
+        ref = r64[k].double()
+        scale_ = max(float(ref.abs().max()), 1e-30)
+        e32 = float((r32[k].double() - ref).abs().max()) / scale_
+        eg = float((got[k].double() - ref).abs().max()) / scale_
+        report.append((name, e32, eg))
+        assert torch.isfinite(got[k]).all() and eg <= max(4.0 * e32, 5e-6), report
+    for k in (2, 3):
+        assert float(got[k][~lig_flag].abs().max()) == 0.0          # protein rows: exact zeros
+    assert torch.equal(got[4], r32[4])                               # x_pred: a gather
+    assert float((got[5] - r32[5]).abs().max()) <= 1e-6              # c_pred = softmax(logits)
+
+
+def test_training_step_through_the_fused_path_equals_tensor_path(synthetic_sd):
+    """whole model, same time steps and draws: losses, results and every parameter gradient"""
+    from cbgbench_amd import synthetic
+    rng = np.random.default_rng(21)
+    batch = synthetic.batch_to(synthetic.make_batch([synthetic.make_pocket(rng, 90, radius=7.0) for _ in range(4)],
+                                                    [8, 10, 7, 12], rng, 13), DEV)
+    batch["num_graphs"] = 4
+    n_lig = batch["ligand_pos"].shape[0]
+    g = torch.Generator(device=DEV).manual_seed(3)
+    t = torch.tensor([0, 300, 999, 650], device=DEV)
+    noise = (torch.randn(n_lig, 3, device=DEV, generator=g), torch.rand(n_lig, 13, device=DEV, generator=g))
+    out = []
+    for fused in (False, True):
+        m = C.get_model(C.default_targetdiff_config(13))
+        m.load_state_dict(synthetic_sd, strict=True)
+        m = m.to(DEV).train()
+        m.fused_training_ops = fused
+        ld, res = m(batch, t=t, noise=noise)
+        (ld["pos"] + 100.0 * ld["atom"]).backward()
+        out.append((ld, res, torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.requires_grad]).clone()))
+    (l0, r0, g0), (l1, r1, g1) = out
+    for k in ("pos", "atom"):       # (the atom loss is a sum of cancelling terms: see the test above)
+        assert abs(float(l0[k].detach()) - float(l1[k].detach())) <= 1e-4 * abs(float(l0[k].detach())), (k, l0[k], l1[k])
+    assert sorted(r0) == sorted(r1)
+    for k in r0:
+        a, b = r0[k], r1[k]
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        assert torch.equal(a, b) if a.dtype in (torch.int64, torch.bool) else float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), k
+    # every parameter gradient: the two paths hand the backward d/dlogits that differ by ~1e-4 of their largest entry (above)
+    d = (g0 - g1).double()
+    assert float(d.norm()) <= 5e-4 * float(g0.double().norm()) and float(d.abs().max()) <= 5e-4 * float(g0.abs().max()), (
+        float(d.norm()) / float(g0.double().norm()), float(d.abs().max()) / float(g0.abs().max()))
+    # evaluation mode (no autograd): the same losses from the fused path
+    m.eval()
+    with torch.no_grad():
+        ld2, _ = m.get_loss(batch, t, noise)
+    assert abs(float(ld2["atom"]) - float(l1["atom"])) <= 1e-4 * abs(float(l1["atom"]))
