@@ -106,7 +106,7 @@ static TrainWs carve_train(void* base, int n) {
     w.qs = (float*)take(N * H * 4);
     w.dqb = (float*)take(N * H * 4);
     w.zb = (float*)take(N * H * 4);
-    w.dP = (float*)take(N * PROW * 4);
+    w.dP = (float*)take(N * PROW * 4 + 256);      // + the x2h edge backward's work counters: zeroed by the same fill
     w.gh = (float*)take(N * H * 4);
     w.gx[0] = (float*)take(N * 3 * 4);
     w.gx[1] = (float*)take(N * 3 * 4);
@@ -195,7 +195,7 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
             HIP_TRY(launch_node_mfma(att, h_in, lig, n, w.P, w.qs, w.Qt, rows, n_rows, nullptr, nullptr, s, x2h));
     }
     if (x2h) HIP_TRY(launch_fold_grad(att, g_out, n, w.Gt, w.gb, s));
-    HIP_TRY(hipMemsetAsync(w.dP, 0, (size_t)n * PROW * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(w.dP, 0, (size_t)n * PROW * sizeof(float) + 256, s));     // (and the work counters behind it)
     if (!qln) {
         qln = w.qln;
         HIP_TRY(hipMemsetAsync(qln, 0, 2 * H * sizeof(float), s));
@@ -210,7 +210,7 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
 #endif
     if (gen3)
         HIP_TRY(launch_edge_backward_x2h(att, x, Pn, Qn, w.Gt, w.gb, nbr, deg, lig, e_w, rows, n_rows, n, w.T, w.S, w.sw,
-                                         w.dP, dx, de_w, w.partial, w.nk, eg, s));
+                                         w.dP, dx, de_w, w.partial, w.nk, reinterpret_cast<int*>(w.dP + (size_t)n * PROW), eg, s));
     else
         HIP_TRY(launch_edge_backward_mfma(x2h, att, x, Pn, Qn, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n,
                                           w.T, w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s, 1));
@@ -535,7 +535,10 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
     }
     if (grad_h_in) HIP_TRY(hipMemcpyAsync(grad_h_in, gh_cur, nh * 4, hipMemcpyDeviceToDevice, s));
     // distance gate (computed once from the input coordinates, used by all 2L blocks)
-    HIP_TRY(launch_gate_backward(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.E8, w.partial, GATE_GRID, s));
+    if (g_edge_impl != 1)
+        HIP_TRY(launch_gate_backward_mfma(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.partial, GATE_GRID, s));
+    else        // first-generation cross-check (libcbgx_xcheck.so, cbgx_debug_set_edge_kernel(1)): the two VALU kernels
+        HIP_TRY(launch_gate_backward(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.E8, w.partial, GATE_GRID, s));
     FOLDED(w.partial, GATE_GRID, GB_SIZE, GB_SIZE);
     RS(fz + GB_W1, fn, fs, G, GH, G, grads[0], G, 0);
     RS(fz + GB_B1, fn, fs, GH, 1, GH, grads[1], GH, 0);
@@ -626,7 +629,10 @@ int cbgx_h2x_stack_backward(const float* packed, int num_layers, const void* tap
         cur = nxt;
     }
     HIP_TRY(hipMemcpyAsync(grad_h, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(launch_gate_backward(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.E8, w.partial, GATE_GRID, s));
+    if (g_edge_impl != 1)
+        HIP_TRY(launch_gate_backward_mfma(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.partial, GATE_GRID, s));
+    else        // first-generation cross-check (libcbgx_xcheck.so, cbgx_debug_set_edge_kernel(1)): the two VALU kernels
+        HIP_TRY(launch_gate_backward(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.E8, w.partial, GATE_GRID, s));
     FOLDED(w.partial, GATE_GRID, GB_SIZE, GB_SIZE);
     RS(fz + GB_W1, fn, fs, G, GH, G, grads[0], G, 0);
     RS(fz + GB_B1, fn, fs, GH, 1, GH, grads[1], GH, 0);

@@ -47,12 +47,13 @@ hipError_t launch_edge_backward_mfma(bool x2h, const float* att, const float* x,
                                      const int* n_rows, int n_nodes, float* T, float* S, float* sw, float* dP, float* dx,
                                      float* de_w, float* partial, int grid, hipStream_t s, int centred = 0);
 // third-generation x2h backward (train_bwd_x2h.hip): one wavefront per node, 8 nodes in flight per workgroup; P must be the
-// centred projection of the MFMA node kernel.  grid = edge_grid_x2h(n) workgroups, one PB_SIZE slab each.
+// centred projection of the MFMA node kernel.  grid = edge_grid_x2h(n) workgroups, one PB_SIZE slab each.  work_ctr: 8 ints, ZERO at
+// launch (the per-XCD counters of the last, partial round of nodes).
 hipError_t launch_edge_backward_x2h(const float* att, const float* x, const float* P, const float* Qt, const float* Gt,
                                     const float* gb, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                                     const float* e_w, const int* rows, const int* n_rows, int n_nodes, float* T, float* S,
-                                    float* sw, float* dP, float* dx, float* de_w, float* partial, float* nk_scratch, int grid,
-                                    hipStream_t s);
+                                    float* sw, float* dP, float* dx, float* de_w, float* partial, float* nk_scratch,
+                                    int* work_ctr, int grid, hipStream_t s);
 // floats of nk_scratch: one slot per wave of the largest grid (the key path parked between two phases of a node)
 constexpr size_t BX_NK_FLOATS = (size_t)256 * 8 * (KNN * H + 128);
 hipError_t launch_fold_grad(const float* att, const float* Gr, int n_nodes, float* Gt, float* gb, hipStream_t s);
@@ -101,6 +102,8 @@ hipError_t launch_sgemm(bool ta, bool tb, const float* A, int lda, const float* 
                         int N, int K, int splits, size_t c_split_stride, int accumulate, hipStream_t s);
 hipError_t launch_gate_backward(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
                                 const float* de_w, float* E8, float* partial, int grid, hipStream_t s);
+hipError_t launch_gate_backward_mfma(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
+                                     const float* de_w, float* partial, int grid, hipStream_t s);
 hipError_t launch_ssp_backward(const float* pre, const float* dact, long n, float* dpre, hipStream_t s);
 // train_loss.hip: TargetDiff's forward noising, its two losses with their gradients, and the scatter of those gradients
 hipError_t launch_train_noise(const float* x0, const int64_t* v0, const int64_t* t, const int64_t* batch, const uint8_t* gen,

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig,
     const float* __restrict__ e_w, const int* __restrict__ rows, const int* __restrict__ n_rows_ptr, int n_nodes,
     float* __restrict__ T, float* __restrict__ S, float* __restrict__ sw, float* __restrict__ dP, float* __restrict__ dx,
-    float* __restrict__ de_w, float* __restrict__ partial, float* __restrict__ nk_scratch
+    float* __restrict__ de_w, float* __restrict__ partial, float* __restrict__ nk_scratch, int* __restrict__ work_ctr
 #ifdef CBGX_ABLATE
     , int abl
 #endif
@@ -145,18 +145,35 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
     // (rows -> deg / nbr -> coordinates) would otherwise open every node
     // XCD-aware persistent schedule (as the forward kernel): workgroup b runs on XCD b % 8, so every XCD gets one contiguous
     // eighth of the work list -- a graph's projection rows and their gradient rows then live in one L2
-    int it, it_end, stride;
+    // Static rounds, dynamic remainder: a training batch is ~8 nodes per wave (16.5 k nodes on 2048 waves), so with a purely
+    // static partition the waves that own a ninth node set the kernel time (9 rounds for 8.06 nodes per wave on average).  Every
+    // wave runs the rounds that are full for its XCD; the nodes of the last, partial round are handed out through one counter
+    // per XCD (work_ctr [8], zeroed by the caller) to the waves that finish first.
+    int it, it_end, stride, full_rounds, tail_base;
+    int* ctr;
     if ((gridDim.x & 7) == 0) {
         const int per_xcd = (((count + 7) >> 3) + BX_WAVES - 1) / BX_WAVES * BX_WAVES;
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        it = xcd * per_xcd + slot * BX_WAVES + wave;
+        const int base = min(count, xcd * per_xcd);
         it_end = min(count, (xcd + 1) * per_xcd);
         stride = (gridDim.x >> 3) * BX_WAVES;
+        it = base + slot * BX_WAVES + wave;
+        full_rounds = (it_end - base) / stride;
+        tail_base = base + full_rounds * stride;
+        ctr = work_ctr + xcd;
     } else {
         it = blockIdx.x * BX_WAVES + wave;
         it_end = count;
         stride = gridDim.x * BX_WAVES;
+        full_rounds = count / stride;
+        tail_base = full_rounds * stride;
+        ctr = work_ctr;
     }
+    auto grab = [&]() {       // next node of the partial round (wave-uniform); it >= it_end when none is left
+        int k = 0;
+        if (lane0 == 0) k = atomicAdd(ctr, 1);
+        it = tail_base + __builtin_amdgcn_readfirstlane(k);
+    };
     int i_n = 0, d_n = 0, lig_n = 0, jr_n[2] = {0, 0};
     auto load_header = [&](int itx) {
         i_n = __builtin_amdgcn_readfirstlane(rows ? rows[itx] : itx);
@@ -165,12 +182,15 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
         jr_n[0] = nbr[(size_t)i_n * KNN + c0];
         jr_n[1] = nbr[(size_t)i_n * KNN + 16 + c0];
     };
+    int round = 0;
+    if (full_rounds == 0) grab();
     if (it < it_end) load_header(it);
-    for (; it < it_end; it += stride) {
+    while (it < it_end) {
         const int i = i_n;
         const int d = __builtin_amdgcn_readfirstlane(d_n), lig_i = __builtin_amdgcn_readfirstlane(lig_n);
         const int jr[2] = {jr_n[0], jr_n[1]};
-        load_header(it + stride < it_end ? it + stride : it);
+        const bool next_static = round + 1 < full_rounds;      // the next node is known: its header travels behind this node's work
+        if (next_static) load_header(it + stride);
         // the lane coordinates are re-materialised every node: otherwise every per-lane address below is loop-invariant, gets
         // hoisted out of the node loop as a 64-bit pointer pair and spilled
         int lane = lane0, c = c0, q = q0;
@@ -835,6 +855,14 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
         }
         wave_sync();
         BX_T(9);
+        if (next_static) {
+            it += stride;
+            ++round;
+        } else {        // the partial round: whoever gets here first takes the next node (its header loads are exposed, once)
+            round = full_rounds;
+            grab();
+            if (it < it_end) load_header(it);
+        }
     }
     // per-workgroup partial sums of the edge-indexed weight gradients
     __syncthreads();
@@ -847,8 +875,8 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
 hipError_t launch_edge_backward_x2h(const float* att, const float* x, const float* P, const float* Qt, const float* Gt,
                                     const float* gb, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                                     const float* e_w, const int* rows, const int* n_rows, int n_nodes, float* T, float* S,
-                                    float* sw, float* dP, float* dx, float* de_w, float* partial, float* nk_scratch, int grid,
-                                    hipStream_t s) {
+                                    float* sw, float* dP, float* dx, float* de_w, float* partial, float* nk_scratch,
+                                    int* work_ctr, int grid, hipStream_t s) {
     profile_mark_begin(rows ? K_EDGE_X2H_BWD_LISTED : K_EDGE_X2H_BWD, s);
 #ifdef CBGX_ABLATE
     static const int abl = getenv("CBGX_BWD_ABL") ? atoi(getenv("CBGX_BWD_ABL")) : 0;
@@ -858,7 +886,7 @@ hipError_t launch_edge_backward_x2h(const float* att, const float* x, const floa
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bx_prof), z, sizeof(z));
     }
     hipLaunchKernelGGL(edge_backward_x2h_kernel, dim3(grid), dim3(BX_WAVES * 64), 0, s, att, x, P, Qt, Gt, gb, nbr, deg, lig,
-                       e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, nk_scratch, abl);
+                       e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, nk_scratch, work_ctr, abl);
     if (prof && !rows) {
         unsigned long long z[16];
         (void)hipStreamSynchronize(s);
@@ -876,7 +904,7 @@ hipError_t launch_edge_backward_x2h(const float* att, const float* x, const floa
     }
 #else
     hipLaunchKernelGGL(edge_backward_x2h_kernel, dim3(grid), dim3(BX_WAVES * 64), 0, s, att, x, P, Qt, Gt, gb, nbr, deg, lig,
-                       e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, nk_scratch);
+                       e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, nk_scratch, work_ctr);
 #endif
     profile_mark_end(s);
     return hipGetLastError();

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "edge_common.h"
 #include "kernels.h"
 #include "layout.h"
 #include "train.h"
@@ -364,6 +365,178 @@ __global__ __launch_bounds__(GH) void gate_bwd_weight_kernel(const float* __rest
     if (u == 0) slab[GB_B2] = aB2;
 }
 
+// The same backward as ONE kernel on the matrix pipe (product path; the two kernels above stay as the cross-check of
+// libcbgx_xcheck.so).  A wave owns tiles of 16 edge slots (half a node):
+//   Y = R W1^T          [16 edges x 160 units], k = 20 rbf      50 v_mfma_f32_16x16x4_f32, Y stays in 40 registers
+//                       D layout: lane (j, q), tile nt, register r <-> edge 4 q + r, unit 16 nt + j
+//   per edge: LayerNorm statistics, the gate value and its gradient, the two sums of the LayerNorm backward -- reductions over the
+//             units = over the 16 lanes of a row (DPP) and the 10 tiles
+//   d W1 += dpre^T R    k = the 16 edges                        80 MFMAs into 20 accumulator tiles (register r of the D layout of
+//                       dpre is the A operand of k-slot q, the rbf of edge 4 q + r at g = lane & 15 the B operand)
+//   per unit: d b1, d gamma, d beta, d W2 accumulate in the lanes that own the unit.
+// The edge pass above evaluates the 160 x 20 products four times per edge on the vector ALU (292 us for 528 k edge slots) and parks
+// eight scalars per edge for the weight pass (205 us); here nothing is parked.  One slab (train.h GB_*) per WAVE.
+constexpr int GATE_WAVES = 4;
+__global__ __launch_bounds__(GATE_WAVES * 64) void gate_bwd_mfma_kernel(const float* __restrict__ wts, const float* __restrict__ x,
+                                                                      const int32_t* __restrict__ nbr,
+                                                                      const int32_t* __restrict__ deg, int n_nodes,
+                                                                      const float* __restrict__ de_w, float* __restrict__ partial) {
+    typedef float floatx4 __attribute__((ext_vector_type(4)));
+    constexpr int NT = GH / 16;      // 10 unit tiles
+    constexpr int KS = G / 4;        // 5 k-steps of the first product
+    __shared__ float sP[4][GH];      // b1 | gamma | beta | W2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+    for (int u = tid; u < 4 * GH; u += GATE_WAVES * 64) (&sP[0][0])[u] = wts[GATE_B1 + u];      // B1, LNG, LNB, W2 are contiguous
+    __syncthreads();
+    // B operand of Y = R W1^T: lane (j, q) supplies W1[unit 16 nt + j][g = 4 s + q]
+    float w1[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) w1[nt][s] = wts[GATE_W1 + (size_t)(16 * nt + j) * G + 4 * s + q];
+    const float b2 = wts[GATE_B2];
+    float mu_a[KS];                  // rbf centres of this lane's A slots (g = 4 s + q) and B slots (g = j, 16 + (j & 3))
+#pragma unroll
+    for (int s = 0; s < KS; ++s) mu_a[s] = c_mu_b[4 * s + q];
+    const float mu_b0 = c_mu_b[j], mu_b1 = c_mu_b[16 + (j & 3)];
+    floatx4 dw[NT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { dw[nt][0] = floatx4{0.f, 0.f, 0.f, 0.f}; dw[nt][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+    float aB1[NT], aG[NT], aBe[NT], aW2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { aB1[nt] = 0.f; aG[nt] = 0.f; aBe[nt] = 0.f; aW2[nt] = 0.f; }
+    float aB2 = 0.f;
+    const long n_tiles = (long)n_nodes * (KNN / 16);
+    const long stride = (long)gridDim.x * GATE_WAVES;
+    long tile = (long)blockIdx.x * GATE_WAVES + wave;
+    // geometry of a tile: lane (j, *) <-> edge slot 16 (tile & 1) + j of node tile >> 1; fetched one tile ahead
+    float dist_n = 0.f, dew_n = 0.f;
+    auto fetch = [&](long tl) {
+        const int i = (int)(tl >> 1), sl = 16 * (int)(tl & 1) + j;
+        const bool valid = sl < deg[i];
+        const int nb = valid ? nbr[(size_t)i * KNN + sl] : i;
+        const float dx = x[3 * i] - x[3 * nb], dy = x[3 * i + 1] - x[3 * nb + 1], dz = x[3 * i + 2] - x[3 * nb + 2];
+        dist_n = sqrtf(dx * dx + dy * dy + dz * dz);
+        dew_n = valid ? de_w[(size_t)i * KNN + sl] : 0.f;       // invalid slots: zero upstream gradient -> zero everywhere below
+    };
+    if (tile < n_tiles) fetch(tile);
+    for (; tile < n_tiles; tile += stride) {
+        const float dist = dist_n, dew = dew_n;
+        fetch(tile + stride < n_tiles ? tile + stride : tile);
+        // ---- Y = R W1^T + b1
+        floatx4 y[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) y[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float t = dist - mu_a[s];
+            const float ra = expf(-0.5f * (t * t));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) y[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra, w1[nt][s], y[nt], 0, 0, 0);
+        }
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float b1 = sP[0][16 * nt + j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { y[nt][r] += b1; sum[r] += y[nt][r]; }
+        }
+        float mean[4], rstd[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mean[r] = row16_sum(sum[r]) * (1.f / GH);
+        float var[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { y[nt][r] -= mean[r]; var[r] = fmaf(y[nt][r], y[nt][r], var[r]); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rstd[r] = 1.f / sqrtf(row16_sum(var[r]) * (1.f / GH) + 1e-5f);
+        // ---- gate value -> d L / d (pre-sigmoid) of the four edges 4 q + r
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float gam = sP[1][16 * nt + j], bet = sP[2][16 * nt + j], w2 = sP[3][16 * nt + j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                y[nt][r] *= rstd[r];                                      // y = the normalised pre-activation n from here on
+                acc[r] = fmaf(w2, fmaxf(fmaf(y[nt][r], gam, bet), 0.f), acc[r]);
+            }
+        }
+        float dacc[4], dist_e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = row16_sum(acc[r]) + b2;
+            const float ew = 1.f / (1.f + expf(-a));
+            dacc[r] = __shfl(dew, 4 * q + r, 64) * ew * (1.f - ew);
+            dist_e[r] = __shfl(dist, 4 * q + r, 64);
+        }
+        // ---- LayerNorm backward: d n, its two per-edge sums, d pre (in place in y); per-unit sums on the way
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float gam = sP[1][16 * nt + j], bet = sP[2][16 * nt + j], w2 = sP[3][16 * nt + j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float n = y[nt][r];
+                const float ya = fmaf(n, gam, bet);
+                aW2[nt] = fmaf(dacc[r], fmaxf(ya, 0.f), aW2[nt]);
+                const float dy = ya > 0.f ? dacc[r] * w2 : 0.f;
+                aG[nt] = fmaf(dy, n, aG[nt]);
+                aBe[nt] += dy;
+                const float dn = dy * gam;
+                s1[r] += dn;
+                s2[r] = fmaf(dn, n, s2[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]) * (1.f / GH); s2[r] = row16_sum(s2[r]) * (1.f / GH); }
+        if (j == 0) aB2 += (dacc[0] + dacc[1]) + (dacc[2] + dacc[3]);
+        // B operand of d W1: rbf of edge 4 q + r at g = j (tile 0) and g = 16 + j (tile 1, j < 4)
+        float rb0[4], rb1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t0 = dist_e[r] - mu_b0, t1 = dist_e[r] - mu_b1;
+            rb0[r] = expf(-0.5f * (t0 * t0));
+            rb1[r] = j < 4 ? expf(-0.5f * (t1 * t1)) : 0.f;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float gam = sP[1][16 * nt + j], bet = sP[2][16 * nt + j], w2 = sP[3][16 * nt + j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float n = y[nt][r];
+                const float dn = fmaf(n, gam, bet) > 0.f ? dacc[r] * w2 * gam : 0.f;
+                const float dp = rstd[r] * (dn - s1[r] - n * s2[r]);
+                aB1[nt] += dp;
+                dw[nt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp, rb0[r], dw[nt][0], 0, 0, 0);
+                dw[nt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp, rb1[r], dw[nt][1], 0, 0, 0);
+            }
+        }
+    }
+    // ---- this wave's slab.  d W1 tiles: lane (gc = j, qq = q), register rr <-> unit 16 nt + 4 qq + rr, g = 16 gt + gc
+    float* slab = partial + ((size_t)blockIdx.x * GATE_WAVES + wave) * GB_SIZE;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int u = 16 * nt + 4 * q + rr;
+            slab[GB_W1 + u * G + j] = dw[nt][0][rr];
+            if (j < 4) slab[GB_W1 + u * G + 16 + j] = dw[nt][1][rr];
+        }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {     // per-unit sums: over the four q groups
+        const float v1 = xrow_sum(aB1[nt]), v2 = xrow_sum(aG[nt]), v3 = xrow_sum(aBe[nt]), v4 = xrow_sum(aW2[nt]);
+        if (q == 0) {
+            slab[GB_B1 + 16 * nt + j] = v1;
+            slab[GB_LNG + 16 * nt + j] = v2;
+            slab[GB_LNB + 16 * nt + j] = v3;
+            slab[GB_W2 + 16 * nt + j] = v4;
+        }
+    }
+    const float vb2 = xrow_sum(aB2);
+    if (lane == 0) slab[GB_B2] = vb2;
+}
+
 // classifier: d(pre) = d(act) * sigmoid(pre)   (derivative of softplus(x) - ln 2)
 __global__ void ssp_backward_kernel(const float* __restrict__ pre, const float* __restrict__ dact, long n,
                                     float* __restrict__ dpre) {
@@ -455,6 +628,15 @@ hipError_t launch_sgemm(bool ta, bool tb, const float* A, int lda, const float* 
     else if (ta && !tb) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, k_chunk, c_split_stride, accumulate);
     else hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, k_chunk, c_split_stride, accumulate);
     profile_mark_end(s);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// product path: one fused kernel; `grid` slabs of GB_SIZE floats in `partial`, every one written (grid a multiple of GATE_WAVES)
+hipError_t launch_gate_backward_mfma(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
+                                     const float* de_w, float* partial, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(gate_bwd_mfma_kernel, dim3(grid / GATE_WAVES), dim3(GATE_WAVES * 64), 0, s, packed, x, nbr, deg, n_nodes,
+                       de_w, partial);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -75,12 +75,12 @@ def _three_ways(C_, B, seed, t_list, scale):
     x_t = ps.forward_add_noise(c["x0"], c["t"], c["bl"], c["gen"], noise=c["eps"])[0]
     out = []
     for dt in (torch.float64, torch.float32):       # tensor path (targetdiff.py get_loss with fused_training_ops = False)
-        xo, logits = xo32.to(dt).requires_grad_(True), lg32.to(dt).requires_grad_(True)
+        xo, logits = xo32.detach().clone().to(dt).requires_grad_(True), lg32.detach().clone().to(dt).requires_grad_(True)
         lp, ip = ps.get_loss(xo[lig_rows], c["x0"].to(dt), x_t.to(dt), c["t"], c["gen"], c["bl"], type="denoise")
         la, ia = ts.get_loss(logits[lig_rows], c["v0"], v_t, c["t"], c["gen"], c["bl"], pred_logit=True)
         (1.0 * lp + 100.0 * la).backward()
         out.append((lp.detach(), la.detach(), xo.grad, logits.grad, ip["x_pred"].detach(), ia["c_pred"].detach()))
-    xo, logits = xo32.clone().requires_grad_(True), lg32.clone().requires_grad_(True)
+    xo, logits = xo32.detach().clone().requires_grad_(True), lg32.detach().clone().requires_grad_(True)
     tables = (ts.log_alphas_v, ts.log_one_minus_alphas_v, ts.log_alphas_cumprod_v, ts.log_one_minus_alphas_cumprod_v)
     fp, fa, x_pred, c_pred = TD._TargetDiffLossFunction.apply(xo, logits, lig_rows.contiguous(), sort_idx.contiguous(), n_rec, c["x0"],
                                                               c["v0"], v_t, c["t"], c["bl"], c["gen"], tables)
@@ -137,6 +137,7 @@ def test_training_step_through_the_fused_path_equals_tensor_path(synthetic_sd):
     for k in r0:
         a, b = r0[k], r1[k]
         assert a.shape == b.shape and a.dtype == b.dtype, k
+        a, b = a.detach(), b.detach()
         assert torch.equal(a, b) if a.dtype in (torch.int64, torch.bool) else float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), k
     # every parameter gradient: the two paths hand the backward d/dlogits that differ by ~1e-4 of their largest entry (above)
     d = (g0 - g1).double()
