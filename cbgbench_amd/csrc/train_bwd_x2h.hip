@@ -66,6 +66,11 @@ __constant__ float c_mu_x[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 
 #define CBGX_BX_WAVES 8      // experiments: scripts/build_variant.py <name> -DCBGX_BX_WAVES=4 (one wave per SIMD, 512 registers)
 #endif
 constexpr int BX_WAVES = CBGX_BX_WAVES;
+#ifndef CBGX_BX_DYN_ROUNDS
+#define CBGX_BX_DYN_ROUNDS 2     // rounds of nodes handed out dynamically at the end of a launch: the partial round and one full one
+                                 // (A/B, scripts/build_variant.py: 1 -> 851, 2 -> 829, 3 -> 845 us per 16.5 k-node launch)
+#endif
+constexpr int BX_DYN_ROUNDS = CBGX_BX_DYN_ROUNDS;
 constexpr int BX_PITCH = H + 4;                 // transpose tile row pitch (floats): 16-byte aligned rows
 constexpr int BX_TILE = KNN * BX_PITCH;         // 4224 floats per wave
 // the four pad columns of a tile row hold per-edge scalars of the node (row = edge) instead of living in registers across the
@@ -147,8 +152,8 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
     // eighth of the work list -- a graph's projection rows and their gradient rows then live in one L2
     // Static rounds, dynamic remainder: a training batch is ~8 nodes per wave (16.5 k nodes on 2048 waves), so with a purely
     // static partition the waves that own a ninth node set the kernel time (9 rounds for 8.06 nodes per wave on average).  Every
-    // wave runs the rounds that are full for its XCD; the nodes of the last, partial round are handed out through one counter
-    // per XCD (work_ctr [8], zeroed by the caller) to the waves that finish first.
+    // wave runs the rounds that are full for its XCD except the last BX_DYN_ROUNDS - 1 of them; the nodes of those and of the
+    // partial round are handed out through one counter per XCD (work_ctr [8], zeroed by the caller) to the waves that finish first.
     int it, it_end, stride, full_rounds, tail_base;
     int* ctr;
     if ((gridDim.x & 7) == 0) {
@@ -158,14 +163,14 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
         it_end = min(count, (xcd + 1) * per_xcd);
         stride = (gridDim.x >> 3) * BX_WAVES;
         it = base + slot * BX_WAVES + wave;
-        full_rounds = (it_end - base) / stride;
+        full_rounds = max((it_end - base) / stride - (BX_DYN_ROUNDS - 1), 0);
         tail_base = base + full_rounds * stride;
         ctr = work_ctr + xcd;
     } else {
         it = blockIdx.x * BX_WAVES + wave;
         it_end = count;
         stride = gridDim.x * BX_WAVES;
-        full_rounds = count / stride;
+        full_rounds = max(count / stride - (BX_DYN_ROUNDS - 1), 0);
         tail_base = full_rounds * stride;
         ctr = work_ctr;
     }

@@ -94,7 +94,7 @@ def _three_ways(C_, B, seed, t_list, scale):
 def test_fused_losses_and_their_gradients_equal_tensor_path(C_, B, t_list, scale):
     """The KL between two nearly equal posteriors is a sum of cancelling terms: in fp32 its value moves by ~1e-5 of itself with the
     association order (measured on the tensor path itself, fp32 against fp64).  So the yardstick is the tensor path in fp64, and the
-    fused kernels must be as close to it as the fp32 tensor path is (within a factor 4, or 5e-6 when that path happens to be exact)."""
+    fused kernels must be as close to it as the fp32 tensor path is (within a factor 4, with floors at that path's typical distance)."""
     (r64, r32, got), lig_flag = _three_ways(C_, B, 11 + B, t_list, scale)
     report = []
     for k, name in ((0, "loss_pos"), (1, "loss_atom"), (2, "d/dx_out"), (3, "d/dlogits")):
@@ -103,7 +103,9 @@ def test_fused_losses_and_their_gradients_equal_tensor_path(C_, B, t_list, scale
         e32 = float((r32[k].double() - ref).abs().max()) / scale_
         eg = float((got[k].double() - ref).abs().max()) / scale_
         report.append((name, e32, eg))
-        assert torch.isfinite(got[k]).all() and eg <= max(4.0 * e32, 5e-6), report
+        # floors: the fp32 tensor path itself sits 2e-7 .. 3e-5 (losses) and 4e-5 .. 1.3e-4 (gradients, of the largest entry) from
+        # fp64 over these cases and CPU replays of them; a case where it happens to land closer must not tighten the bar
+        assert torch.isfinite(got[k]).all() and eg <= max(4.0 * e32, 5e-5 if k < 2 else 2e-4), report
     for k in (2, 3):
         assert float(got[k][~lig_flag].abs().max()) == 0.0          # protein rows: exact zeros
     assert torch.equal(got[4], r32[4])                               # x_pred: a gather
