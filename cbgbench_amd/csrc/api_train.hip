@@ -168,7 +168,10 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
                                     const int32_t* nbr, const int32_t* deg, const uint8_t* lig, const float* e_w,
                                     const int* rows, const int* n_rows, int n, TrainWs& w, float* gh, float* dx,
                                     float* de_w, float* const* grads, hipStream_t s, const float* P_saved = nullptr,
-                                    const float* Qt_saved = nullptr, float* qln = nullptr, const float* gh_src = nullptr) {
+                                    const float* Qt_saved = nullptr, float* qln = nullptr, const float* gh_src = nullptr,
+                                    const int* dp_rows = nullptr, const int* dp_n_rows = nullptr) {
+    // `dp_rows` / `dp_n_rows` (h2x blocks): a device-side list that contains every row of dP this block can touch (the listed nodes
+    // and their neighbours); the dense products and column sums over dP then walk the list instead of all N rows
     // `qln` [2][128]: zeroed accumulator of the query LayerNorm's affine gradients (nullptr: w.qln, zeroed here);
     // `gh_src`: gh = gh_src + (this block's contribution) instead of gh += (the caller then needs no snapshot of g_out == gh_src)
     // x2h blocks run the one-wave-per-node backward (8 nodes in flight per workgroup); h2x blocks and, in libcbgx_xcheck.so,
@@ -273,7 +276,7 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     }
     HIP_TRY(outer(false, w.dqb, w.zb, rows, n_rows, n, pn + NS_WQ1, NS_SIZE, ng, s));
     HIP_TRY(launch_colsum(w.dqb, H, H, nullptr, rows, n_rows, n, pn + NS_Q1B, NS_SIZE, ng, s));
-    HIP_TRY(launch_colsum(w.dP, PROW, PROW, nullptr, nullptr, nullptr, n, pn + NS_DP, NS_SIZE, ng, s));
+    HIP_TRY(launch_colsum(w.dP, PROW, PROW, nullptr, dp_rows, dp_n_rows, n, pn + NS_DP, NS_SIZE, ng, s));
     {
         folded(pn, ng, NS_SIZE, NS_SIZE, w.folded_node);
         piece(fz + NS_WBK, fn, fs, H, H, H, k1w, H, 0);
@@ -293,7 +296,8 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     // dense projection: dWn[k][n] = sum_i h_in[i][k] dP[i][n]  -> h_dst / h_src / q columns of the first Linears
     const int sp = mfma ? wgrad_groups(n) : (splits_for(n) > 32 ? 32 : splits_for(n));
     if (mfma)
-        HIP_TRY(launch_wgrad_mfma(h_in, H, w.dP, PROW, n, PROW / H, w.partial_wgrad, PROW, (size_t)H * PROW, sp, s));
+        HIP_TRY(launch_wgrad_mfma(h_in, H, w.dP, PROW, n, PROW / H, w.partial_wgrad, PROW, (size_t)H * PROW, sp, s, dp_rows,
+                                  dp_n_rows));
     else
         HIP_TRY(launch_sgemm(true, false, h_in, H, w.dP, PROW, w.partial_wgrad, PROW, H, PROW, n, sp, (size_t)H * PROW, 0, s));
     {
@@ -308,7 +312,8 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     HIP_TRY(launch_reduce_store_multi(rb, s));
     // dL/dh_in = (gh_src or gh itself) + dP Wn^T
     if (mfma)
-        HIP_TRY(launch_dgrad_mfma(w.dP, PROW, att + A_WN, PROW, gh, H, n, PROW, 1, s, gh_src));
+        HIP_TRY(launch_dgrad_mfma(w.dP, PROW, att + A_WN, PROW, gh, H, n, PROW, 1, s, gh_src, gh_src ? nullptr : dp_rows,
+                                  gh_src ? nullptr : dp_n_rows));
     else {
         if (gh_src && gh_src != gh) HIP_TRY(hipMemcpyAsync(gh, gh_src, (size_t)n * H * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(launch_sgemm(false, true, w.dP, PROW, att + A_WN, PROW, gh, H, n, H, PROW, 1, 0, 1, s));
@@ -521,7 +526,9 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         RC_TRY(attention_block_backward(false, packed + h2x_off(l), xl, h_mid, w.gx[cur], tp.nbr, tp.deg, lig_flag, tp.e_w,
                                         w.act, w.act_count, n, w, gh_cur, w.gx[nxt], w.de_w, g + 18, s,
                                         Px + (size_t)n * PROW, Qx + (size_t)n * HEADS * H,
-                                        qln_slots ? w.qln + (size_t)(2 * l + 1) * 2 * H : nullptr));
+                                        qln_slots ? w.qln + (size_t)(2 * l + 1) * 2 * H : nullptr, nullptr,
+                                        // dP of an h2x block is non-zero on gen | nbr(gen) only, a subset of the receptive-field list A1
+                                        prune ? w.rf_list[0] : nullptr, prune ? w.rf_count : nullptr));
         // h_mid = h_in + X2H(x_l, h_in): gh_cur holds dL/dh_mid, which is also the residual part of dL/dh_in.  The block reads it
         // (fold, outer products, bias sums) and writes dL/dh_in = gh_cur + dP Wn^T into the OTHER buffer.
         const int k = L - 1 - l;      // 0 for the last layer

@@ -59,11 +59,14 @@ constexpr size_t BX_NK_FLOATS = (size_t)256 * 8 * (KNN * H + 128);
 hipError_t launch_fold_grad(const float* att, const float* Gr, int n_nodes, float* Gt, float* gb, hipStream_t s);
 hipError_t launch_outer_accum_mfma(bool headed, const float* Lm, const float* R, const int* rows, const int* n_rows,
                                    int n_nodes, float* partial, size_t slab_stride, int grid, hipStream_t s);
+// (`rows` / `n_rows`, wgrad and dgrad: restrict the node dimension to a device-side list -- the rows outside it are known to be zero)
 hipError_t launch_wgrad_mfma(const float* Lm, int ldl, const float* R, int ldr, int n_nodes, int col_blocks, float* partial,
-                             int ldo, size_t slab_stride, int groups, hipStream_t s);
+                             int ldo, size_t slab_stride, int groups, hipStream_t s, const int* rows = nullptr,
+                             const int* n_rows = nullptr);
 // `C_in` (accumulate only): the addend is read from C_in instead of C (same leading dimension) -- C = C_in + A B^T out of place
 hipError_t launch_dgrad_mfma(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K,
-                             int accumulate, hipStream_t s, const float* C_in = nullptr);
+                             int accumulate, hipStream_t s, const float* C_in = nullptr, const int* rows = nullptr,
+                             const int* n_rows = nullptr);
 hipError_t launch_q_backward_mfma(const float* att, const float* P, const float* T, const int* rows, const int* n_rows,
                                   int n_nodes, float* qs, float* dqb, float* zb, float* dP, float* partial, int grid,
                                   hipStream_t s);

@@ -926,10 +926,17 @@ __global__ __launch_bounds__(256) void outer_accum_mfma_kernel(const float* __re
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const float* __restrict__ Lm, int ldl, const float* __restrict__ R,
                                                          int ldr, int n_nodes, int nodes_per_group,
-                                                         float* __restrict__ partial, int ldo, size_t slab_stride) {
+                                                         float* __restrict__ partial, int ldo, size_t slab_stride,
+                                                         const int* __restrict__ rows, const int* __restrict__ n_rows_ptr) {
+    // `rows` / `n_rows_ptr`: sum over the listed nodes only (device-side count; the other rows of R are known to be zero -- the
+    // h2x blocks touch the movable nodes and their neighbours); the groups then split the list
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int cb = blockIdx.y;
+    if (rows) {
+        n_nodes = *n_rows_ptr;
+        nodes_per_group = ((n_nodes + (int)gridDim.x - 1) / (int)gridDim.x + 15) / 16 * 16;
+    }
     floatx4 acc[2][8];
 #pragma unroll
     for (int tr = 0; tr < 2; ++tr)
@@ -944,7 +951,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const float* __restrict
         for (int g = 0; g < 4; ++g) {
             const int it = base + 4 * g + kq;
             const bool ok = it < n1;
-            const unsigned node = (unsigned)(ok ? it : n0);
+            const int sel = ok ? it : n0;
+            const unsigned node = (unsigned)(rows ? rows[sel] : sel);
             const float live = ok ? 1.f : 0.f;
 #pragma unroll
             for (int tr = 0; tr < 2; ++tr) a[g][tr] = Lm[node * ldl + 32 * w + 16 * tr + i] * live;
@@ -989,8 +997,14 @@ constexpr int DG_KC = 32, DG_PITCH = DG_KC + 4;
 template <int TR>      // 16 TR rows per workgroup
 __global__ __launch_bounds__(256) void dgrad_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                          int ldb, float* C, int ldc, int M, int K,
-                                                         int accumulate, const float* C_in) {
+                                                         int accumulate, const float* C_in, const int* __restrict__ rows,
+                                                         const int* __restrict__ n_rows_ptr) {
+    // `rows` / `n_rows_ptr`: only the listed rows of A are multiplied and only those rows of C updated (device-side count)
     constexpr int DG_ROWS = 16 * TR;
+    if (rows) {
+        M = *n_rows_ptr;
+        if ((int)blockIdx.x * DG_ROWS >= M) return;
+    }
     __shared__ __attribute__((aligned(16))) float sA[2][DG_ROWS][DG_PITCH];
     __shared__ __attribute__((aligned(16))) float sB[2][H][DG_PITCH];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -1001,7 +1015,10 @@ __global__ __launch_bounds__(256) void dgrad_mfma_kernel(const float* __restrict
     constexpr int NA = TR / 2;      // float4 of A per thread and chunk
     unsigned ao[NA], bo[4];
 #pragma unroll
-    for (int u = 0; u < NA; ++u) ao[u] = (unsigned)min(row0 + lr + 32 * u, M - 1) * lda + lk;
+    for (int u = 0; u < NA; ++u) {
+        const int k = min(row0 + lr + 32 * u, M - 1);
+        ao[u] = (unsigned)(rows ? rows[k] : k) * lda + lk;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) bo[u] = (unsigned)(lr + 32 * u) * ldb + lk;
     // Two register sets: chunk c travels in set c & 1 and is requested TWO chunks before it is staged into LDS (one chunk of
@@ -1072,19 +1089,22 @@ __global__ __launch_bounds__(256) void dgrad_mfma_kernel(const float* __restrict
 #pragma unroll
     for (int tr = 0; tr < TR; ++tr) {
         float cold[2][4];
+        unsigned crow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = min(row0 + 16 * tr + 4 * kq + r, M - 1);
+            crow[r] = (unsigned)(rows ? rows[k] : k);
+        }
 #pragma unroll
         for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned row = (unsigned)min(row0 + 16 * tr + 4 * kq + r, M - 1);
-                cold[tc][r] = accumulate ? C_in[row * ldc + 32 * w + 16 * tc + i] : 0.f;
-            }
+            for (int r = 0; r < 4; ++r) cold[tc][r] = accumulate ? C_in[crow[r] * ldc + 32 * w + 16 * tc + i] : 0.f;
 #pragma unroll
         for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = row0 + 16 * tr + 4 * kq + r;
-                if (row < M) C[(unsigned)row * ldc + 32 * w + 16 * tc + i] = cold[tc][r] + acc[tr][tc][r];
+                if (row < M) C[crow[r] * ldc + 32 * w + 16 * tc + i] = cold[tc][r] + acc[tr][tc][r];
             }
     }
 }
@@ -1151,12 +1171,12 @@ hipError_t launch_outer_accum_mfma(bool headed, const float* Lm, const float* R,
 
 // C_slabs[g][128][ldo] (column blocks of 128) = partial sums over node groups of L^T R; returns the number of slabs
 hipError_t launch_wgrad_mfma(const float* Lm, int ldl, const float* R, int ldr, int n_nodes, int col_blocks, float* partial,
-                             int ldo, size_t slab_stride, int groups, hipStream_t s) {
+                             int ldo, size_t slab_stride, int groups, hipStream_t s, const int* rows, const int* n_rows) {
     if ((long)n_nodes * (ldl > ldr ? ldl : ldr) >= (1L << 32)) return hipErrorInvalidValue;
     const int per = ((n_nodes + groups - 1) / groups + 15) / 16 * 16;
     profile_mark_begin(K_TRAIN_GEMM, s);
     hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(groups, col_blocks), dim3(256), 0, s, Lm, ldl, R, ldr, n_nodes, per, partial,
-                       ldo, slab_stride);
+                       ldo, slab_stride, rows, n_rows);
     profile_mark_end(s);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
@@ -1164,7 +1184,7 @@ hipError_t launch_wgrad_mfma(const float* Lm, int ldl, const float* R, int ldr, 
 
 // C[M][128] (+)= A[M][K] B[128][K]^T, K a multiple of 64
 hipError_t launch_dgrad_mfma(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K,
-                             int accumulate, hipStream_t s, const float* C_in) {
+                             int accumulate, hipStream_t s, const float* C_in, const int* rows, const int* n_rows) {
     if (M <= 0) return hipSuccess;
     if (K % 64 != 0 || (long)M * (lda > ldc ? lda : ldc) >= (1L << 32)) return hipErrorInvalidValue;
     profile_mark_begin(K_TRAIN_GEMM, s);
@@ -1177,7 +1197,7 @@ hipError_t launch_dgrad_mfma(const float* A, int lda, const float* B, int ldb, f
 #endif
     // two workgroups of 32 rows per CU overlap each other's barriers and loads better than one of 64 (measured: 51.7 vs ... us)
     hipLaunchKernelGGL(dgrad_mfma_kernel<2>, dim3((M + 31) / 32), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, accumulate,
-                       C_in ? C_in : C);
+                       C_in ? C_in : C, rows, n_rows);
     profile_mark_end(s);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;

@@ -146,12 +146,26 @@ __global__ __launch_bounds__(256) void train_loss_kernel(
                 gk[k] = 0.f;
         }
         const float l_typ = m0 * nll + (1.f - m0) * kl;
+        // through log_p = un - logsumexp(un): du[k] = g[k] - p[k] G.  Over k it sums to G (1 - sum p) = 0, and for the class that
+        // holds almost all of p (the noisy type itself at most t: p and q both ~1 there) the direct form is the difference of two
+        // numbers of size 1 that agree to 4 - 7 digits -- in fp32 that entry, the largest of the row, keeps 1 - 3 digits.  It is
+        // therefore taken as minus the sum of the others, which are small numbers known to full relative precision.
+        float du_others = 0.f;
+        unsigned dom = 0u;      // one-hot: the first class at the maximum of un_p
+#pragma unroll
+        for (int k = 0; k < LC; ++k) {
+            if (k < C) {
+                gk[k] = gk[k] - expf(unp[k] - plse) * G;
+                const bool is_dom = dom == 0u && unp[k] == pmx;
+                dom |= is_dom ? 1u << k : 0u;
+                du_others += is_dom ? 0.f : gk[k];
+            }
+        }
         float R = 0.f;
 #pragma unroll
         for (int k = 0; k < LC; ++k) {
             if (k < C) {
-                const float p = expf(unp[k] - plse);
-                const float du = gk[k] - p * G;                       // through log_p = un - logsumexp(un)
+                const float du = ((dom >> k) & 1u) ? -du_others : gk[k];
                 gk[k] = du * expf((lp[k] + a0) - Ap[k]);             // through the log-add-exp: d A / d log_c_pred
                 R += gk[k];
             }
