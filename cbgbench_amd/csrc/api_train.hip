@@ -29,7 +29,10 @@ namespace cbgx { int set_error(int code, const char* fmt, ...); }
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 constexpr int EDGE_GRID = 256;    // persistent workgroups of the edge backward (one per CU: ~97 KB LDS each)
-constexpr int NODE_GRID = 256;    // persistent workgroups of the node-level reductions
+#ifndef CBGX_NODE_GRID
+#define CBGX_NODE_GRID 256        // A/B knob (scripts/build_variant.py)
+#endif
+constexpr int NODE_GRID = CBGX_NODE_GRID;    // persistent workgroups of the node-level reductions (one NS_SIZE slab each)
 constexpr int FOLD = 8;           // slab reductions are two-level: n_slabs -> FOLD (slab_fold_kernel) -> 1 (reduce_store)
 constexpr int GATE_GRID = 1024;  // gate weight-gradient kernel: 160-thread workgroups, four per CU keep every SIMD busy
 constexpr int MAX_SPLITS = 128;   // node groups of the weight-gradient products (one [128 x 640] partial slab each)
@@ -135,9 +138,13 @@ static TrainWs carve_train(void* base, int n) {
 static inline int edge_grid(int n) { return n < EDGE_GRID ? (n > 0 ? n : 1) : EDGE_GRID; }
 static inline int node_grid(int n) { return n < NODE_GRID ? (n > 0 ? n : 1) : NODE_GRID; }
 // node groups of wgrad_mfma_kernel: at least 128 nodes (8 passes) each
+#ifndef CBGX_WGRAD_GROUPS_MAX
+#define CBGX_WGRAD_GROUPS_MAX 51      // x 5 column blocks = 255 workgroups, one round on 256 CUs; 16.7 MB of partial slabs instead of 42
+                                      // (A/B, scripts/build_variant.py: 128 -> 1944, 102 -> 1965, 64 -> 1957, 51 -> 1968 graph-steps/s)
+#endif
 static inline int wgrad_groups(int n) {
     int g = (n + 127) / 128;
-    return g < 1 ? 1 : (g > MAX_SPLITS ? MAX_SPLITS : g);
+    return g < 1 ? 1 : (g > CBGX_WGRAD_GROUPS_MAX ? CBGX_WGRAD_GROUPS_MAX : g);
 }
 static inline int splits_for(int n) {
     int s = (n + 511) / 512;
@@ -253,7 +260,7 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     }
     // query MLP backward (fills dP[:, 512:640]); its LayerNorm affine gradients are accumulated into qln by atomics
     {
-        const int tiles = (n + 15) / 16, qgrid = tiles < 4 * NODE_GRID ? tiles : 4 * NODE_GRID;   // ~43 KB LDS: 3 per CU
+        const int tiles = (n + 15) / 16, qgrid = tiles < 1024 ? tiles : 1024;   // 25 KB of LDS, four waves per SIMD: four workgroups per CU
 #ifdef CBGX_XCHECK
         if (!mfma) HIP_TRY(launch_q_backward(att, Pn, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, qln, qgrid, s));
         else
