@@ -72,7 +72,7 @@ static Tape carve_tape(void* base, int n, int L) {
 
 // ---- backward workspace -----------------------------------------------------------------------------------
 struct TrainWs {
-    float *P, *Qt, *Gt, *T, *S, *gb, *sw, *qs, *dqb, *zb, *dP, *gh, *gx[2], *de_w, *E8, *tmp, *partial, *folded, *qln, *nk;
+    float *P, *Qt, *Gt, *T, *S, *gb, *sw, *qs, *dqb, *zb, *dP, *gh, *gx[2], *de_w, *tmp, *partial, *folded, *qln, *nk;
     // an attention block's three slab sets live side by side (edge slabs in `partial`), so that ONE fold launch and ONE
     // reduce-and-store launch per block serve all of them
     float *partial_node, *partial_wgrad, *folded_node, *folded_wgrad;
@@ -114,7 +114,6 @@ static TrainWs carve_train(void* base, int n) {
     w.gx[0] = (float*)take(N * 3 * 4);
     w.gx[1] = (float*)take(N * 3 * 4);
     w.de_w = (float*)take(N * KNN * 4);
-    w.E8 = (float*)take(N * KNN * 8 * 4);
     w.tmp = (float*)take(N * H * 4);
     w.act = (int*)take(N * 4);
     w.act_count = (int*)take(256);
@@ -549,10 +548,7 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
     }
     if (grad_h_in) HIP_TRY(hipMemcpyAsync(grad_h_in, gh_cur, nh * 4, hipMemcpyDeviceToDevice, s));
     // distance gate (computed once from the input coordinates, used by all 2L blocks)
-    if (g_edge_impl != 1)
-        HIP_TRY(launch_gate_backward_mfma(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.partial, GATE_GRID, s));
-    else        // first-generation cross-check (libcbgx_xcheck.so, cbgx_debug_set_edge_kernel(1)): the two VALU kernels
-        HIP_TRY(launch_gate_backward(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.E8, w.partial, GATE_GRID, s));
+    HIP_TRY(launch_gate_backward_mfma(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.partial, GATE_GRID, s));
     FOLDED(w.partial, GATE_GRID, GB_SIZE, GB_SIZE);
     RS(fz + GB_W1, fn, fs, G, GH, G, grads[0], G, 0);
     RS(fz + GB_B1, fn, fs, GH, 1, GH, grads[1], GH, 0);
@@ -643,10 +639,7 @@ int cbgx_h2x_stack_backward(const float* packed, int num_layers, const void* tap
         cur = nxt;
     }
     HIP_TRY(hipMemcpyAsync(grad_h, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
-    if (g_edge_impl != 1)
-        HIP_TRY(launch_gate_backward_mfma(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.partial, GATE_GRID, s));
-    else        // first-generation cross-check (libcbgx_xcheck.so, cbgx_debug_set_edge_kernel(1)): the two VALU kernels
-        HIP_TRY(launch_gate_backward(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.E8, w.partial, GATE_GRID, s));
+    HIP_TRY(launch_gate_backward_mfma(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.partial, GATE_GRID, s));
     FOLDED(w.partial, GATE_GRID, GB_SIZE, GB_SIZE);
     RS(fz + GB_W1, fn, fs, G, GH, G, grads[0], G, 0);
     RS(fz + GB_B1, fn, fs, GH, 1, GH, grads[1], GH, 0);

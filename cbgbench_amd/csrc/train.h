@@ -103,8 +103,6 @@ hipError_t launch_reduce_store(const float* src, int n_slabs, size_t slab_stride
 // writes split z to C + z * c_split_stride (accumulate must be 0 when splits > 1)
 hipError_t launch_sgemm(bool ta, bool tb, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
                         int N, int K, int splits, size_t c_split_stride, int accumulate, hipStream_t s);
-hipError_t launch_gate_backward(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
-                                const float* de_w, float* E8, float* partial, int grid, hipStream_t s);
 hipError_t launch_gate_backward_mfma(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
                                      const float* de_w, float* partial, int grid, hipStream_t s);
 hipError_t launch_ssp_backward(const float* pre, const float* dact, long n, float* dpre, hipStream_t s);

@@ -247,126 +247,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
 // backward), pass 2 per hidden unit (weight gradients).  The gate reads the *input* coordinates, which
 // are data, so no coordinate gradient is produced.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gate_bwd_edge_kernel(const float* __restrict__ wts, const float* __restrict__ x,
-                                                            const int32_t* __restrict__ nbr,
-                                                            const int32_t* __restrict__ deg, int n_nodes,
-                                                            const float* __restrict__ de_w, float* __restrict__ E8) {
-    __shared__ float sW1[GH * G];
-    __shared__ float sB1[GH], sG[GH], sBe[GH], sW2[GH];
-    for (int t = threadIdx.x; t < GH * G; t += blockDim.x) sW1[t] = wts[GATE_W1 + t];
-    for (int t = threadIdx.x; t < GH; t += blockDim.x) {
-        sB1[t] = wts[GATE_B1 + t]; sG[t] = wts[GATE_LNG + t]; sBe[t] = wts[GATE_LNB + t]; sW2[t] = wts[GATE_W2 + t];
-    }
-    __syncthreads();
-    const float b2 = wts[GATE_B2];
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (long)n_nodes * KNN) return;
-    const int i = (int)(e >> 5), s = (int)(e & 31);
-    float* o = E8 + (size_t)e * 8;
-    if (s >= deg[i]) { o[5] = 0.f; o[0] = 0.f; o[1] = 0.f; o[2] = 1.f; o[3] = 0.f; o[4] = 0.f; return; }
-    const int j = nbr[e];
-    const float dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
-    const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-    float r[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) { const float t = dist - c_mu_b[g]; r[g] = expf(-0.5f * (t * t)); }
-    float sum = 0.f;
-    for (int u = 0; u < GH; ++u) {
-        float y = sB1[u];
-#pragma unroll
-        for (int g = 0; g < G; ++g) y = fmaf(sW1[u * G + g], r[g], y);
-        sum += y;
-    }
-    const float mean = sum * (1.f / GH);
-    float var = 0.f;
-    for (int u = 0; u < GH; ++u) {
-        float y = sB1[u];
-#pragma unroll
-        for (int g = 0; g < G; ++g) y = fmaf(sW1[u * G + g], r[g], y);
-        var += (y - mean) * (y - mean);
-    }
-    const float rstd = 1.f / sqrtf(var * (1.f / GH) + 1e-5f);
-    float acc = b2;
-    for (int u = 0; u < GH; ++u) {
-        float y = sB1[u];
-#pragma unroll
-        for (int g = 0; g < G; ++g) y = fmaf(sW1[u * G + g], r[g], y);
-        acc = fmaf(sW2[u], fmaxf((y - mean) * rstd * sG[u] + sBe[u], 0.f), acc);
-    }
-    const float ew = 1.f / (1.f + expf(-acc));
-    const float dacc = de_w[e] * ew * (1.f - ew);
-    float s1 = 0.f, s2 = 0.f;
-    for (int u = 0; u < GH; ++u) {
-        float y = sB1[u];
-#pragma unroll
-        for (int g = 0; g < G; ++g) y = fmaf(sW1[u * G + g], r[g], y);
-        const float n = (y - mean) * rstd;
-        const float dn = (n * sG[u] + sBe[u] > 0.f) ? dacc * sW2[u] * sG[u] : 0.f;
-        s1 += dn;
-        s2 = fmaf(dn, n, s2);
-    }
-    o[0] = dist; o[1] = mean; o[2] = rstd; o[3] = s1 * (1.f / GH); o[4] = s2 * (1.f / GH); o[5] = dacc;
-}
 
-constexpr int GATE_TILE = 64;
-
-__global__ __launch_bounds__(GH) void gate_bwd_weight_kernel(const float* __restrict__ wts, const float* __restrict__ E8,
-                                                             long n_edges, float* __restrict__ partial) {
-    __shared__ float sR[GATE_TILE][G];
-    __shared__ float sE[GATE_TILE][8];
-    const int u = threadIdx.x;
-    float w1[G], aW1[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) { w1[g] = wts[GATE_W1 + u * G + g]; aW1[g] = 0.f; }
-    const float b1 = wts[GATE_B1 + u], gam = wts[GATE_LNG + u], bet = wts[GATE_LNB + u], w2 = wts[GATE_W2 + u];
-    float aB1 = 0.f, aG = 0.f, aBe = 0.f, aW2 = 0.f, aB2 = 0.f;
-    const long tiles = (n_edges + GATE_TILE - 1) / GATE_TILE;
-    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const long e0 = tile * GATE_TILE;
-        __syncthreads();
-        for (int k = u; k < GATE_TILE * 8; k += GH) {
-            const long e = e0 + (k >> 3);
-            sE[k >> 3][k & 7] = e < n_edges ? E8[(size_t)e * 8 + (k & 7)] : 0.f;
-        }
-        __syncthreads();
-        for (int k = u; k < GATE_TILE * G; k += GH) {
-            const int ee = k / G, g = k % G;
-            const float t = sE[ee][0] - c_mu_b[g];
-            sR[ee][g] = expf(-0.5f * (t * t));
-        }
-        __syncthreads();
-        for (int ee = 0; ee < GATE_TILE; ++ee) {
-            const float dacc = sE[ee][5];
-            if (dacc == 0.f) continue;   // padded slot or zero upstream gradient (uniform across the workgroup)
-            float y = b1;
-#pragma unroll
-            for (int g = 0; g < G; ++g) y = fmaf(w1[g], sR[ee][g], y);
-            const float n = (y - sE[ee][1]) * sE[ee][2];
-            const float ya = n * gam + bet;
-            aW2 = fmaf(dacc, fmaxf(ya, 0.f), aW2);
-            aB2 += dacc;
-            const float dy = ya > 0.f ? dacc * w2 : 0.f;
-            aG = fmaf(dy, n, aG);
-            aBe += dy;
-            const float dn = dy * gam;
-            const float dp = sE[ee][2] * (dn - sE[ee][3] - n * sE[ee][4]);
-            aB1 += dp;
-#pragma unroll
-            for (int g = 0; g < G; ++g) aW1[g] = fmaf(dp, sR[ee][g], aW1[g]);
-        }
-    }
-    float* slab = partial + (size_t)blockIdx.x * GB_SIZE;
-#pragma unroll
-    for (int g = 0; g < G; ++g) slab[GB_W1 + u * G + g] = aW1[g];
-    slab[GB_B1 + u] = aB1;
-    slab[GB_LNG + u] = aG;
-    slab[GB_LNB + u] = aBe;
-    slab[GB_W2 + u] = aW2;
-    if (u == 0) slab[GB_B2] = aB2;
-}
-
-// The same backward as ONE kernel on the matrix pipe (product path; the two kernels above stay as the cross-check of
-// libcbgx_xcheck.so).  A wave owns tiles of 16 edge slots (half a node):
+// ONE kernel on the matrix pipe.  A wave owns tiles of 16 edge slots (half a node):
 //   Y = R W1^T          [16 edges x 160 units], k = 20 rbf      50 v_mfma_f32_16x16x4_f32, Y stays in 40 registers
 //                       D layout: lane (j, q), tile nt, register r <-> edge 4 q + r, unit 16 nt + j
 //   per edge: LayerNorm statistics, the gate value and its gradient, the two sums of the LayerNorm backward -- reductions over the
@@ -374,8 +256,10 @@ __global__ __launch_bounds__(GH) void gate_bwd_weight_kernel(const float* __rest
 //   d W1 += dpre^T R    k = the 16 edges                        80 MFMAs into 20 accumulator tiles (register r of the D layout of
 //                       dpre is the A operand of k-slot q, the rbf of edge 4 q + r at g = lane & 15 the B operand)
 //   per unit: d b1, d gamma, d beta, d W2 accumulate in the lanes that own the unit.
-// The edge pass above evaluates the 160 x 20 products four times per edge on the vector ALU (292 us for 528 k edge slots) and parks
-// eight scalars per edge for the weight pass (205 us); here nothing is parked.  One slab (train.h GB_*) per WAVE.
+// (Rounds 1 - 3 ran two VALU kernels: an edge pass that evaluated the 160 x 20 products four times per edge, 292 us for 528 k edge
+// slots, and parked eight scalars per edge for a weight pass of 205 us.)  Nothing is parked here.  One slab (train.h GB_*) per WAVE.
+// Pinned by the reference's recorded gradients of the six gate tensors (tests/test_gpu_training.py) and, lane by lane, by
+// tests/test_lanesim_gate.py.
 constexpr int GATE_WAVES = 4;
 __global__ __launch_bounds__(GATE_WAVES * 64) void gate_bwd_mfma_kernel(const float* __restrict__ wts, const float* __restrict__ x,
                                                                       const int32_t* __restrict__ nbr,
@@ -641,16 +525,6 @@ hipError_t launch_gate_backward_mfma(const float* packed, const float* x, const 
     return hipSuccess;
 }
 
-hipError_t launch_gate_backward(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
-                                const float* de_w, float* E8, float* partial, int grid, hipStream_t s) {
-    const long total = (long)n_nodes * KNN;
-    hipLaunchKernelGGL(gate_bwd_edge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, packed, x, nbr, deg,
-                       n_nodes, de_w, E8);
-    CBGX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gate_bwd_weight_kernel, dim3(grid), dim3(GH), 0, s, packed, E8, total, partial);
-    CBGX_LAUNCH_CHECK();
-    return hipSuccess;
-}
 
 hipError_t launch_ssp_backward(const float* pre, const float* dact, long n, float* dpre, hipStream_t s) {
     if (n == 0) return hipSuccess;

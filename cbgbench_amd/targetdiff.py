@@ -484,7 +484,7 @@ class TargetDiff(BatchesInFlight, nn.Module):
         eps, u = noise if noise is not None else (None, None)
         # one launch for the noising, one for both losses (+ one in the backward) when everything is in the shape the kernels take
         fused = (self.fused_training_ops and x0.is_cuda and self.denoise_structure and self.denoise_atom
-                 and self.num_classes <= 32 and 0 < int(t.shape[0]) <= 4096 and x0.shape[0] > 0
+                 and self.num_classes <= 32 and 0 < int(t.shape[0]) <= 4096 and 0 < x0.shape[0] <= 65536
                  and v0.dtype == torch.int64 and t.dtype == torch.int64 and bl.dtype == torch.int64)
         if fused:
             x0, v0, t, bl, gen_l = x0.contiguous(), v0.contiguous(), t.contiguous(), bl.contiguous(), gen_l.contiguous()
