@@ -79,6 +79,7 @@ struct TrainWs {
     int *act, *act_count;
     uint8_t* mask;        // receptive field of the loss, walked backwards (see cbgx_unitransformer_backward)
     int *rf_list[2], *rf_count;
+    int* lig_list;        // rows with lig_flag (count: rf_count + 32): the classifier head's backward walks it when the loss reads ligand rows only
     size_t partial_floats;
     size_t total;
 };
@@ -121,6 +122,7 @@ static TrainWs carve_train(void* base, int n) {
     w.rf_list[0] = (int*)take(N * 4);
     w.rf_list[1] = (int*)take(N * 4);
     w.rf_count = (int*)take(256);
+    w.lig_list = (int*)take(N * 4);
     w.partial_floats = partial_floats_needed();
     w.partial = (float*)take(w.partial_floats * 4);
     w.folded = (float*)take((size_t)FOLD * H * PROW * 4);
@@ -458,7 +460,35 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
     if (grad_h_out) HIP_TRY(hipMemcpyAsync(w.gh, grad_h_out, nh * 4, hipMemcpyDeviceToDevice, s));
     else HIP_TRY(hipMemsetAsync(w.gh, 0, nh * 4, s));
     float* const* cg = grads + 6 + 36 * L;
-    if (grad_logits) {
+    if (grad_logits && grad_h_out == nullptr && g_edge_impl != 1) {
+        // The caller's promise behind grad_h_out == NULL (include/cbgx.h): its loss reads the logits on lig_flag rows only, so
+        // grad_logits is zero elsewhere and the head's backward walks the ligand rows (a twentieth of the nodes) instead of all
+        // of them: listed node GEMMs for the recompute, listed weight- / input-gradient products, nothing read outside the list.
+        const float* c = packed + cls_off(L);
+        const float* hl = tp.hs + (size_t)L * nh;
+        float* pre = w.qs;    // [N,128] scratch: listed rows only
+        float* act = w.zb;
+        float* dact = w.dqb;
+        const int* ll = w.lig_list;
+        const int* lc = w.rf_count + 32;
+        HIP_TRY(launch_build_active(lig_flag, n, w.lig_list, w.rf_count + 32, s));
+        HIP_TRY(launch_node_gemm(hl, H, c + C_W0T, c + C_B0, pre, H, n, H, 0, s, ll, lc));
+        HIP_TRY(launch_node_gemm(hl, H, c + C_W0T, c + C_B0, act, H, n, H, 1, s, ll, lc));
+        // classifier.2: dW1[c][k] = sum_i dlogits[i][c] act[i][k];  db1 = colsum(dlogits)
+        HIP_TRY(launch_cls_w1_grad_rows(grad_logits, C, act, ll, lc, cg[2], s));
+        HIP_TRY(launch_colsum(grad_logits, C, C, nullptr, ll, lc, n, w.partial, C, ng, s));
+        { FOLDED(w.partial, ng, C, C); RS(fz, fn, fs, C, 1, C, cg[3], C, 0); }
+        // d(act) = dlogits W1 (all rows: a [N x C] x [C x 128] product, zero outside the list);  d(pre) = d(act) sigmoid(pre) on the list
+        HIP_TRY(launch_sgemm(false, true, grad_logits, C, c + C_W1T, C, dact, H, n, H, C, 1, 0, 0, s));
+        HIP_TRY(launch_ssp_backward_rows(pre, dact, ll, lc, n, w.tmp, s));
+        // classifier.0: dW0[n][k] = sum_i dpre[i][n] h[i][k];  db0 = colsum(dpre);  dh += dpre W0
+        const int wg = wgrad_groups(n);
+        HIP_TRY(launch_wgrad_mfma(w.tmp, H, hl, H, n, 1, w.partial, H, (size_t)H * H, wg, s, ll, lc));
+        { FOLDED(w.partial, wg, (size_t)H * H, H * H); RS(fz, fn, fs, H, H, H, cg[0], H, 0); }
+        HIP_TRY(launch_colsum(w.tmp, H, H, nullptr, ll, lc, n, w.partial, H, ng, s));
+        { FOLDED(w.partial, ng, H, H); RS(fz, fn, fs, H, 1, H, cg[1], H, 0); }
+        HIP_TRY(launch_dgrad_mfma(w.tmp, H, c + C_W0T, H, w.gh, H, n, H, 1, s, nullptr, ll, lc));
+    } else if (grad_logits) {
         const float* c = packed + cls_off(L);
         const float* hl = tp.hs + (size_t)L * nh;
         float* pre = w.qs;    // [N,128] scratch

@@ -116,6 +116,10 @@ hipError_t launch_train_loss(const float* x_out, const float* logits, const int6
                              float* c_pred, float* gpos, float* gz, hipStream_t s);
 hipError_t launch_train_loss_bwd(const float* gpos, const float* gz, const int64_t* sort_idx, int n_rec, int n_nodes, int C,
                                  const float* g_pos, const float* g_typ, float* grad_x, float* grad_logits, hipStream_t s);
+hipError_t launch_ssp_backward_rows(const float* pre, const float* dact, const int* rows, const int* n_rows, int max_rows,
+                                    float* dpre, hipStream_t s);
+hipError_t launch_cls_w1_grad_rows(const float* dlogits, int C, const float* act, const int* rows, const int* n_rows, float* dW1,
+                                   hipStream_t s);
 hipError_t launch_add_inplace(float* dst, const float* src, long n, hipStream_t s);
 
 }  // namespace cbgx

@@ -8,7 +8,7 @@
 //   train_loss_bwd_kernel   scatters those gradients, scaled by the upstream gradients of the two losses, into dL/dx_out [N,3] and
 //                           dL/dlogits [N,C] (zeros on protein rows)
 // The training step is bound by the NUMBER of launches as much as by their duration (a dependent launch costs ~4.7 us on an
-// otherwise busy queue: profiles/trace_train_r04n); nothing here is heavy.  One 4-wave workgroup computes the losses (a few hundred
+// otherwise busy queue: profiles/trace_train_r04n); nothing here is heavy.  One workgroup computes the losses (a few hundred
 // to a few thousand ligand atoms, the class loops unrolled over registers): the per-graph sums live in LDS.  Sums over atoms use LDS
 // float atomics, so the losses are reproducible up to summation order (as the reference's index_add on a GPU).
 #include <hip/hip_runtime.h>
@@ -20,7 +20,7 @@
 
 namespace cbgx {
 
-constexpr int LC = 32;      // most atom classes (registers are indexed statically: loops run to LC with k < C guards)
+// atom classes are register arrays indexed statically: the class loops run to the template bound LC (16 or 32) with k < C guards
 
 __device__ __forceinline__ float lae(float a, float b) {      // _log_add_exp of the reference: max + log(exp(a - max) + exp(b - max))
     const float mx = fmaxf(a, b);
@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void train_noise_kernel(
 }
 
 // LDS: s_pos [B], s_typ [B], cnt [B], then one int (largest masked graph id)
-__global__ __launch_bounds__(256) void train_loss_kernel(
+template <int LC, int THREADS>
+__global__ __launch_bounds__(THREADS) void train_loss_kernel(
     const float* __restrict__ x_out, const float* __restrict__ logits, const int64_t* __restrict__ lig_rows,
     const float* __restrict__ x0, const int64_t* __restrict__ v0, const int64_t* __restrict__ vt,
     const int64_t* __restrict__ t, const int64_t* __restrict__ batch, const uint8_t* __restrict__ gen, int n_lig, int B, int C,
@@ -249,8 +250,14 @@ hipError_t launch_train_loss(const float* x_out, const float* logits, const int6
                              int n_lig, int B, int C, const float* const* tables, float log_c, float* losses, float* x_pred,
                              float* c_pred, float* gpos, float* gz, hipStream_t s) {
     const size_t lds = ((size_t)3 * B + 1 + 32) * sizeof(float);
-    hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(256), lds, s, x_out, logits, lig_rows, x0, v0, vt, t, batch, gen, n_lig,
-                       B, C, tables[0], tables[1], tables[2], tables[3], log_c, losses, x_pred, c_pred, gpos, gz);
+    // up to 16 classes (every shipped config): 16-wide class loops leave room for 512 threads, one or two atoms each at a
+    // training batch's few hundred ligand atoms; up to 32 classes: 256 threads
+    if (C <= 16)
+        hipLaunchKernelGGL((train_loss_kernel<16, 512>), dim3(1), dim3(512), lds, s, x_out, logits, lig_rows, x0, v0, vt, t, batch,
+                           gen, n_lig, B, C, tables[0], tables[1], tables[2], tables[3], log_c, losses, x_pred, c_pred, gpos, gz);
+    else
+        hipLaunchKernelGGL((train_loss_kernel<32, 256>), dim3(1), dim3(256), lds, s, x_out, logits, lig_rows, x0, v0, vt, t, batch,
+                           gen, n_lig, B, C, tables[0], tables[1], tables[2], tables[3], log_c, losses, x_pred, c_pred, gpos, gz);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }

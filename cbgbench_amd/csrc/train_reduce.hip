@@ -428,6 +428,36 @@ __global__ void ssp_backward_kernel(const float* __restrict__ pre, const float* 
     if (idx < n) dpre[idx] = dact[idx] / (1.f + expf(-pre[idx]));
 }
 
+// the same on a row list (device-side count): only the listed rows of pre / dact are read, only those rows of dpre written
+__global__ __launch_bounds__(H) void ssp_backward_rows_kernel(const float* __restrict__ pre, const float* __restrict__ dact,
+                                                              const int* __restrict__ rows, const int* __restrict__ n_rows_ptr,
+                                                              float* __restrict__ dpre) {
+    const int count = *n_rows_ptr;
+    for (int k = blockIdx.x; k < count; k += gridDim.x) {
+        const size_t idx = (size_t)rows[k] * H + threadIdx.x;
+        dpre[idx] = dact[idx] / (1.f + expf(-pre[idx]));
+    }
+}
+
+// classifier.2 on a row list: dW1[c][k] = sum over the listed rows i of dlogits[i][c] act[i][k]; one workgroup per class c, thread =
+// k, rows in list order (deterministic, no slabs)
+__global__ __launch_bounds__(H) void cls_w1_grad_rows_kernel(const float* __restrict__ dlogits, int C, const float* __restrict__ act,
+                                                             const int* __restrict__ rows, const int* __restrict__ n_rows_ptr,
+                                                             float* __restrict__ dW1) {
+    const int count = *n_rows_ptr, c = blockIdx.x, k = threadIdx.x;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};       // four independent chains: the loads of four rows in flight
+    int it = 0;
+    for (; it + 3 < count; it += 4) {
+        int r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = rows[it + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = fmaf(dlogits[(size_t)r[u] * C + c], act[(size_t)r[u] * H + k], acc[u]);
+    }
+    for (; it < count; ++it) { const int r = rows[it]; acc[0] = fmaf(dlogits[(size_t)r * C + c], act[(size_t)r * H + k], acc[0]); }
+    dW1[(size_t)c * H + k] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
 __global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < n) dst[idx] += src[idx];
@@ -529,6 +559,22 @@ hipError_t launch_gate_backward_mfma(const float* packed, const float* x, const 
 hipError_t launch_ssp_backward(const float* pre, const float* dact, long n, float* dpre, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(ssp_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, dact, n, dpre);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_ssp_backward_rows(const float* pre, const float* dact, const int* rows, const int* n_rows, int max_rows,
+                                    float* dpre, hipStream_t s) {
+    if (max_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(ssp_backward_rows_kernel, dim3(max_rows < 2048 ? max_rows : 2048), dim3(H), 0, s, pre, dact, rows, n_rows,
+                       dpre);
+    CBGX_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_cls_w1_grad_rows(const float* dlogits, int C, const float* act, const int* rows, const int* n_rows, float* dW1,
+                                   hipStream_t s) {
+    hipLaunchKernelGGL(cls_w1_grad_rows_kernel, dim3(C), dim3(H), 0, s, dlogits, C, act, rows, n_rows, dW1);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }
