@@ -260,8 +260,9 @@ int cbgx_diffsbdd_step(const float *x_den, const float *logits, const int32_t *g
  *       OVERWRITTEN.  No gradient is produced for the input coordinates (they are data: targetdiff.py:87-101).
  *       PRECONDITION of grad_h_out == NULL: the caller's loss reads x_out on gen_flag rows and logits on lig_flag rows only
  *       (what TargetDiff.get_loss / DiffSBDD.get_loss do, targetdiff.py:103-121); the backward of the last x2h blocks is
- *       then pruned to the receptive field of those rows, and gradient entries on other rows are ignored.  A loss that
- *       touches other rows must pass a (possibly all-zero) grad_h_out to get the unpruned backward.
+ *       then pruned to the receptive field of those rows, the classifier head's backward walks the lig_flag rows only, and
+ *       gradient entries on other rows are ignored.  A loss that touches other rows must pass a (possibly all-zero) grad_h_out
+ *       to get the unpruned backward.
  * Both take the larger training workspace (cbgx_train_workspace_bytes).  Neighbour-row gradients are accumulated with
  * fp32 atomics, so results are reproducible only up to summation order (as with the reference's torch_scatter on GPU). */
 size_t cbgx_train_tape_bytes(int n_nodes, int num_layers);

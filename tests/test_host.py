@@ -544,3 +544,26 @@ def test_sync_free_host_forms_equal_the_reference_forms():
     counts = torch.bincount(batch_idx, minlength=4)
     assert torch.equal(graph_ptr, torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)]).to(torch.int32))
     assert torch.equal(graph_ptr_from_batch(batch_idx, 4), graph_ptr) and torch.equal(graph_ptr_from_batch(batch_idx), graph_ptr)
+
+
+def test_ordered_parameter_list_is_cached_and_revalidated():
+    """UniTransformer._ordered_params(): the list cbgx_pack_weights / cbgx_unitransformer_backward take is cached (walking the module
+    tree costs ~1 ms, three times per training step) and re-validated against the owning modules' parameter slots."""
+    import cbgbench_amd as C
+    m = C.get_model(C.default_targetdiff_config(13))
+    d = m.denoiser
+    a = d._ordered_params()
+    assert len(a) == 6 + 36 * d.num_layers + 4 and d._ordered_params() is a           # cached
+    sd = dict(d.named_parameters())
+    assert a[0] is sd["dist_emb.1.net.0.weight"] and a[-1] is sd["classifier.2.bias"] and a[6] is sd["blocks.0.x2h_layers.0.hk_func.net.0.weight"]
+    # a replaced Parameter is seen (identity check against the modules' slots), as is a conversion through _apply
+    lin = d.blocks[3].h2x_layers[0].xv_func.net[3]
+    lin.weight = torch.nn.Parameter(torch.zeros_like(lin.weight))
+    b = d._ordered_params()
+    assert b is not a and any(p is lin.weight for p in b) and len(b) == len(a)
+    m.double()
+    assert d._ordered_params()[0].dtype == torch.float64
+    # load_state_dict copies in place: same objects, same list
+    c = d._ordered_params()
+    m.load_state_dict(m.state_dict())
+    assert d._ordered_params() is c
