@@ -308,7 +308,8 @@ int cbgx_h2x_stack_backward(const float *packed, int num_layers, const void *tap
 
 /* TargetDiff's training arithmetic around the denoiser call (targetdiff.py:82-124), one launch each instead of the ~260 small
  * launches the same formulas take as tensor operations (a training step is bound by its launch count as much as by its kernels).
- * Index tensors are int64 as PyTorch holds them (no conversion launches); gen / masks are bytes.
+ * Index tensors are int64 as PyTorch holds them (no conversion launches); gen / masks are bytes.  Preconditions the library cannot
+ * check without reading device memory: 0 <= batch[a] < n_graphs (the per-graph sums are indexed by it), 0 <= t[g] < T, types < C.
  * cbgx_targetdiff_train_noise: q(x_t | x_0) on gen rows (CTNVPScheduler.forward_add_noise, diffusion_scheduler.py:117-134) and
  *   q(v_t | v_0) by Gumbel-argmax (TypeVPScheduler.forward_add_noise, :339-365).  t [B] per graph, batch [n_lig] graph of each
  *   ligand atom; eps [n_lig,3] ~ N(0,1), u [n_lig,C] ~ U(0,1) are inputs.  Outputs x_t [n_lig,3], c_t [n_lig,C] one-hot, v_t [n_lig].
