@@ -1,6 +1,6 @@
 #!/bin/bash
-# experiment for the next round (not in the tree: docs/experiments/edge_early_first.patch): the first item's loads of the edge kernels
-# requested before the LDS image.  Small-batch rows and the headline on ab_libs/base.so (HEAD) against ab_libs/early.so
+# experiment (measured neutral, not in the tree): the first item's loads of the edge kernels requested before the LDS image
+# (-DCBGX_EDGE_EARLY_FIRST=1 variant of a working copy).  Small-batch rows and the headline on ab_libs/base.so (HEAD) against ab_libs/early.so
 TAG=${1:-r04z1}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
