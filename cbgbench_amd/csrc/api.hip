@@ -44,6 +44,12 @@ int set_error(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(CBGX_E_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
+#ifndef CBGX_EDGE_DYN
+#define CBGX_EDGE_DYN 0
+#endif
+#if CBGX_EDGE_DYN
+constexpr int EDGE_CTR_SLOTS = 64;      // (variant builds) edge launches of a forward call that get work counters
+#endif
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
@@ -76,6 +82,9 @@ struct Workspace {
     int* sp_list[4][2];  // [all nodes | cached layer 1 (D2) | pruned A1 | pruned A2][1 = general, 0 = protein-only]
     int* sp_count;       // per set one 128-byte region: general count at +0, protein-only count at +64 bytes
     int* zero_count;     // an always-empty list's count
+#if CBGX_EDGE_DYN
+    int* edge_ctr;       // EDGE_CTR_SLOTS x 16 work counters of the edge launches of a call (variant builds only)
+#endif
     void* counters;      // flags + act_count, rf_count, fw_count, sp_count, zero_count are carved from ONE block: one fill per call
     size_t counters_bytes;
     size_t total;
@@ -114,6 +123,9 @@ static Workspace carve(void* base, int n) {
         // every device-side list count of a forward call, 64 bytes apart (a counter word is hammered by returning atomics)
         const size_t fl = align_up(N);
         w.counters_bytes = 8 * fl + 256 + 256 + 256 + 4 * 128 + 256;
+#if CBGX_EDGE_DYN
+        w.counters_bytes += EDGE_CTR_SLOTS * 64;
+#endif
         char* c = take(w.counters_bytes);
         w.counters = c;
         w.d1flag = (uint8_t*)c; w.fa1 = w.d1flag + fl; w.fa2 = w.fa1 + fl; w.fa3 = w.fa2 + fl;
@@ -124,6 +136,9 @@ static Workspace carve(void* base, int n) {
         w.fw_count = (int*)(c + 512);
         w.sp_count = (int*)(c + 768);
         w.zero_count = (int*)(c + 768 + 4 * 128);
+#if CBGX_EDGE_DYN
+        w.edge_ctr = (int*)(c + 768 + 4 * 128 + 256);
+#endif
     }
     w.total = off;
     return w;
@@ -524,6 +539,12 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
         return fail(CBGX_E_WORKSPACE, "forward: workspace %zu < %zu", workspace_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(w.counters, 0, w.counters_bytes, s));      // every list count of this call: one fill instead of ~15
+#if CBGX_EDGE_DYN
+    struct CtrScope {     // the edge launches of this call take their (just zeroed) work counters from the pool, in call order
+        CtrScope(int* b) { edge_set_work_counters(b, EDGE_CTR_SLOTS); }
+        ~CtrScope() { edge_set_work_counters(nullptr, 0); }
+    } ctr_scope(w.edge_ctr);
+#endif
     const bool cached = static_h1 && static_h2 && num_layers >= 4;
     // with the graph part of the cache, only the nodes that have a ligand atom within reach get a fresh neighbour list
     // and gate: everything else about the pocket's own graph was computed once (same order, same bits)

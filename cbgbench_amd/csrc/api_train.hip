@@ -26,6 +26,9 @@ namespace cbgx { int set_error(int code, const char* fmt, ...); }
         if (_rc) return _rc; \
     } while (0)
 
+#ifndef CBGX_EDGE_DYN
+#define CBGX_EDGE_DYN 0
+#endif
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 constexpr int EDGE_GRID = 256;    // persistent workgroups of the edge backward (one per CU: ~97 KB LDS each)
@@ -79,6 +82,9 @@ struct TrainWs {
     int *act, *act_count;
     uint8_t* mask;        // receptive field of the loss, walked backwards (see cbgx_unitransformer_backward)
     int *rf_list[2], *rf_count;
+#if CBGX_EDGE_DYN
+    int* edge_ctr;        // 64 x 16 work counters of the taped forward's edge launches (variant builds only, edge_mfma.hip)
+#endif
     int* lig_list;        // rows with lig_flag (count: rf_count + 32): the classifier head's backward walks it when the loss reads ligand rows only
     size_t partial_floats;
     size_t total;
@@ -123,6 +129,9 @@ static TrainWs carve_train(void* base, int n) {
     w.rf_list[1] = (int*)take(N * 4);
     w.rf_count = (int*)take(256);
     w.lig_list = (int*)take(N * 4);
+#if CBGX_EDGE_DYN
+    w.edge_ctr = (int*)take(64 * 64);
+#endif
     w.partial_floats = partial_floats_needed();
     w.partial = (float*)take(w.partial_floats * 4);
     w.folded = (float*)take((size_t)FOLD * H * PROW * 4);
@@ -369,6 +378,13 @@ int cbgx_unitransformer_forward_train(const float* packed, int num_layers, int n
     HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, tp.nbr, tp.deg, s));
     HIP_TRY(launch_gate(packed, x, tp.nbr, tp.deg, n_nodes, tp.e_w, s));
     HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, s));
+#if CBGX_EDGE_DYN
+    HIP_TRY(hipMemsetAsync(w.edge_ctr, 0, 64 * 64, s));
+    struct CtrScope {
+        CtrScope(int* b) { edge_set_work_counters(b, 64); }
+        ~CtrScope() { edge_set_work_counters(nullptr, 0); }
+    } ctr_scope(w.edge_ctr);
+#endif
     for (int l = 0; l < num_layers; ++l) {
         const float* xc = tp.xs + (size_t)l * nx;
         const float* hc = tp.hs + (size_t)l * nh;

@@ -35,6 +35,25 @@
 #include "kernels.h"
 #include "layout.h"
 
+// UNTESTED VARIANT, off in every build of this tree (prepared at the end of round 4, when the GPU budget was spent; to try it:
+// scripts/build_variant.py <name> -DCBGX_EDGE_DYN=2, all GPU tests, scripts/gpu_small_batch.sh).  With CBGX_EDGE_DYN = d > 0 the
+// persistent loop of edge_body runs its first rounds statically as always and hands the last d - 1 full rounds of an XCD's range
+// plus the partial one out through a per-XCD counter (the scheme of edge_backward_x2h_kernel, train_bwd_x2h.hip; index arithmetic
+// pinned by tests/test_bx_partition.py::test_forward_*): a 10-graph batch is 2.15 nodes per wave and runs three static rounds
+// (53 us per x2h launch), the training forward 8.06 nodes per wave and nine.  The counters come from the caller through
+// edge_set_work_counters (16 ints per launch, zero at launch); without them, or when an XCD's range has no full round, the
+// schedule is the static one.
+#ifndef CBGX_EDGE_DYN
+#define CBGX_EDGE_DYN 0
+#endif
+#if CBGX_EDGE_DYN
+#define CBGX_DYN_PARAM , int* __restrict__ work_ctr
+#define CBGX_DYN_ARG(p) , p
+#else
+#define CBGX_DYN_PARAM
+#define CBGX_DYN_ARG(p)
+#endif
+
 namespace cbgx {
 
 
@@ -165,7 +184,7 @@ __device__ __forceinline__ void edge_body(
     const float* __restrict__ P, const float* __restrict__ Qt, const int32_t* __restrict__ nbr,
     const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig, const uint8_t* __restrict__ gen,
     const float* __restrict__ e_w, int n_nodes, float* __restrict__ out, float* __restrict__ dx_out,
-    const int* __restrict__ act_arg, const int* __restrict__ act_count) {
+    const int* __restrict__ act_arg, const int* __restrict__ act_count CBGX_DYN_PARAM) {
     const int* __restrict__ act = LISTED ? act_arg : nullptr;
     static_assert(!PP || (X2H && LISTED), "the protein-only kernel is an x2h work-list kernel");
     static_assert(PP_IMG_SIZE == IMG_SIZE_X2H, "both x2h images fill the same LDS array");
@@ -239,6 +258,16 @@ __device__ __forceinline__ void edge_body(
         i_step = n_wg * WAVES;
     }
     if (i_begin >= i_end) return;
+#if CBGX_EDGE_DYN
+    // static rounds, dynamic remainder: the items [dyn_tail, i_end) of this XCD's range go to whichever wave asks first
+    const int dyn_base = (n_wg & 7) == 0 ? min(n_items, (wg & 7) * ((((n_items + 7) >> 3) + WAVES - 1) / WAVES * WAVES)) : 0;
+    const int dyn_full = (i_end - dyn_base) / i_step;                         // rounds every wave of the range runs
+    const int dyn_static = max(dyn_full - (CBGX_EDGE_DYN - 1), 1);            // the first round is always static
+    const int dyn_tail = dyn_base + dyn_static * i_step;
+    const bool dyn_on = work_ctr != nullptr && dyn_full >= 1 && dyn_tail < i_end;
+    int* const dyn_ctr = work_ctr + ((n_wg & 7) == 0 ? (wg & 7) : 0);
+    int dyn_round = 0;
+#endif
     // power-of-two scales of the split-f16 rbf tables (wave-uniform: scalar registers)
     const RbfScale sck = load_rbf_scale(att, 0), scv = load_rbf_scale(att, 1);
     // h2x: bias of this lane's head, once per launch -- loaded inside the loop it sat behind the next node's 24-row prefetch in the
@@ -277,9 +306,25 @@ __device__ __forceinline__ void edge_body(
         for (int t = 0; t < 8; ++t) ps1[t] = ldo4(sbase(P), o1 + 64 * t);
     }
 
+#if CBGX_EDGE_DYN
+    for (int k = i_begin;;) {
+        const int i = __builtin_amdgcn_readfirstlane(g.node), d = g.d, lig_i = g.lig_i;
+        int k_next = k + i_step;
+        bool more;      // wave-uniform
+        if (!dyn_on) more = k_next < i_end;
+        else if (dyn_round + 1 < dyn_static) more = true;
+        else {          // claimed while this node is still to be processed: its header travels behind this node's work as always
+            int v = 0;
+            if (lane == 0) v = atomicAdd(dyn_ctr, 1);
+            k_next = dyn_tail + __builtin_amdgcn_readfirstlane(v);
+            more = k_next < i_end;
+        }
+#else
     for (int k = i_begin; k < i_end; k += i_step) {
         const int i = __builtin_amdgcn_readfirstlane(g.node), d = g.d, lig_i = g.lig_i;
         const bool more = k + i_step < i_end;   // wave-uniform
+        const int k_next = k + i_step;
+#endif
         // both halves' PD[i] + PS_k[j] as soon as the rows (requested one epilogue ago) are here: the 24 gather registers
         // are then free for this iteration's other gathers
         floatx4 acc0[8], acc1[8];
@@ -294,7 +339,7 @@ __device__ __forceinline__ void edge_body(
         // Issued BEFORE this node's gathers: vmcnt retires in order, so waiting for these few words later (b) leaves the
         // gathers in flight, while the other order would drain them.  The values stay in vector registers until (b).
         ItemGeom ng;
-        const int inext = __builtin_amdgcn_readfirstlane(more ? (act ? act[k + i_step] : k + i_step) : i);
+        const int inext = __builtin_amdgcn_readfirstlane(more ? (act ? act[k_next] : k_next) : i);
         ng.node = inext;
         const int nd_raw = deg[inext];
         const int nlig_raw = PP ? 0 : ldob(sbase(lig), vop((unsigned)inext));
@@ -670,6 +715,11 @@ __device__ __forceinline__ void edge_body(
         nb0 = nnb0; nb1 = nnb1;
         lg0[0] = nlg[0]; lg0[1] = nlg[1]; dist0[0] = ndist[0]; dist0[1] = ndist[1];
         g = ng;
+#if CBGX_EDGE_DYN
+        if (!more) break;
+        k = k_next;
+        ++dyn_round;
+#endif
     }
 }
 
@@ -679,11 +729,11 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     const float* __restrict__ P, const float* __restrict__ Qt, const int32_t* __restrict__ nbr,
     const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig, const uint8_t* __restrict__ gen,
     const float* __restrict__ e_w, int n_nodes, float* __restrict__ out, float* __restrict__ dx_out,
-    const int* __restrict__ act, const int* __restrict__ act_count) {
+    const int* __restrict__ act, const int* __restrict__ act_count CBGX_DYN_PARAM) {
     __shared__ __attribute__((aligned(16))) float lds[X2H ? (int)IMG_SIZE_X2H : (int)IMG_SIZE_H2X];
     __shared__ float lds_mu[G];
     edge_body<X2H, WAVES, LISTED, false>(lds, lds_mu, blockIdx.x, gridDim.x, att, x, h, P, Qt, nbr, deg, lig, gen, e_w, n_nodes, out,
-                                         dx_out, act, act_count);
+                                         dx_out, act, act_count CBGX_DYN_ARG(work_ctr));
 }
 
 // x2h over TWO work lists in one launch: the protein-only destinations (`list_pp`: the node and all its neighbours are protein
@@ -706,7 +756,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_x2h_dual_kernel(
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig,
     const uint8_t* __restrict__ gen, const float* __restrict__ e_w, int n_nodes, float* __restrict__ out,
     const int* __restrict__ list_pp, const int* __restrict__ count_pp, const int* __restrict__ list_gen,
-    const int* __restrict__ count_gen) {
+    const int* __restrict__ count_gen CBGX_DYN_PARAM) {
     __shared__ __attribute__((aligned(16))) float lds[IMG_SIZE_X2H];
     __shared__ float lds_mu[G];
     const int c_pp = *count_pp, c_gen = *count_gen;
@@ -727,10 +777,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_x2h_dual_kernel(
     }
     if ((int)blockIdx.x < n_pp_wg)
         edge_body<true, WAVES, true, true>(lds, lds_mu, blockIdx.x, n_pp_wg, att, x, h, P, qbuf, nbr, deg, lig, gen, e_w, n_nodes,
-                                           out, nullptr, list_pp, count_pp);
+                                           out, nullptr, list_pp, count_pp CBGX_DYN_ARG(work_ctr));
     else
         edge_body<true, WAVES, true, false>(lds, lds_mu, (int)blockIdx.x - n_pp_wg, n_wg - n_pp_wg, att, x, h, P, Qt, nbr, deg, lig,
-                                            gen, e_w, n_nodes, out, nullptr, list_gen, count_gen);
+                                            gen, e_w, n_nodes, out, nullptr, list_gen, count_gen CBGX_DYN_ARG(work_ctr ? work_ctr + 8 : nullptr));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -892,6 +942,23 @@ hipError_t launch_pack_stage2(const PackBlocks& pb, hipStream_t s) {
 static std::atomic<int> g_edge_wg_limit{0};
 int set_edge_workgroup_limit(int n) { return g_edge_wg_limit.exchange(n < 0 ? 0 : n, std::memory_order_relaxed); }
 
+// CBGX_EDGE_DYN builds: the calling thread's pool of zeroed counter slots (16 ints per edge launch); a launch without a slot runs
+// the static schedule.  A no-op in the product build.
+#if CBGX_EDGE_DYN
+static thread_local int* t_ctr_next = nullptr;
+static thread_local int t_ctr_left = 0;
+void edge_set_work_counters(int* base, int slots) { t_ctr_next = base; t_ctr_left = base ? slots : 0; }
+static int* take_ctr_slot() {
+    if (t_ctr_left <= 0) return nullptr;
+    int* p = t_ctr_next;
+    t_ctr_next += 16;
+    --t_ctr_left;
+    return p;
+}
+#else
+void edge_set_work_counters(int*, int) {}
+#endif
+
 hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,
                             const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                             const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,
@@ -907,7 +974,10 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
     profile_mark_begin(x2h ? (act ? K_EDGE_X2H_LISTED : K_EDGE_X2H) : K_EDGE_H2X, s);
 #define CBGX_LAUNCH_EDGE(X2H_, L_)                                                                              \
     hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W, L_>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qt, nbr, deg, \
-                       lig, gen, e_w, n_nodes, out, dx_out, act, act_count)
+                       lig, gen, e_w, n_nodes, out, dx_out, act, act_count CBGX_DYN_ARG(ctr_slot))
+#if CBGX_EDGE_DYN
+    int* const ctr_slot = take_ctr_slot();
+#endif
     if (x2h) {
         if (act) CBGX_LAUNCH_EDGE(true, true); else CBGX_LAUNCH_EDGE(true, false);
     } else {
@@ -933,12 +1003,15 @@ hipError_t launch_edge_x2h_dual(const float* att, const float* x, const float* h
     if (wg_limit >= 8 && grid > wg_limit) grid = wg_limit & ~7;
     if (grid < 2) grid = 2;                     // one workgroup per role at least
     profile_mark_begin(full_layer ? K_EDGE_X2H : K_EDGE_X2H_LISTED, s);
+#if CBGX_EDGE_DYN
+    int* const ctr_slot = take_ctr_slot();
+#endif
     if (full_layer)
         hipLaunchKernelGGL((edge_x2h_dual_kernel<W, true>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qt, qbuf, nbr, deg, lig, gen,
-                           e_w, n_nodes, out, list_pp, count_pp, list_gen, count_gen);
+                           e_w, n_nodes, out, list_pp, count_pp, list_gen, count_gen CBGX_DYN_ARG(ctr_slot));
     else
         hipLaunchKernelGGL((edge_x2h_dual_kernel<W, false>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qt, qbuf, nbr, deg, lig, gen,
-                           e_w, n_nodes, out, list_pp, count_pp, list_gen, count_gen);
+                           e_w, n_nodes, out, list_pp, count_pp, list_gen, count_gen CBGX_DYN_ARG(ctr_slot));
     profile_mark_end(s);
     return hipGetLastError();
 }

@@ -123,6 +123,9 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
                             const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                             const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,
                             const int* act, const int* act_count, hipStream_t s);
+// builds with -DCBGX_EDGE_DYN (an untested variant, edge_mfma.hip): the calling thread's pool of ZEROED counter slots, 16 ints per
+// edge launch, consumed by the launchers below in call order; (nullptr, 0) ends it.  A no-op in the product build.
+void edge_set_work_counters(int* base, int slots);
 hipError_t launch_edge_x2h_dual(const float* att, const float* x, const float* h, const float* P, const float* Qt,
                                 const float* qbuf, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                                 const uint8_t* gen, const float* e_w, int n_nodes, float* out, const int* list_pp,

@@ -82,3 +82,63 @@ def test_config5_shape_runs_seven_static_rounds_and_hands_out_the_rest():
     assert len(done) == 16506
     per_wave_static = (16506 - len(dyn)) / 2048
     assert per_wave_static == 7.0 and len(dyn) == 16506 - 7 * 2048
+
+
+# ---- the forward edge kernels' variant schedule (edge_mfma.hip, -DCBGX_EDGE_DYN=d: untested on the GPU, off in every build) --------
+def forward_schedule(n_items, n_wg, D, waves=8, with_counters=True):
+    """edge_body's loop with CBGX_EDGE_DYN = D restated: the first max(full - (D - 1), 1) rounds of an XCD's range static, the rest
+    claimed one node ahead through the XCD's counter.  -> processed items in order (one interleaving)"""
+    ctr = [0] * 8
+    waves_state = []
+    for wg in range(n_wg):
+        if n_wg % 8 == 0:
+            per_xcd = (((n_items + 7) >> 3) + waves - 1) // waves * waves
+            first = (wg & 7) * per_xcd + (wg >> 3) * waves
+            if first >= min(n_items, ((wg & 7) + 1) * per_xcd):
+                continue
+        elif wg * waves >= n_items:
+            continue
+        for wave in range(waves):
+            if n_wg % 8 == 0:
+                xcd, slot = wg & 7, wg >> 3
+                i_begin = xcd * per_xcd + slot * waves + wave
+                i_end = min(n_items, (xcd + 1) * per_xcd)
+                i_step = (n_wg >> 3) * waves
+                base, c = min(n_items, xcd * per_xcd), xcd
+            else:
+                i_begin, i_end, i_step, base, c = wg * waves + wave, n_items, n_wg * waves, 0, 0
+            if i_begin >= i_end:
+                continue
+            full = (i_end - base) // i_step
+            static = max(full - (D - 1), 1)
+            tail = base + static * i_step
+            on = with_counters and full >= 1 and tail < i_end
+            waves_state.append(dict(k=i_begin, end=i_end, step=i_step, static=static, tail=tail, on=on, c=c, round=0))
+    done = []
+    active = waves_state
+    while active:
+        nxt = []
+        for w in active:
+            assert 0 <= w["k"] < n_items
+            done.append(w["k"])
+            k_next = w["k"] + w["step"]
+            if not w["on"]:
+                more = k_next < w["end"]
+            elif w["round"] + 1 < w["static"]:
+                more = True
+            else:
+                k_next = w["tail"] + ctr[w["c"]]; ctr[w["c"]] += 1
+                more = k_next < w["end"]
+            if more:
+                w["k"] = k_next; w["round"] += 1
+                nxt.append(w)
+        active = nxt
+    return done
+
+
+@pytest.mark.parametrize("D", [1, 2, 3])
+@pytest.mark.parametrize("n_wg", [1, 2, 9, 56, 57, 64, 176, 256])
+def test_forward_variant_schedule_covers_every_item_once(n_wg, D):
+    for n in [1, 5, 8, 9, 445, 1230, 3170, 4404, 16506, 99543]:
+        assert sorted(forward_schedule(n, n_wg, D)) == list(range(n)), (n, n_wg, D)
+        assert sorted(forward_schedule(n, n_wg, D, with_counters=False)) == list(range(n))      # no counters: the static schedule
