@@ -46,6 +46,15 @@
 #ifndef CBGX_EDGE_DYN
 #define CBGX_EDGE_DYN 0
 #endif
+// A second UNTESTED VARIANT, also off in every build (-DCBGX_EDGE_SMALL_W4=1): inputs of at most EDGE_W4_MAX_NODES nodes launch
+// 4-wave workgroups instead of 8-wave ones, so that a node's wave has its SIMD to itself (one workgroup per CU either way: the LDS
+// image).  Reason to try it: a 1-graph edge launch is 6.4 us of launch + image and 18 - 20 us of ONE node's dependent chain on ONE
+// wave (profiles/probe_r04z2.log), 57 CUs busy with two such chains per SIMD while 199 idle -- and in the x2h edge backward a wave
+// alone on its SIMD ran 1.77 x faster than next to a second one (docs/x2h_backward.md).
+#ifndef CBGX_EDGE_SMALL_W4
+#define CBGX_EDGE_SMALL_W4 0
+#endif
+constexpr int EDGE_W4_MAX_NODES = 1016;      // (4 waves per workgroup, 256 workgroups, minus the second role's rounding)
 #if CBGX_EDGE_DYN
 #define CBGX_DYN_PARAM , int* __restrict__ work_ctr
 #define CBGX_DYN_ARG(p) , p
@@ -216,17 +225,36 @@ __device__ __forceinline__ void edge_body(
         const floatx4* src = reinterpret_cast<const floatx4*>(att + (PP ? A_IMG_PP : A_IMG));
         floatx4* dst = reinterpret_cast<floatx4*>(lds);
         constexpr int NV = (IMG / 4 + WAVES * 64 - 1) / (WAVES * 64);
-        floatx4 v[NV];
+        if constexpr (WAVES >= 8) {
+            floatx4 v[NV];
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            const int t = threadIdx.x + u * (WAVES * 64);
-            v[u] = src[t < IMG / 4 ? t : IMG / 4 - 1];
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int u = 0; u < NV; ++u) {
+                const int t = threadIdx.x + u * (WAVES * 64);
+                v[u] = src[t < IMG / 4 ? t : IMG / 4 - 1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            const int t = threadIdx.x + u * (WAVES * 64);
-            if (t < IMG / 4) dst[t] = v[u];
+            for (int u = 0; u < NV; ++u) {
+                const int t = threadIdx.x + u * (WAVES * 64);
+                if (t < IMG / 4) dst[t] = v[u];
+            }
+        } else {        // fewer threads: the same in passes of at most 20 float4 per thread (38 at once would not fit the registers)
+            constexpr int NVC = 20;
+#pragma unroll 1
+            for (int u0 = 0; u0 < NV; u0 += NVC) {
+                floatx4 v[NVC];
+#pragma unroll
+                for (int u = 0; u < NVC; ++u) {
+                    const int t = threadIdx.x + (u0 + u) * (WAVES * 64);
+                    v[u] = src[t < IMG / 4 ? t : IMG / 4 - 1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < NVC; ++u) {
+                    const int t = threadIdx.x + (u0 + u) * (WAVES * 64);
+                    if (t < IMG / 4) dst[t] = v[u];
+                }
+            }
         }
         if (threadIdx.x < G) lds_mu[threadIdx.x] = c_mu[threadIdx.x];
     }
@@ -966,15 +994,25 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
     if (n_nodes == 0) return hipSuccess;
     if ((size_t)n_nodes * PROW * sizeof(float) >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit byte offsets into P
     constexpr int W = 8;                        // waves per persistent workgroup: 2 per SIMD at <= 256 VGPRs per lane
-    int grid = (n_nodes + W - 1) / W;
+#if CBGX_EDGE_SMALL_W4
+    const int wv = n_nodes <= EDGE_W4_MAX_NODES ? 4 : W;      // small input: one wave per SIMD
+#else
+    constexpr int wv = W;
+#endif
+    int grid = (n_nodes + wv - 1) / wv;
     if (grid > 256) grid = 256;                 // persistent: one workgroup per CU (LDS-limited)
     const int wg_limit = g_edge_wg_limit.load(std::memory_order_relaxed);
     if (x2h && wg_limit >= 8 && grid > wg_limit) grid = wg_limit;   // the caller keeps CUs free for another stream
     if (grid >= 64) grid &= ~7;                 // multiple of 8 -> XCD-aware node partition
     profile_mark_begin(x2h ? (act ? K_EDGE_X2H_LISTED : K_EDGE_X2H) : K_EDGE_H2X, s);
-#define CBGX_LAUNCH_EDGE(X2H_, L_)                                                                              \
-    hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W, L_>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qt, nbr, deg, \
+#define CBGX_LAUNCH_EDGE_W(X2H_, L_, W_)                                                                              \
+    hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W_, L_>), dim3(grid), dim3(W_ * 64), 0, s, att, x, h, P, Qt, nbr, deg, \
                        lig, gen, e_w, n_nodes, out, dx_out, act, act_count CBGX_DYN_ARG(ctr_slot))
+#if CBGX_EDGE_SMALL_W4
+#define CBGX_LAUNCH_EDGE(X2H_, L_) do { if (wv == 4) CBGX_LAUNCH_EDGE_W(X2H_, L_, 4); else CBGX_LAUNCH_EDGE_W(X2H_, L_, W); } while (0)
+#else
+#define CBGX_LAUNCH_EDGE(X2H_, L_) CBGX_LAUNCH_EDGE_W(X2H_, L_, W)
+#endif
 #if CBGX_EDGE_DYN
     int* const ctr_slot = take_ctr_slot();
 #endif
@@ -984,6 +1022,7 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
         if (act) CBGX_LAUNCH_EDGE(false, true); else CBGX_LAUNCH_EDGE(false, false);
     }
 #undef CBGX_LAUNCH_EDGE
+#undef CBGX_LAUNCH_EDGE_W
     profile_mark_end(s);
     return hipGetLastError();
 }
@@ -997,7 +1036,12 @@ hipError_t launch_edge_x2h_dual(const float* att, const float* x, const float* h
     if (n_nodes == 0) return hipSuccess;
     if ((size_t)n_nodes * PROW * sizeof(float) >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit byte offsets into P
     constexpr int W = 8;
-    int grid = (n_nodes + W - 1) / W + 1;       // + 1: each role rounds its list up to whole workgroups
+#if CBGX_EDGE_SMALL_W4
+    const int wv = n_nodes <= EDGE_W4_MAX_NODES ? 4 : W;      // small input: one wave per SIMD
+#else
+    constexpr int wv = W;
+#endif
+    int grid = (n_nodes + wv - 1) / wv + 1;     // + 1: each role rounds its list up to whole workgroups
     if (grid > 256) grid = 256;                 // persistent: one workgroup per CU (a multiple of 8 -> XCD-aware partition per role)
     const int wg_limit = g_edge_wg_limit.load(std::memory_order_relaxed);
     if (wg_limit >= 8 && grid > wg_limit) grid = wg_limit & ~7;
@@ -1005,6 +1049,18 @@ hipError_t launch_edge_x2h_dual(const float* att, const float* x, const float* h
     profile_mark_begin(full_layer ? K_EDGE_X2H : K_EDGE_X2H_LISTED, s);
 #if CBGX_EDGE_DYN
     int* const ctr_slot = take_ctr_slot();
+#endif
+#if CBGX_EDGE_SMALL_W4
+    if (wv == 4) {
+        if (full_layer)
+            hipLaunchKernelGGL((edge_x2h_dual_kernel<4, true>), dim3(grid), dim3(256), 0, s, att, x, h, P, Qt, qbuf, nbr, deg, lig, gen,
+                               e_w, n_nodes, out, list_pp, count_pp, list_gen, count_gen CBGX_DYN_ARG(ctr_slot));
+        else
+            hipLaunchKernelGGL((edge_x2h_dual_kernel<4, false>), dim3(grid), dim3(256), 0, s, att, x, h, P, Qt, qbuf, nbr, deg, lig, gen,
+                               e_w, n_nodes, out, list_pp, count_pp, list_gen, count_gen CBGX_DYN_ARG(ctr_slot));
+        profile_mark_end(s);
+        return hipGetLastError();
+    }
 #endif
     if (full_layer)
         hipLaunchKernelGGL((edge_x2h_dual_kernel<W, true>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qt, qbuf, nbr, deg, lig, gen,
