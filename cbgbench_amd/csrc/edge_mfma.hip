@@ -54,7 +54,9 @@
 #ifndef CBGX_EDGE_SMALL_W4
 #define CBGX_EDGE_SMALL_W4 0
 #endif
+#if CBGX_EDGE_SMALL_W4
 constexpr int EDGE_W4_MAX_NODES = 1016;      // (4 waves per workgroup, 256 workgroups, minus the second role's rounding)
+#endif
 #if CBGX_EDGE_DYN
 #define CBGX_DYN_PARAM , int* __restrict__ work_ctr
 #define CBGX_DYN_ARG(p) , p
