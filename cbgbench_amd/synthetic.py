@@ -41,6 +41,19 @@ def make_pocket(rng, n_rec, radius=12.0, spacing=1.5, jitter=0.15):
     return pos.astype(np.float32), feat, aa.astype(np.int64)
 
 
+def make_context(rng, n_ctx, num_classes=13, offset=2.5, radius=1.5):
+    """Fixed atoms of a linker-style job (what choose_ctx_gen + remove_ligand_gen leave of a native ligand, select.py:21-88):
+    two fragments at +-``offset`` A from a random point near the pocket centre, in the pocket's frame.
+    -> (pos [n_ctx,3] float32, atom_type [n_ctx] int64)"""
+    c0 = rng.standard_normal(3) * 1.5
+    axis = rng.standard_normal(3)
+    axis /= np.linalg.norm(axis)
+    half = n_ctx // 2
+    pos = np.concatenate([c0 + offset * axis + rng.standard_normal((half, 3)) * radius / 2,
+                          c0 - offset * axis + rng.standard_normal((n_ctx - half, 3)) * radius / 2])
+    return pos.astype(np.float32), rng.integers(0, num_classes, size=n_ctx).astype(np.int64)
+
+
 def make_batch(pockets, n_lig_list, rng, num_classes=13, n_ctx_list=None, ctx_radius=3.0):
     """Collate pockets [(pos, feat, aa), ...] with fresh ligand priors.
 

@@ -470,6 +470,62 @@ def priors_case(name):
     print(name, sizes, bins)
 
 
+def context_prior_case(name):
+    """The reference's transform chain of a context task -- configs/linker/test/targetdiff.yml:20-31 (frag / scaffold / sidechain
+    share it): assign_gensize -> assign_genatomtype -> center_pos(ligand, ctx_flag) -> assign_genpos -> merge -- run on seeded
+    pockets with fixed context atoms, three replicas each as sample.py:177 makes them, for the three type priors the shipped
+    configs use (uniform: targetdiff, absorbing: diffbp, gaussian: diffsbdd).  Stored: the inputs, every merged key of every
+    replica, and the merged key list: the schema and the deterministic part (context rows, centring, flags) of the batch that
+    cbgbench_amd/priors.py builds."""
+    if not _selected(name):
+        return
+    ref_shim.load_reference()
+    import repo.datasets.transforms.init_lig as IL
+    import repo.datasets.transforms.translation  # noqa: F401  (registers center_pos; the module re-uses the class name)
+    import repo.datasets.transforms.merge as MG
+    from repo.datasets.transforms._base import TRANSFORM_DICT
+    rng = np.random.default_rng(91)
+    out = {}
+    excluded = ["gen_bond_index", "gen_bond_type", "bond_index", "bond_type", "ctx_bond_index", "ctx_bond_type", "gen_index",
+                "ctx_index", "cross_bond_index", "cross_bond_type"]
+    cases = [("uniform", "add_aromatic", 13), ("absorbing", "add_aromatic", 13), ("gaussian", "basic", 8)]
+    pockets = []
+    for k, (n, n_ctx) in enumerate([(70, 9), (55, 14), (64, 0)]):
+        pos, feat, aa = S.make_pocket(rng, n, radius=8.0)
+        pos = pos + rng.standard_normal(3).astype(np.float32) * 4.0          # an un-centred frame, like the raw pocket files
+        cpos, ctyp = S.make_context(rng, n_ctx, 8) if n_ctx else (np.zeros((0, 3), np.float32), np.zeros(0, np.int64))
+        cpos = cpos + pos.mean(0, keepdims=True)
+        pockets.append((pos, feat, aa, cpos, ctyp))
+        out[f"pocket{k}_pos"], out[f"pocket{k}_feat"], out[f"pocket{k}_aa"] = pos, feat, aa
+        out[f"pocket{k}_ctx_pos"], out[f"pocket{k}_ctx_type"] = cpos, ctyp
+    keys = None
+    for ci, (dist, mode, C) in enumerate(cases):
+        np.random.seed(100 + ci)
+        torch.manual_seed(200 + ci)
+        for k, (pos, feat, aa, cpos, ctyp) in enumerate(pockets):
+            for rep in range(3):
+                n_ctx = cpos.shape[0]
+                data = ref_shim.AttrDict(
+                    protein=dict(pos=torch.from_numpy(pos.copy()), atom_feature=torch.from_numpy(feat), aa_type=torch.from_numpy(aa),
+                                 element=torch.zeros(pos.shape[0], dtype=torch.long), lig_flag=torch.zeros(pos.shape[0], dtype=torch.bool)),
+                    ligand=dict(pos=torch.from_numpy(cpos.copy()), atom_type=torch.from_numpy(ctyp.copy()),
+                                element=torch.zeros(n_ctx, dtype=torch.long), ctx_flag=torch.ones(n_ctx, dtype=torch.bool),
+                                gen_flag=torch.zeros(n_ctx, dtype=torch.bool), lig_flag=torch.ones(n_ctx, dtype=torch.bool)))
+                data = IL.AssignGenSize("prior_distcond")(data)
+                data = IL.AssignGenType(dist, mode)(data)
+                data = TRANSFORM_DICT["center_pos"]("ligand", "ctx_flag")(data)
+                data = IL.AssignGenPos("gaussian")(data)
+                merged = MG.MergeKeys(["protein", "ligand"], to_graph=False, excluded_subkeys=excluded)(data)
+                if keys is None:
+                    keys = sorted(merged.keys())
+                assert sorted(merged.keys()) == keys
+                for kk, v in merged.items():
+                    out[f"{dist}_p{k}_r{rep}_{kk}"] = _np(v)
+    out["merged_keys"] = np.array(keys)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, keys)
+
+
 def _selected(name):
     """``python -m oracle.make_golden train_`` regenerates only the fixtures whose name contains an argument."""
     sel = sys.argv[1:]
@@ -525,6 +581,7 @@ def main():
     train_case(model, "train_loss_t0_linker", small_batch([(58, 15), (44, 12)], seed=68, ctx=[10, 8]), seed=16,
                t_override=torch.tensor([0, 700]))
     priors_case("priors_atom_num")
+    context_prior_case("priors_context_tasks")
     diffsbdd_train_case("train_loss_diffsbdd", small_batch([(64, 10), (50, 12), (57, 9)], seed=64, num_classes=8), seed=18)
     # (seed chosen so that no ReLU of the t = 0 graph sits within rounding of zero: with the unnormalised t = 0 term such
     # a unit makes two fp32 evaluation orders differ by 0.5 % in one tensor -- seen with seed 65)

@@ -572,6 +572,55 @@ def test_sampling_driver_end_to_end(tmp_path):
         assert len(s["atom"]) == s["pos"].shape[0] == len(s["aromatic"]) and set(s["atom"]) <= {1, 6, 7, 8, 9, 15, 16, 17}
 
 
+def test_sampling_driver_context_task_end_to_end(tmp_path):
+    """A linker-style config through the driver: context atoms from the pocket file, frame centred on their
+    mean (center_pos with mask_flag ctx_flag), generated atoms appended (assign_gensize), T = 20 steps -- the context atoms come
+    back BIT-IDENTICAL in the pocket file's own frame positions up to the one fp32 translate round trip, their types unchanged,
+    and the generated atoms moved."""
+    import os as _os
+    import numpy as _np
+    from cbgbench_amd import sample_cli, synthetic as S
+    rng = _np.random.default_rng(21)
+    raw = []
+    for k in range(3):
+        pos, feat, aa = S.make_pocket(rng, int(rng.integers(300, 420)))
+        off = rng.standard_normal(3).astype(_np.float32) * 6.0          # raw frame: far from the origin
+        cpos, ctyp = S.make_context(rng, int(rng.integers(8, 20)))
+        raw.append({"protein_pos": pos + off, "protein_atom_feature": feat, "protein_aa_type": aa,
+                    "ligand_ctx_pos": cpos + off, "ligand_ctx_atom_type": ctyp})
+    pfile = str(tmp_path / "pockets.pt")
+    torch.save(raw, pfile)
+    cfg = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "fixtures", "linker_targetdiff_T20.yml")
+    for extra, frame in (([], "raw"), (["--no_translate"], "centred")):
+        out = tmp_path / frame
+        rc = sample_cli.main(["--config", cfg, "--out_root", str(out), "--pockets", pfile, "--pockets_per_batch", "2",
+                              "--random_init"] + extra)
+        assert rc == 0
+        files = sorted(_os.listdir(out / "linker_targetdiff_T20"))
+        assert files == ["pocket_00000.pt", "pocket_00001.pt", "pocket_00002.pt"]
+        for k, f in enumerate(files):
+            rec = torch.load(out / "linker_targetdiff_T20" / f, weights_only=False)
+            assert len(rec["samples"]) == 3
+            cpos, ctyp = torch.from_numpy(raw[k]["ligand_ctx_pos"]), torch.from_numpy(raw[k]["ligand_ctx_atom_type"])
+            centre = cpos.mean(dim=0)
+            for smp in rec["samples"]:
+                c = cpos.shape[0]
+                gen = smp["gen_flag"]
+                assert gen.tolist() == [False] * c + [True] * (len(gen) - c) and len(gen) > c
+                assert smp["type"][:c].tolist() == ctyp.tolist()                     # context types untouched by 20 steps
+                want = (cpos - centre) + centre if frame == "raw" else cpos - centre  # exactly the arithmetic of the round trip
+                assert torch.equal(smp["pos"][:c], want)                             # context atoms never move: bit-identical
+                assert torch.isfinite(smp["pos"]).all()
+                far = (smp["pos"][c:] - (centre if frame == "raw" else 0.0)).norm(dim=-1)
+                assert float(far.max()) < 60.0                                       # generated atoms live around the context
+    # the driver refuses a context config without context atoms
+    for r in raw:
+        r.pop("ligand_ctx_pos"); r.pop("ligand_ctx_atom_type")
+    torch.save(raw, pfile)
+    with pytest.raises(SystemExit, match="context task"):
+        sample_cli.main(["--config", cfg, "--out_root", str(tmp_path / "x"), "--pockets", pfile, "--random_init"])
+
+
 def test_static_context_cache_is_exact(model):
     """the ligand-free cache of the first two layers (cbgx_unitransformer_forward_cached) must not change a single bit of
     a sampling step, on real-size pockets where most protein atoms are far from the ligand"""

@@ -127,3 +127,144 @@ def test_sample_records_follow_the_reference_schema():
     recs = sample_cli.split_samples(x, c, torch.tensor([0, 0, 1, 1, 1]), 2)
     assert [r["atom"] for r in recs] == [[6, 1], [17, 8, 8]] and recs[0]["aromatic"] == [True, False]
     assert recs[1]["type"].tolist() == [12, 5, 5] and torch.equal(recs[1]["pos"], x[2:])
+
+
+# ---- context tasks (linker / frag / scaffold / sidechain): plan of the config's transform list, batch against the reference's chain ----
+REF_CONFIGS = "/root/reference/configs"
+# the prior lines of configs/linker/test/targetdiff.yml:12-28 in this package's words (used when the reference tree is absent)
+CONTEXT_TRANSFORMS = """
+model: {type: %s}
+data:
+  test:
+    transform:
+      - {type: choose_ctx_gen, sampling: fix_zero}
+      - {type: featurize_protein_fa}
+      - {type: remove_ligand_gen, mode: %s}
+      - {type: assign_gensize, distribution: prior_distcond}
+      - {type: assign_genatomtype, distribution: %s, mode: %s}
+      - {type: center_pos, center_flag: ligand, mask_flag: ctx_flag}
+      - {type: assign_genpos, distribution: gaussian}
+sampling: {num_samples: 100, translate: true}
+"""
+
+
+def test_sampling_plan_of_the_reference_configs(tmp_path):
+    from cbgbench_amd import load_config, set_num_atom_type
+    want = {"targetdiff": ("uniform", "add_aromatic", 13), "diffbp": ("absorbing", "add_aromatic", 13),
+            "diffsbdd": ("gaussian", "basic", 8)}
+    seen = 0
+    for task in ("linker", "frag", "scaffold", "sidechain"):
+        for method, (prior, mode, C) in want.items():
+            path = os.path.join(REF_CONFIGS, task, "test", method + ".yml")
+            if not os.path.exists(path):          # GPU box / no reference tree: the same lines from the inline YAML
+                path = str(tmp_path / f"{task}_{method}.yml")
+                with open(path, "w") as f:
+                    f.write(CONTEXT_TRANSFORMS % (method, mode, prior, mode))
+            cfg, _ = load_config(path)
+            set_num_atom_type(cfg)
+            plan = priors.SamplingPlan.from_config(cfg)
+            assert (plan.task, plan.size_dist, plan.type_prior, plan.pos_prior, plan.center, plan.mode) == \
+                ("context", "prior_distcond", prior, "gaussian", "context", mode), (task, method, plan)
+            assert cfg.model.num_atomtype == C
+            seen += 1
+    assert seen == 12
+    # de-novo configs: whole ligands, protein-centred; DiffSBDD's zero-mean Gaussian and all-zero type prior
+    for method, (prior, pos) in {"targetdiff": ("uniform", "gaussian"), "diffbp": ("absorbing", "gaussian"),
+                                 "diffsbdd": ("zeros", "zero_mean_gaussian")}.items():
+        path = os.path.join(REF_CONFIGS, "denovo", "test", method + ".yml")
+        if os.path.exists(path):
+            cfg, _ = load_config(path)
+            plan = priors.SamplingPlan.from_config(cfg)
+            assert (plan.task, plan.type_prior, plan.pos_prior, plan.center) == ("denovo", prior, pos, "protein"), (method, plan)
+        assert repr(priors.SamplingPlan.for_model(method)).count(prior) == 1
+    # the transforms' own errors
+    from cbgbench_amd.config import Config
+    bad = Config({"model": {"type": "targetdiff"}, "data": {"test": {"transform": [{"type": "assign_gensize", "distribution": "posterior"}]}}})
+    with pytest.raises(ValueError, match="Unknown distribution type: posterior"):
+        priors.SamplingPlan.from_config(bad)
+    bad = Config({"model": {"type": "targetdiff"}, "data": {"test": {"transform": [{"type": "assign_genatomtype", "distribution": "zeros"}]}}})
+    with pytest.raises(ValueError, match="Unknown distribution type: zeros"):      # assign_genatomtype has no 'zeros' (init_lig.py:319-332)
+        priors.SamplingPlan.from_config(bad)
+
+
+@pytest.mark.parametrize("prior,num_classes", [("uniform", 13), ("absorbing", 13), ("gaussian", 8)])
+def test_context_batch_equals_the_reference_transform_chain(golden_dir, prior, num_classes):
+    """assign_gensize -> assign_genatomtype -> center_pos(ligand, ctx_flag) -> assign_genpos -> merge, run by the reference itself
+    on three pockets x three replicas (tests/golden/priors_context_tasks.npz, oracle/make_golden.py::context_prior_case): same
+    keys, dtypes and trailing shapes; protein rows, translations, flags and the context rows bit-identical; generated rows
+    distributed as the prior says."""
+    z = np.load(os.path.join(golden_dir, "priors_context_tasks.npz"))
+    P, S = 3, 3
+    pockets = [(z[f"pocket{k}_pos"], z[f"pocket{k}_feat"], z[f"pocket{k}_aa"]) for k in range(P)]
+    ctx = [(z[f"pocket{k}_ctx_pos"], z[f"pocket{k}_ctx_type"]) for k in range(P)]
+    ref = lambda k, r, key: torch.from_numpy(z[f"{prior}_p{k}_r{r}_{key}"])
+    n_lig = np.array([[ref(k, r, "ligand_pos").shape[0] for r in range(S)] for k in range(P)])
+    ps = priors.PocketSet(pockets, center=False)         # raw frame, as the pocket files of a context task come
+    b = priors.build_sampling_batch(ps, S, num_classes, n_lig=n_lig, context=ctx, type_prior=prior, pos_prior="gaussian",
+                                    center_on_context=True, generator=torch.Generator().manual_seed(5))
+    for key in z["merged_keys"]:
+        key = str(key)
+        assert key in b, key
+        mine, theirs = b[key], ref(0, 0, key)
+        assert mine.dtype == theirs.dtype and mine.shape[1:] == theirs.shape[1:], (key, mine.dtype, theirs.dtype)
+    for k in range(P):
+        for r in range(S):
+            g = k * S + r
+            rec, lig = b["protein_element_batch"] == g, b["ligand_element_batch"] == g
+            for key in ("protein_pos", "protein_translation", "protein_atom_feature", "protein_aa_type", "protein_lig_flag"):
+                assert torch.equal(b[key][rec], ref(k, r, key)), (key, k, r)
+            for key in ("ligand_gen_flag", "ligand_ctx_flag", "ligand_lig_flag", "ligand_translation"):
+                assert torch.equal(b[key][lig], ref(k, r, key)), (key, k, r)
+            c = ctx[k][1].shape[0]
+            assert b["ligand_ctx_flag"][lig].tolist() == [True] * c + [False] * (int(lig.sum()) - c)
+            assert torch.equal(b["ligand_pos"][lig][:c], ref(k, r, "ligand_pos")[:c])                 # centred context rows
+            assert torch.equal(b["ligand_atom_type"][lig][:c], ref(k, r, "ligand_atom_type")[:c])     # ids, or float one-hot rows
+            gen_t = b["ligand_atom_type"][lig][c:]
+            if prior == "absorbing":
+                assert int(gen_t.abs().max()) == 0 and int(ref(k, r, "ligand_atom_type")[c:].abs().max()) == 0
+            elif prior == "uniform":
+                assert 0 <= int(gen_t.min()) and int(gen_t.max()) < num_classes
+    # the centre is the context mean (a pocket without context atoms keeps its frame), results translate back to the raw frame
+    for k in range(P):
+        lig = b["ligand_element_batch"] == k * S
+        c = ctx[k][1].shape[0]
+        if c:
+            assert float(b["ligand_pos"][lig][:c].mean(0).abs().max()) < 1e-5
+            back = b["ligand_pos"][lig][:c] + b["ligand_translation"][lig][:c]
+            assert torch.allclose(back, torch.from_numpy(ctx[k][0]), atol=1e-5)
+        else:
+            assert float(b["protein_translation"][b["protein_element_batch"] == k * S].abs().max()) == 0.0
+    # generated rows: N(0, I) positions; gaussian type prior ~ N(0, 1) entries
+    gen = b["ligand_gen_flag"]
+    assert abs(float(b["ligand_pos"][gen].mean())) < 0.25 and 0.75 < float(b["ligand_pos"][gen].std()) < 1.25
+    if prior == "gaussian":
+        assert 0.8 < float(b["ligand_atom_type"][gen].std()) < 1.2
+
+
+def test_sample_cli_context_plumbing(tmp_path):
+    """--context file / ligand_ctx_* keys -> per-pocket context atoms; a context plan without context atoms is an error"""
+    from cbgbench_amd import sample_cli
+    rng = np.random.default_rng(8)
+    pk = _pockets(rng, [40, 52])
+    ctx = [synthetic.make_context(rng, 7), synthetic.make_context(rng, 11)]
+    raw = [{"protein_pos": p[0], "protein_atom_feature": p[1], "protein_aa_type": p[2], "ligand_ctx_pos": c[0],
+            "ligand_ctx_atom_type": c[1]} for p, c in zip(pk, ctx)]
+    got = sample_cli.load_context(raw, None)
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(got, ctx))
+    path = str(tmp_path / "ctx.pt")
+    torch.save([{"pos": c[0], "atom_type": c[1]} for c in ctx], path)
+    got = sample_cli.load_context(raw, path)
+    assert got[1][0].shape == (11, 3) and got[1][1].dtype == np.int64
+    torch.save([{"pos": ctx[0][0], "atom_type": ctx[0][1]}], path)
+    with pytest.raises(ValueError, match="1 entries for 2 pockets"):
+        sample_cli.load_context(raw, path)
+    assert sample_cli.load_context([{k: v for k, v in r.items() if not k.startswith("ligand")} for r in raw], None) is None
+    plan = priors.SamplingPlan("context", type_prior="uniform", center="context")
+    with pytest.raises(ValueError, match="no context atoms"):
+        sample_cli.build_pocket_batch(pk, 2, rng, 13, plan=plan, context=None)
+    b = sample_cli.build_pocket_batch(pk, 2, rng, 13, plan=plan, context=ctx)
+    assert int((~b["ligand_gen_flag"]).sum()) == 2 * (7 + 11) and b["ligand_gen_flag"].dtype == torch.bool
+    d = sample_cli.build_pocket_batch(pk, 2, rng, 8, plan=priors.SamplingPlan.for_model("diffsbdd", "basic"))
+    assert "ligand_gen_flag" not in d and d["ligand_atom_type"].shape[1] == 8
+    m = torch.zeros(4, 3).index_add_(0, d["ligand_element_batch"], d["ligand_pos"])
+    assert float(m.abs().max()) < 1e-4               # zero_mean_gaussian, configs/denovo/test/diffsbdd.yml
