@@ -13,7 +13,7 @@ _LIB = None
 _XLIB = None
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
-ABI_VERSION = 3      # include/cbgx.h CBGX_ABI_VERSION: bumped whenever the packed-weight layout or an entry point changes
+ABI_VERSION = 4      # include/cbgx.h CBGX_ABI_VERSION: bumped whenever the packed-weight layout or an entry point changes
 
 EXPORTS = {
     "cbgx_abi_version": (_i, []),

@@ -44,12 +44,6 @@ int set_error(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(CBGX_E_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
-#ifndef CBGX_EDGE_DYN
-#define CBGX_EDGE_DYN 0
-#endif
-#if CBGX_EDGE_DYN
-constexpr int EDGE_CTR_SLOTS = 64;      // (variant builds) edge launches of a forward call that get work counters
-#endif
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
@@ -82,9 +76,6 @@ struct Workspace {
     int* sp_list[4][2];  // [all nodes | cached layer 1 (D2) | pruned A1 | pruned A2][1 = general, 0 = protein-only]
     int* sp_count;       // per set one 128-byte region: general count at +0, protein-only count at +64 bytes
     int* zero_count;     // an always-empty list's count
-#if CBGX_EDGE_DYN
-    int* edge_ctr;       // EDGE_CTR_SLOTS x 16 work counters of the edge launches of a call (variant builds only)
-#endif
     void* counters;      // flags + act_count, rf_count, fw_count, sp_count, zero_count are carved from ONE block: one fill per call
     size_t counters_bytes;
     size_t total;
@@ -123,9 +114,6 @@ static Workspace carve(void* base, int n) {
         // every device-side list count of a forward call, 64 bytes apart (a counter word is hammered by returning atomics)
         const size_t fl = align_up(N);
         w.counters_bytes = 8 * fl + 256 + 256 + 256 + 4 * 128 + 256;
-#if CBGX_EDGE_DYN
-        w.counters_bytes += EDGE_CTR_SLOTS * 64;
-#endif
         char* c = take(w.counters_bytes);
         w.counters = c;
         w.d1flag = (uint8_t*)c; w.fa1 = w.d1flag + fl; w.fa2 = w.fa1 + fl; w.fa3 = w.fa2 + fl;
@@ -136,9 +124,6 @@ static Workspace carve(void* base, int n) {
         w.fw_count = (int*)(c + 512);
         w.sp_count = (int*)(c + 768);
         w.zero_count = (int*)(c + 768 + 4 * 128);
-#if CBGX_EDGE_DYN
-        w.edge_ctr = (int*)(c + 768 + 4 * 128 + 256);
-#endif
     }
     w.total = off;
     return w;
@@ -539,12 +524,6 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
         return fail(CBGX_E_WORKSPACE, "forward: workspace %zu < %zu", workspace_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(w.counters, 0, w.counters_bytes, s));      // every list count of this call: one fill instead of ~15
-#if CBGX_EDGE_DYN
-    struct CtrScope {     // the edge launches of this call take their (just zeroed) work counters from the pool, in call order
-        CtrScope(int* b) { edge_set_work_counters(b, EDGE_CTR_SLOTS); }
-        ~CtrScope() { edge_set_work_counters(nullptr, 0); }
-    } ctr_scope(w.edge_ctr);
-#endif
     const bool cached = static_h1 && static_h2 && num_layers >= 4;
     // with the graph part of the cache, only the nodes that have a ligand atom within reach get a fresh neighbour list
     // and gate: everything else about the pocket's own graph was computed once (same order, same bits)
@@ -587,7 +566,9 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
     {
         ListJobs jobs;
         memset(&jobs, 0, sizeof(jobs));
+        bool jobs_overflow = false;
         auto add = [&](const uint8_t* f, const uint8_t* f2, int want2, int* list, int* count) {
+            if (jobs.n_jobs >= LIST_JOBS_MAX) { jobs_overflow = true; return; }
             const int k = jobs.n_jobs++;
             jobs.flag[k] = f; jobs.flag2[k] = f2; jobs.want2[k] = want2; jobs.list[k] = list; jobs.count[k] = count;
         };
@@ -612,6 +593,7 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
             if (cached) pair(1, w.fD2);
             if (prune) { pair(2, w.fa1); pair(3, w.fa2); }
         }
+        if (jobs_overflow) return fail(CBGX_E_INVALID, "forward: more than %d node lists (LIST_JOBS_MAX)", LIST_JOBS_MAX);
         HIP_TRY(launch_build_lists(jobs, n_nodes, s));
     }
     struct X2HLists { const int *gen, *gen_n, *pp, *pp_n; bool full; };
@@ -647,6 +629,47 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
     float* qset[2] = {w.q, w.q2};
     const float* xc = x;
     const float* hc = h;
+    // Small inputs (round 5): ONE stream and ONE node-stage launch per layer.  The h2x block of layer l and the x2h block of layer
+    // l + 1 both read h_{l+1} and nothing else that is new, so their node stages are jobs of the same node_stage_kernel launch and a
+    // layer is three dependent launches -- x2h edge, node stages, h2x edge -- with no event between them.  The two-stream schedule
+    // below hides the second node stage behind the h2x block instead, at the price of a fork and a join event per layer, ~7 us
+    // each on the caller's queue: 80 us per layer at one graph, of which 14 are the events and 24 + 25 the two edge launches
+    // (profiles/step_timeline_r05a_p1s1_ov1.json).  CBGX_FUSE_ROWS: largest input that takes this schedule (0 = never).
+    static const int fuse_rows = [] { const char* e = getenv("CBGX_FUSE_ROWS"); return e ? atoi(e) : NODE_STAGE_MAX_ROWS; }();
+    if (dual && num_layers > 1 && n_nodes <= fuse_rows && n_nodes <= NODE_STAGE_MAX_ROWS) {
+        {
+            const int *dst, *dst_n, *src, *src_n;
+            layer_lists(0, dst, dst_n, src, src_n);
+            NodeStageJobs jobs;
+            jobs.n = 0;
+            add_node_stage_jobs(jobs, packed + x2h_off(0), Pset[0], qset[0], Qtset[0], dst, dst_n, src, src_n);
+            HIP_TRY(launch_node_stage_jobs(jobs, h, lig_flag, n_nodes, s));
+        }
+        for (int l = 0; l < num_layers; ++l) {
+            float* hn = (l == num_layers - 1 && h_out) ? h_out : w.hbuf[l & 1];
+            float* xn = (l == num_layers - 1) ? x_out : w.xbuf[l & 1];
+            if (cached && l < 2)
+                HIP_TRY(hipMemcpyAsync(hn, l == 0 ? static_h1 : static_h2, (size_t)n_nodes * H * sizeof(float),
+                                       hipMemcpyDeviceToDevice, s));
+            const X2HLists xl = x2h_lists(l);
+            const int set = l & 1;
+            HIP_TRY(launch_edge_x2h_dual(packed + x2h_off(l), xc, hc, Pset[set], Qtset[set], qset[set], w.nbr, w.deg, lig_flag,
+                                         gen_flag, w.e_w, n_nodes, hn, xl.pp, xl.pp_n, xl.gen, xl.gen_n, xl.full, s));
+            NodeStageJobs jobs;
+            jobs.n = 0;
+            add_node_stage_jobs(jobs, packed + h2x_off(l), w.P3, w.q3, w.Qt3, w.act, w.act_count, w.rf_list[0], w.rf_count);
+            if (l + 1 < num_layers) {
+                const int *d2, *d2n, *s2, *s2n;
+                layer_lists(l + 1, d2, d2n, s2, s2n);
+                add_node_stage_jobs(jobs, packed + x2h_off(l + 1), Pset[set ^ 1], qset[set ^ 1], Qtset[set ^ 1], d2, d2n, s2, s2n);
+            }
+            HIP_TRY(launch_node_stage_jobs(jobs, hn, lig_flag, n_nodes, s));
+            HIP_TRY(launch_edge_mfma(false, packed + h2x_off(l), xc, hn, w.P3, w.Qt3, w.nbr, w.deg, lig_flag, gen_flag, w.e_w,
+                                     n_nodes, xn, nullptr, w.act, w.act_count, s));
+            xc = xn;
+            hc = hn;
+        }
+    } else {
     if (overlap) {
         const int *dst, *dst_n, *src, *src_n;
         layer_lists(0, dst, dst_n, src, src_n);
@@ -696,6 +719,7 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
         xc = xn;
         hc = hn;
     }
+    }   // two-stream / serial schedules
     if (logits) {
         const float* c = packed + cls_off(num_layers);
         // pruned mode: logits are only defined on ligand rows, which are a subset of A1 (rf_list[0])

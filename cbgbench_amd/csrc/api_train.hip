@@ -26,9 +26,6 @@ namespace cbgx { int set_error(int code, const char* fmt, ...); }
         if (_rc) return _rc; \
     } while (0)
 
-#ifndef CBGX_EDGE_DYN
-#define CBGX_EDGE_DYN 0
-#endif
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 constexpr int EDGE_GRID = 256;    // persistent workgroups of the edge backward (one per CU: ~97 KB LDS each)
@@ -82,9 +79,6 @@ struct TrainWs {
     int *act, *act_count;
     uint8_t* mask;        // receptive field of the loss, walked backwards (see cbgx_unitransformer_backward)
     int *rf_list[2], *rf_count;
-#if CBGX_EDGE_DYN
-    int* edge_ctr;        // 64 x 16 work counters of the taped forward's edge launches (variant builds only, edge_mfma.hip)
-#endif
     int* lig_list;        // rows with lig_flag (count: rf_count + 32): the classifier head's backward walks it when the loss reads ligand rows only
     size_t partial_floats;
     size_t total;
@@ -129,9 +123,6 @@ static TrainWs carve_train(void* base, int n) {
     w.rf_list[1] = (int*)take(N * 4);
     w.rf_count = (int*)take(256);
     w.lig_list = (int*)take(N * 4);
-#if CBGX_EDGE_DYN
-    w.edge_ctr = (int*)take(64 * 64);
-#endif
     w.partial_floats = partial_floats_needed();
     w.partial = (float*)take(w.partial_floats * 4);
     w.folded = (float*)take((size_t)FOLD * H * PROW * 4);
@@ -244,12 +235,15 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     rb.n = 0;
     FoldBatch fb;
     fb.n = 0;
+    bool batch_overflow = false;      // (a stack struct passed by value to a kernel must not be overrun by one more piece)
     auto piece = [&](const float* src, int nsl, size_t stride, int ld, int rws, int cls, float* dst, int dld, int tr) {
+        if (rb.n >= RS_MAX) { batch_overflow = true; return; }
         rb.p[rb.n++] = RsPiece{src, dst, stride, nsl, ld, rws, cls, dld, tr};
     };
     const float* fz; int fn; size_t fs;
     auto folded = [&](const float* src, int nsl, size_t stride, int size, float* dst) {
         if (nsl <= FOLD) { fz = src; fn = nsl; fs = stride; return; }
+        if (fb.n >= FOLD_JOBS_MAX) { batch_overflow = true; fz = src; fn = nsl; fs = stride; return; }
         fb.j[fb.n++] = FoldJob{src, dst, stride, nsl, size};
         fz = dst; fn = FOLD; fs = (size_t)size;
     };
@@ -325,6 +319,7 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
         piece(fz + 3 * H, fn, fs, PROW, H, H, v0w + NT + NT * G + H, KV_IN, 1);
         piece(fz + 4 * H, fn, fs, PROW, H, H, q0w, H, 1);
     }
+    if (batch_overflow) return cbgx::set_error(CBGX_E_INVALID, "backward: reduce batch overflow (RS_MAX / FOLD_JOBS_MAX too small)");
     HIP_TRY(launch_slab_fold_multi(fb, FOLD, s));
     HIP_TRY(launch_reduce_store_multi(rb, s));
     // dL/dh_in = (gh_src or gh itself) + dP Wn^T
@@ -378,13 +373,6 @@ int cbgx_unitransformer_forward_train(const float* packed, int num_layers, int n
     HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, tp.nbr, tp.deg, s));
     HIP_TRY(launch_gate(packed, x, tp.nbr, tp.deg, n_nodes, tp.e_w, s));
     HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, s));
-#if CBGX_EDGE_DYN
-    HIP_TRY(hipMemsetAsync(w.edge_ctr, 0, 64 * 64, s));
-    struct CtrScope {
-        CtrScope(int* b) { edge_set_work_counters(b, 64); }
-        ~CtrScope() { edge_set_work_counters(nullptr, 0); }
-    } ctr_scope(w.edge_ctr);
-#endif
     for (int l = 0; l < num_layers; ++l) {
         const float* xc = tp.xs + (size_t)l * nx;
         const float* hc = tp.hs + (size_t)l * nh;

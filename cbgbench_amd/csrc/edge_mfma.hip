@@ -35,34 +35,18 @@
 #include "kernels.h"
 #include "layout.h"
 
-// UNTESTED VARIANT, off in every build of this tree (prepared at the end of round 4, when the GPU budget was spent; to try it:
-// scripts/build_variant.py <name> -DCBGX_EDGE_DYN=2, all GPU tests, scripts/gpu_small_batch.sh).  With CBGX_EDGE_DYN = d > 0 the
-// persistent loop of edge_body runs its first rounds statically as always and hands the last d - 1 full rounds of an XCD's range
-// plus the partial one out through a per-XCD counter (the scheme of edge_backward_x2h_kernel, train_bwd_x2h.hip; index arithmetic
-// pinned by tests/test_bx_partition.py::test_forward_*): a 10-graph batch is 2.15 nodes per wave and runs three static rounds
-// (53 us per x2h launch), the training forward 8.06 nodes per wave and nine.  The counters come from the caller through
-// edge_set_work_counters (16 ints per launch, zero at launch); without them, or when an XCD's range has no full round, the
-// schedule is the static one.
-#ifndef CBGX_EDGE_DYN
-#define CBGX_EDGE_DYN 0
-#endif
-// A second UNTESTED VARIANT, also off in every build (-DCBGX_EDGE_SMALL_W4=1): inputs of at most EDGE_W4_MAX_NODES nodes launch
-// 4-wave workgroups instead of 8-wave ones, so that a node's wave has its SIMD to itself (one workgroup per CU either way: the LDS
-// image).  Reason to try it: a 1-graph edge launch is 6.4 us of launch + image and 18 - 20 us of ONE node's dependent chain on ONE
-// wave (profiles/probe_r04z2.log), 57 CUs busy with two such chains per SIMD while 199 idle -- and in the x2h edge backward a wave
-// alone on its SIMD ran 1.77 x faster than next to a second one (docs/x2h_backward.md).
-#ifndef CBGX_EDGE_SMALL_W4
-#define CBGX_EDGE_SMALL_W4 0
-#endif
-#if CBGX_EDGE_SMALL_W4
-constexpr int EDGE_W4_MAX_NODES = 1016;      // (4 waves per workgroup, 256 workgroups, minus the second role's rounding)
-#endif
-#if CBGX_EDGE_DYN
-#define CBGX_DYN_PARAM , int* __restrict__ work_ctr
-#define CBGX_DYN_ARG(p) , p
-#else
-#define CBGX_DYN_PARAM
-#define CBGX_DYN_ARG(p)
+// Waves of a persistent workgroup that take items.  A launch whose item list is short next to the grid (one graph: 445 nodes, an
+// h2x block: the ~25 movable atoms per graph) is ONE node's dependent chain per wave -- 18 - 20 us of a 27 us launch
+// (profiles/probe_r04z2.log) -- and two such chains on one SIMD slow each other down.  So a workgroup puts only as many of its
+// WAVES waves to work as the list needs, but at least CBGX_EDGE_MIN_WAVES = 4 (one per SIMD), and the launchers size the grid for
+// four nodes per workgroup: the other waves help fill the LDS image and leave.  Decided per launch from the DEVICE-side list length,
+// so cached / pruned / listed launches of a large batch get it too (the ~250 movable atoms of a 10-graph batch).  Same arithmetic per
+// node whatever the schedule.  History: round 4 prepared this as a host-side switch (-DCBGX_EDGE_SMALL_W4, 4-wave workgroups for
+// inputs of <= 1016 nodes) next to a dynamic remainder of the persistent loop (-DCBGX_EDGE_DYN); round 5's first GPU call measured
+// both (profiles/small_dyn_r05a.log): 4 waves 1 167 -> 1 328 graph-steps/s at one graph (edge launches 26.8 -> 21.0 us), the dynamic
+// remainder 9 116 -> 8 278 at ten graphs (x2h launch 52.8 -> 71.4 us) and nothing on the headline or the training line -- deleted.
+#ifndef CBGX_EDGE_MIN_WAVES
+#define CBGX_EDGE_MIN_WAVES 4
 #endif
 
 namespace cbgx {
@@ -70,6 +54,15 @@ namespace cbgx {
 
 __constant__ float c_mu[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.75f, 3.f,
                               3.5f, 4.f, 4.5f, 5.f, 5.5f, 6.f, 7.f, 8.f, 9.f, 10.f};
+
+// waves of a WAVES-wave workgroup that take items when `n_items` items are shared by `n_wg` workgroups (wave-uniform; the same
+// formula sizes the roles of edge_x2h_dual_kernel and is restated in tests/test_bx_partition.py)
+constexpr int EDGE_MIN_WAVES = CBGX_EDGE_MIN_WAVES;
+__host__ __device__ __forceinline__ int edge_active_waves(int n_items, int n_wg, int waves) {
+    const int per_wg = (n_items + n_wg - 1) / (n_wg > 0 ? n_wg : 1);
+    const int lo = EDGE_MIN_WAVES < waves ? EDGE_MIN_WAVES : waves;
+    return per_wg < lo ? lo : (per_wg > waves ? waves : per_wg);
+}
 
 // ---- edge-major path for one half (16 edges): pre-activation -> LayerNorm -> ReLU -> contraction with a
 // per-lane row of B (Qt[i][a] for scores: registers `pre`; Wbv[a] for the h2x values: LDS `lds_brow`, already lane-offset).  Returns the 16x16 result tile:
@@ -195,7 +188,7 @@ __device__ __forceinline__ void edge_body(
     const float* __restrict__ P, const float* __restrict__ Qt, const int32_t* __restrict__ nbr,
     const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig, const uint8_t* __restrict__ gen,
     const float* __restrict__ e_w, int n_nodes, float* __restrict__ out, float* __restrict__ dx_out,
-    const int* __restrict__ act_arg, const int* __restrict__ act_count CBGX_DYN_PARAM) {
+    const int* __restrict__ act_arg, const int* __restrict__ act_count) {
     const int* __restrict__ act = LISTED ? act_arg : nullptr;
     static_assert(!PP || (X2H && LISTED), "the protein-only kernel is an x2h work-list kernel");
     static_assert(PP_IMG_SIZE == IMG_SIZE_X2H, "both x2h images fill the same LDS array");
@@ -209,14 +202,15 @@ __device__ __forceinline__ void edge_body(
             }
     }
     const int n_items = act ? *act_count : n_nodes;
+    const int wv = edge_active_waves(n_items, n_wg, WAVES);     // waves of this workgroup that take items (see CBGX_EDGE_MIN_WAVES)
     {   // a workgroup with no item skips the LDS fill altogether
         int first;
         if ((n_wg & 7) == 0) {
-            const int per_xcd = (((n_items + 7) >> 3) + WAVES - 1) / WAVES * WAVES;
-            first = (wg & 7) * per_xcd + (wg >> 3) * WAVES;
+            const int per_xcd = (((n_items + 7) >> 3) + wv - 1) / wv * wv;
+            first = (wg & 7) * per_xcd + (wg >> 3) * wv;
             if (first >= min(n_items, ((int)(wg & 7) + 1) * per_xcd)) return;
         } else {
-            first = wg * WAVES;
+            first = wg * wv;
             if (first >= n_items) return;
         }
     }
@@ -276,28 +270,19 @@ __device__ __forceinline__ void edge_body(
     // XCD one contiguous eighth of the item range: a graph's PS / Qt rows are then pulled into one L2 only.  (A role of the
     // two-role kernel starts at a multiple of 8, so wg % 8 is still the XCD.)
     int i_begin, i_end, i_step;
+    if (wave >= wv) return;     // (after the barrier: this wave has done its share of the LDS fill)
     if ((n_wg & 7) == 0) {
-        const int per_xcd = (((n_items + 7) >> 3) + WAVES - 1) / WAVES * WAVES;
+        const int per_xcd = (((n_items + 7) >> 3) + wv - 1) / wv * wv;
         const int xcd = wg & 7, slot = wg >> 3;
-        i_begin = xcd * per_xcd + slot * WAVES + wave;
+        i_begin = xcd * per_xcd + slot * wv + wave;
         i_end = min(n_items, (xcd + 1) * per_xcd);
-        i_step = (n_wg >> 3) * WAVES;
+        i_step = (n_wg >> 3) * wv;
     } else {
-        i_begin = wg * WAVES + wave;
+        i_begin = wg * wv + wave;
         i_end = n_items;
-        i_step = n_wg * WAVES;
+        i_step = n_wg * wv;
     }
     if (i_begin >= i_end) return;
-#if CBGX_EDGE_DYN
-    // static rounds, dynamic remainder: the items [dyn_tail, i_end) of this XCD's range go to whichever wave asks first
-    const int dyn_base = (n_wg & 7) == 0 ? min(n_items, (wg & 7) * ((((n_items + 7) >> 3) + WAVES - 1) / WAVES * WAVES)) : 0;
-    const int dyn_full = (i_end - dyn_base) / i_step;                         // rounds every wave of the range runs
-    const int dyn_static = max(dyn_full - (CBGX_EDGE_DYN - 1), 1);            // the first round is always static
-    const int dyn_tail = dyn_base + dyn_static * i_step;
-    const bool dyn_on = work_ctr != nullptr && dyn_full >= 1 && dyn_tail < i_end;
-    int* const dyn_ctr = work_ctr + ((n_wg & 7) == 0 ? (wg & 7) : 0);
-    int dyn_round = 0;
-#endif
     // power-of-two scales of the split-f16 rbf tables (wave-uniform: scalar registers)
     const RbfScale sck = load_rbf_scale(att, 0), scv = load_rbf_scale(att, 1);
     // h2x: bias of this lane's head, once per launch -- loaded inside the loop it sat behind the next node's 24-row prefetch in the
@@ -336,25 +321,10 @@ __device__ __forceinline__ void edge_body(
         for (int t = 0; t < 8; ++t) ps1[t] = ldo4(sbase(P), o1 + 64 * t);
     }
 
-#if CBGX_EDGE_DYN
-    for (int k = i_begin;;) {
-        const int i = __builtin_amdgcn_readfirstlane(g.node), d = g.d, lig_i = g.lig_i;
-        int k_next = k + i_step;
-        bool more;      // wave-uniform
-        if (!dyn_on) more = k_next < i_end;
-        else if (dyn_round + 1 < dyn_static) more = true;
-        else {          // claimed while this node is still to be processed: its header travels behind this node's work as always
-            int v = 0;
-            if (lane == 0) v = atomicAdd(dyn_ctr, 1);
-            k_next = dyn_tail + __builtin_amdgcn_readfirstlane(v);
-            more = k_next < i_end;
-        }
-#else
     for (int k = i_begin; k < i_end; k += i_step) {
         const int i = __builtin_amdgcn_readfirstlane(g.node), d = g.d, lig_i = g.lig_i;
         const bool more = k + i_step < i_end;   // wave-uniform
         const int k_next = k + i_step;
-#endif
         // both halves' PD[i] + PS_k[j] as soon as the rows (requested one epilogue ago) are here: the 24 gather registers
         // are then free for this iteration's other gathers
         floatx4 acc0[8], acc1[8];
@@ -745,11 +715,6 @@ __device__ __forceinline__ void edge_body(
         nb0 = nnb0; nb1 = nnb1;
         lg0[0] = nlg[0]; lg0[1] = nlg[1]; dist0[0] = ndist[0]; dist0[1] = ndist[1];
         g = ng;
-#if CBGX_EDGE_DYN
-        if (!more) break;
-        k = k_next;
-        ++dyn_round;
-#endif
     }
 }
 
@@ -759,11 +724,11 @@ __global__ __launch_bounds__(WAVES * 64) void edge_mfma_kernel(
     const float* __restrict__ P, const float* __restrict__ Qt, const int32_t* __restrict__ nbr,
     const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig, const uint8_t* __restrict__ gen,
     const float* __restrict__ e_w, int n_nodes, float* __restrict__ out, float* __restrict__ dx_out,
-    const int* __restrict__ act, const int* __restrict__ act_count CBGX_DYN_PARAM) {
+    const int* __restrict__ act, const int* __restrict__ act_count) {
     __shared__ __attribute__((aligned(16))) float lds[X2H ? (int)IMG_SIZE_X2H : (int)IMG_SIZE_H2X];
     __shared__ float lds_mu[G];
     edge_body<X2H, WAVES, LISTED, false>(lds, lds_mu, blockIdx.x, gridDim.x, att, x, h, P, Qt, nbr, deg, lig, gen, e_w, n_nodes, out,
-                                         dx_out, act, act_count CBGX_DYN_ARG(work_ctr));
+                                         dx_out, act, act_count);
 }
 
 // x2h over TWO work lists in one launch: the protein-only destinations (`list_pp`: the node and all its neighbours are protein
@@ -786,18 +751,19 @@ __global__ __launch_bounds__(WAVES * 64) void edge_x2h_dual_kernel(
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig,
     const uint8_t* __restrict__ gen, const float* __restrict__ e_w, int n_nodes, float* __restrict__ out,
     const int* __restrict__ list_pp, const int* __restrict__ count_pp, const int* __restrict__ list_gen,
-    const int* __restrict__ count_gen CBGX_DYN_PARAM) {
+    const int* __restrict__ count_gen) {
     __shared__ __attribute__((aligned(16))) float lds[IMG_SIZE_X2H];
     __shared__ float lds_mu[G];
     const int c_pp = *count_pp, c_gen = *count_gen;
     const int n_wg = gridDim.x;
     int n_pp_wg;
-    const int need_pp = (c_pp + WAVES - 1) / WAVES, need_gen = (c_gen + WAVES - 1) / WAVES;
+    // small input: both roles at `wv` nodes per workgroup, the spacing a single list of c_pp + c_gen items would get (the launcher adds
+    // a workgroup for the second role's remainder): a proportional split left one role two nodes per wave, 36 instead of 27 us at one graph
+    const int wv = edge_active_waves(c_pp + c_gen, n_wg > 1 ? n_wg - 1 : 1, WAVES);
+    const int need_pp = (c_pp + wv - 1) / wv, need_gen = (c_gen + wv - 1) / wv;
     if (c_gen == 0) n_pp_wg = n_wg;
     else if (c_pp == 0) n_pp_wg = 0;
-    else if (need_pp + need_gen <= n_wg) n_pp_wg = need_pp;      // small input: one node per wave in both roles (the launcher adds a
-                                                                 // workgroup for the second role's remainder): a proportional split
-                                                                 // left one role two nodes per wave, 36 instead of 27 us at one graph
+    else if (need_pp + need_gen <= n_wg) n_pp_wg = need_pp;
     else {
         const float share = (float)c_pp / ((float)c_pp + DUAL_GEN_COST * (float)c_gen);
         const int unit = n_wg >= 64 ? 8 : 1;
@@ -807,10 +773,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_x2h_dual_kernel(
     }
     if ((int)blockIdx.x < n_pp_wg)
         edge_body<true, WAVES, true, true>(lds, lds_mu, blockIdx.x, n_pp_wg, att, x, h, P, qbuf, nbr, deg, lig, gen, e_w, n_nodes,
-                                           out, nullptr, list_pp, count_pp CBGX_DYN_ARG(work_ctr));
+                                           out, nullptr, list_pp, count_pp);
     else
         edge_body<true, WAVES, true, false>(lds, lds_mu, (int)blockIdx.x - n_pp_wg, n_wg - n_pp_wg, att, x, h, P, Qt, nbr, deg, lig,
-                                            gen, e_w, n_nodes, out, nullptr, list_gen, count_gen CBGX_DYN_ARG(work_ctr ? work_ctr + 8 : nullptr));
+                                            gen, e_w, n_nodes, out, nullptr, list_gen, count_gen);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -972,23 +938,6 @@ hipError_t launch_pack_stage2(const PackBlocks& pb, hipStream_t s) {
 static std::atomic<int> g_edge_wg_limit{0};
 int set_edge_workgroup_limit(int n) { return g_edge_wg_limit.exchange(n < 0 ? 0 : n, std::memory_order_relaxed); }
 
-// CBGX_EDGE_DYN builds: the calling thread's pool of zeroed counter slots (16 ints per edge launch); a launch without a slot runs
-// the static schedule.  A no-op in the product build.
-#if CBGX_EDGE_DYN
-static thread_local int* t_ctr_next = nullptr;
-static thread_local int t_ctr_left = 0;
-void edge_set_work_counters(int* base, int slots) { t_ctr_next = base; t_ctr_left = base ? slots : 0; }
-static int* take_ctr_slot() {
-    if (t_ctr_left <= 0) return nullptr;
-    int* p = t_ctr_next;
-    t_ctr_next += 16;
-    --t_ctr_left;
-    return p;
-}
-#else
-void edge_set_work_counters(int*, int) {}
-#endif
-
 hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const float* h, const float* P,
                             const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                             const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,
@@ -996,35 +945,22 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
     if (n_nodes == 0) return hipSuccess;
     if ((size_t)n_nodes * PROW * sizeof(float) >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit byte offsets into P
     constexpr int W = 8;                        // waves per persistent workgroup: 2 per SIMD at <= 256 VGPRs per lane
-#if CBGX_EDGE_SMALL_W4
-    const int wv = n_nodes <= EDGE_W4_MAX_NODES ? 4 : W;      // small input: one wave per SIMD
-#else
-    constexpr int wv = W;
-#endif
-    int grid = (n_nodes + wv - 1) / wv;
+    // sized for EDGE_MIN_WAVES nodes per workgroup: a short list spreads over more CUs with one wave per SIMD (edge_active_waves)
+    int grid = (n_nodes + EDGE_MIN_WAVES - 1) / EDGE_MIN_WAVES;
     if (grid > 256) grid = 256;                 // persistent: one workgroup per CU (LDS-limited)
     const int wg_limit = g_edge_wg_limit.load(std::memory_order_relaxed);
     if (x2h && wg_limit >= 8 && grid > wg_limit) grid = wg_limit;   // the caller keeps CUs free for another stream
     if (grid >= 64) grid &= ~7;                 // multiple of 8 -> XCD-aware node partition
     profile_mark_begin(x2h ? (act ? K_EDGE_X2H_LISTED : K_EDGE_X2H) : K_EDGE_H2X, s);
-#define CBGX_LAUNCH_EDGE_W(X2H_, L_, W_)                                                                              \
-    hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W_, L_>), dim3(grid), dim3(W_ * 64), 0, s, att, x, h, P, Qt, nbr, deg, \
-                       lig, gen, e_w, n_nodes, out, dx_out, act, act_count CBGX_DYN_ARG(ctr_slot))
-#if CBGX_EDGE_SMALL_W4
-#define CBGX_LAUNCH_EDGE(X2H_, L_) do { if (wv == 4) CBGX_LAUNCH_EDGE_W(X2H_, L_, 4); else CBGX_LAUNCH_EDGE_W(X2H_, L_, W); } while (0)
-#else
-#define CBGX_LAUNCH_EDGE(X2H_, L_) CBGX_LAUNCH_EDGE_W(X2H_, L_, W)
-#endif
-#if CBGX_EDGE_DYN
-    int* const ctr_slot = take_ctr_slot();
-#endif
+#define CBGX_LAUNCH_EDGE(X2H_, L_)                                                                                  \
+    hipLaunchKernelGGL((edge_mfma_kernel<X2H_, W, L_>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qt, nbr, deg, \
+                       lig, gen, e_w, n_nodes, out, dx_out, act, act_count)
     if (x2h) {
         if (act) CBGX_LAUNCH_EDGE(true, true); else CBGX_LAUNCH_EDGE(true, false);
     } else {
         if (act) CBGX_LAUNCH_EDGE(false, true); else CBGX_LAUNCH_EDGE(false, false);
     }
 #undef CBGX_LAUNCH_EDGE
-#undef CBGX_LAUNCH_EDGE_W
     profile_mark_end(s);
     return hipGetLastError();
 }
@@ -1038,38 +974,18 @@ hipError_t launch_edge_x2h_dual(const float* att, const float* x, const float* h
     if (n_nodes == 0) return hipSuccess;
     if ((size_t)n_nodes * PROW * sizeof(float) >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit byte offsets into P
     constexpr int W = 8;
-#if CBGX_EDGE_SMALL_W4
-    const int wv = n_nodes <= EDGE_W4_MAX_NODES ? 4 : W;      // small input: one wave per SIMD
-#else
-    constexpr int wv = W;
-#endif
-    int grid = (n_nodes + wv - 1) / wv + 1;     // + 1: each role rounds its list up to whole workgroups
+    int grid = (n_nodes + EDGE_MIN_WAVES - 1) / EDGE_MIN_WAVES + 1;     // + 1: each role rounds its list up to whole workgroups
     if (grid > 256) grid = 256;                 // persistent: one workgroup per CU (a multiple of 8 -> XCD-aware partition per role)
     const int wg_limit = g_edge_wg_limit.load(std::memory_order_relaxed);
     if (wg_limit >= 8 && grid > wg_limit) grid = wg_limit & ~7;
     if (grid < 2) grid = 2;                     // one workgroup per role at least
     profile_mark_begin(full_layer ? K_EDGE_X2H : K_EDGE_X2H_LISTED, s);
-#if CBGX_EDGE_DYN
-    int* const ctr_slot = take_ctr_slot();
-#endif
-#if CBGX_EDGE_SMALL_W4
-    if (wv == 4) {
-        if (full_layer)
-            hipLaunchKernelGGL((edge_x2h_dual_kernel<4, true>), dim3(grid), dim3(256), 0, s, att, x, h, P, Qt, qbuf, nbr, deg, lig, gen,
-                               e_w, n_nodes, out, list_pp, count_pp, list_gen, count_gen CBGX_DYN_ARG(ctr_slot));
-        else
-            hipLaunchKernelGGL((edge_x2h_dual_kernel<4, false>), dim3(grid), dim3(256), 0, s, att, x, h, P, Qt, qbuf, nbr, deg, lig, gen,
-                               e_w, n_nodes, out, list_pp, count_pp, list_gen, count_gen CBGX_DYN_ARG(ctr_slot));
-        profile_mark_end(s);
-        return hipGetLastError();
-    }
-#endif
     if (full_layer)
         hipLaunchKernelGGL((edge_x2h_dual_kernel<W, true>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qt, qbuf, nbr, deg, lig, gen,
-                           e_w, n_nodes, out, list_pp, count_pp, list_gen, count_gen CBGX_DYN_ARG(ctr_slot));
+                           e_w, n_nodes, out, list_pp, count_pp, list_gen, count_gen);
     else
         hipLaunchKernelGGL((edge_x2h_dual_kernel<W, false>), dim3(grid), dim3(W * 64), 0, s, att, x, h, P, Qt, qbuf, nbr, deg, lig, gen,
-                           e_w, n_nodes, out, list_pp, count_pp, list_gen, count_gen CBGX_DYN_ARG(ctr_slot));
+                           e_w, n_nodes, out, list_pp, count_pp, list_gen, count_gen);
     profile_mark_end(s);
     return hipGetLastError();
 }

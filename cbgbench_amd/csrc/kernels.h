@@ -95,13 +95,31 @@ hipError_t launch_mark_nbr(const int* list, const int* count, int n_upper, const
 hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig, int n_nodes, float* P, float* qbuf,
                             float* Qt, const int* act, const int* act_count, const int* src, const int* src_count,
                             hipStream_t s, bool large_lists = false, const int* fold = nullptr, const int* fold_count = nullptr);
+// the fused node stage (node_stage_kernel, inputs of <= NODE_STAGE_MAX_ROWS rows) as a list of jobs on the same input features:
+// blockIdx.y = job.  `rows` NULL: all n_nodes rows.  `chunk_mask`: 64-column chunks of the projection to produce (CHUNKS_*);
+// `proj_only`: phase 1 only (the PS columns of a block's source rows).
+struct NodeStageJob {
+    const float* att;
+    float *P, *q, *Qt;
+    const int *rows, *n_rows;
+    unsigned chunk_mask;
+    int proj_only;
+};
+constexpr int NS_JOBS_MAX = 4;
+struct NodeStageJobs { NodeStageJob j[NS_JOBS_MAX]; int n; };
+constexpr int NODE_STAGE_MAX_ROWS = 8192;   // up to here the latency-built fused kernel replaces the three-kernel chain
+// the jobs of one attention block's node stage appended to `jobs` (same selection as launch_node_mfma's fused path): with a
+// destination list two jobs (own columns on `act`, PS columns on `src` -- all rows when src is NULL), without one job on all rows
+bool add_node_stage_jobs(NodeStageJobs& jobs, const float* att, float* P, float* qbuf, float* Qt, const int* act,
+                         const int* act_count, const int* src, const int* src_count);
+hipError_t launch_node_stage_jobs(const NodeStageJobs& jobs, const float* h, const uint8_t* lig, int n_nodes, hipStream_t s);
 // all node lists of a forward call in four launches (node_mfma.hip): three level kernels over flags + one multi-job compaction
 struct GraphFlags {
     const uint8_t *gen, *lig;
     const uint8_t* D1;            // input of the cached levels (may alias d1)
     uint8_t *d1, *a1, *a2, *a3, *D2, *S1, *S2;
 };
-constexpr int LIST_JOBS_MAX = 16;
+constexpr int LIST_JOBS_MAX = 20;      // (a cached + pruned + dual call uses 16)
 struct ListJobs {
     const uint8_t* flag[LIST_JOBS_MAX];      // member if flag != 0 (NULL: every node) ...
     const uint8_t* flag2[LIST_JOBS_MAX];     // ... and (flag2 != 0) == want2 when flag2 is given
@@ -123,9 +141,6 @@ hipError_t launch_edge_mfma(bool x2h, const float* att, const float* x, const fl
                             const float* Qt, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                             const uint8_t* gen, const float* e_w, int n_nodes, float* out, float* dx_out,
                             const int* act, const int* act_count, hipStream_t s);
-// builds with -DCBGX_EDGE_DYN (an untested variant, edge_mfma.hip): the calling thread's pool of ZEROED counter slots, 16 ints per
-// edge launch, consumed by the launchers below in call order; (nullptr, 0) ends it.  A no-op in the product build.
-void edge_set_work_counters(int* base, int slots);
 hipError_t launch_edge_x2h_dual(const float* att, const float* x, const float* h, const float* P, const float* Qt,
                                 const float* qbuf, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                                 const uint8_t* gen, const float* e_w, int n_nodes, float* out, const int* list_pp,

@@ -449,21 +449,28 @@ __global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 constexpr int NS_TPITCH = H + 4;   // LDS tile row pitch (floats)
 
-// Two jobs in one launch (gridDim.y == 2, the h2x blocks): y = 0 the full stage on the destination list `rows` with `chunk_mask`,
-// y = 1 the projection only (phase 1) on the SOURCE list `rows2` with `chunk_mask2` (the PS columns of every node that can be a
-// neighbour of a destination) -- one launch instead of node_proj_kernel + node_stage_kernel per h2x block: 9 fewer dependent
-// launches per denoising step, which is what small batches are bound by.
-__global__ __launch_bounds__(1024) void node_stage_kernel(const float* __restrict__ att, const float* __restrict__ h,
-                                                          const uint8_t* __restrict__ lig, float* __restrict__ P,
-                                                          float* __restrict__ qout, float* __restrict__ Qt, int n_nodes,
-                                                          const int* __restrict__ rows, const int* __restrict__ n_rows_ptr,
-                                                          unsigned chunk_mask, const int* __restrict__ rows2,
-                                                          const int* __restrict__ n_rows2_ptr, unsigned chunk_mask2) {
+// Several jobs in one launch (blockIdx.y = job, kernels.h NodeStageJobs): every job is the stage -- or, `proj_only`, just its phase 1
+// -- of one attention block on one row list with one column-chunk mask, all on the same input features `h`:
+//   an h2x block        the full stage on the movable rows (own columns) + the PS columns of the rows that can be their neighbours
+//   an x2h block        the full stage on all rows, or (cached / pruned layers) on the destination list + PS on the source list
+//   a small input's layer   BOTH: the h2x block of layer l and the x2h block of layer l + 1 read the same h_{l+1}, so their node
+//                       stages are one launch (round 5) -- until then the second ran on an auxiliary stream next to the first, and
+//                       the fork / join events cost the caller's queue ~7 us each, twice per layer (profiles/step_timeline_r05a_*)
+// A launch is bound by its longest job; small batches are bound by launch boundaries, which is what this removes.
+__global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, const float* __restrict__ h,
+                                                          const uint8_t* __restrict__ lig, int n_nodes) {
     __shared__ __attribute__((aligned(16))) float qh[16][NS_TPITCH];
     __shared__ __attribute__((aligned(16))) float qt[16][NS_TPITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, q = lane >> 4;
-    const bool proj_only = blockIdx.y == 1;        // workgroup-uniform
-    if (proj_only) { rows = rows2; n_rows_ptr = n_rows2_ptr; chunk_mask = chunk_mask2; }
+    const NodeStageJob& jb = jobs.j[blockIdx.y];       // kernel arguments: scalar loads
+    const float* __restrict__ att = jb.att;
+    float* __restrict__ P = jb.P;
+    float* __restrict__ qout = jb.q;
+    float* __restrict__ Qt = jb.Qt;
+    const int* __restrict__ rows = jb.rows;
+    const int* __restrict__ n_rows_ptr = jb.n_rows;
+    const unsigned chunk_mask = jb.chunk_mask;
+    const bool proj_only = jb.proj_only != 0;        // workgroup-uniform
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
     const int n_tiles = (n_rows + 15) / 16;
     for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
@@ -632,9 +639,32 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const float* __restric
     const int n_tiles = (M + 63) / 64;
     if ((int)blockIdx.x >= n_tiles) return;
     const int npad = (nout + 15) & ~15;
-    for (int t = tid; t < H * npad; t += 256) {
-        const int k = t / npad, col = t - k * npad;
-        lds[t] = col < nout ? Wt[(size_t)k * nout + col] : 0.f;
+    // LDS fill with every load of a pass in flight before the first store: the plain loop compiled to load -> wait -> ds_write per
+    // element, 64 dependent L2 round trips for the [128][128] matrix -- 46 us for the classifier's first Linear at ONE graph
+    // (profiles/step_timeline_r05a_p1s1_ov1.json), more than any edge launch of that step
+    if (npad == nout && (nout & 3) == 0) {
+        const floatx4* src = reinterpret_cast<const floatx4*>(Wt);
+        floatx4* dst = reinterpret_cast<floatx4*>(lds);
+        const int n4 = H * npad / 4;                 // <= 4096: 16 float4 per thread
+        floatx4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int t = tid + 256 * u; v[u] = src[t < n4 ? t : n4 - 1]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int t = tid + 256 * u; if (t < n4) dst[t] = v[u]; }
+    } else {
+        for (int t0 = 0; t0 < H * npad; t0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + tid + 256 * u, k = t / npad, col = t - k * npad;
+                const float w = Wt[min(k, H - 1) * nout + min(col, nout - 1)];     // unconditional: a predicated load is a branch + wait
+                v[u] = (t < H * npad && col < nout) ? w : 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int t = t0 + tid + 256 * u; if (t < H * npad) lds[t] = v[u]; }
+        }
     }
     __syncthreads();
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -1042,7 +1072,23 @@ constexpr unsigned CHUNKS_OWN = 0x30fu;   // PDk | PDv | qh: what the destinatio
 // `act` / `act_count` (optional): only the listed destination nodes will be processed by the edge kernel (h2x: nodes
 // that can move; x2h in the last layers: nodes whose features can still reach an output).  `src` / `src_count`
 // (optional): the nodes that can be *sources* of those destinations; without it PS is produced for every node.
-constexpr int NODE_STAGE_MAX_ROWS = 8192;   // up to here the latency-built fused kernel replaces the three-kernel chain
+
+bool add_node_stage_jobs(NodeStageJobs& jobs, const float* att, float* P, float* qbuf, float* Qt, const int* act,
+                         const int* act_count, const int* src, const int* src_count) {
+    if (jobs.n + (act ? 2 : 1) > NS_JOBS_MAX) return false;
+    jobs.j[jobs.n++] = NodeStageJob{att, P, qbuf, Qt, act, act_count, act ? CHUNKS_OWN : CHUNKS_ALL, 0};
+    if (act) jobs.j[jobs.n++] = NodeStageJob{att, P, qbuf, Qt, src, src_count, CHUNKS_PS, 1};
+    return true;
+}
+
+hipError_t launch_node_stage_jobs(const NodeStageJobs& jobs, const float* h, const uint8_t* lig, int n_nodes, hipStream_t s) {
+    if (n_nodes == 0 || jobs.n == 0) return hipSuccess;
+    if (n_nodes > NODE_STAGE_MAX_ROWS || jobs.n > NS_JOBS_MAX) return hipErrorInvalidValue;
+    profile_mark_begin(K_NODE_QUERY, s);
+    hipLaunchKernelGGL(node_stage_kernel, dim3(min((n_nodes + 15) / 16, 512), jobs.n), dim3(1024), 0, s, jobs, h, lig, n_nodes);
+    profile_mark_end(s);
+    return hipGetLastError();
+}
 
 // `fold` / `fold_count` (optional, x2h blocks of the inference path): the rows whose folded query Qt the edge stage will read -- the
 // GENERAL list of the layer; protein-only destinations fold in registers (edge_mfma.hip) and only need q.  Without it Qt is
@@ -1096,8 +1142,10 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
     if (e != hipSuccess) return e;
     profile_mark_begin(K_NODE_QUERY, s);
     if (fused) {
-        hipLaunchKernelGGL(node_stage_kernel, dim3(min((n_nodes + 15) / 16, 512), two_jobs ? 2 : 1), dim3(1024), 0, s, att, h, lig, P,
-                           qbuf, Qt, n_nodes, act, act_count, act ? CHUNKS_OWN : CHUNKS_ALL, src, src_count, CHUNKS_PS);
+        NodeStageJobs jobs;
+        jobs.n = 0;
+        add_node_stage_jobs(jobs, att, P, qbuf, Qt, act, act_count, src, src_count);
+        hipLaunchKernelGGL(node_stage_kernel, dim3(min((n_nodes + 15) / 16, 512), jobs.n), dim3(1024), 0, s, jobs, h, lig, n_nodes);
     } else {
         hipLaunchKernelGGL(node_qmlp_kernel, dim3(grid, small ? 2 : 1), dim3(256), 0, s, att, P, qbuf, n_nodes, act, act_count);
         if (fold)    // heads spread over four workgroups per row tile: the list is a fraction of the nodes, of unknown length

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void train_noise_kernel(
     v_t[a] = vn;
 }
 
-// LDS: s_pos [B], s_typ [B], cnt [B], then one int (largest masked graph id)
+// LDS: s_pos [B], s_typ [B], cnt [B], one int (largest masked graph id), the block reduction [2][16], one int (bad graph id seen)
 template <int LC, int THREADS>
 __global__ __launch_bounds__(THREADS) void train_loss_kernel(
     const float* __restrict__ x_out, const float* __restrict__ logits, const int64_t* __restrict__ lig_rows,
@@ -77,15 +77,21 @@ __global__ __launch_bounds__(THREADS) void train_loss_kernel(
     float* cnt = lds + 2 * B;
     int* top = reinterpret_cast<int*>(lds + 3 * B);
     float* red = lds + 3 * B + 1;       // [2][16] block reduction
+    int* bad = reinterpret_cast<int*>(lds + 3 * B + 1 + 32);      // an atom's graph id was outside [0, B)
     const int tid = threadIdx.x;
     for (int b = tid; b < 3 * B; b += blockDim.x) lds[b] = 0.f;
-    if (tid == 0) *top = 0;
+    if (tid == 0) { *top = 0; *bad = 0; }
     __syncthreads();
     for (int a = tid; a < n_lig; a += blockDim.x) {
         const int row = (int)lig_rows[a];
-        const int b = (int)batch[a];
+        // a malformed batch (num_graphs smaller than the largest graph id + 1) must not write outside the per-graph sums: such an
+        // atom is skipped and both losses come back NaN (the tensor path raises an index error there)
+        const int b_raw = (int)batch[a];
+        const bool in_range = b_raw >= 0 && b_raw < B;
+        if (!in_range) *bad = 1;
+        const int b = in_range ? b_raw : 0;
         const int tb = (int)t[b];
-        const bool g = gen[a] != 0;
+        const bool g = gen[a] != 0 && in_range;
         // ---- positions: mse = sum_k (x_pred - x0)^2, d mse / d x_pred = 2 (x_pred - x0)
         float mse = 0.f;
 #pragma unroll
@@ -203,13 +209,20 @@ __global__ __launch_bounds__(THREADS) void train_loss_kernel(
     if (tid == 0) {
         float sp = 0.f, st = 0.f;
         for (int w = 0; w < nw; ++w) { sp += red[w]; st += red[16 + w]; }
-        losses[0] = sp / n_eff;
-        losses[1] = st / n_eff;
+        // no generated atom at all: the mean over an empty set of graphs -- NaN, as the reference's scatter_mean of an empty
+        // selection gives (diffusion_scheduler.py:199) -- not the 0 that n_eff = 1 would produce
+        float any = 0.f;
+        for (int b = 0; b < B; ++b) any += cnt[b];
+        const bool undefined = *bad != 0 || any == 0.f;
+        losses[0] = undefined ? __builtin_nanf("") : sp / n_eff;
+        losses[1] = undefined ? __builtin_nanf("") : st / n_eff;
     }
     // per-atom gradients get the weight of their atom in the loss: gen / (max(cnt_b, 1) n_eff)
     for (int a = tid; a < n_lig; a += blockDim.x) {       // (each thread revisits the atoms it wrote)
-        const int b = (int)batch[a];
-        const float wgt = gen[a] ? 1.f / (fmaxf(cnt[b], 1.f) * n_eff) : 0.f;
+        const int b_raw = (int)batch[a];
+        const bool in_range = b_raw >= 0 && b_raw < B;
+        const int b = in_range ? b_raw : 0;
+        const float wgt = (gen[a] && in_range) ? 1.f / (fmaxf(cnt[b], 1.f) * n_eff) : 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) gpos[3 * a + k] *= wgt;
         for (int k = 0; k < C; ++k) gz[(size_t)a * C + k] *= wgt;
@@ -249,7 +262,7 @@ hipError_t launch_train_loss(const float* x_out, const float* logits, const int6
                              const int64_t* v0, const int64_t* vt, const int64_t* t, const int64_t* batch, const uint8_t* gen,
                              int n_lig, int B, int C, const float* const* tables, float log_c, float* losses, float* x_pred,
                              float* c_pred, float* gpos, float* gz, hipStream_t s) {
-    const size_t lds = ((size_t)3 * B + 1 + 32) * sizeof(float);
+    const size_t lds = ((size_t)3 * B + 1 + 32 + 1) * sizeof(float);
     // up to 16 classes (every shipped config): 16-wide class loops leave room for 512 threads, one or two atoms each at a
     // training batch's few hundred ligand atoms; up to 32 classes: 256 threads
     if (C <= 16)

@@ -441,7 +441,9 @@ __global__ __launch_bounds__(H) void ssp_backward_rows_kernel(const float* __res
 
 // classifier.2 on a row list: dW1[c][k] = sum over the listed rows i of dlogits[i][c] act[i][k]; one workgroup per class c, thread =
 // (k, row group g of 8): group g walks the rows g, g + 8, ... four at a time (a single chain of ~800 dependent row gathers took
-// 92 us), the eight partial sums are added in group order through LDS (deterministic, no slabs)
+// 92 us), the eight partial sums are added in group order through LDS (no atomics, no slabs: deterministic for a given row list --
+// the list itself is compacted with atomics, build_active_kernel, so its order, and with it the last bits of these sums, can differ
+// from run to run)
 constexpr int CLS_GROUPS = 8;
 __global__ __launch_bounds__(H * CLS_GROUPS) void cls_w1_grad_rows_kernel(const float* __restrict__ dlogits, int C,
                                                                           const float* __restrict__ act,

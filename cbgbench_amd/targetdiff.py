@@ -617,6 +617,23 @@ class TargetDiff(BatchesInFlight, nn.Module):
             st["traj_c"][t_idx] = st["c_lig"]
         return st
 
+    NOISE_CHUNK = 16
+
+    def _step_noise(self, st, n_lig, C, dev):
+        """(eps [n_lig,3] ~ N(0, I), u [n_lig,C] ~ U(0, 1)) of one step.  The reference draws randn_like(x_lig) then
+        rand_like(log-probs) in every step (targetdiff.py:168-175 -> diffusion_scheduler.py:163, categorical.py:27); the same
+        two generators are drawn here for NOISE_CHUNK steps at a time and handed out step by step: two launches per chunk
+        instead of two per step (10 us of a 900 us one-graph step).  Fresh numbers every step, the same distributions; the order
+        in which the global generator is consumed differs from per-step draws (tests replay noise through ``noise=``)."""
+        q = st.get("_noise_q")
+        if q is None or q[2] >= q[0].shape[0] or q[0].shape[1] != n_lig:
+            q = [torch.randn(self.NOISE_CHUNK, n_lig, 3, dtype=torch.float32, device=dev),
+                 torch.rand(self.NOISE_CHUNK, n_lig, C, dtype=torch.float32, device=dev), 0]
+            st["_noise_q"] = q
+        k = q[2]
+        q[2] = k + 1
+        return q[0][k], q[1][k]
+
     def _denoise_step_native(self, st, t_idx, noise):
         lib = _native.lib()
         dev = st["x"].device
@@ -634,9 +651,8 @@ class TargetDiff(BatchesInFlight, nn.Module):
                                       static_h=st["static_h"])
         if noise is not None:
             eps, u = noise[0].float().contiguous(), noise[1].float().contiguous()
-        else:   # same draw order as the reference: randn_like(x_lig) then rand_like(log-probs)
-            eps = torch.randn(n_lig, 3, dtype=torch.float32, device=dev)
-            u = torch.rand(n_lig, C, dtype=torch.float32, device=dev)
+        else:
+            eps, u = self._step_noise(st, n_lig, C, dev)
         if st["traj_x"] is not None:
             x_next, c_next = st["traj_x"][t_idx], st["traj_c"][t_idx]
         else:

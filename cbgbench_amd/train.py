@@ -256,7 +256,7 @@ def validate(model, batches, loss_weights=None, evaluator=None):
     batch's ``results`` are averaged and all-reduced the same way; the call then returns ``(avg_loss, {metric: value})``."""
     model.eval()
     names = sorted(evaluator.evaluators) if evaluator is not None and len(evaluator) else []
-    acc = [0.0] * (2 + len(names))          # [sum loss * B, sum B, sum metric_k * B ...]
+    acc = [0.0] * (2 + 2 * len(names))      # [sum loss * B, sum B, (sum metric_k * B, sum B over the batches where it is defined) ...]
     with torch.no_grad():
         for batch in batches:
             loss_dict, results = model(batch)
@@ -270,7 +270,9 @@ def validate(model, batches, loss_weights=None, evaluator=None):
                 md = evaluator(results)
                 for k, nm in enumerate(names):
                     v = float(md[nm])
-                    acc[2 + k] += (v if v == v else 0.0) * B          # an undefined metric (no masked atom) counts as 0
+                    if v == v:      # an undefined metric (NaN: a batch without a masked atom) is left out of ITS average -- value
+                        acc[2 + 2 * k] += v * B         # and weight -- instead of entering as 0 with full weight
+                        acc[3 + 2 * k] += B
     val = torch.tensor(acc, dtype=torch.float64)
     if dist.is_available() and dist.is_initialized():
         if dist.get_backend() != "gloo":
@@ -281,4 +283,6 @@ def validate(model, batches, loss_weights=None, evaluator=None):
     avg = float(val[0] / n)
     if evaluator is None:
         return avg
-    return avg, {nm: float(val[2 + k] / n) for k, nm in enumerate(names)}
+    # a metric that was defined on no batch at all is NaN (the reference's accumulator would propagate the NaN too)
+    return avg, {nm: (float(val[2 + 2 * k] / val[3 + 2 * k]) if float(val[3 + 2 * k]) > 0 else float("nan"))
+                 for k, nm in enumerate(names)}

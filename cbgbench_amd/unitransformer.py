@@ -132,8 +132,9 @@ class _DenoiserFunction(torch.autograd.Function):
             # the checked views and their pointer array are kept from step to step (FlatGradients' views never change): the
             # device idles while the host prepares this call
             cache = getattr(module, "_direct_cache", None)
-            if cache is not None and len(cache[0]) == len(views) and all(a is b for a, b in zip(cache[0], views)):
-                arr = cache[1]
+            if (cache is not None and len(cache[0]) == len(views) and all(a is b for a, b in zip(cache[0], views))
+                    and cache[2] == (views[0].data_ptr(), views[-1].data_ptr())):     # (.to() / .float() re-point .grad.data
+                arr = cache[1]                                                        #  behind the same objects: ADVICE r4)
             elif any(v is None or not v.is_contiguous() or v.dtype != torch.float32 or v.device != device for v in views):
                 direct = False
         if not direct:
@@ -143,7 +144,7 @@ class _DenoiserFunction(torch.autograd.Function):
         if arr is None:
             arr = (ctypes.c_void_p * len(views))(*[v.data_ptr() for v in views])
             if direct:
-                module._direct_cache = (views, arr)
+                module._direct_cache = (views, arr, (views[0].data_ptr(), views[-1].data_ptr()))
         need_h = ctx.needs_input_grad[3]
         gh_in = torch.empty(N, module.hidden_dim, dtype=torch.float32, device=device) if need_h else None
         ws = module.train_workspace(N, device)
@@ -225,6 +226,8 @@ class UniTransformer(nn.Module):
     # ---- weights -----------------------------------------------------------------------------
     def _apply(self, fn, *args, **kwargs):
         self._ordered = None        # .to() / .cuda() / .float() may replace Parameter objects
+        self._direct_cache = None   # ... and re-point param.grad.data behind the same tensor objects
+        self.__dict__.pop("_flag_cache", None)
         return super()._apply(fn, *args, **kwargs)
 
     def _ordered_params(self):
@@ -352,6 +355,25 @@ class UniTransformer(nn.Module):
         r32sq[rec_rows] = r32
         return (out[0], out[1], nbr.contiguous(), deg, ew, r32sq)
 
+    def _as_u8(self, flag):
+        """the uint8 copy of a boolean flag tensor that libcbgx reads.  A sampler hands the SAME two flag tensors to all T denoiser
+        calls of a run; converting them each time was two elementwise launches per step (14 us of a 900 us one-graph step,
+        profiles/step_timeline_r05a_p1s1_ov1.json).  The copy is cached per tensor object and re-made when the tensor was
+        written in place (version counter) -- never while a stream is being captured (a capture's allocations belong to the graph)."""
+        if flag.dtype == torch.uint8:
+            return flag.contiguous()
+        if flag.is_cuda and torch.cuda.is_current_stream_capturing():
+            return flag.to(torch.uint8).contiguous()
+        cache = self.__dict__.setdefault("_flag_cache", {})
+        hit = cache.get(id(flag))
+        if hit is not None and hit[0] is flag and hit[1] == flag._version and hit[2].device == flag.device:
+            return hit[2]
+        u8 = flag.to(torch.uint8).contiguous()
+        if len(cache) >= 64:
+            cache.pop(next(iter(cache)))
+        cache[id(flag)] = (flag, flag._version, u8)      # holds `flag`: its id cannot be reused while the entry lives
+        return u8
+
     def forward(self, x, h, batch_idx, lig_flag, gen_flag, graph_ptr=None, need_h=True, static_h=None,
                 ligand_outputs_only=False, workspace=None, h_on_sources=False):
         """Same contract as the reference (unitransformer.py:102-123): returns (x', h', logits).
@@ -377,8 +399,7 @@ class UniTransformer(nn.Module):
         if graph_ptr is None:
             graph_ptr = graph_ptr_from_batch(batch_idx)
         B = graph_ptr.numel() - 1
-        lig = lig_flag.to(torch.uint8).contiguous()
-        gen = gen_flag.to(torch.uint8).contiguous()
+        lig, gen = self._as_u8(lig_flag), self._as_u8(gen_flag)
         if torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.parameters())):
             # training: taped forward + hand-written backward behind torch.autograd
             return _DenoiserFunction.apply(self, ligand_outputs_only, x.detach().to(torch.float32).contiguous(),

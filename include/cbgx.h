@@ -52,8 +52,11 @@ extern "C" {
 #endif
 
 /* 2: the packed-weight layout carries the power-of-two scales of the split-f16 tables (range-safe arithmetic, below); a blob
- * packed by a version-1 library is not understood by version 2 and vice versa -- re-pack with the library that consumes it. */
-#define CBGX_ABI_VERSION 3
+ * packed by a version-1 library is not understood by version 2 and vice versa -- re-pack with the library that consumes it.
+ * 4 (round 5): cbgx_unitransformer_backward with grad_h_out == NULL also prunes the classifier head's backward to the ligand rows
+ * (round 4 changed that without a bump), the cbgx_targetdiff_train_noise / _loss / _loss_backward exports exist, and the workspace
+ * layout of cbgx_unitransformer_forward changed: a caller built against version 3 must not load this library. */
+#define CBGX_ABI_VERSION 4
 
 #define CBGX_OK 0
 #define CBGX_E_INVALID (-1)   /* bad argument (shape, NULL pointer, unsupported hyper-parameter) */

@@ -84,61 +84,99 @@ def test_config5_shape_runs_seven_static_rounds_and_hands_out_the_rest():
     assert per_wave_static == 7.0 and len(dyn) == 16506 - 7 * 2048
 
 
-# ---- the forward edge kernels' variant schedule (edge_mfma.hip, -DCBGX_EDGE_DYN=d: untested on the GPU, off in every build) --------
-def forward_schedule(n_items, n_wg, D, waves=8, with_counters=True):
-    """edge_body's loop with CBGX_EDGE_DYN = D restated: the first max(full - (D - 1), 1) rounds of an XCD's range static, the rest
-    claimed one node ahead through the XCD's counter.  -> processed items in order (one interleaving)"""
-    ctr = [0] * 8
-    waves_state = []
+# ---- the forward edge kernels' schedule (edge_mfma.hip: edge_active_waves + the XCD-aware partition of edge_body, and the role split
+# of edge_x2h_dual_kernel), restated: every item exactly once whatever the list length, and short lists at one wave per SIMD ------------
+MIN_WAVES = 4
+
+
+def active_waves(n_items, n_wg, waves=8):
+    per_wg = -(-n_items // max(n_wg, 1))
+    return min(waves, max(min(MIN_WAVES, waves), per_wg))
+
+
+def forward_schedule(n_items, n_wg, waves=8):
+    """-> {(wg, wave): [items in processing order]} of edge_body"""
+    wv = active_waves(n_items, n_wg, waves)
+    out = {}
     for wg in range(n_wg):
         if n_wg % 8 == 0:
-            per_xcd = (((n_items + 7) >> 3) + waves - 1) // waves * waves
-            first = (wg & 7) * per_xcd + (wg >> 3) * waves
+            per_xcd = (((n_items + 7) >> 3) + wv - 1) // wv * wv
+            first = (wg & 7) * per_xcd + (wg >> 3) * wv
             if first >= min(n_items, ((wg & 7) + 1) * per_xcd):
                 continue
-        elif wg * waves >= n_items:
+        elif wg * wv >= n_items:
             continue
         for wave in range(waves):
+            if wave >= wv:
+                continue
             if n_wg % 8 == 0:
                 xcd, slot = wg & 7, wg >> 3
-                i_begin = xcd * per_xcd + slot * waves + wave
-                i_end = min(n_items, (xcd + 1) * per_xcd)
-                i_step = (n_wg >> 3) * waves
-                base, c = min(n_items, xcd * per_xcd), xcd
+                i_begin, i_end, i_step = xcd * per_xcd + slot * wv + wave, min(n_items, (xcd + 1) * per_xcd), (n_wg >> 3) * wv
             else:
-                i_begin, i_end, i_step, base, c = wg * waves + wave, n_items, n_wg * waves, 0, 0
-            if i_begin >= i_end:
-                continue
-            full = (i_end - base) // i_step
-            static = max(full - (D - 1), 1)
-            tail = base + static * i_step
-            on = with_counters and full >= 1 and tail < i_end
-            waves_state.append(dict(k=i_begin, end=i_end, step=i_step, static=static, tail=tail, on=on, c=c, round=0))
-    done = []
-    active = waves_state
-    while active:
-        nxt = []
-        for w in active:
-            assert 0 <= w["k"] < n_items
-            done.append(w["k"])
-            k_next = w["k"] + w["step"]
-            if not w["on"]:
-                more = k_next < w["end"]
-            elif w["round"] + 1 < w["static"]:
-                more = True
-            else:
-                k_next = w["tail"] + ctr[w["c"]]; ctr[w["c"]] += 1
-                more = k_next < w["end"]
-            if more:
-                w["k"] = k_next; w["round"] += 1
-                nxt.append(w)
-        active = nxt
-    return done
+                i_begin, i_end, i_step = wg * wv + wave, n_items, n_wg * wv
+            if i_begin < i_end:
+                out[(wg, wave)] = list(range(i_begin, i_end, i_step))
+    return out
 
 
-@pytest.mark.parametrize("D", [1, 2, 3])
-@pytest.mark.parametrize("n_wg", [1, 2, 9, 56, 57, 64, 176, 256])
-def test_forward_variant_schedule_covers_every_item_once(n_wg, D):
-    for n in [1, 5, 8, 9, 445, 1230, 3170, 4404, 16506, 99543]:
-        assert sorted(forward_schedule(n, n_wg, D)) == list(range(n)), (n, n_wg, D)
-        assert sorted(forward_schedule(n, n_wg, D, with_counters=False)) == list(range(n))      # no counters: the static schedule
+def launcher_grid(n_nodes, dual=False):
+    grid = min(256, -(-n_nodes // MIN_WAVES) + (1 if dual else 0))
+    if dual:
+        return max(grid, 2)
+    return grid & ~7 if grid >= 64 else grid
+
+
+@pytest.mark.parametrize("n_wg", [1, 2, 9, 56, 57, 64, 112, 176, 256])
+def test_forward_schedule_covers_every_item_once(n_wg):
+    for n in [1, 5, 8, 9, 25, 250, 445, 1024, 1230, 3170, 4404, 16506, 99543]:
+        sched = forward_schedule(n, n_wg)
+        assert sorted(i for v in sched.values() for i in v) == list(range(n)), (n, n_wg)
+
+
+def test_short_lists_run_one_wave_per_simd():
+    # one graph (445 nodes), the movable atoms of a 10-graph batch (250 of 4450 nodes), a 1-graph h2x block (25 of 445): at most four
+    # waves of a workgroup hold items -- waves 0..3, one per SIMD -- and every wave holds one item
+    for n_items, n_nodes in ((445, 445), (250, 4450), (25, 445), (1000, 173558)):
+        sched = forward_schedule(n_items, launcher_grid(n_nodes))
+        assert max(wave for _, wave in sched) <= 3 and max(len(v) for v in sched.values()) == 1, (n_items, n_nodes)
+    # a long list uses all eight waves of all 256 workgroups, balanced to one item
+    sched = forward_schedule(173558, 256)
+    lens = [len(v) for v in sched.values()]
+    assert len(sched) == 2048 and max(lens) - min(lens) <= 1
+    # in between (a cached layer of a 10-graph batch: ~1500 of 4450 nodes): six waves per workgroup, one item each
+    sched = forward_schedule(1500, 256)
+    assert max(wave for _, wave in sched) == 5 and max(len(v) for v in sched.values()) == 1
+
+
+def dual_roles(c_pp, c_gen, n_wg, waves=8, gen_cost=1.15):
+    """edge_x2h_dual_kernel's role split -> (workgroups of the protein-only role, workgroups of the general role)"""
+    wv = active_waves(c_pp + c_gen, n_wg - 1 if n_wg > 1 else 1, waves)
+    need_pp, need_gen = -(-c_pp // wv), -(-c_gen // wv)
+    if c_gen == 0:
+        n_pp = n_wg
+    elif c_pp == 0:
+        n_pp = 0
+    elif need_pp + need_gen <= n_wg:
+        n_pp = need_pp
+    else:
+        share = c_pp / (c_pp + gen_cost * c_gen)
+        unit = 8 if n_wg >= 64 else 1
+        n_pp = int(share * (n_wg // unit) + 0.5) * unit
+        n_pp = max(unit, min(n_wg - unit, n_pp))
+        if n_wg < 2:
+            n_pp = 0
+    return n_pp, n_wg - n_pp
+
+
+def test_dual_roles_cover_both_lists():
+    for c_pp, c_gen in [(320, 125), (0, 445), (445, 0), (3200, 1250), (1, 1), (7, 300), (125000, 48558), (900, 100)]:
+        n_nodes = c_pp + c_gen
+        grid = launcher_grid(n_nodes, dual=True)
+        n_pp, n_gen = dual_roles(c_pp, c_gen, grid)
+        assert n_pp + n_gen == grid and (n_pp > 0 or c_pp == 0) and (n_gen > 0 or c_gen == 0), (c_pp, c_gen, grid)
+        for c, n in ((c_pp, n_pp), (c_gen, n_gen)):
+            if c:
+                sched = forward_schedule(c, n)
+                assert sorted(i for v in sched.values() for i in v) == list(range(c))
+                if n_nodes <= 1000:          # small input: one node per wave, one wave per SIMD, in both roles
+                    assert max(len(v) for v in sched.values()) == 1 and max(wave for _, wave in sched) <= 3, (c_pp, c_gen)
