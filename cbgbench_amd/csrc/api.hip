@@ -547,9 +547,11 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
     const bool dual = g_edge_impl != 1;
     GraphFlags gf{gen_flag, lig_flag, graph_cached ? w.fD1 : w.d1flag, w.d1flag, w.fa1, w.fa2, w.fa3, w.fD2, w.fS1, w.fS2};
     if (graph_cached) {
-        HIP_TRY(launch_lig_proximity(x, graph_ptr, n_graphs, lig_flag, static_r32sq, n_nodes, w.fD1, s));   // D1
-        HIP_TRY(launch_build_active(w.fD1, n_nodes, w.fw_list[0], w.fw_count, s, true));
-        HIP_TRY(launch_restore_graph(static_nbr, static_deg, static_ew, n_nodes, w.nbr, w.deg, w.e_w, s));
+        // D1 flags + list, the pocket's own graph and the cached features of layers 0 / 1 (into hbuf[0] / hbuf[1]: num_layers >= 4,
+        // so neither is the caller's h_out, and nothing else touches them before their layer): one launch
+        HIP_TRY(launch_graph_cache_begin(x, graph_ptr, n_graphs, lig_flag, static_r32sq, n_nodes, w.fD1, w.fw_list[0], w.fw_count,
+                                         static_nbr, static_deg, static_ew, w.nbr, w.deg, w.e_w, static_h1, static_h2, w.hbuf[0],
+                                         w.hbuf[1], s));
         HIP_TRY(launch_knn_merge(x, graph_ptr, n_graphs, n_nodes, lig_flag, static_nbr, static_deg, w.nbr, w.deg, s, w.fw_list[0],
                                  w.fw_count));
         HIP_TRY(launch_gate_mfma(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s, w.fw_list[0], w.fw_count));
@@ -557,44 +559,59 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
         HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s));
         HIP_TRY(launch_gate(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s));
     }
-    // every list of the call: three level kernels over the flags (a level reads what the previous one completed), one compaction
-    HIP_TRY(launch_list_level(gf, w.nbr, w.deg, n_nodes, 0, cached, prune, s));
-    if (cached || prune) {
-        HIP_TRY(launch_list_level(gf, w.nbr, w.deg, n_nodes, 1, cached, prune, s));
-        HIP_TRY(launch_list_level(gf, w.nbr, w.deg, n_nodes, 2, cached, prune, s));
-    }
+    // every list of the call.  Large inputs: three level kernels over the flags (a level reads what the previous one completed) and one
+    // compaction; inputs of <= GRAPH_LISTS_MAX_NODES nodes: one launch, a workgroup per graph with the graph's flags in LDS (round 5:
+    // the four launches were 20 us of a 600 us one-graph step)
     {
+        const bool per_graph = n_nodes <= GRAPH_LISTS_MAX_NODES && g_edge_impl != 1;
+        const uint8_t* flag_ptr[GF_COUNT] = {gen_flag, lig_flag, gf.D1, w.d1flag, w.fa1, w.fa2, w.fa3, w.fD2, w.fS1, w.fS2};
         ListJobs jobs;
+        GraphListJobs gjobs;
         memset(&jobs, 0, sizeof(jobs));
+        memset(&gjobs, 0, sizeof(gjobs));
         bool jobs_overflow = false;
-        auto add = [&](const uint8_t* f, const uint8_t* f2, int want2, int* list, int* count) {
+        auto add = [&](int f, int f2, int want2, int* list, int* count) {
             if (jobs.n_jobs >= LIST_JOBS_MAX) { jobs_overflow = true; return; }
             const int k = jobs.n_jobs++;
-            jobs.flag[k] = f; jobs.flag2[k] = f2; jobs.want2[k] = want2; jobs.list[k] = list; jobs.count[k] = count;
+            jobs.flag[k] = f == GF_ALL ? nullptr : flag_ptr[f]; jobs.flag2[k] = f2 == GF_ALL ? nullptr : flag_ptr[f2];
+            jobs.want2[k] = want2; jobs.list[k] = list; jobs.count[k] = count;
+            gjobs.flag[k] = (signed char)f; gjobs.flag2[k] = (signed char)f2; gjobs.want2[k] = (signed char)want2;
+            gjobs.list[k] = list; gjobs.count[k] = count;
+            gjobs.n_jobs = jobs.n_jobs;
         };
-        add(gen_flag, nullptr, 0, w.act, w.act_count);
-        add(w.fa1, nullptr, 0, w.rf_list[0], w.rf_count);
+        add(GF_GEN, GF_ALL, 0, w.act, w.act_count);
+        add(GF_a1, GF_ALL, 0, w.rf_list[0], w.rf_count);
         if (prune) {
-            add(w.fa2, nullptr, 0, w.rf_list[1], w.rf_count + 16);
-            add(w.fa3, nullptr, 0, w.rf_list[2], w.rf_count + 32);
+            add(GF_a2, GF_ALL, 0, w.rf_list[1], w.rf_count + 16);
+            add(GF_a3, GF_ALL, 0, w.rf_list[2], w.rf_count + 32);
         }
         if (cached) {
-            if (!graph_cached) add(w.d1flag, nullptr, 0, w.fw_list[0], w.fw_count);
-            add(w.fD2, nullptr, 0, w.fw_list[2], w.fw_count + 32);
-            add(w.fS1, nullptr, 0, w.fw_list[1], w.fw_count + 16);
-            add(w.fS2, nullptr, 0, w.fw_list[3], w.fw_count + 48);
+            if (!graph_cached) add(GF_d1, GF_ALL, 0, w.fw_list[0], w.fw_count);
+            add(GF_D2, GF_ALL, 0, w.fw_list[2], w.fw_count + 32);
+            add(GF_S1, GF_ALL, 0, w.fw_list[1], w.fw_count + 16);
+            add(GF_S2, GF_ALL, 0, w.fw_list[3], w.fw_count + 48);
         }
         if (dual) {
-            auto pair = [&](int set, const uint8_t* f) {
-                add(f, w.d1flag, 1, w.sp_list[set][1], w.sp_count + 32 * set);
-                add(f, w.d1flag, 0, w.sp_list[set][0], w.sp_count + 32 * set + 16);
+            auto pair = [&](int set, int f) {
+                add(f, GF_d1, 1, w.sp_list[set][1], w.sp_count + 32 * set);
+                add(f, GF_d1, 0, w.sp_list[set][0], w.sp_count + 32 * set + 16);
             };
-            pair(0, nullptr);
-            if (cached) pair(1, w.fD2);
-            if (prune) { pair(2, w.fa1); pair(3, w.fa2); }
+            pair(0, GF_ALL);
+            if (cached) pair(1, GF_D2);
+            if (prune) { pair(2, GF_a1); pair(3, GF_a2); }
         }
         if (jobs_overflow) return fail(CBGX_E_INVALID, "forward: more than %d node lists (LIST_JOBS_MAX)", LIST_JOBS_MAX);
-        HIP_TRY(launch_build_lists(jobs, n_nodes, s));
+        if (per_graph) {
+            HIP_TRY(launch_graph_lists(gen_flag, lig_flag, graph_cached ? w.fD1 : nullptr, w.nbr, w.deg, graph_ptr, n_graphs, gjobs,
+                                       cached, prune, w.d1flag, s));
+        } else {
+            HIP_TRY(launch_list_level(gf, w.nbr, w.deg, n_nodes, 0, cached, prune, s));
+            if (cached || prune) {
+                HIP_TRY(launch_list_level(gf, w.nbr, w.deg, n_nodes, 1, cached, prune, s));
+                HIP_TRY(launch_list_level(gf, w.nbr, w.deg, n_nodes, 2, cached, prune, s));
+            }
+            HIP_TRY(launch_build_lists(jobs, n_nodes, s));
+        }
     }
     struct X2HLists { const int *gen, *gen_n, *pp, *pp_n; bool full; };
     auto x2h_lists = [&](int l) {
@@ -642,13 +659,16 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
             layer_lists(0, dst, dst_n, src, src_n);
             NodeStageJobs jobs;
             jobs.n = 0;
-            add_node_stage_jobs(jobs, packed + x2h_off(0), Pset[0], qset[0], Qtset[0], dst, dst_n, src, src_n);
+            // (the general role of a cached layer 0 is the whole D1 list: folded rows for all of it; every other x2h layer's
+            // general role is the d1-flagged part of its destinations)
+            add_node_stage_jobs(jobs, packed + x2h_off(0), Pset[0], qset[0], Qtset[0], dst, dst_n, src, src_n,
+                                cached ? nullptr : w.d1flag);
             HIP_TRY(launch_node_stage_jobs(jobs, h, lig_flag, n_nodes, s));
         }
         for (int l = 0; l < num_layers; ++l) {
             float* hn = (l == num_layers - 1 && h_out) ? h_out : w.hbuf[l & 1];
             float* xn = (l == num_layers - 1) ? x_out : w.xbuf[l & 1];
-            if (cached && l < 2)
+            if (cached && l < 2 && !graph_cached)     // (graph-cached calls: restore_graph_kernel has already placed both)
                 HIP_TRY(hipMemcpyAsync(hn, l == 0 ? static_h1 : static_h2, (size_t)n_nodes * H * sizeof(float),
                                        hipMemcpyDeviceToDevice, s));
             const X2HLists xl = x2h_lists(l);
@@ -661,7 +681,8 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
             if (l + 1 < num_layers) {
                 const int *d2, *d2n, *s2, *s2n;
                 layer_lists(l + 1, d2, d2n, s2, s2n);
-                add_node_stage_jobs(jobs, packed + x2h_off(l + 1), Pset[set ^ 1], qset[set ^ 1], Qtset[set ^ 1], d2, d2n, s2, s2n);
+                add_node_stage_jobs(jobs, packed + x2h_off(l + 1), Pset[set ^ 1], qset[set ^ 1], Qtset[set ^ 1], d2, d2n, s2, s2n,
+                                    w.d1flag);
             }
             HIP_TRY(launch_node_stage_jobs(jobs, hn, lig_flag, n_nodes, s));
             HIP_TRY(launch_edge_mfma(false, packed + h2x_off(l), xc, hn, w.P3, w.Qt3, w.nbr, w.deg, lig_flag, gen_flag, w.e_w,
@@ -682,7 +703,7 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
         float* xn = (l == num_layers - 1) ? x_out : w.xbuf[l & 1];
         const int *dst, *dst_n, *src, *src_n;
         layer_lists(l, dst, dst_n, src, src_n);
-        if (cached && l < 2)
+        if (cached && l < 2 && !graph_cached)
             HIP_TRY(hipMemcpyAsync(hn, l == 0 ? static_h1 : static_h2, (size_t)n_nodes * H * sizeof(float),
                                    hipMemcpyDeviceToDevice, s));
         const X2HLists xl = x2h_lists(l);

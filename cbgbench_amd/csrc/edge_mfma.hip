@@ -38,15 +38,17 @@
 // Waves of a persistent workgroup that take items.  A launch whose item list is short next to the grid (one graph: 445 nodes, an
 // h2x block: the ~25 movable atoms per graph) is ONE node's dependent chain per wave -- 18 - 20 us of a 27 us launch
 // (profiles/probe_r04z2.log) -- and two such chains on one SIMD slow each other down.  So a workgroup puts only as many of its
-// WAVES waves to work as the list needs, but at least CBGX_EDGE_MIN_WAVES = 4 (one per SIMD), and the launchers size the grid for
-// four nodes per workgroup: the other waves help fill the LDS image and leave.  Decided per launch from the DEVICE-side list length,
+// WAVES waves to work as the list needs, but at least CBGX_EDGE_MIN_WAVES = 2 (each on its own SIMD), and the launchers size the grid
+// for that many nodes per workgroup: the other waves help fill the LDS image and leave.  Decided per launch from the DEVICE-side list length,
 // so cached / pruned / listed launches of a large batch get it too (the ~250 movable atoms of a 10-graph batch).  Same arithmetic per
 // node whatever the schedule.  History: round 4 prepared this as a host-side switch (-DCBGX_EDGE_SMALL_W4, 4-wave workgroups for
 // inputs of <= 1016 nodes) next to a dynamic remainder of the persistent loop (-DCBGX_EDGE_DYN); round 5's first GPU call measured
 // both (profiles/small_dyn_r05a.log): 4 waves 1 167 -> 1 328 graph-steps/s at one graph (edge launches 26.8 -> 21.0 us), the dynamic
 // remainder 9 116 -> 8 278 at ten graphs (x2h launch 52.8 -> 71.4 us) and nothing on the headline or the training line -- deleted.
+// Second GPU call (profiles/small_r05b.log, fused node stage in every row): at least 8 / 4 / 2 waves per workgroup = 1 362 / 1 680 /
+// 1 796 graph-steps/s at one graph (x2h launch 26.9 / 20.7 / 17.9 us), 9 773 / 10 647 / 10 924 at ten; the headline does not move.
 #ifndef CBGX_EDGE_MIN_WAVES
-#define CBGX_EDGE_MIN_WAVES 4
+#define CBGX_EDGE_MIN_WAVES 2
 #endif
 
 namespace cbgx {

@@ -363,6 +363,76 @@ __global__ void lig_proximity_kernel(const float* __restrict__ x, const int32_t*
     dirty[i] = near ? 1 : 0;
 }
 
+// lig_proximity + the compaction of its flags into the D1 list + restore_graph_kernel (node_mfma.hip: the pocket's own neighbour
+// lists, degrees, gate values and the cached features of layers 0 / 1 into the call's working arrays) in ONE launch: the head of every
+// graph-cached forward call was these three dependent launches (9 + 5 + 5 us of a 600 us one-graph step).  1024-thread workgroups:
+// the first ceil(n / 1024) of them also flag their nodes and append the flagged ones to `list` with one returning atomic each
+// (*count zero on entry, like build_active_kernel); every workgroup copies its slice.
+__global__ __launch_bounds__(1024) void graph_cache_begin_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ graph_ptr, int n_graphs, const uint8_t* __restrict__ lig,
+    const float* __restrict__ r32sq, int n, uint8_t* __restrict__ dirty, int* __restrict__ list, int* __restrict__ count,
+    const int32_t* __restrict__ s_nbr, const int32_t* __restrict__ s_deg, const float* __restrict__ s_ew,
+    int32_t* __restrict__ nbr, int32_t* __restrict__ deg, float* __restrict__ ew, const float* __restrict__ h1,
+    const float* __restrict__ h2, float* __restrict__ out1, float* __restrict__ out2) {
+    __shared__ int s_cnt[16];
+    __shared__ int s_base;
+    const long t = (long)blockIdx.x * 1024 + threadIdx.x;
+    // ---- copies (independent of everything below) ----
+    if (t < (long)n * (KNN / 4)) {      // one thread per 4 neighbour slots
+        reinterpret_cast<int4*>(nbr)[t] = reinterpret_cast<const int4*>(s_nbr)[t];
+        reinterpret_cast<float4*>(ew)[t] = reinterpret_cast<const float4*>(s_ew)[t];
+        if ((t & (KNN / 4 - 1)) == 0) deg[t / (KNN / 4)] = s_deg[t / (KNN / 4)];
+    }
+    if (t < (long)n * (H / 4)) {        // one thread per 4 features
+        reinterpret_cast<float4*>(out1)[t] = reinterpret_cast<const float4*>(h1)[t];
+        reinterpret_cast<float4*>(out2)[t] = reinterpret_cast<const float4*>(h2)[t];
+    }
+    if ((long)blockIdx.x * 1024 >= n) return;       // workgroup-uniform: no node of its own
+    // ---- proximity flag of node t (lig_proximity_kernel) ----
+    const int i = (int)t;
+    bool a = false;
+    if (i < n) {
+        if (lig[i]) a = true;
+        else {
+            int lo_g = 0, hi_g = n_graphs;
+            while (hi_g - lo_g > 1) {
+                const int mid = (lo_g + hi_g) >> 1;
+                if (graph_ptr[mid] <= i) lo_g = mid; else hi_g = mid;
+            }
+            const int gs = graph_ptr[lo_g], ge = graph_ptr[lo_g + 1];
+            const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
+            const float lim = r32sq[i];
+            for (int j = ge - 1; j >= gs && lig[j]; --j)
+                a |= dist2_exact2(xi, yi, zi, x[3 * j], x[3 * j + 1], x[3 * j + 2]) < lim;
+        }
+        dirty[i] = a ? 1 : 0;
+    }
+    // ---- compaction (build_active_kernel) ----
+    const unsigned long long m = __ballot(a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int c = s_cnt[w]; s_cnt[w] = tot; tot += c; }   // exclusive prefix
+        s_base = tot ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
+    if (a) list[s_base + s_cnt[wave] + __popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+hipError_t launch_graph_cache_begin(const float* x, const int32_t* graph_ptr, int n_graphs, const uint8_t* lig, const float* r32sq,
+                                    int n, uint8_t* dirty, int* list, int* count, const int32_t* s_nbr, const int32_t* s_deg,
+                                    const float* s_ew, int32_t* nbr, int32_t* deg, float* ew, const float* h1, const float* h2,
+                                    float* out1, float* out2, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const long threads = (long)n * (H / 4);
+    hipLaunchKernelGGL(graph_cache_begin_kernel, dim3((unsigned)((threads + 1023) / 1024)), dim3(1024), 0, s, x, graph_ptr, n_graphs,
+                       lig, r32sq, n, dirty, list, count, s_nbr, s_deg, s_ew, nbr, deg, ew, h1, h2, out1, out2);
+    return hipGetLastError();
+}
+
 hipError_t launch_lig_proximity(const float* x, const int32_t* graph_ptr, int n_graphs, const uint8_t* lig,
                                 const float* r32sq, int n_nodes, uint8_t* dirty, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;

@@ -80,6 +80,12 @@ hipError_t launch_gate_mfma(const float* packed, const float* x, const int32_t* 
                             float* e_w, hipStream_t s, const int* rows = nullptr, const int* n_rows = nullptr);
 hipError_t launch_lig_proximity(const float* x, const int32_t* graph_ptr, int n_graphs, const uint8_t* lig,
                                 const float* r32sq, int n_nodes, uint8_t* dirty, hipStream_t s);
+// head of a graph-cached forward call in one launch: proximity flags -> `dirty`, their compaction -> `list` / `count` (zero on
+// entry), the pocket's graph -> nbr / deg / ew, the cached features of layers 0 / 1 -> out1 / out2 (graph_mfma.hip)
+hipError_t launch_graph_cache_begin(const float* x, const int32_t* graph_ptr, int n_graphs, const uint8_t* lig, const float* r32sq,
+                                    int n, uint8_t* dirty, int* list, int* count, const int32_t* s_nbr, const int32_t* s_deg,
+                                    const float* s_ew, int32_t* nbr, int32_t* deg, float* ew, const float* h1, const float* h2,
+                                    float* out1, float* out2, hipStream_t s);
 // MFMA node kernels (node_mfma.hip): P = h Wn + bn, q = MLP tail, Qt = folded query
 hipError_t launch_pack_node_tables(const PackBlocks& pb, hipStream_t s);     // node_mfma.hip part of stage 2
 // counter_zeroed: the caller has already set *count to zero on this stream (cbgx_unitransformer_forward zeroes all its list counters
@@ -104,6 +110,10 @@ struct NodeStageJob {
     const int *rows, *n_rows;
     unsigned chunk_mask;
     int proj_only;
+    // optional: the folded query Qt is produced only for rows with fold_flag[row] != 0 -- the x2h edge stage reads it for
+    // general-role destinations only (the node or a neighbour is a ligand atom: ~28 % of a pocket), protein-only ones fold in
+    // registers (edge_mfma.hip) -- 8 KB of stores per row saved for the others
+    const uint8_t* fold_flag;
 };
 constexpr int NS_JOBS_MAX = 4;
 struct NodeStageJobs { NodeStageJob j[NS_JOBS_MAX]; int n; };
@@ -111,7 +121,7 @@ constexpr int NODE_STAGE_MAX_ROWS = 8192;   // up to here the latency-built fuse
 // the jobs of one attention block's node stage appended to `jobs` (same selection as launch_node_mfma's fused path): with a
 // destination list two jobs (own columns on `act`, PS columns on `src` -- all rows when src is NULL), without one job on all rows
 bool add_node_stage_jobs(NodeStageJobs& jobs, const float* att, float* P, float* qbuf, float* Qt, const int* act,
-                         const int* act_count, const int* src, const int* src_count);
+                         const int* act_count, const int* src, const int* src_count, const uint8_t* fold_flag = nullptr);
 hipError_t launch_node_stage_jobs(const NodeStageJobs& jobs, const float* h, const uint8_t* lig, int n_nodes, hipStream_t s);
 // all node lists of a forward call in four launches (node_mfma.hip): three level kernels over flags + one multi-job compaction
 struct GraphFlags {
@@ -130,9 +140,28 @@ struct ListJobs {
 };
 hipError_t launch_list_level(const GraphFlags& f, const int32_t* nbr, const int32_t* deg, int n, int level, bool cached, bool prune,
                              hipStream_t s);
+// Small inputs (n <= GRAPH_LISTS_MAX_NODES): the three level kernels and the compaction above as ONE launch, one workgroup per graph
+// with the graph's flags in LDS (flags only ever propagate along edges, and edges stay inside a graph).  The jobs name their flags by
+// id instead of by pointer; of the flag arrays in global memory only the three inputs are read and only d1 is written.
+enum GraphFlagId { GF_GEN = 0, GF_LIG, GF_D1IN, GF_d1, GF_a1, GF_a2, GF_a3, GF_D2, GF_S1, GF_S2, GF_COUNT, GF_ALL = -1 };
+constexpr int GRAPH_LISTS_MAX_NODES = 8192;
+struct GraphListJobs {
+    signed char flag[LIST_JOBS_MAX];         // GraphFlagId (GF_ALL: every node) ...
+    signed char flag2[LIST_JOBS_MAX];        // ... and (flag2 != 0) == want2 unless GF_ALL
+    signed char want2[LIST_JOBS_MAX];
+    int* list[LIST_JOBS_MAX];
+    int* count[LIST_JOBS_MAX];
+    int n_jobs;
+};
+// `d1_out` [n]: the d1 flags (the node or one of its neighbours is a ligand atom) are also written to global memory
+hipError_t launch_graph_lists(const uint8_t* gen, const uint8_t* lig, const uint8_t* d1_in, const int32_t* nbr, const int32_t* deg,
+                              const int32_t* graph_ptr, int n_graphs, const GraphListJobs& jobs, bool cached, bool prune,
+                              uint8_t* d1_out, hipStream_t s);
 hipError_t launch_build_lists(const ListJobs& jobs, int n, hipStream_t s);
+// `h1` / `h2` -> `out1` / `out2` (optional): the cached features of layers 0 / 1 [n,128] copied in the same launch
 hipError_t launch_restore_graph(const int32_t* s_nbr, const int32_t* s_deg, const float* s_ew, int n, int32_t* nbr, int32_t* deg,
-                                float* ew, hipStream_t s);
+                                float* ew, hipStream_t s, const float* h1 = nullptr, const float* h2 = nullptr,
+                                float* out1 = nullptr, float* out2 = nullptr);
 hipError_t launch_split_list(const int* list, const int* count, int n, const uint8_t* flag, int* out1, int* cnt1, int* out0,
                              int* cnt0, hipStream_t s, bool counters_zeroed = false);
 // MFMA edge kernel (edge_mfma.hip)

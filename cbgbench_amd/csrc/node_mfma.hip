@@ -471,6 +471,7 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
     const int* __restrict__ n_rows_ptr = jb.n_rows;
     const unsigned chunk_mask = jb.chunk_mask;
     const bool proj_only = jb.proj_only != 0;        // workgroup-uniform
+    const uint8_t* __restrict__ fold_flag = jb.fold_flag;
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
     const int n_tiles = (n_rows + 15) / 16;
     for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
@@ -506,6 +507,9 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
         bool lgr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) lgr[r] = lig[orow[r] >= 0 ? orow[r] : arow] != 0;
+        bool fold_row[4];       // rows of the tile whose folded query is wanted (requested here, used in phase 3)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fold_row[r] = orow[r] >= 0 && (!fold_flag || fold_flag[orow[r] >= 0 ? orow[r] : arow] != 0);
         for (int unit = wave; unit < 2 * NP_CHUNKS; unit += 16) {
             const int ch = unit < 4 ? 8 + (unit >> 1) : (unit - 4) >> 1, half = unit & 1;   // units 0..3: chunks 8, 9
             if (!(((chunk_mask | (proj_only ? 0u : 0x300u)) >> ch) & 1u)) continue;
@@ -595,7 +599,8 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
         }
         __syncthreads();
         // ---- phase 3: the fold of head a = wave: Qt[row][a][m] = sum_cc q[row][8a+cc] Wbk[8a+cc][m] / sqrt 8 (exact fp32) ---
-        {
+        // (skipped when no row of the tile wants it: the same answer in every wave, they all look at the same 16 rows)
+        if (__ballot(fold_row[0] || fold_row[1] || fold_row[2] || fold_row[3]) != 0ull) {
             const int a = wave;
             const float* fb = att + A_WBK_FRAG + ((size_t)a * 2 * 64 + lane) * 8;
             const float4 b00 = nld4(fb), b01 = nld4(fb + 4), b10 = nld4(fb + 64 * 8), b11 = nld4(fb + 64 * 8 + 4);
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
                 acc[2] = MFMA(qv.y, b1.y, acc[2]); acc[3] = MFMA(qv.y, b1.w, acc[3]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (orow[r] >= 0) {
+                    if (fold_row[r]) {
                         const float4 o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
                         *reinterpret_cast<float4*>(Qt + ((size_t)orow[r] * HEADS + a) * H + 64 * g + 4 * c) = o;
                     }
@@ -639,31 +644,41 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const float* __restric
     const int n_tiles = (M + 63) / 64;
     if ((int)blockIdx.x >= n_tiles) return;
     const int npad = (nout + 15) & ~15;
-    // LDS fill with every load of a pass in flight before the first store: the plain loop compiled to load -> wait -> ds_write per
-    // element, 64 dependent L2 round trips for the [128][128] matrix -- 46 us for the classifier's first Linear at ONE graph
-    // (profiles/step_timeline_r05a_p1s1_ov1.json), more than any edge launch of that step
-    if (npad == nout && (nout & 3) == 0) {
-        const floatx4* src = reinterpret_cast<const floatx4*>(Wt);
+    // gridDim.y > 1 (few rows: the samplers' classifier on the ligand rows of a small batch): the 16-column tiles are dealt over
+    // blockIdx.y, so a workgroup stages and multiplies only its own columns -- at one graph the first Linear was ONE wave per 16 rows
+    // walking all eight column tiles behind a 64 KB fill, 27 - 46 us (profiles/step_timeline_r05[ab]_p1s1*.json)
+    const int n_ct = npad / 16, ct_per = (n_ct + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int ct0 = (int)blockIdx.y * ct_per, ct1 = min(n_ct, ct0 + ct_per);
+    if (ct0 >= ct1) return;
+    const int wcols = 16 * (ct1 - ct0), col0 = 16 * ct0;
+    // LDS fill [128][wcols] with every load of a pass in flight before the first store: the plain loop compiled to load -> wait ->
+    // ds_write per element, 64 dependent L2 round trips for the [128][128] matrix
+    if ((nout & 3) == 0 && col0 + wcols <= nout) {
         floatx4* dst = reinterpret_cast<floatx4*>(lds);
-        const int n4 = H * npad / 4;                 // <= 4096: 16 float4 per thread
+        const int w4 = wcols / 4, n4 = H * w4;         // <= 4096: 16 float4 per thread
         floatx4 v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int t = tid + 256 * u; v[u] = src[t < n4 ? t : n4 - 1]; }
+        for (int u = 0; u < 16; ++u) {
+            if (256 * u < n4) {          // (workgroup-uniform: a 16-column slice is two float4 per thread, the whole matrix sixteen)
+                const int t = min(tid + 256 * u, n4 - 1), k = t / w4, c4 = t - k * w4;
+                v[u] = *reinterpret_cast<const floatx4*>(Wt + (size_t)k * nout + col0 + 4 * c4);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 16; ++u) { const int t = tid + 256 * u; if (t < n4) dst[t] = v[u]; }
     } else {
-        for (int t0 = 0; t0 < H * npad; t0 += 256 * 8) {
+        for (int t0 = 0; t0 < H * wcols; t0 += 256 * 8) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int t = t0 + tid + 256 * u, k = t / npad, col = t - k * npad;
+                const int t = t0 + tid + 256 * u, k = t / wcols, col = col0 + (t - k * wcols);
                 const float w = Wt[min(k, H - 1) * nout + min(col, nout - 1)];     // unconditional: a predicated load is a branch + wait
-                v[u] = (t < H * npad && col < nout) ? w : 0.f;
+                v[u] = (t < H * wcols && col < nout) ? w : 0.f;
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int t = t0 + tid + 256 * u; if (t < H * npad) lds[t] = v[u]; }
+            for (int u = 0; u < 8; ++u) { const int t = t0 + tid + 256 * u; if (t < H * wcols) lds[t] = v[u]; }
         }
     }
     __syncthreads();
@@ -683,17 +698,17 @@ __global__ __launch_bounds__(256) void node_linear_kernel(const float* __restric
             const float4 v = nld4(A + (size_t)arow * lda + 16 * u + 4 * q);
             a[4 * u] = v.x; a[4 * u + 1] = v.y; a[4 * u + 2] = v.z; a[4 * u + 3] = v.w;
         }
-        for (int ct = 0; ct < npad / 16; ++ct) {
+        for (int ct = ct0; ct < ct1; ++ct) {
             const int col = 16 * ct + c;
-            const float b = (bias && col < nout) ? bias[col] : 0.f;
+            const float b = (bias && col < nout) ? bias[min(col, nout - 1)] : 0.f;
             floatx4 acc0 = {b, b, b, b}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float* wp = lds + (16 * u + 4 * q) * npad + col;
+                const float* wp = lds + (16 * u + 4 * q) * wcols + (col - col0);
                 acc0 = MFMA(a[4 * u + 0], wp[0], acc0);
-                acc1 = MFMA(a[4 * u + 1], wp[npad], acc1);
-                acc0 = MFMA(a[4 * u + 2], wp[2 * npad], acc0);
-                acc1 = MFMA(a[4 * u + 3], wp[3 * npad], acc1);
+                acc1 = MFMA(a[4 * u + 1], wp[wcols], acc1);
+                acc0 = MFMA(a[4 * u + 2], wp[2 * wcols], acc0);
+                acc1 = MFMA(a[4 * u + 3], wp[3 * wcols], acc1);
             }
             if (col < nout) {
 #pragma unroll
@@ -714,7 +729,8 @@ hipError_t launch_node_gemm(const float* A, int lda, const float* Wt, const floa
     if (M == 0) return hipSuccess;
     if (nout < 1 || nout > H) return hipErrorInvalidValue;
     const int tiles = (M + 63) / 64;
-    const dim3 grid(tiles < 512 ? tiles : 512), block(256);
+    // few row tiles: one workgroup per (row tile, 16-column tile) -- see the kernel
+    const dim3 grid(tiles < 512 ? tiles : 512, tiles <= 128 ? (nout + 15) / 16 : 1), block(256);
     profile_mark_begin(K_NODE_GEMM, s);
     if (act == 0)
         hipLaunchKernelGGL(node_linear_kernel<0>, grid, block, 0, s, A, lda, Wt, bias, C, ldc, M, nout, rows, n_rows);
@@ -966,6 +982,103 @@ __global__ __launch_bounds__(BA_THREADS) void build_lists_kernel(ListJobs jobs, 
     if (a) jobs.list[job][s_base + s_cnt[wave] + __popcll(m & ((1ull << lane) - 1ull))] = idx;
 }
 
+// ---- the same four steps for a small input in one launch: one 1024-thread workgroup per graph, flags in LDS (kernels.h) ----------
+__global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __restrict__ gen, const uint8_t* __restrict__ lig,
+                                                           const uint8_t* __restrict__ d1_in, const int32_t* __restrict__ nbr,
+                                                           const int32_t* __restrict__ deg, const int32_t* __restrict__ graph_ptr,
+                                                           GraphListJobs jobs, int cached, int prune,
+                                                           uint8_t* __restrict__ d1_out) {
+    __shared__ uint8_t F[GF_COUNT][GRAPH_LISTS_MAX_NODES];
+    __shared__ int s_cnt[LIST_JOBS_MAX][16];
+    __shared__ int s_base[LIST_JOBS_MAX];
+    const int gs = graph_ptr[blockIdx.x], n = graph_ptr[blockIdx.x + 1] - gs;
+    if (n <= 0 || n > GRAPH_LISTS_MAX_NODES) return;     // (the launcher only takes inputs whose total is within the bound)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < n; k += 1024) {
+        F[GF_GEN][k] = gen[gs + k]; F[GF_LIG][k] = lig[gs + k]; F[GF_D1IN][k] = d1_in ? d1_in[gs + k] : 0;
+#pragma unroll
+        for (int f = GF_d1; f < GF_COUNT; ++f) F[f][k] = 0;
+    }
+    __syncthreads();
+    const int Dx = d1_in ? GF_D1IN : GF_d1;     // "differs from the ligand-free pocket": the caller's proximity flags, or d1 itself
+    const int levels = (cached || prune) ? 3 : 1;
+    for (int level = 0; level < levels; ++level) {
+        for (int t = tid; t < n * KNN; t += 1024) {
+            const int i = t >> 5, e = t & 31;
+            const bool valid = e < deg[gs + i];
+            const int j = valid ? nbr[(size_t)(gs + i) * KNN + e] - gs : i;
+            if (level == 0) {
+                const bool g = F[GF_GEN][i] != 0, l = F[GF_LIG][i] != 0;
+                if (e == 0 && (g || l)) F[GF_a1][i] = 1;
+                if (g && valid) F[GF_a1][j] = 1;
+                if ((e == 0 && l) || (valid && F[GF_LIG][j])) F[GF_d1][i] = 1;
+            } else if (level == 1) {
+                if (prune) {
+                    const bool a = F[GF_a1][i] != 0;
+                    if (e == 0 && a) F[GF_a2][i] = 1;
+                    if (a && valid) F[GF_a2][j] = 1;
+                }
+                if (cached) {
+                    const bool d = F[Dx][i] != 0;
+                    if ((e == 0 && d) || (valid && F[Dx][j])) F[GF_D2][i] = 1;
+                    if (e == 0 && d) F[GF_S1][i] = 1;
+                    if (d && valid) F[GF_S1][j] = 1;
+                }
+            } else {
+                if (prune) {
+                    const bool a = F[GF_a2][i] != 0;
+                    if (e == 0 && a) F[GF_a3][i] = 1;
+                    if (a && valid) F[GF_a3][j] = 1;
+                }
+                if (cached) {
+                    const bool d = F[GF_D2][i] != 0;
+                    if (e == 0 && d) F[GF_S2][i] = 1;
+                    if (d && valid) F[GF_S2][j] = 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (d1_out)
+        for (int k = tid; k < n; k += 1024) d1_out[gs + k] = F[GF_d1][k];
+    // compaction of every job, 1024 nodes of the graph at a time: per job one returning atomic per pass (list order is irrelevant)
+    for (int base = 0; base < n; base += 1024) {
+        const int k = base + tid;
+        unsigned member = 0u;       // bit job
+        for (int job = 0; job < jobs.n_jobs; ++job) {
+            const int fa = jobs.flag[job], fb = jobs.flag2[job];
+            bool a = k < n && (fa == GF_ALL || F[fa == GF_D1IN ? Dx : fa][k] != 0);
+            if (a && fb != GF_ALL) a = (F[fb == GF_D1IN ? Dx : fb][k] != 0) == (jobs.want2[job] != 0);
+            const unsigned long long m = __ballot(a);
+            if (lane == 0) s_cnt[job][wave] = __popcll(m);
+            member |= a ? 1u << job : 0u;
+        }
+        __syncthreads();
+        if (tid < jobs.n_jobs) {
+            int tot = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { const int c = s_cnt[tid][w]; s_cnt[tid][w] = tot; tot += c; }   // exclusive prefix
+            s_base[tid] = tot ? atomicAdd(jobs.count[tid], tot) : 0;
+        }
+        __syncthreads();
+        for (int job = 0; job < jobs.n_jobs; ++job) {
+            const bool a = (member >> job) & 1u;
+            const unsigned long long m = __ballot(a);
+            if (a) jobs.list[job][s_base[job] + s_cnt[job][wave] + __popcll(m & ((1ull << lane) - 1ull))] = gs + k;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_graph_lists(const uint8_t* gen, const uint8_t* lig, const uint8_t* d1_in, const int32_t* nbr, const int32_t* deg,
+                              const int32_t* graph_ptr, int n_graphs, const GraphListJobs& jobs, bool cached, bool prune,
+                              uint8_t* d1_out, hipStream_t s) {
+    if (n_graphs == 0 || jobs.n_jobs == 0) return hipSuccess;
+    hipLaunchKernelGGL(graph_lists_kernel, dim3(n_graphs), dim3(1024), 0, s, gen, lig, d1_in, nbr, deg, graph_ptr, jobs,
+                       cached ? 1 : 0, prune ? 1 : 0, d1_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_list_level(const GraphFlags& f, const int32_t* nbr, const int32_t* deg, int n, int level, bool cached, bool prune,
                              hipStream_t s) {
     if (n == 0) return hipSuccess;
@@ -981,24 +1094,31 @@ hipError_t launch_build_lists(const ListJobs& jobs, int n, hipStream_t s) {
     return hipGetLastError();
 }
 
-// the pocket's own neighbour lists, degrees and gate values (static-context cache) into the call's working arrays: one launch
-// instead of three device-to-device copies
+// the pocket's own neighbour lists, degrees and gate values (static-context cache) into the call's working arrays, and the cached
+// features that leave layers 0 / 1 into the two feature buffers those layers write their listed rows into: one launch instead of
+// three + two device-to-device copies (the two feature copies were separate launches inside the layer loop until round 5)
 __global__ void restore_graph_kernel(const int32_t* __restrict__ s_nbr, const int32_t* __restrict__ s_deg,
                                      const float* __restrict__ s_ew, int n, int32_t* __restrict__ nbr, int32_t* __restrict__ deg,
-                                     float* __restrict__ ew) {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 4 neighbour slots
-    if (t >= (long)n * (KNN / 4)) return;
-    reinterpret_cast<int4*>(nbr)[t] = reinterpret_cast<const int4*>(s_nbr)[t];
-    reinterpret_cast<float4*>(ew)[t] = reinterpret_cast<const float4*>(s_ew)[t];
-    if ((t & (KNN / 4 - 1)) == 0) deg[t / (KNN / 4)] = s_deg[t / (KNN / 4)];
+                                     float* __restrict__ ew, const float* __restrict__ h1, const float* __restrict__ h2,
+                                     float* __restrict__ out1, float* __restrict__ out2) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (long)n * (KNN / 4)) {      // one thread per 4 neighbour slots
+        reinterpret_cast<int4*>(nbr)[t] = reinterpret_cast<const int4*>(s_nbr)[t];
+        reinterpret_cast<float4*>(ew)[t] = reinterpret_cast<const float4*>(s_ew)[t];
+        if ((t & (KNN / 4 - 1)) == 0) deg[t / (KNN / 4)] = s_deg[t / (KNN / 4)];
+    }
+    if (h1 && t < (long)n * (H / 4)) {  // one thread per 4 features
+        reinterpret_cast<float4*>(out1)[t] = reinterpret_cast<const float4*>(h1)[t];
+        reinterpret_cast<float4*>(out2)[t] = reinterpret_cast<const float4*>(h2)[t];
+    }
 }
 
 hipError_t launch_restore_graph(const int32_t* s_nbr, const int32_t* s_deg, const float* s_ew, int n, int32_t* nbr, int32_t* deg,
-                                float* ew, hipStream_t s) {
+                                float* ew, hipStream_t s, const float* h1, const float* h2, float* out1, float* out2) {
     if (n == 0) return hipSuccess;
-    const long threads = (long)n * (KNN / 4);
+    const long threads = (long)n * (h1 ? H / 4 : KNN / 4);
     hipLaunchKernelGGL(restore_graph_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, s_nbr, s_deg, s_ew, n, nbr,
-                       deg, ew);
+                       deg, ew, h1, h2, out1, out2);
     return hipGetLastError();
 }
 
@@ -1074,10 +1194,10 @@ constexpr unsigned CHUNKS_OWN = 0x30fu;   // PDk | PDv | qh: what the destinatio
 // (optional): the nodes that can be *sources* of those destinations; without it PS is produced for every node.
 
 bool add_node_stage_jobs(NodeStageJobs& jobs, const float* att, float* P, float* qbuf, float* Qt, const int* act,
-                         const int* act_count, const int* src, const int* src_count) {
+                         const int* act_count, const int* src, const int* src_count, const uint8_t* fold_flag) {
     if (jobs.n + (act ? 2 : 1) > NS_JOBS_MAX) return false;
-    jobs.j[jobs.n++] = NodeStageJob{att, P, qbuf, Qt, act, act_count, act ? CHUNKS_OWN : CHUNKS_ALL, 0};
-    if (act) jobs.j[jobs.n++] = NodeStageJob{att, P, qbuf, Qt, src, src_count, CHUNKS_PS, 1};
+    jobs.j[jobs.n++] = NodeStageJob{att, P, qbuf, Qt, act, act_count, act ? CHUNKS_OWN : CHUNKS_ALL, 0, fold_flag};
+    if (act) jobs.j[jobs.n++] = NodeStageJob{att, P, qbuf, Qt, src, src_count, CHUNKS_PS, 1, nullptr};
     return true;
 }
 
