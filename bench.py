@@ -277,6 +277,7 @@ def bench_train(args, rank, world, dev):
     torch.cuda.synchronize(); sharding.barrier()
     elapsed = time.perf_counter() - t0
     el_max, units = sharding.reduce_max_sum(elapsed, n_graphs * args.steps, device=dev)
+    per_rank = sharding.gather_values(round(n_graphs * args.steps / elapsed, 1), device=dev)
     seen = ranks_seen(dev)
     if seen != world:
         raise SystemExit(f"bench.py: all-reduce saw {seen} ranks, expected {world}")
@@ -289,7 +290,7 @@ def bench_train(args, rank, world, dev):
         "config": {"workload": f"configs/denovo {args.model} training (BASELINE configs[4] shape): {n_graphs} graphs per GPU per step, "
                                f"Adam lr 5e-4, clip 8.0, one flat gradient all-reduce ({fg.flat.numel()} fp32) per step",
                    "graphs_per_batch_per_gpu": n_graphs, "nodes_per_batch": N, "sharding": f"data-parallel x{world} ranks", "ranks_seen": seen,
-                   "collective_backend": collective_backend(),
+                   "collective_backend": collective_backend(), "per_rank_graph_steps_per_s": per_rank,
                    "allreduce_ms_per_step": round(1e3 * t_ar / max(args.steps, 1), 4)},
     }
     if rank == 0 and not args.no_roofline:
@@ -571,6 +572,7 @@ def bench_sampling(args, rank, world, dev):
             torch.cuda.synchronize(); sharding.barrier()
             elapsed = time.perf_counter() - t0
         el_max, graph_steps = sharding.reduce_max_sum(elapsed, n_graphs * n_blocks * args.steps, device=dev)
+        per_rank = sharding.gather_values(round(n_graphs * n_blocks * args.steps / elapsed, 1), device=dev)   # a straggler shows here
         seen = ranks_seen(dev)
         if seen != world:
             raise SystemExit(f"bench.py: all-reduce saw {seen} ranks, expected {world}")
@@ -595,6 +597,7 @@ def bench_sampling(args, rank, world, dev):
                        "sharding": (f"ONE job of {args.pockets} pockets split over {world} ranks" if split else
                                     f"independent pockets x{world} ranks") + ", no data-path collective",
                        "ranks_seen": seen, "collective_backend": collective_backend(),
+                       "per_rank_graph_steps_per_s": per_rank,
                        "launch": "hipGraph replay per batch and step" if use_graph else "stream launches",
                        "streams": n_streams, "edge_workgroups": edge_wgs or 256},
         }
@@ -633,6 +636,10 @@ def bench_sampling(args, rank, world, dev):
                 "bound": "hbm", "kernel": "cbgx::edge_x2h_dual_kernel (fused x2h edge stage, all nodes of a layer)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": measured_traffic(Nb), "traffic_source": TRAFFIC_SOURCE,
+                # the hardware view next to the nominal `frac`: measured HBM bytes of a launch / its time / the HBM peak (the kernel is
+                # fused -- per-edge k / v never exist in memory -- so this is far below `frac` by design)
+                "hbm_real": (round(measured_traffic(Nb) / x2h_s / 1e9 / HBM_PEAK_GBS, 4)
+                             if (measured_traffic(Nb) and x2h_s > 0) else None),
                 "nodes_per_launch": Nb, "algorithmic_bytes_per_launch": x2h_bytes, "avg_launch_us": round(1e6 * x2h_s, 3),
                 "mfma_view": {"fp32_mfma_tflops": tf(X2H_FP32_MFMA_FLOPS_PER_EDGE * deg_edges), "fp32_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
                               "f16_mfma_tflops_issued": tf(X2H_F16_MFMA_FLOPS_PER_NODE * Nb), "f16_peak_tflops": F16_MFMA_PEAK_TFLOPS,
@@ -667,7 +674,7 @@ def _row(out, keep=()):
     return r
 
 
-def sample_cli_end_to_end(dev, pockets=20, samples=10):
+def sample_cli_end_to_end(dev, pockets=20, samples=10, config="targetdiff_test.yml"):
     """ONE run of the sampling driver (cbgbench_amd/sample_cli.py = the role of the reference's sample.py:159-230) at the full
     T = 1000: synthetic pockets -> priors -> one 200-graph batch -> model.sample (static-context cache, 1000 steps, the 1001-entry
     trajectory kept on the device and downloaded once) -> one result file per pocket.  Wall time of everything after the model
@@ -675,7 +682,8 @@ def sample_cli_end_to_end(dev, pockets=20, samples=10):
     import shutil
     import tempfile
     from cbgbench_amd import sample_cli
-    cfg = os.path.join(ROOT, "tests", "fixtures", "targetdiff_test.yml")      # the reference's config schema, T = 1000
+    cfg = os.path.join(ROOT, "tests", "fixtures", config)      # the reference's config schema, T = 1000
+    name = config[:config.rfind(".")]
     tmp = tempfile.mkdtemp(prefix="cbgx_bench_")
     try:
         torch.cuda.synchronize(dev)
@@ -685,15 +693,19 @@ def sample_cli_end_to_end(dev, pockets=20, samples=10):
                               "--pockets_per_batch", str(pockets), "--random_init"], stats=stats)
         torch.cuda.synchronize(dev)
         wall = time.perf_counter() - t0
-        files = sorted(os.listdir(os.path.join(tmp, "targetdiff_test")))
-        nbytes = sum(os.path.getsize(os.path.join(tmp, "targetdiff_test", f)) for f in files)
+        files = sorted(os.listdir(os.path.join(tmp, name)))
+        nbytes = sum(os.path.getsize(os.path.join(tmp, name, f)) for f in files)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     assert rc == 0 and len(files) == pockets, (rc, files)
     gs = pockets * samples * 1000
     return {"value": round(gs / wall, 2), "unit": "graph-steps/s", "wall_s": round(wall, 3), "graphs": pockets * samples,
             "denoising_steps": 1000, "result_files": len(files), "result_bytes": nbytes,
-            "phases_s": {k: round(v, 2) for k, v in stats.items()},
+            "phases_s": {k: round(v, 2) for k, v in stats.items() if not k.endswith("_s")},
+            # the `sample` phase itemised: what an end-to-end user pays around the T steps
+            "begin_sampling_ms": round(1e3 * stats.get("begin_sampling_s", 0.0), 1),
+            "steps_ms": round(1e3 * stats.get("steps_s", 0.0), 1),
+            "traj_download_ms": round(1e3 * stats.get("traj_download_s", 0.0), 1),
             "what": "python -m cbgbench_amd.sample_cli, T = 1000, wall time config load -> last result file"}
 
 
@@ -741,6 +753,14 @@ def secondary_block(args, dev, primary):
         r["ratio_to_step_sampled_headline"] = round(r["value"] / primary["value"], 4)
         return r
     guarded("sample_cli_T1000_200_graphs", e2e)
+
+    def e2e_linker():
+        # BASELINE configs[2] through the driver: a linker config -- context atoms per pocket, frame centred on
+        # them, generated atoms appended (assign_gensize) -- 256 pockets x 1 sample in one batch, T = 1000, per-pocket files
+        r = sample_cli_end_to_end(dev, pockets=256, samples=1, config="linker_targetdiff_test.yml")
+        r["what"] = "python -m cbgbench_amd.sample_cli, configs/linker schema (context atoms, ctx centring), T = 1000, 256 graphs"
+        return r
+    guarded("sample_cli_linker_T1000_256_graphs", e2e_linker)
     sec["total_s"] = round(time.perf_counter() - t_all, 2)
     return sec
 

@@ -50,6 +50,14 @@
 #ifndef CBGX_EDGE_MIN_WAVES
 #define CBGX_EDGE_MIN_WAVES 2
 #endif
+// Which wave of which workgroup takes item o of a round (S = workgroups x active waves items per round).  0: workgroup-major, o =
+// slot * waves + wave (rounds 1 - 4) -- a partial last round then fills ALL waves of its first few workgroups while the others idle:
+// a 10-graph batch is 2.17 nodes per wave, and the 48 third-round items of an XCD sat on 6 of its 32 workgroups, two to a SIMD.
+// 1: wave-major, o = wave * slots + slot -- the same items go to wave 0 of every workgroup first, one to a SIMD, where a node's
+// chain runs ~1.5 x faster (the waves-per-workgroup measurements above).  Full rounds are the same load either way.
+#ifndef CBGX_EDGE_WAVE_MAJOR
+#define CBGX_EDGE_WAVE_MAJOR 1
+#endif
 
 namespace cbgx {
 
@@ -205,14 +213,14 @@ __device__ __forceinline__ void edge_body(
     }
     const int n_items = act ? *act_count : n_nodes;
     const int wv = edge_active_waves(n_items, n_wg, WAVES);     // waves of this workgroup that take items (see CBGX_EDGE_MIN_WAVES)
-    {   // a workgroup with no item skips the LDS fill altogether
+    {   // a workgroup with no item skips the LDS fill altogether (its wave 0 holds its first item in either mapping)
         int first;
         if ((n_wg & 7) == 0) {
             const int per_xcd = (((n_items + 7) >> 3) + wv - 1) / wv * wv;
-            first = (wg & 7) * per_xcd + (wg >> 3) * wv;
+            first = (wg & 7) * per_xcd + (wg >> 3) * (CBGX_EDGE_WAVE_MAJOR ? 1 : wv);
             if (first >= min(n_items, ((int)(wg & 7) + 1) * per_xcd)) return;
         } else {
-            first = wg * wv;
+            first = wg * (CBGX_EDGE_WAVE_MAJOR ? 1 : wv);
             if (first >= n_items) return;
         }
     }
@@ -275,12 +283,12 @@ __device__ __forceinline__ void edge_body(
     if (wave >= wv) return;     // (after the barrier: this wave has done its share of the LDS fill)
     if ((n_wg & 7) == 0) {
         const int per_xcd = (((n_items + 7) >> 3) + wv - 1) / wv * wv;
-        const int xcd = wg & 7, slot = wg >> 3;
-        i_begin = xcd * per_xcd + slot * wv + wave;
+        const int xcd = wg & 7, slot = wg >> 3, slots = n_wg >> 3;
+        i_begin = xcd * per_xcd + (CBGX_EDGE_WAVE_MAJOR ? wave * slots + slot : slot * wv + wave);
         i_end = min(n_items, (xcd + 1) * per_xcd);
-        i_step = (n_wg >> 3) * wv;
+        i_step = slots * wv;
     } else {
-        i_begin = wg * wv + wave;
+        i_begin = CBGX_EDGE_WAVE_MAJOR ? wave * n_wg + wg : wg * wv + wave;
         i_end = n_items;
         i_step = n_wg * wv;
     }

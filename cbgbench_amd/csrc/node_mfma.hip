@@ -461,6 +461,10 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
                                                           const uint8_t* __restrict__ lig, int n_nodes) {
     __shared__ __attribute__((aligned(16))) float qh[16][NS_TPITCH];
     __shared__ __attribute__((aligned(16))) float qt[16][NS_TPITCH];
+    // phase 2's per-column constants (query LayerNorm gamma / beta, second Linear's bias and column scale), staged once per
+    // workgroup: read from global memory inside phase 2 they were one exposed L2 round trip per 16 columns -- the emitted code was
+    // `load x2, s_waitcnt vmcnt(0)` eight times in a row, a third of the kernel's 17 - 19 us at one graph (scripts/isa_report.py)
+    __shared__ __attribute__((aligned(16))) float cst[4][H];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, q = lane >> 4;
     const NodeStageJob& jb = jobs.j[blockIdx.y];       // kernel arguments: scalar loads
     const float* __restrict__ att = jb.att;
@@ -474,6 +478,11 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
     const uint8_t* __restrict__ fold_flag = jb.fold_flag;
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
     const int n_tiles = (n_rows + 15) / 16;
+    if ((int)blockIdx.x >= n_tiles) return;
+    if (!proj_only && tid < 4 * H) {       // visible after the barrier that ends phase 1
+        const int k = tid >> 7, m = tid & (H - 1);
+        cst[k][m] = att[(k == 0 ? A_LNQ_G : (k == 1 ? A_LNQ_B : (k == 2 ? A_BQ1 : A_WQ1_CINV))) + m];
+    }
     for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
         const int row0 = tl * 16;
         const int ak = min(row0 + c, n_rows - 1);
@@ -546,11 +555,6 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
         // ---- phase 2: query MLP, output tile nt = wave (16 columns 64 (nt >> 2) + 4c + (nt & 3)) ---------------------------
         if (wave < 8) {
             const int nt = wave;
-            const half8* Bh = reinterpret_cast<const half8*>(att + A_WQ1_FRAG) + (size_t)nt * 4 * 64 + lane;   // [nt][u][lane]
-            const half8* Bl = Bh + 8 * 4 * 64;
-            half8 bh[4], bl[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { bh[u] = Bh[u * 64]; bl[u] = Bl[u * 64]; }
             float z[32];
             float sm = 0.f;
 #pragma unroll
@@ -568,7 +572,7 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
             float zmx = 0.f;   // z >= 0 after the ReLU
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float4 g = nld4(att + A_LNQ_G + 16 * u + 4 * q), b = nld4(att + A_LNQ_B + 16 * u + 4 * q);
+                const float4 g = nld4(&cst[0][16 * u + 4 * q]), b = nld4(&cst[1][16 * u + 4 * q]);
                 z[4 * u + 0] = fmaxf(z[4 * u + 0] * rstd * g.x + b.x, 0.f); z[4 * u + 1] = fmaxf(z[4 * u + 1] * rstd * g.y + b.y, 0.f);
                 z[4 * u + 2] = fmaxf(z[4 * u + 2] * rstd * g.z + b.z, 0.f); z[4 * u + 3] = fmaxf(z[4 * u + 3] * rstd * g.w + b.w, 0.f);
                 zmx = fmaxf(fmaxf(zmx, fmaxf(z[4 * u], z[4 * u + 1])), fmaxf(z[4 * u + 2], z[4 * u + 3]));
@@ -581,8 +585,17 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
                 const float v[8] = {z[8 * u], z[8 * u + 1], z[8 * u + 2], z[8 * u + 3], z[8 * u + 4], z[8 * u + 5], z[8 * u + 6], z[8 * u + 7]};
                 split8(v, zup, zh[u], zl[u]);
             }
+            // the tile's B operands: eight loads in flight together, requested once the 32 row values are split (requested first,
+            // as until round 5, the compiler parked them in scratch across the LayerNorm: four reloads behind full waits)
+            __builtin_amdgcn_sched_barrier(0);
+            const half8* Bh = reinterpret_cast<const half8*>(att + A_WQ1_FRAG) + (size_t)nt * 4 * 64 + lane;   // [nt][u][lane]
+            const half8* Bl = Bh + 8 * 4 * 64;
+            half8 bh[4], bl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { bh[u] = Bh[u * 64]; bl[u] = Bl[u * 64]; }
+            __builtin_amdgcn_sched_barrier(0);
             const int col = 64 * (nt >> 2) + 4 * c + (nt & 3);
-            const float b1 = att[A_BQ1 + col], ci = att[A_WQ1_CINV + col];
+            const float b1 = cst[2][col], ci = cst[3][col];
             floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -597,13 +610,18 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
                 if (orow[r] >= 0) qout[(size_t)orow[r] * H + col] = o;
             }
         }
-        __syncthreads();
         // ---- phase 3: the fold of head a = wave: Qt[row][a][m] = sum_cc q[row][8a+cc] Wbk[8a+cc][m] / sqrt 8 (exact fp32) ---
-        // (skipped when no row of the tile wants it: the same answer in every wave, they all look at the same 16 rows)
-        if (__ballot(fold_row[0] || fold_row[1] || fold_row[2] || fold_row[3]) != 0ull) {
+        // (skipped when no row of the tile wants it: the same answer in every wave, they all look at the same 16 rows); its B
+        // operands do not depend on phase 2, so they are requested BEFORE the barrier that ends it and fly while the wave waits
+        const bool do_fold = __ballot(fold_row[0] || fold_row[1] || fold_row[2] || fold_row[3]) != 0ull;
+        float4 b00 = {0.f, 0.f, 0.f, 0.f}, b01 = b00, b10 = b00, b11 = b00;
+        if (do_fold) {
+            const float* fb = att + A_WBK_FRAG + ((size_t)wave * 2 * 64 + lane) * 8;
+            b00 = nld4(fb); b01 = nld4(fb + 4); b10 = nld4(fb + 64 * 8); b11 = nld4(fb + 64 * 8 + 4);
+        }
+        __syncthreads();
+        if (do_fold) {
             const int a = wave;
-            const float* fb = att + A_WBK_FRAG + ((size_t)a * 2 * 64 + lane) * 8;
-            const float4 b00 = nld4(fb), b01 = nld4(fb + 4), b10 = nld4(fb + 64 * 8), b11 = nld4(fb + 64 * 8 + 4);
             const float2 qv = *reinterpret_cast<const float2*>(&qt[c][8 * a + 2 * q]);
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -1002,38 +1020,65 @@ __global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __rest
     __syncthreads();
     const int Dx = d1_in ? GF_D1IN : GF_d1;     // "differs from the ligand-free pocket": the caller's proximity flags, or d1 itself
     const int levels = (cached || prune) ? 3 : 1;
+    // The (node, slot) pairs of a thread -- pair t = tid + 1024 u -- are loaded ONCE, all in flight, and kept in registers over the
+    // three levels when the graph has at most GL_KEEP * 32 nodes (768: every pocket of the shipped data); the first version loaded
+    // deg and nbr inside the level loop, one dependent round trip per iteration: 32 us at one graph, more than the four launches it
+    // replaced (profiles/step_timeline_r05c_p1s1.json).  Rows are -1 padded, so a slot is valid iff its entry is >= 0.
+    constexpr int GL_KEEP = 24;
+    const int n_pairs = n * KNN;
+    const bool keep = n_pairs <= GL_KEEP * 1024;
+    int jl[GL_KEEP];
+    if (keep) {
+#pragma unroll
+        for (int u = 0; u < GL_KEEP; ++u) {
+            const int t = tid + 1024 * u;
+            jl[u] = nbr[(size_t)gs * KNN + min(t, n_pairs - 1)];
+        }
+    }
     for (int level = 0; level < levels; ++level) {
-        for (int t = tid; t < n * KNN; t += 1024) {
-            const int i = t >> 5, e = t & 31;
-            const bool valid = e < deg[gs + i];
-            const int j = valid ? nbr[(size_t)(gs + i) * KNN + e] - gs : i;
-            if (level == 0) {
-                const bool g = F[GF_GEN][i] != 0, l = F[GF_LIG][i] != 0;
-                if (e == 0 && (g || l)) F[GF_a1][i] = 1;
-                if (g && valid) F[GF_a1][j] = 1;
-                if ((e == 0 && l) || (valid && F[GF_LIG][j])) F[GF_d1][i] = 1;
-            } else if (level == 1) {
-                if (prune) {
-                    const bool a = F[GF_a1][i] != 0;
-                    if (e == 0 && a) F[GF_a2][i] = 1;
-                    if (a && valid) F[GF_a2][j] = 1;
+        for (int u0 = 0; u0 * 1024 < n_pairs; u0 += GL_KEEP) {
+            if (!keep) {
+#pragma unroll
+                for (int u = 0; u < GL_KEEP; ++u) {
+                    const int t = tid + 1024 * (u0 + u);
+                    jl[u] = nbr[(size_t)gs * KNN + min(t, n_pairs - 1)];
                 }
-                if (cached) {
-                    const bool d = F[Dx][i] != 0;
-                    if ((e == 0 && d) || (valid && F[Dx][j])) F[GF_D2][i] = 1;
-                    if (e == 0 && d) F[GF_S1][i] = 1;
-                    if (d && valid) F[GF_S1][j] = 1;
-                }
-            } else {
-                if (prune) {
-                    const bool a = F[GF_a2][i] != 0;
-                    if (e == 0 && a) F[GF_a3][i] = 1;
-                    if (a && valid) F[GF_a3][j] = 1;
-                }
-                if (cached) {
-                    const bool d = F[GF_D2][i] != 0;
-                    if (e == 0 && d) F[GF_S2][i] = 1;
-                    if (d && valid) F[GF_S2][j] = 1;
+            }
+#pragma unroll
+            for (int u = 0; u < GL_KEEP; ++u) {
+                const int t = tid + 1024 * (u0 + u);
+                if (t >= n_pairs) continue;
+                const int i = t >> 5, e = t & 31;
+                const bool valid = jl[u] >= 0;
+                const int j = valid ? jl[u] - gs : i;
+                if (level == 0) {
+                    const bool g = F[GF_GEN][i] != 0, l = F[GF_LIG][i] != 0;
+                    if (e == 0 && (g || l)) F[GF_a1][i] = 1;
+                    if (g && valid) F[GF_a1][j] = 1;
+                    if ((e == 0 && l) || (valid && F[GF_LIG][j])) F[GF_d1][i] = 1;
+                } else if (level == 1) {
+                    if (prune) {
+                        const bool a = F[GF_a1][i] != 0;
+                        if (e == 0 && a) F[GF_a2][i] = 1;
+                        if (a && valid) F[GF_a2][j] = 1;
+                    }
+                    if (cached) {
+                        const bool d = F[Dx][i] != 0;
+                        if ((e == 0 && d) || (valid && F[Dx][j])) F[GF_D2][i] = 1;
+                        if (e == 0 && d) F[GF_S1][i] = 1;
+                        if (d && valid) F[GF_S1][j] = 1;
+                    }
+                } else {
+                    if (prune) {
+                        const bool a = F[GF_a2][i] != 0;
+                        if (e == 0 && a) F[GF_a3][i] = 1;
+                        if (a && valid) F[GF_a3][j] = 1;
+                    }
+                    if (cached) {
+                        const bool d = F[GF_D2][i] != 0;
+                        if (e == 0 && d) F[GF_S2][i] = 1;
+                        if (d && valid) F[GF_S2][j] = 1;
+                    }
                 }
             }
         }

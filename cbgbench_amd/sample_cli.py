@@ -205,6 +205,7 @@ def main(argv=None, stats=None):
         return len(ids) * num_samples * model.num_diffusion_timesteps
 
     lap("setup", dev)
+    timing = {}
     t0, graph_steps = time.perf_counter(), 0
     # `--streams` batches are in flight together (independent pockets: sample.py:159's loop has no order); models without
     # sample_many take them one after the other
@@ -216,7 +217,10 @@ def main(argv=None, stats=None):
                                       plan=plan, context=[context[i] for i in ids] if context is not None else None)
                    for ids in chunk]
         lap("batch", dev)
-        trajs = many(batches, streams=args.streams) if many is not None and len(batches) > 1 else [model.sample(b) for b in batches]
+        # (targetdiff itemises its share of the `sample` phase: static context, the T steps, the trajectory download)
+        tk = {"timing": timing} if (stats is not None and config.model.type == "targetdiff") else {}
+        trajs = (many(batches, streams=args.streams, **tk) if many is not None and len(batches) > 1
+                 else [model.sample(b, **tk) for b in batches])
         lap("sample", dev)
         for ids, traj, b in zip(chunk, trajs, batches):
             graph_steps += write_results(ids, traj, b)
@@ -227,6 +231,7 @@ def main(argv=None, stats=None):
     el, gs = sharding.reduce_max_sum(time.perf_counter() - t0, graph_steps, device=dev)
     if stats is not None:
         stats.update(phases)
+        stats.update(timing)
     if rank == 0:
         print(f"sampled {len(pockets)} pockets x {num_samples} samples on {world} rank(s): "
               f"{gs / el:.1f} graph-steps/s, results in {out_dir}")

@@ -50,3 +50,16 @@ def reduce_max_sum(elapsed_s, units, device="cpu"):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t.item()), float(u.item())
+
+
+def gather_values(value, device="cpu"):
+    """[value of rank 0, value of rank 1, ...] on every rank (one all_gather of a double): the per-rank throughputs behind a
+    max / sum pair, so that a straggling rank is visible in the N > 1 bench line."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    if dist.get_backend() == "gloo":
+        device = "cpu"
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]

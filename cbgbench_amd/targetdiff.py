@@ -15,6 +15,7 @@ What differs by design:
 import ctypes
 import math
 import os
+import time
 
 import numpy as np
 import torch
@@ -345,6 +346,27 @@ class PLContextEmbedder(nn.Module):
         return self.ligand_atom_emb(c_lig) + ind1
 
 
+class _Lap:
+    """``lap(key)``: add the wall seconds since the previous lap to ``timing[key]`` after a device synchronisation; a no-op
+    without a timing dict."""
+
+    def __init__(self, timing, dev):
+        self.timing, self.dev = timing, dev
+        if timing is not None:
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            self.t = time.perf_counter()
+
+    def __call__(self, key):
+        if self.timing is None:
+            return
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+        now = time.perf_counter()
+        self.timing[key] = self.timing.get(key, 0.0) + (now - self.t)
+        self.t = now
+
+
 class BatchesInFlight:
     """``sample_many`` for the sampler classes (TargetDiff, DiffBP, DiffSBDD): ``[self.sample(b) for b in batches]`` with the batches
     IN FLIGHT TOGETHER, round-robin over ``streams`` HIP streams.  The batches are independent (the pocket loop of sample.py:159),
@@ -365,15 +387,18 @@ class BatchesInFlight:
         return have[:n]
 
     @torch.no_grad()
-    def sample_many(self, batches, noise_tapes=None, return_device=None, streams=3, use_graph=False, noise_log=None):
+    def sample_many(self, batches, noise_tapes=None, return_device=None, streams=3, use_graph=False, noise_log=None, timing=None):
         """``use_graph`` (classes with ``make_step_graph``; ignored with ``noise_tapes``): every batch's step is captured once as a
         hipGraph on its stream and replayed T times -- one host call per batch and step instead of ~50 launches plus the Python
         around them.  This is what SMALL batches need (the reference's own 10 graphs per batch, sample.py:177-183): one such batch
         is a chain of ~50 dependent 20 us kernels that leaves most of the chip idle, and the host cannot feed eight of them at once;
         eight graphs in flight can.  Same kernels on the same data as the stream launches: identical trajectories
         for identical noise.  ``noise_log`` (tests): a list that receives ``(batch index, t, eps, u)`` after every replay (which
-        synchronises the stream)."""
+        synchronises the stream).  ``timing`` (a dict): the wall seconds of the three parts of the call are ADDED to its keys
+        ``begin_sampling_s`` (static context of every batch), ``steps_s`` (the T steps) and ``traj_download_s`` (trajectory to
+        ``return_device``) -- three device synchronisations per call."""
         dev = batches[0]["ligand_pos"].device
+        lap = _Lap(timing, dev)
         out_dev = torch.device("cpu") if return_device is None else torch.device(return_device)
         tape = lambda k: None if noise_tapes is None else noise_tapes[k]
         T = self.num_diffusion_timesteps
@@ -382,11 +407,15 @@ class BatchesInFlight:
             out = []
             for k, b in enumerate(batches):
                 st = self._many_begin(b, tape(k))
+                lap("begin_sampling_s")
                 for t_idx in reversed(range(T)):
                     self._many_step(st, t_idx, tape(k))
+                lap("steps_s")
                 out.append(self._many_finish(st, out_dev))
+                lap("traj_download_s")
             return out
         states = [self._many_begin(b, tape(k)) for k, b in enumerate(batches)]
+        lap("begin_sampling_s")
         cur = torch.cuda.current_stream(dev)
         side = self._side_streams(dev, max(1, min(streams, len(states))))
         for sx in side:
@@ -408,7 +437,10 @@ class BatchesInFlight:
                         self._many_step(st, t_idx, tape(k))
         for sx in side:
             cur.wait_stream(sx)
-        return [self._many_finish(st, out_dev) for st in states]
+        lap("steps_s")
+        out = [self._many_finish(st, out_dev) for st in states]
+        lap("traj_download_s")
+        return out
 
 
 @register_model("targetdiff")
@@ -721,7 +753,7 @@ class TargetDiff(BatchesInFlight, nn.Module):
         return graph.replay, done
 
     @torch.no_grad()
-    def sample(self, batch, noise_tape=None, return_device=None, use_graph=None):
+    def sample(self, batch, noise_tape=None, return_device=None, use_graph=None, timing=None):
         """Reverse diffusion, T-1 .. 0 (targetdiff.py:127-184).
 
         ``noise_tape`` (tests): dict t -> (eps [N_lig,3], u [N_lig,C]) replacing the torch RNG draws
@@ -731,7 +763,9 @@ class TargetDiff(BatchesInFlight, nn.Module):
         MI355X it changes nothing (1.22 ms per step at 445 nodes either way) -- small batches are bound by the
         dependent-kernel chain on the device, not by host launches."""
         T = self.num_diffusion_timesteps
+        lap = _Lap(timing, batch["ligand_pos"].device)      # (``timing``: see sample_many)
         st = self.begin_sampling(batch, keep_trajectory=True)
+        lap("begin_sampling_s")
         use_graph = bool(use_graph) and noise_tape is None
         if use_graph:
             replay, done = self.make_step_graph(st)
@@ -740,8 +774,10 @@ class TargetDiff(BatchesInFlight, nn.Module):
             st["x_lig"], st["c_lig"] = st["traj_x"][0], st["traj_c"][0]
         for t_idx in (reversed(range(T)) if not use_graph else ()):
             self.denoise_step(st, t_idx, noise_tape[t_idx] if noise_tape is not None else None)
+        lap("steps_s")
         out_dev = torch.device("cpu") if return_device is None else torch.device(return_device)
         traj_x, traj_c, bl_out = st["traj_x"].to(out_dev), st["traj_c"].to(out_dev), st["bl"].to(out_dev)
+        lap("traj_download_s")
         return {t - 1: (traj_x[t], traj_c[t], bl_out) for t in range(T + 1)}
 
     # hooks of BatchesInFlight.sample_many

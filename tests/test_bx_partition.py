@@ -94,26 +94,30 @@ def active_waves(n_items, n_wg, waves=8):
     return min(waves, max(min(MIN_WAVES, waves), per_wg))
 
 
-def forward_schedule(n_items, n_wg, waves=8):
+WAVE_MAJOR = True      # CBGX_EDGE_WAVE_MAJOR: item o of a round -> (wave o // slots, workgroup o % slots)
+
+
+def forward_schedule(n_items, n_wg, waves=8, wave_major=WAVE_MAJOR):
     """-> {(wg, wave): [items in processing order]} of edge_body"""
     wv = active_waves(n_items, n_wg, waves)
     out = {}
     for wg in range(n_wg):
         if n_wg % 8 == 0:
             per_xcd = (((n_items + 7) >> 3) + wv - 1) // wv * wv
-            first = (wg & 7) * per_xcd + (wg >> 3) * wv
+            first = (wg & 7) * per_xcd + (wg >> 3) * (1 if wave_major else wv)
             if first >= min(n_items, ((wg & 7) + 1) * per_xcd):
                 continue
-        elif wg * wv >= n_items:
+        elif wg * (1 if wave_major else wv) >= n_items:
             continue
         for wave in range(waves):
             if wave >= wv:
                 continue
             if n_wg % 8 == 0:
-                xcd, slot = wg & 7, wg >> 3
-                i_begin, i_end, i_step = xcd * per_xcd + slot * wv + wave, min(n_items, (xcd + 1) * per_xcd), (n_wg >> 3) * wv
+                xcd, slot, slots = wg & 7, wg >> 3, n_wg >> 3
+                off = wave * slots + slot if wave_major else slot * wv + wave
+                i_begin, i_end, i_step = xcd * per_xcd + off, min(n_items, (xcd + 1) * per_xcd), slots * wv
             else:
-                i_begin, i_end, i_step = wg * wv + wave, n_items, n_wg * wv
+                i_begin, i_end, i_step = (wave * n_wg + wg if wave_major else wg * wv + wave), n_items, n_wg * wv
             if i_begin < i_end:
                 out[(wg, wave)] = list(range(i_begin, i_end, i_step))
     return out
@@ -129,8 +133,25 @@ def launcher_grid(n_nodes, dual=False):
 @pytest.mark.parametrize("n_wg", [1, 2, 9, 56, 57, 64, 112, 176, 256])
 def test_forward_schedule_covers_every_item_once(n_wg):
     for n in [1, 5, 8, 9, 25, 250, 445, 1024, 1230, 3170, 4404, 16506, 99543]:
+        for wm in (True, False):
+            sched = forward_schedule(n, n_wg, wave_major=wm)
+            assert sorted(i for v in sched.values() for i in v) == list(range(n)), (n, n_wg, wm)
+
+
+def test_a_partial_last_round_spreads_over_the_workgroups():
+    # ten graphs: 4450 nodes, 2.17 per wave; the protein-only role alone, 3200 nodes on 176 workgroups = 2.27 per wave: the items of
+    # the third round go to wave 0 (then wave 1, ...) of every workgroup, not to all eight waves of the first few
+    for n, n_wg in ((4450, 256), (3200, 176)):
         sched = forward_schedule(n, n_wg)
-        assert sorted(i for v in sched.values() for i in v) == list(range(n)), (n, n_wg)
+        third = [(wg, wave) for (wg, wave), v in sched.items() if len(v) == 3]
+        assert third and max(wave for _, wave in third) <= 2
+        per_wg = {}
+        for wg, _ in third:
+            per_wg[wg] = per_wg.get(wg, 0) + 1
+        assert max(per_wg.values()) <= 3                              # at most one per SIMD
+        old = forward_schedule(n, n_wg, wave_major=False)
+        third_old = [(wg, wave) for (wg, wave), v in old.items() if len(v) == 3]
+        assert len(third_old) == len(third) and max(wave for _, wave in third_old) == 7   # (the mapping this replaces)
 
 
 def test_short_lists_run_one_wave_per_simd():
