@@ -36,6 +36,8 @@ EXPORTS = {
     "cbgx_targetdiff_prologue": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cbgx_targetdiff_epilogue": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp,
                                       _vp, _vp]),
+    "cbgx_targetdiff_step_boundary": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp,
+                                           _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cbgx_targetdiff_prologue_traj": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cbgx_targetdiff_epilogue_traj": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp]),
     "cbgx_diffbp_epilogue": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp,

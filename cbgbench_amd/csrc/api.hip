@@ -802,6 +802,25 @@ int cbgx_targetdiff_epilogue(const float* x_den, const float* logits, const int3
     return CBGX_OK;
 }
 
+int cbgx_targetdiff_step_boundary(const float* x_den, const float* logits, const int32_t* lig_rows, const float* x_lig,
+                                  const float* c_lig, const uint8_t* gen_lig, int n_lig, int num_classes, int t,
+                                  int num_timesteps, const float* const* tables, const float* eps, const float* u,
+                                  float* x_next, float* c_next, const float* lig_emb_w, const float* lig_emb_b,
+                                  const float* ind_w, const float* ind_b, float* x, float* h, void* stream) {
+    if (n_lig == 0) return CBGX_OK;
+    if (n_lig < 0 || num_classes < 1 || num_classes > 32 || t < 0 || t >= num_timesteps)
+        return fail(CBGX_E_INVALID, "step_boundary: bad sizes (n_lig=%d C=%d t=%d T=%d)", n_lig, num_classes, t, num_timesteps);
+    if (!x_den || !logits || !lig_rows || !x_lig || !c_lig || !gen_lig || !tables || !eps || !u || !x_next || !c_next ||
+        !lig_emb_w || !lig_emb_b || !ind_w || !ind_b || !x || !h)
+        return fail(CBGX_E_INVALID, "step_boundary: NULL pointer");
+    for (int i = 0; i < 7; ++i)
+        if (!tables[i]) return fail(CBGX_E_INVALID, "step_boundary: table %d is NULL", i);
+    HIP_TRY(launch_step_boundary(x_den, logits, lig_rows, x_lig, c_lig, gen_lig, n_lig, num_classes, t, tables,
+                                 (float)log((double)num_classes), eps, u, x_next, c_next, lig_emb_w, lig_emb_b, ind_w, ind_b, x, h,
+                                 (hipStream_t)stream));
+    return CBGX_OK;
+}
+
 int cbgx_diffbp_epilogue(const float* x_den, const float* x_com, const float* x_in, const float* logits,
                          const int32_t* lig_rows, const int32_t* lig_ptr, const float* x_lig, const float* c_lig,
                          const uint8_t* gen_lig, int n_lig, int n_graphs, int num_classes, int t, int num_timesteps,

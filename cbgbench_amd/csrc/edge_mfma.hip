@@ -55,6 +55,11 @@
 // a 10-graph batch is 2.17 nodes per wave, and the 48 third-round items of an XCD sat on 6 of its 32 workgroups, two to a SIMD.
 // 1: wave-major, o = wave * slots + slot -- the same items go to wave 0 of every workgroup first, one to a SIMD, where a node's
 // chain runs ~1.5 x faster (the waves-per-workgroup measurements above).  Full rounds are the same load either way.
+// 1: the protein-only role's query channels are requested before the wait for the node's rows, and the x2h epilogue's residual row /
+// bias before the v path (ahead of the next item's row prefetch) instead of right before the epilogue.  (A/B knob; 0 = rounds 2 - 4.)
+#ifndef CBGX_EDGE_EARLY_LOADS
+#define CBGX_EDGE_EARLY_LOADS 1
+#endif
 #ifndef CBGX_EDGE_WAVE_MAJOR
 #define CBGX_EDGE_WAVE_MAJOR 1
 #endif
@@ -335,6 +340,15 @@ __device__ __forceinline__ void edge_body(
         const int i = __builtin_amdgcn_readfirstlane(g.node), d = g.d, lig_i = g.lig_i;
         const bool more = k + i_step < i_end;   // wave-uniform
         const int k_next = k + i_step;
+        // PP: the node's eight query channels of head c (32 bytes per lane), folded in k half 0.  Requested BEFORE the wait for the
+        // rows below: in the latency regime (one node per wave: the rows were requested a moment ago) the two round trips then
+        // overlap instead of following each other -- the fold sits one short MFMA block behind the top of the iteration
+        float4 q8a = {0.f, 0.f, 0.f, 0.f}, q8b = {0.f, 0.f, 0.f, 0.f};
+        if (PP && CBGX_EDGE_EARLY_LOADS) {
+            const gptr qp = sbase(Qt + (size_t)i * H);
+            const unsigned oq8 = vop(32 * c);
+            q8a = ldo4(qp, oq8); q8b = ldo4(qp, oq8 + 16);
+        }
         // both halves' PD[i] + PS_k[j] as soon as the rows (requested one epilogue ago) are here: the 24 gather registers
         // are then free for this iteration's other gathers
         floatx4 acc0[8], acc1[8];
@@ -362,12 +376,12 @@ __device__ __forceinline__ void edge_body(
         __builtin_amdgcn_sched_barrier(0);
         // this node's folded query row (B operand of the score MFMAs): consumed after the first pre-activation block
         float4 qrow[8];
-        float4 q8a = {0.f, 0.f, 0.f, 0.f}, q8b = {0.f, 0.f, 0.f, 0.f};
-        if (PP) {   // the eight query channels of head c (32 bytes per lane instead of the 512 of a folded row); folded in k half 0
+        if (PP && !CBGX_EDGE_EARLY_LOADS) {
             const gptr qp = sbase(Qt + (size_t)i * H);
             const unsigned oq8 = vop(32 * c);
             q8a = ldo4(qp, oq8); q8b = ldo4(qp, oq8 + 16);
-        } else {
+        }
+        if (!PP) {
             const gptr qp = sbase(Qt + (size_t)i * HEADS * H);
             const unsigned oqr = vop((c * H + 4 * q) * 4);
 #pragma unroll
@@ -527,6 +541,13 @@ __device__ __forceinline__ void edge_body(
                     sw += w[hf][r];
                 }
             sw = xrow_sum(sw);   // sum_e alpha e_w for head a = c
+            // residual row and bias of this lane's two outputs, used after the Wbv products of the epilogue: requested here, ahead
+            // of the next item's 24-row prefetch (vmcnt retires in order: behind it, the wait for these two words drained the
+            // prefetch -- and in the latency regime was a round trip of its own)
+            const int n0 = 8 * c + 2 * q;
+            const unsigned on0 = vop(n0 * 4);
+            float2 hres, bias2;
+            if (CBGX_EDGE_EARLY_LOADS) { hres = ldo2(sbase(h + (size_t)i * H), on0); bias2 = ldo2(sbase(att + A_BBV), on0); }
             // ---- v path, channel-major, one half at a time: lane (c, q) reg r <-> edge 4q + r + 16hf, m = 8c + t
             // aggregated straight into s2[t] = hid_v^T . w : lane (c = head a, q) reg r' <-> channel 64(t>>2) + 16q + 4r' + (t&3)
             floatx4 s2[8];
@@ -624,12 +645,9 @@ __device__ __forceinline__ void edge_body(
 #pragma unroll
                 for (int t = 0; t < 8; ++t) ps1[t] = ldo4(sbase(P), o1 + 64 * t);
             }
-            // residual row and bias of this lane's two outputs: requested here, used after the Wbv products; then the next
-            // node's neighbour row in the E1 mapping (last in the queue: it is only needed at the top of the next iteration)
-            const int n0 = 8 * c + 2 * q;
-            const unsigned on0 = vop(n0 * 4);
-            const float2 hres = ldo2(sbase(h + (size_t)i * H), on0);
-            const float2 bias2 = ldo2(sbase(att + A_BBV), on0);
+            // (the residual row and bias of this lane's two outputs were requested before the v path); the next node's neighbour
+            // row in the E1 mapping is last in the queue: it is only needed at the top of the next iteration
+            if (!CBGX_EDGE_EARLY_LOADS) { hres = ldo2(sbase(h + (size_t)i * H), on0); bias2 = ldo2(sbase(att + A_BBV), on0); }
             {
                 const gptr nrow2 = sbase(nbr + (size_t)inext * KNN);
                 const unsigned oq2 = vop(16 * q);

@@ -182,6 +182,11 @@ hipError_t launch_step_epilogue(const float* x_den, const float* logits, const i
                                 const float* c_lig, const uint8_t* gen_lig, int n_lig, int C, int t,
                                 const float* const* tabs, float log_c, const float* eps, const float* u, float* x_next,
                                 float* c_next, int32_t* v_next, hipStream_t s, int32_t* t_ptr = nullptr);
+// epilogue of step t + prologue of step t - 1 (the composed rows x[lig_rows], h[lig_rows] of the next denoiser call) in one launch
+hipError_t launch_step_boundary(const float* x_den, const float* logits, const int32_t* lig_rows, const float* x_lig,
+                                const float* c_lig, const uint8_t* gen_lig, int n_lig, int C, int t, const float* const* tabs,
+                                float log_c, const float* eps, const float* u, float* x_next, float* c_next, const float* emb_w,
+                                const float* emb_b, const float* ind_w, const float* ind_b, float* x, float* h, hipStream_t s);
 hipError_t launch_diffbp_epilogue(const float* x_den, const float* x_com, const float* x_in, const float* logits,
                                   const int32_t* lig_rows, const int32_t* lig_ptr, const float* x_lig, const float* c_lig,
                                   const uint8_t* gen_lig, int n_graphs, int C, int t, int T, const float* acp_tab,

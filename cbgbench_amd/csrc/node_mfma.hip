@@ -1006,7 +1006,10 @@ __global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __rest
                                                            const int32_t* __restrict__ deg, const int32_t* __restrict__ graph_ptr,
                                                            GraphListJobs jobs, int cached, int prune,
                                                            uint8_t* __restrict__ d1_out) {
-    __shared__ uint8_t F[GF_COUNT][GRAPH_LISTS_MAX_NODES];
+    // (+ 16: slot GRAPH_LISTS_MAX_NODES of every array is a dump for the stores of pairs that have nothing to mark -- an
+    // unconditional byte store to a selected address instead of a branch per mark: the first version spent 2 000 of its 2 900
+    // instructions per level on exec-mask bookkeeping, 24 us on the one CU that holds a one-graph batch)
+    __shared__ uint8_t F[GF_COUNT][GRAPH_LISTS_MAX_NODES + 16];
     __shared__ int s_cnt[LIST_JOBS_MAX][16];
     __shared__ int s_base[LIST_JOBS_MAX];
     const int gs = graph_ptr[blockIdx.x], n = graph_ptr[blockIdx.x + 1] - gs;
@@ -1035,7 +1038,11 @@ __global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __rest
             jl[u] = nbr[(size_t)gs * KNN + min(t, n_pairs - 1)];
         }
     }
-    for (int level = 0; level < levels; ++level) {
+    constexpr int DUMP = GRAPH_LISTS_MAX_NODES;
+    // one level = every pair once; one straight-line body per level (no per-pair branch), a pair past the end marks nothing (all
+    // its stores go to the dump slot)
+    // (bitwise & / | on 0 / 1 ints and unconditional reads: `a && F[..]` compiles to a branch around the read)
+    auto pairs = [&](auto body) {
         for (int u0 = 0; u0 * 1024 < n_pairs; u0 += GL_KEEP) {
             if (!keep) {
 #pragma unroll
@@ -1047,42 +1054,63 @@ __global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __rest
 #pragma unroll
             for (int u = 0; u < GL_KEEP; ++u) {
                 const int t = tid + 1024 * (u0 + u);
-                if (t >= n_pairs) continue;
-                const int i = t >> 5, e = t & 31;
-                const bool valid = jl[u] >= 0;
+                const int in = t < n_pairs;
+                const int i = min(t, n_pairs - 1) >> 5;
+                const int valid = in & (jl[u] >= 0), e0 = in & ((t & 31) == 0);
                 const int j = valid ? jl[u] - gs : i;
-                if (level == 0) {
-                    const bool g = F[GF_GEN][i] != 0, l = F[GF_LIG][i] != 0;
-                    if (e == 0 && (g || l)) F[GF_a1][i] = 1;
-                    if (g && valid) F[GF_a1][j] = 1;
-                    if ((e == 0 && l) || (valid && F[GF_LIG][j])) F[GF_d1][i] = 1;
-                } else if (level == 1) {
-                    if (prune) {
-                        const bool a = F[GF_a1][i] != 0;
-                        if (e == 0 && a) F[GF_a2][i] = 1;
-                        if (a && valid) F[GF_a2][j] = 1;
-                    }
-                    if (cached) {
-                        const bool d = F[Dx][i] != 0;
-                        if ((e == 0 && d) || (valid && F[Dx][j])) F[GF_D2][i] = 1;
-                        if (e == 0 && d) F[GF_S1][i] = 1;
-                        if (d && valid) F[GF_S1][j] = 1;
-                    }
-                } else {
-                    if (prune) {
-                        const bool a = F[GF_a2][i] != 0;
-                        if (e == 0 && a) F[GF_a3][i] = 1;
-                        if (a && valid) F[GF_a3][j] = 1;
-                    }
-                    if (cached) {
-                        const bool d = F[GF_D2][i] != 0;
-                        if (e == 0 && d) F[GF_S2][i] = 1;
-                        if (d && valid) F[GF_S2][j] = 1;
-                    }
-                }
+                body(i, j, valid, e0);
             }
         }
         __syncthreads();
+    };
+    auto mark = [&](int f, int cond, int k) { F[f][cond ? k : DUMP] = 1; };
+    pairs([&](int i, int j, int valid, int e0) {
+        const int g = F[GF_GEN][i] != 0, l = F[GF_LIG][i] != 0, lj = F[GF_LIG][j] != 0;
+        mark(GF_a1, e0 & (g | l), i);
+        mark(GF_a1, g & valid, j);
+        mark(GF_d1, (e0 & l) | (valid & lj), i);
+    });
+    if (levels > 1) {
+        if (prune && cached) {
+            pairs([&](int i, int j, int valid, int e0) {
+                const int a = F[GF_a1][i] != 0, d = F[Dx][i] != 0, dj = F[Dx][j] != 0;
+                mark(GF_a2, e0 & a, i);
+                mark(GF_a2, a & valid, j);
+                mark(GF_D2, (e0 & d) | (valid & dj), i);
+                mark(GF_S1, e0 & d, i);
+                mark(GF_S1, d & valid, j);
+            });
+            pairs([&](int i, int j, int valid, int e0) {
+                const int a = F[GF_a2][i] != 0, d = F[GF_D2][i] != 0;
+                mark(GF_a3, e0 & a, i);
+                mark(GF_a3, a & valid, j);
+                mark(GF_S2, e0 & d, i);
+                mark(GF_S2, d & valid, j);
+            });
+        } else if (prune) {
+            pairs([&](int i, int j, int valid, int e0) {
+                const int a = F[GF_a1][i] != 0;
+                mark(GF_a2, e0 & a, i);
+                mark(GF_a2, a & valid, j);
+            });
+            pairs([&](int i, int j, int valid, int e0) {
+                const int a = F[GF_a2][i] != 0;
+                mark(GF_a3, e0 & a, i);
+                mark(GF_a3, a & valid, j);
+            });
+        } else {
+            pairs([&](int i, int j, int valid, int e0) {
+                const int d = F[Dx][i] != 0, dj = F[Dx][j] != 0;
+                mark(GF_D2, (e0 & d) | (valid & dj), i);
+                mark(GF_S1, e0 & d, i);
+                mark(GF_S1, d & valid, j);
+            });
+            pairs([&](int i, int j, int valid, int e0) {
+                const int d = F[GF_D2][i] != 0;
+                mark(GF_S2, e0 & d, i);
+                mark(GF_S2, d & valid, j);
+            });
+        }
     }
     if (d1_out)
         for (int k = tid; k < n; k += 1024) d1_out[gs + k] = F[GF_d1][k];

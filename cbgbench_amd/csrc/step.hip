@@ -107,6 +107,96 @@ __global__ __launch_bounds__(256) void step_epilogue_kernel(
     if (v_next) v_next[a] = v;
 }
 
+// ---- TargetDiff, epilogue of step t and prologue of step t - 1 in ONE launch (round 5) ---------------------------------------------
+// The prologue of a step consumes exactly what the epilogue of the step before it produced, so a sampler that runs step after step
+// can have the epilogue write the composed rows as well: x[row] = x_next, h[row] = ligand_atom_emb(c_next) + ligand_indicator(1).
+// One 128-thread workgroup per ligand atom (the prologue's shape): lanes 0..C-1 of its first wave evaluate the type posterior one
+// class each -- the one-thread-per-atom epilogue walked 13 classes x 7 transcendental calls serially, 12 us for 25 atoms -- with
+// every sum over the classes taken in the serial kernel's order (a broadcast loop), so the two kernels agree bit for bit; then all
+// 128 threads write the feature row.  11.8 + 5.3 us of a 550 us one-graph step become one launch.
+__global__ __launch_bounds__(128) void step_boundary_kernel(
+    const float* __restrict__ x_den, const float* __restrict__ logits, const int32_t* __restrict__ lig_rows,
+    const float* __restrict__ x_lig, const float* __restrict__ c_lig, const uint8_t* __restrict__ gen_lig, int n_lig, int C,
+    int t, const float* __restrict__ c0_tab, const float* __restrict__ ct_tab, const float* __restrict__ logvar_tab,
+    const float* __restrict__ log_alpha, const float* __restrict__ log_1m_alpha, const float* __restrict__ log_acp,
+    const float* __restrict__ log_1m_acp, float log_c, const float* __restrict__ eps, const float* __restrict__ u,
+    float* __restrict__ x_next, float* __restrict__ c_next, const float* __restrict__ emb_w, const float* __restrict__ emb_b,
+    const float* __restrict__ ind_w, const float* __restrict__ ind_b, float* __restrict__ x, float* __restrict__ h) {
+    __shared__ float s_c[MAXC];
+    const int a = blockIdx.x, m = threadIdx.x;
+    if (a >= n_lig) return;
+    const int row = lig_rows[a];
+    const bool gen = gen_lig[a] != 0;
+    if (m < 64) {      // the first wave: lane k <-> class k (lanes >= C idle along)
+        const int k = m;
+        const bool live = k < C;
+        const int kc = live ? k : 0;
+        // ---- positions (lanes 0..2)
+        if (k < 3) {
+            const float c0 = c0_tab[t], ct = ct_tab[t];
+            const float sigma = t > 0 ? expf(0.5f * logvar_tab[t]) : 0.f;
+            const float xt = x_lig[3 * a + k];
+            const float xs = (c0 * x_den[3 * row + k] + ct * xt) + sigma * eps[3 * a + k];
+            const float xn = gen ? xs : xt;
+            x_next[3 * a + k] = xn;
+            x[3 * row + k] = xn;
+        }
+        // ---- atom types: the serial kernel's arithmetic, one class per lane; sums over classes in index order
+        const float lgk = logits[(size_t)row * C + kc];
+        float mx = live ? lgk : -INFINITY;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float ek = expf(lgk - mx);
+        float se = 0.f;
+        for (int j = 0; j < C; ++j) se += __shfl(ek, j, 64);
+        const float lse = mx + logf(se);
+        const int tm1 = t > 0 ? t - 1 : 0;
+        const float a0 = log_acp[tm1], b0 = log_1m_acp[tm1] - log_c;
+        const float a1 = log_alpha[t], b1 = log_1m_alpha[t] - log_c;
+        const float ck = c_lig[(size_t)a * C + kc];
+        const float lq0 = log_add_exp((lgk - lse) + a0, b0);
+        const float lq1 = log_add_exp(logf(ck + 1e-8f) + a1, b1);
+        const float un = lq0 + lq1;
+        float umx = live ? un : -INFINITY;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) umx = fmaxf(umx, __shfl_xor(umx, o, 64));
+        const float euk = expf(un - umx);
+        float us = 0.f;
+        for (int j = 0; j < C; ++j) us += __shfl(euk, j, 64);
+        const float ulse = umx + logf(us);
+        const float g = -logf(-logf(u[(size_t)a * C + kc] + 1e-30f) + 1e-30f);
+        const float sk = g + (un - ulse);
+        // first index of the maximum (the serial scan's strict '>'): of the current type vector and of the perturbed log-posterior
+        float cmx = live ? ck : -INFINITY, smx = live ? sk : -INFINITY;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { cmx = fmaxf(cmx, __shfl_xor(cmx, o, 64)); smx = fmaxf(smx, __shfl_xor(smx, o, 64)); }
+        const unsigned long long mc = __ballot(live && ck == cmx), ms = __ballot(live && sk == smx);
+        const int cur = mc ? __builtin_ctzll(mc) : 0, best = ms ? __builtin_ctzll(ms) : 0;
+        const int v = gen ? best : cur;
+        if (live) {
+            const float cn = k == v ? 1.f : 0.f;
+            c_next[(size_t)a * C + k] = cn;
+            s_c[k] = cn;
+        }
+    }
+    __syncthreads();
+    // ---- feature row of the next step (step_prologue_kernel)
+    float acc = 0.f;
+    for (int k = 0; k < C; ++k) acc = fmaf(emb_w[m * C + k], s_c[k], acc);
+    h[(size_t)row * H + m] = (acc + emb_b[m]) + (ind_w[m] + ind_b[m]);
+}
+
+hipError_t launch_step_boundary(const float* x_den, const float* logits, const int32_t* lig_rows, const float* x_lig,
+                                const float* c_lig, const uint8_t* gen_lig, int n_lig, int C, int t, const float* const* tabs,
+                                float log_c, const float* eps, const float* u, float* x_next, float* c_next, const float* emb_w,
+                                const float* emb_b, const float* ind_w, const float* ind_b, float* x, float* h, hipStream_t s) {
+    if (n_lig == 0) return hipSuccess;
+    hipLaunchKernelGGL(step_boundary_kernel, dim3(n_lig), dim3(128), 0, s, x_den, logits, lig_rows, x_lig, c_lig, gen_lig, n_lig, C,
+                       t, tabs[0], tabs[1], tabs[2], tabs[3], tabs[4], tabs[5], tabs[6], log_c, eps, u, x_next, c_next, emb_w, emb_b,
+                       ind_w, ind_b, x, h);
+    return hipGetLastError();
+}
+
 // ---- DiffBP: one wave per graph ----------------------------------------------------------------------------------------
 // diffbp.py:262-297 after the two network calls:
 //   noise  = x_den[lig] - x_in[lig],  noise -= mean_graph(noise)                 (CoMPredictor, diffbp.py:79-101)

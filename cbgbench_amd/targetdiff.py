@@ -650,6 +650,7 @@ class TargetDiff(BatchesInFlight, nn.Module):
         return st
 
     NOISE_CHUNK = 16
+    fuse_step_boundary = True      # epilogue(t) + prologue(t - 1) as one kernel (False: the two kernels, for tests)
 
     def _step_noise(self, st, n_lig, C, dev):
         """(eps [n_lig,3] ~ N(0, I), u [n_lig,C] ~ U(0, 1)) of one step.  The reference draws randn_like(x_lig) then
@@ -673,11 +674,17 @@ class TargetDiff(BatchesInFlight, nn.Module):
         n_lig, C = st["n_lig"], self.num_classes
         x_lig, c_lig = st["x_lig"], st["c_lig"]
         emb = self.context_embedder
-        _native.check(lib.cbgx_targetdiff_prologue(
-            _native.ptr(x_lig), _native.ptr(c_lig), _native.ptr(st["lig_rows32"]), n_lig, C,
-            _native.ptr(emb.ligand_atom_emb.weight), _native.ptr(emb.ligand_atom_emb.bias),
-            _native.ptr(emb.ligand_indicator.weight), _native.ptr(emb.ligand_indicator.bias),
-            _native.ptr(st["x"]), _native.ptr(st["h"]), stream), "cbgx_targetdiff_prologue")
+        # The composed rows of the ligand atoms are already in place when the previous step's boundary kernel wrote them from
+        # exactly this state (same tensor objects, not written since: identity + version counters); otherwise -- the first step
+        # of a run, a caller that replaced or edited st["x_lig"] / st["c_lig"] -- the prologue kernel composes them.
+        comp = st.get("_composed")
+        if not (self.fuse_step_boundary and comp is not None and comp[0] is x_lig and comp[1] is c_lig
+                and comp[2] == x_lig._version and comp[3] == c_lig._version):
+            _native.check(lib.cbgx_targetdiff_prologue(
+                _native.ptr(x_lig), _native.ptr(c_lig), _native.ptr(st["lig_rows32"]), n_lig, C,
+                _native.ptr(emb.ligand_atom_emb.weight), _native.ptr(emb.ligand_atom_emb.bias),
+                _native.ptr(emb.ligand_indicator.weight), _native.ptr(emb.ligand_indicator.bias),
+                _native.ptr(st["x"]), _native.ptr(st["h"]), stream), "cbgx_targetdiff_prologue")
         xo, _, logits = self.denoiser(x=st["x"], h=st["h"], batch_idx=st["batch_idx"], lig_flag=st["lig_flag"],
                                       gen_flag=st["gen_flag"], graph_ptr=st["graph_ptr"], need_h=False,
                                       static_h=st["static_h"])
@@ -689,11 +696,23 @@ class TargetDiff(BatchesInFlight, nn.Module):
             x_next, c_next = st["traj_x"][t_idx], st["traj_c"][t_idx]
         else:
             x_next, c_next = torch.empty_like(x_lig), torch.empty_like(c_lig)
-        _native.check(lib.cbgx_targetdiff_epilogue(
-            _native.ptr(xo), _native.ptr(logits), _native.ptr(st["lig_rows32"]), _native.ptr(x_lig), _native.ptr(c_lig),
-            _native.ptr(st["gen_l8"]), n_lig, C, int(t_idx), self.num_diffusion_timesteps, st["tables"],
-            _native.ptr(eps), _native.ptr(u), _native.ptr(x_next), _native.ptr(c_next), None, stream),
-            "cbgx_targetdiff_epilogue")
+        if self.fuse_step_boundary and t_idx > 0:
+            # epilogue of this step + prologue of the next in one launch (cbgx_targetdiff_step_boundary: same arithmetic)
+            _native.check(lib.cbgx_targetdiff_step_boundary(
+                _native.ptr(xo), _native.ptr(logits), _native.ptr(st["lig_rows32"]), _native.ptr(x_lig), _native.ptr(c_lig),
+                _native.ptr(st["gen_l8"]), n_lig, C, int(t_idx), self.num_diffusion_timesteps, st["tables"],
+                _native.ptr(eps), _native.ptr(u), _native.ptr(x_next), _native.ptr(c_next),
+                _native.ptr(emb.ligand_atom_emb.weight), _native.ptr(emb.ligand_atom_emb.bias),
+                _native.ptr(emb.ligand_indicator.weight), _native.ptr(emb.ligand_indicator.bias),
+                _native.ptr(st["x"]), _native.ptr(st["h"]), stream), "cbgx_targetdiff_step_boundary")
+            st["_composed"] = (x_next, c_next, x_next._version, c_next._version)
+        else:
+            _native.check(lib.cbgx_targetdiff_epilogue(
+                _native.ptr(xo), _native.ptr(logits), _native.ptr(st["lig_rows32"]), _native.ptr(x_lig), _native.ptr(c_lig),
+                _native.ptr(st["gen_l8"]), n_lig, C, int(t_idx), self.num_diffusion_timesteps, st["tables"],
+                _native.ptr(eps), _native.ptr(u), _native.ptr(x_next), _native.ptr(c_next), None, stream),
+                "cbgx_targetdiff_epilogue")
+            st["_composed"] = None
         st["x_lig"], st["c_lig"] = x_next, c_next
         return st
 

@@ -207,6 +207,16 @@ int cbgx_targetdiff_epilogue(const float *x_den, const float *logits, const int3
                              int num_timesteps, const float *const *tables, const float *eps, const float *u,
                              float *x_next, float *c_next, int32_t *v_next, void *stream);
 
+/* Epilogue of step t and prologue of step t - 1 in one launch (round 5): cbgx_targetdiff_epilogue's outputs x_next / c_next, and
+ * in the same launch the composed rows of the NEXT denoiser call -- x[lig_rows] = x_next, h[lig_rows] = ligand_atom_emb(c_next) +
+ * ligand_indicator(1) -- exactly what cbgx_targetdiff_prologue would write from (x_next, c_next).  Same arithmetic, bit for bit,
+ * as the two calls it replaces (targetdiff.py:164-182 followed by :155-158 of the next iteration); x_den must not alias x. */
+int cbgx_targetdiff_step_boundary(const float *x_den, const float *logits, const int32_t *lig_rows, const float *x_lig,
+                                  const float *c_lig, const uint8_t *gen_lig, int n_lig, int num_classes, int t,
+                                  int num_timesteps, const float *const *tables, const float *eps, const float *u,
+                                  float *x_next, float *c_next, const float *lig_emb_w, const float *lig_emb_b,
+                                  const float *ind_w, const float *ind_b, float *x, float *h, void *stream);
+
 /* Trajectory-resident variants: the ligand state lives in traj_x [T+1, n_lig, 3] / traj_c [T+1, n_lig, C] (slot s+1 = the
  * state entering step s, slot 0 = the final state) and the step index in a device int (*t_dev).  The prologue reads slot
  * *t_dev + 1; the epilogue reads slot *t_dev + 1, writes slot *t_dev and then decrements *t_dev.  No argument changes
