@@ -552,9 +552,17 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
         HIP_TRY(launch_graph_cache_begin(x, graph_ptr, n_graphs, lig_flag, static_r32sq, n_nodes, w.fD1, w.fw_list[0], w.fw_count,
                                          static_nbr, static_deg, static_ew, w.nbr, w.deg, w.e_w, static_h1, static_h2, w.hbuf[0],
                                          w.hbuf[1], s));
-        HIP_TRY(launch_knn_merge(x, graph_ptr, n_graphs, n_nodes, lig_flag, static_nbr, static_deg, w.nbr, w.deg, s, w.fw_list[0],
-                                 w.fw_count));
-        HIP_TRY(launch_gate_mfma(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s, w.fw_list[0], w.fw_count));
+        // the D1 centres' merged neighbour lists and gate values (kept pocket entries carry their cached value to their new
+        // rank; the gate MLP runs on the ligand atoms that entered the list): one launch.  CBGX_MERGE_GATE=0: the two kernels.
+        static const bool merge_gate = [] { const char* e = getenv("CBGX_MERGE_GATE"); return !e || atoi(e) != 0; }();
+        if (merge_gate) {
+            HIP_TRY(launch_knn_merge_gate(packed, x, graph_ptr, n_graphs, n_nodes, lig_flag, static_nbr, static_deg, static_ew, w.nbr,
+                                          w.deg, w.e_w, s, w.fw_list[0], w.fw_count));
+        } else {
+            HIP_TRY(launch_knn_merge(x, graph_ptr, n_graphs, n_nodes, lig_flag, static_nbr, static_deg, w.nbr, w.deg, s, w.fw_list[0],
+                                     w.fw_count));
+            HIP_TRY(launch_gate_mfma(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s, w.fw_list[0], w.fw_count));
+        }
     } else {
         HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, w.nbr, w.deg, s));
         HIP_TRY(launch_gate(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s));

@@ -70,8 +70,9 @@ __device__ __forceinline__ float dist2_exact2(float ax, float ay, float az, floa
 constexpr int KNN_SLOTS = 12;
 
 // the search of one centre node i by the wave it is called from: every candidate of the graph is scanned
-__device__ __forceinline__ void knn_scan_node(const float* __restrict__ x, const int32_t* __restrict__ graph_ptr, int n_graphs,
-                                              int i, int lane, int32_t* __restrict__ nbr, int32_t* __restrict__ deg) {
+// -> lane r < 32: the r-th neighbour (-1 past the degree)
+__device__ __forceinline__ int knn_scan_node(const float* __restrict__ x, const int32_t* __restrict__ graph_ptr, int n_graphs,
+                                             int i, int lane, int32_t* __restrict__ nbr, int32_t* __restrict__ deg) {
     int lo_g = 0, hi_g = n_graphs;
     while (hi_g - lo_g > 1) {
         const int mid = (lo_g + hi_g) >> 1;
@@ -126,6 +127,7 @@ __device__ __forceinline__ void knn_scan_node(const float* __restrict__ x, const
     }
     if (lane < KNN) nbr[(size_t)i * KNN + lane] = mine;
     if (lane == 0) deg[i] = d < 0 ? 0 : d;
+    return mine;
 }
 
 __global__ __launch_bounds__(256) void knn_graph_reg_kernel(const float* __restrict__ x,
@@ -227,6 +229,52 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 constexpr int GT = GH / 16;  // 10 tiles
 
+// the gate value of this lane's edge (i, j) -- lane (c = edge of the tile, q), result valid in every q row -- from the LDS image
+// (GATE_IMG layout); `mu` = the lane's five rbf centres 4 s + q.  The arithmetic of a column does not depend on the other columns
+// of the tile, so any assignment of edges to lanes gives the same bits.
+__device__ __forceinline__ float gate_tile_value(const float* __restrict__ lds, const float (&mu)[5], float b2, int lane, int q,
+                                                 float xi, float yi, float zi, float xj, float yj, float zj) {
+    const float* l_frag = lds;
+    const float* l_b1 = lds + GT * 5 * 64;
+    const float* l_g = l_b1 + GH;
+    const float* l_be = l_g + GH;
+    const float* l_w2 = l_be + GH;
+    const float rx = xi - xj, ry = yi - yj, rz = zi - zj;
+    const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
+    float R[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) { const float u = dist - mu[s]; R[s] = expf(-0.5f * (u * u)); }
+    floatx4 acc[GT];
+#pragma unroll
+    for (int t = 0; t < GT; ++t) {
+        const float4 b = *reinterpret_cast<const float4*>(l_b1 + 16 * t + 4 * q);
+        acc[t] = floatx4{b.x, b.y, b.z, b.w};
+    }
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int t = 0; t < GT; ++t) acc[t] = MFMA(l_frag[(t * 5 + s) * 64 + lane], R[s], acc[t]);
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < GT; ++t)
+        v += (acc[t].x * acc[t].x + acc[t].y * acc[t].y) + (acc[t].z * acc[t].z + acc[t].w * acc[t].w);
+    v = g_xrow_sum(v);
+    const float rstd = 1.f / sqrtf(v * (1.f / GH) + 1e-5f);
+    float z = 0.f;
+#pragma unroll
+    for (int t = 0; t < GT; ++t) {
+        const float4 g = *reinterpret_cast<const float4*>(l_g + 16 * t + 4 * q);
+        const float4 be = *reinterpret_cast<const float4*>(l_be + 16 * t + 4 * q);
+        const float4 w2 = *reinterpret_cast<const float4*>(l_w2 + 16 * t + 4 * q);
+        z = fmaf(fmaxf((acc[t].x * rstd) * g.x + be.x, 0.f), w2.x, z);
+        z = fmaf(fmaxf((acc[t].y * rstd) * g.y + be.y, 0.f), w2.y, z);
+        z = fmaf(fmaxf((acc[t].z * rstd) * g.z + be.z, 0.f), w2.z, z);
+        z = fmaf(fmaxf((acc[t].w * rstd) * g.w + be.w, 0.f), w2.w, z);
+    }
+    z = g_xrow_sum(z) + b2;
+    return 1.f / (1.f + expf(-z));
+}
+
 __global__ __launch_bounds__(256) void edge_gate_mfma_kernel(const float* __restrict__ wts,
                                                              const float* __restrict__ x,
                                                              const int32_t* __restrict__ nbr,
@@ -251,12 +299,7 @@ __global__ __launch_bounds__(256) void edge_gate_mfma_kernel(const float* __rest
         }
     }
     __syncthreads();
-    const float* l_frag = lds;                       // [10][5][64]
-    const float* l_b1 = lds + GT * 5 * 64;           // centred bias [160]
-    const float* l_g = l_b1 + GH;
-    const float* l_be = l_g + GH;
-    const float* l_w2 = l_be + GH;
-    const float b2 = wts[GATE_B2];
+    const float b2 = wts[GATE_B2];      // (image layout: frag [10][5][64] | centred bias | gamma | beta | w2: gate_tile_value)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
     float mu[5];
 #pragma unroll
@@ -271,42 +314,161 @@ __global__ __launch_bounds__(256) void edge_gate_mfma_kernel(const float* __rest
             const int e = c + 16 * hf;
             const bool valid = e < d;
             const int j = valid ? nbr[(size_t)i * KNN + e] : i;
-            const float rx = xi - x[3 * j], ry = yi - x[3 * j + 1], rz = zi - x[3 * j + 2];
-            const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
-            float R[5];
-#pragma unroll
-            for (int s = 0; s < 5; ++s) { const float u = dist - mu[s]; R[s] = expf(-0.5f * (u * u)); }
-            floatx4 acc[GT];
-#pragma unroll
-            for (int t = 0; t < GT; ++t) {
-                const float4 b = *reinterpret_cast<const float4*>(l_b1 + 16 * t + 4 * q);
-                acc[t] = floatx4{b.x, b.y, b.z, b.w};
-            }
-#pragma unroll
-            for (int s = 0; s < 5; ++s)
-#pragma unroll
-                for (int t = 0; t < GT; ++t) acc[t] = MFMA(l_frag[(t * 5 + s) * 64 + lane], R[s], acc[t]);
-            float v = 0.f;
-#pragma unroll
-            for (int t = 0; t < GT; ++t)
-                v += (acc[t].x * acc[t].x + acc[t].y * acc[t].y) + (acc[t].z * acc[t].z + acc[t].w * acc[t].w);
-            v = g_xrow_sum(v);
-            const float rstd = 1.f / sqrtf(v * (1.f / GH) + 1e-5f);
-            float z = 0.f;
-#pragma unroll
-            for (int t = 0; t < GT; ++t) {
-                const float4 g = *reinterpret_cast<const float4*>(l_g + 16 * t + 4 * q);
-                const float4 be = *reinterpret_cast<const float4*>(l_be + 16 * t + 4 * q);
-                const float4 w2 = *reinterpret_cast<const float4*>(l_w2 + 16 * t + 4 * q);
-                z = fmaf(fmaxf((acc[t].x * rstd) * g.x + be.x, 0.f), w2.x, z);
-                z = fmaf(fmaxf((acc[t].y * rstd) * g.y + be.y, 0.f), w2.y, z);
-                z = fmaf(fmaxf((acc[t].z * rstd) * g.z + be.z, 0.f), w2.z, z);
-                z = fmaf(fmaxf((acc[t].w * rstd) * g.w + be.w, 0.f), w2.w, z);
-            }
-            z = g_xrow_sum(z) + b2;
-            if (q == 0) e_w[(size_t)i * KNN + e] = valid ? 1.f / (1.f + expf(-z)) : 0.f;
+            const float gv = gate_tile_value(lds, mu, b2, lane, q, xi, yi, zi, x[3 * j], x[3 * j + 1], x[3 * j + 2]);
+            if (q == 0) e_w[(size_t)i * KNN + e] = valid ? gv : 0.f;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Graph-cached calls, round 5: the listed centres' new neighbour lists AND their gate values in one launch.
+// knn_merge_kernel + edge_gate_mfma_kernel re-evaluated the gate MLP on all 32 edges of every listed centre, although a protein
+// centre's edges to protein atoms keep their cached values (the gate is a function of the distance between two atoms that never
+// move: unitransformer.py:109-112): the pocket entry at position p of the static list lands at rank rs of the merged list and takes
+// its value e_w[i][rs] = static e_w[i][p] with it, and the MLP runs only on the ligand atoms that entered the list -- compacted to
+// the head of ONE 16-edge tile for most centres (a protein atom near the ligand has ~1 - 10 ligand neighbours) instead of two full
+// tiles.  Ligand centres (and graphs beyond the merge's limits) take the scan and the two full tiles as before.  Same arithmetic
+// per edge as edge_gate_mfma_kernel (gate_tile_value: a tile's columns are independent), so cached and uncached evaluations of a
+// state still agree bit for bit.  Persistent 4-wave workgroups (the 15 KB image is filled once per workgroup).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gm_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void knn_merge_gate_kernel(
+    const float* __restrict__ wts, const float* __restrict__ x, const int32_t* __restrict__ graph_ptr, int n_graphs,
+    const uint8_t* __restrict__ lig, const int32_t* __restrict__ s_nbr, const int32_t* __restrict__ s_deg,
+    const float* __restrict__ s_ew, int32_t* __restrict__ nbr, int32_t* __restrict__ deg, float* __restrict__ e_w,
+    const int* __restrict__ rows, const int* __restrict__ n_rows_ptr) {
+    __shared__ __attribute__((aligned(16))) float lds[GATE_IMG_SIZE];
+    __shared__ int s_j[4][KNN], s_rank[4][KNN], s_sel[4][KNN];
+    const int count = *n_rows_ptr;
+    if ((int)blockIdx.x * 4 >= count) return;        // no centre for this workgroup: no fill either
+    {   // LDS fill, all loads of the thread in flight together
+        typedef float fx4 __attribute__((ext_vector_type(4)));
+        constexpr int NV = ((int)GATE_IMG_SIZE / 4 + 255) / 256;
+        fx4 v[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int t = threadIdx.x + 256 * u;
+            v[u] = reinterpret_cast<const fx4*>(wts + GATE_IMG)[t < (int)GATE_IMG_SIZE / 4 ? t : (int)GATE_IMG_SIZE / 4 - 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int t = threadIdx.x + 256 * u;
+            if (t < (int)GATE_IMG_SIZE / 4) reinterpret_cast<fx4*>(lds)[t] = v[u];
+        }
+    }
+    __syncthreads();
+    const float b2 = wts[GATE_B2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    float mu[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) mu[s] = c_mu2[4 * s + q];
+    const unsigned NONE = 0xffffffffu;
+    for (int idx = blockIdx.x * 4 + wave; idx < count; idx += gridDim.x * 4) {
+        const int i = rows[idx];
+        int lo_g = 0, hi_g = n_graphs;
+        while (hi_g - lo_g > 1) {
+            const int mid = (lo_g + hi_g) >> 1;
+            if (graph_ptr[mid] <= i) lo_g = mid; else hi_g = mid;
+        }
+        const int gs = graph_ptr[lo_g], ge = graph_ptr[lo_g + 1];
+        // ligand atoms of the graph: the run of flagged rows at its end, counted over the last 128 rows
+        const int r0 = ge - 1 - lane, r1 = ge - 65 - lane;
+        const unsigned long long b0 = __ballot(r0 >= gs && lig[r0 >= gs ? r0 : gs] != 0);
+        const unsigned long long b1 = __ballot(r1 >= gs && lig[r1 >= gs ? r1 : gs] != 0);
+        const int n0 = b0 == ~0ull ? 64 : __builtin_ctzll(~b0);
+        const int n1 = n0 < 64 ? 0 : (b1 == ~0ull ? 64 : __builtin_ctzll(~b1));
+        const int nl = n0 + n1;
+        const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
+        float* ew_out = e_w + (size_t)i * KNN;
+        int jr;      // lane r < 32: the neighbour at rank r that needs a fresh gate value (-1: none)
+        if (lig[i] != 0 || nl >= 128 || ge - gs > 64 * KNN_SLOTS) {      // wave-uniform: the scan, every valid slot is new
+            jr = knn_scan_node(x, graph_ptr, n_graphs, i, lane, nbr, deg);
+            if (lane < KNN && jr < 0) ew_out[lane] = 0.f;
+        } else {
+            // ---- knn_merge_kernel's rank counting (same keys, same comparisons) ----
+            const int sd = s_deg[i];
+            const bool vs = lane < sd && lane < KNN;
+            const int js = vs ? s_nbr[(size_t)i * KNN + lane] : i;
+            const float ews = s_ew[(size_t)i * KNN + (lane < KNN ? lane : 0)];
+            const unsigned ks_h = vs ? __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * js], x[3 * js + 1], x[3 * js + 2])) : NONE;
+            const unsigned ks_l = vs ? (unsigned)js : NONE;
+            const int ls = ge - nl;
+            const bool v0 = lane < nl, v1 = lane + 64 < nl;
+            const int j0 = v0 ? ls + lane : i, j1 = v1 ? ls + 64 + lane : i;
+            const unsigned k0_h = v0 ? __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * j0], x[3 * j0 + 1], x[3 * j0 + 2])) : NONE;
+            const unsigned k1_h = v1 ? __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * j1], x[3 * j1 + 1], x[3 * j1 + 2])) : NONE;
+            const unsigned k0_l = v0 ? (unsigned)j0 : NONE, k1_l = v1 ? (unsigned)j1 : NONE;
+            int rs = lane, r0k = 0, r1k = 0;      // ranks in the union
+            for (int t = 0; t < min(nl, 64); ++t) {
+                const unsigned bh = __builtin_amdgcn_readlane(k0_h, t), bl = __builtin_amdgcn_readlane(k0_l, t);
+                rs += key_less(bh, bl, ks_h, ks_l) ? 1 : 0;
+                r0k += key_less(bh, bl, k0_h, k0_l) ? 1 : 0;
+                r1k += key_less(bh, bl, k1_h, k1_l) ? 1 : 0;
+            }
+            for (int t = 0; t < nl - 64; ++t) {
+                const unsigned bh = __builtin_amdgcn_readlane(k1_h, t), bl = __builtin_amdgcn_readlane(k1_l, t);
+                rs += key_less(bh, bl, ks_h, ks_l) ? 1 : 0;
+                r0k += key_less(bh, bl, k0_h, k0_l) ? 1 : 0;
+                r1k += key_less(bh, bl, k1_h, k1_l) ? 1 : 0;
+            }
+            for (int p = 0; p < min(sd, KNN); ++p) {
+                const unsigned bh = __builtin_amdgcn_readlane(ks_h, p), bl = __builtin_amdgcn_readlane(ks_l, p);
+                r0k += key_less(bh, bl, k0_h, k0_l) ? 1 : 0;
+                r1k += key_less(bh, bl, k1_h, k1_l) ? 1 : 0;
+            }
+            const int d = min(KNN, min(sd, KNN) + nl);
+            int32_t* out = nbr + (size_t)i * KNN;
+            if (lane >= d && lane < KNN) { out[lane] = -1; ew_out[lane] = 0.f; }
+            if (vs && rs < KNN) { out[rs] = js; ew_out[rs] = ews; }      // a pocket entry keeps its gate value
+            if (v0 && r0k < KNN) out[r0k] = j0;
+            if (v1 && r1k < KNN) out[r1k] = j1;
+            if (lane == 0) deg[i] = d;
+            // the ligand atoms that entered the list, by rank
+            if (lane < KNN) s_j[wave][lane] = -1;
+            gm_wave_sync();
+            if (v0 && r0k < KNN) s_j[wave][r0k] = j0;
+            if (v1 && r1k < KNN) s_j[wave][r1k] = j1;
+            gm_wave_sync();
+            jr = lane < KNN ? s_j[wave][lane] : -1;
+        }
+        // ---- gate values of the new entries: compacted to the head of as few 16-edge tiles as they need ----
+        const bool need = lane < KNN && jr >= 0;
+        const unsigned m = (unsigned)(__ballot(need) & 0xffffffffull);
+        const int cnt = __popc(m);
+        if (need) {
+            const int pos = __popc(m & ((1u << lane) - 1u));
+            s_rank[wave][pos] = lane;
+            s_sel[wave][pos] = jr;
+        }
+        gm_wave_sync();
+        for (int t0 = 0; t0 < cnt; t0 += 16) {
+            const int k = t0 + c;
+            const bool valid = k < cnt;
+            const int j = valid ? s_sel[wave][k] : i;
+            const int rank = valid ? s_rank[wave][k] : 0;
+            const float gv = gate_tile_value(lds, mu, b2, lane, q, xi, yi, zi, x[3 * j], x[3 * j + 1], x[3 * j + 2]);
+            if (q == 0 && valid) ew_out[rank] = gv;
+        }
+        gm_wave_sync();      // the per-wave arrays are rewritten by the wave's next centre
+    }
+}
+
+hipError_t launch_knn_merge_gate(const float* packed, const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes,
+                                 const uint8_t* lig, const int32_t* s_nbr, const int32_t* s_deg, const float* s_ew, int32_t* nbr,
+                                 int32_t* deg, float* e_w, hipStream_t s, const int* rows, const int* n_rows) {
+    if (n_nodes == 0) return hipSuccess;
+    int grid = (n_nodes + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    profile_mark_begin(K_KNN, s);
+    hipLaunchKernelGGL(knn_merge_gate_kernel, dim3(grid), dim3(256), 0, s, packed, x, graph_ptr, n_graphs, lig, s_nbr, s_deg, s_ew,
+                       nbr, deg, e_w, rows, n_rows);
+    profile_mark_end(s);
+    return hipGetLastError();
 }
 
 // gate LDS image: frag [10][5][64] | b1c [160] | gamma [160] | beta [160] | w2 [160]

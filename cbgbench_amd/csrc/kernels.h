@@ -76,6 +76,11 @@ hipError_t launch_knn_reg(const float* x, const int32_t* graph_ptr, int n_graphs
 hipError_t launch_knn_merge(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, const uint8_t* lig,
                             const int32_t* s_nbr, const int32_t* s_deg, int32_t* nbr, int32_t* deg, hipStream_t s, const int* rows,
                             const int* n_rows);
+// graph-cached calls: the listed centres' merged neighbour lists and their gate values in one launch -- kept pocket entries carry
+// their cached gate value to their new rank, the gate MLP runs on the entries that are new (graph_mfma.hip, knn_merge_gate_kernel)
+hipError_t launch_knn_merge_gate(const float* packed, const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes,
+                                 const uint8_t* lig, const int32_t* s_nbr, const int32_t* s_deg, const float* s_ew, int32_t* nbr,
+                                 int32_t* deg, float* e_w, hipStream_t s, const int* rows, const int* n_rows);
 hipError_t launch_gate_mfma(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
                             float* e_w, hipStream_t s, const int* rows = nullptr, const int* n_rows = nullptr);
 hipError_t launch_lig_proximity(const float* x, const int32_t* graph_ptr, int n_graphs, const uint8_t* lig,
