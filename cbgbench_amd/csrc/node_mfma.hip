@@ -1001,32 +1001,28 @@ __global__ __launch_bounds__(BA_THREADS) void build_lists_kernel(ListJobs jobs, 
 }
 
 // ---- the same four steps for a small input in one launch: one 1024-thread workgroup per graph, flags in LDS (kernels.h) ----------
+// One 32-bit word per node holds all its flags (bit = GraphFlagId).  A level visits every (node i, slot e) pair once: it reads the
+// words of i and of the neighbour j, ORs what j contributes to i over the node's 32 lanes with a ballot (one atomic OR per node, by
+// the lane of slot 0) and ORs what i contributes to j into j's word (lanes with nothing to contribute are masked, waves without any
+// skip the instruction).  The first two versions kept one byte per flag and stored per mark -- ~8 LDS instructions per pair and
+// level on the ONE compute unit that holds a one-graph batch: 24 - 27 us, more than the four launches this kernel replaced
+// (profiles/step_timeline_r05[c-e]_p1s1.json); the words need two reads and at most two sparse atomics.
 __global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __restrict__ gen, const uint8_t* __restrict__ lig,
                                                            const uint8_t* __restrict__ d1_in, const int32_t* __restrict__ nbr,
                                                            const int32_t* __restrict__ deg, const int32_t* __restrict__ graph_ptr,
                                                            GraphListJobs jobs, int cached, int prune,
                                                            uint8_t* __restrict__ d1_out) {
-    // (+ 16: slot GRAPH_LISTS_MAX_NODES of every array is a dump for the stores of pairs that have nothing to mark -- an
-    // unconditional byte store to a selected address instead of a branch per mark: the first version spent 2 000 of its 2 900
-    // instructions per level on exec-mask bookkeeping, 24 us on the one CU that holds a one-graph batch)
-    __shared__ uint8_t F[GF_COUNT][GRAPH_LISTS_MAX_NODES + 16];
+    __shared__ unsigned F[GRAPH_LISTS_MAX_NODES];
     __shared__ int s_cnt[LIST_JOBS_MAX][16];
     __shared__ int s_base[LIST_JOBS_MAX];
     const int gs = graph_ptr[blockIdx.x], n = graph_ptr[blockIdx.x + 1] - gs;
     if (n <= 0 || n > GRAPH_LISTS_MAX_NODES) return;     // (the launcher only takes inputs whose total is within the bound)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int k = tid; k < n; k += 1024) {
-        F[GF_GEN][k] = gen[gs + k]; F[GF_LIG][k] = lig[gs + k]; F[GF_D1IN][k] = d1_in ? d1_in[gs + k] : 0;
-#pragma unroll
-        for (int f = GF_d1; f < GF_COUNT; ++f) F[f][k] = 0;
-    }
-    __syncthreads();
-    const int Dx = d1_in ? GF_D1IN : GF_d1;     // "differs from the ligand-free pocket": the caller's proximity flags, or d1 itself
-    const int levels = (cached || prune) ? 3 : 1;
-    // The (node, slot) pairs of a thread -- pair t = tid + 1024 u -- are loaded ONCE, all in flight, and kept in registers over the
-    // three levels when the graph has at most GL_KEEP * 32 nodes (768: every pocket of the shipped data); the first version loaded
-    // deg and nbr inside the level loop, one dependent round trip per iteration: 32 us at one graph, more than the four launches it
-    // replaced (profiles/step_timeline_r05c_p1s1.json).  Rows are -1 padded, so a slot is valid iff its entry is >= 0.
+    for (int k = tid; k < n; k += 1024)
+        F[k] = (gen[gs + k] ? 1u << GF_GEN : 0u) | (lig[gs + k] ? 1u << GF_LIG : 0u) | ((d1_in && d1_in[gs + k]) ? 1u << GF_D1IN : 0u);
+    // The (node, slot) pairs of a thread -- pair t = tid + 1024 u, so a wave holds the 2 x 32 slots of two nodes -- are loaded ONCE,
+    // all in flight, and kept in registers over the three levels when the graph has at most GL_KEEP * 32 nodes (768: every pocket
+    // of the shipped data).  Rows are -1 padded, so a slot is valid iff its entry is >= 0.
     constexpr int GL_KEEP = 24;
     const int n_pairs = n * KNN;
     const bool keep = n_pairs <= GL_KEEP * 1024;
@@ -1038,11 +1034,12 @@ __global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __rest
             jl[u] = nbr[(size_t)gs * KNN + min(t, n_pairs - 1)];
         }
     }
-    constexpr int DUMP = GRAPH_LISTS_MAX_NODES;
-    // one level = every pair once; one straight-line body per level (no per-pair branch), a pair past the end marks nothing (all
-    // its stores go to the dump slot)
-    // (bitwise & / | on 0 / 1 ints and unconditional reads: `a && F[..]` compiles to a branch around the read)
-    auto pairs = [&](auto body) {
+    __syncthreads();
+    const unsigned Dx = d1_in ? GF_D1IN : GF_d1;     // "differs from the ligand-free pocket": the caller's proximity flags, or d1 itself
+    const int levels = (cached || prune) ? 3 : 1;
+    const bool hi = lane >= 32;                       // which of the wave's two nodes this lane belongs to
+    const bool e0 = (lane & 31) == 0;
+    for (int level = 0; level < levels; ++level) {
         for (int u0 = 0; u0 * 1024 < n_pairs; u0 += GL_KEEP) {
             if (!keep) {
 #pragma unroll
@@ -1053,75 +1050,53 @@ __global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __rest
             }
 #pragma unroll
             for (int u = 0; u < GL_KEEP; ++u) {
-                const int t = tid + 1024 * (u0 + u);
-                const int in = t < n_pairs;
+                if ((u0 + u) * 1024 + (tid & ~63) >= n_pairs) break;      // wave-uniform: the wave's 64 pairs are past the end
+                const int t = tid + 1024 * (u0 + u);                      // (n_pairs is a multiple of 32: a half-wave is all in or all out)
+                const bool in = t < n_pairs;
                 const int i = min(t, n_pairs - 1) >> 5;
-                const int valid = in & (jl[u] >= 0), e0 = in & ((t & 31) == 0);
+                const bool valid = in && jl[u] >= 0;
                 const int j = valid ? jl[u] - gs : i;
-                body(i, j, valid, e0);
+                const unsigned fi = F[i], fj = F[j];
+                // what the neighbour tells the node (OR over the node's slots) and what the node tells the neighbour
+                unsigned from_j, to_j, self;
+                if (level == 0) {
+                    from_j = (valid && (fj >> GF_LIG & 1u)) ? 1u << GF_d1 : 0u;
+                    self = ((fi >> GF_GEN | fi >> GF_LIG) & 1u) << GF_a1 | (fi >> GF_LIG & 1u) << GF_d1;
+                    to_j = (valid && (fi >> GF_GEN & 1u)) ? 1u << GF_a1 : 0u;
+                } else if (level == 1) {
+                    const unsigned a = prune ? fi >> GF_a1 & 1u : 0u, d = cached ? fi >> Dx & 1u : 0u;
+                    from_j = (cached && valid && (fj >> Dx & 1u)) ? 1u << GF_D2 : 0u;
+                    self = a << GF_a2 | d << GF_D2 | d << GF_S1;
+                    to_j = valid ? (a << GF_a2 | d << GF_S1) : 0u;
+                } else {
+                    const unsigned a = prune ? fi >> GF_a2 & 1u : 0u, d = cached ? fi >> GF_D2 & 1u : 0u;
+                    from_j = 0u;
+                    self = a << GF_a3 | d << GF_S2;
+                    to_j = valid ? (a << GF_a3 | d << GF_S2) : 0u;
+                }
+                // OR of from_j over the node's 32 lanes: every flag it can carry in this level is one bit, so a ballot per level does
+                const unsigned long long bal = __ballot(from_j != 0u);
+                const bool any = ((hi ? bal >> 32 : bal) & 0xffffffffull) != 0ull;
+                const unsigned own = in ? (self | (any ? (level == 0 ? 1u << GF_d1 : 1u << GF_D2) : 0u)) : 0u;
+                if (e0 && own) atomicOr(&F[i], own);
+                if (__ballot(to_j != 0u) != 0ull) {
+                    if (to_j) atomicOr(&F[j], to_j);
+                }
             }
         }
         __syncthreads();
-    };
-    auto mark = [&](int f, int cond, int k) { F[f][cond ? k : DUMP] = 1; };
-    pairs([&](int i, int j, int valid, int e0) {
-        const int g = F[GF_GEN][i] != 0, l = F[GF_LIG][i] != 0, lj = F[GF_LIG][j] != 0;
-        mark(GF_a1, e0 & (g | l), i);
-        mark(GF_a1, g & valid, j);
-        mark(GF_d1, (e0 & l) | (valid & lj), i);
-    });
-    if (levels > 1) {
-        if (prune && cached) {
-            pairs([&](int i, int j, int valid, int e0) {
-                const int a = F[GF_a1][i] != 0, d = F[Dx][i] != 0, dj = F[Dx][j] != 0;
-                mark(GF_a2, e0 & a, i);
-                mark(GF_a2, a & valid, j);
-                mark(GF_D2, (e0 & d) | (valid & dj), i);
-                mark(GF_S1, e0 & d, i);
-                mark(GF_S1, d & valid, j);
-            });
-            pairs([&](int i, int j, int valid, int e0) {
-                const int a = F[GF_a2][i] != 0, d = F[GF_D2][i] != 0;
-                mark(GF_a3, e0 & a, i);
-                mark(GF_a3, a & valid, j);
-                mark(GF_S2, e0 & d, i);
-                mark(GF_S2, d & valid, j);
-            });
-        } else if (prune) {
-            pairs([&](int i, int j, int valid, int e0) {
-                const int a = F[GF_a1][i] != 0;
-                mark(GF_a2, e0 & a, i);
-                mark(GF_a2, a & valid, j);
-            });
-            pairs([&](int i, int j, int valid, int e0) {
-                const int a = F[GF_a2][i] != 0;
-                mark(GF_a3, e0 & a, i);
-                mark(GF_a3, a & valid, j);
-            });
-        } else {
-            pairs([&](int i, int j, int valid, int e0) {
-                const int d = F[Dx][i] != 0, dj = F[Dx][j] != 0;
-                mark(GF_D2, (e0 & d) | (valid & dj), i);
-                mark(GF_S1, e0 & d, i);
-                mark(GF_S1, d & valid, j);
-            });
-            pairs([&](int i, int j, int valid, int e0) {
-                const int d = F[GF_D2][i] != 0;
-                mark(GF_S2, e0 & d, i);
-                mark(GF_S2, d & valid, j);
-            });
-        }
     }
     if (d1_out)
-        for (int k = tid; k < n; k += 1024) d1_out[gs + k] = F[GF_d1][k];
+        for (int k = tid; k < n; k += 1024) d1_out[gs + k] = (uint8_t)(F[k] >> GF_d1 & 1u);
     // compaction of every job, 1024 nodes of the graph at a time: per job one returning atomic per pass (list order is irrelevant)
     for (int base = 0; base < n; base += 1024) {
         const int k = base + tid;
+        const unsigned fk = k < n ? F[k] : 0u;
         unsigned member = 0u;       // bit job
         for (int job = 0; job < jobs.n_jobs; ++job) {
             const int fa = jobs.flag[job], fb = jobs.flag2[job];
-            bool a = k < n && (fa == GF_ALL || F[fa == GF_D1IN ? Dx : fa][k] != 0);
-            if (a && fb != GF_ALL) a = (F[fb == GF_D1IN ? Dx : fb][k] != 0) == (jobs.want2[job] != 0);
+            bool a = k < n && (fa == GF_ALL || (fk >> (fa == GF_D1IN ? Dx : (unsigned)fa) & 1u));
+            if (a && fb != GF_ALL) a = ((fk >> (fb == GF_D1IN ? Dx : (unsigned)fb) & 1u) != 0u) == (jobs.want2[job] != 0);
             const unsigned long long m = __ballot(a);
             if (lane == 0) s_cnt[job][wave] = __popcll(m);
             member |= a ? 1u << job : 0u;
