@@ -134,11 +134,6 @@ static Workspace carve(void* base, int n) {
 // HBM-bound node kernels of one run under the matrix-bound edge kernel of the other) must not have them share an auxiliary stream --
 // the node stages of the second call would queue behind all nine of the first.  A small table keyed by the caller's stream handle;
 // when it is full the entries change owner round-robin (aux_for).  Nothing here is shared between host threads.
-struct AuxStream {
-    hipStream_t owner = nullptr;
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
 constexpr int MAX_AUX = 8;    // batches a caller can keep in flight without aux streams changing owner (bench --streams 8, sample_many)
 struct AuxTable {
     int dev = -1;
@@ -147,7 +142,8 @@ struct AuxTable {
     AuxStream e[MAX_AUX];
 };
 static thread_local AuxTable g_aux_table;
-static AuxStream* aux_for(hipStream_t caller) {
+namespace cbgx {
+AuxStream* aux_for(hipStream_t caller) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     AuxTable& t = g_aux_table;
@@ -168,7 +164,9 @@ static AuxStream* aux_for(hipStream_t caller) {
     a.owner = caller;
     if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&a.done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&a.done[1], hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(a.s);
         return nullptr;
     }
@@ -176,6 +174,7 @@ static AuxStream* aux_for(hipStream_t caller) {
     t.e[t.n] = a;
     return &t.e[t.n++];
 }
+}  // namespace cbgx
 
 extern "C" {
 

@@ -6,6 +6,8 @@
 #include <cstdarg>
 #include <cstdio>
 
+#include <cstdlib>
+
 #include "../../include/cbgx.h"
 #include "kernels.h"
 #include "layout.h"
@@ -80,6 +82,9 @@ struct TrainWs {
     uint8_t* mask;        // receptive field of the loss, walked backwards (see cbgx_unitransformer_backward)
     int *rf_list[2], *rf_count;
     int* lig_list;        // rows with lig_flag (count: rf_count + 32): the classifier head's backward walks it when the loss reads ligand rows only
+    // second set of the per-block buffers (round 5): the weight-gradient reductions of a block run on an auxiliary stream while the
+    // caller's stream is already in the next block, so consecutive blocks alternate between two sets (attention_block_backward)
+    float *T2, *S2, *sw2, *qs2, *dqb2, *zb2, *dP2, *partial2, *folded2, *partial_node2, *partial_wgrad2, *folded_node2, *folded_wgrad2;
     size_t partial_floats;
     size_t total;
 };
@@ -132,6 +137,19 @@ static TrainWs carve_train(void* base, int n) {
     w.folded_node = (float*)take((size_t)FOLD * NS_SIZE * 4);
     w.folded_wgrad = (float*)take((size_t)FOLD * H * PROW * 4);
     w.nk = (float*)take(BX_NK_FLOATS * 4);     // x2h edge backward: the key path of every wave in flight, parked between two phases
+    w.T2 = (float*)take(N * HEADS * H * 4);
+    w.S2 = (float*)take(N * HEADS * H * 4);
+    w.sw2 = (float*)take(N * HEADS * 4);
+    w.qs2 = (float*)take(N * H * 4);
+    w.dqb2 = (float*)take(N * H * 4);
+    w.zb2 = (float*)take(N * H * 4);
+    w.dP2 = (float*)take(N * PROW * 4 + 256);
+    w.partial2 = (float*)take(w.partial_floats * 4);
+    w.folded2 = (float*)take((size_t)FOLD * H * PROW * 4);
+    w.partial_node2 = (float*)take((size_t)NODE_GRID * NS_SIZE * 4);
+    w.partial_wgrad2 = (float*)take((size_t)MAX_SPLITS * H * PROW * 4);
+    w.folded_node2 = (float*)take((size_t)FOLD * NS_SIZE * 4);
+    w.folded_wgrad2 = (float*)take((size_t)FOLD * H * PROW * 4);
     w.total = off;
     return w;
 }
@@ -172,12 +190,36 @@ static int fold_slabs(const float* src, int n_slabs, size_t stride, int size, Tr
 // Effects: gh [N,128] += dL/dh_in contributions (x2h: gh must already hold g_out -- the residual path -- and is
 // updated in place; h2x: gh += ...), dx [N,3] += coordinate gradients (atomics), de_w += gate gradients,
 // grads[18] (k6 v6 q6 tensors, reference layouts) overwritten.
+// Round 5: `ov` (optional) -- the weight-gradient part of the block (the node-level outer products and column sums, the dense
+// projection's weight gradient, the slab folds and the reduce-and-store of all 18 tensors: ~135 us of small kernels per block,
+// 2 ms of a 16 ms training step, none of it needed by the next block) runs on an auxiliary stream behind a fork event recorded
+// after the query backward, while the caller's stream goes on with dgrad and the next block.  Consecutive blocks alternate between
+// two sets of the buffers those kernels read (T, S, sw, qs, dqb, zb, dP and the slab sets); before a block touches its set it waits
+// for the auxiliary work of the block that used the set before it (two blocks earlier -- which also covers g_out: the x2h block two
+// blocks later is the first to overwrite the gradient buffer an x2h block's outer products read).
+struct BlockOverlap {
+    AuxLane* aux;       // auxiliary stream + events of the caller's stream (api.hip); NULL: everything on the caller's stream
+    int next_set;       // set of the next block
+    bool used[2];       // done[set] has been recorded
+};
+
 static int attention_block_backward(bool x2h, const float* att, const float* x, const float* h_in, const float* g_out,
                                     const int32_t* nbr, const int32_t* deg, const uint8_t* lig, const float* e_w,
-                                    const int* rows, const int* n_rows, int n, TrainWs& w, float* gh, float* dx,
+                                    const int* rows, const int* n_rows, int n, TrainWs& w_all, float* gh, float* dx,
                                     float* de_w, float* const* grads, hipStream_t s, const float* P_saved = nullptr,
                                     const float* Qt_saved = nullptr, float* qln = nullptr, const float* gh_src = nullptr,
-                                    const int* dp_rows = nullptr, const int* dp_n_rows = nullptr) {
+                                    const int* dp_rows = nullptr, const int* dp_n_rows = nullptr, BlockOverlap* ov = nullptr) {
+    TrainWs w = w_all;      // this block's view of the workspace: the per-block buffers of its set
+    const int set = (ov && ov->aux) ? ov->next_set : 0;
+    if (set) {
+        w.T = w_all.T2; w.S = w_all.S2; w.sw = w_all.sw2; w.qs = w_all.qs2; w.dqb = w_all.dqb2; w.zb = w_all.zb2; w.dP = w_all.dP2;
+        w.partial = w_all.partial2; w.folded = w_all.folded2; w.partial_node = w_all.partial_node2;
+        w.partial_wgrad = w_all.partial_wgrad2; w.folded_node = w_all.folded_node2; w.folded_wgrad = w_all.folded_wgrad2;
+    }
+    if (ov && ov->aux) {
+        if (ov->used[set]) HIP_TRY(hipStreamWaitEvent(s, ov->aux->done[set], 0));    // the set's previous user has finished with it
+        ov->next_set = set ^ 1;
+    }
     // `dp_rows` / `dp_n_rows` (h2x blocks): a device-side list that contains every row of dP this block can touch (the listed nodes
     // and their neighbours); the dense products and column sums over dP then walk the list instead of all N rows
     // `qln` [2][128]: zeroed accumulator of the query LayerNorm's affine gradients (nullptr: w.qln, zeroed here);
@@ -271,6 +313,22 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
 #endif
             HIP_TRY(launch_q_backward_mfma(att, Pn, w.T, rows, n_rows, n, w.qs, w.dqb, w.zb, w.dP, qln, qgrid, s));
     }
+    // ---- from here to the reduce-and-store: weight gradients only.  With `ov` they go to the auxiliary stream (`s` is shadowed) and
+    // dgrad -- what the next block waits for -- is issued on the caller's stream first.
+    hipStream_t s_main = s;
+    const bool deferred = ov && ov->aux;
+    if (deferred) {
+        HIP_TRY(hipEventRecord(ov->aux->fork, s_main));
+        HIP_TRY(hipStreamWaitEvent(ov->aux->s, ov->aux->fork, 0));
+        if (mfma)
+            HIP_TRY(launch_dgrad_mfma(w.dP, PROW, att + A_WN, PROW, gh, H, n, PROW, 1, s_main, gh_src, gh_src ? nullptr : dp_rows,
+                                      gh_src ? nullptr : dp_n_rows));
+        else {
+            if (gh_src && gh_src != gh) HIP_TRY(hipMemcpyAsync(gh, gh_src, (size_t)n * H * 4, hipMemcpyDeviceToDevice, s_main));
+            HIP_TRY(launch_sgemm(false, true, w.dP, PROW, att + A_WN, PROW, gh, H, n, H, PROW, 1, 0, 1, s_main));
+        }
+        s = ov->aux->s;
+    }
     // node-level reductions, all into one slab per workgroup (NS_* layout), folded and scattered once:
     //   second Linears: dWbk = sum_i (q_i / sqrt 8) (x) T_i ;  x2h: dWbv = sum_i G_i (x) S_i ;  dWq1 = sum_i dq_i (x) z_i
     //   biases: second v / q Linears, and the first Linears = column sums of dP (k | v | - | - | q hidden)
@@ -322,6 +380,11 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     if (batch_overflow) return cbgx::set_error(CBGX_E_INVALID, "backward: reduce batch overflow (RS_MAX / FOLD_JOBS_MAX too small)");
     HIP_TRY(launch_slab_fold_multi(fb, FOLD, s));
     HIP_TRY(launch_reduce_store_multi(rb, s));
+    if (deferred) {
+        HIP_TRY(hipEventRecord(ov->aux->done[set], s));
+        ov->used[set] = true;
+        return CBGX_OK;       // (dgrad was issued above, on the caller's stream)
+    }
     // dL/dh_in = (gh_src or gh itself) + dP Wn^T
     if (mfma)
         HIP_TRY(launch_dgrad_mfma(w.dP, PROW, att + A_WN, PROW, gh, H, n, PROW, 1, s, gh_src, gh_src ? nullptr : dp_rows,
@@ -553,6 +616,10 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
     if (qln_slots) HIP_TRY(hipMemsetAsync(w.qln, 0, (size_t)2 * L * 2 * H * sizeof(float), s));
     float* gh_cur = w.gh;       // dL/dh of the layer boundary being crossed; the x2h blocks write the other buffer (no snapshot copy)
     float* gh_oth = w.tmp;
+    // weight-gradient work of every block on the caller's auxiliary stream (attention_block_backward, BlockOverlap): off while the
+    // per-kernel profile runs (its sections are timed on one stream), with the VALU cross-check kernels, or by CBGX_TRAIN_OVERLAP=0
+    static const bool overlap_env = [] { const char* e = getenv("CBGX_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();
+    BlockOverlap ov{(overlap_env && g_edge_impl != 1 && !profile_is_on()) ? aux_for(s) : nullptr, 0, {false, false}};
     for (int l = L - 1; l >= 0; --l) {
         const float* xl = tp.xs + (size_t)l * nx;
         const float* h_in = tp.hs + (size_t)l * nh;
@@ -568,7 +635,7 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
                                         Px + (size_t)n * PROW, Qx + (size_t)n * HEADS * H,
                                         qln_slots ? w.qln + (size_t)(2 * l + 1) * 2 * H : nullptr, nullptr,
                                         // dP of an h2x block is non-zero on gen | nbr(gen) only, a subset of the receptive-field list A1
-                                        prune ? w.rf_list[0] : nullptr, prune ? w.rf_count : nullptr));
+                                        prune ? w.rf_list[0] : nullptr, prune ? w.rf_count : nullptr, &ov));
         // h_mid = h_in + X2H(x_l, h_in): gh_cur holds dL/dh_mid, which is also the residual part of dL/dh_in.  The block reads it
         // (fold, outer products, bias sums) and writes dL/dh_in = gh_cur + dP Wn^T into the OTHER buffer.
         const int k = L - 1 - l;      // 0 for the last layer
@@ -576,11 +643,16 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         const int* n_rows = (prune && k < 2) ? w.rf_count + 16 * k : nullptr;
         RC_TRY(attention_block_backward(true, packed + x2h_off(l), xl, h_in, gh_cur, tp.nbr, tp.deg, lig_flag, tp.e_w,
                                         rows, n_rows, n, w, gh_oth, w.gx[nxt], w.de_w, g, s, Px, Qx,
-                                        qln_slots ? w.qln + (size_t)(2 * l) * 2 * H : nullptr, gh_cur));
+                                        qln_slots ? w.qln + (size_t)(2 * l) * 2 * H : nullptr, gh_cur, nullptr, nullptr, &ov));
         { float* t = gh_cur; gh_cur = gh_oth; gh_oth = t; }
         cur = nxt;
     }
     if (grad_h_in) HIP_TRY(hipMemcpyAsync(grad_h_in, gh_cur, nh * 4, hipMemcpyDeviceToDevice, s));
+    // the auxiliary stream's last weight gradients must be in place when this call's work on `s` is: join both sets (the gate
+    // backward below also reuses the first set's slab buffer)
+    if (ov.aux)
+        for (int k = 0; k < 2; ++k)
+            if (ov.used[k]) HIP_TRY(hipStreamWaitEvent(s, ov.aux->done[k], 0));
     // distance gate (computed once from the input coordinates, used by all 2L blocks)
     HIP_TRY(launch_gate_backward_mfma(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.partial, GATE_GRID, s));
     FOLDED(w.partial, GATE_GRID, GB_SIZE, GB_SIZE);

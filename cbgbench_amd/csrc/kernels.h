@@ -5,6 +5,17 @@
 
 namespace cbgx {
 
+// Auxiliary stream of a caller stream (api.hip: one per (host thread, caller stream), created on first use, reused for the life of
+// the thread): the forward's two-stream schedule forks / joins it with `fork` / `join`; the training backward runs the weight-gradient
+// part of a block on it and records `done[set]` when the block's buffer set is free again (api_train.hip).  NULL when unavailable.
+struct AuxStream {
+    hipStream_t owner = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, done[2] = {nullptr, nullptr};
+};
+AuxStream* aux_for(hipStream_t caller);
+typedef AuxStream AuxLane;
+
 // ---- optional per-kernel timing (cbgx_profile_begin / cbgx_profile_end) ----
 enum KernelClass { K_KNN = 0, K_GATE, K_NODE_GEMM, K_NODE_QUERY, K_EDGE_X2H, K_EDGE_H2X, K_EDGE_X2H_LISTED, K_EDGE_X2H_BWD, K_EDGE_H2X_BWD,
                    K_TRAIN_GEMM, K_EDGE_X2H_BWD_LISTED, K_NUM_CLASSES };
