@@ -76,6 +76,7 @@ struct Workspace {
     int* sp_list[4][2];  // [all nodes | cached layer 1 (D2) | pruned A1 | pruned A2][1 = general, 0 = protein-only]
     int* sp_count;       // per set one 128-byte region: general count at +0, protein-only count at +64 bytes
     int* zero_count;     // an always-empty list's count
+    unsigned* newmask;   // graph-cached calls: per listed centre, the ranks of its merged neighbour list that hold new entries
     void* counters;      // flags + act_count, rf_count, fw_count, sp_count, zero_count are carved from ONE block: one fill per call
     size_t counters_bytes;
     size_t total;
@@ -110,6 +111,7 @@ static Workspace carve(void* base, int n) {
     w.xbuf[0] = (float*)take(N * 3 * 4);
     w.xbuf[1] = (float*)take(N * 3 * 4);
     for (int k = 0; k < 4; ++k) { w.sp_list[k][1] = (int*)take(N * 4); w.sp_list[k][0] = (int*)take(N * 4); }
+    w.newmask = (unsigned*)take(N * 4);
     {
         // every device-side list count of a forward call, 64 bytes apart (a counter word is hammered by returning atomics)
         const size_t fl = align_up(N);
@@ -553,10 +555,17 @@ static int forward_impl(const float* packed, int num_layers, int num_classes, co
                                          w.hbuf[1], s));
         // the D1 centres' merged neighbour lists and gate values (kept pocket entries carry their cached value to their new
         // rank; the gate MLP runs on the ligand atoms that entered the list): one launch.  CBGX_MERGE_GATE=0: the two kernels.
-        static const bool merge_gate = [] { const char* e = getenv("CBGX_MERGE_GATE"); return !e || atoi(e) != 0; }();
-        if (merge_gate) {
+        // Small inputs: ONE launch (knn_merge_gate_kernel: a persistent kernel at one wave per SIMD -- at 173 k nodes it measured
+        // 612 us against 153 + 175 for the two kernels, profiles/ab_fwd_r05f.log, so large inputs keep two launches); large inputs:
+        // the merge marks the new ranks and the gate kernel evaluates only those.  CBGX_MERGE_GATE=0: the round-4 pair (all slots).
+        static const int merge_gate = [] { const char* e = getenv("CBGX_MERGE_GATE"); return e ? atoi(e) : 1; }();
+        if (merge_gate && n_nodes <= GRAPH_LISTS_MAX_NODES) {
             HIP_TRY(launch_knn_merge_gate(packed, x, graph_ptr, n_graphs, n_nodes, lig_flag, static_nbr, static_deg, static_ew, w.nbr,
                                           w.deg, w.e_w, s, w.fw_list[0], w.fw_count));
+        } else if (merge_gate) {
+            HIP_TRY(launch_knn_merge(x, graph_ptr, n_graphs, n_nodes, lig_flag, static_nbr, static_deg, w.nbr, w.deg, s, w.fw_list[0],
+                                     w.fw_count, static_ew, w.e_w, w.newmask));
+            HIP_TRY(launch_gate_mfma(packed, x, w.nbr, w.deg, n_nodes, w.e_w, s, w.fw_list[0], w.fw_count, w.newmask));
         } else {
             HIP_TRY(launch_knn_merge(x, graph_ptr, n_graphs, n_nodes, lig_flag, static_nbr, static_deg, w.nbr, w.deg, s, w.fw_list[0],
                                      w.fw_count));

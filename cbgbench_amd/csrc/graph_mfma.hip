@@ -157,7 +157,12 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
                                                         int n_graphs, const uint8_t* __restrict__ lig,
                                                         const int32_t* __restrict__ s_nbr, const int32_t* __restrict__ s_deg,
                                                         int32_t* __restrict__ nbr, int32_t* __restrict__ deg,
-                                                        const int* __restrict__ rows, const int* __restrict__ n_rows_ptr) {
+                                                        const int* __restrict__ rows, const int* __restrict__ n_rows_ptr,
+                                                        const float* __restrict__ s_ew, float* __restrict__ e_w,
+                                                        unsigned* __restrict__ newmask) {
+    // `e_w` / `newmask` (optional, round 5): the gate values of the pocket entries that stay in the list move to their new rank
+    // here (the gate is a function of the distance between two atoms that never move), padded slots get 0, and newmask[i] = the
+    // ranks that hold a NEW entry -- the only ones edge_gate_mfma_kernel then evaluates (unitransformer.py:109-112)
     const int lane = threadIdx.x & 63;
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= *n_rows_ptr) return;
@@ -176,7 +181,12 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
     const int n1 = n0 < 64 ? 0 : (b1 == ~0ull ? 64 : __builtin_ctzll(~b1));
     const int nl = n0 + n1;
     if (lig[i] != 0 || nl >= 128 || ge - gs > 64 * KNN_SLOTS) {      // wave-uniform
-        knn_scan_node(x, graph_ptr, n_graphs, i, lane, nbr, deg);
+        const int mine = knn_scan_node(x, graph_ptr, n_graphs, i, lane, nbr, deg);
+        if (e_w) {      // every valid slot is new
+            if (lane < KNN && mine < 0) e_w[(size_t)i * KNN + lane] = 0.f;
+            const unsigned long long b = __ballot(lane < KNN && mine >= 0);
+            if (lane == 0) newmask[i] = (unsigned)(b & 0xffffffffull);
+        }
         return;
     }
     const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
@@ -185,6 +195,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
     const int sd = s_deg[i];
     const bool vs = lane < sd && lane < KNN;
     const int js = vs ? s_nbr[(size_t)i * KNN + lane] : i;
+    const float ews = e_w ? s_ew[(size_t)i * KNN + (lane < KNN ? lane : 0)] : 0.f;
     const unsigned ks_h = vs ? __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * js], x[3 * js + 1], x[3 * js + 2])) : NONE;
     const unsigned ks_l = vs ? (unsigned)js : NONE;
     // ligand candidates: rows ls .. ge-1, two per lane
@@ -220,6 +231,15 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
     if (v0 && r0k < KNN) out[r0k] = j0;
     if (v1 && r1k < KNN) out[r1k] = j1;
     if (lane == 0) deg[i] = d;
+    if (e_w) {
+        float* ew_out = e_w + (size_t)i * KNN;
+        if (lane >= d && lane < KNN) ew_out[lane] = 0.f;
+        if (vs && rs < KNN) ew_out[rs] = ews;
+        unsigned mk = ((v0 && r0k < KNN) ? 1u << r0k : 0u) | ((v1 && r1k < KNN) ? 1u << r1k : 0u);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mk |= (unsigned)__shfl_xor((int)mk, o, 64);
+        if (lane == 0) newmask[i] = mk;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -280,8 +300,10 @@ __global__ __launch_bounds__(256) void edge_gate_mfma_kernel(const float* __rest
                                                              const int32_t* __restrict__ nbr,
                                                              const int32_t* __restrict__ deg, int n_nodes,
                                                              float* __restrict__ e_w, const int* __restrict__ rows,
-                                                             const int* __restrict__ n_rows_ptr) {
+                                                             const int* __restrict__ n_rows_ptr,
+                                                             const unsigned* __restrict__ newmask) {
     __shared__ __attribute__((aligned(16))) float lds[GATE_IMG_SIZE];
+    __shared__ int s_rank[4][KNN];      // newmask mode: the ranks to evaluate, compacted
     {   // LDS fill, all loads of the thread in flight together (a plain loop compiles to one dependent round trip per iteration)
         typedef float fx4 __attribute__((ext_vector_type(4)));
         constexpr int NV = ((int)GATE_IMG_SIZE / 4 + 255) / 256;
@@ -309,6 +331,26 @@ __global__ __launch_bounds__(256) void edge_gate_mfma_kernel(const float* __rest
         const int i = rows ? rows[idx] : idx;
         const int d = deg[i];
         const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
+        if (newmask) {
+            // only the ranks knn_merge_kernel marked as new (a protein centre near the ligand: the ligand atoms that entered its
+            // list, ~1 - 10 of 32; the others kept their cached values), compacted to the head of as few 16-edge tiles as they need
+            const unsigned m = newmask[i];
+            const int cnt = __popc(m);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < KNN && (m >> lane & 1u)) s_rank[wave][__popc(m & ((1u << lane) - 1u))] = lane;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int t0 = 0; t0 < cnt; t0 += 16) {
+                const int k = t0 + c;
+                const bool valid = k < cnt;
+                const int rank = valid ? s_rank[wave][k] : 0;
+                const int j = valid ? nbr[(size_t)i * KNN + rank] : i;
+                const float gv = gate_tile_value(lds, mu, b2, lane, q, xi, yi, zi, x[3 * j], x[3 * j + 1], x[3 * j + 2]);
+                if (q == 0 && valid) e_w[(size_t)i * KNN + rank] = gv;
+            }
+            continue;
+        }
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int e = c + 16 * hf;
@@ -615,22 +657,22 @@ hipError_t launch_knn_reg(const float* x, const int32_t* graph_ptr, int n_graphs
 
 hipError_t launch_knn_merge(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, const uint8_t* lig,
                             const int32_t* s_nbr, const int32_t* s_deg, int32_t* nbr, int32_t* deg, hipStream_t s, const int* rows,
-                            const int* n_rows) {
+                            const int* n_rows, const float* s_ew, float* e_w, unsigned* newmask) {
     if (n_nodes == 0) return hipSuccess;
     profile_mark_begin(K_KNN, s);
     hipLaunchKernelGGL(knn_merge_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, x, graph_ptr, n_graphs, lig, s_nbr, s_deg, nbr,
-                       deg, rows, n_rows);
+                       deg, rows, n_rows, s_ew, e_w, newmask);
     profile_mark_end(s);
     return hipGetLastError();
 }
 
 hipError_t launch_gate_mfma(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
-                            float* e_w, hipStream_t s, const int* rows, const int* n_rows) {
+                            float* e_w, hipStream_t s, const int* rows, const int* n_rows, const unsigned* newmask) {
     if (n_nodes == 0) return hipSuccess;
     int grid = (n_nodes + 3) / 4;
     if (grid > 2048) grid = 2048;
     profile_mark_begin(K_GATE, s);
-    hipLaunchKernelGGL(edge_gate_mfma_kernel, dim3(grid), dim3(256), 0, s, packed, x, nbr, deg, n_nodes, e_w, rows, n_rows);
+    hipLaunchKernelGGL(edge_gate_mfma_kernel, dim3(grid), dim3(256), 0, s, packed, x, nbr, deg, n_nodes, e_w, rows, n_rows, newmask);
     profile_mark_end(s);
     return hipGetLastError();
 }

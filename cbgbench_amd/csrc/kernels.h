@@ -84,16 +84,19 @@ hipError_t launch_pack_gate_img(const float* w1, const float* b1, const float* g
 hipError_t launch_knn_reg(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, int32_t* nbr,
                           int32_t* deg, hipStream_t s, const int* rows = nullptr, const int* n_rows = nullptr);
 // graph-cached calls: the listed centres' lists from (pocket list U the graph's ligand atoms) by rank counting (graph_mfma.hip)
+// `s_ew` / `e_w` / `newmask` (optional): kept pocket entries carry their cached gate value to their new rank, newmask[i] = the ranks
+// that hold new entries -- what launch_gate_mfma(..., newmask) then evaluates instead of all 32 slots
 hipError_t launch_knn_merge(const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes, const uint8_t* lig,
                             const int32_t* s_nbr, const int32_t* s_deg, int32_t* nbr, int32_t* deg, hipStream_t s, const int* rows,
-                            const int* n_rows);
+                            const int* n_rows, const float* s_ew = nullptr, float* e_w = nullptr, unsigned* newmask = nullptr);
 // graph-cached calls: the listed centres' merged neighbour lists and their gate values in one launch -- kept pocket entries carry
 // their cached gate value to their new rank, the gate MLP runs on the entries that are new (graph_mfma.hip, knn_merge_gate_kernel)
 hipError_t launch_knn_merge_gate(const float* packed, const float* x, const int32_t* graph_ptr, int n_graphs, int n_nodes,
                                  const uint8_t* lig, const int32_t* s_nbr, const int32_t* s_deg, const float* s_ew, int32_t* nbr,
                                  int32_t* deg, float* e_w, hipStream_t s, const int* rows, const int* n_rows);
 hipError_t launch_gate_mfma(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
-                            float* e_w, hipStream_t s, const int* rows = nullptr, const int* n_rows = nullptr);
+                            float* e_w, hipStream_t s, const int* rows = nullptr, const int* n_rows = nullptr,
+                            const unsigned* newmask = nullptr);
 hipError_t launch_lig_proximity(const float* x, const int32_t* graph_ptr, int n_graphs, const uint8_t* lig,
                                 const float* r32sq, int n_nodes, uint8_t* dirty, hipStream_t s);
 // head of a graph-cached forward call in one launch: proximity flags -> `dirty`, their compaction -> `list` / `count` (zero on
