@@ -229,6 +229,10 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     const bool gen3 = x2h && g_edge_impl == 0;
     // (gen3: 8 nodes in flight per workgroup; a grid that is a multiple of 8 switches on its XCD-aware node partition)
     int eg = gen3 ? edge_grid((n + 7) / 8) : edge_grid(n);
+    // with the weight-gradient kernels on the auxiliary stream (BlockOverlap), the x2h edge backward may leave a few compute units to
+    // them: it takes a CU whole, so on 256 workgroups nothing runs next to it (CBGX_BX_GRID: its largest grid; an experiment knob)
+    static const int bx_grid = [] { const char* e = getenv("CBGX_BX_GRID"); const int v = e ? atoi(e) : 0; return v >= 8 && v <= EDGE_GRID ? v : EDGE_GRID; }();
+    if (gen3 && ov && ov->aux && eg > bx_grid) eg = bx_grid;
     if (gen3 && eg >= 64) eg &= ~7;
     const int ng = node_grid(n);
     // recompute the node stage of the forward: the MFMA node kernels (centred projection; own columns and query fold only
