@@ -623,7 +623,9 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
     // weight-gradient work of every block on the caller's auxiliary stream (attention_block_backward, BlockOverlap): off while the
     // per-kernel profile runs (its sections are timed on one stream), with the VALU cross-check kernels, or by CBGX_TRAIN_OVERLAP=0
     static const bool overlap_env = [] { const char* e = getenv("CBGX_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();
-    BlockOverlap ov{(overlap_env && g_edge_impl != 1 && !profile_is_on()) ? aux_for(s) : nullptr, 0, {false, false}};
+    // (and only with one query-LayerNorm accumulator slot per block: the shared fallback slot would be refilled by the next block
+    // while the auxiliary stream still reads it)
+    BlockOverlap ov{(overlap_env && g_edge_impl != 1 && !profile_is_on() && qln_slots) ? aux_for(s) : nullptr, 0, {false, false}};
     for (int l = L - 1; l >= 0; --l) {
         const float* xl = tp.xs + (size_t)l * nx;
         const float* h_in = tp.hs + (size_t)l * nh;

@@ -3,7 +3,6 @@
 //   edge_gate_mfma_kernel: the global distance gate MLP (20 -> 160 -> LN -> ReLU -> 1 -> sigmoid) on MFMA
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "kernels.h"
 #include "layout.h"
@@ -137,12 +136,10 @@ __global__ __launch_bounds__(256) void knn_graph_reg_kernel(const float* __restr
                                                             int32_t* __restrict__ deg, const int* __restrict__ rows,
                                                             const int* __restrict__ n_rows_ptr) {
     const int lane = threadIdx.x & 63;
-    const int count = rows ? *n_rows_ptr : n_nodes;
-    // (a loop: with a centre list the launcher caps the grid -- the workgroups beyond the list's end were dispatched only to leave)
-    for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < count; idx += gridDim.x * 4) {
-        const int i = rows ? rows[idx] : idx;      // optional centre list (DiffBP's CoM stack: the movable rows)
-        knn_scan_node(x, graph_ptr, n_graphs, i, lane, nbr, deg);
-    }
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= (rows ? *n_rows_ptr : n_nodes)) return;
+    const int i = rows ? rows[idx] : idx;      // optional centre list (static-context cache: only the nodes near a ligand)
+    knn_scan_node(x, graph_ptr, n_graphs, i, lane, nbr, deg);
 }
 
 // Graph-cached calls (static-context cache): the listed centres are the nodes near a ligand.  A PROTEIN centre's new neighbour
@@ -156,15 +153,20 @@ __global__ __launch_bounds__(256) void knn_graph_reg_kernel(const float* __restr
 // and graphs above the register-cached size take the scan.
 __device__ __forceinline__ bool key_less(unsigned ah, unsigned al, unsigned bh, unsigned bl) { return ah < bh || (ah == bh && al < bl); }
 
-// (the body of one listed centre; the kernel below loops over the centres of its wave)
-__device__ __forceinline__ void knn_merge_node(const float* __restrict__ x, const int32_t* __restrict__ graph_ptr, int n_graphs,
-                                               const uint8_t* __restrict__ lig, const int32_t* __restrict__ s_nbr,
-                                               const int32_t* __restrict__ s_deg, int32_t* __restrict__ nbr, int32_t* __restrict__ deg,
-                                               const float* __restrict__ s_ew, float* __restrict__ e_w,
-                                               unsigned* __restrict__ newmask, const int i, const int lane) {
+__global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ x, const int32_t* __restrict__ graph_ptr,
+                                                        int n_graphs, const uint8_t* __restrict__ lig,
+                                                        const int32_t* __restrict__ s_nbr, const int32_t* __restrict__ s_deg,
+                                                        int32_t* __restrict__ nbr, int32_t* __restrict__ deg,
+                                                        const int* __restrict__ rows, const int* __restrict__ n_rows_ptr,
+                                                        const float* __restrict__ s_ew, float* __restrict__ e_w,
+                                                        unsigned* __restrict__ newmask) {
     // `e_w` / `newmask` (optional, round 5): the gate values of the pocket entries that stay in the list move to their new rank
     // here (the gate is a function of the distance between two atoms that never move), padded slots get 0, and newmask[i] = the
     // ranks that hold a NEW entry -- the only ones edge_gate_mfma_kernel then evaluates (unitransformer.py:109-112)
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= *n_rows_ptr) return;
+    const int i = rows[idx];
     int lo_g = 0, hi_g = n_graphs;
     while (hi_g - lo_g > 1) {
         const int mid = (lo_g + hi_g) >> 1;
@@ -238,21 +240,6 @@ __device__ __forceinline__ void knn_merge_node(const float* __restrict__ x, cons
         for (int o = 32; o >= 1; o >>= 1) mk |= (unsigned)__shfl_xor((int)mk, o, 64);
         if (lane == 0) newmask[i] = mk;
     }
-}
-
-// Persistent over the list (round 5): the grid used to be one workgroup per four NODES of the batch -- 43 k workgroups at the
-// headline size, of which the 31 k beyond the list's end were dispatched only to read the count and leave.
-__global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ x, const int32_t* __restrict__ graph_ptr,
-                                                        int n_graphs, const uint8_t* __restrict__ lig,
-                                                        const int32_t* __restrict__ s_nbr, const int32_t* __restrict__ s_deg,
-                                                        int32_t* __restrict__ nbr, int32_t* __restrict__ deg,
-                                                        const int* __restrict__ rows, const int* __restrict__ n_rows_ptr,
-                                                        const float* __restrict__ s_ew, float* __restrict__ e_w,
-                                                        unsigned* __restrict__ newmask) {
-    const int lane = threadIdx.x & 63;
-    const int count = *n_rows_ptr;
-    for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < count; idx += gridDim.x * 4)
-        knn_merge_node(x, graph_ptr, n_graphs, lig, s_nbr, s_deg, nbr, deg, s_ew, e_w, newmask, rows[idx], lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -662,9 +649,7 @@ hipError_t launch_knn_reg(const float* x, const int32_t* graph_ptr, int n_graphs
                           int32_t* deg, hipStream_t s, const int* rows, const int* n_rows) {
     if (n_nodes == 0) return hipSuccess;
     profile_mark_begin(K_KNN, s);
-    int grid = (n_nodes + 3) / 4;
-    if (rows && grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(knn_graph_reg_kernel, dim3(grid), dim3(256), 0, s, x, graph_ptr, n_graphs, n_nodes,
+    hipLaunchKernelGGL(knn_graph_reg_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, x, graph_ptr, n_graphs, n_nodes,
                        nbr, deg, rows, n_rows);
     profile_mark_end(s);
     return hipGetLastError();
@@ -675,10 +660,7 @@ hipError_t launch_knn_merge(const float* x, const int32_t* graph_ptr, int n_grap
                             const int* n_rows, const float* s_ew, float* e_w, unsigned* newmask) {
     if (n_nodes == 0) return hipSuccess;
     profile_mark_begin(K_KNN, s);
-    static const int max_grid = [] { const char* e = getenv("CBGX_KNN_MERGE_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();
-    int grid = (n_nodes + 3) / 4;
-    if (grid > max_grid) grid = max_grid;
-    hipLaunchKernelGGL(knn_merge_kernel, dim3(grid), dim3(256), 0, s, x, graph_ptr, n_graphs, lig, s_nbr, s_deg, nbr,
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, s, x, graph_ptr, n_graphs, lig, s_nbr, s_deg, nbr,
                        deg, rows, n_rows, s_ew, e_w, newmask);
     profile_mark_end(s);
     return hipGetLastError();
