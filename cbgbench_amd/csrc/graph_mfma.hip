@@ -544,31 +544,12 @@ hipError_t launch_pack_gate_img(const float* w1, const float* b1, const float* g
     return hipGetLastError();
 }
 
-// dirty[i] = 1 for ligand atoms and for protein atoms that have a ligand atom among their 32 nearest neighbours:
-// the nearest ligand atom of the graph (ligand rows close every graph, common.py:200) is closer than the cached distance
-// to the 32nd protein neighbour.  Ties go to the protein atom (smaller index), hence the strict comparison.
-__global__ void lig_proximity_kernel(const float* __restrict__ x, const int32_t* __restrict__ graph_ptr, int n_graphs,
-                                     const uint8_t* __restrict__ lig, const float* __restrict__ r32sq, int n_nodes,
-                                     uint8_t* __restrict__ dirty) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    if (lig[i]) { dirty[i] = 1; return; }
-    int lo_g = 0, hi_g = n_graphs;
-    while (hi_g - lo_g > 1) {
-        const int mid = (lo_g + hi_g) >> 1;
-        if (graph_ptr[mid] <= i) lo_g = mid; else hi_g = mid;
-    }
-    const int gs = graph_ptr[lo_g], ge = graph_ptr[lo_g + 1];
-    const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
-    const float lim = r32sq[i];
-    bool near = false;
-    for (int j = ge - 1; j >= gs && lig[j]; --j)
-        near |= dist2_exact2(xi, yi, zi, x[3 * j], x[3 * j + 1], x[3 * j + 2]) < lim;
-    dirty[i] = near ? 1 : 0;
-}
-
-// lig_proximity + the compaction of its flags into the D1 list + restore_graph_kernel (node_mfma.hip: the pocket's own neighbour
-// lists, degrees, gate values and the cached features of layers 0 / 1 into the call's working arrays) in ONE launch: the head of every
+// (the proximity test itself: dirty[i] = 1 for ligand atoms and for protein atoms that have a ligand atom among their 32 nearest
+// neighbours -- the nearest ligand atom of the graph (ligand rows close every graph, common.py:200) is closer than the cached
+// distance to the 32nd protein neighbour; ties go to the protein atom (smaller index), hence the strict comparison)
+// The proximity flags, their compaction into the D1 list, and the copy of the pocket's own neighbour lists, degrees, gate values and
+// cached features of layers 0 / 1 into the call's working arrays, in ONE launch (until round 5: lig_proximity_kernel,
+// build_active_kernel, restore_graph_kernel and two device-to-device copies): the head of every
 // graph-cached forward call was these three dependent launches (9 + 5 + 5 us of a 600 us one-graph step).  1024-thread workgroups:
 // the first ceil(n / 1024) of them also flag their nodes and append the flagged ones to `list` with one returning atomic each
 // (*count zero on entry, like build_active_kernel); every workgroup copies its slice.
@@ -634,14 +615,6 @@ hipError_t launch_graph_cache_begin(const float* x, const int32_t* graph_ptr, in
     const long threads = (long)n * (H / 4);
     hipLaunchKernelGGL(graph_cache_begin_kernel, dim3((unsigned)((threads + 1023) / 1024)), dim3(1024), 0, s, x, graph_ptr, n_graphs,
                        lig, r32sq, n, dirty, list, count, s_nbr, s_deg, s_ew, nbr, deg, ew, h1, h2, out1, out2);
-    return hipGetLastError();
-}
-
-hipError_t launch_lig_proximity(const float* x, const int32_t* graph_ptr, int n_graphs, const uint8_t* lig,
-                                const float* r32sq, int n_nodes, uint8_t* dirty, hipStream_t s) {
-    if (n_nodes == 0) return hipSuccess;
-    hipLaunchKernelGGL(lig_proximity_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, x, graph_ptr, n_graphs, lig,
-                       r32sq, n_nodes, dirty);
     return hipGetLastError();
 }
 

@@ -97,8 +97,6 @@ hipError_t launch_knn_merge_gate(const float* packed, const float* x, const int3
 hipError_t launch_gate_mfma(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
                             float* e_w, hipStream_t s, const int* rows = nullptr, const int* n_rows = nullptr,
                             const unsigned* newmask = nullptr);
-hipError_t launch_lig_proximity(const float* x, const int32_t* graph_ptr, int n_graphs, const uint8_t* lig,
-                                const float* r32sq, int n_nodes, uint8_t* dirty, hipStream_t s);
 // head of a graph-cached forward call in one launch: proximity flags -> `dirty`, their compaction -> `list` / `count` (zero on
 // entry), the pocket's graph -> nbr / deg / ew, the cached features of layers 0 / 1 -> out1 / out2 (graph_mfma.hip)
 hipError_t launch_graph_cache_begin(const float* x, const int32_t* graph_ptr, int n_graphs, const uint8_t* lig, const float* r32sq,
@@ -177,10 +175,6 @@ hipError_t launch_graph_lists(const uint8_t* gen, const uint8_t* lig, const uint
                               const int32_t* graph_ptr, int n_graphs, const GraphListJobs& jobs, bool cached, bool prune,
                               uint8_t* d1_out, hipStream_t s);
 hipError_t launch_build_lists(const ListJobs& jobs, int n, hipStream_t s);
-// `h1` / `h2` -> `out1` / `out2` (optional): the cached features of layers 0 / 1 [n,128] copied in the same launch
-hipError_t launch_restore_graph(const int32_t* s_nbr, const int32_t* s_deg, const float* s_ew, int n, int32_t* nbr, int32_t* deg,
-                                float* ew, hipStream_t s, const float* h1 = nullptr, const float* h2 = nullptr,
-                                float* out1 = nullptr, float* out2 = nullptr);
 hipError_t launch_split_list(const int* list, const int* count, int n, const uint8_t* flag, int* out1, int* cnt1, int* out0,
                              int* cnt0, hipStream_t s, bool counters_zeroed = false);
 // MFMA edge kernel (edge_mfma.hip)

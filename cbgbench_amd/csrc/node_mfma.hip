@@ -1142,34 +1142,6 @@ hipError_t launch_build_lists(const ListJobs& jobs, int n, hipStream_t s) {
     return hipGetLastError();
 }
 
-// the pocket's own neighbour lists, degrees and gate values (static-context cache) into the call's working arrays, and the cached
-// features that leave layers 0 / 1 into the two feature buffers those layers write their listed rows into: one launch instead of
-// three + two device-to-device copies (the two feature copies were separate launches inside the layer loop until round 5)
-__global__ void restore_graph_kernel(const int32_t* __restrict__ s_nbr, const int32_t* __restrict__ s_deg,
-                                     const float* __restrict__ s_ew, int n, int32_t* __restrict__ nbr, int32_t* __restrict__ deg,
-                                     float* __restrict__ ew, const float* __restrict__ h1, const float* __restrict__ h2,
-                                     float* __restrict__ out1, float* __restrict__ out2) {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < (long)n * (KNN / 4)) {      // one thread per 4 neighbour slots
-        reinterpret_cast<int4*>(nbr)[t] = reinterpret_cast<const int4*>(s_nbr)[t];
-        reinterpret_cast<float4*>(ew)[t] = reinterpret_cast<const float4*>(s_ew)[t];
-        if ((t & (KNN / 4 - 1)) == 0) deg[t / (KNN / 4)] = s_deg[t / (KNN / 4)];
-    }
-    if (h1 && t < (long)n * (H / 4)) {  // one thread per 4 features
-        reinterpret_cast<float4*>(out1)[t] = reinterpret_cast<const float4*>(h1)[t];
-        reinterpret_cast<float4*>(out2)[t] = reinterpret_cast<const float4*>(h2)[t];
-    }
-}
-
-hipError_t launch_restore_graph(const int32_t* s_nbr, const int32_t* s_deg, const float* s_ew, int n, int32_t* nbr, int32_t* deg,
-                                float* ew, hipStream_t s, const float* h1, const float* h2, float* out1, float* out2) {
-    if (n == 0) return hipSuccess;
-    const long threads = (long)n * (h1 ? H / 4 : KNN / 4);
-    hipLaunchKernelGGL(restore_graph_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, s_nbr, s_deg, s_ew, n, nbr,
-                       deg, ew, h1, h2, out1, out2);
-    return hipGetLastError();
-}
-
 // ---- receptive-field pruning helpers ---------------------------------------------------------------
 __global__ void mark_seed_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int n,
                                  uint8_t* __restrict__ m) {
