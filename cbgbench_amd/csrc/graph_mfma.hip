@@ -248,12 +248,30 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
 // LayerNorm needs only sum(y^2).  Fragments [t 10][s 5][lane] = W1c[u = 16t + c][g = 4s + q].
 // ------------------------------------------------------------------------------------------------
 constexpr int GT = GH / 16;  // 10 tiles
+#ifndef CBGX_GATE_WAVES_PER_EU
+#define CBGX_GATE_WAVES_PER_EU 4
+#endif
+constexpr int GATE_WAVES_PER_EU = CBGX_GATE_WAVES_PER_EU;
 
 // the gate value of this lane's edge (i, j) -- lane (c = edge of the tile, q), result valid in every q row -- from the LDS image
 // (GATE_IMG layout); `mu` = the lane's five rbf centres 4 s + q.  The arithmetic of a column does not depend on the other columns
 // of the tile, so any assignment of edges to lanes gives the same bits.
-__device__ __forceinline__ float gate_tile_value(const float* __restrict__ lds, const float (&mu)[5], float b2, int lane, int q,
+// The LDS image is the same for every tile, so the compiler hoists all of its reads out of the centre loop -- 210 registers of
+// fragments and per-channel vectors, 330 in all: ONE wave per SIMD, and a centre is a chain of three or four dependent global round
+// trips (list entry -> mask / degree / position -> neighbour index -> neighbour position) with nothing else to run meanwhile
+// (157 us per 60 k listed centres of the headline batch, ~58 centres per wave in sequence).  With more than one wave per SIMD asked
+// for (GATE_WAVES_PER_EU) every tile addresses the image through an offset the compiler cannot see through: the reads stay where
+// they are used (40 KB of LDS reads per 16-edge tile) and the register budget is met without spilling.
+__device__ __forceinline__ const float* gate_image_of_this_tile(const float* lds_img) {
+    if (GATE_WAVES_PER_EU <= 1) return lds_img;
+    int off = 0;
+    asm volatile("" : "+v"(off));
+    return lds_img + off;
+}
+
+__device__ __forceinline__ float gate_tile_value(const float* lds, const float (&mu)[5], float b2, int lane, int q,
                                                  float xi, float yi, float zi, float xj, float yj, float zj) {
+    lds = gate_image_of_this_tile(lds);
     const float* l_frag = lds;
     const float* l_b1 = lds + GT * 5 * 64;
     const float* l_g = l_b1 + GH;
@@ -295,7 +313,7 @@ __device__ __forceinline__ float gate_tile_value(const float* __restrict__ lds, 
     return 1.f / (1.f + expf(-z));
 }
 
-__global__ __launch_bounds__(256) void edge_gate_mfma_kernel(const float* __restrict__ wts,
+__global__ __launch_bounds__(256, GATE_WAVES_PER_EU) void edge_gate_mfma_kernel(const float* __restrict__ wts,
                                                              const float* __restrict__ x,
                                                              const int32_t* __restrict__ nbr,
                                                              const int32_t* __restrict__ deg, int n_nodes,
@@ -378,7 +396,7 @@ __device__ __forceinline__ void gm_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(256) void knn_merge_gate_kernel(
+__global__ __launch_bounds__(256, GATE_WAVES_PER_EU) void knn_merge_gate_kernel(
     const float* __restrict__ wts, const float* __restrict__ x, const int32_t* __restrict__ graph_ptr, int n_graphs,
     const uint8_t* __restrict__ lig, const int32_t* __restrict__ s_nbr, const int32_t* __restrict__ s_deg,
     const float* __restrict__ s_ew, int32_t* __restrict__ nbr, int32_t* __restrict__ deg, float* __restrict__ e_w,

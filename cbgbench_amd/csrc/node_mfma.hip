@@ -12,6 +12,7 @@
 // MFMA 16x16x4 maps: A[i=c][k=q], B[k=q][j=c], C reg r: [row 4q+r][col c];  lane l: c = l & 15, q = l >> 4.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 #include "layout.h"
@@ -448,6 +449,10 @@ __global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict
 // CBGX_NODE_STAGE_MAX_ROWS rows; beyond that the three throughput kernels above take over.
 // ------------------------------------------------------------------------------------------------
 constexpr int NS_TPITCH = H + 4;   // LDS tile row pitch (floats)
+constexpr int NODE_STAGE_W16_MAX_TILES = 160;   // largest input (row tiles) whose launches use the 16-wave variant
+#ifndef CBGX_NS_LOADS_FIRST
+#define CBGX_NS_LOADS_FIRST 1
+#endif
 
 // Several jobs in one launch (blockIdx.y = job, kernels.h NodeStageJobs): every job is the stage -- or, `proj_only`, just its phase 1
 // -- of one attention block on one row list with one column-chunk mask, all on the same input features `h`:
@@ -457,15 +462,21 @@ constexpr int NS_TPITCH = H + 4;   // LDS tile row pitch (floats)
 //                       stages are one launch (round 5) -- until then the second ran on an auxiliary stream next to the first, and
 //                       the fork / join events cost the caller's queue ~7 us each, twice per layer (profiles/step_timeline_r05a_*)
 // A launch is bound by its longest job; small batches are bound by launch boundaries, which is what this removes.
-__global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, const float* __restrict__ h,
-                                                          const uint8_t* __restrict__ lig, int n_nodes) {
+// NW = 16 or 8 waves per workgroup.  A 16-wave workgroup has a CU to itself (128 registers per wave: four waves per SIMD), so a
+// launch with more than 256 busy (tile, job) pairs runs in two rounds of a ~14 us dependent chain: 30 us per layer at the 10-graph
+// batch of sample.py (276 row tiles x {x2h stage, h2x stage, h2x source columns}; profiles/step_timeline_r05z_p1s10.json).  With 8
+// waves a CU holds two workgroups and every wave takes two or three units / two heads in sequence: a longer chain, one round.
+// Which wave computes a column does not enter its arithmetic: both variants give the same bits.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void node_stage_kernel(NodeStageJobs jobs, const float* __restrict__ h,
+                                                                const uint8_t* __restrict__ lig, int n_nodes) {
     __shared__ __attribute__((aligned(16))) float qh[16][NS_TPITCH];
     __shared__ __attribute__((aligned(16))) float qt[16][NS_TPITCH];
     // phase 2's per-column constants (query LayerNorm gamma / beta, second Linear's bias and column scale), staged once per
     // workgroup: read from global memory inside phase 2 they were one exposed L2 round trip per 16 columns -- the emitted code was
     // `load x2, s_waitcnt vmcnt(0)` eight times in a row, a third of the kernel's 17 - 19 us at one graph (scripts/isa_report.py)
     __shared__ __attribute__((aligned(16))) float cst[4][H];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const NodeStageJob& jb = jobs.j[blockIdx.y];       // kernel arguments: scalar loads
     const float* __restrict__ att = jb.att;
     float* __restrict__ P = jb.P;
@@ -479,47 +490,61 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
     const int n_tiles = (n_rows + 15) / 16;
     if ((int)blockIdx.x >= n_tiles) return;
+    static_assert(NW * 64 >= 4 * H, "one thread per staged constant");
     if (!proj_only && tid < 4 * H) {       // visible after the barrier that ends phase 1
         const int k = tid >> 7, m = tid & (H - 1);
         cst[k][m] = att[(k == 0 ? A_LNQ_G : (k == 1 ? A_LNQ_B : (k == 2 ? A_BQ1 : A_WQ1_CINV))) + m];
     }
     for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
         const int row0 = tl * 16;
+        // the lane coordinates are re-materialised per tile: every per-lane address below is otherwise loop-invariant, gets hoisted
+        // out of the tile loop as a 64-bit pointer pair and spilled (30 scratch reloads, each a memory round trip of this
+        // latency-bound kernel, once phase 1 keeps a unit's sixteen operand loads in flight together)
+        int lane;      // (asm: a plain mbcnt is hoisted and spilled like everything else)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        const int c = lane & 15, q = lane >> 4;
+        // One dependent index load per tile: lane (c, q) reads the list entry of row c (its A-operand row); the rows it WRITES
+        // (4q + r) are other lanes' entries, fetched by ds_bpermute, and the per-row predicates are ballots over lanes 0..15 --
+        // until round 5 these were eight more index / flag loads per lane behind the first, serialised by the register allocator
+        // (load, full wait, spill) in front of phase 1.
         const int ak = min(row0 + c, n_rows - 1);
         const int arow = rows ? rows[ak] : ak;
-        int orow[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = row0 + 4 * q + r;
-            orow[r] = k < n_rows ? (rows ? rows[min(k, n_rows - 1)] : k) : -1;
-        }
+        const uint8_t* __restrict__ ff = fold_flag ? fold_flag : lig;     // (no flag array: read `lig` again, result ignored)
+        unsigned lig_b = lig[arow], fold_b = ff[arow];
         // ---- phase 1: projection, 20 units of 32 columns (half a chunk); the q-hidden chunks first: wave w takes unit w, waves
         // 0..3 a second one.  One unit's 16 operand loads are all in flight at once (64 VGPRs of the 128 a 16-wave group gets).
         half8 ah[4], al[4];
         float rinv[4];
+        float hv[4][8];
+        float mx = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 v0 = nld4(h + (size_t)arow * H + 32 * u + 4 * q), v1 = nld4(h + (size_t)arow * H + 32 * u + 16 + 4 * q);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hv[u][j] = v[j]; mx = fmaxf(mx, fabsf(v[j])); }
+        }
+        asm volatile("" : "+v"(lig_b), "+v"(fold_b));      // both loads issued here, unconditionally, ahead of the row's features
+        int orow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = row0 + 4 * q + r;
+            const int o = __builtin_amdgcn_ds_bpermute((4 * q + r) << 2, arow);       // lane 4q + r (q' = 0) holds row 4q + r of the tile
+            orow[r] = k < n_rows ? o : -1;
+        }
+        // lgm bit r: row 4q + r is a ligand row; fm bit r: its folded query is wanted (phase 3) -- rows past the list's end: no
+        const unsigned valid16 = n_rows - row0 >= 16 ? 0xffffu : (1u << (n_rows - row0)) - 1u;
+        const unsigned lig16 = (unsigned)__ballot(lig_b != 0u) & 0xffffu;
+        const unsigned fold16 = (fold_flag ? (unsigned)__ballot(fold_b != 0u) & 0xffffu : 0xffffu) & valid16;
+        const unsigned lgm = (lig16 >> (4 * q)) & 15u, fm = (fold16 >> (4 * q)) & 15u;
         {
-            float hv[4][8];
-            float mx = 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 v0 = nld4(h + (size_t)arow * H + 32 * u + 4 * q), v1 = nld4(h + (size_t)arow * H + 32 * u + 16 + 4 * q);
-                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { hv[u][j] = v[j]; mx = fmaxf(mx, fabsf(v[j])); }
-            }
             float inv;
             const float up = row_pow2(nxrow_max(mx), inv);
             rows_to_c_layout(inv, q, rinv);
 #pragma unroll
             for (int u = 0; u < 4; ++u) split8(hv[u], up, ah[u], al[u]);
         }
-        bool lgr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lgr[r] = lig[orow[r] >= 0 ? orow[r] : arow] != 0;
-        bool fold_row[4];       // rows of the tile whose folded query is wanted (requested here, used in phase 3)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) fold_row[r] = orow[r] >= 0 && (!fold_flag || fold_flag[orow[r] >= 0 ? orow[r] : arow] != 0);
-        for (int unit = wave; unit < 2 * NP_CHUNKS; unit += 16) {
+        for (int unit = wave; unit < 2 * NP_CHUNKS; unit += NW) {
             const int ch = unit < 4 ? 8 + (unit >> 1) : (unit - 4) >> 1, half = unit & 1;   // units 0..3: chunks 8, 9
             if (!(((chunk_mask | (proj_only ? 0u : 0x300u)) >> ch) & 1u)) continue;
             const half8* Bh = reinterpret_cast<const half8*>(att + A_NPROJ_FRAG + (size_t)ch * NP_CHUNK) + (2 * half) * 4 * 64 + lane;
@@ -529,6 +554,9 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) { bh[u][ct] = Bh[(ct * 4 + u) * 64]; bl[u][ct] = Bl[(ct * 4 + u) * 64]; }
+#if CBGX_NS_LOADS_FIRST
+            __builtin_amdgcn_sched_barrier(0);      // all sixteen in flight before the first MFMA waits for one
+#endif
             const float* bias = att + A_BN2 + 64 * ch + 4 * c + 2 * half;   // [dst class][640]: bias + type column of a protein source
             const float2 bP = *reinterpret_cast<const float2*>(bias), bL = *reinterpret_cast<const float2*>(bias + PROW);
             const float2 ci = *reinterpret_cast<const float2*>(att + A_NPROJ_CINV + 64 * ch + 4 * c + 2 * half);
@@ -544,9 +572,12 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float2 o = {fmaf(acc[0][r] * rinv[r], ci.x, lgr[r] ? bL.x : bP.x),
-                                  fmaf(acc[1][r] * rinv[r], ci.y, lgr[r] ? bL.y : bP.y)};
-                if (orow[r] >= 0) *reinterpret_cast<float2*>(P + (size_t)orow[r] * PROW + 64 * ch + 4 * c + 2 * half) = o;
+                const bool lg = (lgm >> r) & 1u;
+                const float2 o = {fmaf(acc[0][r] * rinv[r], ci.x, lg ? bL.x : bP.x),
+                                  fmaf(acc[1][r] * rinv[r], ci.y, lg ? bL.y : bP.y)};
+                int orw = orow[r];      // (opaque: the 64-bit row offsets are otherwise kept across the unit loop, and spilled)
+                asm volatile("" : "+v"(orw));
+                if (orw >= 0) *reinterpret_cast<float2*>(P + (size_t)orw * PROW + 64 * ch + 4 * c + 2 * half) = o;
                 if (ch >= 8) *reinterpret_cast<float2*>(&qh[4 * q + r][64 * (ch - 8) + 4 * c + 2 * half]) = o;
             }
         }
@@ -607,13 +638,15 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
             for (int r = 0; r < 4; ++r) {
                 const float o = fmaf(acc[r] * zrinv[r], ci, b1);
                 qt[4 * q + r][col] = o;
-                if (orow[r] >= 0) qout[(size_t)orow[r] * H + col] = o;
+                int orw = orow[r];
+                asm volatile("" : "+v"(orw));
+                if (orw >= 0) qout[(size_t)orw * H + col] = o;
             }
         }
         // ---- phase 3: the fold of head a = wave: Qt[row][a][m] = sum_cc q[row][8a+cc] Wbk[8a+cc][m] / sqrt 8 (exact fp32) ---
         // (skipped when no row of the tile wants it: the same answer in every wave, they all look at the same 16 rows); its B
         // operands do not depend on phase 2, so they are requested BEFORE the barrier that ends it and fly while the wave waits
-        const bool do_fold = __ballot(fold_row[0] || fold_row[1] || fold_row[2] || fold_row[3]) != 0ull;
+        const bool do_fold = __ballot(fm != 0u) != 0ull;
         float4 b00 = {0.f, 0.f, 0.f, 0.f}, b01 = b00, b10 = b00, b11 = b00;
         if (do_fold) {
             const float* fb = att + A_WBK_FRAG + ((size_t)wave * 2 * 64 + lane) * 8;
@@ -621,22 +654,31 @@ __global__ __launch_bounds__(1024) void node_stage_kernel(NodeStageJobs jobs, co
         }
         __syncthreads();
         if (do_fold) {
-            const int a = wave;
-            const float2 qv = *reinterpret_cast<const float2*>(&qt[c][8 * a + 2 * q]);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const float4 b0 = g ? b10 : b00, b1 = g ? b11 : b01;
-                floatx4 acc[4];
-                const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-                acc[0] = MFMA(qv.x, b0.x, zero); acc[1] = MFMA(qv.x, b0.z, zero);
-                acc[2] = MFMA(qv.x, b1.x, zero); acc[3] = MFMA(qv.x, b1.z, zero);
-                acc[0] = MFMA(qv.y, b0.y, acc[0]); acc[1] = MFMA(qv.y, b0.w, acc[1]);
-                acc[2] = MFMA(qv.y, b1.y, acc[2]); acc[3] = MFMA(qv.y, b1.w, acc[3]);
+            for (int k = 0; k < HEADS / NW; ++k) {
+                const int a = wave + k * NW;
+                if (k) {      // NW = 8: the wave's second head
+                    const float* fb = att + A_WBK_FRAG + ((size_t)a * 2 * 64 + lane) * 8;
+                    b00 = nld4(fb); b01 = nld4(fb + 4); b10 = nld4(fb + 64 * 8); b11 = nld4(fb + 64 * 8 + 4);
+                }
+                const float2 qv = *reinterpret_cast<const float2*>(&qt[c][8 * a + 2 * q]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (fold_row[r]) {
-                        const float4 o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-                        *reinterpret_cast<float4*>(Qt + ((size_t)orow[r] * HEADS + a) * H + 64 * g + 4 * c) = o;
+                for (int g = 0; g < 2; ++g) {
+                    const float4 b0 = g ? b10 : b00, b1 = g ? b11 : b01;
+                    floatx4 acc[4];
+                    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+                    acc[0] = MFMA(qv.x, b0.x, zero); acc[1] = MFMA(qv.x, b0.z, zero);
+                    acc[2] = MFMA(qv.x, b1.x, zero); acc[3] = MFMA(qv.x, b1.z, zero);
+                    acc[0] = MFMA(qv.y, b0.y, acc[0]); acc[1] = MFMA(qv.y, b0.w, acc[1]);
+                    acc[2] = MFMA(qv.y, b1.y, acc[2]); acc[3] = MFMA(qv.y, b1.w, acc[3]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if ((fm >> r) & 1u) {
+                            const float4 o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                            int orw = orow[r];
+                            asm volatile("" : "+v"(orw));
+                            *reinterpret_cast<float4*>(Qt + ((size_t)orw * HEADS + a) * H + 64 * g + 4 * c) = o;
+                        }
                     }
                 }
             }
@@ -1221,11 +1263,24 @@ bool add_node_stage_jobs(NodeStageJobs& jobs, const float* att, float* P, float*
     return true;
 }
 
+// 16-wave workgroups (one per CU) while every busy (tile, job) pair can have a CU of its own, 8-wave ones (two per CU) beyond that.
+// The lists' lengths live on the device; the row-tile count of the input bounds them, and a typical layer keeps ~1.6 pairs per tile
+// busy (a full stage on every row, the h2x stage on the movable rows, the h2x source columns on their neighbourhood).
+// CBGX_NODE_STAGE_WAVES = 8 | 16 forces one variant (A/B runs and the bit-identity test).
+static void launch_node_stage_grid(const NodeStageJobs& jobs, const float* h, const uint8_t* lig, int n_nodes, hipStream_t s) {
+    static const int forced = [] { const char* e = getenv("CBGX_NODE_STAGE_WAVES"); return e ? atoi(e) : 0; }();
+    const int tiles = (n_nodes + 15) / 16;
+    const bool eight = forced == 8 || (forced != 16 && tiles > NODE_STAGE_W16_MAX_TILES);
+    const dim3 grid(min(tiles, 512), jobs.n);
+    if (eight) hipLaunchKernelGGL(node_stage_kernel<8>, grid, dim3(512), 0, s, jobs, h, lig, n_nodes);
+    else hipLaunchKernelGGL(node_stage_kernel<16>, grid, dim3(1024), 0, s, jobs, h, lig, n_nodes);
+}
+
 hipError_t launch_node_stage_jobs(const NodeStageJobs& jobs, const float* h, const uint8_t* lig, int n_nodes, hipStream_t s) {
     if (n_nodes == 0 || jobs.n == 0) return hipSuccess;
     if (n_nodes > NODE_STAGE_MAX_ROWS || jobs.n > NS_JOBS_MAX) return hipErrorInvalidValue;
     profile_mark_begin(K_NODE_QUERY, s);
-    hipLaunchKernelGGL(node_stage_kernel, dim3(min((n_nodes + 15) / 16, 512), jobs.n), dim3(1024), 0, s, jobs, h, lig, n_nodes);
+    launch_node_stage_grid(jobs, h, lig, n_nodes, s);
     profile_mark_end(s);
     return hipGetLastError();
 }
@@ -1285,7 +1340,7 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
         NodeStageJobs jobs;
         jobs.n = 0;
         add_node_stage_jobs(jobs, att, P, qbuf, Qt, act, act_count, src, src_count);
-        hipLaunchKernelGGL(node_stage_kernel, dim3(min((n_nodes + 15) / 16, 512), jobs.n), dim3(1024), 0, s, jobs, h, lig, n_nodes);
+        launch_node_stage_grid(jobs, h, lig, n_nodes, s);
     } else {
         hipLaunchKernelGGL(node_qmlp_kernel, dim3(grid, small ? 2 : 1), dim3(256), 0, s, att, P, qbuf, n_nodes, act, act_count);
         if (fold)    // heads spread over four workgroups per row tile: the list is a fraction of the nodes, of unknown length

@@ -751,6 +751,55 @@ def test_static_context_cache_is_exact_on_odd_graphs(model):
         assert torch.equal(st["c_lig"].cpu().argmax(-1), c_ref.argmax(-1))
 
 
+_NODE_STAGE_PROBE = r"""
+import hashlib, sys, torch
+import cbgbench_amd as C
+from cbgbench_amd import synthetic
+from oracle import weights as W
+m = C.get_model(C.default_targetdiff_config(13)).eval()
+m.load_state_dict(W.synthetic_state_dict(13, 9, seed=0), strict=True)
+m = m.to("cuda:0")
+out = []
+for n_graphs, ctx in ((1, None), (4, None), (4, [3, 0, 9, 5])):
+    batch = synthetic.denovo_batch(n_graphs, seed=11) if ctx is None else None
+    if batch is None:
+        import numpy as np
+        rng = np.random.default_rng(5)
+        batch = synthetic.make_batch([synthetic.make_pocket(rng, n) for n in (200, 350, 90, 420)], [20, 12, 30, 25], rng, 13, n_ctx_list=ctx)
+    batch = synthetic.batch_to(batch, "cuda:0")
+    n_lig = batch["ligand_pos"].shape[0]
+    g = torch.Generator(device="cuda:0").manual_seed(9)
+    st = m.begin_sampling(batch, keep_trajectory=False)
+    for t in (999, 998, 2):
+        m.denoise_step(st, t, noise=(torch.randn(n_lig, 3, device="cuda:0", generator=g), torch.rand(n_lig, 13, device="cuda:0", generator=g)))
+    x, h, gp = st["x"], st["h"], st["graph_ptr"]
+    with torch.no_grad():
+        full = m.denoiser(x=x, h=h, batch_idx=st["batch_idx"], lig_flag=st["lig_flag"], gen_flag=st["gen_flag"], graph_ptr=gp)
+    torch.cuda.synchronize()
+    for t_ in (st["x_lig"], st["c_lig"]) + tuple(full):
+        out.append(hashlib.sha256(t_.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16])
+print("PROBE " + " ".join(out))
+"""
+
+
+def test_node_stage_variants_give_the_same_bits():
+    """node_stage_kernel<16> (one 16-wave workgroup per CU: inputs up to 160 row tiles) and <8> (two 8-wave workgroups per CU,
+    every wave two or three units / two heads in sequence: larger small inputs) differ in which wave computes a column, not in
+    how: three sampling steps (cached forward, partial gen_flag included) and one plain forward with either variant forced through
+    CBGX_NODE_STAGE_WAVES must give identical bits.  (The default selection is crossed by test_properties_at_full_batch: ten
+    graphs in one batch take <8>, graph 3 alone <16>.)"""
+    import subprocess
+    import sys
+    outs = []
+    for waves in ("16", "8"):
+        env = dict(os.environ, CBGX_NODE_STAGE_WAVES=waves)
+        r = subprocess.run([sys.executable, "-c", _NODE_STAGE_PROBE], capture_output=True, text=True, timeout=600, env=env,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("PROBE ")][-1])
+    assert outs[0] == outs[1] and len(outs[0].split()) == 1 + 3 * 5
+
+
 def test_graph_replay_equals_eager_steps(golden_dir):
     """one captured hipGraph replayed per step (TargetDiff.make_step_graph) against eager steps fed the noise the graph drew"""
     T = 12
