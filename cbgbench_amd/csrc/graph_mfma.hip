@@ -138,7 +138,9 @@ __global__ __launch_bounds__(256) void knn_graph_reg_kernel(const float* __restr
     const int lane = threadIdx.x & 63;
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= (rows ? *n_rows_ptr : n_nodes)) return;
-    const int i = rows ? rows[idx] : idx;      // optional centre list (static-context cache: only the nodes near a ligand)
+    // (wave-uniform, and told so: the graph search below is then scalar loads through the scalar cache instead of one vector
+    // round trip per halving step -- nine in a row for the 340 graphs of a headline batch)
+    const int i = __builtin_amdgcn_readfirstlane(rows ? rows[idx] : idx);      // optional centre list (static-context cache)
     knn_scan_node(x, graph_ptr, n_graphs, i, lane, nbr, deg);
 }
 
@@ -151,7 +153,11 @@ __global__ __launch_bounds__(256) void knn_graph_reg_kernel(const float* __restr
 // tests/test_gpu_parity.py::test_static_context_cache_is_exact compares the two paths on every node).  The ligand atoms close a
 // graph's rows (compose_context, common.py:200); up to 128 of them are handled here.  Ligand centres, graphs with more ligand atoms
 // and graphs above the register-cached size take the scan.
-__device__ __forceinline__ bool key_less(unsigned ah, unsigned al, unsigned bh, unsigned bl) { return ah < bh || (ah == bh && al < bl); }
+// (one 64-bit compare: the lexicographic order of (hi, lo) is the order of hi << 32 | lo -- five 32-bit operations otherwise, in
+// loops that made the merge VALU-bound: ~1100 vector instructions per centre, 60 k centres per headline batch)
+__device__ __forceinline__ bool key_less(unsigned ah, unsigned al, unsigned bh, unsigned bl) {
+    return (((unsigned long long)ah << 32) | al) < (((unsigned long long)bh << 32) | bl);
+}
 
 __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ x, const int32_t* __restrict__ graph_ptr,
                                                         int n_graphs, const uint8_t* __restrict__ lig,
@@ -166,7 +172,14 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= *n_rows_ptr) return;
-    const int i = rows[idx];
+    const int i = __builtin_amdgcn_readfirstlane(rows[idx]);      // wave-uniform: scalar graph search, scalar loop bounds
+    // everything that depends on the centre alone is requested before the graph search, unconditionally (clamped slots), so that
+    // a centre costs three dependent round trips (list entry -> these -> positions) instead of one per `if`
+    const unsigned lig_i = lig[i];
+    const int sd_raw = s_deg[i];
+    const int js_raw = s_nbr[(size_t)i * KNN + (lane & (KNN - 1))];
+    const float ews = e_w ? s_ew[(size_t)i * KNN + (lane & (KNN - 1))] : 0.f;
+    const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
     int lo_g = 0, hi_g = n_graphs;
     while (hi_g - lo_g > 1) {
         const int mid = (lo_g + hi_g) >> 1;
@@ -175,12 +188,13 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
     const int gs = graph_ptr[lo_g], ge = graph_ptr[lo_g + 1];
     // ligand atoms of the graph: the run of flagged rows at its end, counted over the last 128 rows
     const int r0 = ge - 1 - lane, r1 = ge - 65 - lane;
-    const unsigned long long b0 = __ballot(r0 >= gs && lig[r0 >= gs ? r0 : gs] != 0);
-    const unsigned long long b1 = __ballot(r1 >= gs && lig[r1 >= gs ? r1 : gs] != 0);
+    const unsigned l0 = lig[r0 >= gs ? r0 : gs], l1 = lig[r1 >= gs ? r1 : gs];      // both in flight
+    const unsigned long long b0 = __ballot((r0 >= gs) & (l0 != 0u));
+    const unsigned long long b1 = __ballot((r1 >= gs) & (l1 != 0u));
     const int n0 = b0 == ~0ull ? 64 : __builtin_ctzll(~b0);
     const int n1 = n0 < 64 ? 0 : (b1 == ~0ull ? 64 : __builtin_ctzll(~b1));
     const int nl = n0 + n1;
-    if (lig[i] != 0 || nl >= 128 || ge - gs > 64 * KNN_SLOTS) {      // wave-uniform
+    if (lig_i != 0u || nl >= 128 || ge - gs > 64 * KNN_SLOTS) {      // wave-uniform
         const int mine = knn_scan_node(x, graph_ptr, n_graphs, i, lane, nbr, deg);
         if (e_w) {      // every valid slot is new
             if (lane < KNN && mine < 0) e_w[(size_t)i * KNN + lane] = 0.f;
@@ -189,21 +203,23 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
         }
         return;
     }
-    const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
     const unsigned NONE = 0xffffffffu;
     // pocket candidates: lane p < sd holds entry p of the static list
-    const int sd = s_deg[i];
+    const int sd = __builtin_amdgcn_readfirstlane(sd_raw);
     const bool vs = lane < sd && lane < KNN;
-    const int js = vs ? s_nbr[(size_t)i * KNN + lane] : i;
-    const float ews = e_w ? s_ew[(size_t)i * KNN + (lane < KNN ? lane : 0)] : 0.f;
-    const unsigned ks_h = vs ? __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * js], x[3 * js + 1], x[3 * js + 2])) : NONE;
-    const unsigned ks_l = vs ? (unsigned)js : NONE;
+    const int js = vs ? js_raw : i;
     // ligand candidates: rows ls .. ge-1, two per lane
     const int ls = ge - nl;
     const bool v0 = lane < nl, v1 = lane + 64 < nl;
     const int j0 = v0 ? ls + lane : i, j1 = v1 ? ls + 64 + lane : i;
-    const unsigned k0_h = v0 ? __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * j0], x[3 * j0 + 1], x[3 * j0 + 2])) : NONE;
-    const unsigned k1_h = v1 ? __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * j1], x[3 * j1 + 1], x[3 * j1 + 2])) : NONE;
+    // the three position gathers in flight together (padded slots read the centre itself)
+    const float sx = x[3 * js], sy = x[3 * js + 1], sz = x[3 * js + 2];
+    const float ax = x[3 * j0], ay = x[3 * j0 + 1], az = x[3 * j0 + 2];
+    const float bx = x[3 * j1], by = x[3 * j1 + 1], bz = x[3 * j1 + 2];
+    const unsigned ks_h = vs ? __float_as_uint(dist2_exact2(xi, yi, zi, sx, sy, sz)) : NONE;
+    const unsigned ks_l = vs ? (unsigned)js : NONE;
+    const unsigned k0_h = v0 ? __float_as_uint(dist2_exact2(xi, yi, zi, ax, ay, az)) : NONE;
+    const unsigned k1_h = v1 ? __float_as_uint(dist2_exact2(xi, yi, zi, bx, by, bz)) : NONE;
     const unsigned k0_l = v0 ? (unsigned)j0 : NONE, k1_l = v1 ? (unsigned)j1 : NONE;
     int rs = lane, r0k = 0, r1k = 0;      // ranks in the union
     // every ligand key against every candidate of this lane (the loop index is wave-uniform: v_readlane broadcasts key t)
@@ -346,7 +362,7 @@ __global__ __launch_bounds__(256, GATE_WAVES_PER_EU) void edge_gate_mfma_kernel(
     for (int s = 0; s < 5; ++s) mu[s] = c_mu2[4 * s + q];
     const int count = rows ? *n_rows_ptr : n_nodes;
     for (int idx = blockIdx.x * 4 + wave; idx < count; idx += gridDim.x * 4) {
-        const int i = rows ? rows[idx] : idx;
+        const int i = __builtin_amdgcn_readfirstlane(rows ? rows[idx] : idx);
         const int d = deg[i];
         const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
         if (newmask) {
@@ -429,7 +445,13 @@ __global__ __launch_bounds__(256, GATE_WAVES_PER_EU) void knn_merge_gate_kernel(
     for (int s = 0; s < 5; ++s) mu[s] = c_mu2[4 * s + q];
     const unsigned NONE = 0xffffffffu;
     for (int idx = blockIdx.x * 4 + wave; idx < count; idx += gridDim.x * 4) {
-        const int i = rows[idx];
+        const int i = __builtin_amdgcn_readfirstlane(rows[idx]);
+        // what depends on the centre alone: requested before the graph search, unconditionally (knn_merge_kernel)
+        const unsigned lig_i = lig[i];
+        const int sd_raw = s_deg[i];
+        const int js_raw = s_nbr[(size_t)i * KNN + (lane & (KNN - 1))];
+        const float ews = s_ew[(size_t)i * KNN + (lane & (KNN - 1))];
+        const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
         int lo_g = 0, hi_g = n_graphs;
         while (hi_g - lo_g > 1) {
             const int mid = (lo_g + hi_g) >> 1;
@@ -438,30 +460,32 @@ __global__ __launch_bounds__(256, GATE_WAVES_PER_EU) void knn_merge_gate_kernel(
         const int gs = graph_ptr[lo_g], ge = graph_ptr[lo_g + 1];
         // ligand atoms of the graph: the run of flagged rows at its end, counted over the last 128 rows
         const int r0 = ge - 1 - lane, r1 = ge - 65 - lane;
-        const unsigned long long b0 = __ballot(r0 >= gs && lig[r0 >= gs ? r0 : gs] != 0);
-        const unsigned long long b1 = __ballot(r1 >= gs && lig[r1 >= gs ? r1 : gs] != 0);
+        const unsigned l0 = lig[r0 >= gs ? r0 : gs], l1 = lig[r1 >= gs ? r1 : gs];
+        const unsigned long long b0 = __ballot((r0 >= gs) & (l0 != 0u));
+        const unsigned long long b1 = __ballot((r1 >= gs) & (l1 != 0u));
         const int n0 = b0 == ~0ull ? 64 : __builtin_ctzll(~b0);
         const int n1 = n0 < 64 ? 0 : (b1 == ~0ull ? 64 : __builtin_ctzll(~b1));
         const int nl = n0 + n1;
-        const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
         float* ew_out = e_w + (size_t)i * KNN;
         int jr;      // lane r < 32: the neighbour at rank r that needs a fresh gate value (-1: none)
-        if (lig[i] != 0 || nl >= 128 || ge - gs > 64 * KNN_SLOTS) {      // wave-uniform: the scan, every valid slot is new
+        if (lig_i != 0u || nl >= 128 || ge - gs > 64 * KNN_SLOTS) {      // wave-uniform: the scan, every valid slot is new
             jr = knn_scan_node(x, graph_ptr, n_graphs, i, lane, nbr, deg);
             if (lane < KNN && jr < 0) ew_out[lane] = 0.f;
         } else {
             // ---- knn_merge_kernel's rank counting (same keys, same comparisons) ----
-            const int sd = s_deg[i];
+            const int sd = __builtin_amdgcn_readfirstlane(sd_raw);
             const bool vs = lane < sd && lane < KNN;
-            const int js = vs ? s_nbr[(size_t)i * KNN + lane] : i;
-            const float ews = s_ew[(size_t)i * KNN + (lane < KNN ? lane : 0)];
-            const unsigned ks_h = vs ? __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * js], x[3 * js + 1], x[3 * js + 2])) : NONE;
-            const unsigned ks_l = vs ? (unsigned)js : NONE;
+            const int js = vs ? js_raw : i;
             const int ls = ge - nl;
             const bool v0 = lane < nl, v1 = lane + 64 < nl;
             const int j0 = v0 ? ls + lane : i, j1 = v1 ? ls + 64 + lane : i;
-            const unsigned k0_h = v0 ? __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * j0], x[3 * j0 + 1], x[3 * j0 + 2])) : NONE;
-            const unsigned k1_h = v1 ? __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * j1], x[3 * j1 + 1], x[3 * j1 + 2])) : NONE;
+            const float sx = x[3 * js], sy = x[3 * js + 1], sz = x[3 * js + 2];
+            const float ax = x[3 * j0], ay = x[3 * j0 + 1], az = x[3 * j0 + 2];
+            const float bx = x[3 * j1], by = x[3 * j1 + 1], bz = x[3 * j1 + 2];
+            const unsigned ks_h = vs ? __float_as_uint(dist2_exact2(xi, yi, zi, sx, sy, sz)) : NONE;
+            const unsigned ks_l = vs ? (unsigned)js : NONE;
+            const unsigned k0_h = v0 ? __float_as_uint(dist2_exact2(xi, yi, zi, ax, ay, az)) : NONE;
+            const unsigned k1_h = v1 ? __float_as_uint(dist2_exact2(xi, yi, zi, bx, by, bz)) : NONE;
             const unsigned k0_l = v0 ? (unsigned)j0 : NONE, k1_l = v1 ? (unsigned)j1 : NONE;
             int rs = lane, r0k = 0, r1k = 0;      // ranks in the union
             for (int t = 0; t < min(nl, 64); ++t) {
@@ -597,16 +621,40 @@ __global__ __launch_bounds__(1024) void graph_cache_begin_kernel(
     if (i < n) {
         if (lig[i]) a = true;
         else {
-            int lo_g = 0, hi_g = n_graphs;
-            while (hi_g - lo_g > 1) {
-                const int mid = (lo_g + hi_g) >> 1;
-                if (graph_ptr[mid] <= i) lo_g = mid; else hi_g = mid;
+            // the graph of the workgroup's first node by a scalar search, then a few steps forward per thread (1024 consecutive
+            // nodes span two or three graphs): a per-thread search was nine dependent vector round trips at 340 graphs
+            int g = 0;
+            {
+                const int first = (int)blockIdx.x * 1024;
+                int lo_g = 0, hi_g = n_graphs;
+                while (hi_g - lo_g > 1) {
+                    const int mid = (lo_g + hi_g) >> 1;
+                    if (graph_ptr[mid] <= first) lo_g = mid; else hi_g = mid;
+                }
+                g = lo_g;
             }
-            const int gs = graph_ptr[lo_g], ge = graph_ptr[lo_g + 1];
+            while (g + 1 < n_graphs && graph_ptr[g + 1] <= i) ++g;
+            const int gs = graph_ptr[g], ge = graph_ptr[g + 1];
             const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
             const float lim = r32sq[i];
-            for (int j = ge - 1; j >= gs && lig[j]; --j)
-                a |= dist2_exact2(xi, yi, zi, x[3 * j], x[3 * j + 1], x[3 * j + 2]) < lim;
+            // the ligand atoms close the graph's rows: walked from the end four at a time, every load of a step unconditional
+            // (clamped) and in flight together -- one atom per step was ~25 dependent round trips per thread
+            bool alive = true;
+            for (int j = ge - 1; alive && j >= gs; j -= 4) {
+                unsigned lf[4];
+                float px[4], py[4], pz[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = j - u >= gs ? j - u : gs;
+                    lf[u] = lig[jj];
+                    px[u] = x[3 * jj]; py[u] = x[3 * jj + 1]; pz[u] = x[3 * jj + 2];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    alive = alive & (j - u >= gs) & (lf[u] != 0u);
+                    a |= alive & (dist2_exact2(xi, yi, zi, px[u], py[u], pz[u]) < lim);
+                }
+            }
         }
         dirty[i] = a ? 1 : 0;
     }

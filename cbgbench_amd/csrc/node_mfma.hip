@@ -449,7 +449,10 @@ __global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict
 // CBGX_NODE_STAGE_MAX_ROWS rows; beyond that the three throughput kernels above take over.
 // ------------------------------------------------------------------------------------------------
 constexpr int NS_TPITCH = H + 4;   // LDS tile row pitch (floats)
-constexpr int NODE_STAGE_W16_MAX_TILES = 160;   // largest input (row tiles) whose launches use the 16-wave variant
+#ifndef CBGX_NODE_STAGE_WAVES_DEFAULT
+#define CBGX_NODE_STAGE_WAVES_DEFAULT 8
+#endif
+constexpr int NODE_STAGE_WAVES = CBGX_NODE_STAGE_WAVES_DEFAULT;   // waves per node_stage workgroup (launch_node_stage_grid)
 #ifndef CBGX_NS_LOADS_FIRST
 #define CBGX_NS_LOADS_FIRST 1
 #endif
@@ -490,10 +493,12 @@ __global__ __launch_bounds__(NW * 64, 4) void node_stage_kernel(NodeStageJobs jo
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
     const int n_tiles = (n_rows + 15) / 16;
     if ((int)blockIdx.x >= n_tiles) return;
-    static_assert(NW * 64 >= 4 * H, "one thread per staged constant");
-    if (!proj_only && tid < 4 * H) {       // visible after the barrier that ends phase 1
-        const int k = tid >> 7, m = tid & (H - 1);
-        cst[k][m] = att[(k == 0 ? A_LNQ_G : (k == 1 ? A_LNQ_B : (k == 2 ? A_BQ1 : A_WQ1_CINV))) + m];
+    if (!proj_only) {       // visible after the barrier that ends phase 1
+#pragma unroll
+        for (int u = tid; u < 4 * H; u += NW * 64) {
+            const int k = u >> 7, m = u & (H - 1);
+            cst[k][m] = att[(k == 0 ? A_LNQ_G : (k == 1 ? A_LNQ_B : (k == 2 ? A_BQ1 : A_WQ1_CINV))) + m];
+        }
     }
     for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
         const int row0 = tl * 16;
@@ -585,7 +590,6 @@ __global__ __launch_bounds__(NW * 64, 4) void node_stage_kernel(NodeStageJobs jo
         __syncthreads();
         // ---- phase 2: query MLP, output tile nt = wave (16 columns 64 (nt >> 2) + 4c + (nt & 3)) ---------------------------
         if (wave < 8) {
-            const int nt = wave;
             float z[32];
             float sm = 0.f;
 #pragma unroll
@@ -616,31 +620,34 @@ __global__ __launch_bounds__(NW * 64, 4) void node_stage_kernel(NodeStageJobs jo
                 const float v[8] = {z[8 * u], z[8 * u + 1], z[8 * u + 2], z[8 * u + 3], z[8 * u + 4], z[8 * u + 5], z[8 * u + 6], z[8 * u + 7]};
                 split8(v, zup, zh[u], zl[u]);
             }
-            // the tile's B operands: eight loads in flight together, requested once the 32 row values are split (requested first,
-            // as until round 5, the compiler parked them in scratch across the LayerNorm: four reloads behind full waits)
-            __builtin_amdgcn_sched_barrier(0);
-            const half8* Bh = reinterpret_cast<const half8*>(att + A_WQ1_FRAG) + (size_t)nt * 4 * 64 + lane;   // [nt][u][lane]
-            const half8* Bl = Bh + 8 * 4 * 64;
-            half8 bh[4], bl[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { bh[u] = Bh[u * 64]; bl[u] = Bl[u * 64]; }
-            __builtin_amdgcn_sched_barrier(0);
-            const int col = 64 * (nt >> 2) + 4 * c + (nt & 3);
-            const float b1 = cst[2][col], ci = cst[3][col];
-            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int nt = wave; nt < 8; nt += NW) {      // NW = 4: two output tiles per wave
+                // the tile's B operands: eight loads in flight together, requested once the 32 row values are split (requested first,
+                // as until round 5, the compiler parked them in scratch across the LayerNorm: four reloads behind full waits)
+                __builtin_amdgcn_sched_barrier(0);
+                const half8* Bh = reinterpret_cast<const half8*>(att + A_WQ1_FRAG) + (size_t)nt * 4 * 64 + lane;   // [nt][u][lane]
+                const half8* Bl = Bh + 8 * 4 * 64;
+                half8 bh[4], bl[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc = MFMAH32(zh[u], bl[u], acc);
-                acc = MFMAH32(zl[u], bh[u], acc);
-                acc = MFMAH32(zh[u], bh[u], acc);
-            }
+                for (int u = 0; u < 4; ++u) { bh[u] = Bh[u * 64]; bl[u] = Bl[u * 64]; }
+                __builtin_amdgcn_sched_barrier(0);
+                const int col = 64 * (nt >> 2) + 4 * c + (nt & 3);
+                const float b1 = cst[2][col], ci = cst[3][col];
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float o = fmaf(acc[r] * zrinv[r], ci, b1);
-                qt[4 * q + r][col] = o;
-                int orw = orow[r];
-                asm volatile("" : "+v"(orw));
-                if (orw >= 0) qout[(size_t)orw * H + col] = o;
+                for (int u = 0; u < 4; ++u) {
+                    acc = MFMAH32(zh[u], bl[u], acc);
+                    acc = MFMAH32(zl[u], bh[u], acc);
+                    acc = MFMAH32(zh[u], bh[u], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float o = fmaf(acc[r] * zrinv[r], ci, b1);
+                    qt[4 * q + r][col] = o;
+                    int orw = orow[r];
+                    asm volatile("" : "+v"(orw));
+                    if (orw >= 0) qout[(size_t)orw * H + col] = o;
+                }
             }
         }
         // ---- phase 3: the fold of head a = wave: Qt[row][a][m] = sum_cc q[row][8a+cc] Wbk[8a+cc][m] / sqrt 8 (exact fp32) ---
@@ -1263,16 +1270,17 @@ bool add_node_stage_jobs(NodeStageJobs& jobs, const float* att, float* P, float*
     return true;
 }
 
-// 16-wave workgroups (one per CU) while every busy (tile, job) pair can have a CU of its own, 8-wave ones (two per CU) beyond that.
-// The lists' lengths live on the device; the row-tile count of the input bounds them, and a typical layer keeps ~1.6 pairs per tile
-// busy (a full stage on every row, the h2x stage on the movable rows, the h2x source columns on their neighbourhood).
-// CBGX_NODE_STAGE_WAVES = 8 | 16 forces one variant (A/B runs and the bit-identity test).
+// Workgroup size.  Measured (profiles/small_r05k.log): the 8-wave variant (two workgroups per CU) wins at every input size -- at
+// one graph (28 row tiles) 15.6 against 16.8 us per launch, at ten graphs (276 tiles, ~440 busy (tile, job) pairs: more than the 256
+// CUs a 16-wave workgroup needs one each of) 22.4 against 26.1.  CBGX_NODE_STAGE_WAVES = 4 | 8 | 16 forces a variant (A/B runs and
+// the bit-identity test).
 static void launch_node_stage_grid(const NodeStageJobs& jobs, const float* h, const uint8_t* lig, int n_nodes, hipStream_t s) {
     static const int forced = [] { const char* e = getenv("CBGX_NODE_STAGE_WAVES"); return e ? atoi(e) : 0; }();
     const int tiles = (n_nodes + 15) / 16;
-    const bool eight = forced == 8 || (forced != 16 && tiles > NODE_STAGE_W16_MAX_TILES);
-    const dim3 grid(min(tiles, 512), jobs.n);
-    if (eight) hipLaunchKernelGGL(node_stage_kernel<8>, grid, dim3(512), 0, s, jobs, h, lig, n_nodes);
+    const int nw = (forced == 4 || forced == 8 || forced == 16) ? forced : NODE_STAGE_WAVES;
+    const dim3 grid(min(tiles, 1024), jobs.n);
+    if (nw == 4) hipLaunchKernelGGL(node_stage_kernel<4>, grid, dim3(256), 0, s, jobs, h, lig, n_nodes);
+    else if (nw == 8) hipLaunchKernelGGL(node_stage_kernel<8>, grid, dim3(512), 0, s, jobs, h, lig, n_nodes);
     else hipLaunchKernelGGL(node_stage_kernel<16>, grid, dim3(1024), 0, s, jobs, h, lig, n_nodes);
 }
 

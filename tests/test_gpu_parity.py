@@ -783,21 +783,20 @@ print("PROBE " + " ".join(out))
 
 
 def test_node_stage_variants_give_the_same_bits():
-    """node_stage_kernel<16> (one 16-wave workgroup per CU: inputs up to 160 row tiles) and <8> (two 8-wave workgroups per CU,
-    every wave two or three units / two heads in sequence: larger small inputs) differ in which wave computes a column, not in
-    how: three sampling steps (cached forward, partial gen_flag included) and one plain forward with either variant forced through
-    CBGX_NODE_STAGE_WAVES must give identical bits.  (The default selection is crossed by test_properties_at_full_batch: ten
-    graphs in one batch take <8>, graph 3 alone <16>.)"""
+    """node_stage_kernel<16> (one 16-wave workgroup per CU), <8> (two per CU, every wave two or three units / two heads in
+    sequence: the default) and <4> differ in which wave computes a column, not in how: three sampling steps (cached forward,
+    partial gen_flag included) and one plain forward with each variant forced through CBGX_NODE_STAGE_WAVES must give identical
+    bits."""
     import subprocess
     import sys
     outs = []
-    for waves in ("16", "8"):
+    for waves in ("16", "8", "4"):
         env = dict(os.environ, CBGX_NODE_STAGE_WAVES=waves)
         r = subprocess.run([sys.executable, "-c", _NODE_STAGE_PROBE], capture_output=True, text=True, timeout=600, env=env,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("PROBE ")][-1])
-    assert outs[0] == outs[1] and len(outs[0].split()) == 1 + 3 * 5
+    assert outs[0] == outs[1] == outs[2] and len(outs[0].split()) == 1 + 3 * 5
 
 
 def test_graph_replay_equals_eager_steps(golden_dir):
