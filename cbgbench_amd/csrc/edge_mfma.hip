@@ -57,6 +57,9 @@
 // chain runs ~1.5 x faster (the waves-per-workgroup measurements above).  Full rounds are the same load either way.
 // 1: the protein-only role's query channels are requested before the wait for the node's rows, and the x2h epilogue's residual row /
 // bias before the v path (ahead of the next item's row prefetch) instead of right before the epilogue.  (A/B knob; 0 = rounds 2 - 4.)
+#ifndef CBGX_EDGE_EARLY_HEADER
+#define CBGX_EDGE_EARLY_HEADER 1     // the first item's header travels with the LDS fill (0: requested after its barrier, as until round 5)
+#endif
 #ifndef CBGX_EDGE_EARLY_LOADS
 #define CBGX_EDGE_EARLY_LOADS 1
 #endif
@@ -208,14 +211,22 @@ __device__ __forceinline__ void edge_body(
     static_assert(!PP || (X2H && LISTED), "the protein-only kernel is an x2h work-list kernel");
     static_assert(PP_IMG_SIZE == IMG_SIZE_X2H, "both x2h images fill the same LDS array");
     constexpr int IMG = X2H ? (int)IMG_SIZE_X2H : (int)IMG_SIZE_H2X;
-    if (!X2H && act) {
-        // work list mode: x_out = x for every node that cannot move (done by all workgroups, before any early exit)
-        for (int n = wg * (WAVES * 64) + threadIdx.x; n < n_nodes; n += n_wg * WAVES * 64)
-            if (!gen[n]) {
-                out[3 * n] = x[3 * n]; out[3 * n + 1] = x[3 * n + 1]; out[3 * n + 2] = x[3 * n + 2];
-                if (dx_out) { dx_out[3 * n] = 0.f; dx_out[3 * n + 1] = 0.f; dx_out[3 * n + 2] = 0.f; }
+    // work list mode of h2x: x_out = x for every node that cannot move -- by all workgroups, also those without an item.  The
+    // flag and the position are requested together (one round trip, not two), and a workgroup with items does this behind its
+    // LDS fill's loads instead of in front of them.
+    auto copy_fixed_nodes = [&]() {
+        if (!X2H && act) {
+            for (int n = wg * (WAVES * 64) + threadIdx.x; n < n_nodes; n += n_wg * WAVES * 64) {
+                unsigned gn = gen[n];
+                float px = x[3 * n], py = x[3 * n + 1], pz = x[3 * n + 2];
+                asm volatile("" : "+v"(gn), "+v"(px), "+v"(py), "+v"(pz));      // (otherwise the position load sinks into the `if`)
+                if (!gn) {
+                    out[3 * n] = px; out[3 * n + 1] = py; out[3 * n + 2] = pz;
+                    if (dx_out) { dx_out[3 * n] = 0.f; dx_out[3 * n + 1] = 0.f; dx_out[3 * n + 2] = 0.f; }
+                }
             }
-    }
+        }
+    };
     const int n_items = act ? *act_count : n_nodes;
     const int wv = edge_active_waves(n_items, n_wg, WAVES);     // waves of this workgroup that take items (see CBGX_EDGE_MIN_WAVES)
     {   // a workgroup with no item skips the LDS fill altogether (its wave 0 holds its first item in either mapping)
@@ -223,12 +234,50 @@ __device__ __forceinline__ void edge_body(
         if ((n_wg & 7) == 0) {
             const int per_xcd = (((n_items + 7) >> 3) + wv - 1) / wv * wv;
             first = (wg & 7) * per_xcd + (wg >> 3) * (CBGX_EDGE_WAVE_MAJOR ? 1 : wv);
-            if (first >= min(n_items, ((int)(wg & 7) + 1) * per_xcd)) return;
+            if (first >= min(n_items, ((int)(wg & 7) + 1) * per_xcd)) { copy_fixed_nodes(); return; }
         } else {
             first = wg * (CBGX_EDGE_WAVE_MAJOR ? 1 : wv);
-            if (first >= n_items) return;
+            if (first >= n_items) { copy_fixed_nodes(); return; }
         }
     }
+    // the wave index -- and with it every node index of the persistent loop -- lives in scalar registers: node-level values
+    // (degree, flag, position, row bases) are then scalar loads and SGPR operands instead of 64 identical lanes
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, q = lane >> 4;
+
+    // XCD-aware persistent schedule: workgroup b runs on XCD b % 8 (observed dispatch order), so give every
+    // XCD one contiguous eighth of the item range: a graph's PS / Qt rows are then pulled into one L2 only.  (A role of the
+    // two-role kernel starts at a multiple of 8, so wg % 8 is still the XCD.)
+    int i_begin, i_end, i_step;
+    if ((n_wg & 7) == 0) {
+        const int per_xcd = (((n_items + 7) >> 3) + wv - 1) / wv * wv;
+        const int xcd = wg & 7, slot = wg >> 3, slots = n_wg >> 3;
+        i_begin = xcd * per_xcd + (CBGX_EDGE_WAVE_MAJOR ? wave * slots + slot : slot * wv + wave);
+        i_end = min(n_items, (xcd + 1) * per_xcd);
+        i_step = slots * wv;
+    } else {
+        i_begin = CBGX_EDGE_WAVE_MAJOR ? wave * n_wg + wg : wg * wv + wave;
+        i_end = n_items;
+        i_step = n_wg * wv;
+    }
+    const bool has_item = wave < wv && i_begin < i_end;      // wave-uniform
+    // The first item's header -- list entry -> node -> degree, class, position, neighbour row: two dependent round trips -- is
+    // requested BEFORE the LDS fill and travels with it (CBGX_EDGE_EARLY_HEADER): behind the fill's barrier it opened every launch,
+    // ~1.4 us of the ~8 us a small input's launch works (27 launches per denoising step).
+    ItemGeom g;
+    int r0 = 0, r1 = 0;
+    int4 nb0 = {0, 0, 0, 0}, nb1 = {0, 0, 0, 0};      // the node's neighbour row in the E1 mapping (raw, -1 padded)
+    int lig_first = 0;      // (raw: made wave-uniform after the barrier, so that nothing here waits for it)
+    auto first_header = [&]() {
+        const int i = __builtin_amdgcn_readfirstlane(act ? act[i_begin] : i_begin);
+        g.node = i;
+        g.d = deg[i]; lig_first = PP ? 0 : lig[i];
+        g.xi = x[3 * i]; g.yi = x[3 * i + 1]; g.zi = x[3 * i + 2];
+        const gptr nrow = sbase(nbr + (size_t)i * KNN);
+        const unsigned oc = vop(4 * c), oq = vop(16 * q);
+        r0 = ldoi(nrow, oc); r1 = ldoi(nrow, oc + 64);
+        nb0 = ldoi4(nrow, oq); nb1 = ldoi4(nrow, oq + 64);
+    };
     {
         // LDS fill: every load of the thread is requested before the first is written (19 float4 per thread for the x2h image).
         // Left as a plain loop the compiler emits load -> wait -> ds_write per iteration: 19 dependent L2 round trips, ~25 us at
@@ -244,12 +293,17 @@ __device__ __forceinline__ void edge_body(
                 v[u] = src[t < IMG / 4 ? t : IMG / 4 - 1];
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (CBGX_EDGE_EARLY_HEADER && has_item) first_header();      // behind the fill's loads, ahead of its writes
+            copy_fixed_nodes();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int t = threadIdx.x + u * (WAVES * 64);
                 if (t < IMG / 4) dst[t] = v[u];
             }
-        } else {        // fewer threads: the same in passes of at most 20 float4 per thread (38 at once would not fit the registers)
+        } else {
+            if (CBGX_EDGE_EARLY_HEADER && has_item) first_header();
+            copy_fixed_nodes();        // fewer threads: the same in passes of at most 20 float4 per thread (38 at once would not fit the registers)
             constexpr int NVC = 20;
 #pragma unroll 1
             for (int u0 = 0; u0 < NV; u0 += NVC) {
@@ -276,28 +330,9 @@ __device__ __forceinline__ void edge_body(
     const float* lds_dwt = lds + IMG_WT;     // (never read by PP: no ligand source)
     const float* lds_ln = lds + (PP ? PP_LN : IMG_LN);
 
-    // the wave index -- and with it every node index of the persistent loop -- lives in scalar registers: node-level values
-    // (degree, flag, position, row bases) are then scalar loads and SGPR operands instead of 64 identical lanes
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 15, q = lane >> 4;
-
-    // XCD-aware persistent schedule: workgroup b runs on XCD b % 8 (observed dispatch order), so give every
-    // XCD one contiguous eighth of the item range: a graph's PS / Qt rows are then pulled into one L2 only.  (A role of the
-    // two-role kernel starts at a multiple of 8, so wg % 8 is still the XCD.)
-    int i_begin, i_end, i_step;
-    if (wave >= wv) return;     // (after the barrier: this wave has done its share of the LDS fill)
-    if ((n_wg & 7) == 0) {
-        const int per_xcd = (((n_items + 7) >> 3) + wv - 1) / wv * wv;
-        const int xcd = wg & 7, slot = wg >> 3, slots = n_wg >> 3;
-        i_begin = xcd * per_xcd + (CBGX_EDGE_WAVE_MAJOR ? wave * slots + slot : slot * wv + wave);
-        i_end = min(n_items, (xcd + 1) * per_xcd);
-        i_step = slots * wv;
-    } else {
-        i_begin = CBGX_EDGE_WAVE_MAJOR ? wave * n_wg + wg : wg * wv + wave;
-        i_end = n_items;
-        i_step = n_wg * wv;
-    }
-    if (i_begin >= i_end) return;
+    if (!has_item) return;     // (after the barrier: this wave has done its share of the LDS fill)
+    if (!CBGX_EDGE_EARLY_HEADER) first_header();
+    g.lig_i = __builtin_amdgcn_readfirstlane(lig_first);
     // power-of-two scales of the split-f16 rbf tables (wave-uniform: scalar registers)
     const RbfScale sck = load_rbf_scale(att, 0), scv = load_rbf_scale(att, 1);
     // h2x: bias of this lane's head, once per launch -- loaded inside the loop it sat behind the next node's 24-row prefetch in the
@@ -305,20 +340,12 @@ __device__ __forceinline__ void edge_body(
     const float bbv = X2H ? 0.f : att[A_BBV + c];
 
     // ---- first item: geometry and the k-path rows, everything unconditional -------------------------------------
-    ItemGeom g;
     bool lg0[2];
     float dist0[2];
     float4 pd[8], ps0[8], ps1[8];
-    int4 nb0, nb1;      // this node's neighbour row in the E1 mapping (raw, -1 padded): requested with the rows above
     {
-        const int i = __builtin_amdgcn_readfirstlane(act ? act[i_begin] : i_begin);
-        g.node = i;
-        g.d = deg[i]; g.lig_i = PP ? 0 : lig[i];
-        g.xi = x[3 * i]; g.yi = x[3 * i + 1]; g.zi = x[3 * i + 2];
-        const gptr nrow = sbase(nbr + (size_t)i * KNN);
-        const unsigned oc = vop(4 * c), oq = vop(16 * q);
-        const int r0 = ldoi(nrow, oc), r1 = ldoi(nrow, oc + 64);
-        nb0 = ldoi4(nrow, oq); nb1 = ldoi4(nrow, oq + 64);
+        const int i = g.node;
+        const unsigned oq = vop(16 * q);
         g.j0[0] = c < g.d ? r0 : i;
         g.j0[1] = c + 16 < g.d ? r1 : i;
 #pragma unroll

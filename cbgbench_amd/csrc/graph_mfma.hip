@@ -28,7 +28,7 @@ __device__ __forceinline__ float g_xrow_sum(float v) {
 
 // lexicographic min of (hi, lo) pairs over the wave; every lane gets the result
 __device__ __forceinline__ void take_min(unsigned& hi, unsigned& lo, unsigned ohi, unsigned olo) {
-    const bool t = ohi < hi || (ohi == hi && olo < lo);
+    const bool t = (((unsigned long long)ohi << 32) | olo) < (((unsigned long long)hi << 32) | lo);     // one v_cmp_lt_u64
     hi = t ? ohi : hi;
     lo = t ? olo : lo;
 }
@@ -69,6 +69,36 @@ __device__ __forceinline__ float dist2_exact2(float ax, float ay, float az, floa
 // to the oracle (d2 computed with contraction off).  Graphs larger than 64 * KNN_SLOTS use knn_graph_kernel.
 constexpr int KNN_SLOTS = 12;
 
+constexpr int KNN_SLOTS_SMALL = 8;
+// the <= 64 * SLOTS candidates of a graph cached in registers (keys (bits(d2), j)): d rounds of {lane-local min, wave min, retire}
+template <int SLOTS>
+__device__ __forceinline__ int knn_select_cached(const float* __restrict__ x, int gs, int ge, int i, int d, int lane,
+                                                 float xi, float yi, float zi) {
+    unsigned khi[SLOTS], klo[SLOTS];
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const int j = gs + lane + 64 * u;
+        const bool ok = j < ge && j != i;
+        const int jj = ok ? j : i;      // (unconditional gathers: all of a lane's candidates in flight together)
+        const unsigned kh = __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * jj], x[3 * jj + 1], x[3 * jj + 2]));
+        khi[u] = ok ? kh : 0xffffffffu;
+        klo[u] = ok ? (unsigned)j : 0xffffffffu;
+    }
+    int mine = -1;
+    for (int r = 0; r < KNN; ++r) {
+        if (r >= d) break;
+        unsigned bh = 0xffffffffu, bl = 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) take_min(bh, bl, khi[u], klo[u]);
+        wave_min_pair(bh, bl);
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u)
+            if (klo[u] == bl) { khi[u] = 0xffffffffu; klo[u] = 0xffffffffu; }   // indices are unique
+        if (lane == r) mine = (int)bl;
+    }
+    return mine;
+}
+
 // the search of one centre node i by the wave it is called from: every candidate of the graph is scanned
 // -> lane r < 32: the r-th neighbour (-1 past the degree)
 __device__ __forceinline__ int knn_scan_node(const float* __restrict__ x, const int32_t* __restrict__ graph_ptr, int n_graphs,
@@ -83,29 +113,10 @@ __device__ __forceinline__ int knn_scan_node(const float* __restrict__ x, const 
     const int d = min(KNN, n - 1);
     const float xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
     int mine = -1;   // lane r keeps the r-th neighbour
-    if (n <= 64 * KNN_SLOTS) {
-        unsigned khi[KNN_SLOTS], klo[KNN_SLOTS];
-#pragma unroll
-        for (int u = 0; u < KNN_SLOTS; ++u) {
-            const int j = gs + lane + 64 * u;
-            khi[u] = 0xffffffffu;
-            klo[u] = 0xffffffffu;
-            if (j < ge && j != i) {
-                khi[u] = __float_as_uint(dist2_exact2(xi, yi, zi, x[3 * j], x[3 * j + 1], x[3 * j + 2]));
-                klo[u] = (unsigned)j;
-            }
-        }
-        for (int r = 0; r < KNN; ++r) {
-            if (r >= d) break;
-            unsigned bh = 0xffffffffu, bl = 0xffffffffu;
-#pragma unroll
-            for (int u = 0; u < KNN_SLOTS; ++u) take_min(bh, bl, khi[u], klo[u]);
-            wave_min_pair(bh, bl);
-#pragma unroll
-            for (int u = 0; u < KNN_SLOTS; ++u)
-                if (klo[u] == bl) { khi[u] = 0xffffffffu; klo[u] = 0xffffffffu; }   // indices are unique
-            if (lane == r) mine = (int)bl;
-        }
+    if (n <= 64 * KNN_SLOTS_SMALL) {      // (every pocket of the shipped data: 8 cached candidates per lane instead of 12)
+        mine = knn_select_cached<KNN_SLOTS_SMALL>(x, gs, ge, i, d, lane, xi, yi, zi);
+    } else if (n <= 64 * KNN_SLOTS) {
+        mine = knn_select_cached<KNN_SLOTS>(x, gs, ge, i, d, lane, xi, yi, zi);
     } else {
         // large graph: rescan the candidates every round, keeping the smallest key greater than the previous one
         unsigned ph = 0u, pl = 0u;

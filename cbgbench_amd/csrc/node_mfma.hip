@@ -453,6 +453,9 @@ constexpr int NS_TPITCH = H + 4;   // LDS tile row pitch (floats)
 #define CBGX_NODE_STAGE_WAVES_DEFAULT 8
 #endif
 constexpr int NODE_STAGE_WAVES = CBGX_NODE_STAGE_WAVES_DEFAULT;   // waves per node_stage workgroup (launch_node_stage_grid)
+#ifndef CBGX_NS_P2_EARLY
+#define CBGX_NS_P2_EARLY 1
+#endif
 #ifndef CBGX_NS_LOADS_FIRST
 #define CBGX_NS_LOADS_FIRST 1
 #endif
@@ -590,6 +593,18 @@ __global__ __launch_bounds__(NW * 64, 4) void node_stage_kernel(NodeStageJobs jo
         __syncthreads();
         // ---- phase 2: query MLP, output tile nt = wave (16 columns 64 (nt >> 2) + 4c + (nt & 3)) ---------------------------
         if (wave < 8) {
+#if CBGX_NS_P2_EARLY
+            // the first output tile's B operands are requested before the LayerNorm of the row, which they do not depend on (not
+            // before the barrier: from there the compiler moves them up into phase 1 and spills)
+            half8 bh0[4], bl0[4];
+            {
+                const half8* Bh = reinterpret_cast<const half8*>(att + A_WQ1_FRAG) + (size_t)wave * 4 * 64 + lane;
+                const half8* Bl = Bh + 8 * 4 * 64;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { bh0[u] = Bh[u * 64]; bl0[u] = Bl[u * 64]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             float z[32];
             float sm = 0.f;
 #pragma unroll
@@ -628,8 +643,16 @@ __global__ __launch_bounds__(NW * 64, 4) void node_stage_kernel(NodeStageJobs jo
                 const half8* Bh = reinterpret_cast<const half8*>(att + A_WQ1_FRAG) + (size_t)nt * 4 * 64 + lane;   // [nt][u][lane]
                 const half8* Bl = Bh + 8 * 4 * 64;
                 half8 bh[4], bl[4];
+#if CBGX_NS_P2_EARLY
+                if (nt == wave) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { bh[u] = Bh[u * 64]; bl[u] = Bl[u * 64]; }
+                    for (int u = 0; u < 4; ++u) { bh[u] = bh0[u]; bl[u] = bl0[u]; }
+                } else
+#endif
+                {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { bh[u] = Bh[u * 64]; bl[u] = Bl[u * 64]; }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 const int col = 64 * (nt >> 2) + 4 * c + (nt & 3);
                 const float b1 = cst[2][col], ci = cst[3][col];
@@ -1067,8 +1090,9 @@ __global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __rest
     const int gs = graph_ptr[blockIdx.x], n = graph_ptr[blockIdx.x + 1] - gs;
     if (n <= 0 || n > GRAPH_LISTS_MAX_NODES) return;     // (the launcher only takes inputs whose total is within the bound)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int k = tid; k < n; k += 1024)
-        F[k] = (gen[gs + k] ? 1u << GF_GEN : 0u) | (lig[gs + k] ? 1u << GF_LIG : 0u) | ((d1_in && d1_in[gs + k]) ? 1u << GF_D1IN : 0u);
+    // (the three flag bytes of a node are requested together -- without caller flags the third load reads `lig` again and is
+    // ignored -- and BEHIND the neighbour entries below: one round trip for everything the levels need)
+    const uint8_t* __restrict__ d1p = d1_in ? d1_in : lig;
     // The (node, slot) pairs of a thread -- pair t = tid + 1024 u, so a wave holds the 2 x 32 slots of two nodes -- are loaded ONCE,
     // all in flight, and kept in registers over the three levels when the graph has at most GL_KEEP * 32 nodes (768: every pocket
     // of the shipped data).  Rows are -1 padded, so a slot is valid iff its entry is >= 0.
@@ -1082,6 +1106,12 @@ __global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __rest
             const int t = tid + 1024 * u;
             jl[u] = nbr[(size_t)gs * KNN + min(t, n_pairs - 1)];
         }
+    }
+    for (int k0 = 0; k0 < n; k0 += 1024) {
+        const int k = min(k0 + tid, n - 1);
+        const unsigned fg = gen[gs + k], fl = lig[gs + k], fd = d1p[gs + k];
+        if (k0 + tid < n)
+            F[k] = (fg ? 1u << GF_GEN : 0u) | (fl ? 1u << GF_LIG : 0u) | ((d1_in != nullptr && fd) ? 1u << GF_D1IN : 0u);
     }
     __syncthreads();
     const unsigned Dx = d1_in ? GF_D1IN : GF_d1;     // "differs from the ligand-free pocket": the caller's proximity flags, or d1 itself
@@ -1097,15 +1127,34 @@ __global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __rest
                     jl[u] = nbr[(size_t)gs * KNN + min(t, n_pairs - 1)];
                 }
             }
+            // every flag word a level READS was completed by the level before it (a level only sets bits that the next one reads),
+            // so a thread's reads go out twelve pairs at a time, ahead of those pairs' atomics: two LDS round trips per level
+            // instead of one per pair (all 24 at once do not fit the 128 registers of a 1024-thread workgroup)
+            constexpr int GL_BATCH = 12;
 #pragma unroll
-            for (int u = 0; u < GL_KEEP; ++u) {
+            for (int ub = 0; ub < GL_KEEP; ub += GL_BATCH) {
+            if ((u0 + ub) * 1024 + (tid & ~63) >= n_pairs) break;      // wave-uniform
+            unsigned fi_[GL_BATCH], fj_[GL_BATCH];
+#pragma unroll
+            for (int v = 0; v < GL_BATCH; ++v) {
+                const int u = ub + v;
+                const int t = tid + 1024 * (u0 + u);
+                const int i = min(t, n_pairs - 1) >> 5;
+                const bool valid = t < n_pairs && jl[u] >= 0;
+                fi_[v] = F[i];
+                fj_[v] = F[valid ? jl[u] - gs : i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = 0; v < GL_BATCH; ++v) {
+                const int u = ub + v;
                 if ((u0 + u) * 1024 + (tid & ~63) >= n_pairs) break;      // wave-uniform: the wave's 64 pairs are past the end
                 const int t = tid + 1024 * (u0 + u);                      // (n_pairs is a multiple of 32: a half-wave is all in or all out)
                 const bool in = t < n_pairs;
                 const int i = min(t, n_pairs - 1) >> 5;
                 const bool valid = in && jl[u] >= 0;
                 const int j = valid ? jl[u] - gs : i;
-                const unsigned fi = F[i], fj = F[j];
+                const unsigned fi = fi_[v], fj = fj_[v];
                 // what the neighbour tells the node (OR over the node's slots) and what the node tells the neighbour
                 unsigned from_j, to_j, self;
                 if (level == 0) {
@@ -1131,6 +1180,7 @@ __global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __rest
                 if (__ballot(to_j != 0u) != 0ull) {
                     if (to_j) atomicOr(&F[j], to_j);
                 }
+            }
             }
         }
         __syncthreads();
