@@ -389,29 +389,58 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 constexpr int NF_FRAG = 16 * 2 * 64 * 8;  // 16384 floats = 64 KB
 
+// HP = heads per workgroup (HEADS / gridDim.y: 16, or 4 when the heads of a row tile are spread over four workgroups).  Round 5: a
+// row tile's HP query pairs are requested together, before the first head's MFMAs -- one global round trip per head, each behind a
+// full wait, was the kernel's inner loop (`load; s_waitcnt vmcnt(0); 16 MFMAs; stores`, scripts/isa_report.py) -- and the rows a
+// lane writes come from the other lanes' list entries by ds_bpermute instead of four more dependent loads.
+template <int HP>
 __global__ __launch_bounds__(256) void node_qfold_kernel(const float* __restrict__ att, const float* __restrict__ qin,
                                                          float* __restrict__ Qt, int n_nodes,
                                                          const int* __restrict__ rows, const int* __restrict__ n_rows_ptr) {
     __shared__ __attribute__((aligned(16))) float lds[NF_FRAG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, q = lane >> 4;
-    if ((int)blockIdx.x >= ((rows ? *n_rows_ptr : n_nodes) + 63) / 64) return;   // no tile for this workgroup
-    const int heads_per = HEADS / gridDim.y, a_begin = blockIdx.y * heads_per, a_end = a_begin + heads_per;
-    lds_fill_f4<16>(lds, att + A_WBK_FRAG, a_begin * (NF_FRAG / 64), a_end * (NF_FRAG / 64), tid);   // <= 16 float4 per thread
-    __syncthreads();
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
     const int n_tiles = (n_rows + 63) / 64;
+    if ((int)blockIdx.x >= n_tiles) return;   // no tile for this workgroup
+    const int a_begin = blockIdx.y * HP, a_end = a_begin + HP;
+    auto list_row = [&](int tile) {      // the list entry of this lane's A-operand row (clamped past the end)
+        const int ak = min(tile * 64 + wave * 16 + c, n_rows - 1);
+        return rows ? rows[ak] : ak;
+    };
+    auto load_queries = [&](int arow, float2 (&qv)[HP]) {
+#pragma unroll
+        for (int k = 0; k < HP; ++k) qv[k] = *reinterpret_cast<const float2*>(qin + (size_t)arow * H + 8 * (a_begin + k) + 2 * q);
+    };
+    // the first tile's list entry travels with the LDS fill, its queries with the barrier behind it (a workgroup of a listed launch
+    // has ONE tile: fill -> barrier -> entry -> queries -> MFMAs was four dependent round trips for 16 x HP x 512 bytes of output)
+    int arow = list_row(blockIdx.x);
+    lds_fill_f4<HP>(lds, att + A_WBK_FRAG, a_begin * (NF_FRAG / 64), a_end * (NF_FRAG / 64), tid);   // HP float4 per thread
+    float2 qv[HP];
+    load_queries(arow, qv);
+    __syncthreads();
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int row0 = tile * 64 + wave * 16;
-        const int ak = min(row0 + c, n_rows - 1);
-        const int arow = rows ? rows[ak] : ak;
+        if (tile != (int)blockIdx.x) {
+            arow = list_row(tile);
+            load_queries(arow, qv);
+        }
+        if (row0 >= n_rows) continue;      // (wave-uniform: the last tile's trailing waves)
         int orow[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = row0 + 4 * q + r;
-            orow[r] = k < n_rows ? (rows ? rows[k] : k) : -1;
+            const int o = __builtin_amdgcn_ds_bpermute((4 * q + r) << 2, arow);      // lane 4q + r holds row 4q + r of the tile
+            orow[r] = k < n_rows ? o : -1;
         }
-        for (int a = a_begin; a < a_end; ++a) {
-            const float2 qa = *reinterpret_cast<const float2*>(qin + (size_t)arow * H + 8 * a + 2 * q);
+        __builtin_amdgcn_sched_barrier(0);
+        // ONE wait for all of them here: a `s_waitcnt vmcnt(n)` inside the head loop also counts the stores of the heads before it
+        // (loads and stores share the counter on this part), i.e. every head would wait for the previous head's 8 KB to be written
+#pragma unroll
+        for (int k = 0; k < HP; ++k) asm volatile("" : "+v"(qv[k].x), "+v"(qv[k].y));
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            const int a = a_begin + k;
+            const float2 qa = qv[k];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const float* fb = lds + ((a * 2 + g) * 64 + lane) * 8;
@@ -1402,10 +1431,11 @@ hipError_t launch_node_mfma(const float* att, const float* h, const uint8_t* lig
     } else {
         hipLaunchKernelGGL(node_qmlp_kernel, dim3(grid, small ? 2 : 1), dim3(256), 0, s, att, P, qbuf, n_nodes, act, act_count);
         if (fold)    // heads spread over four workgroups per row tile: the list is a fraction of the nodes, of unknown length
-            hipLaunchKernelGGL(node_qfold_kernel, dim3(grid, 4), dim3(256), 0, s, att, qbuf, Qt, n_nodes, fold, fold_count);
+            hipLaunchKernelGGL(node_qfold_kernel<4>, dim3(grid, 4), dim3(256), 0, s, att, qbuf, Qt, n_nodes, fold, fold_count);
+        else if (small)
+            hipLaunchKernelGGL(node_qfold_kernel<4>, dim3(grid, 4), dim3(256), 0, s, att, qbuf, Qt, n_nodes, act, act_count);
         else
-            hipLaunchKernelGGL(node_qfold_kernel, dim3(grid, small ? 4 : 1), dim3(256), 0, s, att, qbuf, Qt, n_nodes, act,
-                               act_count);
+            hipLaunchKernelGGL(node_qfold_kernel<16>, dim3(grid, 1), dim3(256), 0, s, att, qbuf, Qt, n_nodes, act, act_count);
     }
     profile_mark_end(s);
     return hipGetLastError();
