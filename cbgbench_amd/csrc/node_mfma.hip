@@ -305,15 +305,27 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
     __syncthreads();
     const int n_rows = rows ? *n_rows_ptr : n_nodes;
     const int n_tiles = (n_rows + 63) / 64;
+    // bias and column scale of the (at most two) column groups: once per workgroup.  Loaded inside the group loop their wait sat
+    // INSIDE each `if (row is valid)` block of the epilogue -- four `s_waitcnt vmcnt(0); global_store` in a row, every store waiting
+    // for the one before it to be acknowledged (loads and stores share the counter)
+    float4 b4g[2], cig[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int grp = min(grp_begin + g, grp_end - 1);
+        b4g[g] = nld4(att + A_BQ1 + 64 * grp + 4 * c);
+        cig[g] = nld4(att + A_WQ1_CINV + 64 * grp + 4 * c);
+    }
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int row0 = tile * 64 + wave * 16;
+        if (row0 >= n_rows) continue;      // (wave-uniform: the last tile's trailing waves)
         const int ak = min(row0 + c, n_rows - 1);
         const int arow = rows ? rows[ak] : ak;
-        int orow[4];
+        int orow[4];      // the rows this lane writes: other lanes' list entries, by ds_bpermute (were four more dependent loads)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = row0 + 4 * q + r;
-            orow[r] = k < n_rows ? (rows ? rows[k] : k) : -1;
+            const int o = __builtin_amdgcn_ds_bpermute((4 * q + r) << 2, arow);      // lane 4q + r holds row 4q + r of the tile
+            orow[r] = k < n_rows ? o : -1;
         }
         float z[32];
         float sm = 0.f;
@@ -353,9 +365,11 @@ __global__ __launch_bounds__(256) void node_qmlp_kernel(const float* __restrict_
         }
         const half8* Bh = reinterpret_cast<const half8*>(lds) + lane;   // [nt][u][lane]
         const half8* Bl = Bh + 8 * 4 * 64;
-        for (int grp = grp_begin; grp < grp_end; ++grp) {
-            const float4 b4 = nld4(att + A_BQ1 + 64 * grp + 4 * c);
-            const float4 ci = nld4(att + A_WQ1_CINV + 64 * grp + 4 * c);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int grp = grp_begin + gi;
+            if (grp >= grp_end) break;
+            const float4 b4 = b4g[gi], ci = cig[gi];
             floatx4 acc[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};

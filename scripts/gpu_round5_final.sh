@@ -52,3 +52,13 @@ PY
 rm -rf $T/t
 done 2>&1 | tee $OUT/timeline_$TAG.log
 du -sh $OUT | tail -1
+# optional tail: the headline once more on ab_libs/base.so (the commit before the build's last change), when that library travels
+if [ -f $ROOT/ab_libs/base.so ]; then
+echo "== headline on ab_libs/base.so, then on the tree again =="
+for L in $ROOT/ab_libs/base.so $ROOT/cbgbench_amd/lib/libcbgx.so; do
+CBGX_LIBRARY=$L timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); k=d['roofline']['per_kernel_us_avg_and_launches']
+print('$L'.split('/')[-1], d['value'], {n: v for n, v in k.items() if v[1]})"
+done | tee $OUT/ab_fwd_$TAG.log
+fi
