@@ -334,17 +334,10 @@ def block_times(i, T=1000):
 
 
 def launch_ranks(n):
-    """`python bench.py --gpus N` outside torchrun: re-execute under torch.distributed.run with N ranks on this node."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    """`python bench.py --gpus N` outside torchrun: re-execute as N ranks of this node through cbgbench_amd.launch -- a FileStore
+    rendezvous, so no port is picked here for somebody else to take before the ranks bind it; a failing rank's stderr is printed"""
+    from cbgbench_amd import launch
+    return launch.launch(n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
 
 
 def ranks_seen(dev):

@@ -4,7 +4,7 @@ SURVEY.md section 2), plus rank sharding of the pocket loop (``sample.py:159`` i
 
     python -m cbgbench_amd.sample_cli --config cfg.yml --out_root results [--checkpoint ckpt.pt]
                                       [--pockets pockets.pt | --synthetic 16] [--num_samples 10] [--pockets_per_batch 10]
-    torchrun --nproc-per-node 8 -m cbgbench_amd.sample_cli ...      # rank r takes pockets r, r+W, ...
+    python -m cbgbench_amd.launch --nproc 8 -m cbgbench_amd.sample_cli ...      # rank r takes pockets r, r+W, ...; no port to pass
 
 Pocket input: a ``torch.save``d list of dicts with ``protein_pos [n,3]``, ``protein_atom_feature [n,7]``,
 ``protein_aa_type [n]`` (what ``featurize_protein_fa`` + ``center_pos`` produce, protein_featurizer.py:21-30),

@@ -23,11 +23,23 @@ def init_process_group(backend=None):
     # RCCL itself (tests/test_gpu_bench.py) -- the code path of the N-GPU job minus the peers
     force = os.environ.get("CBGX_DIST_FORCE") == "1"
     if (world > 1 or force) and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
         if backend is None:
             backend = os.environ.get("CBGX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # rendezvous, in this order: (1) the FileStore path of cbgbench_amd.launch (no port exists to collide on); (2) an outer
+        # launcher's MASTER_ADDR / MASTER_PORT (torchrun, the driver's N-GPU entry); (3) a one-rank group has nobody to meet: a
+        # private FileStore.  There is no default port: N > 1 ranks without either are a launch error, said so.
+        rdzv = os.environ.get("CBGX_RDZV_FILE")
+        if rdzv is None and "MASTER_PORT" not in os.environ:
+            if world > 1:
+                raise RuntimeError(f"{world} ranks but no rendezvous: start them with `python -m cbgbench_amd.launch --nproc {world} ...` "
+                                   f"(file rendezvous, no port) or under torch.distributed.run (MASTER_ADDR / MASTER_PORT)")
+            import tempfile
+            rdzv = os.path.join(tempfile.mkdtemp(prefix="cbgx_rdzv_"), "store")
+        if rdzv is not None:
+            dist.init_process_group(backend=backend, init_method="file://" + rdzv, rank=rank, world_size=world)
+        else:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 

@@ -3,7 +3,8 @@ with periodic validation -- loss and the config's ``eval.metrics`` (the type-pre
 best-so-far checkpoints, ``train.py:99-273``), minus the LMDB datasets and tensorboard (out of scope), made
 data-parallel the way SURVEY.md 8e/8f-4 asks:
 
-* one process per GPU (``torchrun --nproc-per-node N -m cbgbench_amd.train_cli ...``), every rank holds a full replica;
+* one process per GPU (``python -m cbgbench_amd.launch --nproc N -m cbgbench_amd.train_cli ...``: FileStore rendezvous, no port to
+  pass; ``torchrun`` works too), every rank holds a full replica;
 * a rank-aware loader: one permutation of the training complexes per epoch, seeded identically everywhere, of which rank r
   takes the entries r, r+W, ... -- no sampler object, no collective;
 * gradients of all ranks summed by ONE RCCL all-reduce of the flat fp32 gradient buffer per step (``train.FlatGradients``),

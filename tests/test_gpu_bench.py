@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(args, env=None, timeout=600):
     e = dict(os.environ)
+    for k in ("MASTER_ADDR", "MASTER_PORT", "CBGX_RDZV_FILE", "RANK", "WORLD_SIZE", "LOCAL_RANK"):   # no rendezvous leaks in from outside
+        e.pop(k, None)
     e.update(env or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=e,
                        timeout=timeout, cwd=ROOT)
@@ -43,8 +45,7 @@ def test_bench_one_rank_through_rccl():
     bench.py through init_process_group('nccl'), the device identity all-gather, both barriers and the max / sum / count
     all-reduces on the GPU"""
     out = _run(["--steps", "2", "--warmup", "1", "--pockets", "2", "--graphs-per-batch", "20", "--no-cpu-baseline", "--no-roofline"],
-               env={"CBGX_DIST_FORCE": "1", "CBGX_DIST_BACKEND": "nccl", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29900 + os.getpid() % 90)})
+               env={"CBGX_DIST_FORCE": "1", "CBGX_DIST_BACKEND": "nccl", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert out["n_gpus"] == 1 and "ranks" not in out and out["config"]["ranks_seen"] == 1
     assert out["config"]["collective_backend"] == "nccl"
     assert abs(out["value"] - 20 * 5 / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]
@@ -53,8 +54,7 @@ def test_bench_one_rank_through_rccl():
 def test_bench_train_one_rank_through_rccl():
     """the flat-buffer gradient all-reduce (cbgbench_amd/train.py FlatGrads.all_reduce_mean) on RCCL, one rank"""
     out = _run(["--workload", "train", "--steps", "2", "--warmup", "1", "--pockets", "4", "--no-cpu-baseline", "--no-roofline"],
-               env={"CBGX_DIST_FORCE": "1", "CBGX_DIST_BACKEND": "nccl", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29800 + os.getpid() % 90)})
+               env={"CBGX_DIST_FORCE": "1", "CBGX_DIST_BACKEND": "nccl", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert out["n_gpus"] == 1 and out["config"]["ranks_seen"] == 1 and out["config"]["collective_backend"] == "nccl"
     assert out["config"]["allreduce_ms_per_step"] > 0
 
@@ -115,8 +115,7 @@ def test_sample_cli_two_ranks_write_disjoint_pocket_files(tmp_path):
     import torch
     cfg = os.path.join(ROOT, "tests", "fixtures", "targetdiff_T20.yml")
     e = dict(os.environ, CBGX_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + os.getpid() % 300), "-m", "cbgbench_amd.sample_cli", "--config", cfg, "--out_root",
+    cmd = [sys.executable, "-m", "cbgbench_amd.launch", "--nproc", "2", "-m", "cbgbench_amd.sample_cli", "--config", cfg, "--out_root",
            str(tmp_path), "--synthetic", "5", "--pockets_per_batch", "2", "--random_init"]
     p = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -126,3 +125,51 @@ def test_sample_cli_two_ranks_write_disjoint_pocket_files(tmp_path):
         rec = torch.load(tmp_path / "targetdiff_T20" / f, weights_only=False)
         assert rec["pocket_index"] == i and len(rec["samples"]) == 4
     assert "on 2 rank(s)" in p.stdout
+
+
+def test_two_bench_launches_at_once_on_one_box():
+    """the collision case that stopped round 5's suite: two `bench.py --gpus 2` jobs started in the same instant.  The launcher's
+    rendezvous is a FileStore path per job (cbgbench_amd/launch.py), so there is no port for the two to race for"""
+    import threading
+    res = [None, None]
+
+    def go(i):
+        try:
+            res[i] = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--pockets", "1", "--graphs-per-batch", "10",
+                           "--no-cpu-baseline", "--no-roofline"], env={"CBGX_DIST_BACKEND": "gloo"})
+        except BaseException as e:      # noqa: BLE001 -- reported by the assert below, in the main thread
+            res[i] = e
+
+    th = [threading.Thread(target=go, args=(i,)) for i in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for out in res:
+        assert isinstance(out, dict), out
+        assert out["ranks"] == 2 and out["config"]["ranks_seen"] == 2
+
+
+def test_bench_under_the_drivers_torchrun_entry():
+    """the driver's own N-GPU command line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`): RANK / WORLD_SIZE / MASTER_* come from that launcher and bench.py must not start ranks of
+    its own.  The port is the caller's to choose (here: the test standing in for the driver, so the test retries a taken port)"""
+    import socket
+    err = ""
+    for _ in range(3):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        e = dict(os.environ, CBGX_DIST_BACKEND="gloo")
+        for k in ("CBGX_RDZV_FILE", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            e.pop(k, None)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--pockets",
+               "1", "--graphs-per-batch", "10", "--no-cpu-baseline", "--no-roofline"]
+        p = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=600, cwd=ROOT)
+        err = p.stderr[-2000:]
+        if p.returncode == 0 or "EADDRINUSE" not in p.stderr:
+            break
+    assert p.returncode == 0, err
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["ranks"] == 2 and out["config"]["ranks_seen"] == 2 and out["config"]["collective_backend"] == "gloo"

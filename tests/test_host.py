@@ -16,6 +16,12 @@ from oracle import weights as W
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _rdzv_file():
+    """the FileStore path the ranks of one test job meet on (cbgbench_amd.launch's rendezvous: no port to collide on)"""
+    from cbgbench_amd import launch
+    return os.path.join(launch.rendezvous_dir(), "store")
+
+
 def test_config_include_and_num_atomtype():
     cfg, name = C.load_config(os.path.join(ROOT, "tests", "fixtures", "targetdiff_test.yml"))
     assert name == "targetdiff_test"
@@ -167,9 +173,9 @@ def test_abi_argument_errors_without_gpu():
 
 
 # ---- multi-GPU path: sharding + timing reduction over gloo, world_size 2 ------------------------------
-def _worker(rank, world, port, q):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+def _worker(rank, world, rdzv, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), CBGX_RDZV_FILE=rdzv)
+    os.environ.pop("MASTER_PORT", None)
     r, w, _ = sharding.init_process_group("gloo")
     mine = sharding.shard_indices(11, r, w)
     sharding.barrier()
@@ -182,8 +188,8 @@ def test_pocket_sharding_gloo_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 400)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    rdzv = _rdzv_file()
+    procs = [ctx.Process(target=_worker, args=(r, 2, rdzv, q)) for r in range(2)]
     for p in procs: p.start()
     res = sorted(q.get(timeout=120) for _ in procs)
     for p in procs: p.join(timeout=60)
@@ -193,8 +199,10 @@ def test_pocket_sharding_gloo_world2():
         assert elapsed == 2.0 and units == 11.0                  # max over ranks, sum over ranks
 
 
-def _forced_single_rank_worker(port, q):
-    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CBGX_DIST_FORCE="1")
+def _forced_single_rank_worker(_unused, q):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", CBGX_DIST_FORCE="1")     # no rendezvous given: a private FileStore
+    for k in ("MASTER_ADDR", "MASTER_PORT", "CBGX_RDZV_FILE"):
+        os.environ.pop(k, None)
     r, w, _ = sharding.init_process_group("gloo")
     ok = torch.distributed.is_initialized() and torch.distributed.get_world_size() == 1
     sharding.barrier()
@@ -208,7 +216,7 @@ def test_forced_single_rank_group_runs_the_collectives():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_forced_single_rank_worker, args=(29950 + (os.getpid() % 40), q))
+    p = ctx.Process(target=_forced_single_rank_worker, args=(None, q))
     p.start()
     r, w, ok, red = q.get(timeout=120)
     p.join(timeout=60)
@@ -338,10 +346,10 @@ def _toy_batch(rank):
     return {"x": torch.randn(8, 5, generator=g), "y": torch.randn(8, 3, generator=g)}
 
 
-def _train_worker(rank, world, port, q):
+def _train_worker(rank, world, rdzv, q):
     from cbgbench_amd import train as TRN
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), CBGX_RDZV_FILE=rdzv)
+    os.environ.pop("MASTER_PORT", None)
     sharding.init_process_group("gloo")
     model = _ToyModel()
     with torch.no_grad():
@@ -362,8 +370,8 @@ def test_data_parallel_train_step_gloo_world2():
     from cbgbench_amd import train as TRN
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29900 + (os.getpid() % 90)
-    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    rdzv = _rdzv_file()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, rdzv, q)) for r in range(2)]
     for p in procs: p.start()
     res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs: p.join(timeout=60)

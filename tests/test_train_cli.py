@@ -11,6 +11,12 @@ from cbgbench_amd import registry, sharding, train_cli
 from cbgbench_amd.config import Config
 
 
+def _rdzv_file():
+    """the FileStore path the ranks of one test job meet on (cbgbench_amd.launch's rendezvous: no port to collide on)"""
+    from cbgbench_amd import launch
+    return os.path.join(launch.rendezvous_dir(), "store")
+
+
 def test_sharded_loader_partitions_every_epoch():
     n, world, bs = 11, 3, 2
     loaders = [train_cli.ShardedLoader(n, bs, r, world, seed=5) for r in range(world)]
@@ -107,9 +113,9 @@ def test_loop_checkpoints_and_resume_single_process(tmp_path):
     assert int(st[0]["step"]) == 3 + 2            # 3 restored steps + iterations 3 and 4
 
 
-def _worker(rank, world, port, logdir, q):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+def _worker(rank, world, rdzv, logdir, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), CBGX_RDZV_FILE=rdzv)
+    os.environ.pop("MASTER_PORT", None)
     sharding.init_process_group("gloo")
     registry.register_model("stub_cpu")(_Stub)
     tr, va = _sets()
@@ -122,8 +128,8 @@ def test_loop_data_parallel_gloo_world2(tmp_path):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 90)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    rdzv = _rdzv_file()
+    procs = [ctx.Process(target=_worker, args=(r, 2, rdzv, str(tmp_path), q)) for r in range(2)]
     for p in procs: p.start()
     res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs: p.join(timeout=60)
