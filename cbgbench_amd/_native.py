@@ -147,3 +147,26 @@ def ptr(t):
 
 def current_stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+
+def version(t):
+    """the in-place-write counter of a tensor, for caches keyed on "same tensor, not written since".  Inference tensors
+    (created under torch.inference_mode()) keep no counter and reading it raises; they get a value that never compares equal, even to
+    itself across two calls, so every cache treats them as always stale and takes its uncached route."""
+    if t.is_inference():
+        return _NeverEqual()
+    return t._version
+
+
+class _NeverEqual:
+    __slots__ = ()
+
+    def __eq__(self, other):
+        return False
+
+    def __ne__(self, other):
+        return True
+
+    def __hash__(self):
+        return id(self)

@@ -201,6 +201,14 @@ struct BlockOverlap {
     AuxLane* aux;       // auxiliary stream + events of the caller's stream (api.hip); NULL: everything on the caller's stream
     int next_set;       // set of the next block
     bool used[2];       // done[set] has been recorded
+    bool joined = false;
+    // Every exit path joins the auxiliary stream: an RC_TRY / HIP_TRY return from inside the layer loop must not leave it writing
+    // gradients and slab buffers that the caller -- or the next call on this workspace, which starts with used = {false, false} and
+    // would wait on nothing -- reuses.  The success path joins with stream-side waits (cbgx_unitransformer_backward, below) and sets
+    // `joined`; a failure path blocks the host here until the auxiliary stream has drained.
+    ~BlockOverlap() {
+        if (aux && !joined && (used[0] || used[1])) (void)hipStreamSynchronize(aux->s);
+    }
 };
 
 static int attention_block_backward(bool x2h, const float* att, const float* x, const float* h_in, const float* g_out,
@@ -659,6 +667,7 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
     if (ov.aux)
         for (int k = 0; k < 2; ++k)
             if (ov.used[k]) HIP_TRY(hipStreamWaitEvent(s, ov.aux->done[k], 0));
+    ov.joined = true;
     // distance gate (computed once from the input coordinates, used by all 2L blocks)
     HIP_TRY(launch_gate_backward_mfma(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.partial, GATE_GRID, s));
     FOLDED(w.partial, GATE_GRID, GB_SIZE, GB_SIZE);

@@ -1138,7 +1138,9 @@ __global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __rest
     const uint8_t* __restrict__ d1p = d1_in ? d1_in : lig;
     // The (node, slot) pairs of a thread -- pair t = tid + 1024 u, so a wave holds the 2 x 32 slots of two nodes -- are loaded ONCE,
     // all in flight, and kept in registers over the three levels when the graph has at most GL_KEEP * 32 nodes (768: every pocket
-    // of the shipped data).  Rows are -1 padded, so a slot is valid iff its entry is >= 0.
+    // of the shipped data).  Rows are -1 padded past the node's degree (knn_graph writes them so; cbgx.h states it for a caller's
+    // static_nbr): a slot is valid iff its entry is a node of this graph -- the range check also keeps a foreign table from indexing
+    // LDS out of bounds (`deg` itself is not read: the check costs two VALU per pair, a load would cost a round trip).
     constexpr int GL_KEEP = 24;
     const int n_pairs = n * KNN;
     const bool keep = n_pairs <= GL_KEEP * 1024;
@@ -1183,7 +1185,7 @@ __global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __rest
                 const int u = ub + v;
                 const int t = tid + 1024 * (u0 + u);
                 const int i = min(t, n_pairs - 1) >> 5;
-                const bool valid = t < n_pairs && jl[u] >= 0;
+                const bool valid = t < n_pairs && (unsigned)(jl[u] - gs) < (unsigned)n;     // -1 padding, and ids outside the graph
                 fi_[v] = F[i];
                 fj_[v] = F[valid ? jl[u] - gs : i];
             }
@@ -1195,7 +1197,7 @@ __global__ __launch_bounds__(1024) void graph_lists_kernel(const uint8_t* __rest
                 const int t = tid + 1024 * (u0 + u);                      // (n_pairs is a multiple of 32: a half-wave is all in or all out)
                 const bool in = t < n_pairs;
                 const int i = min(t, n_pairs - 1) >> 5;
-                const bool valid = in && jl[u] >= 0;
+                const bool valid = in && (unsigned)(jl[u] - gs) < (unsigned)n;
                 const int j = valid ? jl[u] - gs : i;
                 const unsigned fi = fi_[v], fj = fj_[v];
                 // what the neighbour tells the node (OR over the node's slots) and what the node tells the neighbour

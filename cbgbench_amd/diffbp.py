@@ -163,7 +163,7 @@ class CoMPredictor(nn.Module):
 
     def packed_weights(self, device):
         params = self._ordered_params()
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (str(device),) + tuple((p.data_ptr(), _native.version(p)) for p in params)
         if self._packed is None or self._packed_key != key:
             lib = _native.lib()
             packed = torch.empty(lib.cbgx_packed_h2x_stack_floats(self.num_layers), dtype=torch.float32, device=device)

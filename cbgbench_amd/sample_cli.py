@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from . import get_model, load_config, priors, set_num_atom_type, sharding, synthetic
-from .config import get_atomic_number_from_index, is_aromatic_from_index, load_checkpoint_file
+from .config import NUM_ATOM_TYPES, get_atomic_number_from_index, is_aromatic_from_index, load_checkpoint_file
 
 
 def build_pocket_batch(pockets, num_samples, rng, num_classes, prior_types="uniform", device="cpu", num_dist=None,
@@ -81,6 +81,17 @@ def split_samples(x, c, batch_idx, n_graphs, mode="add_aromatic"):
                     "atom": get_atomic_number_from_index(typ.tolist(), mode),
                     "aromatic": is_aromatic_from_index(typ.tolist(), mode), "type_vector": c[m].clone()})
     return out
+
+
+def decode_mode(plan_mode, config_mode, num_classes):
+    """the atom-type vocabulary the samples are decoded with (sample.py:211-214 passes the transform's ``mode`` on to
+    ``reconstruct_mol``): the ``mode`` of the config's assign_atomtype / assign_genatomtype transform (``SamplingPlan.mode``), else the
+    top-level ``config.mode`` -- and it must be the vocabulary the model's ``num_atomtype`` was built with"""
+    for mode in (plan_mode, config_mode):
+        if mode in NUM_ATOM_TYPES and NUM_ATOM_TYPES[mode] == num_classes:
+            return mode
+    raise ValueError(f"no atom-type vocabulary of {num_classes} classes among the config's modes "
+                     f"(transform mode {plan_mode!r}, config.mode {config_mode!r}; known: {dict(NUM_ATOM_TYPES)})")
 
 
 def main(argv=None, stats=None):
@@ -159,6 +170,7 @@ def main(argv=None, stats=None):
 
     plan = priors.SamplingPlan.from_config(config)       # priors, centring and task of the config's transform list
     num_classes = config.model.num_atomtype
+    mode = decode_mode(plan.mode, config.get("mode", None), num_classes)
     if args.pockets:
         raw = torch.load(args.pockets, map_location="cpu", weights_only=False)
         pockets = [(np.asarray(p["protein_pos"], np.float32), np.asarray(p["protein_atom_feature"], np.float32),
@@ -192,7 +204,7 @@ def main(argv=None, stats=None):
         x, c, bidx = x.cpu(), c.cpu(), bidx.cpu()
         if translate:       # back to the frame the pockets came in (sample.py:198-199; here per graph: a batch holds many pockets)
             x = x + batch["ligand_translation"].cpu()
-        samples = split_samples(x, c, bidx, len(ids) * num_samples, config.get("mode", "add_aromatic"))
+        samples = split_samples(x, c, bidx, len(ids) * num_samples, mode)
         if "ligand_gen_flag" in batch:      # context tasks: which atoms of a record were generated
             gen = batch["ligand_gen_flag"].cpu()
             for g, smp in enumerate(samples):

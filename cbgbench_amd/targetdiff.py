@@ -657,7 +657,11 @@ class TargetDiff(BatchesInFlight, nn.Module):
         rand_like(log-probs) in every step (targetdiff.py:168-175 -> diffusion_scheduler.py:163, categorical.py:27); the same
         two generators are drawn here for NOISE_CHUNK steps at a time and handed out step by step: two launches per chunk
         instead of two per step (10 us of a 900 us one-graph step).  Fresh numbers every step, the same distributions; the order
-        in which the global generator is consumed differs from per-step draws (tests replay noise through ``noise=``)."""
+        in which the global generator is consumed differs from per-step draws (tests replay noise through ``noise=``).
+        SEED COMPATIBILITY: with NOISE_CHUNK > 1 a fixed torch seed gives a different (equally distributed) trajectory than the
+        reference's per-step draw order, than ``use_graph=True`` (``_traj_step`` draws per step) and than rounds before 5; up to
+        NOISE_CHUNK - 1 unused steps of noise are drawn at the end of a run.  ``model.NOISE_CHUNK = 1`` restores the reference's
+        draw order exactly (randn of step t, rand of step t, randn of step t - 1, ...), identical to the hipGraph path."""
         q = st.get("_noise_q")
         if q is None or q[2] >= q[0].shape[0] or q[0].shape[1] != n_lig:
             q = [torch.randn(self.NOISE_CHUNK, n_lig, 3, dtype=torch.float32, device=dev),
@@ -679,7 +683,7 @@ class TargetDiff(BatchesInFlight, nn.Module):
         # of a run, a caller that replaced or edited st["x_lig"] / st["c_lig"] -- the prologue kernel composes them.
         comp = st.get("_composed")
         if not (self.fuse_step_boundary and comp is not None and comp[0] is x_lig and comp[1] is c_lig
-                and comp[2] == x_lig._version and comp[3] == c_lig._version):
+                and comp[2] == _native.version(x_lig) and comp[3] == _native.version(c_lig)):
             _native.check(lib.cbgx_targetdiff_prologue(
                 _native.ptr(x_lig), _native.ptr(c_lig), _native.ptr(st["lig_rows32"]), n_lig, C,
                 _native.ptr(emb.ligand_atom_emb.weight), _native.ptr(emb.ligand_atom_emb.bias),
@@ -705,7 +709,7 @@ class TargetDiff(BatchesInFlight, nn.Module):
                 _native.ptr(emb.ligand_atom_emb.weight), _native.ptr(emb.ligand_atom_emb.bias),
                 _native.ptr(emb.ligand_indicator.weight), _native.ptr(emb.ligand_indicator.bias),
                 _native.ptr(st["x"]), _native.ptr(st["h"]), stream), "cbgx_targetdiff_step_boundary")
-            st["_composed"] = (x_next, c_next, x_next._version, c_next._version)
+            st["_composed"] = (x_next, c_next, _native.version(x_next), _native.version(c_next))
         else:
             _native.check(lib.cbgx_targetdiff_epilogue(
                 _native.ptr(xo), _native.ptr(logits), _native.ptr(st["lig_rows32"]), _native.ptr(x_lig), _native.ptr(c_lig),
@@ -780,7 +784,9 @@ class TargetDiff(BatchesInFlight, nn.Module):
         ``return_device``: where the returned trajectory lives (default: CPU, like the reference).
         ``use_graph``: replay one captured hipGraph per step instead of ~100 stream launches.  Off by default: measured on
         MI355X it changes nothing (1.22 ms per step at 445 nodes either way) -- small batches are bound by the
-        dependent-kernel chain on the device, not by host launches."""
+        dependent-kernel chain on the device, not by host launches.
+        Fixed-seed reproducibility: see ``_step_noise`` (``NOISE_CHUNK``); works under ``torch.inference_mode()`` as well as
+        ``torch.no_grad()`` (tensors without a version counter take the uncached routes)."""
         T = self.num_diffusion_timesteps
         lap = _Lap(timing, batch["ligand_pos"].device)      # (``timing``: see sample_many)
         st = self.begin_sampling(batch, keep_trajectory=True)

@@ -256,7 +256,7 @@ class UniTransformer(nn.Module):
         if self.classifier is None:
             raise ValueError("libcbgx needs the classifier head (num_classes) to pack weights")
         params = self._ordered_params()
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (str(device),) + tuple((p.data_ptr(), _native.version(p)) for p in params)
         if self._packed is None or self._packed_key != key:
             lib = _native.lib()
             n = lib.cbgx_packed_weights_floats(self.num_layers, self.out_classes)
@@ -366,12 +366,12 @@ class UniTransformer(nn.Module):
             return flag.to(torch.uint8).contiguous()
         cache = self.__dict__.setdefault("_flag_cache", {})
         hit = cache.get(id(flag))
-        if hit is not None and hit[0] is flag and hit[1] == flag._version and hit[2].device == flag.device:
+        if hit is not None and hit[0] is flag and hit[1] == _native.version(flag) and hit[2].device == flag.device:
             return hit[2]
         u8 = flag.to(torch.uint8).contiguous()
         if len(cache) >= 64:
             cache.pop(next(iter(cache)))
-        cache[id(flag)] = (flag, flag._version, u8)      # holds `flag`: its id cannot be reused while the entry lives
+        cache[id(flag)] = (flag, _native.version(flag), u8)      # holds `flag`: its id cannot be reused while the entry lives
         return u8
 
     def forward(self, x, h, batch_idx, lig_flag, gen_flag, graph_ptr=None, need_h=True, static_h=None,

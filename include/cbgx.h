@@ -60,6 +60,12 @@ extern "C" {
 
 #define CBGX_OK 0
 #define CBGX_E_INVALID (-1)   /* bad argument (shape, NULL pointer, unsupported hyper-parameter) */
+/* Unsupported hyper-parameters -- the encoder options of unitransformer.py:17-39 that no shipped config sets and this library does not
+ * implement: num_x2h / num_h2x != 1, num_blocks != 1, ew_type in {'r', 'm'} (x2h_attention.py:70-76; the 'r' branch of
+ * h2x_attention.py:54 is broken in the reference), cutoff_mode in {'radius', 'hybrid'} (unitransformer.py:77,83 reference undefined
+ * names there), x2h_out_fc=True (x2h_attention.py:93-94), n_heads != 16, node_feat_dim != 128, k != 32, num_r_gaussian != 20,
+ * act_fn != 'relu', norm=False, and a `time:` embedding (context_emb.py:190-195).  The host mirror raises ValueError naming the option
+ * (cbgbench_amd/unitransformer.py; texts pinned by tests/test_host.py), the C entry points return CBGX_E_INVALID. */
 #define CBGX_E_WORKSPACE (-2) /* workspace too small */
 #define CBGX_E_HIP (-3)       /* a HIP runtime call / kernel launch failed */
 
@@ -124,7 +130,9 @@ int cbgx_unitransformer_forward(const float *packed, int num_layers, int num_cla
  * Optional graph part (all four or none; NULL = recompute): static_nbr [N,32] / static_deg [N] / static_ew [N,32] = the
  * ligand-free pockets' cbgx_knn_graph lists (in composed row numbers) and cbgx_edge_gate values, static_r32sq [N] = squared
  * distance to the last (32nd) of those neighbours, +inf where deg < 32.  A protein node whose nearest ligand atom is not
- * closer than that keeps its cached list and gate; only the others get fresh ones.
+ * closer than that keeps its cached list and gate; only the others get fresh ones.  static_nbr rows must be what cbgx_knn_graph
+ * writes: ids of nodes of the SAME graph in the first static_deg[i] slots, -1 in the rest (an entry outside its graph is treated as
+ * padding by the list kernels; it is never dereferenced).
  * Results are bit-identical to cbgx_unitransformer_forward.  Requires num_layers >= 4 (otherwise the cache is ignored).
  * flags: CBGX_FWD_H_ON_SOURCES -- the caller reads h_out only on the rows A1 = gen_flag | lig_flag | in-neighbours of gen_flag rows
  *   (what an H2X stack run on the same coordinates reads: DiffBP's CoMPredictor, diffbp.py:79-101; pass the same rows to

@@ -470,6 +470,28 @@ def test_sample_many_equals_sample(synthetic_sd):
             assert torch.equal(a[t][0], b[t][0]) and torch.equal(a[t][1], b[t][1]) and torch.equal(a[t][2], b[t][2])
 
 
+@pytest.mark.parametrize("name", ["targetdiff", "diffbp", "diffsbdd"])
+def test_sampling_under_inference_mode_equals_no_grad(name):
+    """the flag / composed-row / packed-weight caches read tensor._version, which inference tensors do not have.
+    A batch built and sampled inside torch.inference_mode() must run (uncached routes) and give the trajectory of the no_grad run
+    for the same noise."""
+    T, C_ = 6, (8 if name == "diffsbdd" else 13)
+    cfg = {"targetdiff": C.default_targetdiff_config, "diffbp": C.default_diffbp_config, "diffsbdd": C.default_diffsbdd_config}[name]
+    torch.manual_seed(3)
+    m = C.get_model(cfg(C_, num_diffusion_timesteps=T)).eval().to(DEV)
+    host = synthetic.denovo_batch(3, seed=77, n_rec_range=(120, 180), n_lig_range=(8, 14), num_classes=C_)
+    torch.manual_seed(5)
+    ref = m.sample(synthetic.batch_to(host, DEV))
+    with torch.inference_mode():
+        b = synthetic.batch_to({k: (v.clone() if torch.is_tensor(v) else v) for k, v in host.items()}, DEV)
+        assert b["ligand_pos"].is_inference()
+        torch.manual_seed(5)
+        got = m.sample(b)
+    assert sorted(ref.keys()) == sorted(got.keys())
+    for t in ref:
+        assert torch.equal(ref[t][0], got[t][0]) and torch.equal(ref[t][1], got[t][1]), (name, t)
+
+
 def test_sample_many_with_step_graphs_equals_eager_steps(synthetic_sd):
     """small batches kept in flight as captured hipGraphs (sample_many(use_graph=True): four batches on two streams, so two graphs
     share a stream and all four are replayed interleaved, each with its own workspace) against eager steps of the same batches

@@ -575,3 +575,19 @@ def test_ordered_parameter_list_is_cached_and_revalidated():
     c = d._ordered_params()
     m.load_state_dict(m.state_dict())
     assert d._ordered_params() is c
+
+
+def test_version_of_an_inference_tensor_never_matches():
+    """caches keyed on tensor._version must not crash under torch.inference_mode() (inference tensors keep no counter):
+    _native.version hands out a value that never compares equal, so such tensors always take the uncached route"""
+    t = torch.zeros(3)
+    assert _native.version(t) == _native.version(t) == 0
+    t.add_(1)
+    assert _native.version(t) == 1
+    with torch.inference_mode():
+        f = torch.zeros(3, dtype=torch.bool)
+        assert f.is_inference()
+        assert not (_native.version(f) == _native.version(f))
+        assert _native.version(f) != _native.version(f)
+        key = (1, _native.version(f))
+        assert key != (1, _native.version(f))

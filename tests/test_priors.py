@@ -268,3 +268,17 @@ def test_sample_cli_context_plumbing(tmp_path):
     assert "ligand_gen_flag" not in d and d["ligand_atom_type"].shape[1] == 8
     m = torch.zeros(4, 3).index_add_(0, d["ligand_element_batch"], d["ligand_pos"])
     assert float(m.abs().max()) < 1e-4               # zero_mean_gaussian, configs/denovo/test/diffsbdd.yml
+
+
+def test_decode_mode_follows_the_transform_not_a_default():
+    """the diffsbdd configs carry ``mode: basic`` only inside the transform list; their samples must be decoded with the
+    8-class table, and a vocabulary that does not match the model's class count is an error, not a silent mis-decode"""
+    from cbgbench_amd import sample_cli
+    assert sample_cli.decode_mode("basic", None, 8) == "basic"
+    assert sample_cli.decode_mode("basic", "add_aromatic", 13) == "add_aromatic"     # --num_atomtype style override: config.mode wins
+    assert sample_cli.decode_mode("add_aromatic", None, 13) == "add_aromatic"
+    with pytest.raises(ValueError, match="no atom-type vocabulary of 8 classes"):
+        sample_cli.decode_mode("add_aromatic", None, 8)
+    x = torch.zeros(2, 3); c = torch.eye(8)[[5, 7]]
+    rec = sample_cli.split_samples(x, c, torch.tensor([0, 0]), 1, "basic")[0]
+    assert rec["atom"] == [15, 17] and rec["aromatic"] is None
