@@ -54,8 +54,9 @@ hipError_t launch_edge_backward_x2h(const float* att, const float* x, const floa
                                     const float* e_w, const int* rows, const int* n_rows, int n_nodes, float* T, float* S,
                                     float* sw, float* dP, float* dx, float* de_w, float* partial, float* nk_scratch,
                                     int* work_ctr, int grid, hipStream_t s);
-// floats of nk_scratch: one slot per wave of the largest grid (the key path parked between two phases of a node)
-constexpr size_t BX_NK_FLOATS = (size_t)256 * 8 * (KNN * H + 128);
+// floats of nk_scratch: two slots (key | value path) per wave of the largest grid: the normalised pre-activation of a path, parked by its
+// forward part and read back by the backward sweep in the same labeling (the key path also across two phases of a node)
+constexpr size_t BX_NK_FLOATS = (size_t)256 * 8 * 2 * (KNN * H + 128);
 hipError_t launch_fold_grad(const float* att, const float* Gr, int n_nodes, float* Gt, float* gb, hipStream_t s);
 hipError_t launch_outer_accum_mfma(bool headed, const float* Lm, const float* R, const int* rows, const int* n_rows,
                                    int n_nodes, float* partial, size_t slab_stride, int grid, hipStream_t s);

@@ -71,6 +71,11 @@ constexpr int BX_WAVES = CBGX_BX_WAVES;
                                  // (A/B, scripts/build_variant.py: 1 -> 851, 2 -> 829, 3 -> 845 us per 16.5 k-node launch)
 #endif
 constexpr int BX_DYN_ROUNDS = CBGX_BX_DYN_ROUNDS;
+#ifndef CBGX_BX_Y4X4
+#define CBGX_BX_Y4X4 0      // rbf columns g = 16..19 of d Wr on v_mfma_f32_4x4x1 (16 blocks of 4 x 4, 8 cycles) instead of a 16x16x4 tile
+                            // of which 4 of 16 rows are used (32 cycles): see pass 4
+#endif
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 constexpr int BX_PITCH = H + 4;                 // transpose tile row pitch (floats): 16-byte aligned rows
 constexpr int BX_TILE = KNN * BX_PITCH;         // 4224 floats per wave
 // the four pad columns of a tile row hold per-edge scalars of the node (row = edge) instead of living in registers across the
@@ -254,7 +259,8 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     u0[hf][r] = dist - mu0;
                     u1[hf][r] = dist - mu1;
                     r0[hf][r] = fast_exp(-0.5f * (u0[hf][r] * u0[hf][r])) * vm;
-                    r1[hf][r] = fast_exp(-0.5f * (u1[hf][r] * u1[hf][r])) * (c < 4 ? vm : 0.f);
+                    // (CBGX_BX_Y4X4: every lane carries g = 16 + (c & 3) -- the A operand of its 4 x 4 block, see pass 4)
+                    r1[hf][r] = fast_exp(-0.5f * (u1[hf][r] * u1[hf][r])) * ((CBGX_BX_Y4X4 || c < 4) ? vm : 0.f);
                 }
         };
         BX_T(0);
@@ -282,7 +288,8 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
             const RbfScale rsc = load_rbf_scale(att, kv);      // the tile is carried scaled by S until LayerNorm (edge_common.h)
             // the key path's normalised pre-activation is parked in the wave's slot of a scratch buffer in phase 0 and read back in
             // phase 2 (16 coalesced KB each way) instead of being gathered, multiplied and normalised a second time
-            float* nk = nk_scratch + ((size_t)blockIdx.x * BX_WAVES + wave) * BX_NK_SLOT + 4 * lane;
+            // (two slots per wave, key | value: passes 2 + 3 below read the path's n back in the labeling the forward left it in)
+            float* nk = nk_scratch + (((size_t)blockIdx.x * BX_WAVES + wave) * 2 + kv) * BX_NK_SLOT + 4 * lane;
             if (ph == 2) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf)
@@ -386,13 +393,13 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
 #pragma unroll
                     for (int t = 0; t < 8; ++t) n[hf][t] = n[hf][t] * sc;
                 }
-                if (ph == 0) {
+                {       // parked: the key path for phase 2 (n and rstd), either path for its own passes 2 + 3 (n)
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                         for (int t = 0; t < 8; ++t)
                             *reinterpret_cast<float4*>(nk + (hf * 8 + t) * 256) = make_float4(n[hf][t][0], n[hf][t][1], n[hf][t][2], n[hf][t][3]);
-                    *reinterpret_cast<float2*>(nk + 16 * 256 - 2 * lane) = make_float2(rstd[0], rstd[1]);
+                    if (ph == 0) *reinterpret_cast<float2*>(nk + 16 * 256 - 2 * lane) = make_float2(rstd[0], rstd[1]);
                 }
             }
             BX_T(2);
@@ -518,11 +525,6 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     *reinterpret_cast<float4*>(tw + (c + 16 * hf) * BX_PITCH + 16 * t + 4 * q) =
                         make_float4(n[hf][t][0], n[hf][t][1], n[hf][t][2], n[hf][t][3]);
             wave_sync();
-            float rs1[2][4];
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rs1[hf][r] = __shfl(rstd[hf], 4 * q + r, 64);
             BX_T(4);
             // ---- pass 1, C labeling: lane (c, q), step (u, j), [hf][r] <-> channel 32 u + 2 c + j, edge 4q + r + 16 hf ------------
             // folds T / S, LayerNorm affine gradients, the two per-edge sums of the LayerNorm backward.  Padded slots need no mask:
@@ -569,6 +571,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 }
                 floatx4 fold[2];
                 float gsum[2], bsum[2];
+                float vv[2][2][4];      // v = d hidden . gamma behind the ReLU mask: written over n below, read by passes 2 + 3
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const float gmc = j ? g2.y : g2.x, btc = j ? b2.y : b2.x;
@@ -598,12 +601,19 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                             gs = fmaf(dy, nn, gs);
                             bs += dy;
                             const float v = dy * gmc;
+                            vv[j][hf][r] = v;
                             s1[hf][r] += v;
                             s2[hf][r] = fmaf(v, nn, s2[hf][r]);
                         }
                     gsum[j] = xrow_sum(gs);
                     bsum[j] = xrow_sum(bs);
                 }
+                // (every cell of the step was read into nv before the first is overwritten)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        *reinterpret_cast<float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + ch) = make_float2(vv[0][hf][r], vv[1][hf][r]);
                 // fold D: lane (c = head, q) reg r <-> channel 32 u + 2 (4 q + r) + j
                 float* fd = fold_dst + (size_t)c * H + 32 * u + 8 * q;
                 *reinterpret_cast<float4*>(fd) = make_float4(fold[0][0], fold[1][0], fold[0][1], fold[1][1]);
@@ -623,90 +633,97 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     s2[hf][r] = row16_sum(s2[hf][r]) * (1.f / H);
                 }
             BX_T(5);
-            // ---- pass 2 (C): d hidden again (cheaper than 64 live registers of it) -> d pre, in place in the tile.  All cells of a step
-            // are read before the first is written back (the compiler cannot tell the cells apart and would serialise read -> write) ----
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ch = 32 * u + 2 * c;
-                const float2 g2 = g2a[u], b2 = b2a[u];
-                const float2 (&qa)[4] = qaa[u];
-                float2 nn[2][4];
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) nn[hf][r] = *reinterpret_cast<const float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + ch);
-                float2 out[2][4];
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    floatx4 de0 = {0.f, 0.f, 0.f, 0.f}, de1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) { de0 = MFMA(wT[hf][s], qa[s].x, de0); de1 = MFMA(wT[hf][s], qa[s].y, de1); }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float dn0 = fmaf(nn[hf][r].x, g2.x, b2.x) > 0.f ? de0[r] * g2.x : 0.f;
-                        const float dn1 = fmaf(nn[hf][r].y, g2.y, b2.y) > 0.f ? de1[r] * g2.y : 0.f;
-                        // padded slots: d hidden = 0, n = 0, s1 = s2 = 0 -> exact zeros
-                        out[hf][r] = make_float2(rs1[hf][r] * (dn0 - s1[hf][r] - nn[hf][r].x * s2[hf][r]),
-                                                 rs1[hf][r] * (dn1 - s1[hf][r] - nn[hf][r].y * s2[hf][r]));
-                    }
-                }
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) *reinterpret_cast<float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + ch) = out[hf][r];
-            }
             wave_sync();
-            BX_T(6);
-            // ---- pass 3 (E): d rbf[e][g] = sum_m d pre[e][m] Wr[type_e][g][m]  ->  d dist ----------------------------------------------
-            float rT0[2][4], rT1[2][4], u0[2][4], u1[2][4];
-            rbf_e1(vsh, rT0, rT1, u0, u1);
-            float dd[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll 1
-            for (int p = 0; p < 2; ++p) {
-                if (p == 0 ? !has_prot : !has_lig) continue;
-                if (abl & 2) continue;
-                // centred rbf columns [type][g][k | v]: rows g = c and 16 + c (clamped; those results are discarded through rT1 = 0)
-                const float* w0p = att + A_WRC + ((size_t)etype(p == 1, lig_i) * G + c) * 2 * H + kv * H + 4 * q;
-                const float* w1p = att + A_WRC + ((size_t)etype(p == 1, lig_i) * G + (c < 4 ? 16 + c : 19)) * 2 * H + kv * H + 4 * q;
-                const float m0 = (!mixed || lg0[0] == (p == 1)) ? 1.f : 0.f, m1 = (!mixed || lg0[1] == (p == 1)) ? 1.f : 0.f;
-                floatx4 d0[2], d1[2];
+            // ---- passes 2 + 3, E labeling, one sweep (round 6).  Pass 1 left v = d hidden . gamma (ReLU-masked) in the tile in place of n.
+            // The LayerNorm backward  d pre = rstd (v - s1 - n s2)  is elementwise, so it runs in the labeling the forward left n in: n
+            // comes back from the wave's scratch slot, d pre goes to the tile for pass 4, and on the way
+            //     d dist[e] = sum_m d pre[e][m] V[e][m],   V[e][m] = sum_g rbf'_g(d_e) Wr[type_e][g][m],   rbf' = -(d - mu) rbf
+            // -- V is the forward's rbf product with rbf' in place of rbf: the same split-f16 weight tuples, 64 f16 MFMAs (17 cycles)
+            // where  d rbf = d pre . Wr^T  took 128 fp32 ones (32 cycles), and d hidden is not evaluated a second time (64 more).
+            // E1 -> E0: lane (c, q) needs the sums of edge c + 16 hf, which the lanes of row c >> 2 hold in register c & 3
+            auto e1_to_e0 = [&](const float (&a)[4]) {
+                const int r = c & 3;
+                const float sel = r == 0 ? a[0] : (r == 1 ? a[1] : (r == 2 ? a[2] : a[3]));
+                return __shfl(sel, 16 * (c >> 2) + r, 64);
+            };
+            const float s1e[2] = {e1_to_e0(s1[0]), e1_to_e0(s1[1])}, s2e[2] = {e1_to_e0(s2[0]), e1_to_e0(s2[1])};
+            float4 nq0[8];          // n of the first half: requested ahead of the rbf' product
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) { d0[hf] = floatx4{0.f, 0.f, 0.f, 0.f}; d1[hf] = floatx4{0.f, 0.f, 0.f, 0.f}; }
-                float4 w0a[8], w1a[8];
+            for (int t = 0; t < 8; ++t) nq0[t] = ld4(nk + t * 256);
+            floatx4 V[2][8];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) { w0a[t] = ld4(w0p + 16 * t); w1a[t] = ld4(w1p + 16 * t); }
-                SCHED_FENCE();
+            for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const float4 w0 = w0a[t], w1 = w1a[t];
+                for (int t = 0; t < 8; ++t) V[hf][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (!(abl & 2)) {
+                for (int p = p1;;) {        // the source classes present, as in the forward part
+                    WTuples wt[8];
+                    const float* fa = frag + (size_t)etype(p == 1, lig_i) * (8 * FRAG_BLK);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) wt[t] = load_wtuples(fa, t, lane);
+                    half4 B[2][4];
+                    float muq[5];
+#pragma unroll
+                    for (int s = 0; s < 5; ++s) muq[s] = tw[(4 * s + q) * BX_PITCH + BX_MU];
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
-                        const floatx4 dE = f4(*reinterpret_cast<const float4*>(tw + (c + 16 * hf) * BX_PITCH + 16 * t + 4 * q)) * (hf ? m1 : m0);
-                        d0[hf] = MFMA(dE[0], w0.x, d0[hf]);  d1[hf] = MFMA(dE[0], w1.x, d1[hf]);
-                        d0[hf] = MFMA(dE[1], w0.y, d0[hf]);  d1[hf] = MFMA(dE[1], w1.y, d1[hf]);
-                        d0[hf] = MFMA(dE[2], w0.z, d0[hf]);  d1[hf] = MFMA(dE[2], w1.z, d1[hf]);
-                        d0[hf] = MFMA(dE[3], w0.w, d0[hf]);  d1[hf] = MFMA(dE[3], w1.w, d1[hf]);
+                        float Rm[5];
+#pragma unroll
+                        for (int s = 0; s < 5; ++s) {
+                            const float u = dist0[hf] - muq[s];
+                            Rm[s] = (-u * fast_exp(-0.5f * (u * u))) * ((val0[hf] && lg0[hf] == (p == 1)) ? RBF_UP : 0.f);
+                        }
+                        rbf_tuples(Rm, B[hf]);
                     }
+                    SCHED_FENCE();
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        V[0][t] = MFMAH(wt[t].t1, B[0][0], V[0][t]);       V[1][t] = MFMAH(wt[t].t1, B[1][0], V[1][t]);
+                        V[0][t] = MFMAH(wt[t].t1, B[0][1], V[0][t]);       V[1][t] = MFMAH(wt[t].t1, B[1][1], V[1][t]);
+                        V[0][t] = MFMAH(wt[t].t2, B[0][2], V[0][t]);       V[1][t] = MFMAH(wt[t].t2, B[1][2], V[1][t]);
+                        V[0][t] = MFMAH(wt[t].t3, B[0][3], V[0][t]);       V[1][t] = MFMAH(wt[t].t3, B[1][3], V[1][t]);
+                    }
+                    if (p == 1 || !has_lig) break;
+                    p = 1;
                 }
-                // D: lane (c = g | 16 + g, q) reg r <-> edge 4 q + r + 16 hf (rows of the other class are zero)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = d0[hf][r] * (-u0[hf][r] * rT0[hf][r]) + d1[hf][r] * (-u1[hf][r] * rT1[hf][r]);
-                        dd[hf][r] += row16_sum(v);
-                    }
             }
-            if (c == 0) {       // d L / d dist of the row's eight edges, accumulated over the two paths in the pad column
+            float ddE[2];
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
+            for (int hf = 0; hf < 2; ++hf) {
+                float4 n4[8], v4[8];
+                if (hf == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) tw[(4 * q + r + 16 * hf) * BX_PITCH + BX_DDIST] += dd[hf][r];
+                    for (int t = 0; t < 8; ++t) n4[t] = nq0[t];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) n4[t] = ld4(nk + (8 + t) * 256);
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v4[t] = *reinterpret_cast<const float4*>(tw + (c + 16 * hf) * BX_PITCH + 16 * t + 4 * q);
+                SCHED_FENCE();
+                const float rs = rstd[hf], a1 = s1e[hf], a2 = s2e[hf];
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    // padded slots: v = 0, n = 0, s1 = s2 = 0 -> exact zeros
+                    const floatx4 dp = (f4(v4[t]) - a1 - f4(n4[t]) * a2) * rs;
+                    *reinterpret_cast<float4*>(tw + (c + 16 * hf) * BX_PITCH + 16 * t + 4 * q) = make_float4(dp[0], dp[1], dp[2], dp[3]);
+                    acc += dp * V[hf][t];
+                }
+                ddE[hf] = xrow_sum((acc[0] + acc[1]) + (acc[2] + acc[3])) * rsc.c2;      // V carries the forward's scale S; c2 = 1 / S
             }
+            if (q < 2) tw[(c + 16 * q) * BX_PITCH + BX_DDIST] += q ? ddE[1] : ddE[0];     // over the two paths, in the pad column
+            wave_sync();
+            BX_T(6);
             BX_T(7);
             // ---- pass 4 (C): every atomic of the path in one burst, no global load in between (any vmcnt wait after an atomic is a
             // full drain on gfx9): neighbour rows, own row, type columns, rbf columns of the first Linear -------------------------------------
             // (labeling of this pass: step t, lane (c, q), [hf][r] <-> channel 16 t + c -- a row's 16 lanes add to one 64-byte run)
+            float rT0[2][4], rT1[2][4];
+            {
+                float u0[2][4], u1[2][4];
+                rbf_e1(vsh, rT0, rT1, u0, u1);
+            }
             gwptr dPb = sbase_w(dP);
             unsigned joff[2][4];    // byte offset of the neighbour's PS columns of this path
 #pragma unroll
@@ -762,6 +779,13 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     }
                 }
             };
+            auto ysum = [&](floatx4 y) {      // CBGX_BX_Y4X4: the four blocks (q) of a channel group hold partial sums over their edges
+#if CBGX_BX_Y4X4
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = xrow_sum(y[r]);
+#endif
+                return y;
+            };
             floatx4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0, y0 = x0, y1 = x0;
             float dpn[2][4];
 #pragma unroll
@@ -801,16 +825,24 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 // rbf columns of the first source class: A[g][edge] = rbf_g(d_e) over the edges of the class, B[edge][channel] = d pre.
                 // The products of step t are added to the slab during step t + 1, when the matrix pipe has long delivered them.
                 if (!(abl & 4)) {
-                    if (t > 0) flush_rbf_columns(ty1, kv * H + 16 * (t - 1) + c, x0 + x1, y0 + y1);
+                    if (t > 0) flush_rbf_columns(ty1, kv * H + 16 * (t - 1) + c, x0 + x1, ysum(y0 + y1));
                     x0 = x1 = y0 = y1 = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {       // four independent accumulator chains
+#if CBGX_BX_Y4X4
+                        // block (q, c >> 2) of the 16: A[m] = rbf_{16 + m}(edge 4q + r + 16 hf) from lane c & 3 == m, B[n] = d pre of channel
+                        // 16 t + 4 (c >> 2) + n, D[m][n] in register m of lane n: the block's eight edges accumulate over (hf, r), the four
+                        // blocks of a channel group (q) are summed by ysum() -- lane (c, *) register m <-> g = 16 + m, channel 16 t + c
+                        x0 = MFMA(a0m[0][r], dp[0][r], x0); y0 = MFMA4(a1m[0][r], dp[0][r], y0);
+                        x1 = MFMA(a0m[1][r], dp[1][r], x1); y1 = MFMA4(a1m[1][r], dp[1][r], y1);
+#else
                         x0 = MFMA(a0m[0][r], dp[0][r], x0); y0 = MFMA(a1m[0][r], dp[0][r], y0);
                         x1 = MFMA(a0m[1][r], dp[1][r], x1); y1 = MFMA(a1m[1][r], dp[1][r], y1);
+#endif
                     }
                 }
             }
-            if (!(abl & 4)) flush_rbf_columns(ty1, kv * H + 16 * 7 + c, x0 + x1, y0 + y1);
+            if (!(abl & 4)) flush_rbf_columns(ty1, kv * H + 16 * 7 + c, x0 + x1, ysum(y0 + y1));
             if (mixed && !(abl & 4)) {      // rbf columns of the ligand-source class (its type is never 3): a second, rare sweep
                 float lm[2][4];
 #pragma unroll
@@ -826,9 +858,13 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                         for (int r = 0; r < 4; ++r) {
                             const float b = tw[(4 * q + r + 16 * hf) * BX_PITCH + 16 * t + c];
                             a0 = MFMA(rT0[hf][r] * lm[hf][r], b, a0);
+#if CBGX_BX_Y4X4
+                            a1 = MFMA4(rT1[hf][r] * lm[hf][r], b, a1);
+#else
                             a1 = MFMA(rT1[hf][r] * lm[hf][r], b, a1);
+#endif
                         }
-                    flush_rbf_columns(ty_lig, kv * H + 16 * t + c, a0, a1);
+                    flush_rbf_columns(ty_lig, kv * H + 16 * t + c, a0, ysum(a1));
                 }
             }
             wave_sync();
