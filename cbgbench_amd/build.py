@@ -1,5 +1,6 @@
 """Build libcbgx.so (hipcc, gfx950) in-tree: cbgbench_amd/lib/libcbgx.so, and the test-only cross-check build
-cbgbench_amd/lib/libcbgx_xcheck.so (same sources + the first-generation VALU kernels, -DCBGX_XCHECK; include/cbgx_xcheck.h).
+cbgbench_amd/lib/libcbgx_xcheck.so (same sources + the first-generation VALU kernels of tests/xcheck/csrc/, -DCBGX_XCHECK;
+include/cbgx_xcheck.h).
 
 The library is a plain C-ABI shared object (include/cbgx.h); it links against the HIP runtime by
 SONAME (libamdhip64.so.7), which is the one PyTorch-ROCm has already loaded when the Python host
@@ -16,13 +17,13 @@ LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libcbgx.so")
 XCHECK_LIBPATH = os.path.join(LIBDIR, "libcbgx_xcheck.so")
 ARCH = "gfx950"
-# first-generation kernels: compiled into libcbgx_xcheck.so only
-XCHECK_ONLY = ("kernels_v1.hip", "train_bwd_v1.hip")
+# first-generation kernels: test-only sources (tests/xcheck/csrc/), compiled into libcbgx_xcheck.so only
+XCHECK_CSRC = os.path.join(HERE, "..", "tests", "xcheck", "csrc")
 
 
 def sources(xcheck=False):
     src = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    return src if xcheck else [p for p in src if os.path.basename(p) not in XCHECK_ONLY]
+    return src + sorted(glob.glob(os.path.join(XCHECK_CSRC, "*.hip"))) if xcheck else src
 
 
 def _headers():
@@ -58,7 +59,7 @@ def build_native(force=False, verbose=False, xcheck=False, ablate=False):
     objs = []
     # -munsafe-fp-atomics: fp32 atomicAdd of the backward kernels compiles to the hardware global_atomic_add_f32
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-             "-munsafe-fp-atomics"] + (["-DCBGX_XCHECK"] if xcheck else []) + (["-DCBGX_ABLATE"] if ablate else [])
+             "-munsafe-fp-atomics", "-I" + CSRC] + (["-DCBGX_XCHECK"] if xcheck else []) + (["-DCBGX_ABLATE"] if ablate else [])
     newest_header = max(os.path.getmtime(p) for p in _headers())
     jobs = []
     for src in sources(xcheck):

@@ -1,7 +1,7 @@
 // libcbgx -- stage dispatch and weight-packing copies.
 //
 // The product library (libcbgx.so) contains one implementation of every stage: the MFMA / register-resident kernels of
-// graph_mfma.hip, node_mfma.hip and edge_mfma.hip.  The first-generation VALU kernels (kernels_v1.hip, train_bwd_v1.hip)
+// graph_mfma.hip, node_mfma.hip and edge_mfma.hip.  The first-generation VALU kernels (tests/xcheck/csrc/: kernels_v1.hip, train_bwd_v1.hip)
 // are compiled only into the test-only library libcbgx_xcheck.so (-DCBGX_XCHECK), where cbgx_debug_set_edge_kernel(1)
 // (include/cbgx_xcheck.h) routes the same entry points through them as an independent on-device cross-check.
 #include <hip/hip_runtime.h>

@@ -19,10 +19,14 @@
 //   pass 1  fold T | S[a][m] = sum_e w[e][a] hid[e][m], d hid = w . Qt | Gt   64 + 64   C    LayerNorm affine gradients, the two
 //           (labeling: channel 32 u + 2 c + j -- 8-byte tile reads, float2 operand loads)    per-edge sums of LayerNorm's backward
 //   pass 2  d hid again (cheaper than 64 live registers of it) -> d pre, in place in the tile        64        C
-//   pass 3  d rbf = d pre . Wr^T -> d dist (accumulated per edge in a pad column of the tile)        128       E
+//   pass 3  d dist[e] = sum_m d pre[e][m] V[e][m], V = rbf'(d_e) . Wr[type_e]: the forward's split-f16 rbf product with
+//           rbf' = -(d - mu) rbf (round 6; was d rbf = d pre . Wr^T, 128 fp32 MFMAs + 16 weight loads per lane)   64 (f16)  E
 //   pass 4  every atomic of the path in one burst (labeling: channel 16 t + c, so a row's 16 lanes hit one 64-byte run):
-//           d PS[j_e] += d pre[e], d PD[i], type columns; d Wr[type] += rbf^T . d pre                 128       C
+//           d PS[j_e] += d pre[e], d PD[i], type columns; d Wr[type] += rbf^T . d pre            64 + 64 (4x4x1)   C
 //           -> LDS slab (type 3) / the workgroup's slab in memory, flushed one step late
+// What bounds it (round 6, profiles/abl_bwd_r06c.log, profiles/ubench_vmem_r06d.log): not the matrix pipe -- removing 192 of the 528
+// fp32 MFMAs per node changed nothing -- but the compute unit's fp32-atomic path: a 64-lane global_atomic_add_f32 costs 57 - 65 ns of it
+// whatever its shape (a dword store 5.5 ns), a node issues 136 of them, 64.5 nodes per CU = 0.53 ms of the 0.83 ms launch.
 // Per-edge scalars (edge length, neighbour index, d dist, the rbf centres) live in the four pad columns of the tile rows, the LayerNorm
 // affine in LDS.  8 waves per workgroup (2 per SIMD, 256 VGPRs), persistent, one workgroup per CU, XCD-aware node partition; LDS =
 // 8 x 16.9 KB tiles + 20 KB type-3 d Wr + 8 KB of small slabs = 160 KB.  Outputs, slab layout (train.h PB_*) and launch contract are
@@ -71,8 +75,15 @@ constexpr int BX_WAVES = CBGX_BX_WAVES;
                                  // (A/B, scripts/build_variant.py: 1 -> 851, 2 -> 829, 3 -> 845 us per 16.5 k-node launch)
 #endif
 constexpr int BX_DYN_ROUNDS = CBGX_BX_DYN_ROUNDS;
+#ifndef CBGX_BX_SWEEP
+#define CBGX_BX_SWEEP 0     // 1: passes 2 + 3 as one E-labeling sweep over v (pass 1 overwrites n with v, n re-read from the scratch slot:
+                            //    no second d hidden, but 48 KB more scratch traffic per node); 0: pass 2 in place in C labeling (d hidden
+                            //    evaluated again: 64 MFMAs, no memory traffic), pass 3 reads d pre.  Round 6, profiles/abl_bwd_r06c.log:
+                            //    the 192 fp32 MFMAs that variant 1 removes per node bought nothing (851 vs 855 us), its scratch traffic costs
+                            //    87 us -- this kernel is bound by its memory operations, not by the matrix pipe
+#endif
 #ifndef CBGX_BX_Y4X4
-#define CBGX_BX_Y4X4 0      // rbf columns g = 16..19 of d Wr on v_mfma_f32_4x4x1 (16 blocks of 4 x 4, 8 cycles) instead of a 16x16x4 tile
+#define CBGX_BX_Y4X4 1      // rbf columns g = 16..19 of d Wr on v_mfma_f32_4x4x1 (16 blocks of 4 x 4, 8 cycles) instead of a 16x16x4 tile
                             // of which 4 of 16 rows are used (32 cycles): see pass 4
 #endif
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
 #pragma unroll
                     for (int t = 0; t < 8; ++t) n[hf][t] = n[hf][t] * sc;
                 }
-                {       // parked: the key path for phase 2 (n and rstd), either path for its own passes 2 + 3 (n)
+                if (!(abl & 1024) && (CBGX_BX_SWEEP || ph == 0)) {       // parked: the key path for phase 2 (n and rstd) [sweep: either path, n]
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -608,16 +619,20 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     gsum[j] = xrow_sum(gs);
                     bsum[j] = xrow_sum(bs);
                 }
+#if CBGX_BX_SWEEP
                 // (every cell of the step was read into nv before the first is overwritten)
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         *reinterpret_cast<float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + ch) = make_float2(vv[0][hf][r], vv[1][hf][r]);
+#endif
                 // fold D: lane (c = head, q) reg r <-> channel 32 u + 2 (4 q + r) + j
                 float* fd = fold_dst + (size_t)c * H + 32 * u + 8 * q;
-                *reinterpret_cast<float4*>(fd) = make_float4(fold[0][0], fold[1][0], fold[0][1], fold[1][1]);
-                *reinterpret_cast<float4*>(fd + 4) = make_float4(fold[0][2], fold[1][2], fold[0][3], fold[1][3]);
+                if (!(abl & 4096) || fold[0][0] == 12345.f) {
+                    *reinterpret_cast<float4*>(fd) = make_float4(fold[0][0], fold[1][0], fold[0][1], fold[1][1]);
+                    *reinterpret_cast<float4*>(fd + 4) = make_float4(fold[0][2], fold[1][2], fold[0][3], fold[1][3]);
+                }
                 if (q == 0) {
                     atomicAdd(&L.lng[kv * H + ch], gsum[0]);
                     atomicAdd(&L.lng[kv * H + ch + 1], gsum[1]);
@@ -633,6 +648,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     s2[hf][r] = row16_sum(s2[hf][r]) * (1.f / H);
                 }
             BX_T(5);
+#if CBGX_BX_SWEEP
             wave_sync();
             // ---- passes 2 + 3, E labeling, one sweep (round 6).  Pass 1 left v = d hidden . gamma (ReLU-masked) in the tile in place of n.
             // The LayerNorm backward  d pre = rstd (v - s1 - n s2)  is elementwise, so it runs in the labeling the forward left n in: n
@@ -649,7 +665,50 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
             const float s1e[2] = {e1_to_e0(s1[0]), e1_to_e0(s1[1])}, s2e[2] = {e1_to_e0(s2[0]), e1_to_e0(s2[1])};
             float4 nq0[8];          // n of the first half: requested ahead of the rbf' product
 #pragma unroll
-            for (int t = 0; t < 8; ++t) nq0[t] = ld4(nk + t * 256);
+            for (int t = 0; t < 8; ++t) nq0[t] = (abl & 1024) ? make_float4(0.1f, 0.2f, 0.3f, 0.4f) : ld4(nk + t * 256);
+#else
+            float rs1[2][4];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rs1[hf][r] = __shfl(rstd[hf], 4 * q + r, 64);
+            // ---- pass 2 (C): d hidden again (cheaper than 64 live registers of it) -> d pre, in place in the tile.  All cells of a step
+            // are read before the first is written back (the compiler cannot tell the cells apart and would serialise read -> write) ----
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ch = 32 * u + 2 * c;
+                const float2 g2 = g2a[u], b2 = b2a[u];
+                const float2 (&qa)[4] = qaa[u];
+                float2 nn[2][4];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nn[hf][r] = *reinterpret_cast<const float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + ch);
+                float2 out[2][4];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    floatx4 de0 = {0.f, 0.f, 0.f, 0.f}, de1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) { de0 = MFMA(wT[hf][s], qa[s].x, de0); de1 = MFMA(wT[hf][s], qa[s].y, de1); }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dn0 = fmaf(nn[hf][r].x, g2.x, b2.x) > 0.f ? de0[r] * g2.x : 0.f;
+                        const float dn1 = fmaf(nn[hf][r].y, g2.y, b2.y) > 0.f ? de1[r] * g2.y : 0.f;
+                        // padded slots: d hidden = 0, n = 0, s1 = s2 = 0 -> exact zeros
+                        out[hf][r] = make_float2(rs1[hf][r] * (dn0 - s1[hf][r] - nn[hf][r].x * s2[hf][r]),
+                                                 rs1[hf][r] * (dn1 - s1[hf][r] - nn[hf][r].y * s2[hf][r]));
+                    }
+                }
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) *reinterpret_cast<float2*>(tw + (4 * q + r + 16 * hf) * BX_PITCH + ch) = out[hf][r];
+            }
+            wave_sync();
+            // ---- pass 3 (E):  d dist[e] = sum_m d pre[e][m] V[e][m],   V[e][m] = sum_g rbf'_g(d_e) Wr[type_e][g][m],   rbf' = -(d - mu) rbf
+            // -- V is the forward's rbf product with rbf' in place of rbf: the same split-f16 weight tuples, 64 f16 MFMAs (17 cycles)
+            // where  d rbf = d pre . Wr^T  took 128 fp32 ones (32 cycles) and sixteen 16-byte weight loads per lane
+#endif
             floatx4 V[2][8];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
@@ -688,6 +747,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 }
             }
             float ddE[2];
+#if CBGX_BX_SWEEP
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 float4 n4[8], v4[8];
@@ -696,7 +756,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                     for (int t = 0; t < 8; ++t) n4[t] = nq0[t];
                 } else {
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) n4[t] = ld4(nk + (8 + t) * 256);
+                    for (int t = 0; t < 8; ++t) n4[t] = (abl & 1024) ? make_float4(0.1f, 0.2f, 0.3f, 0.4f) : ld4(nk + (8 + t) * 256);
                 }
 #pragma unroll
                 for (int t = 0; t < 8; ++t) v4[t] = *reinterpret_cast<const float4*>(tw + (c + 16 * hf) * BX_PITCH + 16 * t + 4 * q);
@@ -712,6 +772,16 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 }
                 ddE[hf] = xrow_sum((acc[0] + acc[1]) + (acc[2] + acc[3])) * rsc.c2;      // V carries the forward's scale S; c2 = 1 / S
             }
+#else
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    acc += f4(*reinterpret_cast<const float4*>(tw + (c + 16 * hf) * BX_PITCH + 16 * t + 4 * q)) * V[hf][t];
+                ddE[hf] = xrow_sum((acc[0] + acc[1]) + (acc[2] + acc[3])) * rsc.c2;      // V carries the forward's scale S; c2 = 1 / S
+            }
+#endif
             if (q < 2) tw[(c + 16 * q) * BX_PITCH + BX_DDIST] += q ? ddE[1] : ddE[0];     // over the two paths, in the pad column
             wave_sync();
             BX_T(6);
@@ -747,6 +817,10 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
             }
             // D of the rbf-column products: lane (c = channel, q) reg r <-> g = 4 q + r (tile 0), 16 + r (tile 1, q == 0)
             auto flush_rbf_columns = [&](int tyc, int col, floatx4 a0, floatx4 a1) {
+                if (abl & 2048) {       // keep the products alive, skip the slab traffic
+                    if (a0[0] + a0[1] + a0[2] + a0[3] + a1[0] + a1[1] + a1[2] + a1[3] == 12345.f) L.dwr3[0][col] = 1.f;
+                    return;
+                }
                 const int slot = col >> 4;      // 16 locks, one per 16 columns: pad column BX_MU of rows 20..27 of tiles 0, 1
                 int* lk = reinterpret_cast<int*>(&L.tile[slot >> 3][(20 + (slot & 7)) * BX_PITCH + BX_MU]);
                 if (tyc == 3) {
@@ -818,7 +892,9 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 all = xrow_sum(all);
                 ligs = xrow_sum(ligs);
                 if (q == 0) {
-                    atomo(dPb, ioff + 64 * t, all);
+                    // the PD columns of a node's own row have one writer, this wave: a plain store (dP is zero-filled; the atomic path is
+                    // what bounds the kernel, see the header)
+                    *reinterpret_cast<__attribute__((address_space(1))) float*>(dPb + (ioff + 64 * t)) = all;
                     atomicAdd(&L.wt[ty_lig][kv * H + 16 * t + c], ligs);
                     atomicAdd(&L.wt[ty_prot][kv * H + 16 * t + c], all - ligs);
                 }

@@ -1,7 +1,7 @@
 // libcbgx -- node-level helpers of the denoiser's backward (training): the fold of the
 // output gradient through the second v Linear, column sums, two-level slab reductions into the reference's tensor layouts,
 // a small SGEMM, the gate MLP's backward, ShiftedSoftplus' backward.  The fused edge backward and the MFMA node kernels live
-// in train_bwd_mfma.hip; the first-generation VALU kernels (test-only cross-check) in train_bwd_v1.hip.
+// in train_bwd_mfma.hip; the first-generation VALU kernels (test-only cross-check) in tests/xcheck/csrc/train_bwd_v1.hip.
 // Math follows the reference modules (autograd of x2h_attention.py:43-97, h2x_attention.py:34-73,
 // common.py:151-171); oracle/training.py + torch.autograd is the checker (tests/test_gpu_training.py).
 #include <hip/hip_runtime.h>

@@ -1,7 +1,7 @@
 /* libcbgx_xcheck.so -- TEST-ONLY build of libcbgx (same sources compiled with -DCBGX_XCHECK).
  *
  * It exports everything include/cbgx.h declares plus the switch below, and additionally contains the first-generation
- * VALU kernels (cbgbench_amd/csrc/kernels_v1.hip, train_bwd_v1.hip).  Those implement the same stages as the MFMA
+ * VALU kernels (tests/xcheck/csrc/kernels_v1.hip, train_bwd_v1.hip).  Those implement the same stages as the MFMA
  * kernels of libcbgx.so with different code, which makes them an independent on-device cross-check at sizes the CPU
  * oracle cannot reach (tests/test_gpu_parity.py, tests/test_gpu_training.py).  The product library libcbgx.so contains
  * neither the switch nor those kernels. */

@@ -2,7 +2,7 @@
 // occupancy of the x2h backward (one 512-thread workgroup per CU).  Each wave issues REPS batches of 16 independent instructions of
 // one shape against an L2-resident buffer and reports cycles per instruction per CU (wall cycles of the workgroup / instructions of
 // ONE wave: with 8 waves sharing the addresser, that is 8 x the addresser cost per instruction).
-//   hipcc --offload-arch=gfx950 -O3 -o vmem vmem.hip && ./vmem
+//   hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -o vmem vmem.hip && ./vmem
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -11,7 +11,7 @@
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 constexpr int ROWF = 640;        // floats per row (the projection row of libcbgx)
-constexpr int NROWS = 4096;      // 10 MB: L2 / MALL resident
+constexpr int NROWS = 16384;     // 42 MB (the size of dP at 16.5 k nodes): L2 / MALL resident
 constexpr int REPS = 200;
 
 // shape 0: dwordx4, lane (c, q): row r_c, 16 bytes at 4q floats (+16 t): 16 rows x 64 B per instruction   (edge-major gather)
@@ -22,6 +22,10 @@ constexpr int REPS = 200;
 // shape 5: fp32 atomic add, 4 rows x 64 B per instruction (no return)
 // shape 6: fp32 atomic add, 16 rows x 16 B (stride-2 dwords as in a pair labeling): lane (c,q): row r_q, dword 2c
 // shape 7: dword store, 4 rows x 64 B
+// shape 8: fp32 atomic add, ONE row x 256 B per instruction (lane = dword of the row)
+// shape 9: fp32 atomic add, 2 rows x 128 B
+// shapes 10, 11: as 5 and 8 on rows PRIVATE to the workgroup (64 rows each, shared by its 8 waves): what the x2h backward's neighbour
+//            rows look like under the XCD-aware partition -- the rows of a graph are touched by one workgroup's neighbourhood only
 template <int SHAPE>
 __global__ __launch_bounds__(512) void vmem_kernel(float* buf, const int* rows, unsigned long long* out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
@@ -55,9 +59,21 @@ __global__ __launch_bounds__(512) void vmem_kernel(float* buf, const int* rows, 
             } else if (SHAPE == 6) {
                 const int r = rw[(4 * (k & 3) + q + base) & 63];
                 atomicAdd(buf + (size_t)r * ROWF + 32 * (k >> 2) + 2 * c, 1.0f);
-            } else {
+            } else if (SHAPE == 7) {
                 const int r = rw[(4 * (k & 3) + q + base) & 63];
                 buf[(size_t)r * ROWF + 256 + 16 * (k >> 2) + c] = (float)k;
+            } else if (SHAPE == 8) {
+                const int r = rw[(k + base) & 63];
+                atomicAdd(buf + (size_t)r * ROWF + 64 * (rep & 3) + lane, 1.0f);
+            } else if (SHAPE == 9) {
+                const int r = rw[(2 * k + (lane >> 5) + base) & 63];
+                atomicAdd(buf + (size_t)r * ROWF + 32 * (rep & 7) + (lane & 31), 1.0f);
+            } else if (SHAPE == 10) {
+                const int r = blockIdx.x * 64 + (rw[(4 * (k & 3) + q + base) & 63] & 63);
+                atomicAdd(buf + (size_t)r * ROWF + 16 * (k >> 2) + c, 1.0f);
+            } else {
+                const int r = blockIdx.x * 64 + (rw[(k + base) & 63] & 63);
+                atomicAdd(buf + (size_t)r * ROWF + 64 * (rep & 3) + lane, 1.0f);
             }
         }
     }
@@ -106,5 +122,9 @@ int main() {
     run<5>("5 atomic add f32, 4 rows x 64 B", buf, rows, out);
     run<6>("6 atomic add f32, 4 rows x 16 lanes stride 2 dwords", buf, rows, out);
     run<7>("7 dword store, 4 rows x 64 B", buf, rows, out);
+    run<8>("8 atomic add f32, 1 row x 256 B", buf, rows, out);
+    run<9>("9 atomic add f32, 2 rows x 128 B", buf, rows, out);
+    run<10>("10 atomic add f32, 4 rows x 64 B, workgroup-private rows", buf, rows, out);
+    run<11>("11 atomic add f32, 1 row x 256 B, workgroup-private rows", buf, rows, out);
     return 0;
 }
