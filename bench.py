@@ -65,6 +65,11 @@ FLOPS_PER_EDGE_LAYER, FLOPS_PER_NODE_LAYER = 122880, 8 * 32768 + 131072
 # value's second Linear applied after aggregation (2*128*128, packed fp32 VALU).  Both second Linears have left the edge.
 X2H_FP32_MFMA_FLOPS_PER_EDGE = 2 * 128 * 16 + 2 * 16 * 128
 X2H_F16_MFMA_FLOPS_PER_NODE = 128 * 2 * 16 * 16 * 16
+X2H_MFMA_ISSUE_CYCLES_PER_NODE = 128 * 17 + 128 * 32     # issue cycles of a node's MFMAs on its SIMD (roofline.issue_frac)
+N_SIMDS, SIMD_CLOCK_HZ = 256 * 4, 2.4e9
+N_CUS = 256
+X2H_BWD_ATOMICS_PER_NODE = 136      # 64-lane atomic instructions of the x2h edge backward per node (train_bwd_x2h.hip, pass 4 + coordinates)
+ATOMIC_INSTR_S = 60e-9              # one of them on a CU's atomic path (scripts/ubench/vmem.hip shapes 5, 8 - 11: 56 - 66 ns)
 X2H_EXEC_FLOPS_PER_EDGE, X2H_EXEC_FLOPS_PER_NODE = 2 * 20 * 256 + 2 * 128 * 16 + 2 * 16 * 128, 2 * 128 * 128
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 matrix peak
 
@@ -320,6 +325,10 @@ def bench_train(args, rank, world, dev):
             "bound": "hbm", "kernel": "cbgx::edge_backward_x2h_kernel (backward of the x2h block)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": None, "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_us": round(1e6 * bwd_s, 3),
+            # what bounds this kernel (round 6, profiles/abl_bwd_r06c.log + profiles/ubench_vmem_r06d.log): the compute unit's fp32
+            # atomic path -- a 64-lane global_atomic_add_f32 occupies it for ~60 ns whatever its shape (a dword store 5.5 ns), a node issues
+            # 136 of them (neighbour rows of d P: 32 edges x 256 columns) -- its busy time per launch / the launch time
+            "atomic_path_frac": round(N * X2H_BWD_ATOMICS_PER_NODE * ATOMIC_INSTR_S / N_CUS / bwd_s, 4) if bwd_s > 0 else None,
             "per_kernel_us_avg_and_launches": per,
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "targetdiff":
@@ -639,6 +648,11 @@ def bench_sampling(args, rank, world, dev):
                 # fused -- per-edge k / v never exist in memory -- so this is far below `frac` by design)
                 "hbm_real": (round(measured_traffic(Nb) / x2h_s / 1e9 / HBM_PEAK_GBS, 4)
                              if (measured_traffic(Nb) and x2h_s > 0) else None),
+                # the kernel's own bound: the matrix-pipe issue floor of a launch -- per node 128 f16 MFMAs (17
+                # cycles measured, scripts/ubench/pipes.hip) + 128 fp32 16x16x4 MFMAs (32 cycles) = 6 272 SIMD cycles, on 1024 SIMDs at
+                # 2.4 GHz -- divided by the measured launch time.  (fp32 MFMAs and VALU share a SIMD's issue port: ~1 400 VALU per node
+                # on top)
+                "issue_frac": round(Nb * X2H_MFMA_ISSUE_CYCLES_PER_NODE / (N_SIMDS * SIMD_CLOCK_HZ) / x2h_s, 4) if x2h_s > 0 else None,
                 "nodes_per_launch": Nb, "algorithmic_bytes_per_launch": x2h_bytes, "avg_launch_us": round(1e6 * x2h_s, 3),
                 "mfma_view": {"fp32_mfma_tflops": tf(X2H_FP32_MFMA_FLOPS_PER_EDGE * deg_edges), "fp32_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
                               "f16_mfma_tflops_issued": tf(X2H_F16_MFMA_FLOPS_PER_NODE * Nb), "f16_peak_tflops": F16_MFMA_PEAK_TFLOPS,

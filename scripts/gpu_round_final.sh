@@ -1,15 +1,15 @@
 #!/bin/bash
-# Evidence call of round 5 (one gpurun): all GPU tests, smoke, the driver's default bench command (headline + secondary block + both
-# CPU legs), rocprofv3 kernel stats of the sampling and the training command, PMC passes of the dominant forward kernel
-# (instruction mix / waits, HBM traffic in separate FETCH_SIZE / WRITE_SIZE passes).
-# Usage (repo root on the GPU box): bash scripts/gpu_round4_final.sh [tag]
-TAG=${1:-r05z}
+# Evidence call of a round (one gpurun): all GPU tests (the driver's command with -x), smoke, the driver's default bench command
+# (headline + secondary block + the CPU legs), rocprofv3 kernel stats of the sampling and the training command, PMC passes of the dominant
+# forward kernel (instruction mix / waits, HBM traffic in separate FETCH_SIZE / WRITE_SIZE passes) and of the x2h edge backward.
+# Usage (repo root on the GPU box): bash scripts/gpu_round_final.sh [tag]
+TAG=${1:-r06z}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT; cd $ROOT; export TMPDIR=/tmp
 echo "== host =="; rocminfo | grep -m2 -E "gfx|Compute Unit"; nproc; free -g | sed -n 2p
 echo "== pytest -m gpu =="
-timeout 1800 python -m pytest tests -q -m gpu --durations=6 -s -p no:faulthandler 2>&1 | grep -v "^$" | grep -E "passed|failed|Error|error|FAILED|roll-out|ReLU flip|worst relative|pocket frame|linker-256|^\| |^[0-9.]+s " | tail -60 | cut -c1-300 | tee $OUT/pytest_gpu_$TAG.log
+timeout 1800 python -m pytest tests/ -x -q -m gpu --durations=6 -s -p no:faulthandler 2>&1 | grep -v "^$" | grep -E "passed|failed|Error|error|FAILED|roll-out|ReLU flip|worst relative|pocket frame|linker-256|^\| |^[0-9.]+s " | tail -60 | cut -c1-300 | tee $OUT/pytest_gpu_$TAG.log
 echo "== smoke =="
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke_$TAG.log
 echo "== bench: the driver's command =="
@@ -26,6 +26,8 @@ find $OUT/prof_$TAG $OUT/prof_train_$TAG -name "*kernel_trace.csv" -delete; find
 echo "== PMC: forward x2h (instruction mix, traffic) =="
 bash scripts/gpu_pmc_x2h.sh $TAG 2>&1 | tail -30
 bash scripts/gpu_pmc_traffic.sh $TAG 2>&1 | tail -12
+echo "== PMC: x2h edge backward (training bench) =="
+bash scripts/gpu_pmc_bwd.sh $TAG 2>&1 | tail -30
 du -sh $OUT | tail -1
 echo "== step timelines of the small inputs (kernel trace of one denoising step) =="
 for cfg in "1 1" "1 10"; do set -- $cfg
