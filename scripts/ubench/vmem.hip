@@ -24,6 +24,7 @@ constexpr int REPS = 200;
 // shape 7: dword store, 4 rows x 64 B
 // shape 8: fp32 atomic add, ONE row x 256 B per instruction (lane = dword of the row)
 // shape 9: fp32 atomic add, 2 rows x 128 B
+// shapes 12 - 15: integer / 64-bit atomics (is the atomic path priced per lane-operation or per byte?)
 // shapes 10, 11: as 5 and 8 on rows PRIVATE to the workgroup (64 rows each, shared by its 8 waves): what the x2h backward's neighbour
 //            rows look like under the XCD-aware partition -- the rows of a graph are touched by one workgroup's neighbourhood only
 template <int SHAPE>
@@ -71,9 +72,21 @@ __global__ __launch_bounds__(512) void vmem_kernel(float* buf, const int* rows, 
             } else if (SHAPE == 10) {
                 const int r = blockIdx.x * 64 + (rw[(4 * (k & 3) + q + base) & 63] & 63);
                 atomicAdd(buf + (size_t)r * ROWF + 16 * (k >> 2) + c, 1.0f);
-            } else {
+            } else if (SHAPE == 11) {
                 const int r = blockIdx.x * 64 + (rw[(k + base) & 63] & 63);
                 atomicAdd(buf + (size_t)r * ROWF + 64 * (rep & 3) + lane, 1.0f);
+            } else if (SHAPE == 12) {       // u64 integer add, 4 rows x 128 B (16 lanes x 8 B): two 32-bit fixed-point columns per lane-operation
+                const int r = rw[(4 * (k & 3) + q + base) & 63];
+                atomicAdd(reinterpret_cast<unsigned long long*>(buf + (size_t)r * ROWF + 32 * (k >> 2) + 2 * c), 0x0000000100000001ull);
+            } else if (SHAPE == 13) {       // f64 add, same addresses
+                const int r = rw[(4 * (k & 3) + q + base) & 63];
+                atomicAdd(reinterpret_cast<double*>(buf + (size_t)r * ROWF + 32 * (k >> 2) + 2 * c), 1.0);
+            } else if (SHAPE == 14) {       // u32 integer add, 4 rows x 64 B
+                const int r = rw[(4 * (k & 3) + q + base) & 63];
+                atomicAdd(reinterpret_cast<unsigned*>(buf + (size_t)r * ROWF + 16 * (k >> 2) + c), 1u);
+            } else {                        // u64 integer add, 2 rows x 256 B (32 lanes x 8 B)
+                const int r = rw[(2 * k + (lane >> 5) + base) & 63];
+                atomicAdd(reinterpret_cast<unsigned long long*>(buf + (size_t)r * ROWF + 64 * (rep & 3) + 2 * (lane & 31)), 0x0000000100000001ull);
             }
         }
     }
@@ -126,5 +139,9 @@ int main() {
     run<9>("9 atomic add f32, 2 rows x 128 B", buf, rows, out);
     run<10>("10 atomic add f32, 4 rows x 64 B, workgroup-private rows", buf, rows, out);
     run<11>("11 atomic add f32, 1 row x 256 B, workgroup-private rows", buf, rows, out);
+    run<12>("12 atomic add u64, 4 rows x 128 B", buf, rows, out);
+    run<13>("13 atomic add f64, 4 rows x 128 B", buf, rows, out);
+    run<14>("14 atomic add u32, 4 rows x 64 B", buf, rows, out);
+    run<15>("15 atomic add u64, 2 rows x 256 B", buf, rows, out);
     return 0;
 }
