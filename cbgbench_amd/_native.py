@@ -67,7 +67,7 @@ EXPORTS = {
 }
 
 PROFILE_CLASSES = ("knn", "gate", "node_gemm", "node_query", "edge_x2h", "edge_h2x", "edge_x2h_listed",
-                   "edge_x2h_bwd", "edge_h2x_bwd", "train_gemm", "edge_x2h_bwd_listed")
+                   "edge_x2h_bwd", "edge_h2x_bwd", "train_gemm", "edge_x2h_bwd_listed", "edge_rows_reduce")
 
 
 class NativeError(RuntimeError):

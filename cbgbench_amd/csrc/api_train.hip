@@ -30,6 +30,20 @@ namespace cbgx { int set_error(int code, const char* fmt, ...); }
 
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// Neighbour-row gradients of the x2h edge backward: 0 = fp32 atomics on dP (default: the faster training step), 1 = edge rows + a gather
+// in a fixed order (train_scatter.hip): the kernel is 10 % faster (750 vs 832 us per 16.5 k-node launch) and dL/dh becomes reproducible
+// bit for bit, but the gather reads N x 32 KB (105 us, HBM-bound) and the step is 2 - 3 % slower (profiles/ab_train_r06[jkmn].log).
+// Same mathematics, different summation order; chosen per call by the environment (CBGX_BX_EDGE_ROWS=1), this macro is the default.
+#ifndef CBGX_BX_EDGE_ROWS
+#define CBGX_BX_EDGE_ROWS 0
+#endif
+static inline bool edge_rows_mode() {
+    const char* e = getenv("CBGX_BX_EDGE_ROWS");
+    return e ? atoi(e) != 0 : CBGX_BX_EDGE_ROWS != 0;
+}
+// schedule-only knobs of the training path, read at every call (a getenv next to a 15 ms step) so that one process can compare them
+// (tests/test_gpu_training.py, scripts/ab_train_base.sh)
+static inline bool env_on(const char* name) { const char* e = getenv(name); return !e || atoi(e) != 0; }
 constexpr int EDGE_GRID = 256;    // persistent workgroups of the edge backward (one per CU: ~97 KB LDS each)
 #ifndef CBGX_NODE_GRID
 #define CBGX_NODE_GRID 256        // A/B knob (scripts/build_variant.py)
@@ -81,6 +95,10 @@ struct TrainWs {
     int *act, *act_count;
     uint8_t* mask;        // receptive field of the loss, walked backwards (see cbgx_unitransformer_backward)
     int *rf_list[2], *rf_count;
+    // round 6, x2h edge backward without neighbour-row atomics (train_scatter.hip, CBGX_BX_EDGE_ROWS=1): one row per edge, and the
+    // incoming-edge lists of every source node (built once per backward call)
+    float* dE;            // [N][32][256]
+    int *rin_cnt, *rin_ptr, *rin_tmp, *rin_edge;
     int* lig_list;        // rows with lig_flag (count: rf_count + 32): the classifier head's backward walks it when the loss reads ligand rows only
     // second set of the per-block buffers (round 5): the weight-gradient reductions of a block run on an auxiliary stream while the
     // caller's stream is already in the next block, so consecutive blocks alternate between two sets (attention_block_backward)
@@ -137,6 +155,11 @@ static TrainWs carve_train(void* base, int n) {
     w.folded_node = (float*)take((size_t)FOLD * NS_SIZE * 4);
     w.folded_wgrad = (float*)take((size_t)FOLD * H * PROW * 4);
     w.nk = (float*)take(BX_NK_FLOATS * 4);     // x2h edge backward: the key path of every wave in flight, parked between two phases
+    w.dE = (float*)take(N * KNN * 2 * H * 4);
+    w.rin_cnt = (int*)take(N * 4);
+    w.rin_ptr = (int*)take((N + 1) * 4);
+    w.rin_tmp = (int*)take(N * KNN * 4);
+    w.rin_edge = (int*)take(N * KNN * 4);
     w.T2 = (float*)take(N * HEADS * H * 4);
     w.S2 = (float*)take(N * HEADS * H * 4);
     w.sw2 = (float*)take(N * HEADS * 4);
@@ -216,7 +239,8 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
                                     const int* rows, const int* n_rows, int n, TrainWs& w_all, float* gh, float* dx,
                                     float* de_w, float* const* grads, hipStream_t s, const float* P_saved = nullptr,
                                     const float* Qt_saved = nullptr, float* qln = nullptr, const float* gh_src = nullptr,
-                                    const int* dp_rows = nullptr, const int* dp_n_rows = nullptr, BlockOverlap* ov = nullptr) {
+                                    const int* dp_rows = nullptr, const int* dp_n_rows = nullptr, BlockOverlap* ov = nullptr,
+                                    bool rin_ready = false) {
     TrainWs w = w_all;      // this block's view of the workspace: the per-block buffers of its set
     const int set = (ov && ov->aux) ? ov->next_set : 0;
     if (set) {
@@ -260,7 +284,17 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
             HIP_TRY(launch_node_mfma(att, h_in, lig, n, w.P, w.qs, w.Qt, rows, n_rows, nullptr, nullptr, s, x2h));
     }
     if (x2h) HIP_TRY(launch_fold_grad(att, g_out, n, w.Gt, w.gb, s));
-    HIP_TRY(hipMemsetAsync(w.dP, 0, (size_t)n * PROW * sizeof(float) + 256, s));     // (and the work counters behind it)
+    // Edge rows (CBGX_BX_EDGE_ROWS=1, round 6): a full launch of the one-wave-per-node kernel writes d pre of every edge to the edge's own
+    // row of w.dE and launch_edge_rows_reduce gathers the rows of every source node in a fixed order -- no atomics on dP.  Every column
+    // of dP then has exactly one writer (PD: the edge kernel's plain stores, PS: the gather, q hidden: the query backward), so only the
+    // work counters behind it are zeroed.  `rin_ready`: the caller has built the incoming-edge lists (w_all.rin_ptr / rin_edge).
+    const bool er = gen3 && !rows && rin_ready;
+    if (er) HIP_TRY(hipMemsetAsync(w.dP + (size_t)n * PROW, 0, 256, s));
+    else if (!x2h && dp_rows && mfma && ov && ov->aux && env_on("CBGX_TRAIN_ZERO_ROWS"))
+        // h2x block in the layer loop: every reader of dP walks `dp_rows`, so only those rows are zeroed (a fill of all N rows was 42 MB
+        // per block; +0.4 % on the training line, profiles/ab_train_r06r.log)
+        HIP_TRY(launch_zero_rows(w.dP, PROW, dp_rows, dp_n_rows, n, s));
+    else HIP_TRY(hipMemsetAsync(w.dP, 0, (size_t)n * PROW * sizeof(float) + 256, s));     // (and the work counters behind it)
     if (!qln) {
         qln = w.qln;
         HIP_TRY(hipMemsetAsync(qln, 0, 2 * H * sizeof(float), s));
@@ -273,10 +307,12 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
                                      w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s));
     else
 #endif
-    if (gen3)
+    if (gen3) {
         HIP_TRY(launch_edge_backward_x2h(att, x, Pn, Qn, w.Gt, w.gb, nbr, deg, lig, e_w, rows, n_rows, n, w.T, w.S, w.sw,
-                                         w.dP, dx, de_w, w.partial, w.nk, reinterpret_cast<int*>(w.dP + (size_t)n * PROW), eg, s));
-    else
+                                         w.dP, dx, de_w, w.partial, w.nk, reinterpret_cast<int*>(w.dP + (size_t)n * PROW), eg, s,
+                                         er ? w.dE : nullptr));
+        if (er) HIP_TRY(launch_edge_rows_reduce(w.dE, w.rin_ptr, w.rin_edge, n, w.dP, s));
+    } else
         HIP_TRY(launch_edge_backward_mfma(x2h, att, x, Pn, Qn, w.Gt, w.gb, g_out, nbr, deg, lig, e_w, rows, n_rows, n,
                                           w.T, w.S, w.sw, w.dP, dx, de_w, w.partial, eg, s, 1));
     float *k0w = grads[0], *k0b = grads[1], *kg = grads[2], *kb = grads[3], *k1w = grads[4], *k1b = grads[5];
@@ -448,6 +484,17 @@ int cbgx_unitransformer_forward_train(const float* packed, int num_layers, int n
     HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, tp.nbr, tp.deg, s));
     HIP_TRY(launch_gate(packed, x, tp.nbr, tp.deg, n_nodes, tp.e_w, s));
     HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, s));
+    // Round 6: the node stage of the x2h block of layer l + 1 (projection, query MLP, fold: ~57 us at 16.5 k nodes) reads h_{l+1} only,
+    // like the h2x block of layer l (~60 us) -- it runs on the caller's auxiliary stream next to that block (what the sampling forward
+    // has done since round 3); every block owns its P / Qt on the tape, the two node stages use different query scratch rows.
+    // +0.7 % on the training line (profiles/ab_train_r06r.log).  CBGX_TRAIN_OVERLAP=0 / CBGX_TRAIN_FWD_OVERLAP=0, the per-kernel
+    // profile and the VALU cross-check kernels keep one stream.
+    AuxLane* aux = (env_on("CBGX_TRAIN_OVERLAP") && env_on("CBGX_TRAIN_FWD_OVERLAP") && g_edge_impl == 0 && !profile_is_on() &&
+                    num_layers > 1) ? aux_for(s) : nullptr;
+    struct Joiner {     // a failure between fork and join must not leave the auxiliary stream writing the tape
+        AuxLane* a; bool out = false;
+        ~Joiner() { if (a && out) (void)hipStreamSynchronize(a->s); }
+    } jn{aux};
     for (int l = 0; l < num_layers; ++l) {
         const float* xc = tp.xs + (size_t)l * nx;
         const float* hc = tp.hs + (size_t)l * nh;
@@ -455,8 +502,25 @@ int cbgx_unitransformer_forward_train(const float* packed, int num_layers, int n
         float* hn = tp.hs + (size_t)(l + 1) * nh;
         float* Px = tp.P + (size_t)(2 * l) * n_nodes * PROW;
         float* Qx = tp.Qt + (size_t)(2 * l) * n_nodes * HEADS * H;
-        HIP_TRY(launch_attention(true, packed + x2h_off(l), xc, hc, tp.nbr, tp.deg, lig_flag, gen_flag, tp.e_w, n_nodes,
-                                 Px, Qx, w.qs, hn, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+        if (!aux) {
+            HIP_TRY(launch_attention(true, packed + x2h_off(l), xc, hc, tp.nbr, tp.deg, lig_flag, gen_flag, tp.e_w, n_nodes,
+                                     Px, Qx, w.qs, hn, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+        } else {
+            if (l == 0) HIP_TRY(launch_node_mfma(packed + x2h_off(0), hc, lig_flag, n_nodes, Px, w.qs2, Qx, nullptr, nullptr,
+                                                 nullptr, nullptr, s, true));
+            else { HIP_TRY(hipStreamWaitEvent(s, aux->join, 0)); jn.out = false; }      // this layer's node stage (auxiliary stream)
+            HIP_TRY(launch_edge_mfma(true, packed + x2h_off(l), xc, hc, Px, Qx, tp.nbr, tp.deg, lig_flag, gen_flag, tp.e_w, n_nodes,
+                                     hn, nullptr, nullptr, nullptr, s));
+            if (l + 1 < num_layers) {
+                HIP_TRY(hipEventRecord(aux->fork, s));
+                HIP_TRY(hipStreamWaitEvent(aux->s, aux->fork, 0));
+                jn.out = true;
+                HIP_TRY(launch_node_mfma(packed + x2h_off(l + 1), hn, lig_flag, n_nodes, tp.P + (size_t)(2 * l + 2) * n_nodes * PROW,
+                                         w.qs2, tp.Qt + (size_t)(2 * l + 2) * n_nodes * HEADS * H, nullptr, nullptr, nullptr,
+                                         nullptr, aux->s, true));
+                HIP_TRY(hipEventRecord(aux->join, aux->s));
+            }
+        }
         HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, tp.nbr, tp.deg, lig_flag, gen_flag, tp.e_w, n_nodes,
                                  Px + (size_t)n_nodes * PROW, Qx + (size_t)n_nodes * HEADS * H, w.qs, xn, nullptr, w.act,
                                  w.act_count, nullptr, nullptr, s));
@@ -490,8 +554,11 @@ int cbgx_x2h_attention_backward(const float* packed, int layer, const float* x, 
     HIP_TRY(hipMemcpyAsync(grad_h, grad_h_out, (size_t)n_nodes * H * 4, hipMemcpyDeviceToDevice, s));   // residual
     HIP_TRY(hipMemsetAsync(grad_x, 0, (size_t)n_nodes * 3 * 4, s));
     HIP_TRY(hipMemsetAsync(grad_e_w, 0, (size_t)n_nodes * KNN * 4, s));
+    const bool rin = edge_rows_mode() && g_edge_impl == 0;
+    if (rin) HIP_TRY(launch_rin_build(nbr, deg, n_nodes, w.rin_cnt, w.rin_ptr, w.rin_tmp, w.rin_edge, s));
     return attention_block_backward(true, packed + x2h_off(layer), x, h, grad_h_out, nbr, deg, lig_flag, e_w, nullptr,
-                                    nullptr, n_nodes, w, grad_h, grad_x, grad_e_w, grads, s);
+                                    nullptr, n_nodes, w, grad_h, grad_x, grad_e_w, grads, s, nullptr, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, rin);
 }
 
 int cbgx_h2x_attention_backward(const float* packed, int layer, const float* x, const float* h, const int32_t* nbr,
@@ -630,10 +697,13 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
     float* gh_oth = w.tmp;
     // weight-gradient work of every block on the caller's auxiliary stream (attention_block_backward, BlockOverlap): off while the
     // per-kernel profile runs (its sections are timed on one stream), with the VALU cross-check kernels, or by CBGX_TRAIN_OVERLAP=0
-    static const bool overlap_env = [] { const char* e = getenv("CBGX_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();
+    const bool overlap_env = env_on("CBGX_TRAIN_OVERLAP");
     // (and only with one query-LayerNorm accumulator slot per block: the shared fallback slot would be refilled by the next block
     // while the auxiliary stream still reads it)
     BlockOverlap ov{(overlap_env && g_edge_impl != 1 && !profile_is_on() && qln_slots) ? aux_for(s) : nullptr, 0, {false, false}};
+    // edge-row mode: incoming-edge lists of every source node, once for all layers
+    const bool rin = edge_rows_mode() && g_edge_impl == 0 && (!prune || L > 2);
+    if (rin) HIP_TRY(launch_rin_build(tp.nbr, tp.deg, n, w.rin_cnt, w.rin_ptr, w.rin_tmp, w.rin_edge, s));
     for (int l = L - 1; l >= 0; --l) {
         const float* xl = tp.xs + (size_t)l * nx;
         const float* h_in = tp.hs + (size_t)l * nh;
@@ -657,7 +727,7 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         const int* n_rows = (prune && k < 2) ? w.rf_count + 16 * k : nullptr;
         RC_TRY(attention_block_backward(true, packed + x2h_off(l), xl, h_in, gh_cur, tp.nbr, tp.deg, lig_flag, tp.e_w,
                                         rows, n_rows, n, w, gh_oth, w.gx[nxt], w.de_w, g, s, Px, Qx,
-                                        qln_slots ? w.qln + (size_t)(2 * l) * 2 * H : nullptr, gh_cur, nullptr, nullptr, &ov));
+                                        qln_slots ? w.qln + (size_t)(2 * l) * 2 * H : nullptr, gh_cur, nullptr, nullptr, &ov, rin));
         { float* t = gh_cur; gh_cur = gh_oth; gh_oth = t; }
         cur = nxt;
     }

@@ -18,7 +18,7 @@ typedef AuxStream AuxLane;
 
 // ---- optional per-kernel timing (cbgx_profile_begin / cbgx_profile_end) ----
 enum KernelClass { K_KNN = 0, K_GATE, K_NODE_GEMM, K_NODE_QUERY, K_EDGE_X2H, K_EDGE_H2X, K_EDGE_X2H_LISTED, K_EDGE_X2H_BWD, K_EDGE_H2X_BWD,
-                   K_TRAIN_GEMM, K_EDGE_X2H_BWD_LISTED, K_NUM_CLASSES };
+                   K_TRAIN_GEMM, K_EDGE_X2H_BWD_LISTED, K_EDGE_ROWS_REDUCE, K_NUM_CLASSES };
 void profile_mark_begin(int cls, hipStream_t s);
 void profile_mark_end(hipStream_t s);
 bool profile_is_on();

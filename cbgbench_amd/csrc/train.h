@@ -53,7 +53,16 @@ hipError_t launch_edge_backward_x2h(const float* att, const float* x, const floa
                                     const float* gb, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                                     const float* e_w, const int* rows, const int* n_rows, int n_nodes, float* T, float* S,
                                     float* sw, float* dP, float* dx, float* de_w, float* partial, float* nk_scratch,
-                                    int* work_ctr, int grid, hipStream_t s);
+                                    int* work_ctr, int grid, hipStream_t s, float* dE = nullptr);
+// Round 6, the neighbour-row gradients without atomics (train_scatter.hip).  `dE` [N][32][256]: the edge backward (full launches)
+// stores d pre of every edge (k | v) in the edge's own row; the incoming-edge lists of every SOURCE node -- `rin_ptr` [N + 1] offsets,
+// `rin_edge` edge ids 32 i + slot in ascending order -- are built once per backward call (the graph is the same for all layers), and
+// launch_edge_rows_reduce writes dP[j][256:512] = sum over the incoming edges of j, in list order (bit-reproducible).
+// launch_rin_build: `cnt` [N] and `tmp` [32 N] are scratch; `ptr` [N + 1], `edges` [32 N] the result.
+hipError_t launch_rin_build(const int32_t* nbr, const int32_t* deg, int n_nodes, int* cnt, int* ptr, int* tmp, int* edges,
+                            hipStream_t s);
+hipError_t launch_zero_rows(float* A, int ld, const int* rows, const int* n_rows_ptr, int max_rows, hipStream_t s);
+hipError_t launch_edge_rows_reduce(const float* dE, const int* rin_ptr, const int* rin_edge, int n_nodes, float* dP, hipStream_t s);
 // floats of nk_scratch: two slots (key | value path) per wave of the largest grid: the normalised pre-activation of a path, parked by its
 // forward part and read back by the backward sweep in the same labeling (the key path also across two phases of a node)
 constexpr size_t BX_NK_FLOATS = (size_t)256 * 8 * 2 * (KNN * H + 128);

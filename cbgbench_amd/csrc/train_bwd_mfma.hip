@@ -642,7 +642,12 @@ __global__ __launch_bounds__(BWD_THREADS) void edge_backward_mfma_kernel(
 // ------------------------------------------------------------------------------------------------
 constexpr int QB_LD = H + 4;   // row stride of the LDS tiles (16-byte aligned rows, conflict-light b128 reads)
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void q_backward_mfma_kernel(const float* __restrict__ att, const float* __restrict__ P,
+#ifndef CBGX_QB_WAVES
+#define CBGX_QB_WAVES 4     // waves per SIMD = workgroups per CU.  A tile's dependent chain is ~45 us whatever runs beside it, so the launch
+                            // time is rounds x 45: a training batch of 16 506 nodes is 1 032 tiles on 4 x 256 = 1 024 slots -- eight
+                            // workgroups run a second tile and the launch takes two rounds (88 us); 5 fits them in one (96 registers)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CBGX_QB_WAVES, CBGX_QB_WAVES))) void q_backward_mfma_kernel(const float* __restrict__ att, const float* __restrict__ P,
                                                               const float* __restrict__ T, const int* __restrict__ rows,
                                                               const int* __restrict__ n_rows_ptr, int n_nodes,
                                                               float* __restrict__ qs, float* __restrict__ dqb,

@@ -82,6 +82,10 @@ constexpr int BX_DYN_ROUNDS = CBGX_BX_DYN_ROUNDS;
                             //    the 192 fp32 MFMAs that variant 1 removes per node bought nothing (851 vs 855 us), its scratch traffic costs
                             //    87 us -- this kernel is bound by its memory operations, not by the matrix pipe
 #endif
+#ifndef CBGX_BX_PARK
+#define CBGX_BX_PARK 1      // 1: the key path's normalised pre-activation is parked in the wave's scratch slot in phase 0 and read back in phase 2;
+                            // 0: phase 2 gathers, multiplies and normalises it again (A/B knob, scripts/build_variant.py)
+#endif
 #ifndef CBGX_BX_Y4X4
 #define CBGX_BX_Y4X4 1      // rbf columns g = 16..19 of d Wr on v_mfma_f32_4x4x1 (16 blocks of 4 x 4, 8 cycles) instead of a 16x16x4 tile
                             // of which 4 of 16 rows are used (32 cycles): see pass 4
@@ -129,13 +133,19 @@ __device__ __forceinline__ void lds_unlock_w(int* lk, int lane) {
 }
 __device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
 
+// ER (round 6): the neighbour-row gradient of every edge goes to its own row of `dE` [N][32][256] by plain stores (a 64-lane dword
+// store costs the CU 5.5 ns, the atomic it replaces 57 - 65) and edge_rows_reduce_kernel (train_scatter.hip) sums the rows of every
+// SOURCE node over its incoming edges in a fixed order: no atomics on dP at all, PS columns reproducible bit for bit.  Full launches
+// only; a listed launch (pruned last layers) keeps the atomics (ER = false).
+template <bool ER>
 __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
     const float* __restrict__ att, const float* __restrict__ x, const float* __restrict__ P,
     const float* __restrict__ Qt, const float* __restrict__ Gt, const float* __restrict__ gb,
     const int32_t* __restrict__ nbr, const int32_t* __restrict__ deg, const uint8_t* __restrict__ lig,
     const float* __restrict__ e_w, const int* __restrict__ rows, const int* __restrict__ n_rows_ptr, int n_nodes,
     float* __restrict__ T, float* __restrict__ S, float* __restrict__ sw, float* __restrict__ dP, float* __restrict__ dx,
-    float* __restrict__ de_w, float* __restrict__ partial, float* __restrict__ nk_scratch, int* __restrict__ work_ctr
+    float* __restrict__ de_w, float* __restrict__ partial, float* __restrict__ nk_scratch, int* __restrict__ work_ctr,
+    float* __restrict__ dE
 #ifdef CBGX_ABLATE
     , int abl
 #endif
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
             // phase 2 (16 coalesced KB each way) instead of being gathered, multiplied and normalised a second time
             // (two slots per wave, key | value: passes 2 + 3 below read the path's n back in the labeling the forward left it in)
             float* nk = nk_scratch + (((size_t)blockIdx.x * BX_WAVES + wave) * 2 + kv) * BX_NK_SLOT + 4 * lane;
-            if (ph == 2) {
+            if (CBGX_BX_PARK && ph == 2) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
 #pragma unroll
                     for (int t = 0; t < 8; ++t) n[hf][t] = n[hf][t] * sc;
                 }
-                if (!(abl & 1024) && (CBGX_BX_SWEEP || ph == 0)) {       // parked: the key path for phase 2 (n and rstd) [sweep: either path, n]
+                if (!(abl & 1024) && (CBGX_BX_SWEEP || (CBGX_BX_PARK && ph == 0))) {       // parked: the key path for phase 2 (n and rstd) [sweep: either path, n]
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -795,12 +805,15 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                 rbf_e1(vsh, rT0, rT1, u0, u1);
             }
             gwptr dPb = sbase_w(dP);
-            unsigned joff[2][4];    // byte offset of the neighbour's PS columns of this path
+            unsigned joff[2][4];    // byte offset of the neighbour's PS columns of this path (ER: of the edge's own row of dE)
+            // ER: the node's 32 edge rows [32][k 128 | v 128] are one contiguous 32 KB block behind a wave-uniform base
+            gwptr dEb = sbase_w(ER ? dE + (size_t)i * (KNN * 2 * H) : dP);
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    joff[hf][r] = ((unsigned)reinterpret_cast<const int*>(tw)[(4 * q + r + 16 * hf) * BX_PITCH + BX_NBR] * (unsigned)PROW + (unsigned)((2 + kv) * H + c)) * 4u;
+                    joff[hf][r] = ER ? ((unsigned)(4 * q + r + 16 * hf) * (unsigned)(2 * H) + (unsigned)(kv * H + c)) * 4u
+                                     : ((unsigned)reinterpret_cast<const int*>(tw)[(4 * q + r + 16 * hf) * BX_PITCH + BX_NBR] * (unsigned)PROW + (unsigned)((2 + kv) * H + c)) * 4u;
             const unsigned ioff = ((unsigned)i * (unsigned)PROW + (unsigned)(kv * H + c)) * 4u;
             const int ty1 = p1 ? ty_lig : ty_prot;
             float a0m[2][4], a1m[2][4];     // rbf of the edges of the first source class (padded slots: rT = 0)
@@ -887,7 +900,10 @@ __global__ __launch_bounds__(BX_WAVES * 64) void edge_backward_x2h_kernel(
                         all += dp[hf][r];
                         const float lm = ((msh >> (r + 16 * hf)) & 1u) ? 1.f : 0.f;
                         ligs = fmaf(lm, dp[hf][r], ligs);
-                        if (!(abl & 1)) atomo(dPb, joff[hf][r] + 64 * t, dp[hf][r]);   // padded slots add 0 to the node's own row
+                        if (!(abl & 1)) {
+                            if (ER) *reinterpret_cast<__attribute__((address_space(1))) float*>(dEb + (joff[hf][r] + 64 * t)) = dp[hf][r];   // (padded slots: rows nobody reads)
+                            else atomo(dPb, joff[hf][r] + 64 * t, dp[hf][r]);   // padded slots add 0 to the node's own row
+                        }
                     }
                 all = xrow_sum(all);
                 ligs = xrow_sum(ligs);
@@ -993,7 +1009,8 @@ hipError_t launch_edge_backward_x2h(const float* att, const float* x, const floa
                                     const float* gb, const int32_t* nbr, const int32_t* deg, const uint8_t* lig,
                                     const float* e_w, const int* rows, const int* n_rows, int n_nodes, float* T, float* S,
                                     float* sw, float* dP, float* dx, float* de_w, float* partial, float* nk_scratch,
-                                    int* work_ctr, int grid, hipStream_t s) {
+                                    int* work_ctr, int grid, hipStream_t s, float* dE) {
+    if (dE && rows) return hipErrorInvalidValue;      // edge rows are a full-launch mode (a listed launch would leave stale rows behind)
     profile_mark_begin(rows ? K_EDGE_X2H_BWD_LISTED : K_EDGE_X2H_BWD, s);
 #ifdef CBGX_ABLATE
     static const int abl = getenv("CBGX_BWD_ABL") ? atoi(getenv("CBGX_BWD_ABL")) : 0;
@@ -1002,8 +1019,12 @@ hipError_t launch_edge_backward_x2h(const float* att, const float* x, const floa
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bx_prof), z, sizeof(z));
     }
-    hipLaunchKernelGGL(edge_backward_x2h_kernel, dim3(grid), dim3(BX_WAVES * 64), 0, s, att, x, P, Qt, Gt, gb, nbr, deg, lig,
-                       e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, nk_scratch, work_ctr, abl);
+    if (dE)
+        hipLaunchKernelGGL(edge_backward_x2h_kernel<true>, dim3(grid), dim3(BX_WAVES * 64), 0, s, att, x, P, Qt, Gt, gb, nbr, deg, lig,
+                           e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, nk_scratch, work_ctr, dE, abl);
+    else
+        hipLaunchKernelGGL(edge_backward_x2h_kernel<false>, dim3(grid), dim3(BX_WAVES * 64), 0, s, att, x, P, Qt, Gt, gb, nbr, deg, lig,
+                           e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, nk_scratch, work_ctr, dE, abl);
     if (prof && !rows) {
         unsigned long long z[16];
         (void)hipStreamSynchronize(s);
@@ -1020,8 +1041,12 @@ hipError_t launch_edge_backward_x2h(const float* att, const float* x, const floa
         }
     }
 #else
-    hipLaunchKernelGGL(edge_backward_x2h_kernel, dim3(grid), dim3(BX_WAVES * 64), 0, s, att, x, P, Qt, Gt, gb, nbr, deg, lig,
-                       e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, nk_scratch, work_ctr);
+    if (dE)
+        hipLaunchKernelGGL(edge_backward_x2h_kernel<true>, dim3(grid), dim3(BX_WAVES * 64), 0, s, att, x, P, Qt, Gt, gb, nbr, deg, lig,
+                           e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, nk_scratch, work_ctr, dE);
+    else
+        hipLaunchKernelGGL(edge_backward_x2h_kernel<false>, dim3(grid), dim3(BX_WAVES * 64), 0, s, att, x, P, Qt, Gt, gb, nbr, deg, lig,
+                           e_w, rows, n_rows, n_nodes, T, S, sw, dP, dx, de_w, partial, nk_scratch, work_ctr, dE);
 #endif
     profile_mark_end(s);
     return hipGetLastError();

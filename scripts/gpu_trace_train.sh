@@ -6,7 +6,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/trace_train_$TAG
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT -o tr -- python $ROOT/bench.py --workload train --steps 3 --warmup 3 --no-cpu-baseline --no-roofline > $OUT/bench.log 2>&1
-find $OUT -name "*kernel_trace.csv" | head -1 | xargs -I{} python - {} $OUT <<'P'
+CSV=$(find $OUT -name "*kernel_trace.csv" | head -1)
+python - $CSV $OUT <<'P'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))

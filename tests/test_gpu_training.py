@@ -142,6 +142,74 @@ def test_attention_block_backward(golden_dir, synthetic_sd, model, case, kind, e
         accept_single_flip(near, failures, lambda force: compare(_oracle_block(synthetic_sd, g, 0, kind, seed=3, force=force)[2:6]))
 
 
+@contextlib.contextmanager
+def edge_rows(on=True):
+    """CBGX_BX_EDGE_ROWS=1 (read by the library at every backward call): neighbour-row gradients through edge rows + an ordered gather
+    instead of fp32 atomics"""
+    old = os.environ.get("CBGX_BX_EDGE_ROWS")
+    os.environ["CBGX_BX_EDGE_ROWS"] = "1" if on else "0"
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop("CBGX_BX_EDGE_ROWS", None)
+        else:
+            os.environ["CBGX_BX_EDGE_ROWS"] = old
+
+
+@pytest.mark.parametrize("case", ["denoiser_2graphs", "denoiser_linker", "denoiser_small_graphs"])
+def test_x2h_backward_with_edge_rows_matches_autograd(golden_dir, synthetic_sd, model, case):
+    """the x2h block's backward in edge-row mode (csrc/train_scatter.hip) against autograd on the oracle, same tolerances as the
+    default (atomics) mode in test_attention_block_backward"""
+    g = load(golden_dir, case)
+    h_in, gout, gx_ref, gh_ref, gew_ref, pg_ref, keys, ei, near = _oracle_block(synthetic_sd, g, 0, "x2h", seed=3)
+    x = g["x"].to(DEV)
+    gp = graph_ptr_from_batch(g["batch_idx"].to(DEV))
+    lig = g["lig_flag"].to(DEV).to(torch.uint8)
+    packed = model.denoiser.packed_weights(torch.device(DEV))
+    nbr, deg = stages.knn_graph(x, gp)
+    e_w = stages.edge_gate(packed, x, nbr, deg)
+    with edge_rows():
+        gh, gx, gew, pg = stages.x2h_attention_backward(packed, 0, x, h_in.to(DEV), nbr, deg, lig, e_w, gout.to(DEV))
+        torch.cuda.synchronize()
+    mask = (torch.arange(32, device=DEV)[None, :] < deg[:, None])
+    def compare(ref):
+        gx_r, gh_r, gew_r, pg_r = ref
+        msgs = [gerr(gh, gh_r, "x2h grad_h"), gerr(gx, gx_r, "x2h grad_x"), gerr(gew[mask], gew_r.flatten(), "x2h grad_e_w")]
+        msgs += [gerr(a, b, k) for k, a, b in zip(keys, pg, pg_r) if not k.endswith("k_func.net.3.bias")]
+        return [m for m in msgs if m]
+    failures = compare((gx_ref, gh_ref, gew_ref, pg_ref))
+    if failures:
+        accept_single_flip(near, failures, lambda force: compare(_oracle_block(synthetic_sd, g, 0, "x2h", seed=3, force=force)[2:6]))
+
+
+def test_x2h_backward_feature_gradient_is_bit_reproducible(golden_dir, synthetic_sd, model):
+    """Round 6, edge-row mode (CBGX_BX_EDGE_ROWS=1): the neighbour-row gradients of the x2h edge backward are gathered per source node
+    in a fixed order (edge rows + incoming-edge lists, csrc/train_scatter.hip) instead of being added by fp32 atomics, so dL/dh of an
+    x2h block -- g_out + dP Wn^T, every column of dP with one writer -- is the same bits in every run.  (The coordinate gradient still
+    uses atomics; the default mode keeps the atomics on dP: its training step is 2 - 3 % faster.)"""
+    with edge_rows():
+        _bit_reproducible(golden_dir, model)
+
+
+def _bit_reproducible(golden_dir, model):
+    g = load(golden_dir, "denoiser_2graphs")
+    x = g["x"].to(DEV)
+    gp = graph_ptr_from_batch(g["batch_idx"].to(DEV))
+    lig = g["lig_flag"].to(DEV).to(torch.uint8)
+    packed = model.denoiser.packed_weights(torch.device(DEV))
+    nbr, deg = stages.knn_graph(x, gp)
+    e_w = stages.edge_gate(packed, x, nbr, deg)
+    gout = torch.randn(g["h"].shape, generator=torch.Generator().manual_seed(11)).to(DEV)
+    runs = []
+    for _ in range(4):
+        gh, gx, gew, pg = stages.x2h_attention_backward(packed, 0, x, g["h"].to(DEV), nbr, deg, lig, e_w, gout)
+        torch.cuda.synchronize()
+        runs.append(gh.clone())
+    assert all(torch.equal(runs[0], r) for r in runs[1:])
+    assert float(runs[0].abs().max()) > 0.0 and bool(torch.isfinite(runs[0]).all())
+
+
 def golden_batch(g, device):
     return {k[len("batch_"):]: v.to(device) for k, v in g.items() if k.startswith("batch_")}
 
@@ -230,6 +298,46 @@ def test_training_step_matches_reference_gradients(golden_dir, synthetic_sd, cas
             return near, TR.loss_and_grads(synthetic_sd, golden_batch(g, "cpu"), g["t"], g["eps"], g["u"], 13)[1]
 
     check_golden_gradients(m, g, 8 + 6 + 9 * 36 + 4, oracle_run)
+
+
+def test_backward_schedules_give_the_same_gradients(golden_dir, synthetic_sd):
+    """The training path's stream schedule -- weight-gradient kernels of every block on the auxiliary stream (CBGX_TRAIN_OVERLAP), the
+    next x2h block's node stage next to the h2x block in the taped forward (CBGX_TRAIN_FWD_OVERLAP), listed-row zeroing of an h2x
+    block's projection gradient (CBGX_TRAIN_ZERO_ROWS) -- changes no arithmetic, and the edge-row mode of the neighbour-row gradients
+    (CBGX_BX_EDGE_ROWS=1) only their summation order: all parameter gradients of one step agree between the default and every other
+    setting to within what the fp32 atomics move them, run to run."""
+    g = load(golden_dir, "train_loss_denovo")
+    m = C.get_model(C.default_targetdiff_config(13))
+    m.load_state_dict(synthetic_sd, strict=True)
+    m = m.to(DEV).train()
+    batch = golden_batch(g, DEV)
+
+    def grads(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            m.zero_grad(set_to_none=True)
+            ld, _ = m(batch, t=g["t"].to(DEV), noise=(g["eps"].to(DEV), g["u"].to(DEV)))
+            (1.0 * ld["pos"] + 100.0 * ld["atom"]).backward()
+            torch.cuda.synchronize()
+            return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    ref = grads({})
+    again = grads({})
+    noise = max(float((again[k] - ref[k]).norm() / (ref[k].norm() + 1e-30)) for k in ref)      # atomics alone, same schedule
+    for env in ({"CBGX_TRAIN_FWD_OVERLAP": "0"}, {"CBGX_TRAIN_ZERO_ROWS": "0"}, {"CBGX_TRAIN_OVERLAP": "0"},
+                {"CBGX_BX_EDGE_ROWS": "1"}, {"CBGX_BX_EDGE_ROWS": "1", "CBGX_TRAIN_OVERLAP": "0"}):
+        got = grads(env)
+        assert got.keys() == ref.keys()
+        for k in ref:
+            d = float((got[k] - ref[k]).norm() / (ref[k].norm() + 1e-30))
+            assert d <= max(5e-6, 4 * noise), (env, k, d, noise)
 
 
 def test_training_loss_decreases_with_adam(synthetic_sd):
