@@ -285,7 +285,11 @@ int cbgx_diffsbdd_step(const float *x_den, const float *logits, const int32_t *g
  *       gradient entries on other rows are ignored.  A loss that touches other rows must pass a (possibly all-zero) grad_h_out
  *       to get the unpruned backward.
  * Both take the larger training workspace (cbgx_train_workspace_bytes).  Neighbour-row gradients are accumulated with
- * fp32 atomics, so results are reproducible only up to summation order (as with the reference's torch_scatter on GPU). */
+ * fp32 atomics, so results are reproducible only up to summation order (as with the reference's torch_scatter on GPU).
+ * CBGX_BX_EDGE_ROWS=1 in the environment (read at every backward call; ABI unchanged, the workspace always holds the buffers:
+ * 32 KB per node) selects the edge-row mode of the x2h blocks instead: every edge's contribution goes to its own row and the rows of
+ * every source node are summed in a fixed order (csrc/train_scatter.hip) -- dL/dh then has the same bits in every run, the
+ * coordinate gradient still uses atomics, and a training step is 1 - 3 % slower.  Same mathematics, same tolerances in the tests. */
 size_t cbgx_train_tape_bytes(int n_nodes, int num_layers);
 size_t cbgx_train_workspace_bytes(int n_nodes);
 int cbgx_unitransformer_forward_train(const float *packed, int num_layers, int num_classes,
