@@ -103,11 +103,20 @@ def test_x2h_backward_kernel_fits_its_budget(tmp_path):
     per node, measured at 1.04 ms per launch) is capped here so that an edit cannot quietly bring back the several hundred spilled
     registers that every early version of the kernel had (1.3 - 1.9 ms per launch)."""
     res, text = kernel_resources("train_bwd_x2h.hip", tmp_path)
-    k = find(res, "edge_backward_x2h_kernel")
+    # two instantiations (round 6): <false> adds the neighbour-row gradients by fp32 atomics, <true> stores them into per-edge rows
+    n_at = {inst: _check_x2h_backward(res, text, inst) for inst in ("ILb0E", "ILb1E")}
+    # neighbour rows: 64 atomic sites (8 per step of pass 4) in the atomics build, plain stores in the edge-row build; what both keep
+    # are the coordinate gradient and the rarely-taken rbf-column flushes of edge types 0..2
+    assert n_at["ILb0E"] - n_at["ILb1E"] == 64 and n_at["ILb1E"] <= 96, n_at
+
+
+def _check_x2h_backward(res, text, inst):
+    k = find(res, "edge_backward_x2h_kernel" + inst)
     assert k["vgpr"] <= 256 and k["lds"] <= 160 * 1024
     assert k["scratch"] <= 256, k            # bytes per lane: <= 64 spilled registers
-    start = re.search(r"^_ZN4cbgx24edge_backward_x2h_kernel\S*:", text, flags=re.M).start()
+    start = re.search(r"^_ZN4cbgx24edge_backward_x2h_kernel" + inst + r"\S*:", text, flags=re.M).start()
     body = text[start:text.index(".end_amdhsa_kernel", start)]
+    n_atomic = len(re.findall(r"^\s+global_atomic_add_f32", body, flags=re.M))
     mfma32 = len(re.findall(r"^\s+v_mfma_f32_16x16x4", body, flags=re.M))
     mfma16 = len(re.findall(r"^\s+v_mfma_f32_16x16x16_f16", body, flags=re.M))
     mfma4 = len(re.findall(r"^\s+v_mfma_f32_4x4x1", body, flags=re.M))
@@ -120,6 +129,7 @@ def test_x2h_backward_kernel_fits_its_budget(tmp_path):
     # node at 64 LDS cycles each -- kept the CU's LDS pipe a third busy on their own); what is left are the 16-lane adds of the type
     # columns and the LayerNorm affine
     assert len(re.findall(r"^\s+ds_add_f32", body, flags=re.M)) <= 32 and len(re.findall(r"^\s+ds_cmpst_rtn_b32", body, flags=re.M)) >= 1
+    return n_atomic
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
