@@ -64,3 +64,12 @@ d=json.loads(sys.stdin.read()); k=d['roofline']['per_kernel_us_avg_and_launches'
 print('$L'.split('/')[-1], d['value'], {n: v for n, v in k.items() if v[1]})"
 done | tee $OUT/ab_fwd_$TAG.log
 fi
+echo "== training step: kernel trace with queue ids (critical path of the caller's stream) =="
+bash scripts/gpu_trace_train.sh $TAG 2>&1 | head -12
+cp $OUT/trace_train_$TAG/critical.txt $OUT/trace_train_critical_$TAG.txt 2>/dev/null
+echo "== training line under the per-call knobs (edge rows, schedule) =="
+for set in "" "CBGX_BX_EDGE_ROWS=1" "CBGX_TRAIN_FWD_OVERLAP=0 CBGX_TRAIN_ZERO_ROWS=0" "CBGX_TRAIN_OVERLAP=0"; do for rep in 1 2; do
+env $set python bench.py --workload train --steps 20 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']['per_kernel_us_avg_and_launches']
+print('[$set] train', d['value'], 'graph-steps/s; x2h backward', d['roofline']['avg_launch_us'], 'us; gather', r.get('edge_rows_reduce'))"; done; done | tee $OUT/train_knobs_$TAG.log
