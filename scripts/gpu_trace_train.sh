@@ -1,11 +1,11 @@
 #!/bin/bash
 # kernel trace of a few training steps with the queue of every dispatch: what is on the critical path (the caller's stream) and what
 # runs beside it (the library's auxiliary stream).  Output: gpurun_out/trace_train_<tag>/{last_step.tsv, critical.txt}
-TAG=${1:-r06}
+TAG=${1:-r06}; MODEL=${2:-targetdiff}      # model class: targetdiff | diffbp | diffsbdd
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/trace_train_$TAG
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o tr -- python $ROOT/bench.py --workload train --steps 3 --warmup 3 --no-cpu-baseline --no-roofline > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o tr -- python $ROOT/bench.py --workload train --model $MODEL --steps 3 --warmup 3 --no-cpu-baseline --no-roofline > $OUT/bench.log 2>&1
 CSV=$(find $OUT -name "*kernel_trace.csv" | head -1)
 python - $CSV $OUT <<'P'
 import csv, sys, collections
