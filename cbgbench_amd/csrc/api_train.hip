@@ -680,9 +680,13 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
     // on ligand rows only (classifier), the last h2x block adds rows of A1 = gen | lig | nbr(gen), and the x2h block of a
     // layer spreads its input gradient one hop further (A2 = A1 | nbr(A1)).  Rows outside carry an exactly zero gradient
     // and contribute exactly zero to everything, so the last two x2h blocks are walked on A1 / A2 only.
-    const bool prune = (grad_h_out == nullptr) && L >= 3;
+    // Round 6: with a caller gradient on h_out the same pruning holds around ITS support (the rows with a non-zero entry, marked on
+    // the device): DiffBP's centre-of-mass head reads h_out on the movable atoms and their neighbours only, and until now its
+    // training ran all nine x2h blocks -- and the dense products of all nine h2x blocks -- on every row (CBGX_TRAIN_PRUNE_GH=0: as before).
+    const bool prune = (grad_h_out == nullptr || env_on("CBGX_TRAIN_PRUNE_GH")) && L >= 3;
     if (prune) {
         HIP_TRY(launch_mark_seed(gen_flag, lig_flag, n, w.mask, s));
+        if (grad_h_out) HIP_TRY(launch_mark_nonzero_rows(grad_h_out, n, w.mask, s));
         HIP_TRY(launch_mark_nbr(w.act, w.act_count, n, tp.nbr, tp.deg, w.mask, s));
         HIP_TRY(launch_build_active(w.mask, n, w.rf_list[0], w.rf_count, s));
         HIP_TRY(launch_mark_nbr(w.rf_list[0], w.rf_count, n, tp.nbr, tp.deg, w.mask, s));
@@ -821,14 +825,32 @@ int cbgx_h2x_stack_backward(const float* packed, int num_layers, const void* tap
     HIP_TRY(hipMemcpyAsync(w.gx[cur], grad_x_out, nx * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemsetAsync(w.de_w, 0, (size_t)n * KNN * 4, s));
     HIP_TRY(launch_build_active(gen_flag, n, w.act, w.act_count, s));
+    // Round 6, as the denoiser's layer loop: the projection gradient of an h2x block is non-zero on gen | nbr(gen) only (this stack's
+    // own graph), so its fill and every dense product over it walk that list; the weight-gradient kernels of a block run on the caller's
+    // auxiliary stream on alternating buffer sets, one query-LayerNorm accumulator slot per block (CBGX_TRAIN_OVERLAP=0: one stream)
+    const bool lists = g_edge_impl != 1 && env_on("CBGX_TRAIN_STACK_LISTS");
+    if (lists) {
+        HIP_TRY(launch_mark_seed(gen_flag, gen_flag, n, w.mask, s));
+        HIP_TRY(launch_mark_nbr(w.act, w.act_count, n, tp.nbr, tp.deg, w.mask, s));
+        HIP_TRY(launch_build_active(w.mask, n, w.rf_list[0], w.rf_count, s));
+    }
+    const bool qln_slots = num_layers <= QLN_SLOTS;
+    if (qln_slots) HIP_TRY(hipMemsetAsync(w.qln, 0, (size_t)num_layers * 2 * H * sizeof(float), s));
+    BlockOverlap ov{(lists && env_on("CBGX_TRAIN_OVERLAP") && !profile_is_on() && qln_slots) ? aux_for(s) : nullptr, 0, {false, false}};
     for (int l = num_layers - 1; l >= 0; --l) {
         const int nxt = cur ^ 1;
         HIP_TRY(hipMemcpyAsync(w.gx[nxt], w.gx[cur], nx * 4, hipMemcpyDeviceToDevice, s));      // x_out = x + gen * delta
         RC_TRY(attention_block_backward(false, packed + GATE_SIZE + (size_t)l * ATT_SIZE, tp.xs + (size_t)l * nx, h, w.gx[cur],
                                         tp.nbr, tp.deg, lig_flag, tp.e_w, w.act, w.act_count, n, w, w.gh, w.gx[nxt], w.de_w,
-                                        grads + 6 + 18 * l, s));
+                                        grads + 6 + 18 * l, s, nullptr, nullptr,
+                                        qln_slots ? w.qln + (size_t)l * 2 * H : nullptr, nullptr,
+                                        lists ? w.rf_list[0] : nullptr, lists ? w.rf_count : nullptr, &ov));
         cur = nxt;
     }
+    if (ov.aux)
+        for (int k = 0; k < 2; ++k)
+            if (ov.used[k]) HIP_TRY(hipStreamWaitEvent(s, ov.aux->done[k], 0));
+    ov.joined = true;
     HIP_TRY(hipMemcpyAsync(grad_h, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(launch_gate_backward_mfma(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.partial, GATE_GRID, s));
     FOLDED(w.partial, GATE_GRID, GB_SIZE, GB_SIZE);
