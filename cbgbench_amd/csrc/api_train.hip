@@ -495,6 +495,29 @@ int cbgx_unitransformer_forward_train(const float* packed, int num_layers, int n
         AuxLane* a; bool out = false;
         ~Joiner() { if (a && out) (void)hipStreamSynchronize(a->s); }
     } jn{aux};
+    // Round 6, h_out == NULL (the caller does not read h': TargetDiff / DiffSBDD training, whose backward then comes with
+    // grad_h_out == NULL and prunes the same way): the receptive-field pruning of the sampling forward.  The outputs that remain are
+    // x_out and the logits of ligand rows, so the last x2h block only has to produce h' on A1 = gen | lig | nbr(gen), the one before it
+    // on A2 = A1 | nbr(A1) (its sources: A3 = A2 | nbr(A2)); h2x blocks need the neighbour projection on nbr(gen) only (subset of A1).
+    // Rows outside those sets are zero on the tape (the pruned backward's dense products over h walk all rows with zero weights).
+    const bool fprune = !h_out && num_layers >= 3 && g_edge_impl != 1 && env_on("CBGX_TRAIN_FWD_PRUNE");
+    const int* A[3] = {w.rf_list[0], w.rf_list[1], w.lig_list};
+    const int* An[3] = {w.rf_count, w.rf_count + 16, w.rf_count + 32};
+    if (fprune) {
+        HIP_TRY(launch_mark_seed(gen_flag, lig_flag, n_nodes, w.mask, s));
+        HIP_TRY(launch_mark_nbr(w.act, w.act_count, n_nodes, tp.nbr, tp.deg, w.mask, s));
+        HIP_TRY(launch_build_active(w.mask, n_nodes, w.rf_list[0], w.rf_count, s));
+        HIP_TRY(launch_mark_nbr(w.rf_list[0], w.rf_count, n_nodes, tp.nbr, tp.deg, w.mask, s));
+        HIP_TRY(launch_build_active(w.mask, n_nodes, w.rf_list[1], w.rf_count + 16, s));
+        HIP_TRY(launch_mark_nbr(w.rf_list[1], w.rf_count + 16, n_nodes, tp.nbr, tp.deg, w.mask, s));
+        HIP_TRY(launch_build_active(w.mask, n_nodes, w.lig_list, w.rf_count + 32, s));
+    }
+    // (destination list, its count, source list, its count) of the x2h block of layer l
+    auto x2h_lists = [&](int l, const int*& d, const int*& dn, const int*& sr, const int*& sn) {
+        d = dn = sr = sn = nullptr;
+        const int k = num_layers - 1 - l;      // 0 for the last layer
+        if (fprune && k < 2) { d = A[k]; dn = An[k]; sr = A[k + 1]; sn = An[k + 1]; }
+    };
     for (int l = 0; l < num_layers; ++l) {
         const float* xc = tp.xs + (size_t)l * nx;
         const float* hc = tp.hs + (size_t)l * nh;
@@ -502,28 +525,31 @@ int cbgx_unitransformer_forward_train(const float* packed, int num_layers, int n
         float* hn = tp.hs + (size_t)(l + 1) * nh;
         float* Px = tp.P + (size_t)(2 * l) * n_nodes * PROW;
         float* Qx = tp.Qt + (size_t)(2 * l) * n_nodes * HEADS * H;
+        const int *d, *dn, *sr, *sn;
+        x2h_lists(l, d, dn, sr, sn);
+        if (d) HIP_TRY(hipMemsetAsync(hn, 0, nh * 4, s));      // rows the listed launch does not write
         if (!aux) {
             HIP_TRY(launch_attention(true, packed + x2h_off(l), xc, hc, tp.nbr, tp.deg, lig_flag, gen_flag, tp.e_w, n_nodes,
-                                     Px, Qx, w.qs, hn, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+                                     Px, Qx, w.qs, hn, nullptr, d, dn, sr, sn, s));
         } else {
-            if (l == 0) HIP_TRY(launch_node_mfma(packed + x2h_off(0), hc, lig_flag, n_nodes, Px, w.qs2, Qx, nullptr, nullptr,
-                                                 nullptr, nullptr, s, true));
+            if (l == 0) HIP_TRY(launch_node_mfma(packed + x2h_off(0), hc, lig_flag, n_nodes, Px, w.qs2, Qx, d, dn, sr, sn, s, true));
             else { HIP_TRY(hipStreamWaitEvent(s, aux->join, 0)); jn.out = false; }      // this layer's node stage (auxiliary stream)
             HIP_TRY(launch_edge_mfma(true, packed + x2h_off(l), xc, hc, Px, Qx, tp.nbr, tp.deg, lig_flag, gen_flag, tp.e_w, n_nodes,
-                                     hn, nullptr, nullptr, nullptr, s));
+                                     hn, nullptr, d, dn, s));
             if (l + 1 < num_layers) {
+                const int *d2, *d2n, *s2, *s2n;
+                x2h_lists(l + 1, d2, d2n, s2, s2n);
                 HIP_TRY(hipEventRecord(aux->fork, s));
                 HIP_TRY(hipStreamWaitEvent(aux->s, aux->fork, 0));
                 jn.out = true;
                 HIP_TRY(launch_node_mfma(packed + x2h_off(l + 1), hn, lig_flag, n_nodes, tp.P + (size_t)(2 * l + 2) * n_nodes * PROW,
-                                         w.qs2, tp.Qt + (size_t)(2 * l + 2) * n_nodes * HEADS * H, nullptr, nullptr, nullptr,
-                                         nullptr, aux->s, true));
+                                         w.qs2, tp.Qt + (size_t)(2 * l + 2) * n_nodes * HEADS * H, d2, d2n, s2, s2n, aux->s, true));
                 HIP_TRY(hipEventRecord(aux->join, aux->s));
             }
         }
         HIP_TRY(launch_attention(false, packed + h2x_off(l), xc, hn, tp.nbr, tp.deg, lig_flag, gen_flag, tp.e_w, n_nodes,
                                  Px + (size_t)n_nodes * PROW, Qx + (size_t)n_nodes * HEADS * H, w.qs, xn, nullptr, w.act,
-                                 w.act_count, nullptr, nullptr, s));
+                                 w.act_count, fprune ? A[0] : nullptr, fprune ? An[0] : nullptr, s));
     }
     const float* hl = tp.hs + (size_t)num_layers * nh;
     HIP_TRY(hipMemcpyAsync(x_out, tp.xs + (size_t)num_layers * nx, nx * 4, hipMemcpyDeviceToDevice, s));
@@ -531,9 +557,10 @@ int cbgx_unitransformer_forward_train(const float* packed, int num_layers, int n
     if (logits) {
         if (num_classes < 1) return set_error(CBGX_E_INVALID, "forward_train: num_classes=%d", num_classes);
         const float* c = packed + cls_off(num_layers);
-        HIP_TRY(launch_node_gemm(hl, H, c + C_W0T, c + C_B0, w.P, H, n_nodes, H, 1, s));
+        // (pruned: the logits of the A1 rows -- the ligand rows are among them; other rows of `logits` are not written)
+        HIP_TRY(launch_node_gemm(hl, H, c + C_W0T, c + C_B0, w.P, H, n_nodes, H, 1, s, fprune ? A[0] : nullptr, fprune ? An[0] : nullptr));
         HIP_TRY(launch_node_gemm(w.P, H, c + C_W1T, c + cls_b1(num_classes), logits, num_classes, n_nodes, num_classes,
-                                 0, s));
+                                 0, s, fprune ? A[0] : nullptr, fprune ? An[0] : nullptr));
     }
     return CBGX_OK;
 }
@@ -606,7 +633,10 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
     if (grad_h_out) HIP_TRY(hipMemcpyAsync(w.gh, grad_h_out, nh * 4, hipMemcpyDeviceToDevice, s));
     else HIP_TRY(hipMemsetAsync(w.gh, 0, nh * 4, s));
     float* const* cg = grads + 6 + 36 * L;
-    if (grad_logits && grad_h_out == nullptr && g_edge_impl != 1) {
+    // (round 6: with a caller gradient on h_out the same listed head runs on the SUPPORT of grad_logits -- the rows with a non-zero
+    // entry, marked on the device; DiffBP's losses read the logits of ligand rows only as well.  CBGX_TRAIN_PRUNE_GH=0: the dense head)
+    const bool head_listed = grad_logits && g_edge_impl != 1 && C <= 128 && (grad_h_out == nullptr || env_on("CBGX_TRAIN_PRUNE_GH"));
+    if (head_listed) {
         // The caller's promise behind grad_h_out == NULL (include/cbgx.h): its loss reads the logits on lig_flag rows only, so
         // grad_logits is zero elsewhere and the head's backward walks the ligand rows (a twentieth of the nodes) instead of all
         // of them: listed node GEMMs for the recompute, listed weight- / input-gradient products, nothing read outside the list.
@@ -617,7 +647,11 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         float* dact = w.dqb;
         const int* ll = w.lig_list;
         const int* lc = w.rf_count + 32;
-        HIP_TRY(launch_build_active(lig_flag, n, w.lig_list, w.rf_count + 32, s));
+        if (grad_h_out) {       // no promise about grad_logits: its support
+            HIP_TRY(launch_mark_nonzero_rows(grad_logits, n, w.mask, s, C, 1));
+            HIP_TRY(launch_build_active(w.mask, n, w.lig_list, w.rf_count + 32, s));
+        } else
+            HIP_TRY(launch_build_active(lig_flag, n, w.lig_list, w.rf_count + 32, s));
         HIP_TRY(launch_node_gemm(hl, H, c + C_W0T, c + C_B0, pre, H, n, H, 0, s, ll, lc));
         HIP_TRY(launch_node_gemm(hl, H, c + C_W0T, c + C_B0, act, H, n, H, 1, s, ll, lc));
         // classifier.2: dW1[c][k] = sum_i dlogits[i][c] act[i][k];  db1 = colsum(dlogits)
@@ -683,10 +717,13 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
     // Round 6: with a caller gradient on h_out the same pruning holds around ITS support (the rows with a non-zero entry, marked on
     // the device): DiffBP's centre-of-mass head reads h_out on the movable atoms and their neighbours only, and until now its
     // training ran all nine x2h blocks -- and the dense products of all nine h2x blocks -- on every row (CBGX_TRAIN_PRUNE_GH=0: as before).
-    const bool prune = (grad_h_out == nullptr || env_on("CBGX_TRAIN_PRUNE_GH")) && L >= 3;
+    const bool prune = (grad_h_out == nullptr || (env_on("CBGX_TRAIN_PRUNE_GH") && (!grad_logits || C <= 128))) && L >= 3;
     if (prune) {
         HIP_TRY(launch_mark_seed(gen_flag, lig_flag, n, w.mask, s));
-        if (grad_h_out) HIP_TRY(launch_mark_nonzero_rows(grad_h_out, n, w.mask, s));
+        if (grad_h_out) {       // the seed: every row where dL/dh_L can be non-zero (no promise about the caller's two gradients)
+            HIP_TRY(launch_mark_nonzero_rows(grad_h_out, n, w.mask, s));
+            if (grad_logits && C <= 128) HIP_TRY(launch_mark_nonzero_rows(grad_logits, n, w.mask, s, C, 0));
+        }
         HIP_TRY(launch_mark_nbr(w.act, w.act_count, n, tp.nbr, tp.deg, w.mask, s));
         HIP_TRY(launch_build_active(w.mask, n, w.rf_list[0], w.rf_count, s));
         HIP_TRY(launch_mark_nbr(w.rf_list[0], w.rf_count, n, tp.nbr, tp.deg, w.mask, s));

@@ -155,17 +155,22 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ A, i
 // m[i] = 1 for every row of g [n][128] with a non-zero entry (one wavefront per row): the support of a caller's dL/dh_out, so that
 // the backward's receptive-field pruning also applies when such a gradient exists (it is exactly zero outside: DiffBP's centre-of-mass
 // head reads the features of the movable atoms and their neighbours only)
-__global__ __launch_bounds__(256) void mark_nonzero_rows_kernel(const float* __restrict__ g, int n, uint8_t* __restrict__ m) {
+// (`cols` <= 128 columns per row; `set`: m[i] = 0 / 1 instead of only raising it)
+__global__ __launch_bounds__(256) void mark_nonzero_rows_kernel(const float* __restrict__ g, int n, int cols, int set,
+                                                                 uint8_t* __restrict__ m) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
-    const float2 v = *reinterpret_cast<const float2*>(g + (size_t)i * H + 2 * lane);
-    if (__ballot(v.x != 0.f || v.y != 0.f) && lane == 0) m[i] = 1;
+    const float* row = g + (size_t)i * cols;
+    const float a = lane < cols ? row[lane] : 0.f, b = lane + 64 < cols ? row[lane + 64] : 0.f;
+    const bool any = __ballot(a != 0.f || b != 0.f) != 0;
+    if (lane == 0) { if (set) m[i] = any ? 1 : 0; else if (any) m[i] = 1; }
 }
 
-hipError_t launch_mark_nonzero_rows(const float* g, int n, uint8_t* m, hipStream_t s) {
+hipError_t launch_mark_nonzero_rows(const float* g, int n, uint8_t* m, hipStream_t s, int cols, int set) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(mark_nonzero_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, s, g, n, m);
+    if (cols < 1 || cols > 128) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mark_nonzero_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, s, g, n, cols, set, m);
     return hipGetLastError();
 }
 

@@ -100,13 +100,19 @@ class _DenoiserFunction(torch.autograd.Function):
         packed = module.packed_weights(device)
         tape = torch.empty(lib.cbgx_train_tape_bytes(N, L), dtype=torch.uint8, device=device)
         ws = module.train_workspace(N, device)
-        x_out, h_out = torch.empty_like(x), torch.empty_like(h)
+        # ligand_outputs_only: the caller reads x' on gen_flag rows and the logits on lig_flag rows, never h' -- h_out = NULL lets the
+        # library prune the taped forward to the receptive field of those rows (include/cbgx.h); what is returned in place of h' is an
+        # EMPTY tensor, so that a caller who breaks the promise fails on the shape instead of reading unwritten rows
+        x_out = torch.empty_like(x)
+        h_out = None if ligand_outputs_only else torch.empty_like(h)
         logits = torch.empty(N, C, dtype=torch.float32, device=device)
         rc = lib.cbgx_unitransformer_forward_train(
             _native.ptr(packed), L, C, _native.ptr(x), _native.ptr(h), _native.ptr(graph_ptr), _native.ptr(lig),
             _native.ptr(gen), N, B, _native.ptr(x_out), _native.ptr(h_out), _native.ptr(logits), _native.ptr(tape),
             tape.numel(), _native.ptr(ws), ws.numel(), _native.current_stream(device))
         _native.check(rc, "cbgx_unitransformer_forward_train")
+        if h_out is None:
+            h_out = torch.empty(0, h.shape[1], dtype=torch.float32, device=device)
         ctx.module, ctx.tape, ctx.packed, ctx.flags, ctx.n = module, tape, packed, (lig, gen), N
         ctx.ligand_outputs_only = bool(ligand_outputs_only)
         ctx.param_shapes = [tuple(p.shape) for p in params]
@@ -150,6 +156,9 @@ class _DenoiserFunction(torch.autograd.Function):
         ws = module.train_workspace(N, device)
         cont = lambda g: None if g is None else g.contiguous().float()
         gx, gh, gl = cont(gx), cont(gh), cont(gl)
+        if gh is not None and ctx.ligand_outputs_only:
+            raise RuntimeError("UniTransformer(ligand_outputs_only=True): the loss has a gradient on h' -- the taped forward was pruned "
+                               "on the promise that h' is not read")
         if gh is None and not ctx.ligand_outputs_only:
             # a NULL dL/dh_out makes the library prune the backward of the last blocks to the receptive field of the
             # ligand / movable rows (include/cbgx.h); only callers that promise their loss reads x' on gen_flag rows and

@@ -271,9 +271,13 @@ int cbgx_diffsbdd_step(const float *x_den, const float *logits, const int32_t *g
  * train.py:185-189 runs `loss_dict, _ = model(batch); loss.backward()`; autograd walks UniTransformer.forward
  * (unitransformer.py:102-123) backwards through every X2HAttention / H2XAttention (x2h_attention.py:43-97,
  * h2x_attention.py:34-73), the gate and the classifier.  libcbgx replaces that pair with
- *   cbgx_unitransformer_forward_train : same outputs as cbgx_unitransformer_forward (no pruning) and a *tape*
+ *   cbgx_unitransformer_forward_train : same outputs as cbgx_unitransformer_forward and a *tape*
  *       (caller-owned, cbgx_train_tape_bytes) holding the kNN lists, the gate, the per-layer x / h inputs and the node
- *       stage of every block (projection [N,640] + folded query [N,16,128]: 177 KB per node and layer);
+ *       stage of every block (projection [N,640] + folded query [N,16,128]: 177 KB per node and layer).  h_out != NULL: no
+ *       pruning.  h_out == NULL (round 6): the caller promises that its loss reads x_out on gen_flag rows and logits on
+ *       lig_flag rows only -- and will call the backward with grad_h_out == NULL; the last two x2h blocks, the neighbour
+ *       projections of the h2x blocks and the classifier then run on the receptive field of those rows, as in the sampling
+ *       forward (rows of `logits` outside gen | lig | nbr(gen) are not written);
  *   cbgx_unitransformer_backward      : given dL/dx_out [N,3], dL/dh_out [N,128], dL/dlogits [N,C] (each may be
  *       NULL = zero) it recomputes the per-edge intermediates block by block (nothing per-edge is ever stored) and
  *       writes dL/dh_in [N,128] (may be NULL) and the gradient of every parameter tensor: `grads` is a HOST array
@@ -283,7 +287,10 @@ int cbgx_diffsbdd_step(const float *x_den, const float *logits, const int32_t *g
  *       (what TargetDiff.get_loss / DiffSBDD.get_loss do, targetdiff.py:103-121); the backward of the last x2h blocks is
  *       then pruned to the receptive field of those rows, the classifier head's backward walks the lig_flag rows only, and
  *       gradient entries on other rows are ignored.  A loss that touches other rows must pass a (possibly all-zero) grad_h_out
- *       to get the unpruned backward.
+ *       (and must have run the forward with h_out != NULL): the backward is then exact for ANY loss -- since round 6 it still
+ *       prunes, but around the support of the caller's gradients, which it finds itself (the rows of grad_h_out / grad_logits
+ *       with a non-zero entry are marked on the device and join the seed of the receptive field; DiffBP's centre-of-mass head
+ *       reads h_out on the movable atoms and their neighbours only: + 9.6 % on its training step).
  * Both take the larger training workspace (cbgx_train_workspace_bytes).  Neighbour-row gradients are accumulated with
  * fp32 atomics, so results are reproducible only up to summation order (as with the reference's torch_scatter on GPU).
  * CBGX_BX_EDGE_ROWS=1 in the environment (read at every backward call; ABI unchanged, the workspace always holds the buffers:

@@ -340,6 +340,59 @@ def test_backward_schedules_give_the_same_gradients(golden_dir, synthetic_sd):
             assert d <= max(5e-6, 4 * noise), (env, k, d, noise)
 
 
+@pytest.mark.parametrize("support", ["sparse", "dense", "off_ligand_logits"])
+def test_pruning_around_a_callers_feature_gradient(golden_dir, synthetic_sd, support):
+    """Round 6: the backward's receptive-field pruning also runs when the caller has a gradient on h_out -- around that gradient's
+    support, marked on the device (rows with a non-zero entry of dL/dh_out or dL/dlogits).  Exact by construction; checked against
+    the unpruned backward (CBGX_TRAIN_PRUNE_GH=0) for a loss that reads h_out on a few rows (DiffBP's centre-of-mass head does),
+    on every row, and one that reads the logits of PROTEIN rows (no promise about the caller's gradients is used)."""
+    g = load(golden_dir, "denoiser_linker")
+    m = C.get_model(C.default_targetdiff_config(13))
+    m.load_state_dict(synthetic_sd, strict=True)
+    m = m.to(DEV).train()
+    x, h = g["x"].to(DEV), g["h"].to(DEV)
+    bi, lig, gen = g["batch_idx"].to(DEV), g["lig_flag"].to(DEV), g["gen_flag"].to(DEV)
+    N = x.shape[0]
+    gen_w = torch.Generator().manual_seed(5)
+    wh = torch.randn(N, 128, generator=gen_w).to(DEV)
+    wl = torch.randn(N, 13, generator=gen_w).to(DEV)
+    rows = torch.zeros(N, dtype=torch.bool, device=DEV)
+    if support == "sparse":
+        rows[torch.randperm(N, generator=gen_w)[: max(4, N // 50)].to(DEV)] = True
+    else:
+        rows[:] = True
+    lrows = lig.bool() if support != "off_ligand_logits" else ~lig.bool()
+
+    def grads(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            m.zero_grad(set_to_none=True)
+            xo, ho, logits = m.denoiser(x=x, h=h, batch_idx=bi, lig_flag=lig, gen_flag=gen)
+            loss = (ho * wh)[rows].sum() + (logits * wl)[lrows].sum() + (xo ** 2).sum()
+            loss.backward()
+            torch.cuda.synchronize()
+            return {k: p.grad.detach().clone() for k, p in m.denoiser.named_parameters() if p.grad is not None}
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    ref = grads({"CBGX_TRAIN_PRUNE_GH": "0"})
+    again = grads({"CBGX_TRAIN_PRUNE_GH": "0"})
+    noise = max(float((again[k] - ref[k]).norm() / (ref[k].norm() + 1e-30)) for k in ref)
+    got = grads({})
+    assert got.keys() == ref.keys() and len(ref) > 300
+    for k in ref:
+        d = float((got[k] - ref[k]).norm() / (ref[k].norm() + 1e-30))
+        # (a listed launch partitions the nodes over the workgroups differently from a full one: the per-workgroup partial sums of the
+        # weight gradients are added in another order -- fp32 re-association, 1e-6 .. 1e-5 of a tensor's norm; an error of the
+        # pruning itself would be a missing row's whole contribution)
+        assert d <= max(5e-5, 4 * noise), (support, k, d, noise)
+
+
 def test_training_loss_decreases_with_adam(synthetic_sd):
     """a few optimiser steps on one fixed batch and fixed noise: the weighted loss must go down (train.py:173-190)."""
     from cbgbench_amd import synthetic
