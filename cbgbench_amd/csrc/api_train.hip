@@ -97,6 +97,7 @@ struct TrainWs {
     int *rf_list[2], *rf_count;
     // round 6, x2h edge backward without neighbour-row atomics (train_scatter.hip, CBGX_BX_EDGE_ROWS=1): one row per edge, and the
     // incoming-edge lists of every source node (built once per backward call)
+    float *gate_partial, *gate_folded;     // the gate backward's own slabs: it runs before the auxiliary stream is joined (round 6)
     float* dE;            // [N][32][256]
     int *rin_cnt, *rin_ptr, *rin_tmp, *rin_edge;
     int* lig_list;        // rows with lig_flag (count: rf_count + 32): the classifier head's backward walks it when the loss reads ligand rows only
@@ -155,6 +156,8 @@ static TrainWs carve_train(void* base, int n) {
     w.folded_node = (float*)take((size_t)FOLD * NS_SIZE * 4);
     w.folded_wgrad = (float*)take((size_t)FOLD * H * PROW * 4);
     w.nk = (float*)take(BX_NK_FLOATS * 4);     // x2h edge backward: the key path of every wave in flight, parked between two phases
+    w.gate_partial = (float*)take((size_t)GATE_GRID * GB_SIZE * 4);
+    w.gate_folded = (float*)take((size_t)FOLD * GB_SIZE * 4);
     w.dE = (float*)take(N * KNN * 2 * H * 4);
     w.rin_cnt = (int*)take(N * 4);
     w.rin_ptr = (int*)take((N + 1) * 4);
@@ -283,7 +286,7 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
 #endif
             HIP_TRY(launch_node_mfma(att, h_in, lig, n, w.P, w.qs, w.Qt, rows, n_rows, nullptr, nullptr, s, x2h));
     }
-    if (x2h) HIP_TRY(launch_fold_grad(att, g_out, n, w.Gt, w.gb, s));
+    if (x2h) HIP_TRY(launch_fold_grad(att, g_out, n, w.Gt, w.gb, s, mfma ? rows : nullptr, mfma ? n_rows : nullptr));      // (a listed block reads listed rows' folds only)
     // Edge rows (CBGX_BX_EDGE_ROWS=1, round 6): a full launch of the one-wave-per-node kernel writes d pre of every edge to the edge's own
     // row of w.dE and launch_edge_rows_reduce gathers the rows of every source node in a fixed order -- no atomics on dP.  Every column
     // of dP then has exactly one writer (PD: the edge kernel's plain stores, PS: the gather, q hidden: the query backward), so only the
@@ -441,6 +444,22 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
         if (gh_src && gh_src != gh) HIP_TRY(hipMemcpyAsync(gh, gh_src, (size_t)n * H * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(launch_sgemm(false, true, w.dP, PROW, att + A_WN, PROW, gh, H, n, H, PROW, 1, 0, 1, s));
     }
+    return CBGX_OK;
+}
+
+// backward of the distance gate: weight gradients from the accumulated dL/de_w, on the workspace's gate slabs (no buffer of a block set)
+static int gate_backward(const float* packed, const float* xs, const int32_t* nbr, const int32_t* deg, int n, TrainWs& w_all,
+                         float* const* grads, hipStream_t s) {
+    TrainWs w = w_all;
+    w.folded = w_all.gate_folded;
+    HIP_TRY(launch_gate_backward_mfma(packed, xs, nbr, deg, n, w.de_w, w.gate_partial, GATE_GRID, s));
+    FOLDED(w.gate_partial, GATE_GRID, GB_SIZE, GB_SIZE);
+    RS(fz + GB_W1, fn, fs, G, GH, G, grads[0], G, 0);
+    RS(fz + GB_B1, fn, fs, GH, 1, GH, grads[1], GH, 0);
+    RS(fz + GB_LNG, fn, fs, GH, 1, GH, grads[2], GH, 0);
+    RS(fz + GB_LNB, fn, fs, GH, 1, GH, grads[3], GH, 0);
+    RS(fz + GB_W2, fn, fs, GH, 1, GH, grads[4], GH, 0);
+    RS(fz + GB_B2, fn, fs, 1, 1, 1, grads[5], 1, 0);
     return CBGX_OK;
 }
 
@@ -773,21 +792,14 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         cur = nxt;
     }
     if (grad_h_in) HIP_TRY(hipMemcpyAsync(grad_h_in, gh_cur, nh * 4, hipMemcpyDeviceToDevice, s));
-    // the auxiliary stream's last weight gradients must be in place when this call's work on `s` is: join both sets (the gate
-    // backward below also reuses the first set's slab buffer)
+    // distance gate (computed once from the input coordinates, used by all 2L blocks): on its own slab buffers, BEFORE the auxiliary
+    // stream is joined -- the last blocks' weight-gradient kernels (~150 us) run beside it instead of ahead of it
+    RC_TRY(gate_backward(packed, tp.xs, tp.nbr, tp.deg, n, w, grads, s));
+    // the auxiliary stream's last weight gradients must be in place when this call's work on `s` is: join both sets
     if (ov.aux)
         for (int k = 0; k < 2; ++k)
             if (ov.used[k]) HIP_TRY(hipStreamWaitEvent(s, ov.aux->done[k], 0));
     ov.joined = true;
-    // distance gate (computed once from the input coordinates, used by all 2L blocks)
-    HIP_TRY(launch_gate_backward_mfma(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.partial, GATE_GRID, s));
-    FOLDED(w.partial, GATE_GRID, GB_SIZE, GB_SIZE);
-    RS(fz + GB_W1, fn, fs, G, GH, G, grads[0], G, 0);
-    RS(fz + GB_B1, fn, fs, GH, 1, GH, grads[1], GH, 0);
-    RS(fz + GB_LNG, fn, fs, GH, 1, GH, grads[2], GH, 0);
-    RS(fz + GB_LNB, fn, fs, GH, 1, GH, grads[3], GH, 0);
-    RS(fz + GB_W2, fn, fs, GH, 1, GH, grads[4], GH, 0);
-    RS(fz + GB_B2, fn, fs, 1, 1, 1, grads[5], 1, 0);
     return CBGX_OK;
 }
 
@@ -884,19 +896,12 @@ int cbgx_h2x_stack_backward(const float* packed, int num_layers, const void* tap
                                         lists ? w.rf_list[0] : nullptr, lists ? w.rf_count : nullptr, &ov));
         cur = nxt;
     }
+    HIP_TRY(hipMemcpyAsync(grad_h, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
+    RC_TRY(gate_backward(packed, tp.xs, tp.nbr, tp.deg, n, w, grads, s));
     if (ov.aux)
         for (int k = 0; k < 2; ++k)
             if (ov.used[k]) HIP_TRY(hipStreamWaitEvent(s, ov.aux->done[k], 0));
     ov.joined = true;
-    HIP_TRY(hipMemcpyAsync(grad_h, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(launch_gate_backward_mfma(packed, tp.xs, tp.nbr, tp.deg, n, w.de_w, w.partial, GATE_GRID, s));
-    FOLDED(w.partial, GATE_GRID, GB_SIZE, GB_SIZE);
-    RS(fz + GB_W1, fn, fs, G, GH, G, grads[0], G, 0);
-    RS(fz + GB_B1, fn, fs, GH, 1, GH, grads[1], GH, 0);
-    RS(fz + GB_LNG, fn, fs, GH, 1, GH, grads[2], GH, 0);
-    RS(fz + GB_LNB, fn, fs, GH, 1, GH, grads[3], GH, 0);
-    RS(fz + GB_W2, fn, fs, GH, 1, GH, grads[4], GH, 0);
-    RS(fz + GB_B2, fn, fs, 1, 1, 1, grads[5], 1, 0);
     return CBGX_OK;
 }
 

@@ -67,7 +67,8 @@ hipError_t launch_edge_rows_reduce(const float* dE, const int* rin_ptr, const in
 // floats of nk_scratch: two slots (key | value path) per wave of the largest grid: the normalised pre-activation of a path, parked by its
 // forward part and read back by the backward sweep in the same labeling (the key path also across two phases of a node)
 constexpr size_t BX_NK_FLOATS = (size_t)256 * 8 * 2 * (KNN * H + 128);
-hipError_t launch_fold_grad(const float* att, const float* Gr, int n_nodes, float* Gt, float* gb, hipStream_t s);
+hipError_t launch_fold_grad(const float* att, const float* Gr, int n_nodes, float* Gt, float* gb, hipStream_t s,
+                            const int* rows = nullptr, const int* n_rows = nullptr);
 hipError_t launch_outer_accum_mfma(bool headed, const float* Lm, const float* R, const int* rows, const int* n_rows,
                                    int n_nodes, float* partial, size_t slab_stride, int grid, hipStream_t s);
 // (`rows` / `n_rows`, wgrad and dgrad: restrict the node dimension to a device-side list -- the rows outside it are known to be zero)

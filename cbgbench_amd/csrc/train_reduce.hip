@@ -23,32 +23,44 @@ __constant__ float c_mu_b[G] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 
 // x2h: fold the output gradient through the second v Linear (the mirror image of the query fold):
 //   Gt[i][a][m] = sum_c G[i][8a+c] Wbv[8a+c][m],   gb[i][a] = sum_c G[i][8a+c] bbv[8a+c]
 // ------------------------------------------------------------------------------------------------
+// LISTED (the pruned last x2h blocks of a backward): only the rows of a device-side list -- the edge kernel reads no other row's fold;
+// a row's result depends on that row alone, so a listed launch writes the bits a full one would
+template <bool LISTED>
 __global__ __launch_bounds__(128) void fold_grad_kernel(const float* __restrict__ att, const float* __restrict__ Gr,
-                                                        int n_nodes, float* __restrict__ Gt, float* __restrict__ gb) {
+                                                        int n_nodes, float* __restrict__ Gt, float* __restrict__ gb,
+                                                        const int* __restrict__ rows, const int* __restrict__ n_rows_ptr) {
     __shared__ float sG[16][H];
+    __shared__ int sRow[16];
+    const int count = LISTED ? *n_rows_ptr : n_nodes;
     const int row0 = blockIdx.x * 16, m = threadIdx.x;
+    if (row0 >= count) return;
+    if (LISTED) {
+        if (m < 16) sRow[m] = row0 + m < count ? rows[row0 + m] : 0;
+        __syncthreads();
+    }
+    auto node = [&](int r) { return LISTED ? sRow[r] : row0 + r; };
     for (int u = m; u < 16 * H; u += 128) {
         const int r = u >> 7;
-        sG[r][u & 127] = row0 + r < n_nodes ? Gr[(size_t)(row0 + r) * H + (u & 127)] : 0.f;
+        sG[r][u & 127] = row0 + r < count ? Gr[(size_t)node(r) * H + (u & 127)] : 0.f;
     }
     __syncthreads();
     for (int a = 0; a < HEADS; ++a) {
         float w[DH];
 #pragma unroll
         for (int cc = 0; cc < DH; ++cc) w[cc] = att[A_WBV + (size_t)m * H + a * DH + cc];   // x2h layout [m][n]
-        for (int r = 0; r < 16 && row0 + r < n_nodes; ++r) {
+        for (int r = 0; r < 16 && row0 + r < count; ++r) {
             float s = 0.f;
 #pragma unroll
             for (int cc = 0; cc < DH; ++cc) s = fmaf(sG[r][a * DH + cc], w[cc], s);
-            Gt[((size_t)(row0 + r) * HEADS + a) * H + m] = s;
+            Gt[((size_t)node(r) * HEADS + a) * H + m] = s;
         }
     }
     if (m < HEADS) {
-        for (int r = 0; r < 16 && row0 + r < n_nodes; ++r) {
+        for (int r = 0; r < 16 && row0 + r < count; ++r) {
             float s = 0.f;
 #pragma unroll
             for (int cc = 0; cc < DH; ++cc) s = fmaf(sG[r][m * DH + cc], att[A_BBV + m * DH + cc], s);
-            gb[(size_t)(row0 + r) * HEADS + m] = s;
+            gb[(size_t)node(r) * HEADS + m] = s;
         }
     }
 }
@@ -487,8 +499,10 @@ __global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restr
     } while (0)
 
 
-hipError_t launch_fold_grad(const float* att, const float* Gr, int n_nodes, float* Gt, float* gb, hipStream_t s) {
-    hipLaunchKernelGGL(fold_grad_kernel, dim3((n_nodes + 15) / 16), dim3(128), 0, s, att, Gr, n_nodes, Gt, gb);
+hipError_t launch_fold_grad(const float* att, const float* Gr, int n_nodes, float* Gt, float* gb, hipStream_t s, const int* rows,
+                            const int* n_rows) {
+    if (rows) hipLaunchKernelGGL(fold_grad_kernel<true>, dim3((n_nodes + 15) / 16), dim3(128), 0, s, att, Gr, n_nodes, Gt, gb, rows, n_rows);
+    else hipLaunchKernelGGL(fold_grad_kernel<false>, dim3((n_nodes + 15) / 16), dim3(128), 0, s, att, Gr, n_nodes, Gt, gb, rows, n_rows);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }
