@@ -942,6 +942,24 @@ int cbgx_targetdiff_loss(const float* x_out, const float* logits, const int64_t*
     return CBGX_OK;
 }
 
+int cbgx_diffbp_loss(const float* x_out, const float* x_in, const float* x_stack, const float* logits, const int64_t* sort_idx,
+                     const int32_t* graph_ptr, const uint8_t* lig_flag, const float* pos_noise, const float* com_noise,
+                     const int64_t* v0, const uint8_t* type_flag, const uint8_t* gen, const int64_t* t, int n_protein, int n_lig,
+                     int n_graphs, int num_classes, const float* alphas_cumprod, const float* betas, float rho, float gamma,
+                     float* losses, float* scal, float* gstats, float* a_pos, float* a_int, float* b_com, float* b_int, float* z_atom,
+                     int32_t* bad, void* stream) {
+    if (n_lig <= 0 || n_graphs <= 0 || n_protein < 0 || num_classes < 1 || num_classes > 32)
+        return set_error(CBGX_E_INVALID, "diffbp_loss: bad sizes (n_lig=%d B=%d C=%d)", n_lig, n_graphs, num_classes);
+    if (!x_out || !x_in || !x_stack || !logits || !sort_idx || !graph_ptr || !lig_flag || !pos_noise || !com_noise || !v0 || !type_flag ||
+        !gen || !t || !alphas_cumprod || !betas || !losses || !scal || !gstats || !a_pos || !a_int || !b_com || !b_int || !z_atom || !bad)
+        return set_error(CBGX_E_INVALID, "diffbp_loss: NULL pointer");
+    HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int32_t), (hipStream_t)stream));
+    HIP_TRY(launch_diffbp_loss(x_out, x_in, x_stack, logits, sort_idx, graph_ptr, lig_flag, pos_noise, com_noise, v0, type_flag, gen, t,
+                               n_protein, n_lig, n_graphs, num_classes, alphas_cumprod, betas, rho, gamma, gstats, losses, scal, a_pos,
+                               a_int, b_com, b_int, z_atom, bad, (hipStream_t)stream));
+    return CBGX_OK;
+}
+
 int cbgx_targetdiff_loss_backward(const float* grad_pos, const float* grad_logit, const int64_t* sort_idx, int n_protein,
                                   int n_nodes, int num_classes, const float* g_loss_pos, const float* g_loss_atom,
                                   float* grad_x_out, float* grad_logits, void* stream) {

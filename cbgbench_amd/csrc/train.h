@@ -128,6 +128,13 @@ hipError_t launch_train_loss(const float* x_out, const float* logits, const int6
                              float* c_pred, float* gpos, float* gz, hipStream_t s);
 hipError_t launch_train_loss_bwd(const float* gpos, const float* gz, const int64_t* sort_idx, int n_rec, int n_nodes, int C,
                                  const float* g_pos, const float* g_typ, float* grad_x, float* grad_logits, hipStream_t s);
+// train_loss_diffbp.hip: DiffBP's four losses and their gradients with respect to the network outputs (composed row order)
+hipError_t launch_diffbp_loss(const float* x_out, const float* x_in, const float* x_stack, const float* logits, const int64_t* sort_idx,
+                              const int32_t* graph_ptr, const uint8_t* lig, const float* pos_noise, const float* com_noise,
+                              const int64_t* v0, const uint8_t* type_flag, const uint8_t* gen, const int64_t* t, int n_rec, int n_lig,
+                              int B, int C, const float* acp, const float* betas, float rho, float gamma, float* gstats, float* losses,
+                              float* scal, float* a_pos, float* a_int, float* b_com, float* b_int, float* z_atom, int* bad,
+                              hipStream_t s);
 hipError_t launch_ssp_backward_rows(const float* pre, const float* dact, const int* rows, const int* n_rows, int max_rows,
                                     float* dpre, hipStream_t s);
 hipError_t launch_cls_w1_grad_rows(const float* dlogits, int C, const float* act, const int* rows, const int* n_rows, float* dW1,

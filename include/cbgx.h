@@ -56,7 +56,7 @@ extern "C" {
  * 4 (round 5): cbgx_unitransformer_backward with grad_h_out == NULL also prunes the classifier head's backward to the ligand rows
  * (round 4 changed that without a bump), the cbgx_targetdiff_train_noise / _loss / _loss_backward exports exist, and the workspace
  * layout of cbgx_unitransformer_forward changed: a caller built against version 3 must not load this library. */
-#define CBGX_ABI_VERSION 4
+#define CBGX_ABI_VERSION 5
 
 #define CBGX_OK 0
 #define CBGX_E_INVALID (-1)   /* bad argument (shape, NULL pointer, unsupported hyper-parameter) */
@@ -366,6 +366,25 @@ int cbgx_targetdiff_loss(const float *x_out, const float *logits, const int64_t 
 int cbgx_targetdiff_loss_backward(const float *grad_pos, const float *grad_logit, const int64_t *sort_idx, int n_protein,
                                   int n_nodes, int num_classes, const float *g_loss_pos, const float *g_loss_atom,
                                   float *grad_x_out, float *grad_logits, void *stream);
+/* cbgx_diffbp_loss (ABI 5): DiffBP's four training losses around its two network calls -- zero-COM noise prediction + centre-of-mass
+ *   prediction (CoMPredictor.forward, diffbp.py:79-101), get_score_loss x 2 (diffusion_scheduler.py:203-218), MaskTypeSchedule.get_loss
+ *   (:499-511: cross_entropy of the softmax OUTPUT, as the reference has it), xs_mean (:166-183) and interior_loss (diffbp.py:18-28)
+ *   -- in two launches, with their gradients with respect to the network outputs.  All [N,.] arrays are in the COMPOSED row order
+ *   (per graph: protein rows, then ligand rows; graph_ptr [B+1]; sort_idx [N] as above; lig_flag [N]); x_in = the composed input
+ *   positions (protein positions and x_t), x_stack = the centre-of-mass head's output positions.  pos_noise / com_noise [n_lig,3],
+ *   v0, type_flag (the mask of the type loss), gen [n_lig] in LIGAND order; t [B].  Ligands of at most 48 atoms (beyond that the
+ *   reference restricts every protein atom to its 48 nearest ligand atoms: *bad is set to 1 and the host must take its tensor path).
+ *   losses [4] = {pos, atom, com, inter}; scal [2] = {1 / D_gen, 1 / D_type}, the graph-count divisors of the masked means;
+ *   gstats [8 n_graphs] scratch.  Gradient pieces, [N,3] / [N,C], zero on protein rows, to be combined by the caller with the
+ *   upstream gradients g_* of the four losses:
+ *     d L / d x_out   = g_pos scal[0] a_pos + g_inter a_int        d L / d x_stack = g_com scal[0] b_com + g_inter b_int
+ *     d L / d logits  = g_atom scal[1] z_atom */
+int cbgx_diffbp_loss(const float *x_out, const float *x_in, const float *x_stack, const float *logits, const int64_t *sort_idx,
+                     const int32_t *graph_ptr, const uint8_t *lig_flag, const float *pos_noise, const float *com_noise,
+                     const int64_t *v0, const uint8_t *type_flag, const uint8_t *gen, const int64_t *t, int n_protein, int n_lig,
+                     int n_graphs, int num_classes, const float *alphas_cumprod, const float *betas, float rho, float gamma,
+                     float *losses, float *scal, float *gstats, float *a_pos, float *a_int, float *b_com, float *b_int,
+                     float *z_atom, int32_t *bad, void *stream);
 
 /* ---- measurement hook (bench.py) ----------------------------------------------------------------
  * Between cbgx_profile_begin() and cbgx_profile_end() every kernel launch is bracketed by HIP events on
@@ -373,8 +392,9 @@ int cbgx_targetdiff_loss_backward(const float *grad_pos, const float *grad_logit
  * device time in ms and the launch count.  Classes: 0 knn, 1 gate, 2 node GEMM, 3 node query fold,
  * 4 x2h edge kernel over all nodes, 5 h2x edge kernel (node list), 6 x2h edge kernel over a node list (pruned last
  * layers), 7 x2h edge backward over all nodes, 8 h2x edge backward, 9 training GEMMs, 10 x2h edge backward over a node list
- * (CBGX_PROFILE_CLASSES = 11).  Not thread-safe with concurrent launches from other threads; process-wide. */
-#define CBGX_PROFILE_CLASSES 11
+ * 11 the ordered gather of the x2h backward's edge-row mode (CBGX_PROFILE_CLASSES = 12).  Not thread-safe with concurrent launches
+ * from other threads; process-wide. */
+#define CBGX_PROFILE_CLASSES 12
 int cbgx_profile_begin(int max_launches);
 int cbgx_profile_end(double *ms_by_class, int *launches_by_class, int num_classes);
 

@@ -471,6 +471,42 @@ def test_diffbp_training_step_matches_reference_gradients(golden_dir):
     check_golden_gradients(m, g, 8 + 6 + 9 * 36 + 4 + (6 + 3 * 18), oracle_run)
 
 
+def test_diffbp_fused_losses_match_the_tensor_path(golden_dir):
+    """Round 6: DiffBP's arithmetic between the two network calls and its four losses as two launches (cbgx_diffbp_loss,
+    csrc/train_loss_diffbp.hip; taken when the collate records `max_ligand_atoms` <= 48) against the tensor path that the golden
+    test above pins to the reference: the four losses, and every parameter gradient of the summed loss."""
+    from oracle import weights as W
+    g = load(golden_dir, "train_loss_diffbp")
+    sd = W.synthetic_state_dict_diffbp(13, 9, seed=0, num_timesteps=1000)
+    out = {}
+    for fused in (False, True):
+        m = C.get_model(C.default_diffbp_config(13))
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV).train()
+        m.fused_training_ops = fused
+        batch = golden_batch(g, DEV)
+        batch["max_ligand_atoms"] = int(torch.bincount(batch["ligand_element_batch"]).max())
+        assert batch["max_ligand_atoms"] <= 48
+        ld, res = m(batch, t=g["t"].to(DEV), noise=(g["eps"].to(DEV), g["u"].to(DEV)))
+        assert ("fused_bad" in res) == fused
+        if fused:
+            assert int(res["fused_bad"]) == 0
+        (1.0 * ld["pos"] + 0.7 * ld["atom"] + 1.3 * ld["com"] + 0.9 * ld["inter"]).backward()
+        torch.cuda.synchronize()
+        out[fused] = ({k: float(v.detach()) for k, v in ld.items()},
+                      {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    for k in ("pos", "atom", "com", "inter"):
+        assert abs(out[True][0][k] - out[False][0][k]) <= 2e-5 * abs(out[False][0][k]) + 1e-7, (k, out[True][0][k], out[False][0][k])
+        assert abs(out[True][0][k] - g["loss_" + k]) <= 2e-4 * abs(g["loss_" + k]) + 1e-6
+    assert out[True][1].keys() == out[False][1].keys() and len(out[True][1]) > 390
+    for k, ref in out[False][1].items():
+        rn = float(ref.norm())
+        if rn < 1e-7:
+            continue
+        d = float((out[True][1][k] - ref).norm()) / rn
+        assert d <= 2e-4, (k, d)
+
+
 @pytest.mark.parametrize("case", ["train_loss_diffsbdd", "train_loss_diffsbdd_t0"])
 def test_diffsbdd_training_step_matches_reference_gradients(golden_dir, case):
     """DiffSBDD: variational training loss around the shared denoiser (diffsbdd.py:91-195) against the reference's losses and
