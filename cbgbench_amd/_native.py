@@ -53,6 +53,8 @@ EXPORTS = {
     "cbgx_train_workspace_bytes": (_sz, [_i]),
     "cbgx_unitransformer_forward_train": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz,
                                                _vp, _sz, _vp]),
+    "cbgx_unitransformer_forward_train_ex": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, ctypes.c_uint, _vp, _sz,
+                                                  _vp, _sz, _vp]),
     "cbgx_unitransformer_backward": (_i, [_vp, _i, _i, _vp, _sz, _vp, _vp, _i, _vp, _vp, _vp, ctypes.POINTER(_vp), _i,
                                           _vp, _vp, _sz, _vp]),
     "cbgx_x2h_attention_backward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,

@@ -449,10 +449,10 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
 
 // backward of the distance gate: weight gradients from the accumulated dL/de_w, on the workspace's gate slabs (no buffer of a block set)
 static int gate_backward(const float* packed, const float* xs, const int32_t* nbr, const int32_t* deg, int n, TrainWs& w_all,
-                         float* const* grads, hipStream_t s) {
+                         float* const* grads, hipStream_t s, const int* rows = nullptr, const int* n_rows = nullptr) {
     TrainWs w = w_all;
     w.folded = w_all.gate_folded;
-    HIP_TRY(launch_gate_backward_mfma(packed, xs, nbr, deg, n, w.de_w, w.gate_partial, GATE_GRID, s));
+    HIP_TRY(launch_gate_backward_mfma(packed, xs, nbr, deg, n, w.de_w, w.gate_partial, GATE_GRID, s, rows, n_rows));
     FOLDED(w.gate_partial, GATE_GRID, GB_SIZE, GB_SIZE);
     RS(fz + GB_W1, fn, fs, G, GH, G, grads[0], G, 0);
     RS(fz + GB_B1, fn, fs, GH, 1, GH, grads[1], GH, 0);
@@ -487,6 +487,16 @@ int cbgx_unitransformer_forward_train(const float* packed, int num_layers, int n
                                       const uint8_t* gen_flag, int n_nodes, int n_graphs, float* x_out, float* h_out,
                                       float* logits, void* tape, size_t tape_bytes, void* workspace,
                                       size_t workspace_bytes, void* stream) {
+    return cbgx_unitransformer_forward_train_ex(packed, num_layers, num_classes, x, h, graph_ptr, lig_flag, gen_flag, n_nodes, n_graphs,
+                                                x_out, h_out, logits, 0u, tape, tape_bytes, workspace, workspace_bytes, stream);
+}
+
+int cbgx_unitransformer_forward_train_ex(const float* packed, int num_layers, int num_classes, const float* x,
+                                         const float* h, const int32_t* graph_ptr, const uint8_t* lig_flag,
+                                         const uint8_t* gen_flag, int n_nodes, int n_graphs, float* x_out, float* h_out,
+                                         float* logits, unsigned flags, void* tape, size_t tape_bytes, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    if (flags & ~CBGX_FWD_H_ON_SOURCES) return set_error(CBGX_E_INVALID, "forward_train: unknown flags 0x%x", flags);
     if (n_nodes < 0 || n_graphs < 0 || num_layers < 1) return set_error(CBGX_E_INVALID, "forward_train: bad sizes");
     if (n_nodes == 0) return CBGX_OK;
     if (!packed || !x || !h || !graph_ptr || !lig_flag || !gen_flag || !x_out || !tape || !workspace)
@@ -519,7 +529,10 @@ int cbgx_unitransformer_forward_train(const float* packed, int num_layers, int n
     // x_out and the logits of ligand rows, so the last x2h block only has to produce h' on A1 = gen | lig | nbr(gen), the one before it
     // on A2 = A1 | nbr(A1) (its sources: A3 = A2 | nbr(A2)); h2x blocks need the neighbour projection on nbr(gen) only (subset of A1).
     // Rows outside those sets are zero on the tape (the pruned backward's dense products over h walk all rows with zero weights).
-    const bool fprune = !h_out && num_layers >= 3 && g_edge_impl != 1 && env_on("CBGX_TRAIN_FWD_PRUNE");
+    // (CBGX_FWD_H_ON_SOURCES: h_out is wanted, but on A1 only -- DiffBP's centre-of-mass head reads it on the movable atoms and their
+    // neighbours; the backward then prunes around the support of its dL/dh_out, which lies inside A1, unless CBGX_TRAIN_PRUNE_GH=0)
+    const bool fprune = (!h_out || ((flags & CBGX_FWD_H_ON_SOURCES) && env_on("CBGX_TRAIN_PRUNE_GH"))) && num_layers >= 3 &&
+                        g_edge_impl != 1 && env_on("CBGX_TRAIN_FWD_PRUNE") && (!h_out || !logits || num_classes <= 128);
     const int* A[3] = {w.rf_list[0], w.rf_list[1], w.lig_list};
     const int* An[3] = {w.rf_count, w.rf_count + 16, w.rf_count + 32};
     if (fprune) {
@@ -897,7 +910,8 @@ int cbgx_h2x_stack_backward(const float* packed, int num_layers, const void* tap
         cur = nxt;
     }
     HIP_TRY(hipMemcpyAsync(grad_h, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));
-    RC_TRY(gate_backward(packed, tp.xs, tp.nbr, tp.deg, n, w, grads, s));
+    // (the stack's blocks add to de_w on the movable rows only: the gate backward walks that list -- 16.5 k rows -> ~900)
+    RC_TRY(gate_backward(packed, tp.xs, tp.nbr, tp.deg, n, w, grads, s, lists ? w.act : nullptr, lists ? w.act_count : nullptr));
     if (ov.aux)
         for (int k = 0; k < 2; ++k)
             if (ov.used[k]) HIP_TRY(hipStreamWaitEvent(s, ov.aux->done[k], 0));

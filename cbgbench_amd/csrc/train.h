@@ -116,7 +116,8 @@ hipError_t launch_reduce_store(const float* src, int n_slabs, size_t slab_stride
 hipError_t launch_sgemm(bool ta, bool tb, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
                         int N, int K, int splits, size_t c_split_stride, int accumulate, hipStream_t s);
 hipError_t launch_gate_backward_mfma(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
-                                     const float* de_w, float* partial, int grid, hipStream_t s);
+                                     const float* de_w, float* partial, int grid, hipStream_t s, const int* rows = nullptr,
+                                     const int* n_rows = nullptr);
 hipError_t launch_ssp_backward(const float* pre, const float* dact, long n, float* dpre, hipStream_t s);
 // train_loss.hip: TargetDiff's forward noising, its two losses with their gradients, and the scatter of those gradients
 hipError_t launch_train_noise(const float* x0, const int64_t* v0, const int64_t* t, const int64_t* batch, const uint8_t* gen,

@@ -276,7 +276,9 @@ constexpr int GATE_WAVES = 4;
 __global__ __launch_bounds__(GATE_WAVES * 64) void gate_bwd_mfma_kernel(const float* __restrict__ wts, const float* __restrict__ x,
                                                                       const int32_t* __restrict__ nbr,
                                                                       const int32_t* __restrict__ deg, int n_nodes,
-                                                                      const float* __restrict__ de_w, float* __restrict__ partial) {
+                                                                      const float* __restrict__ de_w, float* __restrict__ partial,
+                                                                      const int* __restrict__ rows, const int* __restrict__ n_rows_ptr) {
+    // `rows` (optional): the nodes whose edges can carry a gate gradient (an h2x stack adds to de_w on its movable rows only)
     typedef float floatx4 __attribute__((ext_vector_type(4)));
     constexpr int NT = GH / 16;      // 10 unit tiles
     constexpr int KS = G / 4;        // 5 k-steps of the first product
@@ -302,13 +304,13 @@ __global__ __launch_bounds__(GATE_WAVES * 64) void gate_bwd_mfma_kernel(const fl
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { aB1[nt] = 0.f; aG[nt] = 0.f; aBe[nt] = 0.f; aW2[nt] = 0.f; }
     float aB2 = 0.f;
-    const long n_tiles = (long)n_nodes * (KNN / 16);
+    const long n_tiles = (long)(rows ? *n_rows_ptr : n_nodes) * (KNN / 16);
     const long stride = (long)gridDim.x * GATE_WAVES;
     long tile = (long)blockIdx.x * GATE_WAVES + wave;
     // geometry of a tile: lane (j, *) <-> edge slot 16 (tile & 1) + j of node tile >> 1; fetched one tile ahead
     float dist_n = 0.f, dew_n = 0.f;
     auto fetch = [&](long tl) {
-        const int i = (int)(tl >> 1), sl = 16 * (int)(tl & 1) + j;
+        const int i = rows ? rows[tl >> 1] : (int)(tl >> 1), sl = 16 * (int)(tl & 1) + j;
         const bool valid = sl < deg[i];
         const int nb = valid ? nbr[(size_t)i * KNN + sl] : i;
         const float dx = x[3 * i] - x[3 * nb], dy = x[3 * i + 1] - x[3 * nb + 1], dz = x[3 * i + 2] - x[3 * nb + 2];
@@ -576,9 +578,9 @@ hipError_t launch_sgemm(bool ta, bool tb, const float* A, int lda, const float* 
 
 // product path: one fused kernel; `grid` slabs of GB_SIZE floats in `partial`, every one written (grid a multiple of GATE_WAVES)
 hipError_t launch_gate_backward_mfma(const float* packed, const float* x, const int32_t* nbr, const int32_t* deg, int n_nodes,
-                                     const float* de_w, float* partial, int grid, hipStream_t s) {
+                                     const float* de_w, float* partial, int grid, hipStream_t s, const int* rows, const int* n_rows) {
     hipLaunchKernelGGL(gate_bwd_mfma_kernel, dim3(grid / GATE_WAVES), dim3(GATE_WAVES * 64), 0, s, packed, x, nbr, deg, n_nodes,
-                       de_w, partial);
+                       de_w, partial, rows, n_rows);
     CBGX_LAUNCH_CHECK();
     return hipSuccess;
 }

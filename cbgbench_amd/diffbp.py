@@ -383,8 +383,10 @@ class DiffBP(BatchesInFlight, nn.Module):
         x = torch.cat([x_rec, x_t], 0)[sort_idx]
         h = torch.cat([h_rec, h_lig], 0)[sort_idx]
         gen_flag = torch.cat([gen_r, gen_l], 0)[sort_idx]
+        # (h' is read by the centre-of-mass head only, on the movable atoms and their neighbours in the SAME k-nearest-neighbour graph
+        # -- both networks build it from x -- so the denoiser may prune its last blocks to that receptive field, forward and backward)
         xo, ho, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
-                                       graph_ptr=graph_ptr)
+                                       graph_ptr=graph_ptr, h_on_sources=True)
         # Round 6: the arithmetic between the two network calls and the four losses in two launches (csrc/train_loss_diffbp.hip) when the
         # batch is in the shape the kernel takes: training on the GPU, the largest ligand known to the host (`max_ligand_atoms`, which
         # the collate records) and at most 48 atoms -- beyond that interior_loss restricts every protein atom to its 48 nearest ligand

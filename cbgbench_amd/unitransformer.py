@@ -93,6 +93,9 @@ class _DenoiserFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, ligand_outputs_only, x, h, graph_ptr, lig, gen, *params):
+        # ligand_outputs_only: False / True / "h_on_sources" (h' is read on gen | lig | in-neighbours of gen rows only)
+        h_on_sources = ligand_outputs_only == "h_on_sources"
+        ligand_outputs_only = ligand_outputs_only is True
         device = x.device
         N, B = x.shape[0], graph_ptr.numel() - 1
         L, C = module.num_layers, module.out_classes
@@ -106,11 +109,11 @@ class _DenoiserFunction(torch.autograd.Function):
         x_out = torch.empty_like(x)
         h_out = None if ligand_outputs_only else torch.empty_like(h)
         logits = torch.empty(N, C, dtype=torch.float32, device=device)
-        rc = lib.cbgx_unitransformer_forward_train(
+        rc = lib.cbgx_unitransformer_forward_train_ex(
             _native.ptr(packed), L, C, _native.ptr(x), _native.ptr(h), _native.ptr(graph_ptr), _native.ptr(lig),
-            _native.ptr(gen), N, B, _native.ptr(x_out), _native.ptr(h_out), _native.ptr(logits), _native.ptr(tape),
-            tape.numel(), _native.ptr(ws), ws.numel(), _native.current_stream(device))
-        _native.check(rc, "cbgx_unitransformer_forward_train")
+            _native.ptr(gen), N, B, _native.ptr(x_out), _native.ptr(h_out), _native.ptr(logits), 1 if h_on_sources else 0,
+            _native.ptr(tape), tape.numel(), _native.ptr(ws), ws.numel(), _native.current_stream(device))
+        _native.check(rc, "cbgx_unitransformer_forward_train_ex")
         if h_out is None:
             h_out = torch.empty(0, h.shape[1], dtype=torch.float32, device=device)
         ctx.module, ctx.tape, ctx.packed, ctx.flags, ctx.n = module, tape, packed, (lig, gen), N
@@ -411,7 +414,8 @@ class UniTransformer(nn.Module):
         lig, gen = self._as_u8(lig_flag), self._as_u8(gen_flag)
         if torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.parameters())):
             # training: taped forward + hand-written backward behind torch.autograd
-            return _DenoiserFunction.apply(self, ligand_outputs_only, x.detach().to(torch.float32).contiguous(),
+            return _DenoiserFunction.apply(self, "h_on_sources" if (h_on_sources and not ligand_outputs_only) else bool(ligand_outputs_only),
+                                           x.detach().to(torch.float32).contiguous(),
                                            h.to(torch.float32).contiguous(), graph_ptr, lig, gen,
                                            *self._ordered_params())
         x = x.detach().to(torch.float32).contiguous()

@@ -297,6 +297,10 @@ int cbgx_diffsbdd_step(const float *x_den, const float *logits, const int32_t *g
  * 32 KB per node) selects the edge-row mode of the x2h blocks instead: every edge's contribution goes to its own row and the rows of
  * every source node are summed in a fixed order (csrc/train_scatter.hip) -- dL/dh then has the same bits in every run, the
  * coordinate gradient still uses atomics, and a training step is 1 - 3 % slower.  Same mathematics, same tolerances in the tests. */
+/* cbgx_unitransformer_forward_train_ex (ABI 5): the same with `flags`; CBGX_FWD_H_ON_SOURCES = h_out is wanted on
+ * A1 = gen_flag | lig_flag | in-neighbours of gen_flag rows only (zero elsewhere) -- the taped forward prunes as with h_out == NULL,
+ * and the caller's dL/dh_out must vanish outside A1 (DiffBP: the centre-of-mass head reads h_out on the movable atoms and their
+ * neighbours in the same k-nearest-neighbour graph). */
 size_t cbgx_train_tape_bytes(int n_nodes, int num_layers);
 size_t cbgx_train_workspace_bytes(int n_nodes);
 int cbgx_unitransformer_forward_train(const float *packed, int num_layers, int num_classes,
@@ -313,6 +317,10 @@ int cbgx_unitransformer_backward(const float *packed, int num_layers, int num_cl
  * pointers {hk,hv,hq}_func (x2h) / {xk,xv,xq}_func (h2x) x net.{0.weight,0.bias,1.weight,1.bias,3.weight,3.bias}.
  * x2h: grad_h includes the residual path.  h2x: grad_x includes the identity path of x_out = x + delta_x * gen_flag.
  * grad_e_w [N,32] is the gradient with respect to the gate values. */
+int cbgx_unitransformer_forward_train_ex(const float *packed, int num_layers, int num_classes, const float *x, const float *h,
+                                         const int32_t *graph_ptr, const uint8_t *lig_flag, const uint8_t *gen_flag,
+                                         int n_nodes, int n_graphs, float *x_out, float *h_out, float *logits, unsigned flags,
+                                         void *tape, size_t tape_bytes, void *workspace, size_t workspace_bytes, void *stream);
 int cbgx_x2h_attention_backward(const float *packed, int layer, const float *x, const float *h,
                                 const int32_t *nbr, const int32_t *deg, const uint8_t *lig_flag, const float *e_w,
                                 int n_nodes, const float *grad_h_out, float *grad_h, float *grad_x, float *grad_e_w,
