@@ -852,13 +852,27 @@ int cbgx_h2x_stack_forward_train(const float* packed, int num_layers, const floa
     hipStream_t s = (hipStream_t)stream;
     const size_t nx = (size_t)n_nodes * 3;
     HIP_TRY(hipMemcpyAsync(tp.xs, x, nx * 4, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, tp.nbr, tp.deg, s));
-    HIP_TRY(launch_gate(packed, x, tp.nbr, tp.deg, n_nodes, tp.e_w, s));
     HIP_TRY(launch_build_active(gen_flag, n_nodes, w.act, w.act_count, s));
+    // As cbgx_h2x_stack_forward (api.hip): an h2x block only reads the neighbour lists and gate values of the rows it moves and the
+    // projections of their in-neighbours, so the kNN search, the gate MLP and the neighbour projection run on those lists (round 6;
+    // the backward walks the same lists -- CBGX_TRAIN_STACK_LISTS=0 switches both back to all rows)
+    const bool lists = g_edge_impl == 0 && env_on("CBGX_TRAIN_STACK_LISTS");
+    const int *src = nullptr, *src_n = nullptr;
+    if (lists) {
+        HIP_TRY(launch_knn_reg(x, graph_ptr, n_graphs, n_nodes, tp.nbr, tp.deg, s, w.act, w.act_count));
+        HIP_TRY(launch_gate_mfma(packed, x, tp.nbr, tp.deg, n_nodes, tp.e_w, s, w.act, w.act_count));
+        HIP_TRY(launch_mark_seed(gen_flag, gen_flag, n_nodes, w.mask, s));
+        HIP_TRY(launch_mark_nbr(w.act, w.act_count, n_nodes, tp.nbr, tp.deg, w.mask, s));
+        HIP_TRY(launch_build_active(w.mask, n_nodes, w.rf_list[0], w.rf_count, s));
+        src = w.rf_list[0]; src_n = w.rf_count;
+    } else {
+        HIP_TRY(launch_knn(x, graph_ptr, n_graphs, n_nodes, tp.nbr, tp.deg, s));
+        HIP_TRY(launch_gate(packed, x, tp.nbr, tp.deg, n_nodes, tp.e_w, s));
+    }
     for (int l = 0; l < num_layers; ++l)
         HIP_TRY(launch_attention(false, packed + GATE_SIZE + (size_t)l * ATT_SIZE, tp.xs + (size_t)l * nx, h, tp.nbr, tp.deg,
                                  lig_flag, gen_flag, tp.e_w, n_nodes, w.P, w.Qt, w.qs, tp.xs + (size_t)(l + 1) * nx, nullptr,
-                                 w.act, w.act_count, nullptr, nullptr, s));
+                                 w.act, w.act_count, src, src_n, s));
     HIP_TRY(hipMemcpyAsync(x_out, tp.xs + (size_t)num_layers * nx, nx * 4, hipMemcpyDeviceToDevice, s));
     return CBGX_OK;
 }
