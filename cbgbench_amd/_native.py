@@ -13,7 +13,7 @@ _LIB = None
 _XLIB = None
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
-ABI_VERSION = 5      # include/cbgx.h CBGX_ABI_VERSION: bumped whenever the packed-weight layout or an entry point changes
+ABI_VERSION = 6      # include/cbgx.h CBGX_ABI_VERSION: bumped whenever the packed-weight layout or an entry point changes
 
 EXPORTS = {
     "cbgx_abi_version": (_i, []),
@@ -48,6 +48,8 @@ EXPORTS = {
     "cbgx_targetdiff_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(_vp), _vp, _vp, _vp,
                                   _vp, _vp, _vp]),
     "cbgx_targetdiff_loss_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "cbgx_embed_compose": (_i, [_vp] * 8 + [_i] * 5 + [ctypes.POINTER(_vp)] + [_vp] * 5),
+    "cbgx_embed_compose_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "cbgx_diffbp_loss": (_i, [_vp] * 13 + [_i, _i, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float] + [_vp] * 9 + [_vp]),
     "cbgx_train_tape_bytes": (_sz, [_i, _i]),
     "cbgx_train_workspace_bytes": (_sz, [_i]),

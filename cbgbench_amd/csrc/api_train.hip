@@ -988,6 +988,41 @@ int cbgx_diffbp_loss(const float* x_out, const float* x_in, const float* x_stack
     return CBGX_OK;
 }
 
+int cbgx_embed_compose(const float* x_protein, const float* x_ligand, const float* protein_feat, const int64_t* protein_aa,
+                       const float* ligand_feat, const int64_t* sort_idx, const uint8_t* gen_protein, const uint8_t* gen_ligand,
+                       int n_protein, int n_ligand, int feat_dim, int num_aa, int lig_dim, const float* const* params, float* x, float* h,
+                       float* ext, uint8_t* gen_flag, void* stream) {
+    if (n_protein < 0 || n_ligand < 0 || feat_dim < 1 || num_aa < 1 || lig_dim < 1 || feat_dim + num_aa + lig_dim + 2 > EMB_MAX_J)
+        return set_error(CBGX_E_INVALID, "embed_compose: bad sizes (N_protein=%d N_ligand=%d F=%d A=%d C=%d; F + A + C + 2 <= %d)",
+                         n_protein, n_ligand, feat_dim, num_aa, lig_dim, EMB_MAX_J);
+    if (n_protein + n_ligand == 0) return CBGX_OK;
+    if (!params || !sort_idx || !x || !h || !ext || (n_protein && (!x_protein || !protein_feat || !protein_aa)) ||
+        (n_ligand && (!x_ligand || !ligand_feat)) || (gen_flag && n_ligand && !gen_ligand))
+        return set_error(CBGX_E_INVALID, "embed_compose: NULL pointer");
+    for (int i = 0; i < 8; ++i)
+        if (!params[i]) return set_error(CBGX_E_INVALID, "embed_compose: parameter %d is NULL", i);
+    const EmbedParams p{params[0], params[1], params[2], params[3], params[4], params[5], params[6], params[7]};
+    HIP_TRY(launch_embed_compose(x_protein, x_ligand, protein_feat, protein_aa, ligand_feat, sort_idx, gen_protein, gen_ligand, n_protein,
+                                 n_ligand, feat_dim, num_aa, lig_dim, p, x, h, ext, gen_flag, (hipStream_t)stream));
+    return CBGX_OK;
+}
+
+int cbgx_embed_compose_backward(const float* grad_h, const float* ext, int n_nodes, int feat_dim, int num_aa, int lig_dim, float* partial,
+                                int groups, float* grad_out, void* stream) {
+    if (n_nodes < 0 || feat_dim < 1 || num_aa < 1 || lig_dim < 1 || feat_dim + num_aa + lig_dim + 2 > EMB_MAX_J || groups < 1 ||
+        groups > 256)
+        return set_error(CBGX_E_INVALID, "embed_compose_backward: bad sizes (N=%d F=%d A=%d C=%d groups=%d)", n_nodes, feat_dim, num_aa,
+                         lig_dim, groups);
+    if (!grad_out || (n_nodes && (!grad_h || !ext || !partial))) return set_error(CBGX_E_INVALID, "embed_compose_backward: NULL pointer");
+    if (n_nodes == 0) {
+        HIP_TRY(hipMemsetAsync(grad_out, 0, sizeof(float) * H * (feat_dim + num_aa + lig_dim + 2), (hipStream_t)stream));
+        return CBGX_OK;
+    }
+    HIP_TRY(launch_embed_compose_backward(grad_h, ext, n_nodes, feat_dim, num_aa, lig_dim, partial, groups, grad_out,
+                                          (hipStream_t)stream));
+    return CBGX_OK;
+}
+
 int cbgx_targetdiff_loss_backward(const float* grad_pos, const float* grad_logit, const int64_t* sort_idx, int n_protein,
                                   int n_nodes, int num_classes, const float* g_loss_pos, const float* g_loss_atom,
                                   float* grad_x_out, float* grad_logits, void* stream) {

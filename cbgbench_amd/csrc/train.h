@@ -91,6 +91,15 @@ hipError_t launch_q_backward(const float* att, const float* P, const float* T, c
 hipError_t launch_outer_accum(bool headed, const float* Lm, const float* R, const int* rows, const int* n_rows,
                               int n_nodes, float* partial, size_t slab_stride, int grid, hipStream_t s);
 #endif
+// train_embed.hip: PLContextEmbedder + compose_context of a training step in one launch; its weight gradients through wgrad_mfma
+constexpr int EMB_LD = 128;            // columns of the extended input rows (feat | onehot aa | 1 | c | 1 | zeros)
+constexpr int EMB_MAX_J = 120;         // F + A + C + 2: the stacked weights (J x 128 floats) + four rows fit 64 KB of LDS
+struct EmbedParams { const float *w_pa, *b_pa, *w_res, *b_res, *w_la, *b_la, *w_ind, *b_ind; };
+hipError_t launch_embed_compose(const float* x_rec, const float* x_lig, const float* feat, const int64_t* aa, const float* c_lig,
+                                const int64_t* sort_idx, const uint8_t* gen_rec, const uint8_t* gen_lig, int n_rec, int n_lig, int F,
+                                int A, int C, const EmbedParams& p, float* x, float* h, float* ext, uint8_t* gen, hipStream_t s);
+hipError_t launch_embed_compose_backward(const float* grad_h, const float* ext, int n, int F, int A, int C, float* partial, int groups,
+                                         float* grad_out, hipStream_t s);
 hipError_t launch_colsum(const float* A, int lda, int cols, const float* scale, const int* rows, const int* n_rows_ptr,
                          int n_rows, float* partial, size_t slab_stride, int grid, hipStream_t s);
 // up to RS_MAX reduce_store pieces in one launch

@@ -1,0 +1,112 @@
+// libcbgx -- the training step's input side as one launch, and its weight gradients as two:
+//   PLContextEmbedder (repo/modules/context_emb.py:137-230, the shipped configuration: linear atom / residue / indicator embeddings)
+//       protein row:  h = W_pa feat + b_pa + W_res onehot(aa) + b_res + (W_ind 0 + b_ind)
+//       ligand row:   h = W_la c + b_la + (W_ind 1 + b_ind)
+//   compose_context (repo/modules/common.py:189-214): cat(protein, ligand)[sort_idx] of the coordinates, the features and the movable
+//       flag, sort_idx = stable argsort of the graph ids.
+// Both embeddings are ONE product with a stacked weight matrix: every composed row gets an "extended input"
+//       ext = [ feat (F) | onehot aa (A) | 1 if protein | c (C) | 1 if ligand | 0 ... ]          (EMB_LD columns)
+// and h = ext . Wext with Wext rows = W_pa^T | W_res^T | b_pa + b_res + b_ind | W_la^T | b_la + W_ind + b_ind.  The forward kernel
+// writes ext next to h; the backward is then the weight gradient of a single Linear,  dWext[c][j] = sum_r dh[r][c] ext[r][j]
+// (wgrad_mfma_kernel + one reduce), from whose columns every parameter's gradient is a slice.  The tensor path takes ~20 launches
+// forward and ~35 backward for the same numbers -- index_put's sort, three GEMMs with K = 27 / 20 / C that run at ~1 TFLOP/s, five
+// column reductions -- 0.45 ms of a 14.7 ms step (profiles/trace_train_r06/).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "layout.h"
+#include "train.h"
+
+namespace cbgx {
+
+static_assert(H == 128 && EMB_LD == 128, "two columns per lane");
+
+// One wave per composed row, lane l owns the columns 2l, 2l+1 of h and the entries l, l + 64 of ext; the stacked weights sit in LDS.
+__global__ __launch_bounds__(256) void embed_compose_kernel(
+    const float* __restrict__ x_rec, const float* __restrict__ x_lig, const float* __restrict__ feat, const int64_t* __restrict__ aa,
+    const float* __restrict__ c_lig, const int64_t* __restrict__ sort_idx, const uint8_t* __restrict__ gen_rec,
+    const uint8_t* __restrict__ gen_lig, int n_rec, int n_lig, int F, int A, int C, EmbedParams p, float* __restrict__ x,
+    float* __restrict__ h, float* __restrict__ ext, uint8_t* __restrict__ gen) {
+    extern __shared__ float smem[];
+    const int J = F + A + C + 2, jp = F + A, jl = J - 1;
+    float* Wt = smem;                     // [J][H]
+    float* erow = smem + J * H;           // [4 waves][EMB_LD]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int e = tid; e < H * F; e += 256) Wt[(e % F) * H + e / F] = p.w_pa[e];
+    for (int e = tid; e < H * A; e += 256) Wt[(F + e % A) * H + e / A] = p.w_res[e];
+    for (int e = tid; e < H * C; e += 256) Wt[(jp + 1 + e % C) * H + e / C] = p.w_la[e];
+    if (tid < H) {
+        Wt[jp * H + tid] = (p.b_pa[tid] + p.b_res[tid]) + p.b_ind[tid];
+        Wt[jl * H + tid] = p.b_la[tid] + (p.w_ind[tid] + p.b_ind[tid]);
+    }
+    __syncthreads();
+    float* er = erow + w * EMB_LD;
+    const int n = n_rec + n_lig;
+    for (int r = blockIdx.x * 4 + w; r < n; r += gridDim.x * 4) {
+        const long src = __builtin_amdgcn_readfirstlane((int)sort_idx[r]);
+        const bool prot = src < n_rec;
+        const long ls = src - n_rec;
+        float e0 = 0.f, e1 = 0.f;          // ext[lane], ext[lane + 64]
+        if (prot) {
+            const int a = (int)aa[src];
+            auto entry = [&](int j) { return j < F ? feat[src * F + j] : (j < jp ? (j - F == a ? 1.f : 0.f) : (j == jp ? 1.f : 0.f)); };
+            e0 = entry(lane);
+            e1 = entry(lane + 64);
+        } else {
+            auto entry = [&](int j) { return j > jp && j < jl ? c_lig[ls * C + (j - jp - 1)] : (j == jl ? 1.f : 0.f); };
+            e0 = entry(lane);
+            e1 = entry(lane + 64);
+        }
+        ext[(size_t)r * EMB_LD + lane] = e0;
+        ext[(size_t)r * EMB_LD + 64 + lane] = e1;
+        er[lane] = e0;
+        er[lane + 64] = e1;
+        __builtin_amdgcn_wave_barrier();   // the wave's own LDS row: written above, read below by all of its lanes, in program order
+        if (lane < 3) x[(size_t)r * 3 + lane] = prot ? x_rec[src * 3 + lane] : x_lig[ls * 3 + lane];
+        if (gen && lane == 0) gen[r] = prot ? (gen_rec ? gen_rec[src] : 0) : gen_lig[ls];
+        const int j0 = prot ? 0 : jp + 1, j1 = prot ? jp + 1 : J;
+        float2 acc = make_float2(0.f, 0.f);
+        for (int j = j0; j < j1; ++j) {
+            const float e = er[j];
+            const float2 wv = *reinterpret_cast<const float2*>(Wt + j * H + 2 * lane);
+            acc.x = fmaf(e, wv.x, acc.x);
+            acc.y = fmaf(e, wv.y, acc.y);
+        }
+        *reinterpret_cast<float2*>(h + (size_t)r * H + 2 * lane) = acc;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+hipError_t launch_embed_compose(const float* x_rec, const float* x_lig, const float* feat, const int64_t* aa, const float* c_lig,
+                                const int64_t* sort_idx, const uint8_t* gen_rec, const uint8_t* gen_lig, int n_rec, int n_lig, int F,
+                                int A, int C, const EmbedParams& p, float* x, float* h, float* ext, uint8_t* gen, hipStream_t s) {
+    const int n = n_rec + n_lig;
+    if (n <= 0) return hipSuccess;
+    const int J = F + A + C + 2;
+    const size_t lds = (size_t)(J * H + 4 * EMB_LD) * sizeof(float);
+    int grid = (n + 63) / 64;              // >= 16 rows per wave: the weight staging (J x 128 floats per workgroup) stays a small part
+    grid = grid < 1 ? 1 : (grid > 512 ? 512 : grid);
+    hipLaunchKernelGGL(embed_compose_kernel, dim3(grid), dim3(256), lds, s, x_rec, x_lig, feat, aa, c_lig, sort_idx, gen_rec, gen_lig,
+                       n_rec, n_lig, F, A, C, p, x, h, ext, gen);
+    return hipGetLastError();
+}
+
+// grad_out: [H x F | H x A | H | H x C | H] = dW_pa, dW_res, the protein bias column, dW_la, the ligand bias column (see the header)
+hipError_t launch_embed_compose_backward(const float* grad_h, const float* ext, int n, int F, int A, int C, float* partial, int groups,
+                                         float* grad_out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipError_t e = launch_wgrad_mfma(grad_h, H, ext, EMB_LD, n, 1, partial, EMB_LD, (size_t)H * EMB_LD, groups, s);
+    if (e != hipSuccess) return e;
+    const int off[5] = {0, F, F + A, F + A + 1, F + A + C + 1}, cols[5] = {F, A, 1, C, 1};
+    RsBatch b;
+    b.n = 5;
+    float* dst = grad_out;
+    for (int k = 0; k < 5; ++k) {
+        b.p[k] = RsPiece{partial + off[k], dst, (size_t)H * EMB_LD, groups, EMB_LD, H, cols[k], cols[k], 0};
+        dst += (size_t)H * cols[k];
+    }
+    return launch_reduce_store_multi(b, s);
+}
+
+}  // namespace cbgx

@@ -15,7 +15,8 @@ from torch import nn
 
 from . import _native
 from .registry import get_e3_gnn, register_model
-from .targetdiff import NUM_AA, BatchesInFlight, CTNVPScheduler, PLContextEmbedder, TargetDiff, masked_graph_mean, scatter_mean
+from .targetdiff import (NUM_AA, BatchesInFlight, CTNVPScheduler, PLContextEmbedder, TargetDiff, compose_embed, masked_graph_mean,
+                         scatter_mean)
 from .unitransformer import GaussianSmearing, H2XAttention, MLP, _MLP_KEYS
 
 ABSORBING_STATE = 0   # repo/utils/molecule/constants.py:8
@@ -376,13 +377,9 @@ class DiffBP(BatchesInFlight, nn.Module):
         eps, u = noise if noise is not None else (None, None)
         x_t, pos_noise, com_noise = self.pos_scheduler.forward_add_noise(x0, t, bl, gen_l, noise=eps, zero_center=True)
         v_t, c_t, type_flag = self.type_scheduler.forward_add_noise(v0, t, bl, gen_l, uniform=u)
-        aa = F.one_hot(batch["protein_aa_type"], NUM_AA).float()
-        h_lig = self.context_embedder.embed_ligand(c_t)
-        h_rec = self.context_embedder.embed_protein(batch["protein_atom_feature"].float(), aa)
         sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = TargetDiff.compose_plan(bl, br, int(t.shape[0]))
-        x = torch.cat([x_rec, x_t], 0)[sort_idx]
-        h = torch.cat([h_rec, h_lig], 0)[sort_idx]
-        gen_flag = torch.cat([gen_r, gen_l], 0)[sort_idx]
+        x, h, gen_flag = compose_embed(self.context_embedder, x_rec, x_t, batch["protein_atom_feature"].float(), batch["protein_aa_type"],
+                                       c_t, sort_idx, gen_r, gen_l, fused=self.fused_training_ops)
         # (h' is read by the centre-of-mass head only, on the movable atoms and their neighbours in the SAME k-nearest-neighbour graph
         # -- both networks build it from x -- so the denoiser may prune its last blocks to that receptive field, forward and backward)
         xo, ho, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,

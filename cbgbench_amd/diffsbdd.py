@@ -16,7 +16,7 @@ from torch import nn
 
 from . import _native
 from .registry import get_e3_gnn, register_model
-from .targetdiff import NUM_AA, BatchesInFlight, PLContextEmbedder, TargetDiff
+from .targetdiff import NUM_AA, BatchesInFlight, PLContextEmbedder, TargetDiff, compose_embed
 
 
 class PredefinedNoiseSchedule(nn.Module):
@@ -243,17 +243,13 @@ class DiffSBDD(BatchesInFlight, nn.Module):
         v_rec = batch["protein_atom_feature"].float() / 4.0
         t = t_int / T
         x0c, xr0 = self.pos_scheduler.remove_mean_batch(x0, batch["protein_pos"].float(), bl, br, B)
-        aa = F.one_hot(batch["protein_aa_type"], NUM_AA).float()
-        h_rec = self.context_embedder.embed_protein(v_rec, aa)
         sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = TargetDiff.compose_plan(bl, br, B)
-        gen_flag = torch.cat([gen_r, gen_l], 0)[sort_idx]
 
         def noise_and_denoise(tt, eps_x, eps_c):
             x_t, pos_noise, xr_t = self.pos_scheduler.forward_pos_center_noise(x0c, xr0, tt, bl, br, B, gen_l, noise=eps_x)
             c_t, type_noise = self.type_scheduler.forward_type_add_noise(c0, tt, bl, B, gen_l, noise=eps_c)
-            h_lig = self.context_embedder.embed_ligand(c_t)
-            x = torch.cat([xr_t, x_t], 0)[sort_idx]
-            h = torch.cat([h_rec, h_lig], 0)[sort_idx]
+            x, h, gen_flag = compose_embed(self.context_embedder, xr_t, x_t, v_rec, batch["protein_aa_type"], c_t, sort_idx, gen_r,
+                                           gen_l)
             xo, _, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
                                           graph_ptr=graph_ptr, ligand_outputs_only=True)
             return xo[lig_rows], logits[lig_rows], pos_noise, type_noise, c_t

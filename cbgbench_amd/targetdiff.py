@@ -346,6 +346,70 @@ class PLContextEmbedder(nn.Module):
         return self.ligand_atom_emb(c_lig) + ind1
 
 
+class _ComposeEmbedFunction(torch.autograd.Function):
+    """``PLContextEmbedder`` on both atom sets + ``compose_context`` of coordinates, features and the movable flag
+    (repo/modules/context_emb.py:137-230, repo/modules/common.py:189-214) as one launch; the backward is the weight gradient of ONE
+    Linear over "extended input" rows the forward leaves behind (csrc/train_embed.hip, cbgx_embed_compose{,_backward}) -- two launches
+    instead of index_put's sort, three thin GEMMs and five column sums."""
+
+    @staticmethod
+    def forward(ctx, x_rec, x_lig, feat, aa, c_lig, sort_idx, gen_r, gen_l, w_pa, b_pa, w_res, b_res, w_la, b_la, w_ind, b_ind):
+        dev = x_rec.device
+        n_rec, n_lig = x_rec.shape[0], x_lig.shape[0]
+        N, E = n_rec + n_lig, w_pa.shape[0]
+        dims = (w_pa.shape[1], w_res.shape[1], w_la.shape[1])
+        x = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        h = torch.empty(N, E, dtype=torch.float32, device=dev)
+        ext = torch.empty(N, 128, dtype=torch.float32, device=dev)
+        gen = torch.empty(N, dtype=torch.bool, device=dev)
+        params = [p.detach().contiguous() for p in (w_pa, b_pa, w_res, b_res, w_la, b_la, w_ind, b_ind)]
+        arr = (ctypes.c_void_p * 8)(*[p.data_ptr() for p in params])
+        _native.check(_native.lib().cbgx_embed_compose(
+            _native.ptr(x_rec), _native.ptr(x_lig), _native.ptr(feat), _native.ptr(aa), _native.ptr(c_lig), _native.ptr(sort_idx),
+            _native.ptr(gen_r), _native.ptr(gen_l), n_rec, n_lig, dims[0], dims[1], dims[2], arr, _native.ptr(x), _native.ptr(h),
+            _native.ptr(ext), _native.ptr(gen), _native.current_stream(dev)), "cbgx_embed_compose")
+        ctx.save_for_backward(ext)
+        ctx.dims = dims
+        ctx.mark_non_differentiable(x, gen)
+        return x, h, gen
+
+    @staticmethod
+    def backward(ctx, _gx, gh, _gg):
+        (ext,) = ctx.saved_tensors
+        Fd, A, C = ctx.dims
+        N, dev = ext.shape[0], ext.device
+        groups = max(1, min(64, (N + 127) // 128))
+        partial = torch.empty(groups * 128 * 128, dtype=torch.float32, device=dev)
+        out = torch.empty(128 * (Fd + A + C + 2), dtype=torch.float32, device=dev)
+        _native.check(_native.lib().cbgx_embed_compose_backward(
+            _native.ptr(gh.to(torch.float32).contiguous()), _native.ptr(ext), N, Fd, A, C, _native.ptr(partial), groups,
+            _native.ptr(out), _native.current_stream(dev)), "cbgx_embed_compose_backward")
+        dw_pa, dw_res, u, dw_la, v = out.split([128 * Fd, 128 * A, 128, 128 * C, 128])
+        return (None,) * 8 + (dw_pa.view(128, Fd), u, dw_res.view(128, A), u, dw_la.view(128, C), v, v.view(128, 1), u + v)
+
+
+def compose_embed(embedder, x_rec, x_lig, feat_rec, aa_rec, c_lig, sort_idx, gen_r, gen_l, fused=True):
+    """(x, h, gen_flag) of a training step in composed row order: ``cat(protein, ligand)[sort_idx]`` of the coordinates, of
+    ``embed_protein(feat_rec, one_hot(aa_rec))`` / ``embed_ligand(c_lig)`` and of the movable flags (targetdiff.py:89-101 and the same
+    lines of the other two model classes).  One launch when the inputs are in the shape the kernel takes (``CBGX_FUSED_EMBED=0``: the
+    tensor path, which is also the CPU path)."""
+    e = embedder
+    n_in = e.protein_atom_emb.in_features + e.residue_emb.in_features + e.ligand_atom_emb.in_features + 2
+    if (fused and x_rec.is_cuda and e.emb_dim == 128 and n_in <= 120 and os.environ.get("CBGX_FUSED_EMBED", "1") != "0"
+            and aa_rec.dtype == torch.int64 and sort_idx.dtype == torch.int64 and gen_l.dtype == torch.bool
+            and gen_r.dtype == torch.bool and all(t.dtype == torch.float32 for t in (x_rec, x_lig, feat_rec, c_lig))
+            and feat_rec.shape[1] == e.protein_atom_emb.in_features and c_lig.shape[1] == e.ligand_atom_emb.in_features
+            and e.protein_atom_emb.weight.dtype == torch.float32):
+        return _ComposeEmbedFunction.apply(
+            x_rec.contiguous(), x_lig.contiguous(), feat_rec.contiguous(), aa_rec.contiguous(), c_lig.contiguous(),
+            sort_idx.contiguous(), gen_r.contiguous(), gen_l.contiguous(), e.protein_atom_emb.weight, e.protein_atom_emb.bias,
+            e.residue_emb.weight, e.residue_emb.bias, e.ligand_atom_emb.weight, e.ligand_atom_emb.bias, e.ligand_indicator.weight,
+            e.ligand_indicator.bias)
+    aa = F.one_hot(aa_rec, e.residue_emb.in_features).float()
+    h = torch.cat([e.embed_protein(feat_rec, aa), e.embed_ligand(c_lig)], 0)[sort_idx]
+    return torch.cat([x_rec, x_lig], 0)[sort_idx], h, torch.cat([gen_r, gen_l], 0)[sort_idx]
+
+
 class _Lap:
     """``lap(key)``: add the wall seconds since the previous lap to ``timing[key]`` after a device synchronisation; a no-op
     without a timing dict."""
@@ -527,13 +591,9 @@ class TargetDiff(BatchesInFlight, nn.Module):
                 c_t, v_t = self.type_scheduler.forward_add_noise(v0, t, bl, gen_l, uniform=u)
             else:
                 c_t, v_t = F.one_hot(v0, self.num_classes).float(), v0
-        aa = F.one_hot(batch["protein_aa_type"], NUM_AA).float()
-        h_lig = self.context_embedder.embed_ligand(c_t)
-        h_rec = self.context_embedder.embed_protein(batch["protein_atom_feature"].float(), aa)
         sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = self.compose_plan(bl, br, int(t.shape[0]))
-        x = torch.cat([x_rec, x_t], 0)[sort_idx]
-        h = torch.cat([h_rec, h_lig], 0)[sort_idx]
-        gen_flag = torch.cat([gen_r, gen_l], 0)[sort_idx]
+        x, h, gen_flag = compose_embed(self.context_embedder, x_rec, x_t, batch["protein_atom_feature"].float(), batch["protein_aa_type"],
+                                       c_t, sort_idx, gen_r, gen_l, fused=self.fused_training_ops)
         xo, _, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag,
                                       graph_ptr=graph_ptr, ligand_outputs_only=True)
         if fused:

@@ -56,7 +56,7 @@ extern "C" {
  * 4 (round 5): cbgx_unitransformer_backward with grad_h_out == NULL also prunes the classifier head's backward to the ligand rows
  * (round 4 changed that without a bump), the cbgx_targetdiff_train_noise / _loss / _loss_backward exports exist, and the workspace
  * layout of cbgx_unitransformer_forward changed: a caller built against version 3 must not load this library. */
-#define CBGX_ABI_VERSION 5
+#define CBGX_ABI_VERSION 6
 
 #define CBGX_OK 0
 #define CBGX_E_INVALID (-1)   /* bad argument (shape, NULL pointer, unsupported hyper-parameter) */
@@ -393,6 +393,29 @@ int cbgx_diffbp_loss(const float *x_out, const float *x_in, const float *x_stack
                      int n_graphs, int num_classes, const float *alphas_cumprod, const float *betas, float rho, float gamma,
                      float *losses, float *scal, float *gstats, float *a_pos, float *a_int, float *b_com, float *b_int,
                      float *z_atom, int32_t *bad, void *stream);
+
+/* cbgx_embed_compose / cbgx_embed_compose_backward (ABI 6): the input side of a training step -- PLContextEmbedder
+ *   (repo/modules/context_emb.py:137-230, the shipped configuration: Linear atom / residue / ligand-indicator embeddings, no time / vec)
+ *   and compose_context (repo/modules/common.py:189-214) -- as one launch, and the embedder's weight gradients as two.
+ *     protein row:  h = W_pa feat + b_pa + W_res onehot(aa) + b_res + b_ind           ligand row:  h = W_la c + b_la + W_ind + b_ind
+ *     x = cat(x_protein, x_ligand)[sort_idx],  h likewise,  gen_flag = cat(gen_protein, gen_ligand)[sort_idx]
+ *   protein_feat [n_protein, feat_dim] fp32, protein_aa [n_protein] class indices (an index outside [0, num_aa) embeds as no residue),
+ *   ligand_feat [n_ligand, lig_dim] fp32 (one-hot or noised types); sort_idx [N] as above; gen_protein may be NULL (all 0), gen_flag may be
+ *   NULL (not written).  params: the eight tensors of the embedder in nn.Linear layout -- protein_atom_emb.weight [128, feat_dim], .bias,
+ *   residue_emb.weight [128, num_aa], .bias, ligand_atom_emb.weight [128, lig_dim], .bias, ligand_indicator.weight [128, 1], .bias.
+ *   feat_dim + num_aa + lig_dim + 2 <= 120.  Outputs x [N,3], h [N,128] and ext [N,128], the rows
+ *     ext = [ feat | onehot(aa) | 1 if protein | c | 1 if ligand | 0 ... ]
+ *   that the backward multiplies with: h = ext . Wext for the stacked weights, so  dWext[c][j] = sum_r grad_h[r][c] ext[r][j]  holds
+ *   every parameter's gradient.  cbgx_embed_compose_backward: partial = scratch of `groups` slabs of 128 x 128 floats (1 <= groups <= 256:
+ *   the rows are split into that many partial sums, added in slab order -- reproducible); grad_out [128 (feat_dim + num_aa + lig_dim + 2)]
+ *   = dW_pa [128, feat_dim] | dW_res [128, num_aa] | u [128] | dW_la [128, lig_dim] | v [128]  back to back, with
+ *   db_pa = db_res = u,  db_la = dW_ind[:, 0] = v,  db_ind = u + v.  Coordinates and features get no gradient (they are data). */
+int cbgx_embed_compose(const float *x_protein, const float *x_ligand, const float *protein_feat, const int64_t *protein_aa,
+                       const float *ligand_feat, const int64_t *sort_idx, const uint8_t *gen_protein, const uint8_t *gen_ligand,
+                       int n_protein, int n_ligand, int feat_dim, int num_aa, int lig_dim, const float *const *params, float *x,
+                       float *h, float *ext, uint8_t *gen_flag, void *stream);
+int cbgx_embed_compose_backward(const float *grad_h, const float *ext, int n_nodes, int feat_dim, int num_aa, int lig_dim,
+                                float *partial, int groups, float *grad_out, void *stream);
 
 /* ---- measurement hook (bench.py) ----------------------------------------------------------------
  * Between cbgx_profile_begin() and cbgx_profile_end() every kernel launch is bracketed by HIP events on

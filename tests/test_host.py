@@ -138,7 +138,7 @@ def test_library_exports_every_declared_symbol():
     lib = _native.lib()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.cbgx_abi_version() == _native.ABI_VERSION == 5
+    assert lib.cbgx_abi_version() == _native.ABI_VERSION == 6
     # the product library carries no debug switch and none of the first-generation kernels; the test-only build has both
     import subprocess
     assert not hasattr(lib, "cbgx_debug_set_edge_kernel")

@@ -158,3 +158,16 @@ def test_node_and_graph_kernels_do_not_spill(tmp_path):
         # four waves per SIMD (round 5): with the LDS image's reads hoisted out of the centre loop these kernels took 332 registers
         # and ran one wave per SIMD through a chain of dependent global round trips per centre
         assert find(res, name)["vgpr"] <= 128, (name, find(res, name))
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_training_node_kernels_do_not_spill(tmp_path):
+    res, _ = kernel_resources("train_reduce.hip", tmp_path)
+    for name in ("fold_grad_kernelILb0E", "fold_grad_kernelILb1E"):
+        # 64 weights per thread stay in registers across the row tiles; four waves per SIMD (round 6: with affine row numbers the
+        # compiler pipelined the row loop into 258 registers = one wave per SIMD, and spilled when capped -- row ids now come from LDS)
+        k = find(res, name)
+        assert k["scratch"] == 0 and k["vgpr"] <= 128, (name, k)
+    res, _ = kernel_resources("train_embed.hip", tmp_path)
+    k = find(res, "embed_compose_kernel")
+    assert k["scratch"] == 0 and k["vgpr"] <= 64, k
