@@ -596,8 +596,8 @@ def test_fused_embedder_gives_the_model_the_same_gradients(golden_dir, synthetic
     assert out[True][1].keys() == out[False][1].keys()
     assert sum(k.startswith("context_embedder.") for k in out[True][1]) == 8
     # the two sides' embeddings differ in the last bit (one fma chain against three GEMMs), which can move a ReLU whose pre-activation
-    # sits within that bit of zero (tests/relu_flip.py; the golden-gradient tests re-run the oracle to adjudicate): at most two
-    # tensors may carry such a flip, and then by no more than the flip budget
+    # sits within that bit of zero (tests/relu_flip.py; the golden-gradient tests re-run the oracle to adjudicate).  A flip shows in
+    # every parameter of the Linear-LayerNorm-ReLU-Linear it sits in: at most two such MLPs may carry one, by no more than the flip budget
     over = {}
     for k, ref in out[False][1].items():
         rn = float(ref.norm())
@@ -606,7 +606,8 @@ def test_fused_embedder_gives_the_model_the_same_gradients(golden_dir, synthetic
         d = float((out[True][1][k] - ref).norm()) / rn
         if d > 2e-4:
             over[k] = d
-    assert len(over) <= 2 and all(d <= 5e-3 for d in over.values()) and not any(k.startswith("context_embedder.") for k in over), over
+    mlps = {k.split(".net.")[0] for k in over}
+    assert len(mlps) <= 2 and all(d <= 5e-3 for d in over.values()) and all(".net." in k for k in over), over
 
 
 @pytest.mark.parametrize("case", ["train_loss_diffsbdd", "train_loss_diffsbdd_t0"])
