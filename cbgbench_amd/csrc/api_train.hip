@@ -243,7 +243,8 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
                                     float* de_w, float* const* grads, hipStream_t s, const float* P_saved = nullptr,
                                     const float* Qt_saved = nullptr, float* qln = nullptr, const float* gh_src = nullptr,
                                     const int* dp_rows = nullptr, const int* dp_n_rows = nullptr, BlockOverlap* ov = nullptr,
-                                    bool rin_ready = false) {
+                                    bool rin_ready = false, const float* dx_init = nullptr) {
+    // `dx_init` (h2x blocks of a layer loop): dx = dx_init (the identity path of x_{l+1} = x_l + ...) before the block adds to it
     TrainWs w = w_all;      // this block's view of the workspace: the per-block buffers of its set
     const int set = (ov && ov->aux) ? ov->next_set : 0;
     if (set) {
@@ -296,8 +297,11 @@ static int attention_block_backward(bool x2h, const float* att, const float* x, 
     else if (!x2h && dp_rows && mfma && ov && ov->aux && env_on("CBGX_TRAIN_ZERO_ROWS"))
         // h2x block in the layer loop: every reader of dP walks `dp_rows`, so only those rows are zeroed (a fill of all N rows was 42 MB
         // per block; +0.4 % on the training line, profiles/ab_train_r06r.log)
-        HIP_TRY(launch_zero_rows(w.dP, PROW, dp_rows, dp_n_rows, n, s));
-    else HIP_TRY(hipMemsetAsync(w.dP, 0, (size_t)n * PROW * sizeof(float) + 256, s));     // (and the work counters behind it)
+    {
+        HIP_TRY(launch_zero_rows(w.dP, PROW, dp_rows, dp_n_rows, n, s, dx_init ? dx : nullptr, dx_init, n * 3));
+        dx_init = nullptr;
+    } else HIP_TRY(hipMemsetAsync(w.dP, 0, (size_t)n * PROW * sizeof(float) + 256, s));     // (and the work counters behind it)
+    if (dx_init) HIP_TRY(hipMemcpyAsync(dx, dx_init, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (!qln) {
         qln = w.qln;
         HIP_TRY(hipMemsetAsync(qln, 0, 2 * H * sizeof(float), s));
@@ -784,7 +788,6 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
         float* const* g = grads + 6 + 36 * l;
         // x_{l+1} = x_l + gen * H2X(x_l, h_mid): identity path first, then the block's own contributions
         const int nxt = cur ^ 1;
-        HIP_TRY(hipMemcpyAsync(w.gx[nxt], w.gx[cur], nx * 4, hipMemcpyDeviceToDevice, s));
         const float* Px = tp.P + (size_t)(2 * l) * n * PROW;
         const float* Qx = tp.Qt + (size_t)(2 * l) * n * HEADS * H;
         RC_TRY(attention_block_backward(false, packed + h2x_off(l), xl, h_mid, w.gx[cur], tp.nbr, tp.deg, lig_flag, tp.e_w,
@@ -792,7 +795,7 @@ int cbgx_unitransformer_backward(const float* packed, int num_layers, int num_cl
                                         Px + (size_t)n * PROW, Qx + (size_t)n * HEADS * H,
                                         qln_slots ? w.qln + (size_t)(2 * l + 1) * 2 * H : nullptr, nullptr,
                                         // dP of an h2x block is non-zero on gen | nbr(gen) only, a subset of the receptive-field list A1
-                                        prune ? w.rf_list[0] : nullptr, prune ? w.rf_count : nullptr, &ov));
+                                        prune ? w.rf_list[0] : nullptr, prune ? w.rf_count : nullptr, &ov, false, w.gx[cur]));
         // h_mid = h_in + X2H(x_l, h_in): gh_cur holds dL/dh_mid, which is also the residual part of dL/dh_in.  The block reads it
         // (fold, outer products, bias sums) and writes dL/dh_in = gh_cur + dP Wn^T into the OTHER buffer.
         const int k = L - 1 - l;      // 0 for the last layer
@@ -915,12 +918,12 @@ int cbgx_h2x_stack_backward(const float* packed, int num_layers, const void* tap
     BlockOverlap ov{(lists && env_on("CBGX_TRAIN_OVERLAP") && !profile_is_on() && qln_slots) ? aux_for(s) : nullptr, 0, {false, false}};
     for (int l = num_layers - 1; l >= 0; --l) {
         const int nxt = cur ^ 1;
-        HIP_TRY(hipMemcpyAsync(w.gx[nxt], w.gx[cur], nx * 4, hipMemcpyDeviceToDevice, s));      // x_out = x + gen * delta
+        // x_out = x + gen * delta: the identity part of the coordinate gradient is the block's `dx_init`
         RC_TRY(attention_block_backward(false, packed + GATE_SIZE + (size_t)l * ATT_SIZE, tp.xs + (size_t)l * nx, h, w.gx[cur],
                                         tp.nbr, tp.deg, lig_flag, tp.e_w, w.act, w.act_count, n, w, w.gh, w.gx[nxt], w.de_w,
                                         grads + 6 + 18 * l, s, nullptr, nullptr,
                                         qln_slots ? w.qln + (size_t)l * 2 * H : nullptr, nullptr,
-                                        lists ? w.rf_list[0] : nullptr, lists ? w.rf_count : nullptr, &ov));
+                                        lists ? w.rf_list[0] : nullptr, lists ? w.rf_count : nullptr, &ov, false, w.gx[cur]));
         cur = nxt;
     }
     HIP_TRY(hipMemcpyAsync(grad_h, w.gh, nh * 4, hipMemcpyDeviceToDevice, s));

@@ -62,7 +62,8 @@ hipError_t launch_edge_backward_x2h(const float* att, const float* x, const floa
 hipError_t launch_rin_build(const int32_t* nbr, const int32_t* deg, int n_nodes, int* cnt, int* ptr, int* tmp, int* edges,
                             hipStream_t s);
 hipError_t launch_mark_nonzero_rows(const float* g, int n, uint8_t* m, hipStream_t s, int cols = H, int set = 0);
-hipError_t launch_zero_rows(float* A, int ld, const int* rows, const int* n_rows_ptr, int max_rows, hipStream_t s);
+hipError_t launch_zero_rows(float* A, int ld, const int* rows, const int* n_rows_ptr, int max_rows, hipStream_t s,
+                            float* copy_dst = nullptr, const float* copy_src = nullptr, int copy_n = 0);
 hipError_t launch_edge_rows_reduce(const float* dE, const int* rin_ptr, const int* rin_edge, int n_nodes, float* dP, hipStream_t s);
 // floats of nk_scratch: two slots (key | value path) per wave of the largest grid: the normalised pre-activation of a path, parked by its
 // forward part and read back by the backward sweep in the same labeling (the key path also across two phases of a node)

@@ -85,8 +85,11 @@ hipError_t launch_embed_compose(const float* x_rec, const float* x_lig, const fl
     if (n <= 0) return hipSuccess;
     const int J = F + A + C + 2;
     const size_t lds = (size_t)(J * H + 4 * EMB_LD) * sizeof(float);
-    int grid = (n + 63) / 64;              // >= 16 rows per wave: the weight staging (J x 128 floats per workgroup) stays a small part
-    grid = grid < 1 ? 1 : (grid > 512 ? 512 : grid);
+    // four rows per wave: a row is a chain of three dependent memory round trips (sort_idx -> its inputs -> the stores) that the row
+    // loop does not overlap -- at 16 rows per wave the launch took 47 us for 16.5 k rows; the weight staging (J x 128 floats per
+    // workgroup, from L2) costs one more round trip per workgroup whatever the grid
+    int grid = (n + 15) / 16;
+    grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
     hipLaunchKernelGGL(embed_compose_kernel, dim3(grid), dim3(256), lds, s, x_rec, x_lig, feat, aa, c_lig, sort_idx, gen_rec, gen_lig,
                        n_rec, n_lig, F, A, C, p, x, h, ext, gen);
     return hipGetLastError();

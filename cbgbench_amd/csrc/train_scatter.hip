@@ -143,13 +143,17 @@ __global__ __launch_bounds__(256) void edge_rows_reduce_kernel(const float* __re
 
 // zero the listed rows of A [.][ld] (ld a multiple of 4): the projection gradient of an h2x block is non-zero -- and read -- on
 // gen | nbr(gen) only, a fill of all N rows was 42 MB per block
+// (+ `copy_dst` [copy_n] = `copy_src`, when given: the identity part of an h2x block's coordinate gradient rides along instead of
+// taking a launch of its own between the two edge kernels of a layer)
 __global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ A, int ld, const int* __restrict__ rows,
-                                                         const int* __restrict__ n_rows_ptr) {
+                                                         const int* __restrict__ n_rows_ptr, float* __restrict__ copy_dst,
+                                                         const float* __restrict__ copy_src, int copy_n) {
     const int count = *n_rows_ptr, lane = threadIdx.x & 63;
     for (int it = blockIdx.x * 4 + (threadIdx.x >> 6); it < count; it += gridDim.x * 4) {
         floatx4s* row = reinterpret_cast<floatx4s*>(A + (size_t)rows[it] * ld);
         for (int k = lane; k < ld / 4; k += 64) row[k] = floatx4s{0.f, 0.f, 0.f, 0.f};
     }
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < copy_n; k += gridDim.x * 256) copy_dst[k] = copy_src[k];
 }
 
 // m[i] = 1 for every row of g [n][128] with a non-zero entry (one wavefront per row): the support of a caller's dL/dh_out, so that
@@ -174,10 +178,13 @@ hipError_t launch_mark_nonzero_rows(const float* g, int n, uint8_t* m, hipStream
     return hipGetLastError();
 }
 
-hipError_t launch_zero_rows(float* A, int ld, const int* rows, const int* n_rows_ptr, int max_rows, hipStream_t s) {
-    if (max_rows <= 0) return hipSuccess;
+hipError_t launch_zero_rows(float* A, int ld, const int* rows, const int* n_rows_ptr, int max_rows, hipStream_t s, float* copy_dst,
+                            const float* copy_src, int copy_n) {
+    if (max_rows <= 0 && copy_n <= 0) return hipSuccess;
+    // two workgroups per CU: a listed block has ~2 k rows, and 2048 workgroups that mostly read the count and leave took 12 us
     const int g = (max_rows + 3) / 4;
-    hipLaunchKernelGGL(zero_rows_kernel, dim3(g < 2048 ? g : 2048), dim3(256), 0, s, A, ld, rows, n_rows_ptr);
+    hipLaunchKernelGGL(zero_rows_kernel, dim3(g < 1 ? 1 : (g < 512 ? g : 512)), dim3(256), 0, s, A, ld, rows, n_rows_ptr, copy_dst,
+                       copy_src, copy_dst ? copy_n : 0);
     return hipGetLastError();
 }
 
