@@ -48,6 +48,9 @@ EXPORTS = {
     "cbgx_targetdiff_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(_vp), _vp, _vp, _vp,
                                   _vp, _vp, _vp]),
     "cbgx_targetdiff_loss_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "cbgx_diffsbdd_train_noise": (_i, [_vp] * 9 + [_i] * 4 + [_vp, _vp, _i] + [_vp] * 5),
+    "cbgx_diffsbdd_loss": (_i, [_vp] * 7 + [_i] * 4 + [_vp] * 8),
+    "cbgx_compose_plan": (_i, [_vp, _vp, _i, _i, _i] + [_vp] * 7),
     "cbgx_embed_compose": (_i, [_vp] * 8 + [_i] * 5 + [ctypes.POINTER(_vp)] + [_vp] * 5),
     "cbgx_embed_compose_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "cbgx_diffbp_loss": (_i, [_vp] * 13 + [_i, _i, _i, _i, _vp, _vp, ctypes.c_float, ctypes.c_float] + [_vp] * 9 + [_vp]),

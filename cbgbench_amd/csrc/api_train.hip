@@ -991,6 +991,48 @@ int cbgx_diffbp_loss(const float* x_out, const float* x_in, const float* x_stack
     return CBGX_OK;
 }
 
+int cbgx_diffsbdd_train_noise(const float* x0, const float* x_protein, const int64_t* v0, const float* eps_x, const float* eps_c,
+                              const uint8_t* gen, const int64_t* t, const int64_t* sort_idx, const int32_t* graph_ptr, int n_protein,
+                              int n_lig, int n_graphs, int num_classes, const float* alpha_table, const float* sigma_table,
+                              int num_timesteps, float* x_t, float* x_protein_t, float* c_t, float* gdata, void* stream) {
+    if (n_lig <= 0 || n_graphs <= 0 || n_protein < 0 || num_classes < 1 || num_classes > 32 || num_timesteps < 1)
+        return set_error(CBGX_E_INVALID, "diffsbdd_train_noise: bad sizes (n_lig=%d B=%d C=%d T=%d)", n_lig, n_graphs, num_classes,
+                         num_timesteps);
+    if (!x0 || (n_protein && (!x_protein || !x_protein_t)) || !v0 || !eps_x || !eps_c || !gen || !t || !sort_idx || !graph_ptr ||
+        !alpha_table || !sigma_table || !x_t || !c_t || !gdata)
+        return set_error(CBGX_E_INVALID, "diffsbdd_train_noise: NULL pointer");
+    HIP_TRY(launch_diffsbdd_noise(x0, x_protein, v0, eps_x, eps_c, gen, t, sort_idx, graph_ptr, n_protein, n_graphs, num_classes,
+                                  alpha_table, sigma_table, num_timesteps, x_t, x_protein_t, c_t, gdata, (hipStream_t)stream));
+    return CBGX_OK;
+}
+
+int cbgx_diffsbdd_loss(const float* x_out, const float* logits, const float* eps_x, const float* eps_c, const int64_t* t,
+                       const int64_t* sort_idx, const int32_t* graph_ptr, int n_protein, int n_lig, int n_graphs, int num_classes,
+                       const float* gdata, float* glosses, float* losses, float* x_pred, float* c_pred, float* grad_pos,
+                       float* grad_logit, void* stream) {
+    if (n_lig <= 0 || n_graphs <= 0 || n_protein < 0 || num_classes < 1 || num_classes > 32)
+        return set_error(CBGX_E_INVALID, "diffsbdd_loss: bad sizes (n_lig=%d B=%d C=%d)", n_lig, n_graphs, num_classes);
+    if (!x_out || !logits || !eps_x || !eps_c || !t || !sort_idx || !graph_ptr || !gdata || !glosses || !losses || !x_pred || !c_pred ||
+        !grad_pos || !grad_logit)
+        return set_error(CBGX_E_INVALID, "diffsbdd_loss: NULL pointer");
+    HIP_TRY(launch_diffsbdd_loss(x_out, logits, eps_x, eps_c, t, sort_idx, graph_ptr, n_protein, n_graphs, num_classes, gdata, glosses,
+                                 losses, x_pred, c_pred, grad_pos, grad_logit, (hipStream_t)stream));
+    return CBGX_OK;
+}
+
+int cbgx_compose_plan(const int64_t* batch_protein, const int64_t* batch_ligand, int n_protein, int n_ligand, int n_graphs,
+                      int32_t* scratch, int64_t* sort_idx, int64_t* batch_idx, uint8_t* lig_flag, int64_t* lig_rows, int32_t* graph_ptr,
+                      void* stream) {
+    if (n_protein < 0 || n_ligand < 0 || n_graphs < 1 || n_graphs > (1 << 20))
+        return set_error(CBGX_E_INVALID, "compose_plan: bad sizes (N_protein=%d N_ligand=%d B=%d)", n_protein, n_ligand, n_graphs);
+    if (!scratch || !graph_ptr || (n_protein && !batch_protein) || (n_ligand && (!batch_ligand || !lig_rows)) ||
+        ((n_protein + n_ligand) && (!sort_idx || !batch_idx || !lig_flag)))
+        return set_error(CBGX_E_INVALID, "compose_plan: NULL pointer");
+    HIP_TRY(launch_compose_plan(batch_protein, batch_ligand, n_protein, n_ligand, n_graphs, scratch, sort_idx, batch_idx, lig_flag,
+                                lig_rows, graph_ptr, (hipStream_t)stream));
+    return CBGX_OK;
+}
+
 int cbgx_embed_compose(const float* x_protein, const float* x_ligand, const float* protein_feat, const int64_t* protein_aa,
                        const float* ligand_feat, const int64_t* sort_idx, const uint8_t* gen_protein, const uint8_t* gen_ligand,
                        int n_protein, int n_ligand, int feat_dim, int num_aa, int lig_dim, const float* const* params, float* x, float* h,

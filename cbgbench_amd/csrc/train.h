@@ -92,6 +92,16 @@ hipError_t launch_q_backward(const float* att, const float* P, const float* T, c
 hipError_t launch_outer_accum(bool headed, const float* Lm, const float* R, const int* rows, const int* n_rows,
                               int n_nodes, float* partial, size_t slab_stride, int grid, hipStream_t s);
 #endif
+hipError_t launch_compose_plan(const int64_t* br, const int64_t* bl, int n_rec, int n_lig, int B, int* scratch, int64_t* sort_idx,
+                               int64_t* batch_idx, uint8_t* lig_flag, int64_t* lig_rows, int32_t* graph_ptr, hipStream_t s);
+// train_loss_diffsbdd.hip: DiffSBDD's noising + data-only loss terms (one launch), its two losses and their gradients (two)
+hipError_t launch_diffsbdd_noise(const float* x0, const float* x_rec, const int64_t* v0, const float* eps_x, const float* eps_c,
+                                 const uint8_t* gen, const int64_t* t, const int64_t* sort_idx, const int32_t* graph_ptr, int n_rec, int B,
+                                 int C, const float* alpha_tab, const float* sigma_tab, int T, float* x_t, float* xr_t, float* c_t,
+                                 float* gdata, hipStream_t s);
+hipError_t launch_diffsbdd_loss(const float* x_out, const float* logits, const float* eps_x, const float* eps_c, const int64_t* t,
+                                const int64_t* sort_idx, const int32_t* graph_ptr, int n_rec, int B, int C, const float* gdata,
+                                float* glosses, float* losses, float* x_pred, float* c_pred, float* gpos, float* gz, hipStream_t s);
 // train_embed.hip: PLContextEmbedder + compose_context of a training step in one launch; its weight gradients through wgrad_mfma
 constexpr int EMB_LD = 128;            // columns of the extended input rows (feat | onehot aa | 1 | c | 1 | zeros)
 constexpr int EMB_MAX_J = 120;         // F + A + C + 2: the stacked weights (J x 128 floats) + four rows fit 64 KB of LDS

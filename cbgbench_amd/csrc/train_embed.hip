@@ -112,4 +112,95 @@ hipError_t launch_embed_compose_backward(const float* grad_h, const float* ext, 
     return launch_reduce_store_multi(b, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// compose_context's index work (repo/modules/common.py:189-214): the stable argsort of cat(protein graph ids, ligand graph ids) and what
+// the callers derive from it -- the sorted ids, the ligand flag, the composed rows of the ligand atoms, the CSR offsets of the graphs --
+// as three launches (count, scan, place) instead of the ~20 of the tensor path (radix sort, scatter, cumsum ...).  A stable sort by
+// graph id is a counting sort: row = offset(graph) [+ protein atoms of the graph, for a ligand atom] + rank among the EARLIER atoms of
+// the same array with the same id.  Collated batches have non-decreasing ids, where that rank is i - (atoms of earlier graphs); the count
+// pass checks it, and an array that is not sorted takes the literal definition (a scan over the earlier entries: slow, exact).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void compose_count_kernel(const int64_t* __restrict__ br, const int64_t* __restrict__ bl, int n_rec, int n_lig,
+                                                            int B, int* __restrict__ cnt, int* __restrict__ flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rec + n_lig) return;
+    const bool lig = i >= n_rec;
+    const int64_t* a = lig ? bl : br;
+    const int k = lig ? i - n_rec : i;
+    const int64_t g = a[k];
+    if (g < 0 || g >= B) { atomicOr(flag, 4); return; }
+    atomicAdd(&cnt[(lig ? B : 0) + (int)g], 1);
+    if (k > 0 && a[k - 1] > g) atomicOr(flag, lig ? 2 : 1);
+}
+
+// one workgroup: exclusive prefix sums over the graphs -- pre[0][g] / pre[1][g] = protein / ligand atoms of the graphs before g,
+// graph_ptr[g] = both
+__global__ __launch_bounds__(1024) void compose_scan_kernel(const int* __restrict__ cnt, int B, int* __restrict__ pre, int32_t* __restrict__ graph_ptr) {
+    __shared__ int s_part[2][1024];
+    const int t = threadIdx.x, per = (B + 1023) / 1024;
+    const int g0 = t * per, g1 = min(B, g0 + per);
+    int s0 = 0, s1 = 0;
+    for (int g = g0; g < g1; ++g) { s0 += cnt[g]; s1 += cnt[B + g]; }
+    s_part[0][t] = s0;
+    s_part[1][t] = s1;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {       // inclusive scan of the per-thread totals
+        const int a0 = t >= off ? s_part[0][t - off] : 0, a1 = t >= off ? s_part[1][t - off] : 0;
+        __syncthreads();
+        s_part[0][t] += a0;
+        s_part[1][t] += a1;
+        __syncthreads();
+    }
+    int p0 = s_part[0][t] - s0, p1 = s_part[1][t] - s1;
+    for (int g = g0; g < g1; ++g) {
+        pre[g] = p0;
+        pre[B + g] = p1;
+        graph_ptr[g] = p0 + p1;
+        p0 += cnt[g];
+        p1 += cnt[B + g];
+    }
+    if (t == 1023) graph_ptr[B] = s_part[0][1023] + s_part[1][1023];
+}
+
+__global__ __launch_bounds__(256) void compose_place_kernel(const int64_t* __restrict__ br, const int64_t* __restrict__ bl, int n_rec, int n_lig,
+                                                            int B, const int* __restrict__ cnt, const int* __restrict__ pre,
+                                                            const int* __restrict__ flag, int64_t* __restrict__ sort_idx,
+                                                            int64_t* __restrict__ batch_idx, uint8_t* __restrict__ lig_flag,
+                                                            int64_t* __restrict__ lig_rows) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rec + n_lig) return;
+    const bool lig = i >= n_rec;
+    const int64_t* a = lig ? bl : br;
+    const int k = lig ? i - n_rec : i;
+    const int64_t g64 = a[k];
+    if (g64 < 0 || g64 >= B) return;
+    const int g = (int)g64;
+    int rank;
+    if (*flag & (lig ? 2 : 1)) {
+        rank = 0;
+        for (int j = 0; j < k; ++j) rank += a[j] == g64 ? 1 : 0;
+    } else
+        rank = k - pre[(lig ? B : 0) + g];
+    const int pos = pre[g] + pre[B + g] + (lig ? cnt[g] : 0) + rank;
+    sort_idx[pos] = i;
+    batch_idx[pos] = g64;
+    lig_flag[pos] = lig ? 1 : 0;
+    if (lig) lig_rows[k] = pos;
+}
+
+hipError_t launch_compose_plan(const int64_t* br, const int64_t* bl, int n_rec, int n_lig, int B, int* scratch, int64_t* sort_idx,
+                               int64_t* batch_idx, uint8_t* lig_flag, int64_t* lig_rows, int32_t* graph_ptr, hipStream_t s) {
+    // scratch: cnt [2 B] | pre [2 B] | flag [1]
+    int *cnt = scratch, *pre = scratch + 2 * B, *flag = scratch + 4 * B;
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(int) * (4 * (size_t)B + 1), s);
+    if (e != hipSuccess) return e;
+    const int n = n_rec + n_lig, grid = (n + 255) / 256;
+    if (n > 0) hipLaunchKernelGGL(compose_count_kernel, dim3(grid), dim3(256), 0, s, br, bl, n_rec, n_lig, B, cnt, flag);
+    hipLaunchKernelGGL(compose_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, B, pre, graph_ptr);
+    if (n > 0)
+        hipLaunchKernelGGL(compose_place_kernel, dim3(grid), dim3(256), 0, s, br, bl, n_rec, n_lig, B, cnt, pre, flag, sort_idx, batch_idx,
+                           lig_flag, lig_rows);
+    return hipGetLastError();
+}
+
 }  // namespace cbgx

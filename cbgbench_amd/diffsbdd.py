@@ -8,6 +8,7 @@ Sampler semantics reproduced from the reference (quirks included, see oracle/dif
 types normalised by 4, the pocket re-centred on the ligand mean at every Gaussian draw (COM-free subspace), every
 ligand atom updated, ``traj[0]`` overwritten by the final ``sample_p_xh_given_z0`` result."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -183,6 +184,46 @@ class DiffsbddVariationalScheduler(nn.Module):
         return self.sample_normal_zero_com(mu, xh0_pocket, sigma, bl, br, B, com=False, eps=eps), xh0_pocket
 
 
+class _DiffSBDDLossFunction(torch.autograd.Function):
+    """Both training losses of ``DiffSBDD.get_loss`` on the ligand rows of the denoiser outputs (diffsbdd.py:91-195;
+    ``DiffsbddVariationalScheduler.get_score_loss`` x 2) in two launches, which also leave their gradients with respect to those rows
+    (csrc/train_loss_diffsbdd.hip, cbgx_diffsbdd_loss); the backward scatters them, scaled by the upstream gradients, into full-size
+    dL/dx_out and dL/dlogits with the kernel TargetDiff's losses use (cbgx_targetdiff_loss_backward)."""
+
+    @staticmethod
+    def forward(ctx, xo, logits, eps_x, eps_c, t_idx, sort_idx, graph_ptr, n_rec, gdata):
+        dev = xo.device
+        n_lig, C, B = eps_x.shape[0], logits.shape[1], t_idx.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        losses, glosses = torch.empty(2, **f32), torch.empty(2 * B, **f32)
+        x_pred, c_pred = torch.empty(n_lig, 3, **f32), torch.empty(n_lig, C, **f32)
+        gpos, gz = torch.empty(n_lig, 3, **f32), torch.empty(n_lig, C, **f32)
+        _native.check(_native.lib().cbgx_diffsbdd_loss(
+            _native.ptr(xo), _native.ptr(logits), _native.ptr(eps_x), _native.ptr(eps_c), _native.ptr(t_idx), _native.ptr(sort_idx),
+            _native.ptr(graph_ptr), int(n_rec), n_lig, B, C, _native.ptr(gdata), _native.ptr(glosses), _native.ptr(losses),
+            _native.ptr(x_pred), _native.ptr(c_pred), _native.ptr(gpos), _native.ptr(gz), _native.current_stream(dev)),
+            "cbgx_diffsbdd_loss")
+        ctx.saved = (gpos, gz, sort_idx)
+        ctx.dims = (int(n_rec), xo.shape[0], C)
+        ctx.mark_non_differentiable(x_pred, c_pred)
+        loss_pos, loss_atom = losses.unbind(0)
+        return loss_pos, loss_atom, x_pred, c_pred
+
+    @staticmethod
+    def backward(ctx, g_pos, g_atom, _gx, _gc):
+        gpos, gz, sort_idx = ctx.saved
+        n_rec, N, C = ctx.dims
+        dev = gpos.device
+        cont = lambda g: None if g is None else g.to(torch.float32).contiguous()
+        g_pos, g_atom = cont(g_pos), cont(g_atom)
+        grad_x = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        grad_logits = torch.empty(N, C, dtype=torch.float32, device=dev)
+        _native.check(_native.lib().cbgx_targetdiff_loss_backward(
+            _native.ptr(gpos), _native.ptr(gz), _native.ptr(sort_idx), n_rec, N, C, _native.ptr(g_pos), _native.ptr(g_atom),
+            _native.ptr(grad_x), _native.ptr(grad_logits), _native.current_stream(dev)), "cbgx_targetdiff_loss_backward")
+        return (grad_x, grad_logits) + (None,) * 7
+
+
 @register_model("diffsbdd")
 class DiffSBDD(BatchesInFlight, nn.Module):
     def __init__(self, cfg):
@@ -199,6 +240,8 @@ class DiffSBDD(BatchesInFlight, nn.Module):
         self.context_embedder = PLContextEmbedder(cfg.embedder)
         self.denoiser = get_e3_gnn(cfg.encoder, num_classes=self.num_classes)
         self.intersect_reg = cfg.get("intersect_reg", True)
+        # CBGX_FUSED_TRAINING_OPS=0: the noising and both losses as tensor operations (the path the evaluation mode always takes)
+        self.fused_training_ops = os.environ.get("CBGX_FUSED_TRAINING_OPS", "1") != "0"
 
     # ---- training (diffsbdd.py:45-195, training mode) ----------------------------------------------------------
     def sample_time(self, batch_size, device="cuda"):
@@ -239,9 +282,14 @@ class DiffSBDD(BatchesInFlight, nn.Module):
         gen_l = batch.get("ligand_gen_flag", lig_flag_l).bool()
         gen_r = batch.get("protein_gen_flag", torch.zeros_like(batch["protein_lig_flag"])).bool()
         B = int(t_int.shape[0])
-        c0 = F.one_hot(batch["ligand_atom_type"], C).float() / 4.0
         v_rec = batch["protein_atom_feature"].float() / 4.0
         t = t_int / T
+        v0 = batch["ligand_atom_type"]
+        if (self.fused_training_ops and not evaluate and x0.is_cuda and C <= 32 and v0.dtype == torch.int64 and x0.shape[0] > 0
+                and batch["protein_pos"].shape[0] > 0 and self.pos_scheduler.gamma.gamma.shape[0] == T + 1):
+            sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = TargetDiff.compose_plan(bl, br, B)
+            return self._get_loss_fused(batch, t_int, t, noise, x0, v0, v_rec, gen_l, gen_r, sort_idx, batch_idx, lig_flag, graph_ptr, B)
+        c0 = F.one_hot(v0, C).float() / 4.0
         x0c, xr0 = self.pos_scheduler.remove_mean_batch(x0, batch["protein_pos"].float(), bl, br, B)
         sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = TargetDiff.compose_plan(bl, br, B)
 
@@ -270,6 +318,50 @@ class DiffSBDD(BatchesInFlight, nn.Module):
                                                                            type_noise0, c_lig_0=c0, c_lig_t0=c_t0)
         results = {k + "_pos": v for k, v in pos_info.items()}
         results.update({k + "_atom": v for k, v in atom_info.items()})
+        return {"pos": loss_pos, "atom": loss_atom}, results
+
+    def _schedule_tables(self, dev):
+        """alpha(t) / sigma(t) for t = 0 .. T with the tensor path's own operations, so that the fused noising multiplies by the same
+        bits; cached (the gamma table is frozen)"""
+        tab = getattr(self, "_alpha_sigma", None)
+        if tab is None or tab[0].device != torch.device(dev):
+            ps, ts = self.pos_scheduler, self.type_scheduler
+            assert torch.equal(ps.gamma.gamma, ts.gamma.gamma), "coordinates and types share one schedule in every shipped config"
+            g = ps.gamma.gamma.to(dev)
+            tab = (ps.alpha(g).contiguous(), ps.sigma(g).contiguous())
+            self._alpha_sigma = tab
+        return tab
+
+    def _get_loss_fused(self, batch, t_int, t, noise, x0, v0, v_rec, gen_l, gen_r, sort_idx, batch_idx, lig_flag, graph_ptr, B):
+        """training-mode ``get_loss`` with its tensor operations in three launches (csrc/train_loss_diffsbdd.hip): the noising and the
+        network-independent loss terms before the denoiser, both losses and their gradients after it.  Draws are made here, in the
+        order and shapes of the tensor path, so a seeded run sees the same noise on both."""
+        T, C = self.num_diffusion_timesteps, self.num_classes
+        dev = x0.device
+        x_rec = batch["protein_pos"].float().contiguous()
+        x0 = x0.contiguous()
+        n_rec, n_lig = x_rec.shape[0], x0.shape[0]
+        eps_x, eps_c = noise if noise is not None else (None, None)
+        eps_x = torch.randn_like(x0) if eps_x is None else eps_x.float().contiguous()
+        eps_c = torch.randn(n_lig, C, dtype=torch.float32, device=dev) if eps_c is None else eps_c.float().contiguous()
+        t_idx = torch.round(t * T).long()                      # PredefinedNoiseSchedule.forward's index
+        alpha_tab, sigma_tab = self._schedule_tables(dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        x_t, xr_t, c_t = torch.empty(n_lig, 3, **f32), torch.empty(n_rec, 3, **f32), torch.empty(n_lig, C, **f32)
+        gdata = torch.empty(4 * B, **f32)
+        sort_idx, gen_l = sort_idx.contiguous(), gen_l.contiguous()
+        _native.check(_native.lib().cbgx_diffsbdd_train_noise(
+            _native.ptr(x0), _native.ptr(x_rec), _native.ptr(v0.contiguous()), _native.ptr(eps_x), _native.ptr(eps_c), _native.ptr(gen_l),
+            _native.ptr(t_idx), _native.ptr(sort_idx), _native.ptr(graph_ptr), n_rec, n_lig, B, C, _native.ptr(alpha_tab),
+            _native.ptr(sigma_tab), T, _native.ptr(x_t), _native.ptr(xr_t), _native.ptr(c_t), _native.ptr(gdata),
+            _native.current_stream(dev)), "cbgx_diffsbdd_train_noise")
+        x, h, gen_flag = compose_embed(self.context_embedder, xr_t, x_t, v_rec, batch["protein_aa_type"], c_t, sort_idx, gen_r, gen_l)
+        xo, _, logits = self.denoiser(x=x, h=h, batch_idx=batch_idx, lig_flag=lig_flag, gen_flag=gen_flag, graph_ptr=graph_ptr,
+                                      ligand_outputs_only=True)
+        loss_pos, loss_atom, x_pred, c_pred = _DiffSBDDLossFunction.apply(xo, logits, eps_x, eps_c, t_idx, sort_idx, graph_ptr, n_rec,
+                                                                           gdata)
+        results = {"eps_0_pos": eps_x, "eps_pred_pos": x_pred, "mask_gen_pos": gen_l,
+                   "eps_0_atom": eps_c, "eps_pred_atom": c_pred, "mask_gen_atom": gen_l}
         return {"pos": loss_pos, "atom": loss_atom}, results
 
     @torch.no_grad()

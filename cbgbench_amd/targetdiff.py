@@ -622,6 +622,23 @@ class TargetDiff(BatchesInFlight, nn.Module):
     def compose_plan(batch_idx_lig, batch_idx_rec, n_graphs=None):
         """compose_context (repo/modules/common.py:189-214): cat(rec, lig) + stable sort by graph id.
         Returns (sort_idx, batch_idx, lig_rows, graph_ptr); computed once per batch."""
+        n_rec, n_lig = batch_idx_rec.shape[0], batch_idx_lig.shape[0]
+        if (n_graphs is not None and batch_idx_rec.is_cuda and batch_idx_rec.dtype == torch.int64 and batch_idx_lig.dtype == torch.int64
+                and 0 < n_graphs <= (1 << 20) and n_rec + n_lig > 0 and os.environ.get("CBGX_FUSED_COMPOSE", "0") != "0"):
+            # the same five results from a counting sort in three launches (csrc/train_embed.hip, cbgx_compose_plan) instead of ~20
+            dev = batch_idx_rec.device
+            N = n_rec + n_lig
+            sort_idx = torch.empty(N, dtype=torch.int64, device=dev)
+            batch_idx = torch.empty(N, dtype=torch.int64, device=dev)
+            lig_flag = torch.empty(N, dtype=torch.bool, device=dev)
+            lig_rows = torch.empty(n_lig, dtype=torch.int64, device=dev)
+            graph_ptr = torch.empty(n_graphs + 1, dtype=torch.int32, device=dev)
+            scratch = torch.empty(4 * n_graphs + 1, dtype=torch.int32, device=dev)
+            _native.check(_native.lib().cbgx_compose_plan(
+                _native.ptr(batch_idx_rec.contiguous()), _native.ptr(batch_idx_lig.contiguous()), n_rec, n_lig, int(n_graphs),
+                _native.ptr(scratch), _native.ptr(sort_idx), _native.ptr(batch_idx), _native.ptr(lig_flag), _native.ptr(lig_rows),
+                _native.ptr(graph_ptr), _native.current_stream(dev)), "cbgx_compose_plan")
+            return sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr
         batch_ctx = torch.cat([batch_idx_rec, batch_idx_lig], 0)
         sort_idx = torch.sort(batch_ctx, stable=True).indices
         batch_idx = batch_ctx[sort_idx]

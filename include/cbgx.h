@@ -394,6 +394,36 @@ int cbgx_diffbp_loss(const float *x_out, const float *x_in, const float *x_stack
                      float *losses, float *scal, float *gstats, float *a_pos, float *a_int, float *b_com, float *b_int,
                      float *z_atom, int32_t *bad, void *stream);
 
+/* cbgx_compose_plan (ABI 6): the index work of compose_context (repo/modules/common.py:189-214) -- sort_idx [N] = the STABLE argsort of
+ *   cat(batch_protein, batch_ligand) (graph ids in [0, n_graphs), int64), and what its callers derive from it: batch_idx [N] the sorted ids,
+ *   lig_flag [N] (1 = ligand atom), lig_rows [n_ligand] the composed row of every ligand atom, graph_ptr [n_graphs + 1] the CSR offsets --
+ *   as a counting sort in three launches.  Exact for any order of the ids (arrays that are not non-decreasing, which no collated batch is,
+ *   take a slow rank pass); ids outside [0, n_graphs) are dropped.  scratch: 4 n_graphs + 1 ints. */
+int cbgx_compose_plan(const int64_t *batch_protein, const int64_t *batch_ligand, int n_protein, int n_ligand, int n_graphs,
+                      int32_t *scratch, int64_t *sort_idx, int64_t *batch_idx, uint8_t *lig_flag, int64_t *lig_rows,
+                      int32_t *graph_ptr, void *stream);
+
+/* cbgx_diffsbdd_train_noise / cbgx_diffsbdd_loss (ABI 6): the tensor operations of DiffSBDD.get_loss (training mode) around its denoiser
+ *   call, diffsbdd.py:91-195.  All graph-wise sums are taken per graph of the COMPOSED order (graph_ptr [B+1], sort_idx [N] as above), in a
+ *   fixed order.  x0 [n_lig,3], x_protein [n_protein,3], v0 [n_lig] class indices (the one-hot / 4 features are formed inside), eps_x
+ *   [n_lig,3] / eps_c [n_lig,C] the Gaussian draws, gen [n_lig], t [B] integer time steps in [0, T]; alpha_table / sigma_table [T+1] =
+ *   sqrt(sigmoid(-gamma)), sqrt(sigmoid(gamma)) of the predefined schedule (schedule_utils.py:60-96).
+ *   _train_noise: ligand centred on its mean, z_t for coordinates and types with the pocket re-centred on the noisy ligand
+ *   (diffusion_scheduler.py:740-790) -> x_t, x_protein_t, c_t; gdata [4 B] = per graph {ligand atoms, KL prior of the coordinates, KL prior
+ *   of the types (:846-868), -log p(c | z_0) [t == 0] (:930-945)}: every term of the loss that does not depend on the network.
+ *   _loss: x_out [N,3] / logits [N,C] = the denoiser's outputs (composed order); losses [2] = {pos, atom} = mean over graphs of
+ *   0.5 sum(err^2) [t != 0] / (n dim) + the t == 0 terms + KL (:886-900); glosses [2 B] scratch; x_pred / c_pred = the outputs on the
+ *   ligand rows, in ligand order; grad_pos [n_lig,3] / grad_logit [n_lig,C] = d losses / d those rows -- scatter them with
+ *   cbgx_targetdiff_loss_backward. */
+int cbgx_diffsbdd_train_noise(const float *x0, const float *x_protein, const int64_t *v0, const float *eps_x, const float *eps_c,
+                              const uint8_t *gen, const int64_t *t, const int64_t *sort_idx, const int32_t *graph_ptr, int n_protein,
+                              int n_lig, int n_graphs, int num_classes, const float *alpha_table, const float *sigma_table,
+                              int num_timesteps, float *x_t, float *x_protein_t, float *c_t, float *gdata, void *stream);
+int cbgx_diffsbdd_loss(const float *x_out, const float *logits, const float *eps_x, const float *eps_c, const int64_t *t,
+                       const int64_t *sort_idx, const int32_t *graph_ptr, int n_protein, int n_lig, int n_graphs, int num_classes,
+                       const float *gdata, float *glosses, float *losses, float *x_pred, float *c_pred, float *grad_pos,
+                       float *grad_logit, void *stream);
+
 /* cbgx_embed_compose / cbgx_embed_compose_backward (ABI 6): the input side of a training step -- PLContextEmbedder
  *   (repo/modules/context_emb.py:137-230, the shipped configuration: Linear atom / residue / ligand-indicator embeddings, no time / vec)
  *   and compose_context (repo/modules/common.py:189-214) -- as one launch, and the embedder's weight gradients as two.
