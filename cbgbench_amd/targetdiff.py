@@ -624,7 +624,7 @@ class TargetDiff(BatchesInFlight, nn.Module):
         Returns (sort_idx, batch_idx, lig_rows, graph_ptr); computed once per batch."""
         n_rec, n_lig = batch_idx_rec.shape[0], batch_idx_lig.shape[0]
         if (n_graphs is not None and batch_idx_rec.is_cuda and batch_idx_rec.dtype == torch.int64 and batch_idx_lig.dtype == torch.int64
-                and 0 < n_graphs <= (1 << 20) and n_rec + n_lig > 0 and os.environ.get("CBGX_FUSED_COMPOSE", "0") != "0"):
+                and 0 < n_graphs <= (1 << 20) and n_rec + n_lig > 0 and os.environ.get("CBGX_FUSED_COMPOSE", "1") != "0"):
             # the same five results from a counting sort in three launches (csrc/train_embed.hip, cbgx_compose_plan) instead of ~20
             dev = batch_idx_rec.device
             N = n_rec + n_lig
