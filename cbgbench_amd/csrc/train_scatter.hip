@@ -149,9 +149,17 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ A, i
                                                          const int* __restrict__ n_rows_ptr, float* __restrict__ copy_dst,
                                                          const float* __restrict__ copy_src, int copy_n) {
     const int count = *n_rows_ptr, lane = threadIdx.x & 63;
-    for (int it = blockIdx.x * 4 + (threadIdx.x >> 6); it < count; it += gridDim.x * 4) {
-        floatx4s* row = reinterpret_cast<floatx4s*>(A + (size_t)rows[it] * ld);
-        for (int k = lane; k < ld / 4; k += 64) row[k] = floatx4s{0.f, 0.f, 0.f, 0.f};
+    const int first = blockIdx.x * 4 + (threadIdx.x >> 6), stride = gridDim.x * 4;
+    for (int it0 = first; it0 < count; it0 += 4 * stride) {
+        int r[4];       // a wavefront's row numbers first, all in flight; then the stores (one dependent round trip, not one per row)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = it0 + u * stride < count ? rows[it0 + u * stride] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (r[u] >= 0) {
+                floatx4s* row = reinterpret_cast<floatx4s*>(A + (size_t)r[u] * ld);
+                for (int k = lane; k < ld / 4; k += 64) row[k] = floatx4s{0.f, 0.f, 0.f, 0.f};
+            }
     }
     for (int k = blockIdx.x * 256 + threadIdx.x; k < copy_n; k += gridDim.x * 256) copy_dst[k] = copy_src[k];
 }
