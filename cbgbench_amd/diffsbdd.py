@@ -323,14 +323,18 @@ class DiffSBDD(BatchesInFlight, nn.Module):
     def _schedule_tables(self, dev):
         """alpha(t) / sigma(t) for t = 0 .. T with the tensor path's own operations, so that the fused noising multiplies by the same
         bits; cached (the gamma table is frozen)"""
+        ps, ts = self.pos_scheduler, self.type_scheduler
+        key = (torch.device(dev), ps.gamma.gamma.data_ptr(), _native.version(ps.gamma.gamma), ts.gamma.gamma.data_ptr(),
+               _native.version(ts.gamma.gamma))
         tab = getattr(self, "_alpha_sigma", None)
-        if tab is None or tab[0].device != torch.device(dev):
-            ps, ts = self.pos_scheduler, self.type_scheduler
-            assert torch.equal(ps.gamma.gamma, ts.gamma.gamma), "coordinates and types share one schedule in every shipped config"
-            g = ps.gamma.gamma.to(dev)
-            tab = (ps.alpha(g).contiguous(), ps.sigma(g).contiguous())
+        if tab is None or tab[0] != key:      # (a load_state_dict / .to() writes or replaces the table's storage: rebuilt)
+            if not torch.equal(ps.gamma.gamma, ts.gamma.gamma):
+                raise ValueError("the fused DiffSBDD losses take one schedule for coordinates and types (every shipped config); "
+                                 "set CBGX_FUSED_TRAINING_OPS=0 for separate ones")
+            g = ps.gamma.gamma.detach().to(dev)
+            tab = (key, ps.alpha(g).contiguous(), ps.sigma(g).contiguous())
             self._alpha_sigma = tab
-        return tab
+        return tab[1], tab[2]
 
     def _get_loss_fused(self, batch, t_int, t, noise, x0, v0, v_rec, gen_l, gen_r, sort_idx, batch_idx, lig_flag, graph_ptr, B):
         """training-mode ``get_loss`` with its tensor operations in three launches (csrc/train_loss_diffsbdd.hip): the noising and the
