@@ -115,6 +115,42 @@ def test_embedder_matches_oracle():
         assert torch.allclose(model.context_embedder.embed_protein(v, aa), hr, atol=1e-6)
 
 
+def test_compose_embed_host_path_is_embedder_then_compose_context():
+    """targetdiff.compose_embed on the host = PLContextEmbedder on both atom sets, then compose_context of coordinates, features and the
+    movable flag (targetdiff.py:89-101 of the reference; the oracle's restatement): what the fused kernel (cbgx_embed_compose, GPU tests)
+    is compared with.  Also the stacked-weight identity the kernel's backward rests on: h = ext . Wext for the extended input rows."""
+    from cbgbench_amd.targetdiff import TargetDiff, compose_embed
+    torch.manual_seed(1)
+    model = C.get_model(C.default_targetdiff_config(13))
+    sd = W.synthetic_state_dict(13, 9)
+    model.load_state_dict(sd)
+    emb = model.context_embedder
+    n_rec, n_lig, B = 23, 7, 3
+    br, bl = torch.sort(torch.randint(0, B, (n_rec,))).values, torch.sort(torch.randint(0, B, (n_lig,))).values
+    x_rec, x_lig = torch.randn(n_rec, 3), torch.randn(n_lig, 3)
+    feat, aa = torch.rand(n_rec, 7), torch.randint(0, 20, (n_rec,))
+    c = torch.nn.functional.one_hot(torch.randint(0, 13, (n_lig,)), 13).float()
+    gen_r, gen_l = torch.zeros(n_rec, dtype=torch.bool), torch.rand(n_lig) < 0.7
+    sort_idx, batch_idx, lig_flag, lig_rows, graph_ptr = TargetDiff.compose_plan(bl, br, B)
+    with torch.no_grad():
+        x, h, g = compose_embed(emb, x_rec, x_lig, feat, aa, c, sort_idx, gen_r, gen_l)
+    hl, hr = OT.context_embed(sd, c, feat, torch.nn.functional.one_hot(aa, 20).float())
+    assert torch.equal(x, torch.cat([x_rec, x_lig])[sort_idx]) and torch.equal(g, torch.cat([gen_r, gen_l])[sort_idx])
+    assert torch.allclose(h, torch.cat([hr, hl])[sort_idx], atol=1e-6)
+    assert torch.equal(batch_idx, torch.cat([br, bl])[sort_idx]) and torch.equal(lig_flag, sort_idx >= n_rec)
+    assert torch.equal(sort_idx[lig_rows], n_rec + torch.arange(n_lig)) and int(graph_ptr[-1]) == n_rec + n_lig
+    # extended rows and stacked weights (csrc/train_embed.hip): [feat | onehot aa | 1 | c | 1] . [W_pa^T ; W_res^T ; b_p ; W_la^T ; b_l]
+    with torch.no_grad():
+        ext = torch.zeros(n_rec + n_lig, 7 + 20 + 1 + 13 + 1)
+        ext[:n_rec, :7], ext[:n_rec, 27] = feat, 1.0
+        ext[torch.arange(n_rec), 7 + aa] = 1.0
+        ext[n_rec:, 28:41], ext[n_rec:, 41] = c, 1.0
+        b_p = emb.protein_atom_emb.bias + emb.residue_emb.bias + emb.ligand_indicator.bias
+        b_l = emb.ligand_atom_emb.bias + emb.ligand_indicator.weight[:, 0] + emb.ligand_indicator.bias
+        wext = torch.cat([emb.protein_atom_emb.weight.T, emb.residue_emb.weight.T, b_p[None], emb.ligand_atom_emb.weight.T, b_l[None]])
+        assert torch.allclose((ext @ wext)[sort_idx], h, atol=1e-5)
+
+
 def test_no_cpu_fallback():
     model = C.get_model(C.default_targetdiff_config(13))
     x = torch.zeros(4, 3); h = torch.zeros(4, 128)
