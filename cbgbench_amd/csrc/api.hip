@@ -164,7 +164,13 @@ AuxStream* aux_for(hipStream_t caller) {
     }
     AuxStream a;
     a.owner = caller;
-    if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    // CBGX_AUX_PRIORITY=low (opt-in, schedule only): the auxiliary stream at the device's least priority, so that the caller's node-level
+    // kernels get the CUs first where both queues have workgroups ready (measured: profiles/ab_train_r06r2.log)
+    static const bool low = [] { const char* e = getenv("CBGX_AUX_PRIORITY"); return e && e[0] == 'l'; }();
+    int least = 0, greatest = 0;
+    if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+        if (hipStreamCreateWithPriority(&a.s, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+    } else if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&a.done[0], hipEventDisableTiming) != hipSuccess ||
